@@ -1,0 +1,54 @@
+# oracle/ref.mk — TEST INFRASTRUCTURE ONLY.
+#
+# Builds oracle/_ref/libsrslte_ref.so from the reference's own C sources WHERE THEY LIE under
+# $(REF) (never copied into this repo), with the reference's release flags
+# (CMakeLists.txt:355,372,392: -O3 -Ofast -funroll-loops -mfpmath=sse -mavx2 -mfma, LV_HAVE_*).
+#
+# What is NOT built, and why (see DESIGN.md "Oracle"):
+#   * lib/src/phy/dft/dft_fftw.c needs <fftw3.h>/libfftw3f, absent from this image -> unbuildable.
+#     Everything that reaches srslte_dft_* (ofdm.c, dft_precoding.c, pss/sss FFT helpers, prach,
+#     fading, conv_fft) is dropped by --gc-sections because the export map does not root it.
+#   * Nothing is stubbed: no stand-in headers, libraries or generated files are written.
+#     `srslte/srslte.h` pulls the cmake-generated `srslte/version.h` (version macros only); the
+#     recipe pre-defines srslte.h's own include guard so that umbrella header contributes
+#     nothing, and instead force-includes the very reference headers that umbrella lists
+#     (derived from srslte.h itself at make time, minus version.h).
+#
+# Output only into oracle/_ref/ (git-ignored, NOT gpurun-ignored: it travels to the GPU box).
+
+REF      ?= /root/reference
+RLIB     := $(REF)/lib
+OUT      := _ref
+OBJ      := $(OUT)/obj
+
+REF_DIRS := ch_estimation common fec mimo modem phch resampling scrambling utils sync
+REF_C    := $(foreach d,$(REF_DIRS),$(wildcard $(RLIB)/src/phy/$(d)/*.c)) \
+            $(RLIB)/src/phy/channel/ch_awgn.c $(RLIB)/src/phy/channel/gauss.c
+REF_CXX  := $(RLIB)/src/phy/utils/random.cpp
+# NEON-only translation unit: not part of an x86 build of the reference
+REF_C    := $(filter-out %viterbi37_neon.c,$(REF_C))
+
+UMBRELLA := $(shell grep -o '"srslte/[a-z0-9_/]*\.h"' $(RLIB)/include/srslte/srslte.h 2>/dev/null | tr -d '"' | grep -v -e version.h -e config.h)
+FORCEINC := -include complex.h -include math.h -include srslte/config.h $(foreach h,$(UMBRELLA),-include $(h))
+
+REF_FLAGS := -D_GNU_SOURCE -O3 -fno-trapping-math -fno-math-errno -Ofast -funroll-loops \
+             -mfpmath=sse -mavx2 -mfma -DLV_HAVE_SSE -DLV_HAVE_AVX -DLV_HAVE_AVX2 -DLV_HAVE_FMA \
+             -DDISABLE_RF -fPIC -ffunction-sections -fdata-sections -w \
+             -I$(RLIB)/include -I$(RLIB)/src/phy -DSRSLTE_SRSLTE_H
+
+OBJS := $(patsubst $(RLIB)/src/phy/%.c,$(OBJ)/%.o,$(REF_C)) $(patsubst $(RLIB)/src/phy/%.cpp,$(OBJ)/%.o,$(REF_CXX))
+
+.PHONY: ref all clean
+ref: $(OUT)/libsrslte_ref.so
+
+$(OBJ)/%.o: $(RLIB)/src/phy/%.c
+	@mkdir -p $(dir $@)
+	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) -c $< -o $@
+
+$(OBJ)/%.o: $(RLIB)/src/phy/%.cpp
+	@mkdir -p $(dir $@)
+	g++ -std=c++11 $(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS)) -c $< -o $@
+
+$(OUT)/libsrslte_ref.so: $(OBJS) ref_exports.map
+	g++ -shared -o $@ $(OBJS) -Wl,--gc-sections -Wl,--version-script=ref_exports.map -lm -lpthread
+	@if nm -D --undefined-only $@ | grep -q 'srslte_\|fftw'; then echo "ERROR: unresolved reference symbols:"; nm -D --undefined-only $@ | grep 'srslte_\|fftw'; rm -f $@; exit 1; fi
