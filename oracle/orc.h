@@ -62,7 +62,7 @@ uint32_t orc_crc_bytes(uint32_t poly, int order, const uint8_t* data, int nbits)
 /* ---------------------------------------------------------------- turbo encoder (turbocoder.c) */
 int orc_tcod_encode_bits(const uint8_t* in, uint8_t* out, uint32_t K);
 /* byte-packed: sys[K/8+1] gets the tail nibble, par[(2K+8)/8+1]; optional fused CRCs as encode_lut */
-int orc_tcod_encode_bytes(uint8_t* sys, uint8_t* par, uint32_t K, uint32_t* crc_tb_state, bool use_cb_crc, bool last_cb);
+int orc_tcod_encode_bytes(uint8_t* sys, uint8_t* par, uint32_t K);
 
 /* ---------------------------------------------------------------- rate matching (rm_turbo.c) */
 int orc_rm_rx_table(uint32_t K, uint32_t rv, uint32_t W, uint16_t* table); /* 3K+12 entries */
@@ -132,6 +132,7 @@ int orc_demod_soft_b(int mod, const orc_cf_t* sym, int8_t* llr, int nsym);
 /* precoding.c:238-249,293-322 single-port one-tap equaliser */
 void orc_predecoding_single(const orc_cf_t* y, const orc_cf_t* h, orc_cf_t* x, int nsym, float scaling, float noise_estimate);
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
+int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx);
 int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms,
                  bool put);
 void orc_scramble_s(int16_t* llr, const uint8_t* c, int len); /* scrambling.c:45-48 */

@@ -1,0 +1,228 @@
+/*
+ * oracle/orc_chest.c — TEST INFRASTRUCTURE ONLY (see orc.h).
+ * CPU restatement of srslte_chest_dl_estimate_cfg for one rx antenna / one tx port (FDD, normal
+ * subframes): LS pilot estimates -> noise from pilots -> Gauss/triangle smoothing (+ optional
+ * time averaging) -> linear interpolation in frequency and time -> scalar measurements.
+ * Follows chest_dl.c:304-379 (noise), :415-511 (interpolate), :513-556 (average), :558-569 (rssi),
+ * :573-596 (cfo), :598-716 (per-port driver), :718-908 (aggregation); chest_common.c:62-88;
+ * interp.c:145-168,240-267; convolution.c:180-218 (the "extrapolates extremes" variant is the one compiled).
+ */
+#include "orc.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef orc_cf_t cf;
+static inline cf c_add(cf a, cf b) { return (cf){a.re + b.re, a.im + b.im}; }
+static inline cf c_sub(cf a, cf b) { return (cf){a.re - b.re, a.im - b.im}; }
+static inline cf c_scale(cf a, float s) { return (cf){a.re * s, a.im * s}; }
+static inline cf c_mulconj(cf a, cf b) { return (cf){a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im}; } /* a * conj(b) */
+
+static float avg_power(const cf* x, uint32_t n)
+{ /* vector.c:365-367 */
+  float acc = 0;
+  for (uint32_t i = 0; i < n; i++) acc += x[i].re * x[i].re + x[i].im * x[i].im;
+  return acc / n;
+}
+
+static uint32_t gauss_filter(float* filter, uint32_t order, float std_dev)
+{ /* chest_common.c:70-88 */
+  uint32_t len = order + 1;
+  int      center = (int)(len - 1) / 2;
+  float    norm = 0;
+  for (uint32_t i = 0; i < len; i++) {
+    filter[i] = expf(-powf((float)((int)i - center), 2) / (2.0f * powf(std_dev, 2)));
+    norm += filter[i];
+  }
+  for (uint32_t i = 0; i < len; i++) filter[i] *= 1.0f / norm;
+  return len;
+}
+
+static void conv_same_cf(const cf* in, const float* h, cf* out, uint32_t N, uint32_t M)
+{ /* convolution.c:180-218 */
+  cf* first = malloc(sizeof(cf) * (M + M / 2));
+  cf* last  = malloc(sizeof(cf) * (M + M / 2));
+  for (uint32_t i = 0; i < M + M / 2; i++) {
+    if (i < M / 2) {
+      first[i] = c_sub(c_scale(in[1], (float)(2 + M / 2 - i)), c_scale(in[0], (float)(1 + M / 2 - i)));
+    } else {
+      first[i] = in[i - M / 2];
+    }
+    if (i >= M - 1) {
+      last[i] = c_sub(c_scale(in[N - 1], (float)(2 + i - M / 2)), c_scale(in[N - 2], (float)(1 + i - M / 2)));
+    } else {
+      last[i] = in[N - M + i + 1];
+    }
+  }
+  uint32_t i = 0, j = 0;
+  for (; i < N; i++) {
+    const cf* src = i < M / 2 ? &first[i] : (i < N - M / 2 ? &in[i - M / 2] : &last[j++]);
+    cf acc = {0, 0};
+    for (uint32_t t = 0; t < M; t++) acc = c_add(acc, c_scale(src[t], h[t]));
+    out[i] = acc;
+  }
+  free(first);
+  free(last);
+}
+
+static void interp_linear_offset(const cf* in, cf* out, uint32_t L, uint32_t M, uint32_t off_st, uint32_t off_end)
+{ /* interp.c:240-267 */
+  for (uint32_t j = 0; j < off_st; j++) {
+    cf d = c_sub(in[1], in[0]);
+    out[off_st - j - 1] = c_sub(in[0], c_scale(c_scale(d, (float)(j + 1)), 1.0f / M));
+  }
+  for (uint32_t i = 0; i + 1 < L; i++) {
+    cf d = c_scale(c_sub(in[i + 1], in[i]), 1.0f / (float)M);
+    for (uint32_t j = 0; j < M; j++) out[i * M + j + off_st] = c_add(in[i], c_scale(d, (float)j));
+  }
+  if (L > 1) {
+    cf d = c_sub(in[L - 1], in[L - 2]);
+    for (uint32_t j = 0; j < off_end; j++) out[(L - 1) * M + j + off_st] = c_add(in[L - 1], c_scale(c_scale(d, (float)j), 1.0f / M));
+  }
+}
+
+static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* between, uint32_t dist, uint32_t M, uint32_t len)
+{ /* interp.c:145-168 (to_right) */
+  cf* diff = malloc(sizeof(cf) * len);
+  for (uint32_t i = 0; i < len; i++) diff[i] = c_scale(c_sub(in1[i], in0[i]), (float)1 / dist);
+  const cf* s = start ? start : in0;
+  for (uint32_t i = 0; i < len; i++) between[i] = c_add(s[i], diff[i]);
+  for (uint32_t m = 0; m + 1 < M; m++) {
+    for (uint32_t i = 0; i < len; i++) between[len + i] = c_add(between[i], diff[i]);
+    between += len;
+  }
+  free(diff);
+}
+
+int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, orc_chest_res_t* res)
+{
+  const uint32_t port = 0, P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
+  const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
+  if (!cell->cp_norm) return -1; /* extended CP time interpolation not restated */
+  cf* known = malloc(sizeof(cf) * npil);
+  cf* recv  = malloc(sizeof(cf) * npil);
+  cf* est   = malloc(sizeof(cf) * npil);
+  cf* avg   = malloc(sizeof(cf) * npil);
+  cf* tmp   = malloc(sizeof(cf) * 3 * (nref + 2));
+  orc_crs_pilots(cell, sf_idx, port, known);
+
+  /* pilots + LS (chest_dl.c:684-690) */
+  for (uint32_t l = 0; l < nsym; l++) {
+    uint32_t sym = orc_crs_nsymbol(l, cell->cp_norm, port), fidx = orc_crs_fidx(cell, l, port);
+    for (uint32_t i = 0; i < nref; i++) {
+      recv[l * nref + i] = grid[sym * nre + fidx + 6 * i];
+      est[l * nref + i]  = c_mulconj(recv[l * nref + i], known[l * nref + i]);
+    }
+  }
+  float rsrp = avg_power(recv, npil); /* chest_dl.c:710 */
+  float rssi = 0;                     /* chest_dl.c:558-569 */
+  for (uint32_t l = 0; l < nsym; l++) {
+    rssi += avg_power(&grid[orc_crs_nsymbol(l, cell->cp_norm, port) * nre], nre) * nre;
+  }
+  rssi /= nsym;
+
+  float cfo = 0;
+  if (cfg->cfo_estimate_enable) { /* chest_dl.c:573-596 */
+    float n = (float)orc_symbol_sz((int)P), ns = 7.0f, ng = (float)orc_cp_len_norm(1, (int)n);
+    cf    sum = {0, 0};
+    for (uint32_t i = 0; i < 2; i++) {
+      for (uint32_t k = 0; k < npil / 4; k++) sum = c_add(sum, c_mulconj(est[i * npil / 4 + k], est[(i + 2) * npil / 4 + k]));
+    }
+    cfo = (float)(-atan2f(sum.im, sum.re) * n / (ns * (n + ng)) / 2 / M_PI);
+  }
+
+  /* noise from pilots (chest_dl.c:304-379) */
+  float noise = 0;
+  if (cfg->noise_alg == 0) {
+    uint32_t fidx0 = orc_crs_fidx(cell, 0, port);
+    cf*      in2d[6];
+    for (uint32_t i = 0; i < nsym; i++) in2d[i + 1] = &est[i * nref];
+    in2d[0] = &tmp[nref];
+    in2d[5] = &tmp[2 * nref];
+    for (uint32_t k = 0; k < nref; k++) {
+      in2d[0][k] = c_sub(c_scale(in2d[2][k], 2.0f), in2d[4][k]);
+      in2d[5][k] = c_sub(c_scale(in2d[3][k], 2.0f), in2d[1][k]);
+    }
+    float sum_power = 0;
+    int   count     = 0;
+    for (uint32_t i = 1; i < nsym + 1; i++) {
+      uint32_t off = ((fidx0 < 3) ^ (i & 1)) ? 0 : 1;
+      for (uint32_t k = 0; k < nref; k++) tmp[k] = in2d[i][k];
+      for (int side = -1; side <= 1; side += 2) {
+        const cf* nb = in2d[(int)i + side];
+        for (uint32_t k = 0; k < nref - off; k++) tmp[off + k] = c_add(tmp[off + k], nb[k]);
+        for (uint32_t k = 0; k < nref + off - 1; k++) tmp[k] = c_add(tmp[k], nb[1 - off + k]);
+        if (off) {
+          tmp[0] = c_add(tmp[0], c_sub(c_scale(nb[0], 2.0f), nb[1]));
+        } else {
+          tmp[nref - 1] = c_add(tmp[nref - 1], c_sub(c_scale(nb[nref - 2], 2.0f), nb[nref - 1]));
+        }
+      }
+      for (uint32_t k = 0; k < nref; k++) tmp[k] = c_sub(in2d[i][k], c_scale(tmp[k], 1.0f / 5.0f));
+      sum_power = avg_power(tmp, nref); /* '=' not '+=': upstream quirk (chest_dl.c:374) */
+      count++;
+    }
+    noise = sum_power / (float)count * sqrtf(5.0f);
+  }
+
+  if (ce) {
+    float    filter[64];
+    uint32_t flen = 0;
+    if (cfg->filter_type == 0) { /* chest_dl.c:628-637 */
+      flen = cfg->filter_coef[0] <= 0 ? gauss_filter(filter, 4, noise * 200.0f) : gauss_filter(filter, (uint32_t)cfg->filter_coef[0], cfg->filter_coef[1]);
+    } else if (cfg->filter_type == 1) { /* chest_common.c:62-68 */
+      filter[0] = cfg->filter_coef[0]; filter[2] = cfg->filter_coef[0]; filter[1] = 1 - 2 * cfg->filter_coef[0];
+      flen = 3;
+    }
+    const cf* pil = est;
+    if (cfg->filter_type != 2) { /* average_pilots, chest_dl.c:513-556 */
+      uint32_t n = nref, ns = nsym;
+      if (!cfg->interpolate_subframe) {
+        bool first_low = orc_crs_fidx(cell, 0, port) < 3;
+        for (uint32_t k = 0; k < nref; k++) {
+          cf a = c_add(est[k], est[2 * nref + k]), b = c_add(est[nref + k], est[3 * nref + k]);
+          avg[2 * k]     = first_low ? a : b;
+          avg[2 * k + 1] = first_low ? b : a;
+        }
+        n = 2 * nref;
+        for (uint32_t k = 0; k < n; k++) est[k] = c_scale(avg[k], 2.0f / (float)nsym);
+        ns = 1;
+      }
+      for (uint32_t l = 0; l < ns; l++) conv_same_cf(&est[l * n], filter, &avg[l * n], n, flen);
+      pil = avg;
+    }
+    /* interpolate_pilots, chest_dl.c:415-511 */
+    if (!cfg->interpolate_subframe) {
+      uint32_t off = cell->id % 3;
+      interp_linear_offset(pil, ce, 4 * P, 3, off, 3 - off);
+      for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);
+    } else {
+      for (uint32_t l = 0; l < nsym; l++) {
+        uint32_t off = orc_crs_fidx(cell, l, port);
+        interp_linear_offset(&pil[nref * l], &ce[orc_crs_nsymbol(l, true, port) * nre], nref, 6, off, 6 - off);
+      }
+#define S(i) (&ce[(i) * nre])
+      interp_vector(S(0), S(4), NULL, S(1), 4, 3, nre);
+      interp_vector(S(4), S(7), NULL, S(5), 3, 2, nre);
+      interp_vector(S(7), S(11), NULL, S(8), 4, 3, nre);
+      interp_vector(S(7), S(11), S(11), S(12), 4, 2, nre);
+#undef S
+    }
+  }
+
+  if (res) { /* fill_res, chest_dl.c:845-871 (1 rx, 1 port) */
+    memset(res, 0, sizeof(*res));
+    res->noise_estimate     = noise;
+    res->noise_estimate_dbm = (float)(10 * log10(noise) + 30);
+    res->cfo                = cfo;
+    res->rsrp               = rsrp;
+    res->rsrp_dbm           = (float)(10 * log10(rsrp) + 30);
+    res->rsrq               = P * rsrp / rssi;
+    res->rsrq_db            = (float)(10 * log10(res->rsrq));
+    res->snr_db             = (float)(10 * log10(rsrp / noise));
+    res->rssi_dbm           = (float)(10 * log10(4 * rssi / P / 12) + 30);
+    res->sync_error         = NAN;
+  }
+  free(known); free(recv); free(est); free(avg); free(tmp);
+  return 0;
+}

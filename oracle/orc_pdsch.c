@@ -1,0 +1,73 @@
+/*
+ * oracle/orc_pdsch.c — TEST INFRASTRUCTURE ONLY (see orc.h).
+ * CPU restatement of the PDSCH glue between the named hot-path stages:
+ * RE (de)mapping (pdsch.c:81-206 + prb_dl.c:45-91), single-port one-tap equaliser
+ * (precoding.c:238-322), LLR descrambling (scrambling.c:45-48, sequences.c:58-60).
+ */
+#include "orc.h"
+#include <stdlib.h>
+#include <string.h>
+
+int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx)
+{ /* pdsch.c:81-206 expressed per RE: symbol-major, PRB ascending, skipping CRS and (FDD) the central
+     72 sub-carriers of PSS/SSS symbols (slot 0, last two symbols, sf 0/5) and PBCH symbols (slot 1, l<4, sf 0).
+     For odd nof_prb the half-PRB handling of pdsch.c:167-188 is the same per-RE rule. */
+  uint32_t P = cell->nof_prb, nre = 12 * P, nsymb = cell->cp_norm ? 7 : 6, n = 0;
+  uint32_t nof_refs = cell->nof_ports == 1 ? 2 : 4;
+  for (uint32_t s = 0; s < 2; s++) {
+    for (uint32_t l = (s == 0 ? lstart : 0); l < nsymb; l++) {
+      bool has_ref = (l == 1 && cell->nof_ports == 4) || l == 0 || l == nsymb - 3; /* phy_common.h:139-141 */
+      uint32_t offset = nof_refs == 2 ? (l == 0 ? cell->id % 6 : (cell->id + 3) % 6) : cell->id % 3;
+      bool sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= nsymb - 2) || (s == 1 && sf_idx == 0 && l < 4);
+      for (uint32_t p = 0; p < P; p++) {
+        if (prb_mask && !prb_mask[p]) continue;
+        for (uint32_t k = 12 * p; k < 12 * p + 12; k++) {
+          if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) continue;
+          if (has_ref && (k % (12 / nof_refs)) == offset % (12 / nof_refs)) continue;
+          idx[n++] = (s * nsymb + l) * nre + k;
+        }
+      }
+    }
+  }
+  return (int)n;
+}
+
+int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms, bool put)
+{
+  uint32_t* idx = malloc(sizeof(uint32_t) * 14 * 12 * cell->nof_prb);
+  int       n   = orc_pdsch_indices(cell, sf_idx, lstart, prb_mask, idx);
+  for (int i = 0; i < n; i++) {
+    if (put) {
+      grid[idx[i]] = syms[i];
+    } else {
+      syms[i] = grid[idx[i]];
+    }
+  }
+  free(idx);
+  return n;
+}
+
+void orc_predecoding_single(const orc_cf_t* y, const orc_cf_t* h, orc_cf_t* x, int nsym, float scaling, float noise_estimate)
+{ /* precoding.c:277-288 (scalar form of the csi variant srslte_pdsch_decode reaches: x = y h* (1/scaling) / (|h|^2 + N0)).
+     NOTE: the reference's AVX body replaces the division by _mm256_rcp_ps (12-bit approximation whose
+     result differs between CPU vendors), so parity with it is checked at 1e-3, not 1e-4. */
+  float norm = 1.0f / scaling;
+  for (int i = 0; i < nsym; i++) {
+    float re = y[i].re * h[i].re + y[i].im * h[i].im, im = y[i].im * h[i].re - y[i].re * h[i].im;
+    float csi = h[i].re * h[i].re + h[i].im * h[i].im + noise_estimate;
+    x[i].re = re * norm / csi;
+    x[i].im = im * norm / csi;
+  }
+}
+
+void orc_scramble_s(int16_t* llr, const uint8_t* c, int len)
+{ /* scrambling.c:45-48 -> srslte_vec_neg_sss: negate where c_short = 1-2c is negative */
+  for (int i = 0; i < len; i++) {
+    if (c[i]) llr[i] = (int16_t)-llr[i];
+  }
+}
+
+uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t cell_id)
+{ /* sequences.c:58-60 with nslot = 2*sf_idx (pdsch.c:469) */
+  return ((uint32_t)rnti << 14) + (cw << 13) + (((2 * sf_idx) / 2) << 9) + cell_id;
+}

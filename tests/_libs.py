@@ -1,0 +1,141 @@
+"""Test-side loaders for the three native libraries.
+
+* ``oracle()``  - oracle/liboracle.so, the CPU restatement (test infrastructure; built on demand with gcc).
+* ``ref()``     - oracle/_ref/libsrslte_ref.so, the reference's own sources compiled where they lie
+                  (only exists where /root/reference was present at build time; ``None`` otherwise).
+* ``hip()``     - srslte-emane_amd/csrc/libsrslte_phy_hip.so, the product. Never built here implicitly
+                  except through __graft_entry__.build().
+
+ctypes mirrors of the reference structs used by the parity harness follow the reference headers
+(lib/include/srslte/phy/common/phy_common.h:195-212, ch_estimation/chest_dl.h:49-130).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libsrslte_ref.so")
+PKG_DIR = os.path.join(ROOT, "srslte-emane_amd")
+HIP_SO = os.path.join(PKG_DIR, "csrc", "libsrslte_phy_hip.so")
+
+_cache = {}
+
+
+def p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def aligned(n, dtype, al=64):
+    """numpy array whose data pointer is `al`-byte aligned (the reference uses aligned SIMD loads)."""
+    isz = np.dtype(dtype).itemsize
+    raw = np.zeros(n * isz + al, np.uint8)
+    off = (-raw.ctypes.data) % al
+    return raw[off:off + n * isz].view(dtype)
+
+
+def acopy(a):
+    b = aligned(a.size, a.dtype)
+    b[:] = a.ravel()
+    return b
+
+
+def oracle():
+    if "orc" not in _cache:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.startswith("orc") and f[-2:] in (".c", ".h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "liboracle.so"])
+        lib = C.CDLL(so)
+        lib.orc_crc_bytes.restype = C.c_uint32
+        lib.orc_pdsch_cinit.restype = C.c_uint32
+        lib.orc_dft_precoding_valid_prb.restype = C.c_bool
+        lib.orc_predecoding_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
+        _cache["orc"] = lib
+    return _cache["orc"]
+
+
+def ref():
+    if "ref" not in _cache:
+        lib = None
+        if os.path.exists(REF_SO):
+            lib = C.CDLL(REF_SO)
+            lib.srslte_rm_turbo_gentables()
+            lib.srslte_predecoding_single.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
+            lib.srslte_chest_set_smooth_filter_gauss.argtypes = [C.c_void_p, C.c_uint32, C.c_float]
+        _cache["ref"] = lib
+    return _cache["ref"]
+
+
+def hip():
+    """The product library. Raises if it has not been built: tests must fail loudly, never fall back."""
+    if "hip" not in _cache:
+        if not os.path.exists(HIP_SO):
+            raise RuntimeError("libsrslte_phy_hip.so is not built; run python -c 'import __graft_entry__ as g; g.build()'")
+        _cache["hip"] = C.CDLL(HIP_SO)
+    return _cache["hip"]
+
+
+# ---------------------------------------------------------------- oracle structs
+class OrcCell(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("cp_norm", C.c_bool)]
+
+
+class OrcChestCfg(C.Structure):
+    _fields_ = [("noise_alg", C.c_int), ("filter_type", C.c_int), ("filter_coef", C.c_float * 2),
+                ("interpolate_subframe", C.c_bool), ("rsrp_neighbour", C.c_bool), ("cfo_estimate_enable", C.c_bool),
+                ("sync_error_enable", C.c_bool)]
+
+
+class OrcChestRes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db",
+                                         "rssi_dbm", "cfo", "sync_error")]
+
+
+class OrcOfdm(C.Structure):
+    _fields_ = [("nof_prb", C.c_int), ("symbol_sz", C.c_int), ("nof_re", C.c_int), ("nof_symbols", C.c_int), ("sf_sz", C.c_int),
+                ("slot_sz", C.c_int), ("cp_norm", C.c_int), ("normalize", C.c_bool), ("freq_shift", C.c_bool),
+                ("freq_shift_f", C.c_float), ("exact", C.c_bool)]
+
+
+class OrcSchCfg(C.Structure):
+    _fields_ = [("tbs", C.c_uint32), ("nof_bits", C.c_uint32), ("Qm", C.c_uint32), ("rv", C.c_uint32), ("max_iter", C.c_uint32)]
+
+
+class OrcCbsegm(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs")]
+
+
+# ---------------------------------------------------------------- reference structs
+class RefCell(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("cp", C.c_int), ("phich_length", C.c_int),
+                ("phich_resources", C.c_int), ("frame_type", C.c_int)]
+
+
+class RefTddCfg(C.Structure):
+    _fields_ = [("sf_config", C.c_uint32), ("ss_config", C.c_uint32), ("configured", C.c_bool)]
+
+
+class RefDlSfCfg(C.Structure):
+    _fields_ = [("tdd_config", RefTddCfg), ("tti", C.c_uint32), ("cfi", C.c_uint32), ("sf_type", C.c_int), ("non_mbsfn_region", C.c_uint32)]
+
+
+class RefChestRes(C.Structure):
+    _fields_ = [("ce", (C.c_void_p * 4) * 4), ("nof_re", C.c_uint32), ("noise_estimate", C.c_float), ("noise_estimate_dbm", C.c_float),
+                ("snr_db", C.c_float), ("snr_ant_port_db", (C.c_float * 4) * 4), ("rsrp", C.c_float), ("rsrp_dbm", C.c_float),
+                ("rsrp_neigh", C.c_float), ("rsrp_port_dbm", C.c_float * 4), ("rsrp_ant_port_dbm", (C.c_float * 4) * 4),
+                ("rsrq", C.c_float), ("rsrq_db", C.c_float), ("rsrq_ant_port_db", (C.c_float * 4) * 4), ("rssi_dbm", C.c_float),
+                ("cfo", C.c_float), ("sync_error", C.c_float)]
+
+
+class RefChestCfg(C.Structure):
+    _fields_ = [("noise_alg", C.c_int), ("filter_type", C.c_int), ("filter_coef", C.c_float * 2), ("mbsfn_area_id", C.c_uint16),
+                ("interpolate_subframe", C.c_bool), ("rsrp_neighbour", C.c_bool), ("cfo_estimate_enable", C.c_bool),
+                ("cfo_estimate_sf_mask", C.c_uint32), ("sync_error_enable", C.c_bool)]
+
+
+def opaque(nbytes=1 << 20):
+    """Zeroed storage for a reference object struct the harness never inspects (srslte_tdec_t, srslte_chest_dl_t ...)."""
+    return C.create_string_buffer(nbytes)
