@@ -1,0 +1,143 @@
+/*
+ * include/srslte_hip/phy_hip.h — batched C ABI of libsrslte_phy_hip.so (MI355X / gfx950).
+ *
+ * This is the throughput path of the drop-in (last row): device-resident buffers, one launch per
+ * stage per batch of subframes. Every entry point is extern "C", takes plain pointers/sizes (device pointers are
+ * marked d_), returns SRSLTE_SUCCESS 0 / SRSLTE_ERROR -1 / SRSLTE_ERROR_INVALID_INPUTS -2 (config.h:58-66) and
+ * names the reference interface it replaces (paths relative to the reference tree).
+ * The single-subframe srslte_* look-alikes that a caller such as lib/src/phy/ue/ue_dl.c binds are declared in
+ * include/srslte_hip/srslte_compat.h and are thin host wrappers over these.
+ *
+ * Layouts (all cf_t = interleaved float re,im):
+ *   time samples  [nof_sf][15*N]            N = srslte_symbol_sz(nof_prb)
+ *   resource grid [nof_sf][nsym][12*prb]    nsym = 14 (normal CP) / 12, sub-carrier ascending, DC removed
+ *   LLRs          [nof_sf][nof_re*Qm]       bit order b0(I) b1(Q) b2 ... as demod_soft.c
+ */
+#ifndef SRSLTE_HIP_PHY_HIP_H
+#define SRSLTE_HIP_PHY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ device plumbing (no HIP headers needed by callers) */
+int   srslte_hip_device_count(void);
+int   srslte_hip_set_device(int device);
+void* srslte_hip_malloc(size_t nbytes);
+void  srslte_hip_free(void* d_ptr);
+int   srslte_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t nbytes);
+int   srslte_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t nbytes);
+int   srslte_hip_memset(void* d_dst, int value, size_t nbytes);
+int   srslte_hip_sync(void);
+void* srslte_hip_stream_create(void);
+void  srslte_hip_stream_destroy(void* stream);
+int   srslte_hip_stream_sync(void* stream);
+
+/* ------------------------------------------------------------------ OFDM (replaces srslte_ofdm_rx_sf / srslte_ofdm_tx_sf,
+ * lib/include/srslte/phy/dft/ofdm.h:82-153, lib/src/phy/dft/ofdm.c:384-594, and FFTW behind dft_fftw.c) */
+typedef struct srslte_hip_ofdm srslte_hip_ofdm_t;
+srslte_hip_ofdm_t* srslte_hip_ofdm_create(int nof_prb, int cp_is_norm, int is_rx);     /* ofdm.c:235-273 */
+void               srslte_hip_ofdm_destroy(srslte_hip_ofdm_t* q);                      /* ofdm.c:214-233 */
+int                srslte_hip_ofdm_set_normalize(srslte_hip_ofdm_t* q, int enable);    /* ofdm.c:576-578 */
+int                srslte_hip_ofdm_set_freq_shift(srslte_hip_ofdm_t* q, float shift);  /* ofdm.c:360-378 */
+int                srslte_hip_ofdm_symbol_sz(const srslte_hip_ofdm_t* q);
+int                srslte_hip_ofdm_sf_len(const srslte_hip_ofdm_t* q);
+int srslte_hip_ofdm_rx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_time, void* d_out_grid, int nof_sf, void* stream); /* ofdm.c:453-467 */
+int srslte_hip_ofdm_tx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_grid, void* d_out_time, int nof_sf, void* stream); /* ofdm.c:580-594 */
+
+/* generic batched c2c DFT (replaces srslte_dft_run_guru_c, dft.h:137-152, dft_fftw.c:137-165,307-313) */
+int srslte_hip_dft_batch(const void* d_in, void* d_out, int N, int howmany, int idist, int odist, int forward, float scale, void* stream);
+/* SC-FDMA transform precoding (replaces srslte_dft_precoding, dft_precoding.h:39-64, dft_precoding.c:88-113) */
+int srslte_hip_dft_precoding_valid_prb(uint32_t nof_prb);
+int srslte_hip_dft_precoding_batch(const void* d_in, void* d_out, uint32_t nof_prb, uint32_t nof_symbols, int forward, void* stream);
+
+/* ------------------------------------------------------------------ DL channel estimator (replaces srslte_chest_dl_estimate_cfg,
+ * ch_estimation/chest_dl.h:49-156, chest_dl.c:598-908) */
+typedef struct srslte_hip_chest_dl srslte_hip_chest_dl_t;
+typedef struct {             /* same members, order and meaning as srslte_chest_dl_cfg_t (chest_dl.h:116-130) */
+  int      noise_alg;        /* 0 REFS (the only one on device), 1 PSS, 2 EMPTY */
+  int      filter_type;      /* 0 GAUSS, 1 TRIANGLE, 2 NONE (chest_common.h:30-34) */
+  float    filter_coef[2];
+  uint16_t mbsfn_area_id;
+  uint8_t  interpolate_subframe;
+  uint8_t  rsrp_neighbour;
+  uint8_t  cfo_estimate_enable;
+  uint32_t cfo_estimate_sf_mask;
+  uint8_t  sync_error_enable;
+} srslte_hip_chest_dl_cfg_t;
+typedef struct {             /* scalar members of srslte_chest_dl_res_t (chest_dl.h:49-67), one per subframe */
+  float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
+} srslte_hip_chest_dl_res_t;
+srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm); /* chest_dl.c:69-160,193-300 */
+void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
+int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
+                                       void* d_ce, void* d_res, int nof_sf, void* stream);
+
+/* ------------------------------------------------------------------ soft demapper (replaces srslte_demod_soft_demodulate{,_s,_b},
+ * modem/demod_soft.h:39-53, demod_soft.c:479-549). mod: 0 BPSK, 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM (srslte_mod_t).
+ * ncalls independent calls of nsymbols each (the scalar-tail rounding of the reference depends on nsymbols). */
+int srslte_hip_demod_soft_demodulate_batch(int mod, const void* d_symbols, float* d_llr, int nsymbols, int ncalls, void* stream);
+int srslte_hip_demod_soft_demodulate_s_batch(int mod, const void* d_symbols, short* d_llr, int nsymbols, int ncalls, void* stream);
+int srslte_hip_demod_soft_demodulate_b_batch(int mod, const void* d_symbols, int8_t* d_llr, int nsymbols, int ncalls, void* stream);
+
+/* ------------------------------------------------------------------ turbo decoder (replaces srslte_tdec_run_all / srslte_tdec_iteration,
+ * fec/turbodecoder.h:63-135, turbodecoder.c:146-593, turbodecoder_iter.h:71-139, turbodecoder_win.h, turbodecoder_gen.c) */
+typedef struct srslte_hip_tdec srslte_hip_tdec_t;
+srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint32_t max_nof_cb);
+void               srslte_hip_tdec_destroy(srslte_hip_tdec_t* q);
+uint32_t           srslte_hip_tdec_autoimp_get_subblocks(uint32_t long_cb);           /* turbodecoder.c:394-406 */
+uint32_t           srslte_hip_tdec_input_len(uint32_t long_cb, int sb_layout);        /* int16 per code block */
+/* Decodes nof_cb code blocks of equal length long_cb.
+ *   d_input: [nof_cb][in_stride] int16; layout = [s p0 p1]*K + 12 tail (sb_layout = 0, srslte_tdec_force_not_sb)
+ *            or the rm_turbo "SB" layout 3*(K+32)+12 (sb_layout = 1; turbodecoder_iter.h:84-91)
+ *   nof_iterations: SISO passes (one srslte_tdec_iteration each)
+ *   crc_poly: 0 = run all passes (srslte_tdec_run_all); else stop a block at the first pass whose hard decision has
+ *             a zero CRC-24 remainder over crc_nbits bits (sch.c:353-383)
+ *   d_output: [nof_cb][out_stride] bytes, K/8 per block, MSB first; d_iters/d_crc_ok: [nof_cb] or NULL */
+int srslte_hip_tdec_run_batch(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
+                              uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
+                              uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream);
+
+/* ------------------------------------------------------------------ turbo encoder (replaces srslte_tcod_encode, fec/turbocoder.h:44-76,
+ * turbocoder.c:76-186): bits in (one per byte) -> 3K+12 bits out ([s p0 p1] triplets + 12 tail), nof_cb blocks */
+int srslte_hip_tcod_encode_batch(const uint8_t* d_input, uint8_t* d_output, uint32_t long_cb, uint32_t nof_cb, void* stream);
+
+/* ------------------------------------------------------------------ segmentation / interleaver (host, replaces cbsegm.c, tc_interl_lte.c) */
+typedef struct { /* same members and order as srslte_cbsegm_t (cbsegm.h:33-44) */
+  uint32_t F, C, K1, K2, K1_idx, K2_idx, C1, C2, tbs;
+} srslte_hip_cbsegm_t;
+int srslte_hip_cbsegm(srslte_hip_cbsegm_t* s, uint32_t tbs);
+int srslte_hip_cbsegm_cbindex(uint32_t long_cb);
+int srslte_hip_cbsegm_cbsize(uint32_t index);
+int srslte_hip_tc_interl_LTE_gen_interl(uint16_t* forward, uint16_t* reverse, uint32_t long_cb, uint32_t interl_win);
+
+/* ------------------------------------------------------------------ PDSCH receive pipeline (SURVEY §8f N1 glue fused on device):
+ * OFDM RX -> chest_dl -> RE extraction + one-tap MMSE -> soft demap + descramble -> turbo rate de-matching ->
+ * turbo decode with CRC early stop -> TB CRC. Single port, single rx antenna, full-band grant, rv 0, FDD, normal CP. */
+typedef struct srslte_hip_dl_rx srslte_hip_dl_rx_t;
+typedef struct {
+  uint32_t cell_id, nof_prb, cfi;
+  uint16_t rnti;
+  int      mod;            /* srslte_mod_t */
+  uint32_t tbs;            /* transport block size, bits */
+  uint32_t max_iterations; /* SISO passes, sch.c:114 */
+  uint32_t max_batch;      /* subframes per call */
+  int      mmse;           /* 1: noise_estimate from chest (pdsch.c:862), 0: ZF */
+  srslte_hip_chest_dl_cfg_t chest_cfg;
+} srslte_hip_dl_rx_cfg_t;
+srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
+void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
+uint32_t            srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_t sf_idx);
+/* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf] */
+int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
+                           uint8_t* d_tb_ok, void* stream);
+/* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d, 4 e (LLRs), 5 w, 6 cb iters */
+const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

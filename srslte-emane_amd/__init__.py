@@ -1,0 +1,360 @@
+"""srslte-emane_amd — MI355X-native drop-in for the sample-level hot path of srsLTE's lib/src/phy.
+
+The product is ``csrc/libsrslte_phy_hip.so`` (hand-written HIP for gfx950 behind a C ABI, see
+``include/srslte_hip/phy_hip.h``). This module is only the host-side mirror of the reference's operator
+interface used by the tests, ``bench.py`` and ``__graft_entry__``: same names, argument meaning and error
+behaviour as the ``srslte_*`` calls, numpy arrays in and out, device buffers managed through the C ABI.
+
+There is NO CPU fallback: importing the native handle without a built library raises, and every call needs a GPU.
+(The directory name carries a hyphen; import it with ``importlib.import_module("srslte-emane_amd")``.)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsrslte_phy_hip.so")
+
+SRSLTE_SUCCESS, SRSLTE_ERROR, SRSLTE_ERROR_INVALID_INPUTS = 0, -1, -2
+MOD_BPSK, MOD_QPSK, MOD_16QAM, MOD_64QAM, MOD_256QAM = range(5)
+CRC24A, CRC24B = 0x1864CFB, 0x1800063
+
+_lib = None
+
+
+class ChestDlCfg(C.Structure):
+    """srslte_chest_dl_cfg_t (chest_dl.h:116-130)."""
+    _fields_ = [("noise_alg", C.c_int), ("filter_type", C.c_int), ("filter_coef", C.c_float * 2), ("mbsfn_area_id", C.c_uint16),
+                ("interpolate_subframe", C.c_uint8), ("rsrp_neighbour", C.c_uint8), ("cfo_estimate_enable", C.c_uint8),
+                ("cfo_estimate_sf_mask", C.c_uint32), ("sync_error_enable", C.c_uint8)]
+
+
+CHEST_RES_FIELDS = ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo", "sync_error")
+
+
+class Cbsegm(C.Structure):
+    """srslte_cbsegm_t (cbsegm.h:33-44)."""
+    _fields_ = [(n, C.c_uint32) for n in ("F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs")]
+
+
+class DlRxCfg(C.Structure):
+    _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int),
+                ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg)]
+
+
+def lib():
+    """The native library; raises if it was not built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.srslte_hip_malloc.restype = vp
+        L.srslte_hip_malloc.argtypes = [C.c_size_t]
+        L.srslte_hip_free.argtypes = [vp]
+        L.srslte_hip_memcpy_h2d.argtypes = [vp, vp, C.c_size_t]
+        L.srslte_hip_memcpy_d2h.argtypes = [vp, vp, C.c_size_t]
+        L.srslte_hip_memset.argtypes = [vp, C.c_int, C.c_size_t]
+        L.srslte_hip_stream_create.restype = vp
+        L.srslte_hip_stream_destroy.argtypes = [vp]
+        L.srslte_hip_stream_sync.argtypes = [vp]
+        L.srslte_hip_event_create.restype = vp
+        L.srslte_hip_event_record.argtypes = [vp, vp]
+        L.srslte_hip_event_elapsed_ms.restype = C.c_float
+        L.srslte_hip_event_elapsed_ms.argtypes = [vp, vp]
+        L.srslte_hip_event_destroy.argtypes = [vp]
+        L.srslte_hip_ofdm_create.restype = vp
+        L.srslte_hip_ofdm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.srslte_hip_ofdm_destroy.argtypes = [vp]
+        L.srslte_hip_ofdm_set_normalize.argtypes = [vp, C.c_int]
+        L.srslte_hip_ofdm_set_freq_shift.argtypes = [vp, C.c_float]
+        L.srslte_hip_ofdm_symbol_sz.argtypes = [vp]
+        L.srslte_hip_ofdm_sf_len.argtypes = [vp]
+        L.srslte_hip_ofdm_rx_sf_batch.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.srslte_hip_ofdm_tx_sf_batch.argtypes = [vp, vp, vp, C.c_int, vp]
+        L.srslte_hip_dft_batch.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp]
+        L.srslte_hip_dft_precoding_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_int, vp]
+        L.srslte_hip_chest_dl_create.restype = vp
+        L.srslte_hip_chest_dl_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.srslte_hip_chest_dl_destroy.argtypes = [vp]
+        L.srslte_hip_chest_dl_estimate_batch.argtypes = [vp, C.POINTER(ChestDlCfg), C.c_uint32, vp, vp, vp, C.c_int, vp]
+        for n in ("", "_s", "_b"):
+            getattr(L, "srslte_hip_demod_soft_demodulate%s_batch" % n).argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, vp]
+        L.srslte_hip_tdec_create.restype = vp
+        L.srslte_hip_tdec_create.argtypes = [C.c_uint32, C.c_uint32]
+        L.srslte_hip_tdec_destroy.argtypes = [vp]
+        L.srslte_hip_tdec_autoimp_get_subblocks.restype = C.c_uint32
+        L.srslte_hip_tdec_input_len.restype = C.c_uint32
+        L.srslte_hip_tdec_run_batch.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                vp, C.c_uint32, vp, vp, vp]
+        L.srslte_hip_tdec_run_batch_manual.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                                       C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp, vp]
+        L.srslte_hip_tcod_encode_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
+        L.srslte_hip_cbsegm.argtypes = [C.POINTER(Cbsegm), C.c_uint32]
+        L.srslte_hip_tc_interl_LTE_gen_interl.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+        L.srslte_hip_dl_rx_create.restype = vp
+        L.srslte_hip_dl_rx_create.argtypes = [C.POINTER(DlRxCfg)]
+        L.srslte_hip_dl_rx_destroy.argtypes = [vp]
+        L.srslte_hip_dl_rx_nof_re.restype = C.c_uint32
+        L.srslte_hip_dl_rx_nof_re.argtypes = [vp, C.c_uint32]
+        L.srslte_hip_dl_rx_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.srslte_hip_dl_rx_stage.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.srslte_hip_dl_rx_debug_buffer.restype = vp
+        L.srslte_hip_dl_rx_debug_buffer.argtypes = [vp, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != SRSLTE_SUCCESS:
+        raise RuntimeError("%s failed with %d" % (what, rc))
+
+
+class DevBuf:
+    """A device allocation owned through the C ABI."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        self.ptr = lib().srslte_hip_malloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("srslte_hip_malloc(%d)" % nbytes)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(max(arr.nbytes, 1))
+        _check(lib().srslte_hip_memcpy_h2d(b.ptr, arr.ctypes.data, arr.nbytes), "memcpy_h2d")
+        return b
+
+    def to_host(self, dtype, count=None):
+        dtype = np.dtype(dtype)
+        n = self.nbytes // dtype.itemsize if count is None else int(count)
+        out = np.empty(n, dtype)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().srslte_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    _check(lib().srslte_hip_sync(), "sync")
+
+
+def symbol_sz(nof_prb):
+    """srslte_symbol_sz (phy_common.c:322-345)."""
+    for lim, n in ((6, 128), (15, 256), (25, 384), (50, 768), (75, 1024), (110, 1536)):
+        if 0 < nof_prb <= lim:
+            return n
+    return -1
+
+
+class Ofdm:
+    """srslte_ofdm_t: srslte_ofdm_rx_init/tx_init + set_normalize/set_freq_shift + rx_sf/tx_sf (ofdm.h), batched."""
+
+    def __init__(self, nof_prb, cp_norm=True, rx=True):
+        self.h = lib().srslte_hip_ofdm_create(nof_prb, 1 if cp_norm else 0, 1 if rx else 0)
+        if not self.h:
+            raise RuntimeError("srslte_hip_ofdm_create failed")
+        self.nof_prb, self.rx = nof_prb, rx
+        self.nsym = 14 if cp_norm else 12
+        self.sf_len = lib().srslte_hip_ofdm_sf_len(self.h)
+        self.grid_len = self.nsym * 12 * nof_prb
+
+    def set_normalize(self, en):
+        _check(lib().srslte_hip_ofdm_set_normalize(self.h, 1 if en else 0), "set_normalize")
+
+    def set_freq_shift(self, f):
+        _check(lib().srslte_hip_ofdm_set_freq_shift(self.h, f), "set_freq_shift")
+
+    def rx_sf(self, time_samples):
+        x = np.ascontiguousarray(time_samples, np.complex64).reshape(-1, self.sf_len)
+        din, dout = DevBuf.from_host(x), DevBuf(x.shape[0] * self.grid_len * 8)
+        _check(lib().srslte_hip_ofdm_rx_sf_batch(self.h, din.ptr, dout.ptr, x.shape[0], None), "ofdm_rx_sf_batch")
+        sync()
+        return dout.to_host(np.complex64).reshape(x.shape[0], self.grid_len)
+
+    def tx_sf(self, grid):
+        x = np.ascontiguousarray(grid, np.complex64).reshape(-1, self.grid_len)
+        din, dout = DevBuf.from_host(x), DevBuf(x.shape[0] * self.sf_len * 8)
+        _check(lib().srslte_hip_ofdm_tx_sf_batch(self.h, din.ptr, dout.ptr, x.shape[0], None), "ofdm_tx_sf_batch")
+        sync()
+        return dout.to_host(np.complex64).reshape(x.shape[0], self.sf_len)
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_ofdm_destroy(self.h)
+            self.h = None
+
+
+def dft(x, forward=True, scale=1.0):
+    """srslte_dft_run_c on each row of x (unnormalised unless scale given)."""
+    x = np.ascontiguousarray(x, np.complex64)
+    x2 = x.reshape(-1, x.shape[-1])
+    din, dout = DevBuf.from_host(x2), DevBuf(x2.nbytes)
+    n = x2.shape[1]
+    rc = lib().srslte_hip_dft_batch(din.ptr, dout.ptr, n, x2.shape[0], n, n, 1 if forward else 0, scale, None)
+    _check(rc, "dft_batch")
+    sync()
+    return dout.to_host(np.complex64).reshape(x.shape)
+
+
+def dft_precoding(x, nof_prb, nof_symbols, forward=True):
+    """srslte_dft_precoding (dft_precoding.c:100-113)."""
+    x = np.ascontiguousarray(x, np.complex64)
+    din, dout = DevBuf.from_host(x), DevBuf(x.nbytes)
+    rc = lib().srslte_hip_dft_precoding_batch(din.ptr, dout.ptr, nof_prb, nof_symbols, 1 if forward else 0, None)
+    if rc != SRSLTE_SUCCESS:
+        return rc, None
+    sync()
+    return rc, dout.to_host(np.complex64).reshape(x.shape)
+
+
+class ChestDl:
+    """srslte_chest_dl_t: init + set_cell + estimate_cfg (chest_dl.h:132-156), batched over subframes tti0, tti0+1, ..."""
+
+    def __init__(self, cell_id, nof_prb, nof_ports=1, cp_norm=True):
+        self.h = lib().srslte_hip_chest_dl_create(cell_id, nof_prb, nof_ports, 1 if cp_norm else 0)
+        if not self.h:
+            raise RuntimeError("srslte_hip_chest_dl_create failed")
+        self.grid_len = 14 * 12 * nof_prb
+
+    def estimate(self, grid, tti0=0, cfg=None, want_ce=True):
+        cfg = cfg or ChestDlCfg()
+        g = np.ascontiguousarray(grid, np.complex64).reshape(-1, self.grid_len)
+        n = g.shape[0]
+        dg, dce, dres = DevBuf.from_host(g), DevBuf(g.nbytes), DevBuf(n * 40)
+        rc = lib().srslte_hip_chest_dl_estimate_batch(self.h, C.byref(cfg), tti0, dg.ptr, dce.ptr if want_ce else None, dres.ptr, n, None)
+        _check(rc, "chest_dl_estimate_batch")
+        sync()
+        res = dres.to_host(np.float32).reshape(n, 10)
+        return (dce.to_host(np.complex64).reshape(n, self.grid_len) if want_ce else None), {k: res[:, i] for i, k in enumerate(CHEST_RES_FIELDS)}
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_chest_dl_destroy(self.h)
+            self.h = None
+
+
+_LLR_DT = {"f": np.float32, "s": np.int16, "b": np.int8}
+
+
+def demod_soft_demodulate(mod, symbols, kind="s", ncalls=1):
+    """srslte_demod_soft_demodulate / _s / _b (demod_soft.h:39-53); kind in 'f','s','b'. Returns (rc, llr)."""
+    s = np.ascontiguousarray(symbols, np.complex64).reshape(ncalls, -1)
+    nsym = s.shape[1]
+    qm = 1 if mod == MOD_BPSK else 2 * mod
+    dt = np.dtype(_LLR_DT[kind])
+    ds, dl = DevBuf.from_host(s), DevBuf(max(1, s.size * qm * dt.itemsize))
+    fn = getattr(lib(), "srslte_hip_demod_soft_demodulate%s_batch" % ("" if kind == "f" else "_" + kind))
+    rc = fn(mod, ds.ptr, dl.ptr, nsym, ncalls, None)
+    if rc != SRSLTE_SUCCESS:
+        return rc, None
+    sync()
+    return rc, dl.to_host(dt, s.size * qm).reshape(ncalls, nsym * qm)
+
+
+class Tdec:
+    """srslte_tdec_t: srslte_tdec_init + srslte_tdec_run_all / iteration-with-CRC (turbodecoder.h:63-135), batched."""
+
+    def __init__(self, max_long_cb=6144, max_nof_cb=64):
+        self.h = lib().srslte_hip_tdec_create(max_long_cb, max_nof_cb)
+        if not self.h:
+            raise RuntimeError("srslte_hip_tdec_create failed")
+
+    def run_all(self, llr, long_cb, nof_iterations, sb_layout=False, crc_poly=0, crc_nbits=0, force_subblocks=None):
+        x = np.ascontiguousarray(llr, np.int16)
+        x = x.reshape(-1, x.shape[-1])
+        ncb = x.shape[0]
+        din, dout = DevBuf.from_host(x), DevBuf(ncb * (long_cb // 8))
+        dit, dok = DevBuf(4 * ncb), DevBuf(ncb)
+        if force_subblocks is None:
+            rc = lib().srslte_hip_tdec_run_batch(self.h, din.ptr, x.shape[1], 1 if sb_layout else 0, long_cb, ncb, nof_iterations, crc_poly,
+                                                 crc_nbits, dout.ptr, long_cb // 8, dit.ptr, dok.ptr, None)
+        else:
+            rc = lib().srslte_hip_tdec_run_batch_manual(self.h, din.ptr, x.shape[1], 1 if sb_layout else 0, long_cb, force_subblocks, ncb,
+                                                        nof_iterations, crc_poly, crc_nbits, dout.ptr, long_cb // 8, dit.ptr, dok.ptr, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None, None
+        sync()
+        return rc, dout.to_host(np.uint8).reshape(ncb, long_cb // 8), dit.to_host(np.uint32), dok.to_host(np.uint8)
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_tdec_destroy(self.h)
+            self.h = None
+
+
+def tcod_encode(bits, long_cb):
+    """srslte_tcod_encode (turbocoder.c:76-186): [ncb][K] bits -> [ncb][3K+12]. Returns (rc, out)."""
+    x = np.ascontiguousarray(bits, np.uint8).reshape(-1, long_cb)
+    din, dout = DevBuf.from_host(x), DevBuf(x.shape[0] * (3 * long_cb + 12))
+    rc = lib().srslte_hip_tcod_encode_batch(din.ptr, dout.ptr, long_cb, x.shape[0], None)
+    if rc != SRSLTE_SUCCESS:
+        return rc, None
+    sync()
+    return rc, dout.to_host(np.uint8).reshape(x.shape[0], 3 * long_cb + 12)
+
+
+def cbsegm(tbs):
+    s = Cbsegm()
+    rc = lib().srslte_hip_cbsegm(C.byref(s), tbs)
+    return rc, s
+
+
+def tc_interl(long_cb, win=1):
+    f, r = np.zeros(long_cb, np.uint16), np.zeros(long_cb, np.uint16)
+    rc = lib().srslte_hip_tc_interl_LTE_gen_interl(f.ctypes.data, r.ctypes.data, long_cb, win)
+    return rc, f, r
+
+
+class DlRx:
+    """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
+
+    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None):
+        self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg())
+        self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("srslte_hip_dl_rx_create failed")
+        self.tbs, self.max_batch = tbs, max_batch
+        self.tb_stride = (tbs // 8 + 6 + 15) & ~15
+        self.sf_len = 15 * symbol_sz(nof_prb)
+        self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+
+    def nof_re(self, sf_idx):
+        return lib().srslte_hip_dl_rx_nof_re(self.h, sf_idx)
+
+    def run_device(self, d_iq_ptr, tti0, nof_sf, stream=None):
+        return lib().srslte_hip_dl_rx_batch(self.h, d_iq_ptr, tti0, nof_sf, self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, stream)
+
+    def stage(self, stage, d_iq_ptr, tti0, nof_sf, stream=None):
+        return lib().srslte_hip_dl_rx_stage(self.h, stage, d_iq_ptr, tti0, nof_sf, self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, stream)
+
+    def decode(self, iq, tti0=0):
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
+        din = DevBuf.from_host(x)
+        _check(self.run_device(din.ptr, tti0, x.shape[0]), "dl_rx_batch")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def debug(self, which, dtype, count):
+        ptr = lib().srslte_hip_dl_rx_debug_buffer(self.h, which)
+        out = np.empty(count, dtype)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_dl_rx_destroy(self.h)
+            self.h = None

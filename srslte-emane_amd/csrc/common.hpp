@@ -1,0 +1,41 @@
+// Shared host/device definitions for libsrslte_phy_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define SRSLTE_SUCCESS 0
+#define SRSLTE_ERROR -1
+#define SRSLTE_ERROR_INVALID_INPUTS -2
+
+// Every HIP failure surfaces as SRSLTE_ERROR with a diagnostic on stderr (config.h:58-66 convention).
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e__ = (expr);                                                                            \
+    if (e__ != hipSuccess) {                                                                            \
+      fprintf(stderr, "[srslte_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      return SRSLTE_ERROR;                                                                              \
+    }                                                                                                   \
+  } while (0)
+
+#define LAUNCH_CHECK() HIP_TRY(hipGetLastError())
+
+typedef float2 cf32; // layout-compatible with C99 float _Complex (cf_t, config.h:68)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- LTE numerology (restates phy_common.c:322-345, phy_common.h:93-116) ----
+static inline int lte_symbol_sz(int nof_prb)
+{
+  if (nof_prb <= 0) return -1;
+  if (nof_prb <= 6) return 128;
+  if (nof_prb <= 15) return 256;
+  if (nof_prb <= 25) return 384;
+  if (nof_prb <= 50) return 768;
+  if (nof_prb <= 75) return 1024;
+  if (nof_prb <= 110) return 1536;
+  return -1;
+}
+static inline int lte_cp_len(int N, int c) { return (c * N + 2047) / 2048; }
+static inline int lte_cp_len_norm(int l, int N) { return l == 0 ? lte_cp_len(N, 160) : lte_cp_len(N, 144); }
+static inline int lte_cp_len_ext(int N) { return lte_cp_len(N, 512); }

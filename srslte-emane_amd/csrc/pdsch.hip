@@ -1,0 +1,369 @@
+// PDSCH receive pipeline for gfx950: keeps IQ -> grid -> estimates -> LLRs -> soft buffers -> transport blocks on the
+// device for a whole batch of subframes (SURVEY §8b "batch entry points", §8f N1 glue).
+//
+// Stages and the reference code they replace:
+//   ofdm_rx_kernel (fft.hip)      srslte_ofdm_rx_sf                       ofdm.c:453-467
+//   chest_dl_kernel (chest.hip)   srslte_chest_dl_estimate_cfg            chest_dl.c:884-908
+//   pdsch_demod_kernel (here)     srslte_pdsch_get x2 + srslte_predecoding_single + srslte_demod_soft_demodulate_s +
+//                                 srslte_scrambling_s_offset              pdsch.c:81-206,:760-779,:890-935, precoding.c:262-322
+//   rm_rx_kernel (here)           srslte_rm_turbo_rx_lut per code block   sch.c:318-346, rm_turbo.c:374-420
+//   tdec_*_kernel (tdec.hip)      srslte_tdec_new_cb/_iteration + CB CRC  sch.c:348-383
+//   tb_crc_kernel (here)          payload assembly + TB CRC24A            sch.c:401-410,:470-488
+// Single tx port, single rx antenna, full-band grant, rv 0 (first transmission), FDD, normal CP.
+//
+// The fused demod kernel gathers each PDSCH RE and its channel estimate once, equalises with an exact division
+// (the reference's AVX body uses the 12-bit _mm256_rcp_ps approximation, precoding.c:262-275, whose value is CPU-vendor
+// dependent; LLRs may therefore differ from a given host's by an LSB, decoded blocks do not), demaps, descrambles and
+// writes int16 LLRs: 16 B read and 2*Qm B written per RE, no intermediate d/e round trips through HBM.
+#include "common.hpp"
+#include "demod_dev.hpp"
+#include "phy_hip_internal.hpp"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
+                     uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
+                     uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st);
+
+namespace {
+
+struct ChestResDev {
+  float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
+};
+
+struct SfClass { // RE list per subframe class: 0 = sf 0 (PSS/SSS+PBCH), 1 = sf 5 (PSS/SSS), 2 = the rest
+  const uint32_t* idx;
+  int             nof_re;
+};
+
+struct PdschGeom {
+  SfClass cls[3];
+  int     grid_len;   // 14 * 12 * nof_prb
+  int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0;
+};
+
+__device__ __forceinline__ int sf_class(int sf_idx) { return sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2); }
+
+// grid = (ceil(max_re/256), nof_sf)
+__global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                          const ChestResDev* __restrict__ res, const uint32_t* __restrict__ scr,
+                                                          cf32* __restrict__ d_out, int16_t* __restrict__ e_out, PdschGeom g)
+{
+  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int     i  = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= c.nof_re) return;
+  const uint32_t k = c.idx[i];
+  const cf32     y = grid[(size_t)sf * g.grid_len + k], h = ce[(size_t)sf * g.grid_len + k];
+  const float    n0 = g.mmse ? res[sf].noise_estimate : 0.f;
+  // precoding.c:277-288 with scaling = 1 (pdsch.c:852-858, power_scale off)
+  const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
+  const cf32  x  = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+  if (d_out) d_out[(size_t)sf * g.max_re + i] = x;
+  short o[8];
+  demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
+  int16_t*        dst = e_out + (size_t)sf * g.max_bits + (size_t)i * g.Qm;
+  for (int j = 0; j < g.Qm; j++) {
+    const int bit = i * g.Qm + j;
+    short     v   = o[j];
+    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (short)-v; // scrambling.c:45-48
+    dst[j] = v;
+  }
+}
+
+struct RmGeom {
+  int C, K, Qm, tti0, max_bits, w_stride, out_len; // out_len = 3K+12
+  int nof_re[3];
+};
+
+// grid = (ceil(out_len/256), nof_sf*C): w[cb][tbl[n]] = sum_m e[rp + n + m*out_len]   (wrapping int16, rm_turbo.c:407-409)
+__global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ tbl,
+                                                    RmGeom g)
+{
+  const int cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C;
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= g.out_len) return;
+  const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)]; // nof_bits / Qm
+  const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
+  int       rp = cb * n_e, n_e2 = n_e;
+  if (cb > g.C - gamma) { // sch.c:331-334 (the '>' quirk is upstream's)
+    n_e2 = n_e + g.Qm;
+    rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
+  }
+  const int16_t* src = e + (size_t)sf * g.max_bits + rp;
+  int            acc = 0;
+  for (int i = n; i < n_e2; i += g.out_len) acc += src[i];
+  w[(size_t)cbg * g.w_stride + tbl[n]] = (int16_t)acc;
+}
+
+struct TbGeom {
+  int C, K, tbs, rlen, cb_stride, tb_stride;
+};
+
+// one workgroup per subframe: assemble the payload (sch.c:360,:401-410) and check CRC24A (sch.c:470-488)
+__global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok,
+                                                     const uint32_t* __restrict__ crc_rem, uint8_t* __restrict__ tb, uint8_t* __restrict__ tb_ok,
+                                                     TbGeom g)
+{
+  __shared__ uint32_t red[4];
+  const int sf = blockIdx.x, nbytes = g.tbs / 8 + 3;
+  uint8_t*  dst = tb + (size_t)sf * g.tb_stride;
+  uint32_t  syn = 0;
+  for (int b = threadIdx.x; b < nbytes + 3; b += blockDim.x) {
+    int cb = b / (g.rlen / 8);
+    if (cb > g.C - 1) cb = g.C - 1;
+    const int     off = b - cb * (g.rlen / 8);
+    const uint8_t v   = off < g.K / 8 ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : 0;
+    dst[b]            = v;
+    if (b < nbytes) {
+      for (int j = 0; j < 8; j++) {
+        if ((v >> (7 - j)) & 1) syn ^= crc_rem[8 * b + j];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = syn;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    syn = red[0] ^ red[1] ^ red[2] ^ red[3];
+    bool ok = syn == 0;
+    for (int c = 0; c < g.C; c++) ok = ok && cb_ok[sf * g.C + c];
+    // par_rx == par_tx && par_rx != 0 (sch.c:481): a zero parity with zero syndrome is rejected upstream
+    const uint8_t* p = dst + g.tbs / 8;
+    ok               = ok && (p[0] | p[1] | p[2]);
+    tb_ok[sf]        = ok ? 1 : 0;
+  }
+}
+
+// pdsch.c:81-206 as a per-RE rule (see oracle/orc_pdsch.c for the derivation): symbol-major, sub-carrier ascending,
+// skipping CRS, and the central 72 sub-carriers of the PSS/SSS symbols (slot 0, l >= 5, sf 0/5) and PBCH symbols (slot 1, l < 4, sf 0)
+void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t sf_idx, uint32_t lstart, std::vector<uint32_t>& idx)
+{
+  const uint32_t nre = 12 * nof_prb;
+  idx.clear();
+  for (uint32_t s = 0; s < 2; s++) {
+    for (uint32_t l = (s == 0 ? lstart : 0); l < 7; l++) {
+      const bool     has_ref = l == 0 || l == 4;
+      const uint32_t offset  = l == 0 ? cell_id % 6 : (cell_id + 3) % 6;
+      const bool     sync    = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
+      for (uint32_t k = 0; k < nre; k++) {
+        if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) continue;
+        if (has_ref && (k % 6) == offset % 6) continue;
+        idx.push_back((s * 7 + l) * nre + k);
+      }
+    }
+  }
+}
+
+template <typename T>
+int upload(T** d, const std::vector<T>& h)
+{
+  HIP_TRY(hipMalloc((void**)d, sizeof(T) * (h.size() ? h.size() : 1)));
+  HIP_TRY(hipMemcpy(*d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice));
+  return SRSLTE_SUCCESS;
+}
+
+} // namespace
+
+struct srslte_hip_dl_rx {
+  srslte_hip_dl_rx_cfg_t cfg;
+  srslte_hip_ofdm_t*     ofdm;
+  srslte_hip_chest_dl_t* chest;
+  srslte_hip_tdec_t*     tdec;
+  srslte_hip_cbsegm_t    seg;
+  PdschGeom              pg;
+  RmGeom                 rg;
+  TbGeom                 tg;
+  uint32_t               W, in_stride;
+  uint32_t*              d_idx[3];
+  uint32_t*              d_scr;
+  uint32_t*              d_rm_tbl;
+  uint32_t*              d_tbcrc;
+  cf32 *                 d_grid, *d_ce, *d_d;
+  ChestResDev*           d_res;
+  int16_t *              d_e, *d_w;
+  uint8_t *              d_cb_bytes, *d_cb_ok;
+  uint32_t*              d_cb_iters;
+};
+
+extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
+{
+  if (!q) return;
+  srslte_hip_ofdm_destroy(q->ofdm);
+  srslte_hip_chest_dl_destroy(q->chest);
+  srslte_hip_tdec_destroy(q->tdec);
+  void* bufs[] = {q->d_idx[0], q->d_idx[1], q->d_idx[2], q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_grid, q->d_ce, q->d_d,
+                  q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters};
+  for (void* b : bufs) {
+    if (b) (void)hipFree(b);
+  }
+  delete q;
+}
+
+extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
+{
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0) {
+    fprintf(stderr, "[srslte_hip] dl_rx: invalid configuration\n");
+    return nullptr;
+  }
+  auto* q = new srslte_hip_dl_rx();
+  memset(q, 0, sizeof(*q));
+  q->cfg = *cfg;
+  if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
+    fprintf(stderr, "[srslte_hip] dl_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    delete q;
+    return nullptr;
+  }
+  const uint32_t P = cfg->nof_prb, nre = 12 * P, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod;
+  const uint32_t lstart = cfg->cfi + (P < 10 ? 1 : 0); // SRSLTE_NOF_CTRL_SYMBOLS, phy_common.h:143
+  q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
+  q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, 1, 1);
+  q->tdec  = srslte_hip_tdec_create(K, B * C);
+  bool ok  = q->ofdm && q->chest && q->tdec;
+  // RE lists
+  uint32_t max_re = 0;
+  const uint32_t rep_sf[3] = {0, 5, 1};
+  for (int c = 0; c < 3 && ok; c++) {
+    std::vector<uint32_t> idx;
+    pdsch_re_indices(cfg->cell_id, P, rep_sf[c], lstart, idx);
+    q->pg.cls[c].nof_re = (int)idx.size();
+    q->rg.nof_re[c]     = (int)idx.size();
+    max_re              = idx.size() > max_re ? (uint32_t)idx.size() : max_re;
+    ok                  = upload(&q->d_idx[c], idx) == SRSLTE_SUCCESS;
+    q->pg.cls[c].idx    = q->d_idx[c];
+  }
+  const uint32_t max_bits = max_re * Qm, scr_words = (max_bits + 31) / 32;
+  // scrambling sequences, one per subframe index (sequences.c:58-60, pdsch.c:469)
+  if (ok) {
+    std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
+    std::vector<uint8_t>  c;
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, max_bits, c);
+      for (uint32_t i = 0; i < max_bits; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
+    }
+    ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
+  }
+  // rate-dematching table in the decoder's input layout (rm_turbo.c:160-260)
+  q->W         = srslte_hip_tdec_autoimp_get_subblocks(K);
+  q->in_stride = (srslte_hip_tdec_input_len(K, q->W != 0) + 31) & ~31u;
+  if (ok) {
+    std::vector<uint32_t> t;
+    lte_rm_rx_table(K, 0, t);
+    if (q->W) {
+      for (auto& v : t) {
+        v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
+      }
+    }
+    ok = upload(&q->d_rm_tbl, t) == SRSLTE_SUCCESS;
+  }
+  // TB CRC24A remainders x^(tbs+24-1-j) mod g
+  if (ok) {
+    std::vector<uint32_t> rem(cfg->tbs + 24);
+    uint32_t              v = 1;
+    for (int j = (int)cfg->tbs + 23; j >= 0; j--) {
+      rem[j] = v;
+      v <<= 1;
+      if (v & 0x1000000) v ^= 0x1864CFB;
+    }
+    ok = upload(&q->d_tbcrc, rem) == SRSLTE_SUCCESS;
+  }
+  const size_t glen = (size_t)14 * nre;
+  ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)max_re * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_e, sizeof(int16_t) * (size_t)max_bits * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[srslte_hip] dl_rx: initialisation failed\n");
+    srslte_hip_dl_rx_destroy(q);
+    return nullptr;
+  }
+  q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
+  q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words;
+  q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
+  q->rg.out_len = (int)(3 * K + 12);
+  q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
+  return q;
+}
+
+extern "C" uint32_t srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_t sf_idx)
+{
+  return q ? (uint32_t)q->pg.cls[sf_idx % 10 == 0 ? 0 : (sf_idx % 10 == 5 ? 1 : 2)].nof_re : 0;
+}
+
+extern "C" const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which)
+{
+  if (!q) return nullptr;
+  switch (which) {
+    case 0: return q->d_grid;
+    case 1: return q->d_ce;
+    case 2: return q->d_res;
+    case 3: return q->d_d;
+    case 4: return q->d_e;
+    case 5: return q->d_w;
+    case 6: return q->d_cb_iters;
+    case 7: return q->d_cb_ok;
+    case 8: return q->d_cb_bytes;
+  }
+  return nullptr;
+}
+
+// Stage launchers, also used one by one by bench.py to time each kernel in isolation.
+extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,
+                                      uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || nof_sf > q->cfg.max_batch) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  hipStream_t    st = (hipStream_t)stream;
+  const uint32_t C = q->seg.C, K = q->seg.K1;
+  switch (stage) {
+    case 0: return srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
+    case 1: return srslte_hip_chest_dl_estimate_batch(q->chest, &q->cfg.chest_cfg, tti0, q->d_grid, q->d_ce, q->d_res, (int)nof_sf, stream);
+    case 2: {
+      PdschGeom g = q->pg;
+      g.tti0      = (int)tti0;
+      hipLaunchKernelGGL(pdsch_demod_kernel, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
+                         (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
+      LAUNCH_CHECK();
+      return SRSLTE_SUCCESS;
+    }
+    case 3: {
+      RmGeom g = q->rg;
+      g.tti0   = (int)tti0;
+      hipLaunchKernelGGL(rm_rx_kernel, dim3(ceil_div(g.out_len, 256), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w,
+                         (const uint32_t*)q->d_rm_tbl, g);
+      LAUNCH_CHECK();
+      return SRSLTE_SUCCESS;
+    }
+    case 4:
+      return tdec_run_batch_w(q->tdec, q->d_w, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
+                              C > 1 ? 0x1800063u : 0x1864CFBu, C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
+    case 5: {
+      if (!d_tb || !d_tb_ok || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+      TbGeom g    = q->tg;
+      g.tb_stride = (int)tb_stride;
+      hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+                         (const uint32_t*)q->d_tbcrc, d_tb, d_tb_ok, g);
+      LAUNCH_CHECK();
+      return SRSLTE_SUCCESS;
+    }
+  }
+  return SRSLTE_ERROR_INVALID_INPUTS;
+}
+
+extern "C" int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,
+                                      uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !d_tb || !d_tb_ok) return SRSLTE_ERROR_INVALID_INPUTS;
+  for (int s = 0; s < 6; s++) {
+    int r = srslte_hip_dl_rx_stage(q, s, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+    if (r) return r;
+  }
+  return SRSLTE_SUCCESS;
+}

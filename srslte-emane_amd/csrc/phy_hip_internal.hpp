@@ -1,0 +1,28 @@
+// Internal (non-ABI) declarations shared between the translation units of libsrslte_phy_hip.so.
+#pragma once
+#include "common.hpp"
+#include "srslte_hip/phy_hip.h"
+#include <vector>
+
+struct FftFactors {
+  int N, nf;
+  int radix[8];
+};
+
+// Returns (creating on first use, per device) the factorisation and the device twiddle table exp(-j2*pi*k/N).
+int fft_get_plan(int N, FftFactors* f, const cf32** d_tw);
+
+
+// Gold sequence c(n) of 36.211 7.2 (sequence.c:48-79), host side, for init-time tables.
+void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c);
+
+// demod.hip: type 0 float / 1 int16 / 2 int8; optional packed scrambling bits [10][scr_words] selected by (tti0+call)%10
+int demod_launch(int type, int mod, const void* d_sym, void* d_llr, int nsym, int ncalls, const uint32_t* d_scr, int scr_words, int tti0,
+                 hipStream_t st);
+
+// fec_tables.cpp: 36.212 tables shared by encoder, decoder and rate matching (host)
+struct QppRow { uint16_t K, f1, f2; };
+extern const QppRow lte_qpp_table[188];
+int  lte_cb_index(uint32_t K);
+void lte_qpp_tables(uint32_t K, uint32_t W, std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);
+void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); // circular-buffer order -> 3*i+s

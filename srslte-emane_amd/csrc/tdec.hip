@@ -1,0 +1,648 @@
+// LTE turbo decoder for gfx950: srslte_tdec_run_all / srslte_tdec_iteration (turbodecoder.c:539-562), bit-exact with the
+// reference's 16-bit back-ends as selected on an AVX2 host (turbodecoder.c:394-420):
+//   K > 800, K%16==0 : 16-window max-log-MAP, saturating int16, normalise every 2 steps          (turbodecoder_win.h, avx16)
+//   K > 400, K%8==0  :  8-window, same but extrinsic output >> 1                                  (turbodecoder_win.h, sse16)
+//   otherwise        : unwindowed, wrapping int16, normalise every 4 steps, tail inside the sweep (turbodecoder_gen.c)
+// and the extrinsic-exchange schedule of turbodecoder_iter.h:71-139 with CRC early stop as sch.c:353-383.
+//
+// Mapping to CDNA4 (no MFMA: there is no contraction here):
+//   * one 64-lane wavefront per code block (windowed) / per 8 code blocks (generic);
+//   * a lane owns ONE trellis state of TWO windows: the two int16 path metrics are packed in one VGPR and every
+//     add/sub/max is a single v_pk_{add,sub}_i16 [clamp] / v_pk_max_i16, i.e. exactly _mm256_adds_epi16 & co;
+//   * lanes are (state-slot p: lane bits 0,1,3) x (window pair g: lane bits 2,4,5). The radix-2 trellis butterfly
+//     {2m,2m+1} -> {m,m+4} is done IN PLACE: after a step the slot that held state s holds state rotr3(s), so at
+//     time t slot p holds state rotr3^t(p) and its butterfly partner is always p ^ (1 << (t%3)), i.e. lane ^1,
+//     lane ^2 or lane ^8 - one DPP move (quad_perm / row_ror:8), no LDS, no ds_bpermute in the inner loop;
+//   * the backward (beta) metrics of all steps are parked in a per-wave global scratch slab, one coalesced
+//     256-B store/load per step (HBM/L2; 8*K*2 B per block is more LDS than a CU can spare at useful occupancy);
+//   * 40-step warm-ups from -INF over the neighbouring window, the one-window shift of the start metrics and the
+//     scalar tail trellis are as turbodecoder_win.h:398-456,:529-583,:351-395.
+#include "common.hpp"
+#include "phy_hip_internal.hpp"
+#include <map>
+#include <mutex>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+typedef int   pk_t; // two int16 lanes: lo = first window of the pair, hi = second
+
+constexpr int TD_INF      = 10000;
+constexpr int WIN_OVERLAP = 40;
+
+__device__ __forceinline__ v2s  as_v(pk_t a) { return __builtin_bit_cast(v2s, a); }
+__device__ __forceinline__ pk_t as_p(v2s a) { return __builtin_bit_cast(pk_t, a); }
+template <bool SAT>
+__device__ __forceinline__ pk_t pk_add(pk_t a, pk_t b)
+{
+  if constexpr (SAT) return as_p(__builtin_elementwise_add_sat(as_v(a), as_v(b)));
+  return as_p(as_v(a) + as_v(b));
+}
+template <bool SAT>
+__device__ __forceinline__ pk_t pk_sub(pk_t a, pk_t b)
+{
+  if constexpr (SAT) return as_p(__builtin_elementwise_sub_sat(as_v(a), as_v(b)));
+  return as_p(as_v(a) - as_v(b));
+}
+__device__ __forceinline__ pk_t pk_max(pk_t a, pk_t b) { return as_p(__builtin_elementwise_max(as_v(a), as_v(b))); }
+__device__ __forceinline__ pk_t pk_make(int lo, int hi) { return (pk_t)((lo & 0xffff) | (hi << 16)); }
+__device__ __forceinline__ int  pk_lo(pk_t a) { return (int)(short)(a & 0xffff); }
+__device__ __forceinline__ int  pk_hi(pk_t a) { return a >> 16; }
+
+// lane ^ 1, ^ 2, ^ 8 as DPP moves
+template <int PH>
+__device__ __forceinline__ pk_t dpp_partner(pk_t v)
+{
+  if constexpr (PH == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+  if constexpr (PH == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);                        // row_ror:8
+}
+// value of slot 0 (state 0 at every time step) broadcast to the 8 slots of the group
+__device__ __forceinline__ pk_t bcast_slot0(pk_t v)
+{
+  pk_t t = __builtin_amdgcn_update_dpp(v, v, 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
+  return __builtin_amdgcn_update_dpp(t, t, 0x118, 0xf, 0xf, false);   // row_shr:8, lanes 0..7 of the row keep t
+}
+
+struct LaneGeom {
+  int  lane, p, g;
+  bool p0, p1, p2;
+};
+__device__ __forceinline__ LaneGeom lane_geom()
+{
+  LaneGeom L;
+  L.lane = threadIdx.x & 63;
+  L.p0   = L.lane & 1;
+  L.p1   = (L.lane >> 1) & 1;
+  L.p2   = (L.lane >> 3) & 1;
+  L.p    = (L.lane & 3) | (((L.lane >> 3) & 1) << 2);
+  L.g    = ((L.lane >> 2) & 1) | (((L.lane >> 4) & 3) << 1);
+  return L;
+}
+__device__ __forceinline__ int lane_of(int g, int p) { return (p & 3) | ((g & 1) << 2) | (((p >> 2) & 1) << 3) | ((g >> 1) << 4); }
+__device__ __forceinline__ int rotr3(int s, int n)
+{
+  for (int i = 0; i < n; i++) s = (s >> 1) | ((s & 1) << 2);
+  return s;
+}
+__device__ __forceinline__ int rotl3(int s, int n)
+{
+  for (int i = 0; i < n; i++) s = ((s << 1) & 7) | (s >> 2);
+  return s;
+}
+
+// One add-compare-select step for the slot's state at phase PH = time % 3 (time of the OLD metrics for the forward
+// recursion, of the NEW metrics for the backward one - the same code serves both, see header comment).
+// Branch metrics: (own, partner) = (0,xy) (x,y) (y,x) (xy,0) for state>>1 = 0..3 (turbodecoder_win.h:471-491,:621-641).
+template <int PH, bool SAT>
+__device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y, pk_t xy, pk_t* t_own, pk_t* t_par)
+{
+  const bool b1 = PH == 0 ? L.p2 : (PH == 1 ? L.p0 : L.p1);
+  const bool b0 = PH == 0 ? L.p1 : (PH == 1 ? L.p2 : L.p0);
+  const pk_t g_own = b1 ? (b0 ? xy : y) : (b0 ? x : 0);
+  const pk_t g_par = b1 ? (b0 ? 0 : x) : (b0 ? y : xy);
+  const pk_t po    = dpp_partner<PH>(old);
+  *t_own           = pk_add<SAT>(old, g_own);
+  *t_par           = pk_add<SAT>(po, g_par);
+  return pk_max(*t_own, *t_par);
+}
+
+// max over the 8 slots of a group
+__device__ __forceinline__ pk_t group_max(pk_t v)
+{
+  v = pk_max(v, dpp_partner<0>(v));
+  v = pk_max(v, dpp_partner<1>(v));
+  v = pk_max(v, dpp_partner<2>(v));
+  return v;
+}
+
+struct TdecTables {            // per (K, W) device tables
+  const uint16_t* inter;       // app1[inter[i]] = ext2[i]
+  const uint16_t* deinter;     // app2[deinter[i]] = ext1[i]
+  const uint32_t* crc_rem;     // x^(nbits-1-nat(i)) mod g for array position i (0 beyond nbits); nullptr = no early stop
+};
+
+struct TdecArgs {
+  const int16_t* in;
+  uint32_t       in_stride;
+  int            sb_layout;
+  uint32_t       K, nof_cb, nof_iter;
+  int16_t*       work;         // per block: 7 arrays of Kp int16
+  uint32_t       Kp;
+  pk_t*          beta;         // per wave: (steps+1) * 64 dwords
+  uint32_t       beta_stride;  // dwords per wave
+  uint8_t*       out;
+  uint32_t       out_stride;
+  uint32_t*      iters;
+  uint8_t*       crc_ok;
+  TdecTables     t;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Windowed SISO (W = 16: packed pairs w = 2g+h; W = 8: w = g in the low half, high half idle)
+// ------------------------------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ pk_t ld_pair(const int16_t* a, int k, int g)
+{
+  if constexpr (W == 16) return reinterpret_cast<const pk_t*>(a)[k * 8 + g];
+  return (pk_t)(uint16_t)a[k * 8 + g];
+}
+
+template <int W>
+__device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
+                         const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
+                         pk_t* __restrict__ beta, int K)
+{
+  constexpr bool SAT = true;
+  const int      Lw  = K / W;
+  const pk_t     NEG = pk_make(-TD_INF, -TD_INF);
+  pk_t           v, to, tp;
+
+#define LOAD_XY(k)                                                     \
+  pk_t x = ld_pair<W>(in, (k), L.g), y = ld_pair<W>(par, (k), L.g);    \
+  if (app) x = pk_add<SAT>(ld_pair<W>(app, (k), L.g), x);              \
+  const pk_t xy = pk_add<SAT>(x, y);
+#define ACS(ph)                                                        \
+  switch (ph) {                                                        \
+    case 0: v = acs<0, SAT>(L, v, x, y, xy, &to, &tp); break;          \
+    case 1: v = acs<1, SAT>(L, v, x, y, xy, &to, &tp); break;          \
+    default: v = acs<2, SAT>(L, v, x, y, xy, &to, &tp); break;         \
+  }
+#define NORMALIZE(k) \
+  if (((k) & 1) == 0 && (k) != 0) v = pk_sub<SAT>(v, bcast_slot0(v)); /* turbodecoder_win.h:332-349 */
+
+  // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464)
+  v = NEG;
+  for (int k = WIN_OVERLAP - 1, ph = (WIN_OVERLAP - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
+    LOAD_XY(k);
+    ACS(ph);
+    NORMALIZE(k);
+  }
+  // ---- tail trellis for the last window: scalar, wrapping adds (turbodecoder_win.h:351-395)
+  int tail[8];
+  {
+    int o[8] = {0, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF};
+    for (int j = 2; j >= 0; j--) {
+      const int x = tail_in[j], y = tail_par[j], xy = (short)(x + y);
+#define WA(a, b) ((int)(short)((a) + (b)))
+      int m[8] = {WA(o[4], xy), o[4], WA(o[5], y), WA(o[5], x), WA(o[6], x), WA(o[6], y), o[7], WA(o[7], xy)};
+      int n[8] = {o[0], WA(o[0], xy), WA(o[1], x), WA(o[1], y), WA(o[2], y), WA(o[2], x), WA(o[3], xy), o[3]};
+#undef WA
+      for (int i = 0; i < 8; i++) o[i] = m[i] > n[i] ? m[i] : n[i];
+    }
+    for (int i = 0; i < 8; i++) tail[i] = o[i];
+  }
+  // ---- window shift: window w starts from the warm-up of window w+1, the last one from the tail (:428-448)
+  {
+    const int s    = rotr3(L.p, Lw % 3);                 // state this slot holds at time Lw
+    const pk_t a   = __shfl(v, lane_of(L.g, s), 64);       // same group
+    const pk_t b   = __shfl(v, lane_of((L.g + 1) & 7, s), 64);
+    int        ts  = tail[0];
+    for (int i = 1; i < 8; i++) ts = s == i ? tail[i] : ts;
+    if constexpr (W == 16) {
+      v = pk_make(pk_hi(a), L.g == 7 ? ts : pk_lo(b));
+    } else {
+      v = pk_make(L.g == 7 ? ts : pk_lo(b), 0);
+    }
+  }
+  beta[Lw * 64 + L.lane] = v;
+  // ---- beta main pass (:466-526): store after the max, before normalisation
+  for (int k = Lw - 1, ph = (Lw - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
+    LOAD_XY(k);
+    ACS(ph);
+    beta[k * 64 + L.lane] = v;
+    NORMALIZE(k);
+  }
+
+  // ---- alpha warm-up over the last 40 steps of every window (:586-603)
+  v = NEG;
+  for (int j = 0, k = Lw - WIN_OVERLAP, ph = (Lw - WIN_OVERLAP) % 3; j < WIN_OVERLAP; j++, k++, ph = ph == 2 ? 0 : ph + 1) {
+    LOAD_XY(k);
+    ACS(ph);
+    NORMALIZE(j);
+  }
+  // ---- window shift: window w starts from the end of window w-1, window 0 from the known state (:560-583)
+  {
+    const int  sp   = rotl3(L.p, Lw % 3);                 // slot that holds state p at time Lw
+    const pk_t a    = __shfl(v, lane_of(L.g, sp), 64);
+    const pk_t b    = __shfl(v, lane_of((L.g + 7) & 7, sp), 64);
+    const int  init = L.p == 0 ? 0 : -TD_INF;
+    if constexpr (W == 16) {
+      v = pk_make(L.g == 0 ? init : pk_hi(b), pk_lo(a));
+    } else {
+      v = pk_make(L.g == 0 ? init : pk_lo(b), 0);
+    }
+  }
+  // ---- alpha main pass with extrinsic output (:605-679)
+  __syncthreads(); // beta stores of this wave are visible to its loads
+  for (int k = 0, ph = 0; k < Lw; k++, ph = ph == 2 ? 0 : ph + 1) {
+    LOAD_XY(k);
+    const pk_t B = beta[(k + 1) * 64 + L.lane];
+    ACS(ph);
+    const bool b0 = ph == 0 ? L.p1 : (ph == 1 ? L.p2 : L.p0); // own transition carries info bit b0
+    pk_t       m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
+    pk_t       m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
+    pk_t       o  = pk_sub<SAT>(m1, m0);
+    if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
+    if (L.p == 0) {
+      if constexpr (W == 16) {
+        reinterpret_cast<pk_t*>(out)[k * 8 + L.g] = o;
+      } else {
+        out[k * 8 + L.g] = (int16_t)pk_lo(o);
+      }
+    }
+    NORMALIZE(k);
+  }
+#undef LOAD_XY
+#undef ACS
+#undef NORMALIZE
+}
+
+template <int W>
+__device__ __forceinline__ int win_pos(int n, int K)
+{ // natural index -> window-interleaved array position
+  const int Lw = K / W;
+  return (n % Lw) * W + n / Lw;
+}
+
+template <int W>
+__global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
+{
+  const int      cb = blockIdx.x, K = (int)a.K;
+  const LaneGeom L  = lane_geom();
+  const int16_t* in = a.in + (size_t)cb * a.in_stride;
+  int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
+  int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
+          *ext2 = wk + 6 * a.Kp;
+  pk_t* beta = a.beta + (size_t)cb * a.beta_stride;
+
+  // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91); tails live at [K..K+2]
+  const int tb = a.sb_layout ? 3 * (K + 32) : 3 * K;
+  if (a.sb_layout) {
+    for (int i = L.lane; i < K; i += 64) {
+      syst[i] = in[i];
+      par0[i] = in[K + 32 + i];
+      par1[i] = in[2 * (K + 32) + i];
+    }
+  } else {
+    for (int n = L.lane; n < K; n += 64) {
+      const int x = win_pos<W>(n, K);
+      syst[x]     = in[3 * n];
+      par0[x]     = in[3 * n + 1];
+      par1[x]     = in[3 * n + 2];
+    }
+  }
+  if (L.lane < 3) {
+    syst[K + L.lane] = in[tb + 2 * L.lane];
+    par0[K + L.lane] = in[tb + 2 * L.lane + 1];
+    app2[K + L.lane] = in[tb + 6 + 2 * L.lane];
+    par1[K + L.lane] = in[tb + 6 + 2 * L.lane + 1];
+  }
+  __syncthreads();
+
+  uint32_t       n_iter = 0;
+  bool           ok     = false;
+  const int16_t* dec    = ext1;
+  while (n_iter < a.nof_iter && !ok) {
+    if ((n_iter & 1) == 0) {
+      if (n_iter) {
+        for (int i = L.lane; i < K; i += 64) app1[i] = (int16_t)(app1[i] - ext1[i]); // srslte_vec_sub_sss, wrapping
+        __syncthreads();
+      }
+      win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, K);
+      dec = ext1;
+    } else {
+      if (n_iter > 1) {
+        for (int i = L.lane; i < K; i += 64) ext1[i] = (int16_t)(ext1[i] - app1[i]);
+        __syncthreads();
+      }
+      for (int i = L.lane; i < K; i += 64) app2[a.t.deinter[i]] = ext1[i]; // srslte_vec_lut_sss
+      __syncthreads();
+      win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, K);
+      __syncthreads();
+      for (int i = L.lane; i < K; i += 64) app1[a.t.inter[i]] = ext2[i];
+      dec = app1;
+    }
+    __syncthreads();
+    n_iter++;
+    if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
+      uint32_t syn = 0;
+      for (int i = L.lane; i < K; i += 64) syn ^= dec[i] > 0 ? a.t.crc_rem[i] : 0u;
+      for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
+      ok = syn == 0;
+    }
+  }
+  // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838)
+  uint8_t* o = a.out + (size_t)cb * a.out_stride;
+  for (int b = L.lane; b < K / 8; b += 64) {
+    uint32_t byte = 0;
+    for (int j = 0; j < 8; j++) byte |= (dec[win_pos<W>(8 * b + j, K)] > 0 ? 0x80u : 0u) >> j;
+    o[b] = (uint8_t)byte;
+  }
+  if (L.lane == 0) {
+    if (a.iters) a.iters[cb] = n_iter;
+    if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
+// ------------------------------------------------------------------------------------------------------------------
+__device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
+                         const int16_t* __restrict__ par, int16_t* __restrict__ out, pk_t* __restrict__ beta, int K, bool active)
+{
+  constexpr bool SAT = false;
+  pk_t           v, to, tp;
+  const int      end = K + 3;
+#define ACS(ph)                                                        \
+  switch (ph) {                                                        \
+    case 0: v = acs<0, SAT>(L, v, x, y, xy, &to, &tp); break;          \
+    case 1: v = acs<1, SAT>(L, v, x, y, xy, &to, &tp); break;          \
+    default: v = acs<2, SAT>(L, v, x, y, xy, &to, &tp); break;         \
+  }
+  // beta (:54-110): known end state after the 3 tail steps
+  v                        = pk_make(L.p == 0 ? 0 : -TD_INF, 0);
+  beta[end * 64 + L.lane] = v;
+  for (int k = end - 1, ph = (end - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
+    int xi = in[k];
+    if (app && k < K) xi += app[k];
+    const pk_t x = pk_make(xi, 0), y = pk_make(par[k], 0), xy = pk_add<SAT>(x, y);
+    ACS(ph);
+    beta[k * 64 + L.lane] = v;
+    if ((k & 3) == 0 && k < K) v = pk_sub<SAT>(v, bcast_slot0(v));
+  }
+  __syncthreads();
+  // alpha (:112-194)
+  v = pk_make(L.p == 0 ? 0 : -TD_INF, 0);
+  for (int k = 1, ph = 0; k < K + 1; k++, ph = ph == 2 ? 0 : ph + 1) {
+    int xi = in[k - 1];
+    if (app) xi += app[k - 1];
+    const pk_t x = pk_make(xi, 0), y = pk_make(par[k - 1], 0), xy = pk_add<SAT>(x, y);
+    const pk_t B = beta[k * 64 + L.lane];
+    ACS(ph);
+    const bool b0 = ph == 0 ? L.p1 : (ph == 1 ? L.p2 : L.p0);
+    pk_t       m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
+    pk_t       m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
+    if ((k & 3) == 0) v = pk_sub<SAT>(v, bcast_slot0(v));
+    if (L.p == 0 && active) out[k - 1] = (int16_t)pk_lo(pk_sub<SAT>(m1, m0));
+  }
+#undef ACS
+}
+
+__global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
+{
+  const LaneGeom L      = lane_geom();
+  const int      K      = (int)a.K;
+  const uint32_t cb_raw = blockIdx.x * 8 + L.g;
+  const bool     active = cb_raw < a.nof_cb;
+  const uint32_t cb     = active ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
+  const int16_t* in     = a.in + (size_t)cb * a.in_stride;
+  int16_t*       wk     = a.work + (size_t)cb * 7 * a.Kp;
+  int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
+          *ext2 = wk + 6 * a.Kp;
+  pk_t* beta = a.beta + (size_t)blockIdx.x * a.beta_stride;
+
+  // extraction (turbodecoder_gen.c:235-253): each group's 8 slots stride over their block
+  if (active) {
+    for (int n = L.p; n < K; n += 8) {
+      syst[n] = in[3 * n];
+      par0[n] = in[3 * n + 1];
+      par1[n] = in[3 * n + 2];
+    }
+    if (L.p < 3) {
+      syst[K + L.p] = in[3 * K + 2 * L.p];
+      par0[K + L.p] = in[3 * K + 2 * L.p + 1];
+      app2[K + L.p] = in[3 * K + 6 + 2 * L.p];
+      par1[K + L.p] = in[3 * K + 6 + 2 * L.p + 1];
+    }
+  }
+  __syncthreads();
+
+  // all 8 blocks of a wave run the same number of passes; a block whose CRC already passed keeps its result
+  uint32_t       my_iters = 0;
+  bool           ok       = false;
+  bool           use_app1 = false;
+  const uint32_t nbytes   = K / 8;
+  uint8_t*       o        = a.out + (size_t)cb * a.out_stride;
+  for (uint32_t n_iter = 0; n_iter < a.nof_iter; n_iter++) {
+    const bool run = active && !ok;
+    if ((n_iter & 1) == 0) {
+      if (n_iter && run) {
+        for (int i = L.p; i < K; i += 8) app1[i] = (int16_t)(app1[i] - ext1[i]);
+      }
+      __syncthreads();
+      gen_siso(L, syst, n_iter ? app1 : nullptr, par0, ext1, beta, K, run);
+      use_app1 = false;
+    } else {
+      if (run) {
+        if (n_iter > 1) {
+          for (int i = L.p; i < K; i += 8) ext1[i] = (int16_t)(ext1[i] - app1[i]);
+        }
+        __syncthreads();
+        for (int i = L.p; i < K; i += 8) app2[a.t.deinter[i]] = ext1[i];
+      } else {
+        __syncthreads();
+      }
+      __syncthreads();
+      gen_siso(L, app2, nullptr, par1, ext2, beta, K, run);
+      __syncthreads();
+      if (run) {
+        for (int i = L.p; i < K; i += 8) app1[a.t.inter[i]] = ext2[i];
+      }
+      use_app1 = true;
+    }
+    __syncthreads();
+    if (run) {
+      my_iters            = n_iter + 1;
+      const int16_t* dec  = use_app1 ? app1 : ext1;
+      uint32_t       syn  = 0;
+      for (uint32_t b = L.p; b < nbytes; b += 8) { // hard decision of this pass (turbodecoder_gen.c:255-273)
+        uint32_t byte = 0;
+        for (int j = 0; j < 8; j++) {
+          const bool bit = dec[8 * b + j] > 0;
+          byte |= (bit ? 0x80u : 0u) >> j;
+          if (a.t.crc_rem && bit) syn ^= a.t.crc_rem[8 * b + j];
+        }
+        o[b] = (uint8_t)byte;
+      }
+      if (a.t.crc_rem) {
+        syn ^= __builtin_amdgcn_update_dpp(syn, syn, 0xB1, 0xf, 0xf, false);
+        syn ^= __builtin_amdgcn_update_dpp(syn, syn, 0x4E, 0xf, 0xf, false);
+        syn ^= __builtin_amdgcn_update_dpp(syn, syn, 0x128, 0xf, 0xf, false);
+        ok = syn == 0;
+      }
+    }
+    if (__all(ok || !active)) break; // sch.c:383 per block; the wave leaves when every block has stopped
+  }
+  if (L.p == 0 && active) {
+    if (a.iters) a.iters[cb] = my_iters;
+    if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+struct TabKey {
+  uint32_t K, W, poly, nbits;
+  bool     operator<(const TabKey& o) const { return memcmp(this, &o, sizeof(*this)) < 0; }
+};
+struct TabDev {
+  uint16_t *inter, *deinter;
+  uint32_t* crc_rem;
+};
+
+} // namespace
+
+struct srslte_hip_tdec {
+  uint32_t                 max_long_cb, max_nof_cb, Kp;
+  int16_t*                 d_work;
+  pk_t*                    d_beta;
+  uint32_t                 beta_stride;
+  std::map<TabKey, TabDev> tabs;
+  std::mutex               mtx;
+};
+
+extern "C" uint32_t srslte_hip_tdec_autoimp_get_subblocks(uint32_t K)
+{ // turbodecoder.c:394-406 on an AVX2 host
+  if (!(K % 16) && K > 800) return 16;
+  if (!(K % 8) && K > 400) return 8;
+  return 0;
+}
+
+extern "C" uint32_t srslte_hip_tdec_input_len(uint32_t K, int sb_layout) { return sb_layout ? 3 * (K + 32) + 12 : 3 * K + 12; }
+
+extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint32_t max_nof_cb)
+{
+  if (max_long_cb < 40 || max_long_cb > 6144 || max_nof_cb == 0) {
+    fprintf(stderr, "[srslte_hip] tdec: invalid max_long_cb=%u / max_nof_cb=%u\n", max_long_cb, max_nof_cb);
+    return nullptr;
+  }
+  auto* q         = new srslte_hip_tdec();
+  q->max_long_cb  = max_long_cb;
+  q->max_nof_cb   = max_nof_cb;
+  q->Kp           = (max_long_cb + 16 + 31) & ~31u;
+  q->beta_stride  = (max_long_cb + 8) * 64; // generic: K+4 steps; windowed: K/8+1
+  q->d_work       = nullptr;
+  q->d_beta       = nullptr;
+  // windowed kernels need (K/W+1)*64 dwords per block; the generic one (K+4)*64 per 8 blocks: size for the worst
+  const size_t beta_words = (size_t)max_nof_cb * (max_long_cb / 8 + 2) * 64;
+  const size_t gen_words  = (size_t)((max_nof_cb + 7) / 8) * (max_long_cb + 8) * 64;
+  if (hipMalloc((void**)&q->d_work, (size_t)max_nof_cb * 7 * q->Kp * sizeof(int16_t)) != hipSuccess ||
+      hipMalloc((void**)&q->d_beta, sizeof(pk_t) * (beta_words > gen_words ? beta_words : gen_words)) != hipSuccess) {
+    fprintf(stderr, "[srslte_hip] tdec: device allocation failed\n");
+    if (q->d_work) (void)hipFree(q->d_work);
+    delete q;
+    return nullptr;
+  }
+  return q;
+}
+
+extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
+{
+  if (!q) return;
+  for (auto& kv : q->tabs) {
+    (void)hipFree(kv.second.inter);
+    (void)hipFree(kv.second.deinter);
+    if (kv.second.crc_rem) (void)hipFree(kv.second.crc_rem);
+  }
+  (void)hipFree(q->d_work);
+  (void)hipFree(q->d_beta);
+  delete q;
+}
+
+static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_t poly, uint32_t nbits, TdecTables* t)
+{
+  std::lock_guard<std::mutex> lk(q->mtx);
+  TabKey key;
+  memset(&key, 0, sizeof(key));
+  key.K = K; key.W = W; key.poly = poly; key.nbits = poly ? nbits : 0;
+  auto it = q->tabs.find(key);
+  if (it == q->tabs.end()) {
+    std::vector<uint16_t> f, r;
+    lte_qpp_tables(K, W, f, r);
+    TabDev d = {nullptr, nullptr, nullptr};
+    HIP_TRY(hipMalloc((void**)&d.inter, K * 2));
+    HIP_TRY(hipMalloc((void**)&d.deinter, K * 2));
+    HIP_TRY(hipMemcpy(d.inter, f.data(), K * 2, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d.deinter, r.data(), K * 2, hipMemcpyHostToDevice));
+    if (poly) {
+      // rem[j] = x^(nbits-1-j) mod g (24-bit CRC, crc.c:33-47 polynomial convention with the x^24 term included)
+      std::vector<uint32_t> nat(K, 0), pos(K, 0);
+      uint32_t              v = 1;
+      for (int j = (int)nbits - 1; j >= 0; j--) {
+        nat[j] = v;
+        v <<= 1;
+        if (v & 0x1000000) v ^= poly;
+      }
+      for (uint32_t n = 0; n < K; n++) pos[W ? (n % (K / W)) * W + n / (K / W) : n] = nat[n];
+      HIP_TRY(hipMalloc((void**)&d.crc_rem, K * 4));
+      HIP_TRY(hipMemcpy(d.crc_rem, pos.data(), K * 4, hipMemcpyHostToDevice));
+    }
+    it = q->tabs.emplace(key, d).first;
+  }
+  t->inter   = it->second.inter;
+  t->deinter = it->second.deinter;
+  t->crc_rem = it->second.crc_rem;
+  return SRSLTE_SUCCESS;
+}
+
+int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
+                     uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
+                     uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st)
+{
+  if (!q || !d_input || !d_output) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (K > q->max_long_cb) {
+    fprintf(stderr, "[srslte_hip] TDEC was initialized for max_long_cb=%u\n", q->max_long_cb); // turbodecoder.c:524-527
+    return SRSLTE_ERROR;
+  }
+  const int idx = lte_cb_index(K);
+  if (idx < 0 || lte_qpp_table[idx].K != K) {
+    fprintf(stderr, "[srslte_hip] Invalid CB length %u\n", K); // turbodecoder.c:531-534
+    return SRSLTE_ERROR;
+  }
+  if (nof_cb > q->max_nof_cb || nof_iterations == 0 || out_stride < K / 8 || in_stride < srslte_hip_tdec_input_len(K, sb_layout) ||
+      (crc_poly && (crc_nbits > K || (crc_poly >> 24) != 1)))
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_cb == 0) return SRSLTE_SUCCESS;
+  const uint32_t W = force_w >= 0 ? (uint32_t)force_w : srslte_hip_tdec_autoimp_get_subblocks(K);
+  if ((W != 0 && W != 8 && W != 16) || (W && (K % W || K / W < WIN_OVERLAP)) || (sb_layout && !W)) return SRSLTE_ERROR_INVALID_INPUTS;
+  TdecArgs a;
+  a.in = d_input; a.in_stride = in_stride; a.sb_layout = sb_layout; a.K = K; a.nof_cb = nof_cb; a.nof_iter = nof_iterations;
+  a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta;
+  a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
+  int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
+  if (r) return r;
+  if (W == 16) {
+    a.beta_stride = (K / 16 + 1) * 64;
+    hipLaunchKernelGGL(tdec_win_kernel<16>, dim3(nof_cb), dim3(64), 0, st, a);
+  } else if (W == 8) {
+    a.beta_stride = (K / 8 + 1) * 64;
+    hipLaunchKernelGGL(tdec_win_kernel<8>, dim3(nof_cb), dim3(64), 0, st, a);
+  } else {
+    a.beta_stride = (K + 4) * 64;
+    hipLaunchKernelGGL(tdec_gen_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a);
+  }
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" int srslte_hip_tdec_run_batch(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
+                                         uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits,
+                                         uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream)
+{
+  return tdec_run_batch_w(q, d_input, in_stride, sb_layout, long_cb, -1, nof_cb, nof_iterations, crc_poly, crc_nbits, d_output, out_stride,
+                          d_iters, d_crc_ok, (hipStream_t)stream);
+}
+
+// srslte_tdec_init_manual equivalent (turbodecoder.c:168-215): force the numerics, W = 0 generic / 8 sse16 / 16 avx16
+extern "C" int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout,
+                                                uint32_t long_cb, uint32_t nof_subblocks, uint32_t nof_cb, uint32_t nof_iterations,
+                                                uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output, uint32_t out_stride,
+                                                uint32_t* d_iters, uint8_t* d_crc_ok, void* stream)
+{
+  return tdec_run_batch_w(q, d_input, in_stride, sb_layout, long_cb, (int)nof_subblocks, nof_cb, nof_iterations, crc_poly, crc_nbits,
+                          d_output, out_stride, d_iters, d_crc_ok, (hipStream_t)stream);
+}

@@ -1,0 +1,339 @@
+"""Parity of the HIP path (through the C ABI of libsrslte_phy_hip.so) against the oracle on seeded inputs.
+
+Bars (BASELINE.json north_star / SURVEY §8d): hard bits, decoded blocks, iteration counts, encoder output and integer
+LLRs fed identical symbols: bit-exact. Float arrays: |a-b| <= 1e-4 * max(|b|, rms(b)) per element.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+
+from _libs import OrcCell, OrcChestCfg, OrcChestRes, OrcOfdm, acopy, oracle, p
+from lte_sim import DlConfig, make_subframe, oracle_rx
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return importlib.import_module("srslte-emane_amd")
+
+
+def assert_close_c(a, b, what, tol=TOL):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    ref = max(np.abs(b).max(), np.sqrt((np.abs(b) ** 2).mean()))
+    err = np.abs(a - b).max()
+    assert err <= tol * ref, "%s: max err %.3e vs %.3e allowed" % (what, err, tol * ref)
+
+
+# ---------------------------------------------------------------- DFT / OFDM
+DFT_SIZES = [128, 256, 384, 512, 768, 1024, 1536, 2048] + [12 * n for n in (1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 27,
+                                                                           30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100)]
+
+
+@pytest.mark.parametrize("N", DFT_SIZES)
+def test_dft_sizes(hp, N):
+    rng = np.random.default_rng(N)
+    x = (rng.standard_normal((3, N)) + 1j * rng.standard_normal((3, N))).astype(np.complex64)
+    for fwd in (True, False):
+        y = hp.dft(x, forward=fwd)
+        ref = np.zeros_like(x)
+        for i in range(3):
+            oracle().orc_dft_exact(p(x[i]), p(ref[i]), N, 1 if fwd else 0)
+        assert_close_c(y, ref, "dft N=%d fwd=%s" % (N, fwd))
+
+
+@pytest.mark.parametrize("prb", [6, 15, 25, 50, 75, 100])
+@pytest.mark.parametrize("norm,shift", [(False, 0.0), (True, 0.0), (True, 0.5), (False, -0.5)])
+def test_ofdm_rx_tx(hp, prb, norm, shift):
+    rng = np.random.default_rng(prb)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    q.normalize, q.exact = norm, prb <= 25
+    if shift:
+        q.freq_shift, q.freq_shift_f = True, shift
+    nsf = 3
+    grid = (rng.standard_normal((nsf, 14 * 12 * prb)) + 1j * rng.standard_normal((nsf, 14 * 12 * prb))).astype(np.complex64)
+    tx = hp.Ofdm(prb, True, rx=False)
+    rx = hp.Ofdm(prb, True, rx=True)
+    for o in (tx, rx):
+        o.set_normalize(norm)
+        if shift:
+            o.set_freq_shift(shift)
+    t_gpu = tx.tx_sf(grid)
+    t_ref = np.zeros((nsf, q.sf_sz), np.complex64)
+    for i in range(nsf):
+        oracle().orc_ofdm_tx_sf(C.byref(q), p(grid[i]), p(t_ref[i]))
+    assert_close_c(t_gpu, t_ref, "ofdm_tx prb=%d" % prb)
+    time_in = (rng.standard_normal((nsf, q.sf_sz)) + 1j * rng.standard_normal((nsf, q.sf_sz))).astype(np.complex64)
+    g_gpu = rx.rx_sf(time_in)
+    g_ref = np.zeros((nsf, 14 * 12 * prb), np.complex64)
+    for i in range(nsf):
+        oracle().orc_ofdm_rx_sf(C.byref(q), p(time_in[i]), p(g_ref[i]))
+    assert_close_c(g_gpu, g_ref, "ofdm_rx prb=%d" % prb)
+    if not shift:  # ofdm_test.c:74-179 round trip, MSE bound 0.07 upstream (normalised) - ours must be ~0
+        back = rx.rx_sf(tx.tx_sf(grid))
+        scale = 1.0 if norm else float(q.symbol_sz)
+        assert np.mean(np.abs(back / scale - grid) ** 2) < 1e-9
+    tx.free()
+    rx.free()
+
+
+def test_dft_precoding_invalid(hp):
+    rc, _ = hp.dft_precoding(np.zeros(12 * 7, np.complex64), 7, 1)
+    assert rc == hp.SRSLTE_ERROR  # dft_precoding.c:104-107
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 5, 25, 50, 100])
+def test_dft_precoding(hp, L):
+    rng = np.random.default_rng(L)
+    x = (rng.standard_normal((12, 12 * L)) + 1j * rng.standard_normal((12, 12 * L))).astype(np.complex64)
+    for fwd in (True, False):
+        rc, y = hp.dft_precoding(x, L, 12, forward=fwd)
+        assert rc == 0
+        ref = np.zeros_like(x)
+        assert oracle().orc_dft_precoding(p(x), p(ref), L, 12, 1 if fwd else 0, True) == 0
+        assert_close_c(y, ref, "precoding L=%d" % L)
+
+
+# ---------------------------------------------------------------- demapper
+@pytest.mark.parametrize("mod", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("nsym", [1, 3, 4, 7, 8, 15, 33, 14580])
+def test_demod_soft(hp, mod, nsym):
+    rng = np.random.default_rng(100 * mod + nsym)
+    qm = 1 if mod == 0 else 2 * mod
+    ncalls = 3
+    for scale in (1.0, 40.0):
+        s = ((rng.standard_normal((ncalls, nsym)) + 1j * rng.standard_normal((ncalls, nsym))) * scale).astype(np.complex64)
+        for kind, dt in (("f", np.float32), ("s", np.int16), ("b", np.int8)):
+            rc, llr = hp.demod_soft_demodulate(mod, s, kind, ncalls)
+            assert rc == 0
+            ref = np.zeros((ncalls, nsym * qm), dt)
+            for c in range(ncalls):
+                getattr(oracle(), "orc_demod_soft_" + kind)(mod, p(acopy(s[c].view(np.float32))), p(ref[c]), nsym)
+            if kind == "f":
+                assert_close_c(llr, ref, "demod f mod=%d" % mod, 1e-6)
+            else:
+                assert np.array_equal(llr, ref), "demod %s mod=%d nsym=%d: %d mismatches" % (kind, mod, nsym, (llr != ref).sum())
+
+
+def test_demod_invalid_mod(hp):
+    rc, _ = hp.demod_soft_demodulate(7, np.zeros(4, np.complex64), "s")
+    assert rc == hp.SRSLTE_ERROR  # demod_soft.c:496-498
+
+
+# ---------------------------------------------------------------- channel estimator
+def _chest_case(prb, cid, sf_idx, rng, snr_db=20):
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)  # as chest_test_dl.c:157-161, smoother
+    sig = 10 ** (-snr_db / 20)
+    return cell, (g * h + sig * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+
+
+CHEST_CFGS = [{}, {"filter_coef": (4.0, 1.0)}, {"interpolate_subframe": True, "filter_coef": (4.0, 2.0), "cfo_estimate_enable": True},
+              {"interpolate_subframe": True, "filter_type": 2}, {"filter_type": 1, "filter_coef": (0.1, 0.0)}, {"filter_type": 2}]
+
+
+@pytest.mark.parametrize("prb,cid", [(6, 1), (6, 0), (25, 2), (50, 3), (100, 1), (100, 4), (100, 5), (15, 150)])
+@pytest.mark.parametrize("ci", range(len(CHEST_CFGS)))
+def test_chest_dl(hp, prb, cid, ci):
+    rng = np.random.default_rng(prb * 1000 + cid)
+    tti0, nsf = 8, 4  # covers sf 8, 9, 0, 1
+    grids, cells = [], None
+    for b in range(nsf):
+        cells, g = _chest_case(prb, cid, (tti0 + b) % 10, rng)
+        grids.append(g)
+    hc, oc = hp.ChestDlCfg(), OrcChestCfg()
+    for k, v in CHEST_CFGS[ci].items():
+        if k == "filter_coef":
+            hc.filter_coef[0], hc.filter_coef[1] = v
+            oc.filter_coef[0], oc.filter_coef[1] = v
+        else:
+            setattr(hc, k, 1 if v is True else v)
+            setattr(oc, k, v)
+    est = hp.ChestDl(cid, prb)
+    ce, res = est.estimate(np.stack(grids), tti0, hc)
+    for b in range(nsf):
+        ref, rres = np.zeros(14 * 12 * prb, np.complex64), OrcChestRes()
+        assert oracle().orc_chest_dl(C.byref(cells), (tti0 + b) % 10, C.byref(oc), p(grids[b]), p(ref), C.byref(rres)) == 0
+        assert_close_c(ce[b], ref, "ce prb=%d sf=%d cfg=%d" % (prb, b, ci))
+        for name in ("noise_estimate", "rsrp", "rsrq", "cfo"):
+            a, r = float(res[name][b]), float(getattr(rres, name))
+            assert abs(a - r) <= 1e-4 * abs(r) + 1e-9, (name, a, r)
+        for name in ("noise_estimate_dbm", "snr_db", "rsrp_dbm", "rsrq_db", "rssi_dbm"):
+            assert abs(float(res[name][b]) - float(getattr(rres, name))) <= 1e-3, name
+    est.free()
+
+
+# ---------------------------------------------------------------- turbo
+def _noisy_llr(rng, enc_bits, snr_db, scale=100):
+    tx = 2.0 * enc_bits.astype(np.float64) - 1.0
+    return (scale * (tx + 10 ** (-snr_db / 20) * rng.standard_normal(tx.shape))).clip(-32000, 32000).astype(np.int16)
+
+
+@pytest.mark.parametrize("K", [40, 176, 400, 408, 504, 800, 816, 1008, 2048, 5824, 6144])
+def test_tcod_encode(hp, K):
+    rng = np.random.default_rng(K)
+    bits = rng.integers(0, 2, (5, K)).astype(np.uint8)
+    rc, out = hp.tcod_encode(bits, K)
+    assert rc == 0
+    for i in range(5):
+        ref = np.zeros(3 * K + 12, np.uint8)
+        assert oracle().orc_tcod_encode_bits(p(bits[i]), p(ref), K) == 0
+        assert np.array_equal(out[i], ref), "tcod K=%d block %d" % (K, i)
+
+
+def test_tcod_invalid_len(hp):
+    rc, _ = hp.tcod_encode(np.zeros(41, np.uint8), 41)
+    assert rc == hp.SRSLTE_ERROR  # turbocoder.c:89-93
+
+
+@pytest.mark.parametrize("K", [40, 176, 400, 408, 504, 800, 816, 1008, 2048, 5824, 6144])
+def test_tdec_run_all(hp, K):
+    """srslte_tdec_run_all on [s p0 p1] input (force_not_sb), as turbodecoder_test.c:117-311."""
+    rng = np.random.default_rng(K)
+    ncb = 9
+    dec = hp.Tdec(6144, 16)
+    bits = rng.integers(0, 2, (ncb, K)).astype(np.uint8)
+    enc = np.zeros((ncb, 3 * K + 12), np.uint8)
+    for i in range(ncb):
+        oracle().orc_tcod_encode_bits(p(bits[i]), p(enc[i]), K)
+    for snr, scale in ((0.0, 100), (2.0, 100), (1.0, 400), (-3.0, 2000)):
+        llr = _noisy_llr(rng, enc, snr, scale)
+        for nit in (1, 2, 3, 6):
+            rc, out, _, _ = dec.run_all(llr, K, nit)
+            assert rc == 0
+            for i in range(ncb):
+                ref = np.zeros(K // 8, np.uint8)
+                assert oracle().orc_tdec_run(p(llr[i]), False, K, nit, p(ref), None) == 0
+                assert np.array_equal(out[i], ref), "tdec K=%d snr=%s nit=%d cb=%d: %d byte mismatches" % (K, snr, nit, i, (out[i] != ref).sum())
+    dec.free()
+
+
+@pytest.mark.parametrize("K,W", [(504, 0), (504, 16), (1008, 8), (1008, 0), (6144, 8)])
+def test_tdec_manual_numerics(hp, K, W):
+    """srslte_tdec_init_manual: force generic / sse16 / avx16 numerics on any K (turbodecoder.c:168-215)."""
+    if W == 16 and (K % 16 or K // 16 < 40):
+        pytest.skip("window shorter than the 40-step overlap")
+    rng = np.random.default_rng(K + W)
+    dec = hp.Tdec(6144, 8)
+    bits = rng.integers(0, 2, (3, K)).astype(np.uint8)
+    enc = np.zeros((3, 3 * K + 12), np.uint8)
+    for i in range(3):
+        oracle().orc_tcod_encode_bits(p(bits[i]), p(enc[i]), K)
+    llr = _noisy_llr(rng, enc, 1.0, 300)
+    for nit in (1, 4):
+        rc, out, _, _ = dec.run_all(llr, K, nit, force_subblocks=W)
+        assert rc == 0
+        for i in range(3):
+            ref = np.zeros(K // 8, np.uint8)
+            assert oracle().orc_tdec_run_w(p(llr[i]), False, K, W, nit, p(ref), None) == 0
+            assert np.array_equal(out[i], ref)
+    dec.free()
+
+
+@pytest.mark.parametrize("K", [408, 816, 5824, 6144])
+def test_tdec_sb_layout_and_early_stop(hp, K):
+    """rm_turbo SB-layout input + CRC early stop as sch.c:348-383 (CB CRC24B over K bits)."""
+    rng = np.random.default_rng(K + 1)
+    ncb, W = 6, oracle().orc_tdec_autoimp_subblocks(K)
+    dec = hp.Tdec(6144, 8)
+    n_e = (3 * K * 9 // 10) // 6 * 6
+    stride = 3 * (K + 32) + 12
+    w = np.zeros((ncb, stride), np.int16)
+    for i in range(ncb):
+        payload = rng.integers(0, 256, (K - 24) // 8, dtype=np.uint8)
+        crc = oracle().orc_crc_bytes(0x1800063, 24, p(payload), K - 24)
+        cb = np.concatenate([payload, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)])
+        bits = np.unpackbits(cb)
+        enc = np.zeros(3 * K + 12, np.uint8)
+        oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+        e = np.zeros(n_e, np.uint8)
+        oracle().orc_rm_turbo_tx_bits(p(enc), p(e), n_e, K, 0)
+        snr = [8.0, 3.0, 1.5, 1.0, 0.5, -2.0][i]
+        llr = _noisy_llr(rng, e, snr, 100)
+        oracle().orc_rm_turbo_rx(p(llr), p(w[i]), n_e, K, 0, W)
+    rc, out, iters, ok = dec.run_all(w, K, 6, sb_layout=True, crc_poly=hp.CRC24B, crc_nbits=K)
+    assert rc == 0
+    for i in range(ncb):
+        per = np.zeros((6, K // 8), np.uint8)
+        ref = np.zeros(K // 8, np.uint8)
+        assert oracle().orc_tdec_run(p(w[i]), True, K, 6, p(ref), p(per)) == 0
+        n = 0
+        good = False
+        while n < 6 and not good:
+            good = oracle().orc_crc_bytes(0x1800063, 24, p(per[n]), K) == 0
+            n += 1
+        assert iters[i] == n and bool(ok[i]) == good, (K, i, iters[i], n, ok[i], good)
+        assert np.array_equal(out[i], per[n - 1])
+    assert ok[0] == 1 and ok[-1] == 0  # the sweep must exercise both outcomes
+    dec.free()
+
+
+def test_tdec_errors(hp):
+    dec = hp.Tdec(1024, 4)
+    rc, *_ = dec.run_all(np.zeros((1, 3 * 2048 + 12), np.int16), 2048, 1)
+    assert rc == hp.SRSLTE_ERROR  # turbodecoder.c:524-527: exceeds max_long_cb
+    rc, *_ = dec.run_all(np.zeros((1, 3 * 41 + 12), np.int16), 41, 1)
+    assert rc == hp.SRSLTE_ERROR  # turbodecoder.c:531-534: invalid CB length
+    dec.free()
+
+
+def test_cbsegm_and_interleaver(hp):
+    for tbs in (16, 152, 936, 6120, 6144, 6200, 75376, 97896):
+        rc, s = hp.cbsegm(tbs)
+        from _libs import OrcCbsegm
+        r = OrcCbsegm()
+        assert oracle().orc_cbsegm(C.byref(r), tbs) == rc == 0
+        assert all(getattr(s, f) == getattr(r, f) for f, _ in OrcCbsegm._fields_)
+    for K, W in ((40, 1), (504, 8), (5824, 16), (6144, 16), (6144, 1)):
+        rc, f, r = hp.tc_interl(K, W)
+        rf, rr = np.zeros(K, np.uint16), np.zeros(K, np.uint16)
+        assert oracle().orc_qpp(K, W, p(rf), p(rr)) == rc == 0
+        assert np.array_equal(f, rf) and np.array_equal(r, rr)
+    assert hp.tc_interl(41, 1)[0] == hp.SRSLTE_ERROR
+
+
+# ---------------------------------------------------------------- end to end
+@pytest.mark.parametrize("prb,mod,tbs,snr,tti0,nsf", [(6, 1, 936, 12.0, 1, 4), (6, 1, 936, 2.5, 1, 4), (100, 3, 75376, 30.0, 8, 4),
+                                                       (100, 3, 75376, 19.0, 9, 3), (100, 4, 97896, 35.0, 4, 3)])
+def test_dl_rx_chain(hp, prb, mod, tbs, snr, tti0, nsf):
+    """IQ -> TB on the device vs the oracle chain on identical IQ: TB bytes, CRC flags and per-CB iteration counts equal."""
+    rng = np.random.default_rng(prb + mod + int(snr * 10))
+    cfg = DlConfig(prb, 1, mod, tbs)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.05 / np.sqrt(prb) * 20) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    grid = rx.debug(0, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    ce = rx.debug(1, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int16, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    n_diff = n_tot = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        assert nre == len(r["d"])
+        assert_close_c(grid[b], r["grid"], "grid sf %d" % b)
+        assert_close_c(ce[b], r["ce"], "ce sf %d" % b)
+        e = e_all[b, :nre * cfg.Qm].astype(np.int32)
+        diff = np.abs(e - r["e"].astype(np.int32))
+        assert diff.max() <= 1, "LLR differs by more than 1 LSB (sf %d: %d)" % (b, diff.max())
+        n_diff += int((diff != 0).sum())
+        n_tot += diff.size
+        assert bool(ok[b]) == r["ok"], "tb_ok sf %d" % b
+        assert np.array_equal(it[b], r["iters"]), "iterations sf %d: %s vs %s" % (b, it[b], r["iters"])
+        assert np.array_equal(tb[b], r["tb"]), "TB bytes sf %d" % b
+        if r["ok"]:
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_diff <= 1e-3 * n_tot, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
+    rx.free()
