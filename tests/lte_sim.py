@@ -109,3 +109,96 @@ def oracle_rx(cfg, iq, tti, keep=False):
     if keep:
         out.update(grid=grid, ce=ce, noise=res.noise_estimate, d=d, e=e, res=res)
     return out
+
+
+class RefRx:
+    """UE receive chain on the REFERENCE's own compiled code (oracle/_ref/libsrslte_ref.so) for every stage it holds:
+    srslte_chest_dl_estimate_cfg, srslte_predecoding_single, srslte_demod_soft_demodulate_s, srslte_rm_turbo_rx_lut,
+    srslte_tdec_new_cb/_iteration and srslte_crc_checksum_byte, driven as pdsch.c:833-997 / sch.c:299-500 drive them.
+    The FFT is the oracle's (FFTW is absent from this image), RE extraction and descrambling are numpy one-liners.
+    Used as bench.py's cpu_baseline (kind "reference") and to pin the oracle chain in tests."""
+
+    def __init__(self, cfg):
+        from _libs import RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, aligned, opaque, ref
+        self.R = ref()
+        assert self.R is not None, "oracle/_ref/libsrslte_ref.so is not built"
+        self.cfg = cfg
+        self.aligned = aligned
+        self.chest = opaque(1 << 20)
+        assert self.R.srslte_chest_dl_init(self.chest, cfg.nof_prb, 1) == 0
+        assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
+        self.rc = RefChestCfg()
+        for k, v in cfg.chest.items():
+            if k == "filter_coef":
+                self.rc.filter_coef[0], self.rc.filter_coef[1] = v
+            else:
+                setattr(self.rc, k, v)
+        self.res, self.sf = RefChestRes(), RefDlSfCfg()
+        self.ce = aligned(2 * cfg.grid_len, np.float32)
+        self.res.ce[0][0] = self.ce.ctypes.data
+        self.tdec = opaque(1 << 20)
+        assert self.R.srslte_tdec_init(self.tdec, 6144) == 0
+        self.crc_tb, self.crc_cb = opaque(4096), opaque(4096)
+        self.R.srslte_crc_init(self.crc_tb, 0x1864CFB, 24)
+        self.R.srslte_crc_init(self.crc_cb, 0x1800063, 24)
+        self.R.srslte_crc_checksum_byte.restype = C.c_uint32
+        self.R.srslte_cbsegm_cbindex.restype = C.c_int
+        self.q = OrcOfdm()
+        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, True)
+        self.idx = {s: cfg.indices(s) for s in range(10)}
+        self.scr = {}
+
+    def run(self, iq, tti):
+        cfg, R, orc = self.cfg, self.R, oracle()
+        sf_idx = tti % 10
+        grid = self.aligned(2 * cfg.grid_len, np.float32)
+        orc.orc_ofdm_rx_sf(C.byref(self.q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
+        self.sf.tti = sf_idx
+        inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+        assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
+        idx = self.idx[sf_idx]
+        n = len(idx)
+        y, h, d = self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32)
+        y.view(np.complex64)[:] = grid.view(np.complex64)[idx]
+        h.view(np.complex64)[:] = self.ce.view(np.complex64)[idx]
+        R.srslte_predecoding_single(p(y), p(h), p(d), None, n, 1.0, self.res.noise_estimate)
+        nbits = n * cfg.Qm
+        e = self.aligned(nbits + 64, np.int16)
+        R.srslte_demod_soft_demodulate_s(cfg.mod, p(d), p(e), n)
+        if (sf_idx, nbits) not in self.scr:
+            self.scr[(sf_idx, nbits)] = scramble_seq(cfg, sf_idx, nbits).astype(bool)
+        ev = e[:nbits]
+        ev[self.scr[(sf_idx, nbits)]] *= -1
+        s = cfg.seg
+        tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
+        iters, all_ok = np.zeros(s.C, np.uint32), True
+        Gp = nbits // cfg.Qm
+        gamma, n_e = Gp % s.C, cfg.Qm * (Gp // s.C)
+        for cb in range(s.C):
+            K = s.K1 if cb < s.C1 else s.K2
+            rlen = K if s.C == 1 else K - 24
+            rp, n_e2 = cb * n_e, n_e
+            if cb > s.C - gamma:
+                n_e2 = n_e + cfg.Qm
+                rp = (s.C - gamma) * n_e + (cb - (s.C - gamma)) * n_e2
+            w = self.aligned(3 * (K + 32) + 12 + 64, np.int16)
+            ein = self.aligned(n_e2 + 64, np.int16)
+            ein[:n_e2] = e[rp:rp + n_e2]
+            assert R.srslte_rm_turbo_rx_lut(p(ein), p(w), n_e2, R.srslte_cbsegm_cbindex(K), 0) == 0
+            assert R.srslte_tdec_new_cb(self.tdec, K) == 0
+            out = tb[cb * rlen // 8:]
+            ok, noi = False, 0
+            while noi < cfg.max_iter and not ok:
+                R.srslte_tdec_iteration(self.tdec, p(w), p(out))
+                noi += 1
+                if s.C > 1:
+                    ok = R.srslte_crc_checksum_byte(self.crc_cb, p(out), K) == 0
+                else:
+                    ok = R.srslte_crc_checksum_byte(self.crc_tb, p(out), cfg.tbs + 24) == 0
+            iters[cb] = noi
+            all_ok = all_ok and ok
+        if all_ok:
+            par_rx = R.srslte_crc_checksum_byte(self.crc_tb, p(tb), cfg.tbs)
+            par_tx = (int(tb[cfg.tbs // 8]) << 16) | (int(tb[cfg.tbs // 8 + 1]) << 8) | int(tb[cfg.tbs // 8 + 2])
+            all_ok = par_rx == par_tx and par_rx != 0
+        return {"tb": tb[:cfg.tbs // 8 + 3], "ok": all_ok, "iters": iters}

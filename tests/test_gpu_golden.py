@@ -1,0 +1,94 @@
+"""HIP path against the committed golden vectors (reference outputs, tests/gen_golden.py)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return importlib.import_module("srslte-emane_amd")
+
+
+def load(name):
+    return np.load(os.path.join(G, name))
+
+
+def test_tcod_golden(hp):
+    g = load("tcod.npz")
+    for K in (40, 176, 504, 1008, 5824, 6144):
+        rc, out = hp.tcod_encode(g["in_%d" % K], K)
+        assert rc == 0 and np.array_equal(out[0], g["out_%d" % K])
+
+
+def test_tdec_golden(hp):
+    g = load("tdec.npz")
+    dec = hp.Tdec(6144, 4)
+    for K in (40, 176, 504, 1008, 5824, 6144):
+        for nit in range(1, 7):
+            rc, out, _, _ = dec.run_all(g["llr_%d" % K], K, nit)
+            assert rc == 0 and np.array_equal(out[0], g["hard_%d" % K][nit - 1]), (K, nit)
+    for K in (816, 5824):
+        w = g["sb_w_%d" % K][:3 * (K + 32) + 12]
+        for nit in range(1, 7):
+            rc, out, _, _ = dec.run_all(w, K, nit, sb_layout=True)
+            assert rc == 0 and np.array_equal(out[0], g["sb_hard_%d" % K][nit - 1]), (K, nit)
+    kat = load("tcod.npz")
+    llr = (100 * (2 * kat["kat_out"].astype(np.int16) - 1)).astype(np.int16)
+    rc, out, _, _ = dec.run_all(llr, 504, 2)
+    assert np.array_equal(np.unpackbits(out[0]), kat["kat_in"])
+    dec.free()
+
+
+def test_demod_golden(hp):
+    g = load("demod.npz")
+    for mod in range(5):
+        x = g["sym_%d" % mod].view(np.complex64)
+        for kind, name in (("f", "llr"), ("s", "llr_s"), ("b", "llr_b")):
+            rc, llr = hp.demod_soft_demodulate(mod, x, kind)
+            ref = g["%s_%d" % (name, mod)]
+            if kind == "f":
+                assert np.abs(llr[0] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+            else:
+                assert np.array_equal(llr[0], ref), (mod, kind)
+
+
+def test_chest_golden(hp):
+    g = load("chest.npz")
+    for tag in ("6_0", "6_1", "25_0", "25_1"):
+        prb, cid, sf_idx, ci = [int(v) for v in g["meta_" + tag]]
+        cfg = hp.ChestDlCfg()
+        if ci == 0:
+            cfg.filter_coef[0], cfg.filter_coef[1] = 4.0, 1.0
+        else:
+            cfg.interpolate_subframe, cfg.cfo_estimate_enable = 1, 1
+            cfg.filter_coef[0], cfg.filter_coef[1] = 4.0, 2.0
+        est = hp.ChestDl(cid, prb)
+        ce, res = est.estimate(g["grid_%d" % prb].view(np.complex64), sf_idx, cfg)
+        ref = g["ce_" + tag].view(np.complex64)
+        assert np.abs(ce[0] - ref).max() <= 1e-4 * max(np.abs(ref).max(), np.sqrt((np.abs(ref) ** 2).mean()))
+        names = ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo")
+        scal = np.array([res[n][0] for n in names])
+        assert np.all(np.abs(scal - g["scal_" + tag]) <= 1e-4 * np.abs(g["scal_" + tag]) + 1e-3)
+        est.free()
+
+
+def test_dl_chain_golden(hp):
+    g = load("dl_chain.npz")
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    for tag, prb, mod, tbs, ttis in (("cfg1", 6, 1, 936, (1, 2, 3)), ("cfg2", 100, 3, 75376, (0,))):
+        rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, len(ttis), True, hc)
+        iq = np.stack([g["%s_iq_%d" % (tag, t)] for t in ttis])
+        tb, ok = rx.decode(iq, ttis[0])
+        C_ = 1 if prb == 6 else 13
+        it = rx.debug(6, np.uint32, len(ttis) * C_).reshape(len(ttis), C_)
+        for i, t in enumerate(ttis):
+            assert bool(ok[i]) == bool(g["%s_ok_%d" % (tag, t)][0])
+            assert np.array_equal(it[i], g["%s_iters_%d" % (tag, t)])
+            assert np.array_equal(tb[i], g["%s_tb_%d" % (tag, t)])
+        rx.free()

@@ -1,0 +1,190 @@
+"""Oracle vs the reference's own compiled code (oracle/_ref/libsrslte_ref.so) on seeded random inputs.
+Skipped where the reference build is absent (it only exists where /root/reference was available to `make -C oracle ref`)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _libs import (OrcCell, OrcChestCfg, OrcChestRes, RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, acopy, aligned, opaque, oracle, p, ref)
+from lte_sim import DlConfig, RefRx, make_subframe, oracle_rx
+
+pytestmark = pytest.mark.skipif(ref() is None, reason="oracle/_ref/libsrslte_ref.so not built")
+ALL_K = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))
+
+
+def test_cbsegm_all_tbs_sample():
+    from _libs import OrcCbsegm
+    R = ref()
+    for tbs in list(range(16, 6200, 8))[::7] + [6120, 6144, 6200, 75376, 97896, 149776]:
+        a, b = OrcCbsegm(), OrcCbsegm()
+        ra, rb = R.srslte_cbsegm(C.byref(a), tbs), oracle().orc_cbsegm(C.byref(b), tbs)
+        assert (ra == 0) == (rb == 0)
+        if ra == 0:
+            assert all(getattr(a, f) == getattr(b, f) for f, _ in OrcCbsegm._fields_), tbs
+
+
+def test_turbo_encoder_all_188_sizes():
+    """turbocoder_test.c:67-129 sweeps all K; here bit-exact vs the reference encoder."""
+    R, rng = ref(), np.random.default_rng(1)
+    tcod = opaque(4096)
+    R.srslte_tcod_init(tcod, 6144)
+    for K in ALL_K:
+        bits = rng.integers(0, 2, K).astype(np.uint8)
+        a, b = np.zeros(3 * K + 12, np.uint8), np.zeros(3 * K + 12, np.uint8)
+        R.srslte_tcod_encode(tcod, p(bits), p(a), K)
+        assert oracle().orc_tcod_encode_bits(p(bits), p(b), K) == 0
+        assert np.array_equal(a, b), K
+
+
+@pytest.mark.parametrize("K", ALL_K[::6] + [400, 408, 800, 816, 6144])
+def test_turbo_decoder_vs_ref(K):
+    """Both input layouts, 1..6 passes, three SNR/scale points (turbodecoder_test.c:117-311 style stimulus)."""
+    R, rng = ref(), np.random.default_rng(K)
+    R.srslte_cbsegm_cbindex.restype = C.c_int
+    tcod = opaque(4096)
+    R.srslte_tcod_init(tcod, 6144)
+    bits = rng.integers(0, 2, K).astype(np.uint8)
+    enc = np.zeros(3 * K + 12, np.uint8)
+    R.srslte_tcod_encode(tcod, p(bits), p(enc), K)
+    W = oracle().orc_tdec_autoimp_subblocks(K)
+    for snr, scale in ((0.5, 100), (2.0, 100), (-3.0, 3000)):
+        llr = acopy((scale * ((2.0 * enc - 1) + 10 ** (-snr / 20) * rng.standard_normal(enc.shape))).clip(-32000, 32000).astype(np.int16))
+        tdec = opaque(1 << 20)
+        assert R.srslte_tdec_init(tdec, 6144) == 0
+        R.srslte_tdec_force_not_sb(tdec)
+        for nit in (1, 2, 3, 6):
+            a, b = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8)
+            R.srslte_tdec_run_all(tdec, p(llr), p(a), nit, K)
+            assert oracle().orc_tdec_run(p(llr), False, K, nit, p(b), None) == 0
+            assert np.array_equal(a, b), (K, snr, nit)
+        R.srslte_tdec_free(tdec)
+        if W:  # SB layout via the reference rate de-matcher
+            n_e = (3 * K * 8 // 10) // 6 * 6
+            eb = np.zeros(n_e, np.uint8)
+            oracle().orc_rm_turbo_tx_bits(p(enc), p(eb), n_e, K, 0)
+            e = acopy((scale * ((2.0 * eb - 1) + 10 ** (-snr / 20) * rng.standard_normal(n_e))).clip(-32000, 32000).astype(np.int16))
+            w1, w2 = aligned(3 * (K + 32) + 76, np.int16), aligned(3 * (K + 32) + 76, np.int16)
+            R.srslte_rm_turbo_rx_lut(p(e), p(w1), n_e, R.srslte_cbsegm_cbindex(K), 0)
+            oracle().orc_rm_turbo_rx(p(e), p(w2), n_e, K, 0, W)
+            assert np.array_equal(w1, w2)
+            tdec = opaque(1 << 20)
+            assert R.srslte_tdec_init(tdec, 6144) == 0
+            for nit in (1, 4, 6):
+                a, b = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8)
+                R.srslte_tdec_run_all(tdec, p(acopy(w1)), p(a), nit, K)
+                assert oracle().orc_tdec_run(p(w2), True, K, nit, p(b), None) == 0
+                assert np.array_equal(a, b), (K, snr, nit, "sb")
+            R.srslte_tdec_free(tdec)
+
+
+@pytest.mark.parametrize("K", [40, 176, 504, 1008, 5824, 6144])
+def test_rate_dematching_all_rv_and_wraps(K):
+    R, rng = ref(), np.random.default_rng(K)
+    R.srslte_cbsegm_cbindex.restype = C.c_int
+    W = oracle().orc_tdec_autoimp_subblocks(K)
+    for rv in range(4):
+        for n_e in (3 * K - 90, 3 * K + 12, 2 * (3 * K + 12) + 37, 1000):
+            e = acopy(rng.integers(-2000, 2000, n_e).astype(np.int16))
+            a, b = aligned(3 * (K + 32) + 76, np.int16), aligned(3 * (K + 32) + 76, np.int16)
+            assert R.srslte_rm_turbo_rx_lut(p(e), p(a), n_e, R.srslte_cbsegm_cbindex(K), rv) == 0
+            assert oracle().orc_rm_turbo_rx(p(e), p(b), n_e, K, rv, W) == 0
+            assert np.array_equal(a, b), (K, rv, n_e)
+
+
+def test_gold_and_crs():
+    R = ref()
+    for seed in (1, 12345, 0x7FFFFFFF, (0x1234 << 14) + (3 << 9) + 1):
+        n = 5000
+        c = np.zeros(n, np.uint8)
+        oracle().orc_gold(C.c_uint32(seed), n, p(c))
+        q = opaque(256)
+        assert R.srslte_sequence_LTE_pr(q, n, C.c_uint32(seed)) == 0
+        ptr = C.cast(q, C.POINTER(C.c_void_p))[0]
+        assert np.array_equal(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), (n,)), c)
+
+
+@pytest.mark.parametrize("mod", [0, 1, 2, 3, 4])
+def test_modem_vs_ref(mod):
+    R, rng = ref(), np.random.default_rng(mod)
+    qm = 1 if mod == 0 else 2 * mod
+    tab = opaque(1 << 16)
+    assert R.srslte_modem_table_lte(tab, mod) == 0
+    for nsym in (1, 3, 4, 7, 8, 15, 16, 33, 120, 14580):
+        bits = rng.integers(0, 2, nsym * qm).astype(np.uint8)
+        a, b = aligned(2 * nsym, np.float32), aligned(2 * nsym, np.float32)
+        R.srslte_mod_modulate(tab, p(bits), p(a), nsym * qm)
+        oracle().orc_modulate(mod, p(bits), p(b), nsym * qm)
+        assert np.array_equal(a, b)
+        for scale in (1, 3, 40):
+            x = acopy(((a + 0.3 * rng.standard_normal(2 * nsym)) * scale).astype(np.float32))
+            for name, on, dt in (("", "_f", np.float32), ("_s", "_s", np.int16), ("_b", "_b", np.int8)):
+                l1, l2 = aligned(nsym * qm + 64, dt), aligned(nsym * qm + 64, dt)
+                getattr(R, "srslte_demod_soft_demodulate" + name)(mod, p(x), p(l1), nsym)
+                getattr(oracle(), "orc_demod_soft" + on)(mod, p(x), p(l2), nsym)
+                assert np.array_equal(l1, l2), (mod, nsym, scale, name)
+
+
+CHEST_CFGS = [{}, {"filter_coef": (4.0, 1.0)}, {"interpolate_subframe": True, "filter_coef": (4.0, 2.0), "cfo_estimate_enable": True},
+              {"interpolate_subframe": True, "filter_type": 2}, {"filter_type": 1, "filter_coef": (0.1, 0.0)}, {"filter_type": 2}]
+
+
+@pytest.mark.parametrize("prb,cid", [(6, 1), (6, 0), (25, 2), (50, 3), (100, 1), (100, 4), (100, 5), (15, 150)])
+def test_chest_dl_vs_ref(prb, cid):
+    R, rng = ref(), np.random.default_rng(prb + cid)
+    for sf_idx in (0, 3):
+        nre, n = 12 * prb, 14 * 12 * prb
+        cell = OrcCell(cid, prb, 1, True)
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+        grid = acopy((g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        for kw in CHEST_CFGS:
+            q = opaque(1 << 20)
+            assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+            rc, oc = RefChestCfg(), OrcChestCfg()
+            for kk, v in kw.items():
+                if kk == "filter_coef":
+                    rc.filter_coef[0], rc.filter_coef[1] = v
+                    oc.filter_coef[0], oc.filter_coef[1] = v
+                else:
+                    setattr(rc, kk, v)
+                    setattr(oc, kk, v)
+            rc.cfo_estimate_sf_mask = 0x3FF
+            ce1, res, sf = aligned(2 * n, np.float32), RefChestRes(), RefDlSfCfg()
+            res.ce[0][0] = ce1.ctypes.data
+            sf.tti = sf_idx
+            inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+            assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+            ce2, ores = np.zeros(n, np.complex64), OrcChestRes()
+            assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ce2), C.byref(ores)) == 0
+            a = ce1.view(np.complex64)
+            assert np.abs(a - ce2).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (prb, cid, kw)
+            for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo"):
+                x, y = getattr(res, nm), getattr(ores, nm)
+                assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+            R.srslte_chest_dl_free(q)
+
+
+def test_equaliser_vs_ref_rcp_tolerance():
+    """The reference's AVX body uses _mm256_rcp_ps (12-bit): parity at 1e-3, see oracle/orc_pdsch.c."""
+    R, rng = ref(), np.random.default_rng(9)
+    n = 1000
+    y, h = acopy(rng.standard_normal(2 * n).astype(np.float32)), acopy((rng.standard_normal(2 * n) + 2).astype(np.float32))
+    a, b = aligned(2 * n, np.float32), aligned(2 * n, np.float32)
+    R.srslte_predecoding_single(p(y), p(h), p(a), None, n, 1.0, 0.1)
+    oracle().orc_predecoding_single(p(y), p(h), p(b), n, 1.0, 0.1)
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr", [(6, 1, 936, 3.0), (100, 3, 75376, 18.0), (100, 4, 97896, 27.0)])
+def test_whole_chain_vs_reference_code(prb, mod, tbs, snr):
+    """Same IQ through the oracle chain and through the reference's compiled chest/eq/demod/rm/tdec/crc: same TBs and pass counts."""
+    rng = np.random.default_rng(prb + mod)
+    cfg = DlConfig(prb, 1, mod, tbs)
+    chain = RefRx(cfg)
+    ttis = (1, 2, 3) if prb == 6 else (0, 5, 7)
+    for t in ttis:
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
