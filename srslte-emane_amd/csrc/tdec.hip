@@ -132,6 +132,7 @@ struct TdecArgs {
   int16_t*       work;         // per block: 7 arrays of Kp int16
   uint32_t       Kp;
   pk_t*          beta;         // per wave: (steps+1) * 64 dwords
+  int2*          xy;           // per block: K int2 (combine-pass scratch of the windowed decoders)
   uint32_t       beta_stride;  // dwords per wave
   uint8_t*       out;
   uint32_t       out_stride;
@@ -150,45 +151,169 @@ __device__ __forceinline__ pk_t ld_pair(const int16_t* a, int k, int g)
   return (pk_t)(uint16_t)a[k * 8 + g];
 }
 
+// ---- one trellis step on prepared inputs: in.x = systematic (+ a-priori, already added with saturation), in.y = parity
+// MODE 0: warm-up, 1: beta main pass, 2: alpha main pass (also forms the extrinsic output o from beta value B)
+template <int PH, int MODE, int W>
+__device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, int2 in, pk_t B, pk_t& o)
+{
+  constexpr bool SAT = true;
+  pk_t           to, tp;
+  const pk_t     x = in.x, y = in.y, xy = pk_add<SAT>(x, y);
+  v = acs<PH, SAT>(L, v, x, y, xy, &to, &tp);
+  if constexpr (MODE == 2) {
+    const bool b0 = PH == 0 ? L.p1 : (PH == 1 ? L.p2 : L.p0); // own transition carries info bit b0
+    const pk_t m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
+    const pk_t m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
+    o             = pk_sub<SAT>(m1, m0);
+    if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
+  }
+}
+
+__device__ __forceinline__ void win_normalize(pk_t& v) { v = pk_sub<true>(v, bcast_slot0(v)); } // turbodecoder_win.h:332-349
+
+template <int W>
+__device__ __forceinline__ void store_out(int16_t* out, int k, int g, pk_t o)
+{
+  if constexpr (W == 16) {
+    reinterpret_cast<pk_t*>(out)[k * 8 + g] = o;
+  } else {
+    out[k * 8 + g] = (int16_t)pk_lo(o);
+  }
+}
+
+// nb blocks of BLK steps (BLK a multiple of 6 so that trellis phase and normalisation parity are compile-time), first
+// step k_first, direction DIR, phase of the first step PH0, normalisation counter n_first (parity NPAR0).
+// Every operand of a block is requested at its top and consumed in order: the memory round trip is paid once per BLK
+// steps instead of once per step, and the second wavefront of the SIMD computes meanwhile. (Prefetching across the
+// loop back-edge does not survive hipcc's waitcnt insertion, which drains vmcnt(0) there; in-flight registers managed
+// by hand from inline asm were tried and are unsafe at this register pressure: the allocator copies them.)
+template <int W, int BLK, int PH0, int DIR, int MODE, int NPAR0>
+__device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
+                                        int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out)
+{
+  for (int b = 0; b < nb; b++) {
+    const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b;
+    int2      c[BLK];
+    pk_t      cb[BLK];
+#pragma unroll
+    for (int j = 0; j < BLK; j++) {
+      c[j]  = my[k0 + DIR * j];
+      cb[j] = 0;
+      if constexpr (MODE == 2) cb[j] = bl[(k0 + DIR * j + 1) * 64];
+    }
+    pk_t keep = 0;
+#pragma unroll
+    for (int j6 = 0; j6 < BLK; j6 += 6) {
+#define STEP6(J)                                                                  \
+  {                                                                               \
+    constexpr int PH = DIR > 0 ? (PH0 + J) % 3 : (PH0 + 18 - J) % 3;              \
+    pk_t          o  = 0;                                                         \
+    win_step<PH, MODE, W>(L, v, c[j6 + J], cb[j6 + J], o);                        \
+    if constexpr (MODE == 1) beta[(k0 + DIR * (j6 + J)) * 64 + L.lane] = v;       \
+    if constexpr (MODE == 2) keep = L.p == J ? o : keep;                          \
+    if constexpr (((NPAR0 + J) & 1) == 0) {                                       \
+      if (n0 + DIR * (j6 + J) != 0) win_normalize(v);                             \
+    }                                                                             \
+  }
+      STEP6(0) STEP6(1) STEP6(2) STEP6(3) STEP6(4) STEP6(5)
+#undef STEP6
+      if constexpr (MODE == 2) { // after the group reduction every slot holds the step's output: slot j keeps step j
+        if (L.p < 6) store_out<W>(out, k0 + j6 + L.p, L.g, keep);
+      }
+    }
+  }
+}
+
+// up to 5 left-over steps with run-time phase; their loads are issued together up front
+template <int W, int DIR, int MODE>
+__device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
+                                        int n_first, int ph_first, int r, pk_t* __restrict__ beta, int16_t* __restrict__ out)
+{
+  int2 in[5];
+  pk_t B[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    in[j] = make_int2(0, 0);
+    B[j]  = 0;
+    if (j < r) {
+      in[j] = my[k_first + DIR * j];
+      if constexpr (MODE == 2) B[j] = bl[(k_first + DIR * j + 1) * 64];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    if (j < r) {
+      const int k = k_first + DIR * j, n = n_first + DIR * j, ph = ((ph_first + DIR * j) % 3 + 3) % 3;
+      pk_t      o = 0;
+      switch (ph) {
+        case 0: win_step<0, MODE, W>(L, v, in[j], B[j], o); break;
+        case 1: win_step<1, MODE, W>(L, v, in[j], B[j], o); break;
+        default: win_step<2, MODE, W>(L, v, in[j], B[j], o); break;
+      }
+      if constexpr (MODE == 1) beta[k * 64 + L.lane] = v;
+      if constexpr (MODE == 2) {
+        if (L.p == 0) store_out<W>(out, k, L.g, o);
+      }
+      if ((n & 1) == 0 && n != 0) win_normalize(v);
+    }
+  }
+}
+
+// Elementwise phase over i = lane, lane+64, ... < n with U elements per lane in flight: every load of a batch is issued
+// before its first store, so the memory round trip is paid once per batch instead of once per element.
+template <int U, typename Ld, typename St>
+__device__ __forceinline__ void batched(int lane, int n, Ld ld, St st)
+{
+  for (int base = lane; base < n; base += 64 * U) {
+    decltype(ld(0)) v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + 64 * u;
+      if (i < n) v[u] = ld(i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int i = base + 64 * u;
+      if (i < n) st(i, v[u]);
+    }
+  }
+}
+struct I3 { int a, b, c; };
+
 template <int W>
 __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
-                         pk_t* __restrict__ beta, int K)
+                         pk_t* __restrict__ beta, int2* __restrict__ xy, int K)
 {
-  constexpr bool SAT = true;
-  const int      Lw  = K / W;
-  const pk_t     NEG = pk_make(-TD_INF, -TD_INF);
-  pk_t           v, to, tp;
+  const int  Lw  = K / W;
+  const pk_t NEG = pk_make(-TD_INF, -TD_INF);
+  pk_t       v;
 
-#define LOAD_XY(k)                                                     \
-  pk_t x = ld_pair<W>(in, (k), L.g), y = ld_pair<W>(par, (k), L.g);    \
-  if (app) x = pk_add<SAT>(ld_pair<W>(app, (k), L.g), x);              \
-  const pk_t xy = pk_add<SAT>(x, y);
-#define ACS(ph)                                                        \
-  switch (ph) {                                                        \
-    case 0: v = acs<0, SAT>(L, v, x, y, xy, &to, &tp); break;          \
-    case 1: v = acs<1, SAT>(L, v, x, y, xy, &to, &tp); break;          \
-    default: v = acs<2, SAT>(L, v, x, y, xy, &to, &tp); break;         \
-  }
-#define NORMALIZE(k) \
-  if (((k) & 1) == 0 && (k) != 0) v = pk_sub<SAT>(v, bcast_slot0(v)); /* turbodecoder_win.h:332-349 */
+  // ---- combine pass: xy[g][k] = (sat(app + syst), parity) for the window pair g at step k, so that one 8-byte load
+  //      per step feeds the recursion (turbodecoder_win.h:472-478: x = adds(ap, x))
+  batched<8>(
+      L.lane, 8 * Lw,
+      [&](int i) { return I3{ld_pair<W>(in, i >> 3, i & 7), app ? ld_pair<W>(app, i >> 3, i & 7) : 0, ld_pair<W>(par, i >> 3, i & 7)}; },
+      [&](int i, I3 t) { xy[(i & 7) * Lw + (i >> 3)] = make_int2(app ? pk_add<true>(t.b, t.a) : t.a, t.c); });
+  __syncthreads();
+  const int2* my = xy + L.g * Lw;
+  const pk_t* bl = beta + L.lane;
 
-  // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464)
+  // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464); positions are fixed: all static
   v = NEG;
-  for (int k = WIN_OVERLAP - 1, ph = (WIN_OVERLAP - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
-    LOAD_XY(k);
-    ACS(ph);
-    NORMALIZE(k);
-  }
+  static_assert(WIN_OVERLAP == 40, "block plan below is written for the 40-step overlap");
+  win_run<W, 24, 39 % 3, -1, 0, 1>(L, v, my, bl, 39, 39, 1, beta, out);  // steps 39..16
+  win_run<W, 12, 15 % 3, -1, 0, 1>(L, v, my, bl, 15, 15, 1, beta, out);  // steps 15..4
+  win_rem<W, -1, 0>(L, v, my, bl, 3, 3, 0, 4, beta, out);                // steps 3..0
   // ---- tail trellis for the last window: scalar, wrapping adds (turbodecoder_win.h:351-395)
   int tail[8];
   {
     int o[8] = {0, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF};
     for (int j = 2; j >= 0; j--) {
-      const int x = tail_in[j], y = tail_par[j], xy = (short)(x + y);
+      const int x = tail_in[j], y = tail_par[j], xy_ = (short)(x + y);
 #define WA(a, b) ((int)(short)((a) + (b)))
-      int m[8] = {WA(o[4], xy), o[4], WA(o[5], y), WA(o[5], x), WA(o[6], x), WA(o[6], y), o[7], WA(o[7], xy)};
-      int n[8] = {o[0], WA(o[0], xy), WA(o[1], x), WA(o[1], y), WA(o[2], y), WA(o[2], x), WA(o[3], xy), o[3]};
+      int m[8] = {WA(o[4], xy_), o[4], WA(o[5], y), WA(o[5], x), WA(o[6], x), WA(o[6], y), o[7], WA(o[7], xy_)};
+      int n[8] = {o[0], WA(o[0], xy_), WA(o[1], x), WA(o[1], y), WA(o[2], y), WA(o[2], x), WA(o[3], xy_), o[3]};
 #undef WA
       for (int i = 0; i < 8; i++) o[i] = m[i] > n[i] ? m[i] : n[i];
     }
@@ -208,20 +333,25 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     }
   }
   beta[Lw * 64 + L.lane] = v;
-  // ---- beta main pass (:466-526): store after the max, before normalisation
-  for (int k = Lw - 1, ph = (Lw - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
-    LOAD_XY(k);
-    ACS(ph);
-    beta[k * 64 + L.lane] = v;
-    NORMALIZE(k);
+  // ---- beta main pass (:466-526): store after the max, before normalisation. Left-over steps first, then aligned blocks.
+  {
+    const int r = Lw % 6, n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
+    win_rem<W, -1, 1>(L, v, my, bl, Lw - 1, Lw - 1, (Lw - 1) % 3, r, beta, out);
+    win_run<W, 6, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1, Lw - r - 1, r6, beta, out); // first step index = 5 (mod 6)
+    win_run<W, 24, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, beta, out);
   }
 
-  // ---- alpha warm-up over the last 40 steps of every window (:586-603)
+  // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter j = 0..39
   v = NEG;
-  for (int j = 0, k = Lw - WIN_OVERLAP, ph = (Lw - WIN_OVERLAP) % 3; j < WIN_OVERLAP; j++, k++, ph = ph == 2 ? 0 : ph + 1) {
-    LOAD_XY(k);
-    ACS(ph);
-    NORMALIZE(j);
+  {
+    const int k0 = Lw - WIN_OVERLAP, ph0 = k0 % 3;
+    switch (ph0) {
+      case 0: win_run<W, 24, 0, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 0, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
+      case 1: win_run<W, 24, 1, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 1, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
+      default: win_run<W, 24, 2, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 2, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
+    }
+    const int done = 36;
+    win_rem<W, 1, 0>(L, v, my, bl, k0 + done, done, (ph0 + done) % 3, WIN_OVERLAP - done, beta, out);
   }
   // ---- window shift: window w starts from the end of window w-1, window 0 from the known state (:560-583)
   {
@@ -237,27 +367,12 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   }
   // ---- alpha main pass with extrinsic output (:605-679)
   __syncthreads(); // beta stores of this wave are visible to its loads
-  for (int k = 0, ph = 0; k < Lw; k++, ph = ph == 2 ? 0 : ph + 1) {
-    LOAD_XY(k);
-    const pk_t B = beta[(k + 1) * 64 + L.lane];
-    ACS(ph);
-    const bool b0 = ph == 0 ? L.p1 : (ph == 1 ? L.p2 : L.p0); // own transition carries info bit b0
-    pk_t       m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
-    pk_t       m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
-    pk_t       o  = pk_sub<SAT>(m1, m0);
-    if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
-    if (L.p == 0) {
-      if constexpr (W == 16) {
-        reinterpret_cast<pk_t*>(out)[k * 8 + L.g] = o;
-      } else {
-        out[k * 8 + L.g] = (int16_t)pk_lo(o);
-      }
-    }
-    NORMALIZE(k);
+  {
+    const int n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
+    win_run<W, 24, 0, 1, 2, 0>(L, v, my, bl, 0, 0, n24, beta, out);
+    win_run<W, 6, 0, 1, 2, 0>(L, v, my, bl, 24 * n24, 24 * n24, r6, beta, out);
+    win_rem<W, 1, 2>(L, v, my, bl, 6 * n6, 6 * n6, 0, Lw % 6, beta, out);
   }
-#undef LOAD_XY
-#undef ACS
-#undef NORMALIZE
 }
 
 template <int W>
@@ -277,22 +392,27 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
   pk_t* beta = a.beta + (size_t)cb * a.beta_stride;
+  int2* xy   = a.xy + (size_t)cb * a.K;
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91); tails live at [K..K+2]
   const int tb = a.sb_layout ? 3 * (K + 32) : 3 * K;
   if (a.sb_layout) {
-    for (int i = L.lane; i < K; i += 64) {
-      syst[i] = in[i];
-      par0[i] = in[K + 32 + i];
-      par1[i] = in[2 * (K + 32) + i];
-    }
+    batched<8>(
+        L.lane, K, [&](int i) { return I3{in[i], in[K + 32 + i], in[2 * (K + 32) + i]}; },
+        [&](int i, I3 t) {
+          syst[i] = (int16_t)t.a;
+          par0[i] = (int16_t)t.b;
+          par1[i] = (int16_t)t.c;
+        });
   } else {
-    for (int n = L.lane; n < K; n += 64) {
-      const int x = win_pos<W>(n, K);
-      syst[x]     = in[3 * n];
-      par0[x]     = in[3 * n + 1];
-      par1[x]     = in[3 * n + 2];
-    }
+    batched<8>(
+        L.lane, K, [&](int n) { return I3{in[3 * n], in[3 * n + 1], in[3 * n + 2]}; },
+        [&](int n, I3 t) {
+          const int x = win_pos<W>(n, K);
+          syst[x]     = (int16_t)t.a;
+          par0[x]     = (int16_t)t.b;
+          par1[x]     = (int16_t)t.c;
+        });
   }
   if (L.lane < 3) {
     syst[K + L.lane] = in[tb + 2 * L.lane];
@@ -308,39 +428,50 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
   while (n_iter < a.nof_iter && !ok) {
     if ((n_iter & 1) == 0) {
       if (n_iter) {
-        for (int i = L.lane; i < K; i += 64) app1[i] = (int16_t)(app1[i] - ext1[i]); // srslte_vec_sub_sss, wrapping
+        batched<8>(
+            L.lane, K, [&](int i) { return I3{app1[i], ext1[i], 0}; },
+            [&](int i, I3 t) { app1[i] = (int16_t)(t.a - t.b); }); // srslte_vec_sub_sss, wrapping
         __syncthreads();
       }
-      win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, K);
+      win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, xy, K);
       dec = ext1;
     } else {
-      if (n_iter > 1) {
-        for (int i = L.lane; i < K; i += 64) ext1[i] = (int16_t)(ext1[i] - app1[i]);
-        __syncthreads();
-      }
-      for (int i = L.lane; i < K; i += 64) app2[a.t.deinter[i]] = ext1[i]; // srslte_vec_lut_sss
+      const bool sub = n_iter > 1; // ext1 -= app1 (srslte_vec_sub_sss) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut_sss)
+      batched<8>(
+          L.lane, K, [&](int i) { return I3{ext1[i], sub ? app1[i] : 0, a.t.deinter[i]}; },
+          [&](int i, I3 t) {
+            const int16_t e = (int16_t)(t.a - t.b);
+            if (sub) ext1[i] = e;
+            app2[t.c] = e;
+          });
       __syncthreads();
-      win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, K);
+      win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, xy, K);
       __syncthreads();
-      for (int i = L.lane; i < K; i += 64) app1[a.t.inter[i]] = ext2[i];
+      batched<8>(
+          L.lane, K, [&](int i) { return I3{ext2[i], a.t.inter[i], 0}; }, [&](int i, I3 t) { app1[t.b] = (int16_t)t.a; });
       dec = app1;
     }
     __syncthreads();
     n_iter++;
     if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
       uint32_t syn = 0;
-      for (int i = L.lane; i < K; i += 64) syn ^= dec[i] > 0 ? a.t.crc_rem[i] : 0u;
+      batched<8>(
+          L.lane, K, [&](int i) { return I3{dec[i], (int)a.t.crc_rem[i], 0}; }, [&](int i, I3 t) { syn ^= t.a > 0 ? (uint32_t)t.b : 0u; });
       for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
       ok = syn == 0;
     }
   }
   // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838)
   uint8_t* o = a.out + (size_t)cb * a.out_stride;
-  for (int b = L.lane; b < K / 8; b += 64) {
-    uint32_t byte = 0;
-    for (int j = 0; j < 8; j++) byte |= (dec[win_pos<W>(8 * b + j, K)] > 0 ? 0x80u : 0u) >> j;
-    o[b] = (uint8_t)byte;
-  }
+  batched<2>(
+      L.lane, K / 8,
+      [&](int b) {
+        uint32_t byte = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) byte |= (dec[win_pos<W>(8 * b + j, K)] > 0 ? 0x80u : 0u) >> j;
+        return byte;
+      },
+      [&](int b, uint32_t byte) { o[b] = (uint8_t)byte; });
   if (L.lane == 0) {
     if (a.iters) a.iters[cb] = n_iter;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
@@ -500,6 +631,7 @@ struct srslte_hip_tdec {
   uint32_t                 max_long_cb, max_nof_cb, Kp;
   int16_t*                 d_work;
   pk_t*                    d_beta;
+  int2*                    d_xy;
   uint32_t                 beta_stride;
   std::map<TabKey, TabDev> tabs;
   std::mutex               mtx;
@@ -527,11 +659,13 @@ extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint3
   q->beta_stride  = (max_long_cb + 8) * 64; // generic: K+4 steps; windowed: K/8+1
   q->d_work       = nullptr;
   q->d_beta       = nullptr;
+  q->d_xy         = nullptr;
   // windowed kernels need (K/W+1)*64 dwords per block; the generic one (K+4)*64 per 8 blocks: size for the worst
   const size_t beta_words = (size_t)max_nof_cb * (max_long_cb / 8 + 2) * 64;
   const size_t gen_words  = (size_t)((max_nof_cb + 7) / 8) * (max_long_cb + 8) * 64;
   if (hipMalloc((void**)&q->d_work, (size_t)max_nof_cb * 7 * q->Kp * sizeof(int16_t)) != hipSuccess ||
-      hipMalloc((void**)&q->d_beta, sizeof(pk_t) * (beta_words > gen_words ? beta_words : gen_words)) != hipSuccess) {
+      hipMalloc((void**)&q->d_beta, sizeof(pk_t) * (beta_words > gen_words ? beta_words : gen_words)) != hipSuccess ||
+      hipMalloc((void**)&q->d_xy, sizeof(int2) * (size_t)max_nof_cb * max_long_cb) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] tdec: device allocation failed\n");
     if (q->d_work) (void)hipFree(q->d_work);
     delete q;
@@ -550,6 +684,7 @@ extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
   }
   (void)hipFree(q->d_work);
   (void)hipFree(q->d_beta);
+  (void)hipFree(q->d_xy);
   delete q;
 }
 
@@ -611,7 +746,7 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_s
   if ((W != 0 && W != 8 && W != 16) || (W && (K % W || K / W < WIN_OVERLAP)) || (sb_layout && !W)) return SRSLTE_ERROR_INVALID_INPUTS;
   TdecArgs a;
   a.in = d_input; a.in_stride = in_stride; a.sb_layout = sb_layout; a.K = K; a.nof_cb = nof_cb; a.nof_iter = nof_iterations;
-  a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta;
+  a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy;
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
