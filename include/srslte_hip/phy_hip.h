@@ -35,6 +35,10 @@ int   srslte_hip_sync(void);
 void* srslte_hip_stream_create(void);
 void  srslte_hip_stream_destroy(void* stream);
 int   srslte_hip_stream_sync(void* stream);
+void* srslte_hip_event_create(void);                      /* HIP events on the caller's stream, for kernel timing */
+int   srslte_hip_event_record(void* event, void* stream);
+float srslte_hip_event_elapsed_ms(void* start, void* stop);
+void  srslte_hip_event_destroy(void* event);
 
 /* ------------------------------------------------------------------ OFDM (replaces srslte_ofdm_rx_sf / srslte_ofdm_tx_sf,
  * lib/include/srslte/phy/dft/ofdm.h:82-153, lib/src/phy/dft/ofdm.c:384-594, and FFTW behind dft_fftw.c) */
@@ -73,6 +77,7 @@ typedef struct {             /* scalar members of srslte_chest_dl_res_t (chest_d
 } srslte_hip_chest_dl_res_t;
 srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm); /* chest_dl.c:69-160,193-300 */
 void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
+const void*            srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q); /* device CRS table [10][4][2*prb] (refsignal_dl.c:66-116) */
 int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                        void* d_ce, void* d_res, int nof_sf, void* stream);
 
@@ -100,6 +105,11 @@ uint32_t           srslte_hip_tdec_input_len(uint32_t long_cb, int sb_layout);  
 int srslte_hip_tdec_run_batch(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
                               uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
                               uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream);
+
+/* srslte_tdec_init_manual equivalent (turbodecoder.c:168-215): nof_subblocks 0 = generic, 8 = sse16, 16 = avx16 numerics on any K */
+int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
+                                     uint32_t nof_subblocks, uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits,
+                                     uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream);
 
 /* ------------------------------------------------------------------ turbo encoder (replaces srslte_tcod_encode, fec/turbocoder.h:44-76,
  * turbocoder.c:76-186): bits in (one per byte) -> 3K+12 bits out ([s p0 p1] triplets + 12 tail), nof_cb blocks */
@@ -134,6 +144,10 @@ uint32_t            srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_
 /* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf] */
 int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                            uint8_t* d_tb_ok, void* stream);
+/* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
+ * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
+int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,
+                           uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d, 4 e (LLRs), 5 w, 6 cb iters */
 const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which);
 

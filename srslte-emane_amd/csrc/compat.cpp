@@ -1,0 +1,744 @@
+// The reference's single-call C API (include/srslte_hip/srslte_compat.h) as synchronous host wrappers over the HIP
+// kernels: copy in -> launch on the default stream -> copy out. One object per host thread, as upstream
+// (SURVEY §8b "Threading"); staging buffers are per object, so distinct objects may be used from distinct threads.
+#include "phy_hip_internal.hpp"
+#include "srslte_hip/srslte_compat.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+
+#define ERROR(...)                            \
+  do {                                        \
+    fprintf(stderr, "[srslte_hip] " __VA_ARGS__); \
+    fprintf(stderr, "\n");                    \
+  } while (0)
+
+namespace {
+
+struct DevStage { // grow-only device staging buffer
+  void*  ptr   = nullptr;
+  size_t bytes = 0;
+  void*  get(size_t n)
+  {
+    if (n > bytes) {
+      if (ptr) (void)hipFree(ptr);
+      ptr   = nullptr;
+      bytes = 0;
+      if (hipMalloc(&ptr, n) != hipSuccess) {
+        ERROR("hipMalloc(%zu) failed", n);
+        return nullptr;
+      }
+      bytes = n;
+    }
+    return ptr;
+  }
+  void release()
+  {
+    if (ptr) (void)hipFree(ptr);
+    ptr   = nullptr;
+    bytes = 0;
+  }
+};
+
+bool h2d(void* d, const void* h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; }
+bool d2h(void* h, const void* d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess; }
+
+void* host_alloc(size_t n)
+{ // srslte_vec_malloc: posix_memalign to the SIMD width (vector.c:118-125)
+  void* p = nullptr;
+  if (posix_memalign(&p, 64, n ? n : 64)) return nullptr;
+  return p;
+}
+
+// ---- state behind srslte_dft_plan_t.p
+struct DftState {
+  DevStage in, out;
+  cf_t *   g_in = nullptr, *g_out = nullptr; // guru: caller buffers captured at plan time (dft_fftw.c:137-165)
+  int      how_many = 0, idist = 0, odist = 0;
+};
+
+// ---- state behind srslte_ofdm_t.fft_plan.p
+struct OfdmState {
+  srslte_hip_ofdm_t* h = nullptr;
+  DevStage           in, out;
+  bool               is_rx = true, norm = false, shift = false;
+  float              shift_f = 0.f;
+};
+
+struct TdecState {
+  srslte_hip_tdec_t* h = nullptr;
+  DevStage           in, out;
+};
+
+struct ChestState {
+  srslte_hip_chest_dl_t* h = nullptr;
+  DevStage               grid, ce, res;
+};
+
+DevStage g_demod_in, g_demod_out, g_tcod_in, g_tcod_out; // demod/tcod have no object to hang state on (one host thread at a time)
+
+int cp_nsymb(srslte_cp_t cp) { return cp == SRSLTE_CP_NORM ? 7 : 6; }
+
+} // namespace
+
+extern "C" {
+
+int srslte_symbol_sz(uint32_t nof_prb) { return lte_symbol_sz((int)nof_prb); }
+
+// ====================================================================================================== DFT
+void srslte_dft_load(void) {} // FFTW wisdom import/export (dft_fftw.c:44-57): nothing to persist
+void srslte_dft_exit(void) {}
+
+int srslte_dft_plan_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir)
+{ // dft_fftw.c:167-191
+  if (!plan) return SRSLTE_ERROR_INVALID_INPUTS;
+  FftFactors  f;
+  const cf32* tw;
+  if (fft_get_plan(dft_points, &f, &tw)) return SRSLTE_ERROR;
+  memset(plan, 0, sizeof(*plan));
+  plan->in  = host_alloc(sizeof(cf_t) * dft_points);
+  plan->out = host_alloc(sizeof(cf_t) * dft_points);
+  plan->p   = new DftState();
+  plan->size = plan->init_size = dft_points;
+  plan->mode    = SRSLTE_DFT_COMPLEX;
+  plan->dir     = dir;
+  plan->forward = dir == SRSLTE_DFT_FORWARD;
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_dft_plan(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, srslte_dft_mode_t mode)
+{ // dft_fftw.c:80-85
+  if (mode == SRSLTE_DFT_COMPLEX) return srslte_dft_plan_c(plan, dft_points, dir);
+  ERROR("real (r2r) DFT plans are not provided by the HIP build");
+  return SRSLTE_ERROR;
+}
+
+int srslte_dft_plan_guru_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, cf_t* in_buffer, cf_t* out_buffer, int istride,
+                           int ostride, int how_many, int idist, int odist)
+{ // dft_fftw.c:137-165: batched strided transform bound to caller buffers
+  if (!plan || !in_buffer || !out_buffer) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (istride != 1 || ostride != 1) {
+    ERROR("guru plans with element stride != 1 are not supported");
+    return SRSLTE_ERROR;
+  }
+  FftFactors  f;
+  const cf32* tw;
+  if (fft_get_plan(dft_points, &f, &tw)) return SRSLTE_ERROR;
+  memset(plan, 0, sizeof(*plan));
+  auto* st     = new DftState();
+  st->g_in     = in_buffer;
+  st->g_out    = out_buffer;
+  st->how_many = how_many;
+  st->idist    = idist;
+  st->odist    = odist;
+  plan->p      = st;
+  plan->size = plan->init_size = dft_points;
+  plan->mode    = SRSLTE_DFT_COMPLEX;
+  plan->dir     = dir;
+  plan->forward = dir == SRSLTE_DFT_FORWARD;
+  plan->is_guru = true;
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_dft_replan_c(srslte_dft_plan_t* plan, int new_dft_points)
+{ // dft_fftw.c:120-135
+  FftFactors  f;
+  const cf32* tw;
+  if (!plan || fft_get_plan(new_dft_points, &f, &tw)) return SRSLTE_ERROR;
+  if (new_dft_points > plan->init_size) {
+    free(plan->in);
+    free(plan->out);
+    plan->in        = host_alloc(sizeof(cf_t) * new_dft_points);
+    plan->out       = host_alloc(sizeof(cf_t) * new_dft_points);
+    plan->init_size = new_dft_points;
+  }
+  plan->size = new_dft_points;
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_dft_replan_guru_c(srslte_dft_plan_t* plan, int new_dft_points, cf_t* in_buffer, cf_t* out_buffer, int istride, int ostride,
+                             int how_many, int idist, int odist)
+{ // dft_fftw.c:93-118
+  if (!plan || !plan->p) return SRSLTE_ERROR_INVALID_INPUTS;
+  const srslte_dft_dir_t dir = plan->dir;
+  const bool             norm = plan->norm, dc = plan->dc, mirror = plan->mirror;
+  delete (DftState*)plan->p;
+  int r = srslte_dft_plan_guru_c(plan, new_dft_points, dir, in_buffer, out_buffer, istride, ostride, how_many, idist, odist);
+  plan->norm = norm; plan->dc = dc; plan->mirror = mirror;
+  return r;
+}
+
+void srslte_dft_plan_set_mirror(srslte_dft_plan_t* plan, bool val) { plan->mirror = val; }
+void srslte_dft_plan_set_db(srslte_dft_plan_t* plan, bool val) { plan->db = val; }
+void srslte_dft_plan_set_norm(srslte_dft_plan_t* plan, bool val) { plan->norm = val; }
+void srslte_dft_plan_set_dc(srslte_dft_plan_t* plan, bool val) { plan->dc = val; }
+
+void srslte_dft_plan_free(srslte_dft_plan_t* plan)
+{ // dft_fftw.c:336-347
+  if (!plan || !plan->size) return;
+  if (!plan->is_guru) {
+    free(plan->in);
+    free(plan->out);
+  }
+  if (plan->p) {
+    auto* st = (DftState*)plan->p;
+    st->in.release();
+    st->out.release();
+    delete st;
+  }
+  memset(plan, 0, sizeof(*plan));
+}
+
+static void dft_exec(srslte_dft_plan_t* plan, const cf_t* in, cf_t* out, int howmany, int idist, int odist)
+{
+  auto*        st = (DftState*)plan->p;
+  const size_t nin = sizeof(cf_t) * ((size_t)(howmany - 1) * idist + plan->size), nout = sizeof(cf_t) * ((size_t)(howmany - 1) * odist + plan->size);
+  void *       di = st->in.get(nin), *dout = st->out.get(nout);
+  if (!di || !dout || !h2d(di, in, nin)) return;
+  if (srslte_hip_dft_batch(di, dout, plan->size, howmany, idist, odist, plan->forward ? 1 : 0, 1.0f, nullptr)) return;
+  if (howmany > 1 && odist != plan->size) {
+    for (int i = 0; i < howmany; i++) d2h(out + (size_t)i * odist, (char*)dout + sizeof(cf_t) * (size_t)i * odist, sizeof(cf_t) * plan->size);
+  } else {
+    d2h(out, dout, nout);
+  }
+}
+
+void srslte_dft_run_c_zerocopy(srslte_dft_plan_t* plan, const cf_t* in, cf_t* out) { dft_exec(plan, in, out, 1, plan->size, plan->size); } // dft_fftw.c:277-279
+
+void srslte_dft_run_c(srslte_dft_plan_t* plan, const cf_t* in, cf_t* out)
+{ // dft_fftw.c:281-305: copy_pre (mirror/dc for BACKWARD) -> transform -> norm -> dB -> copy_post (mirror for FORWARD)
+  const int N = plan->size, offset = plan->dc ? 1 : 0;
+  cf_t *    pin = (cf_t*)plan->in, *pout = (cf_t*)plan->out;
+  if (plan->mirror && !plan->forward) { // dft_fftw.c:249-260
+    const int hlen = N / 2;
+    memset(pin, 0, sizeof(cf_t) * offset);
+    memcpy(&pin[offset], &in[hlen], sizeof(cf_t) * (N - hlen - offset));
+    memcpy(&pin[N - hlen], in, sizeof(cf_t) * hlen);
+  } else {
+    memcpy(pin, in, sizeof(cf_t) * N);
+  }
+  dft_exec(plan, pin, pout, 1, N, N);
+  float* f = (float*)pout;
+  if (plan->norm) {
+    const float norm = 1.0f / sqrtf((float)N);
+    for (int i = 0; i < 2 * N; i++) f[i] *= norm;
+  }
+  if (plan->db) { // dft_fftw.c:298-302: 10*log10 of the complex value; only the real-magnitude use survives upstream
+    for (int i = 0; i < N; i++) {
+      f[2 * i]     = 10.0f * log10f(hypotf(f[2 * i], f[2 * i + 1]));
+      f[2 * i + 1] = 0.f;
+    }
+  }
+  if (plan->mirror && plan->forward) { // dft_fftw.c:262-272
+    const int hlen = (N + 1) / 2;
+    memcpy(out, &pout[hlen], sizeof(cf_t) * (N - hlen));
+    memcpy(&out[N - hlen], &pout[offset], sizeof(cf_t) * (hlen - offset));
+  } else {
+    memcpy(out, pout, sizeof(cf_t) * N);
+  }
+}
+
+void srslte_dft_run(srslte_dft_plan_t* plan, const void* in, void* out)
+{
+  if (plan->mode == SRSLTE_DFT_COMPLEX) {
+    srslte_dft_run_c(plan, (const cf_t*)in, (cf_t*)out);
+  } else {
+    ERROR("real DFT plans are not provided by the HIP build");
+  }
+}
+
+void srslte_dft_run_guru_c(srslte_dft_plan_t* plan)
+{ // dft_fftw.c:307-313
+  if (!plan->is_guru) {
+    ERROR("srslte_dft_run_guru_c: the selected plan is not guru!");
+    return;
+  }
+  auto* st = (DftState*)plan->p;
+  dft_exec(plan, st->g_in, st->g_out, st->how_many, st->idist, st->odist);
+}
+
+// ====================================================================================================== OFDM
+static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb, bool rx)
+{ // ofdm.c:43-133
+  const int N = lte_symbol_sz((int)nof_prb);
+  if (!q || N < 0) {
+    ERROR("Error: Invalid nof_prb=%u", nof_prb);
+    return SRSLTE_ERROR;
+  }
+  memset(q, 0, sizeof(*q));
+  q->max_prb = nof_prb;
+  q->symbol_sz = (uint32_t)N; q->nof_symbols = (uint32_t)cp_nsymb(cp); q->nof_symbols_mbsfn = 6; q->cp = cp;
+  q->nof_re = 12 * nof_prb; q->nof_guards = (N - q->nof_re) / 2; q->slot_sz = 15 * N / 2; q->sf_sz = 15 * N;
+  q->in_buffer = in_buffer; q->out_buffer = out_buffer;
+  q->fft_plan.size = q->fft_plan.init_size = N;
+  q->fft_plan.dir     = rx ? SRSLTE_DFT_FORWARD : SRSLTE_DFT_BACKWARD;
+  q->fft_plan.forward = rx;
+  q->fft_plan.mirror  = true; // ofdm.c:110-111
+  q->fft_plan.dc      = true;
+  auto* st            = new OfdmState();
+  st->is_rx           = rx;
+  st->h               = srslte_hip_ofdm_create((int)nof_prb, cp == SRSLTE_CP_NORM, rx);
+  if (!st->h) {
+    delete st;
+    return SRSLTE_ERROR;
+  }
+  q->fft_plan.p = st;
+  if (in_buffer) bzero(in_buffer, sizeof(cf_t) * (rx ? q->sf_sz : 2 * q->nof_symbols * q->nof_re)); // ofdm.c:80-84
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_ofdm_rx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t max_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, max_prb, true); }
+int srslte_ofdm_tx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, nof_prb, false); }
+
+static void ofdm_free(srslte_ofdm_t* q)
+{ // ofdm.c:214-233
+  if (!q) return;
+  auto* st = (OfdmState*)q->fft_plan.p;
+  if (st) {
+    srslte_hip_ofdm_destroy(st->h);
+    st->in.release();
+    st->out.release();
+    delete st;
+  }
+  memset(q, 0, sizeof(*q));
+}
+void srslte_ofdm_rx_free(srslte_ofdm_t* q) { ofdm_free(q); }
+void srslte_ofdm_tx_free(srslte_ofdm_t* q) { ofdm_free(q); }
+
+static int ofdm_set_prb(srslte_ofdm_t* q, srslte_cp_t cp, uint32_t nof_prb, bool rx)
+{ // ofdm.c:307-350
+  if (nof_prb > q->max_prb) {
+    ERROR("OFDM: Error calling set_prb: nof_prb (%u) must be equal or lower initialized max_prb (%u)", nof_prb, q->max_prb);
+    return SRSLTE_ERROR;
+  }
+  const uint32_t max_prb = q->max_prb;
+  cf_t *         in = q->in_buffer, *out = q->out_buffer;
+  const bool     norm = q->fft_plan.norm, shift = q->freq_shift;
+  const float    sf = q->freq_shift_f;
+  ofdm_free(q);
+  if (ofdm_init(q, cp, in, out, nof_prb, rx)) return SRSLTE_ERROR;
+  q->max_prb       = max_prb;
+  q->fft_plan.norm = norm;
+  if (shift) srslte_ofdm_set_freq_shift(q, sf);
+  return SRSLTE_SUCCESS;
+}
+int srslte_ofdm_rx_set_prb(srslte_ofdm_t* q, srslte_cp_t cp, uint32_t nof_prb) { return ofdm_set_prb(q, cp, nof_prb, true); }
+int srslte_ofdm_tx_set_prb(srslte_ofdm_t* q, srslte_cp_t cp, uint32_t nof_prb) { return ofdm_set_prb(q, cp, nof_prb, false); }
+
+int srslte_ofdm_set_freq_shift(srslte_ofdm_t* q, float freq_shift)
+{ // ofdm.c:360-378
+  q->fft_plan.dc  = false;
+  q->freq_shift   = true;
+  q->freq_shift_f = freq_shift;
+  return SRSLTE_SUCCESS;
+}
+void srslte_ofdm_set_normalize(srslte_ofdm_t* q, bool normalize_enable) { q->fft_plan.norm = normalize_enable; } // ofdm.c:576-578
+
+static bool ofdm_sync_state(srslte_ofdm_t* q, OfdmState* st)
+{
+  if (st->norm != q->fft_plan.norm) {
+    st->norm = q->fft_plan.norm;
+    if (srslte_hip_ofdm_set_normalize(st->h, st->norm)) return false;
+  }
+  if (q->freq_shift && (!st->shift || st->shift_f != q->freq_shift_f)) {
+    st->shift   = true;
+    st->shift_f = q->freq_shift_f;
+    if (srslte_hip_ofdm_set_freq_shift(st->h, st->shift_f)) return false;
+  }
+  return true;
+}
+
+static void ofdm_run_sf(srslte_ofdm_t* q, cf_t* input, cf_t* output)
+{
+  auto* st = (OfdmState*)q->fft_plan.p;
+  if (!st || !ofdm_sync_state(q, st)) return;
+  const size_t n_time = sizeof(cf_t) * q->sf_sz, n_grid = sizeof(cf_t) * 2 * q->nof_symbols * q->nof_re;
+  const size_t nin = st->is_rx ? n_time : n_grid, nout = st->is_rx ? n_grid : n_time;
+  void *       di = st->in.get(nin), *dout = st->out.get(nout);
+  if (!di || !dout || !h2d(di, input, nin)) return;
+  int r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
+  if (r == SRSLTE_SUCCESS) d2h(output, dout, nout);
+}
+
+void srslte_ofdm_rx_sf(srslte_ofdm_t* q) { ofdm_run_sf(q, q->in_buffer, q->out_buffer); }                    // ofdm.c:453-467
+void srslte_ofdm_tx_sf(srslte_ofdm_t* q) { ofdm_run_sf(q, q->in_buffer, q->out_buffer); }                    // ofdm.c:580-594
+void srslte_ofdm_rx_sf_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output) { ofdm_run_sf(q, input, output); }   // ofdm.c:469-483
+
+static void ofdm_run_slot(srslte_ofdm_t* q, int slot)
+{ // a slot call processes the whole subframe on the device and returns the requested half (ofdm.c:398-422,:488-530)
+  auto* st = (OfdmState*)q->fft_plan.p;
+  if (!st || !ofdm_sync_state(q, st)) return;
+  const size_t n_time = sizeof(cf_t) * q->sf_sz, n_grid = sizeof(cf_t) * 2 * q->nof_symbols * q->nof_re;
+  const size_t nin = st->is_rx ? n_time : n_grid, nout = st->is_rx ? n_grid : n_time;
+  void *       di = st->in.get(nin), *dout = st->out.get(nout);
+  if (!di || !dout || !h2d(di, q->in_buffer, nin)) return;
+  int r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
+  if (r) return;
+  const size_t half = nout / 2;
+  d2h((char*)q->out_buffer + slot * half, (char*)dout + slot * half, half);
+}
+void srslte_ofdm_rx_slot(srslte_ofdm_t* q, int slot_in_sf) { ofdm_run_slot(q, slot_in_sf); }
+void srslte_ofdm_tx_slot(srslte_ofdm_t* q, int slot_in_sf) { ofdm_run_slot(q, slot_in_sf); }
+
+// ====================================================================================================== transform precoding
+bool srslte_dft_precoding_valid_prb(uint32_t nof_prb) { return srslte_hip_dft_precoding_valid_prb(nof_prb) != 0; }
+
+int srslte_dft_precoding_init(srslte_dft_precoding_t* q, uint32_t max_prb, bool is_tx)
+{ // dft_precoding.c:39-69: one normalised plan per valid nof_prb
+  if (!q || max_prb > SRSLTE_MAX_PRB) return SRSLTE_ERROR_INVALID_INPUTS;
+  memset(q, 0, sizeof(*q));
+  for (uint32_t i = 1; i <= max_prb; i++) {
+    if (srslte_dft_precoding_valid_prb(i)) {
+      if (srslte_dft_plan_c(&q->dft_plan[i], 12 * (int)i, is_tx ? SRSLTE_DFT_FORWARD : SRSLTE_DFT_BACKWARD)) {
+        srslte_dft_precoding_free(q);
+        return SRSLTE_ERROR;
+      }
+      srslte_dft_plan_set_norm(&q->dft_plan[i], true);
+    }
+  }
+  q->max_prb = max_prb;
+  return SRSLTE_SUCCESS;
+}
+int  srslte_dft_precoding_init_tx(srslte_dft_precoding_t* q, uint32_t max_prb) { return srslte_dft_precoding_init(q, max_prb, true); }
+int  srslte_dft_precoding_init_rx(srslte_dft_precoding_t* q, uint32_t max_prb) { return srslte_dft_precoding_init(q, max_prb, false); }
+void srslte_dft_precoding_free(srslte_dft_precoding_t* q)
+{
+  for (uint32_t i = 1; i <= q->max_prb && i <= SRSLTE_MAX_PRB; i++) {
+    if (srslte_dft_precoding_valid_prb(i)) srslte_dft_plan_free(&q->dft_plan[i]);
+  }
+  memset(q, 0, sizeof(*q));
+}
+
+int srslte_dft_precoding(srslte_dft_precoding_t* q, cf_t* input, cf_t* output, uint32_t nof_prb, uint32_t nof_symbols)
+{ // dft_precoding.c:100-113
+  if (!srslte_dft_precoding_valid_prb(nof_prb) || nof_prb > q->max_prb) {
+    ERROR("Error invalid number of PRB (%u)", nof_prb);
+    return SRSLTE_ERROR;
+  }
+  srslte_dft_plan_t* plan = &q->dft_plan[nof_prb];
+  auto*              st   = (DftState*)plan->p;
+  const int          N    = 12 * (int)nof_prb;
+  const size_t       n    = sizeof(cf_t) * (size_t)N * nof_symbols;
+  void *             di = st->in.get(n), *dout = st->out.get(n);
+  if (!di || !dout || !h2d(di, input, n)) return SRSLTE_ERROR;
+  if (srslte_hip_dft_precoding_batch(di, dout, nof_prb, nof_symbols, plan->forward ? 1 : 0, nullptr)) return SRSLTE_ERROR;
+  return d2h(output, dout, n) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+
+// ====================================================================================================== segmentation / interleaver
+int  srslte_cbsegm(srslte_cbsegm_t* s, uint32_t tbs) { return srslte_hip_cbsegm((srslte_hip_cbsegm_t*)s, tbs); }
+int  srslte_cbsegm_cbsize(uint32_t index) { return srslte_hip_cbsegm_cbsize(index); }
+int  srslte_cbsegm_cbindex(uint32_t long_cb) { return srslte_hip_cbsegm_cbindex(long_cb); }
+bool srslte_cbsegm_cbsize_isvalid(uint32_t size)
+{
+  const int i = lte_cb_index(size);
+  return i >= 0 && lte_qpp_table[i].K == size;
+}
+
+int srslte_tc_interl_init(srslte_tc_interl_t* h, uint32_t max_long_cb)
+{ // tc_interl_umts.c-style allocation used by both interleavers
+  h->forward = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
+  h->reverse = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
+  if (!h->forward || !h->reverse) {
+    free(h->forward);
+    free(h->reverse);
+    return SRSLTE_ERROR;
+  }
+  h->max_long_cb = max_long_cb;
+  return SRSLTE_SUCCESS;
+}
+void srslte_tc_interl_free(srslte_tc_interl_t* h)
+{
+  free(h->forward);
+  free(h->reverse);
+  memset(h, 0, sizeof(*h));
+}
+int srslte_tc_interl_LTE_gen_interl(srslte_tc_interl_t* h, uint32_t long_cb, uint32_t interl_win)
+{ // tc_interl_lte.c:75-114
+  if (long_cb > h->max_long_cb) {
+    ERROR("Interleaver initiated for max_long_cb=%u", h->max_long_cb);
+    return SRSLTE_ERROR;
+  }
+  return srslte_hip_tc_interl_LTE_gen_interl(h->forward, h->reverse, long_cb, interl_win);
+}
+int srslte_tc_interl_LTE_gen(srslte_tc_interl_t* h, uint32_t long_cb) { return srslte_tc_interl_LTE_gen_interl(h, long_cb, 1); }
+
+// ====================================================================================================== turbo encoder
+int srslte_tcod_init(srslte_tcod_t* h, uint32_t max_long_cb)
+{ // turbocoder.c:49-60
+  h->max_long_cb = max_long_cb;
+  h->temp        = (uint8_t*)host_alloc(max_long_cb / 8 + 1);
+  return h->temp ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+void srslte_tcod_free(srslte_tcod_t* h)
+{
+  h->max_long_cb = 0;
+  free(h->temp);
+  h->temp = nullptr;
+}
+int srslte_tcod_encode(srslte_tcod_t* h, uint8_t* input, uint8_t* output, uint32_t long_cb)
+{ // turbocoder.c:76-186
+  if (long_cb > h->max_long_cb) {
+    ERROR("Turbo coder initiated for max_long_cb=%u", h->max_long_cb);
+    return SRSLTE_ERROR;
+  }
+  void *di = g_tcod_in.get(long_cb), *dout = g_tcod_out.get(3 * long_cb + 12);
+  if (!di || !dout || !h2d(di, input, long_cb)) return SRSLTE_ERROR;
+  if (srslte_hip_tcod_encode_batch((const uint8_t*)di, (uint8_t*)dout, long_cb, 1, nullptr)) return SRSLTE_ERROR;
+  return d2h(output, dout, 3 * long_cb + 12) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+
+// ====================================================================================================== turbo decoder
+uint32_t srslte_tdec_autoimp_get_subblocks(uint32_t long_cb) { return srslte_hip_tdec_autoimp_get_subblocks(long_cb); }
+
+int srslte_tdec_init_manual(srslte_tdec_t* h, uint32_t max_long_cb, srslte_tdec_impl_type_t dec_type)
+{ // turbodecoder.c:165-330: 16-bit back-ends only; the device object replaces app/ext/beta work buffers
+  if (!h) return SRSLTE_ERROR_INVALID_INPUTS;
+  memset(h, 0, sizeof(*h));
+  switch (dec_type) {
+    case SRSLTE_TDEC_AUTO:
+    case SRSLTE_TDEC_GENERIC:
+    case SRSLTE_TDEC_SSE_WINDOW:
+    case SRSLTE_TDEC_AVX_WINDOW: break;
+    default: ERROR("Error decoder %d not supported", (int)dec_type); return SRSLTE_ERROR;
+  }
+  auto* st = new TdecState();
+  st->h    = srslte_hip_tdec_create(max_long_cb, 1);
+  if (!st->h) {
+    delete st;
+    return SRSLTE_ERROR;
+  }
+  h->dec16_hdlr[0]    = st;
+  h->max_long_cb      = max_long_cb;
+  h->dec_type         = dec_type;
+  h->current_llr_type = SRSLTE_TDEC_16;
+  h->current_cbidx    = -1;
+  return SRSLTE_SUCCESS;
+}
+int srslte_tdec_init(srslte_tdec_t* h, uint32_t max_long_cb) { return srslte_tdec_init_manual(h, max_long_cb, SRSLTE_TDEC_AUTO); }
+
+void srslte_tdec_free(srslte_tdec_t* h)
+{
+  auto* st = (TdecState*)h->dec16_hdlr[0];
+  if (st) {
+    srslte_hip_tdec_destroy(st->h);
+    st->in.release();
+    st->out.release();
+    delete st;
+  }
+  memset(h, 0, sizeof(*h));
+}
+void srslte_tdec_force_not_sb(srslte_tdec_t* h) { h->force_not_sb = true; }
+int  srslte_tdec_get_nof_iterations(srslte_tdec_t* h) { return h->n_iter; }
+
+int srslte_tdec_new_cb(srslte_tdec_t* h, uint32_t long_cb)
+{ // turbodecoder.c:522-537
+  if (long_cb > h->max_long_cb) {
+    ERROR("TDEC was initialized for max_long_cb=%u", h->max_long_cb);
+    return SRSLTE_ERROR;
+  }
+  h->n_iter          = 0;
+  h->current_long_cb = long_cb;
+  h->current_cbidx   = srslte_cbsegm_cbindex(long_cb);
+  if (h->current_cbidx < 0 || lte_qpp_table[h->current_cbidx].K != long_cb) {
+    ERROR("Invalid CB length %u", long_cb);
+    h->current_cbidx = -1;
+    return SRSLTE_ERROR;
+  }
+  return SRSLTE_SUCCESS;
+}
+
+static int tdec_passes(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t passes)
+{
+  auto*          st = (TdecState*)h->dec16_hdlr[0];
+  const uint32_t K  = h->current_long_cb;
+  int            W  = -1; // AUTO (turbodecoder.c:408-420)
+  if (h->dec_type == SRSLTE_TDEC_GENERIC) W = 0;
+  if (h->dec_type == SRSLTE_TDEC_SSE_WINDOW) W = 8;
+  if (h->dec_type == SRSLTE_TDEC_AVX_WINDOW) W = 16;
+  const uint32_t nsb = W < 0 ? srslte_hip_tdec_autoimp_get_subblocks(K) : (uint32_t)W;
+  const int      sb  = (!h->force_not_sb && nsb > 0) ? 1 : 0; // turbodecoder_iter.h:84
+  const uint32_t len = srslte_hip_tdec_input_len(K, sb);
+  void *         di = st->in.get(len * sizeof(int16_t)), *dout = st->out.get(K / 8);
+  if (!di || !dout || !h2d(di, input, len * sizeof(int16_t))) return SRSLTE_ERROR;
+  if (tdec_run_batch_w(st->h, (const int16_t*)di, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, nullptr))
+    return SRSLTE_ERROR;
+  return d2h(output, dout, K / 8) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+
+void srslte_tdec_iteration(srslte_tdec_t* h, int16_t* input, uint8_t* output)
+{ // turbodecoder.c:539-545. One more SISO pass: the device re-runs passes 1..n_iter+1 from the unchanged input, which is
+  // bit-identical to continuing the previous state (the schedule is deterministic) and keeps the object stateless on device.
+  if (h->current_cbidx >= 0) {
+    if (tdec_passes(h, input, output, (uint32_t)h->n_iter + 1) == SRSLTE_SUCCESS) h->n_iter++;
+  } else {
+    ERROR("Error CB index not set (call srslte_tdec_new_cb() first");
+  }
+}
+
+int srslte_tdec_run_all(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{ // turbodecoder.c:547-562
+  if (srslte_tdec_new_cb(h, long_cb)) return SRSLTE_ERROR;
+  if (nof_iterations == 0) nof_iterations = 1; // do { } while: at least one pass
+  if (tdec_passes(h, input, output, nof_iterations)) return SRSLTE_ERROR;
+  h->n_iter = (int)nof_iterations;
+  return SRSLTE_SUCCESS;
+}
+
+// ====================================================================================================== channel estimator
+int srslte_chest_dl_init(srslte_chest_dl_t* q, uint32_t max_prb, uint32_t nof_rx_antennas)
+{ // chest_dl.c:69-160
+  if (!q || nof_rx_antennas == 0 || nof_rx_antennas > SRSLTE_MAX_PORTS || max_prb > SRSLTE_MAX_PRB) return SRSLTE_ERROR_INVALID_INPUTS;
+  memset(q, 0, sizeof(*q));
+  q->nof_rx_antennas = nof_rx_antennas;
+  q->tmp_noise       = (cf_t*)new ChestState(); // opaque slot for the device state
+  return SRSLTE_SUCCESS;
+}
+
+static void chest_drop_cell(srslte_chest_dl_t* q)
+{
+  auto* st = (ChestState*)q->tmp_noise;
+  if (st && st->h) {
+    srslte_hip_chest_dl_destroy(st->h);
+    st->h = nullptr;
+  }
+  for (int sf = 0; sf < SRSLTE_NOF_SF_X_FRAME; sf++) {
+    free(q->csr_refs.pilots[0][sf]);
+    q->csr_refs.pilots[0][sf] = nullptr;
+  }
+}
+
+void srslte_chest_dl_free(srslte_chest_dl_t* q)
+{ // chest_dl.c:162-191
+  if (!q) return;
+  chest_drop_cell(q);
+  auto* st = (ChestState*)q->tmp_noise;
+  if (st) {
+    st->grid.release();
+    st->ce.release();
+    st->res.release();
+    delete st;
+  }
+  memset(q, 0, sizeof(*q));
+}
+
+int srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell)
+{ // chest_dl.c:244-300
+  if (!q || !q->tmp_noise || cell.nof_prb < 6 || cell.nof_prb > SRSLTE_MAX_PRB || cell.id > 503) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->cell.id == cell.id && q->cell.nof_prb == cell.nof_prb && ((ChestState*)q->tmp_noise)->h) return SRSLTE_SUCCESS;
+  chest_drop_cell(q);
+  auto* st = (ChestState*)q->tmp_noise;
+  st->h    = srslte_hip_chest_dl_create(cell.id, cell.nof_prb, cell.nof_ports, cell.cp == SRSLTE_CP_NORM);
+  if (!st->h) return SRSLTE_ERROR;
+  q->cell          = cell;
+  q->csr_refs.cell = cell;
+  // host copy of the CRS values for callers that use srslte_refsignal_cs_put_sf(&q->csr_refs, ...) (chest_test_dl.c:154)
+  const size_t npil = (size_t)4 * 2 * cell.nof_prb;
+  for (int sf = 0; sf < SRSLTE_NOF_SF_X_FRAME; sf++) {
+    q->csr_refs.pilots[0][sf] = (cf_t*)host_alloc(sizeof(cf_t) * npil);
+    if (!q->csr_refs.pilots[0][sf] ||
+        !d2h(q->csr_refs.pilots[0][sf], (const char*)srslte_hip_chest_dl_pilots(st->h) + sizeof(cf_t) * npil * sf, sizeof(cf_t) * npil))
+      return SRSLTE_ERROR;
+  }
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_chest_dl_res_init(srslte_chest_dl_res_t* q, uint32_t max_prb)
+{ // chest_dl.c:193-210
+  memset(q, 0, sizeof(*q));
+  q->nof_re = 14 * 12 * max_prb;
+  for (int i = 0; i < SRSLTE_MAX_PORTS; i++) {
+    for (int j = 0; j < SRSLTE_MAX_PORTS; j++) {
+      q->ce[i][j] = (cf_t*)host_alloc(sizeof(cf_t) * q->nof_re);
+      if (!q->ce[i][j]) return SRSLTE_ERROR;
+      bzero(q->ce[i][j], sizeof(cf_t) * q->nof_re);
+    }
+  }
+  return SRSLTE_SUCCESS;
+}
+static void res_fill(srslte_chest_dl_res_t* q, bool identity)
+{
+  for (int i = 0; i < SRSLTE_MAX_PORTS; i++) {
+    for (int j = 0; j < SRSLTE_MAX_PORTS; j++) {
+      float* p = (float*)q->ce[i][j];
+      if (!p) continue;
+      for (uint32_t k = 0; k < q->nof_re; k++) {
+        p[2 * k]     = (!identity || i == j) ? 1.0f : 0.0f;
+        p[2 * k + 1] = 0.0f;
+      }
+    }
+  }
+}
+void srslte_chest_dl_res_set_identity(srslte_chest_dl_res_t* q) { res_fill(q, true); } // chest_dl.c:212-221
+void srslte_chest_dl_res_set_ones(srslte_chest_dl_res_t* q) { res_fill(q, false); }    // chest_dl.c:223-231
+void srslte_chest_dl_res_free(srslte_chest_dl_res_t* q)
+{
+  for (int i = 0; i < SRSLTE_MAX_PORTS; i++) {
+    for (int j = 0; j < SRSLTE_MAX_PORTS; j++) free(q->ce[i][j]);
+  }
+  memset(q, 0, sizeof(*q));
+}
+
+int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg, cf_t* input[SRSLTE_MAX_PORTS],
+                                 srslte_chest_dl_res_t* res)
+{ // chest_dl.c:884-908
+  auto* st = q ? (ChestState*)q->tmp_noise : nullptr;
+  if (!st || !st->h || !sf || !cfg || !input || !input[0] || !res) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->nof_rx_antennas != 1 || q->cell.nof_ports != 1 || sf->sf_type != SRSLTE_SF_NORM) {
+    ERROR("chest_dl: only 1 rx antenna / 1 port / normal subframes are implemented on device");
+    return SRSLTE_ERROR;
+  }
+  const size_t n = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
+  void *       dg = st->grid.get(n), *dce = st->ce.get(n), *dres = st->res.get(sizeof(srslte_hip_chest_dl_res_t));
+  if (!dg || !dce || !dres || !h2d(dg, input[0], n)) return SRSLTE_ERROR;
+  srslte_hip_chest_dl_cfg_t hc;
+  memset(&hc, 0, sizeof(hc));
+  hc.noise_alg = cfg->noise_alg; hc.filter_type = cfg->filter_type; hc.filter_coef[0] = cfg->filter_coef[0]; hc.filter_coef[1] = cfg->filter_coef[1];
+  hc.interpolate_subframe = cfg->interpolate_subframe; hc.rsrp_neighbour = cfg->rsrp_neighbour;
+  hc.cfo_estimate_enable  = cfg->cfo_estimate_enable && ((1u << (sf->tti % 10)) & cfg->cfo_estimate_sf_mask);
+  hc.cfo_estimate_sf_mask = cfg->cfo_estimate_sf_mask; hc.sync_error_enable = cfg->sync_error_enable;
+  cf_t* ce = res->ce[0][0];
+  if (srslte_hip_chest_dl_estimate_batch(st->h, &hc, sf->tti % 10, dg, ce ? dce : nullptr, dres, 1, nullptr)) return SRSLTE_ERROR;
+  srslte_hip_chest_dl_res_t r;
+  if (!d2h(&r, dres, sizeof(r)) || (ce && !d2h(ce, dce, n))) return SRSLTE_ERROR;
+  // fill_res, chest_dl.c:845-871
+  q->noise_estimate[0][0] = r.noise_estimate;
+  q->rsrp[0][0]           = r.rsrp;
+  if (hc.cfo_estimate_enable) q->cfo = r.cfo;
+  q->sync_err[0][0]       = NAN;
+  res->noise_estimate = r.noise_estimate; res->noise_estimate_dbm = r.noise_estimate_dbm; res->snr_db = r.snr_db;
+  res->rsrp = r.rsrp; res->rsrp_dbm = r.rsrp_dbm; res->rsrq = r.rsrq; res->rsrq_db = r.rsrq_db; res->rssi_dbm = r.rssi_dbm;
+  res->cfo = q->cfo; res->sync_error = NAN; res->rsrp_neigh = 0.f;
+  res->rsrp_port_dbm[0] = r.rsrp_dbm; res->snr_ant_port_db[0][0] = r.snr_db; res->rsrp_ant_port_dbm[0][0] = r.rsrp_dbm;
+  res->rsrq_ant_port_db[0][0] = r.rsrq_db;
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_chest_dl_estimate(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res)
+{ // chest_dl.c:873-882: all-zero configuration
+  srslte_chest_dl_cfg_t cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  return srslte_chest_dl_estimate_cfg(q, sf, &cfg, input, res);
+}
+
+// ====================================================================================================== soft demapper
+static int demod_host(int type, srslte_mod_t mod, const cf_t* symbols, void* llr, int nsymbols, size_t llr_elem)
+{
+  if ((int)mod < 0 || (int)mod > 4) {
+    ERROR("Invalid modulation %d", (int)mod);
+    return SRSLTE_ERROR;
+  }
+  if (nsymbols <= 0) return SRSLTE_SUCCESS;
+  const int    Qm = mod == SRSLTE_MOD_BPSK ? 1 : 2 * (int)mod;
+  const size_t nin = sizeof(cf_t) * nsymbols, nout = llr_elem * Qm * nsymbols;
+  void *       di = g_demod_in.get(nin), *dout = g_demod_out.get(nout);
+  if (!di || !dout || !h2d(di, symbols, nin)) return SRSLTE_ERROR;
+  if (demod_launch(type, (int)mod, di, dout, nsymbols, 1, nullptr, 0, 0, nullptr)) return SRSLTE_ERROR;
+  return d2h(llr, dout, nout) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+int srslte_demod_soft_demodulate(srslte_mod_t m, const cf_t* s, float* llr, int n) { return demod_host(0, m, s, llr, n, sizeof(float)); }
+int srslte_demod_soft_demodulate_s(srslte_mod_t m, const cf_t* s, short* llr, int n) { return demod_host(1, m, s, llr, n, sizeof(short)); }
+int srslte_demod_soft_demodulate_b(srslte_mod_t m, const cf_t* s, int8_t* llr, int n) { return demod_host(2, m, s, llr, n, sizeof(int8_t)); }
+
+} // extern "C"

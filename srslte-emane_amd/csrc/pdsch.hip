@@ -22,10 +22,6 @@
 #include <string.h>
 #include <vector>
 
-int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
-                     uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
-                     uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st);
-
 namespace {
 
 struct ChestResDev {

@@ -1,0 +1,57 @@
+"""sizeof/offsetof of every public struct in include/srslte_hip/srslte_compat.h against the reference headers.
+Callers embed these structs by value and poke their fields, so the layouts must be identical.
+Needs the reference headers: skipped where /root/reference is absent (the GPU box)."""
+import os
+import subprocess
+import tempfile
+
+import pytest
+
+from _libs import ROOT
+
+REF_INC = "/root/reference/lib/include"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF_INC), reason="reference headers not available")
+
+STRUCTS = {
+    "srslte_cell_t": ["nof_prb", "nof_ports", "id", "cp", "phich_length", "phich_resources", "frame_type"],
+    "srslte_dl_sf_cfg_t": ["tdd_config", "tti", "cfi", "sf_type", "non_mbsfn_region"],
+    "srslte_dft_plan_t": ["init_size", "size", "in", "out", "p", "is_guru", "forward", "mirror", "db", "norm", "dc", "dir", "mode"],
+    "srslte_ofdm_t": ["fft_plan", "fft_plan_sf", "max_prb", "nof_symbols", "symbol_sz", "nof_guards", "nof_re", "slot_sz", "sf_sz", "cp", "tmp",
+                      "in_buffer", "out_buffer", "mbsfn_subframe", "mbsfn_guard_len", "nof_symbols_mbsfn", "non_mbsfn_region", "freq_shift",
+                      "freq_shift_f", "shift_buffer"],
+    "srslte_dft_precoding_t": ["max_prb", "dft_plan"],
+    "srslte_cbsegm_t": ["F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs"],
+    "srslte_tc_interl_t": ["forward", "reverse", "max_long_cb"],
+    "srslte_tcod_t": ["max_long_cb", "temp"],
+    "srslte_tdec_t": ["max_long_cb", "dec8_hdlr", "dec16_hdlr", "dec8", "dec16", "nof_blocks8", "nof_blocks16", "app1", "app2", "ext1", "ext2", "syst0",
+                      "parity0", "parity1", "input_conv", "force_not_sb", "dec_type", "current_llr_type", "current_dec", "current_long_cb",
+                      "current_inter_idx", "current_cbidx", "interleaver", "n_iter"],
+    "srslte_refsignal_t": ["cell", "pilots", "type", "mbsfn_area_id"],
+    "srslte_chest_dl_res_t": ["ce", "nof_re", "noise_estimate", "noise_estimate_dbm", "snr_db", "snr_ant_port_db", "rsrp", "rsrp_dbm", "rsrp_neigh",
+                              "rsrp_port_dbm", "rsrp_ant_port_dbm", "rsrq", "rsrq_db", "rsrq_ant_port_db", "rssi_dbm", "cfo", "sync_error"],
+    "srslte_chest_dl_t": ["cell", "nof_rx_antennas", "csr_refs", "mbsfn_refs", "pilot_estimates", "pilot_estimates_average", "pilot_recv_signal",
+                          "tmp_noise", "tmp_cfo_estimate", "srslte_interp_linvec", "srslte_interp_lin", "srslte_interp_lin_3",
+                          "srslte_interp_lin_mbsfn", "rssi", "rsrp", "rsrp_corr", "noise_estimate", "sync_err", "cfo", "pss_signal", "tmp_pss",
+                          "tmp_pss_noisy"],
+    "srslte_chest_dl_cfg_t": ["noise_alg", "filter_type", "filter_coef", "mbsfn_area_id", "interpolate_subframe", "rsrp_neighbour",
+                              "cfo_estimate_enable", "cfo_estimate_sf_mask", "sync_error_enable"],
+}
+
+
+def layout(includes, incdirs):
+    body = "\n".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (s, s) + "".join('  printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (s, f, s, f) for f in fs)
+                     for s, fs in STRUCTS.items())
+    src = "#include <stdio.h>\n#include <stddef.h>\n" + "".join('#include "%s"\n' % i for i in includes) + "int main(void) {\n" + body + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "l.c"), os.path.join(d, "l")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-w"] + ["-I" + i for i in incdirs] + [c, "-o", exe])
+        return dict(line.split() for line in subprocess.check_output([exe]).decode().splitlines())
+
+
+def test_struct_layouts_match_reference():
+    ref = layout(["srslte/phy/dft/ofdm.h", "srslte/phy/dft/dft_precoding.h", "srslte/phy/fec/cbsegm.h", "srslte/phy/fec/tc_interl.h",
+                  "srslte/phy/fec/turbocoder.h", "srslte/phy/fec/turbodecoder.h", "srslte/phy/ch_estimation/chest_dl.h"], [REF_INC])
+    ours = layout(["srslte_hip/srslte_compat.h"], [os.path.join(ROOT, "include")])
+    diff = {k: (ref[k], ours.get(k)) for k in ref if ref[k] != ours.get(k)}
+    assert not diff, "layout differences (reference, ours): %s" % diff

@@ -1,0 +1,165 @@
+"""The reference's own single-call API (include/srslte_hip/srslte_compat.h) served by the HIP library: host pointers in
+and out, same names/arguments/error codes. Written the way the reference's unit tests drive these calls
+(ofdm_test.c, dft_test.c, turbodecoder_test.c, chest_test_dl.c, soft_demod_test.c), checked against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from _libs import (OrcCell, OrcChestCfg, OrcChestRes, OrcOfdm, RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, acopy, aligned, hip, opaque, oracle, p)
+
+pytestmark = pytest.mark.gpu
+
+
+class DftPlan(C.Structure):
+    _fields_ = [("init_size", C.c_int), ("size", C.c_int), ("in_", C.c_void_p), ("out", C.c_void_p), ("p", C.c_void_p), ("is_guru", C.c_bool),
+                ("forward", C.c_bool), ("mirror", C.c_bool), ("db", C.c_bool), ("norm", C.c_bool), ("dc", C.c_bool), ("dir", C.c_int), ("mode", C.c_int)]
+
+
+def close(a, b, tol=1e-4):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    return np.abs(a - b).max() <= tol * max(np.abs(b).max(), np.sqrt((np.abs(b) ** 2).mean()))
+
+
+@pytest.mark.parametrize("prb", [6, 25, 100])
+def test_ofdm_objects(prb):
+    """ofdm_test.c:74-179: tx -> rx round trip through srslte_ofdm_t objects bound to caller buffers."""
+    L, rng = hip(), np.random.default_rng(prb)
+    N = L.srslte_symbol_sz(prb)
+    nre, sf = 14 * 12 * prb, 15 * N
+    grid_in, time_buf, grid_out = aligned(2 * nre, np.float32), aligned(2 * sf, np.float32), aligned(2 * nre, np.float32)
+    tx, rx = opaque(4096), opaque(4096)
+    assert L.srslte_ofdm_tx_init(tx, 0, p(grid_in), p(time_buf), prb) == 0
+    assert L.srslte_ofdm_rx_init(rx, 0, p(time_buf), p(grid_out), prb) == 0
+    L.srslte_ofdm_set_normalize(tx, True)
+    L.srslte_ofdm_set_normalize(rx, True)
+    g = (rng.standard_normal(nre) + 1j * rng.standard_normal(nre)).astype(np.complex64)
+    grid_in.view(np.complex64)[:] = g
+    L.srslte_ofdm_tx_sf(tx)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    q.normalize = True
+    ref_t = np.zeros(sf, np.complex64)
+    oracle().orc_ofdm_tx_sf(C.byref(q), p(g), p(ref_t))
+    assert close(time_buf.view(np.complex64), ref_t)
+    L.srslte_ofdm_rx_sf(rx)
+    assert np.mean(np.abs(grid_out.view(np.complex64) - g) ** 2) < 1e-9  # ofdm_test.c:155 accepts 0.07
+    L.srslte_ofdm_tx_free(tx)
+    L.srslte_ofdm_rx_free(rx)
+    assert L.srslte_ofdm_rx_init(rx, 0, p(time_buf), p(grid_out), 111) == -1  # ofdm.c:237-240
+
+
+@pytest.mark.parametrize("N", [128, 1536, 12 * 25])
+def test_dft_plan_options(N):
+    """dft_test.c:80-130: forward o backward identity for the mirror/dc/norm option combinations + direct check."""
+    L, rng = hip(), np.random.default_rng(N)
+    x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
+    for mirror, dc, norm in ((False, False, False), (True, False, True), (True, True, True), (False, False, True)):
+        fwd, bwd = DftPlan(), DftPlan()
+        assert L.srslte_dft_plan_c(C.byref(fwd), N, 0) == 0 and L.srslte_dft_plan_c(C.byref(bwd), N, 1) == 0
+        for pl in (fwd, bwd):
+            L.srslte_dft_plan_set_mirror(C.byref(pl), mirror)
+            L.srslte_dft_plan_set_dc(C.byref(pl), dc)
+            L.srslte_dft_plan_set_norm(C.byref(pl), norm)
+        y, z = np.zeros(N, np.complex64), np.zeros(N, np.complex64)
+        L.srslte_dft_run_c(C.byref(fwd), p(x), p(y))
+        if not mirror:
+            ref = np.zeros(N, np.complex64)
+            oracle().orc_dft_exact(p(x), p(ref), N, 1)
+            assert close(y, ref / (np.sqrt(N) if norm else 1.0))
+        L.srslte_dft_run_c(C.byref(bwd), p(y), p(z))
+        if dc:
+            pass  # the DC bin is dropped on the way: identity does not hold (dft_test.c skips the comparison of bin 0 likewise)
+        else:
+            scale = 1.0 if norm else float(N)
+            assert np.abs(z / scale - x).max() < 1e-4 * np.abs(x).max() * 10
+        L.srslte_dft_plan_free(C.byref(fwd))
+        L.srslte_dft_plan_free(C.byref(bwd))
+    bad = DftPlan()
+    assert L.srslte_dft_plan_c(C.byref(bad), 7 * 12, 0) == -1
+
+
+def test_dft_precoding_object():
+    L, rng = hip(), np.random.default_rng(3)
+    q = opaque(1 << 16)
+    assert L.srslte_dft_precoding_init_tx(q, 100) == 0
+    for nprb in (1, 6, 25, 100):
+        x = (rng.standard_normal(12 * 12 * nprb) + 1j * rng.standard_normal(12 * 12 * nprb)).astype(np.complex64)
+        y, ref = np.zeros_like(x), np.zeros_like(x)
+        assert L.srslte_dft_precoding(q, p(x), p(y), nprb, 12) == 0
+        oracle().orc_dft_precoding(p(x), p(ref), nprb, 12, 1, True)
+        assert close(y, ref)
+    assert L.srslte_dft_precoding(q, p(x), p(y), 7, 12) == -1
+    L.srslte_dft_precoding_free(q)
+
+
+@pytest.mark.parametrize("K", [176, 504, 5824])
+def test_tdec_object(K):
+    """turbodecoder_test.c:117-311: tcod_encode -> noisy LLRs -> srslte_tdec_run_all, and the per-iteration API."""
+    L, rng = hip(), np.random.default_rng(K)
+    tcod, tdec = opaque(64), opaque(1 << 16)
+    assert L.srslte_tcod_init(tcod, 6144) == 0 and L.srslte_tdec_init(tdec, 6144) == 0
+    bits = rng.integers(0, 2, K).astype(np.uint8)
+    enc, ref_enc = np.zeros(3 * K + 12, np.uint8), np.zeros(3 * K + 12, np.uint8)
+    assert L.srslte_tcod_encode(tcod, p(bits), p(enc), K) == 0
+    oracle().orc_tcod_encode_bits(p(bits), p(ref_enc), K)
+    assert np.array_equal(enc, ref_enc)
+    llr = (100 * ((2.0 * enc - 1) + 0.9 * rng.standard_normal(enc.shape))).astype(np.int16)
+    L.srslte_tdec_force_not_sb(tdec)
+    out, ref = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8)
+    assert L.srslte_tdec_run_all(tdec, p(llr), p(out), 4, K) == 0
+    oracle().orc_tdec_run(p(llr), False, K, 4, p(ref), None)
+    assert np.array_equal(out, ref) and L.srslte_tdec_get_nof_iterations(tdec) == 4
+    per = np.zeros((6, K // 8), np.uint8)
+    oracle().orc_tdec_run(p(llr), False, K, 6, p(ref), p(per))
+    assert L.srslte_tdec_new_cb(tdec, K) == 0
+    for it in range(6):  # sch.c:353-383 drives it like this
+        L.srslte_tdec_iteration(tdec, p(llr), p(out))
+        assert np.array_equal(out, per[it]) and L.srslte_tdec_get_nof_iterations(tdec) == it + 1
+    assert L.srslte_tdec_new_cb(tdec, 41) == -1 and L.srslte_tdec_new_cb(tdec, 6145) == -1
+    L.srslte_tdec_free(tdec)
+    L.srslte_tcod_free(tcod)
+
+
+def test_chest_dl_object():
+    """chest_test_dl.c:78-255: init, set_cell, res_init, estimate with the default configuration."""
+    L, rng = hip(), np.random.default_rng(4)
+    prb, cid = 25, 2
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0
+    assert L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    for sf_idx in (0, 4):
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        grid = acopy((g * ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))) + 0.05 * rng.standard_normal(n)).astype(np.complex64).view(np.float32))
+        sf = RefDlSfCfg()
+        sf.tti = 10 + sf_idx
+        inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+        assert L.srslte_chest_dl_estimate(est, C.byref(sf), inp, C.byref(res)) == 0
+        ref, rres, oc = np.zeros(n, np.complex64), OrcChestRes(), OrcChestCfg()
+        assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ref), C.byref(rres)) == 0
+        ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+        assert close(ce, ref)
+        assert abs(res.noise_estimate - rres.noise_estimate) <= 1e-4 * rres.noise_estimate and abs(res.snr_db - rres.snr_db) < 1e-3
+        assert abs(res.rsrp_dbm - rres.rsrp_dbm) < 1e-3 and np.isnan(res.sync_error)
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)
+
+
+@pytest.mark.parametrize("mod", [1, 2, 3, 4])
+def test_demod_calls(mod):
+    """soft_demod_test.c:118-249: srslte_demod_soft_demodulate{,_s,_b} on host arrays."""
+    L, rng = hip(), np.random.default_rng(mod)
+    nsym, qm = 1203, 2 * mod
+    x = acopy(rng.standard_normal(2 * nsym).astype(np.float32))
+    for fn, on, dt in (("srslte_demod_soft_demodulate", "orc_demod_soft_f", np.float32), ("srslte_demod_soft_demodulate_s", "orc_demod_soft_s", np.int16),
+                       ("srslte_demod_soft_demodulate_b", "orc_demod_soft_b", np.int8)):
+        a, b = np.zeros(nsym * qm, dt), np.zeros(nsym * qm, dt)
+        assert getattr(L, fn)(mod, p(x), p(a), nsym) == 0
+        getattr(oracle(), on)(mod, p(x), p(b), nsym)
+        assert np.array_equal(a, b) if dt != np.float32 else np.abs(a - b).max() < 1e-6
+    assert L.srslte_demod_soft_demodulate_s(9, p(x), p(a), nsym) == -1
