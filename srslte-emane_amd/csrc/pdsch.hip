@@ -6,7 +6,7 @@
 //   chest_dl_kernel (chest.hip)   srslte_chest_dl_estimate_cfg            chest_dl.c:884-908
 //   pdsch_demod_kernel (here)     srslte_pdsch_get x2 + srslte_predecoding_single + srslte_demod_soft_demodulate_s +
 //                                 srslte_scrambling_s_offset              pdsch.c:81-206,:760-779,:890-935, precoding.c:262-322
-//   rm_rx_kernel (here)           srslte_rm_turbo_rx_lut per code block   sch.c:318-346, rm_turbo.c:374-420
+//   rm_rx_kernel (here)           srslte_rm_turbo_rx_lut per code block   sch.c:318-346, rm_turbo.c:374-420 (gather form)
 //   tdec_*_kernel (tdec.hip)      srslte_tdec_new_cb/_iteration + CB CRC  sch.c:348-383
 //   tb_crc_kernel (here)          payload assembly + TB CRC24A            sch.c:401-410,:470-488
 // Single tx port, single rx antenna, full-band grant, rv 0 (first transmission), FDD, normal CP.
@@ -74,13 +74,16 @@ struct RmGeom {
   int nof_re[3];
 };
 
-// grid = (ceil(out_len/256), nof_sf*C): w[cb][tbl[n]] = sum_m e[rp + n + m*out_len]   (wrapping int16, rm_turbo.c:407-409)
-__global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ tbl,
+// grid = (ceil(w_stride/512), nof_sf*C): gather form of w[deint[i]] += e[i] (wrapping int16, rm_turbo.c:407-409).
+// inv[j] = circular-buffer position n that lands on soft-buffer slot j (0xffffffff for padding); a thread owns two
+// adjacent slots, sums their <= ceil(n_e/out_len) wraps from e and writes one dword: stores are coalesced and every
+// slot, padding included, is written exactly once (no memset, no atomics).
+__global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ inv,
                                                     RmGeom g)
 {
   const int cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C;
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= g.out_len) return;
+  const int j = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  if (j >= g.w_stride) return;
   const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)]; // nof_bits / Qm
   const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
   int       rp = cb * n_e, n_e2 = n_e;
@@ -89,9 +92,15 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ 
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
   const int16_t* src = e + (size_t)sf * g.max_bits + rp;
-  int            acc = 0;
-  for (int i = n; i < n_e2; i += g.out_len) acc += src[i];
-  w[(size_t)cbg * g.w_stride + tbl[n]] = (int16_t)acc;
+  const uint2    n   = *reinterpret_cast<const uint2*>(inv + j);
+  int            a0 = 0, a1 = 0;
+  if (n.x != 0xffffffffu) {
+    for (int i = (int)n.x; i < n_e2; i += g.out_len) a0 += src[i];
+  }
+  if (n.y != 0xffffffffu) {
+    for (int i = (int)n.y; i < n_e2; i += g.out_len) a1 += src[i];
+  }
+  *reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j) = ((uint32_t)a0 & 0xffffu) | ((uint32_t)a1 << 16);
 }
 
 struct TbGeom {
@@ -252,7 +261,9 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
         v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
       }
     }
-    ok = upload(&q->d_rm_tbl, t) == SRSLTE_SUCCESS;
+    std::vector<uint32_t> inv(q->in_stride, 0xffffffffu); // slot -> circular-buffer position (in_stride is a multiple of 32)
+    for (uint32_t n = 0; n < t.size(); n++) inv[t[n]] = n;
+    ok = upload(&q->d_rm_tbl, inv) == SRSLTE_SUCCESS;
   }
   // TB CRC24A remainders x^(tbs+24-1-j) mod g
   if (ok) {
@@ -332,7 +343,7 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     case 3: {
       RmGeom g = q->rg;
       g.tti0   = (int)tti0;
-      hipLaunchKernelGGL(rm_rx_kernel, dim3(ceil_div(g.out_len, 256), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w,
+      hipLaunchKernelGGL(rm_rx_kernel, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w,
                          (const uint32_t*)q->d_rm_tbl, g);
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;

@@ -21,6 +21,7 @@
 #include "phy_hip_internal.hpp"
 #include <map>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -30,7 +31,9 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 typedef int   pk_t; // two int16 lanes: lo = first window of the pair, hi = second
 
 constexpr int TD_INF      = 10000;
+constexpr int SRSLTE_HIP_MAX_K = 6144;
 constexpr int WIN_OVERLAP = 40;
+constexpr int CKPT        = 24; // beta checkpoint spacing = alpha segment length (multiple of 6)
 
 __device__ __forceinline__ v2s  as_v(pk_t a) { return __builtin_bit_cast(v2s, a); }
 __device__ __forceinline__ pk_t as_p(v2s a) { return __builtin_bit_cast(pk_t, a); }
@@ -69,6 +72,7 @@ __device__ __forceinline__ pk_t bcast_slot0(pk_t v)
 struct LaneGeom {
   int  lane, p, g;
   bool p0, p1, p2;
+  int  m0, m1, m2; // all-ones where slot bit 0 / 1 / 2 is set: VGPR masks for v_bfi selections (no SGPR mask traffic)
 };
 __device__ __forceinline__ LaneGeom lane_geom()
 {
@@ -79,6 +83,9 @@ __device__ __forceinline__ LaneGeom lane_geom()
   L.p2   = (L.lane >> 3) & 1;
   L.p    = (L.lane & 3) | (((L.lane >> 3) & 1) << 2);
   L.g    = ((L.lane >> 2) & 1) | (((L.lane >> 4) & 3) << 1);
+  L.m0   = L.p0 ? -1 : 0;
+  L.m1   = L.p1 ? -1 : 0;
+  L.m2   = L.p2 ? -1 : 0;
   return L;
 }
 __device__ __forceinline__ int lane_of(int g, int p) { return (p & 3) | ((g & 1) << 2) | (((p >> 2) & 1) << 3) | ((g >> 1) << 4); }
@@ -99,10 +106,12 @@ __device__ __forceinline__ int rotl3(int s, int n)
 template <int PH, bool SAT>
 __device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y, pk_t xy, pk_t* t_own, pk_t* t_par)
 {
-  const bool b1 = PH == 0 ? L.p2 : (PH == 1 ? L.p0 : L.p1);
-  const bool b0 = PH == 0 ? L.p1 : (PH == 1 ? L.p2 : L.p0);
-  const pk_t g_own = b1 ? (b0 ? xy : y) : (b0 ? x : 0);
-  const pk_t g_par = b1 ? (b0 ? 0 : x) : (b0 ? y : xy);
+  const int  b1 = PH == 0 ? L.m2 : (PH == 1 ? L.m0 : L.m1); // state bit 2 of this slot at this phase, as a mask
+  const int  b0 = PH == 0 ? L.m1 : (PH == 1 ? L.m2 : L.m0); // state bit 1
+#define BFI(m, a, b) (((a) & (m)) | ((b) & ~(m)))               /* v_bfi_b32 */
+  const pk_t g_own = BFI(b1, BFI(b0, xy, y), x & b0);
+  const pk_t g_par = BFI(b1, x & ~b0, BFI(b0, y, xy));
+#undef BFI
   const pk_t po    = dpp_partner<PH>(old);
   *t_own           = pk_add<SAT>(old, g_own);
   *t_par           = pk_add<SAT>(po, g_par);
@@ -139,6 +148,7 @@ struct TdecArgs {
   uint32_t*      iters;
   uint8_t*       crc_ok;
   TdecTables     t;
+  int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise phases
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -161,9 +171,9 @@ __device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, int2 in, pk
   const pk_t     x = in.x, y = in.y, xy = pk_add<SAT>(x, y);
   v = acs<PH, SAT>(L, v, x, y, xy, &to, &tp);
   if constexpr (MODE == 2) {
-    const bool b0 = PH == 0 ? L.p1 : (PH == 1 ? L.p2 : L.p0); // own transition carries info bit b0
-    const pk_t m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
-    const pk_t m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
+    const int  b0 = PH == 0 ? L.m1 : (PH == 1 ? L.m2 : L.m0); // own transition carries info bit b0
+    const pk_t m0 = group_max(pk_add<SAT>(B, (tp & b0) | (to & ~b0)));
+    const pk_t m1 = group_max(pk_add<SAT>(B, (to & b0) | (tp & ~b0)));
     o             = pk_sub<SAT>(m1, m0);
     if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
   }
@@ -189,7 +199,7 @@ __device__ __forceinline__ void store_out(int16_t* out, int k, int g, pk_t o)
 // by hand from inline asm were tried and are unsafe at this register pressure: the allocator copies them.)
 template <int W, int BLK, int PH0, int DIR, int MODE, int NPAR0>
 __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
-                                        int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out)
+                                        int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out, int& sink)
 {
   for (int b = 0; b < nb; b++) {
     const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b;
@@ -201,6 +211,10 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
       cb[j] = 0;
       if constexpr (MODE == 2) cb[j] = bl[(k0 + DIR * j + 1) * 64];
     }
+    // touch the next block's operands now (slot p takes every 3rd step: all of its cache lines) so that its loads hit L1/L2;
+    // the value is only consumed after this block's steps, i.e. the request never stalls the trellis chain
+    int pf = 0;
+    if (BLK >= 24 && b + 1 < nb) pf = my[k0 + DIR * (BLK + min(3 * L.p, BLK - 1))].x;
     pk_t keep = 0;
 #pragma unroll
     for (int j6 = 0; j6 < BLK; j6 += 6) {
@@ -209,7 +223,10 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
     constexpr int PH = DIR > 0 ? (PH0 + J) % 3 : (PH0 + 18 - J) % 3;              \
     pk_t          o  = 0;                                                         \
     win_step<PH, MODE, W>(L, v, c[j6 + J], cb[j6 + J], o);                        \
-    if constexpr (MODE == 1) beta[(k0 + DIR * (j6 + J)) * 64 + L.lane] = v;       \
+    if constexpr (MODE == 1) {                                                    \
+      const int kq = k0 + DIR * (j6 + J);                                         \
+      if (kq % CKPT == 0) beta[(kq / CKPT) * 64 + L.lane] = v; /* checkpoint */   \
+    }                                                                             \
     if constexpr (MODE == 2) keep = L.p == J ? o : keep;                          \
     if constexpr (((NPAR0 + J) & 1) == 0) {                                       \
       if (n0 + DIR * (j6 + J) != 0) win_normalize(v);                             \
@@ -221,6 +238,7 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
         if (L.p < 6) store_out<W>(out, k0 + j6 + L.p, L.g, keep);
       }
     }
+    sink ^= pf;
   }
 }
 
@@ -250,7 +268,9 @@ __device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const int2* 
         case 1: win_step<1, MODE, W>(L, v, in[j], B[j], o); break;
         default: win_step<2, MODE, W>(L, v, in[j], B[j], o); break;
       }
-      if constexpr (MODE == 1) beta[k * 64 + L.lane] = v;
+      if constexpr (MODE == 1) {
+        if (k % CKPT == 0) beta[(k / CKPT) * 64 + L.lane] = v; // checkpoint
+      }
       if constexpr (MODE == 2) {
         if (L.p == 0) store_out<W>(out, k, L.g, o);
       }
@@ -283,11 +303,12 @@ struct I3 { int a, b, c; };
 template <int W>
 __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
-                         pk_t* __restrict__ beta, int2* __restrict__ xy, int K)
+                         pk_t* __restrict__ beta, pk_t* __restrict__ seg, int2* __restrict__ xy, int K)
 {
   const int  Lw  = K / W;
   const pk_t NEG = pk_make(-TD_INF, -TD_INF);
   pk_t       v;
+  int        sink = 0; // keeps the prefetch touches alive (see win_run)
 
   // ---- combine pass: xy[g][k] = (sat(app + syst), parity) for the window pair g at step k, so that one 8-byte load
   //      per step feeds the recursion (turbodecoder_win.h:472-478: x = adds(ap, x))
@@ -302,8 +323,8 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464); positions are fixed: all static
   v = NEG;
   static_assert(WIN_OVERLAP == 40, "block plan below is written for the 40-step overlap");
-  win_run<W, 24, 39 % 3, -1, 0, 1>(L, v, my, bl, 39, 39, 1, beta, out);  // steps 39..16
-  win_run<W, 12, 15 % 3, -1, 0, 1>(L, v, my, bl, 15, 15, 1, beta, out);  // steps 15..4
+  win_run<W, 24, 39 % 3, -1, 0, 1>(L, v, my, bl, 39, 39, 1, beta, out, sink);  // steps 39..16
+  win_run<W, 12, 15 % 3, -1, 0, 1>(L, v, my, bl, 15, 15, 1, beta, out, sink);  // steps 15..4
   win_rem<W, -1, 0>(L, v, my, bl, 3, 3, 0, 4, beta, out);                // steps 3..0
   // ---- tail trellis for the last window: scalar, wrapping adds (turbodecoder_win.h:351-395)
   int tail[8];
@@ -332,13 +353,15 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
       v = pk_make(L.g == 7 ? ts : pk_lo(b), 0);
     }
   }
-  beta[Lw * 64 + L.lane] = v;
-  // ---- beta main pass (:466-526): store after the max, before normalisation. Left-over steps first, then aligned blocks.
+  const int top = (Lw + CKPT - 1) / CKPT; // checkpoint slot of the start metrics beta[Lw]
+  beta[top * 64 + L.lane] = v;
+  // ---- beta main pass (:466-526). Only every CKPT-th metric set is kept (in LDS, `beta`); the alpha pass recomputes the
+  //      rest segment by segment. Left-over steps first, then aligned blocks.
   {
     const int r = Lw % 6, n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
     win_rem<W, -1, 1>(L, v, my, bl, Lw - 1, Lw - 1, (Lw - 1) % 3, r, beta, out);
-    win_run<W, 6, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1, Lw - r - 1, r6, beta, out); // first step index = 5 (mod 6)
-    win_run<W, 24, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, beta, out);
+    win_run<W, 6, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1, Lw - r - 1, r6, beta, out, sink); // first step index = 5 (mod 6)
+    win_run<W, 24, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, beta, out, sink);
   }
 
   // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter j = 0..39
@@ -346,9 +369,9 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   {
     const int k0 = Lw - WIN_OVERLAP, ph0 = k0 % 3;
     switch (ph0) {
-      case 0: win_run<W, 24, 0, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 0, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
-      case 1: win_run<W, 24, 1, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 1, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
-      default: win_run<W, 24, 2, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out); win_run<W, 12, 2, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out); break;
+      case 0: win_run<W, 24, 0, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 0, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
+      case 1: win_run<W, 24, 1, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 1, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
+      default: win_run<W, 24, 2, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 2, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
     }
     const int done = 36;
     win_rem<W, 1, 0>(L, v, my, bl, k0 + done, done, (ph0 + done) % 3, WIN_OVERLAP - done, beta, out);
@@ -365,13 +388,79 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
       v = pk_make(L.g == 0 ? init : pk_lo(b), 0);
     }
   }
-  // ---- alpha main pass with extrinsic output (:605-679)
-  __syncthreads(); // beta stores of this wave are visible to its loads
-  {
-    const int n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
-    win_run<W, 24, 0, 1, 2, 0>(L, v, my, bl, 0, 0, n24, beta, out);
-    win_run<W, 6, 0, 1, 2, 0>(L, v, my, bl, 24 * n24, 24 * n24, r6, beta, out);
-    win_rem<W, 1, 2>(L, v, my, bl, 6 * n6, 6 * n6, 0, Lw % 6, beta, out);
+  // ---- alpha main pass with extrinsic output (:605-679), CKPT steps at a time: the beta metrics of the segment are
+  //      recomputed from its checkpoint into LDS (`seg`, one dword per lane and step: lane-private, no barrier), using
+  //      the very operands the alpha steps need, then consumed. No beta traffic leaves the CU.
+  const int nf = Lw / CKPT;
+  for (int j = 0; j < nf; j++) {
+    const int k0 = CKPT * j;
+    int2      c[CKPT];
+#pragma unroll
+    for (int i = 0; i < CKPT; i++) c[i] = my[k0 + i];
+    int pf = 0;
+    if (k0 + 2 * CKPT <= Lw) pf = my[k0 + CKPT + min(3 * L.p, CKPT - 1)].x; // touch the next segment's operands
+    const pk_t Btop = beta[(j + 1) * 64 + L.lane]; // beta[k0 + CKPT], as stored (before its normalisation)
+    pk_t       vb   = Btop, dummy = 0;
+    if (k0 + CKPT < Lw) win_normalize(vb); // the recursion continued from the normalised value (k even, != 0); beta[Lw] is a start value
+#pragma unroll
+    for (int i = CKPT - 1; i >= 1; i--) { // beta[k0+i], i = 23..1 (phase (k0+i)%3 = i%3)
+      switch (i % 3) {
+        case 0: win_step<0, 0, W>(L, vb, c[i], 0, dummy); break;
+        case 1: win_step<1, 0, W>(L, vb, c[i], 0, dummy); break;
+        default: win_step<2, 0, W>(L, vb, c[i], 0, dummy); break;
+      }
+      seg[i * 64 + L.lane] = vb;
+      if ((i & 1) == 0) win_normalize(vb);
+    }
+#pragma unroll
+    for (int i6 = 0; i6 < CKPT; i6 += 6) {
+      pk_t keep = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const int  kk = i6 + i;
+        const pk_t B  = kk == CKPT - 1 ? Btop : seg[(kk + 1) * 64 + L.lane];
+        pk_t       o  = 0;
+        switch (i % 3) {
+          case 0: win_step<0, 2, W>(L, v, c[kk], B, o); break;
+          case 1: win_step<1, 2, W>(L, v, c[kk], B, o); break;
+          default: win_step<2, 2, W>(L, v, c[kk], B, o); break;
+        }
+        keep = L.p == i ? o : keep;
+        if ((kk & 1) == 0 && k0 + kk != 0) win_normalize(v);
+      }
+      if (L.p < 6) store_out<W>(out, k0 + i6 + L.p, L.g, keep);
+    }
+    sink ^= pf;
+  }
+  asm volatile("" ::"v"(sink)); // keeps the touches live without any observable effect
+  { // last, shorter segment [CKPT*nf, Lw): run-time phases, same scheme
+    const int k0 = CKPT * nf, t = Lw - k0;
+    if (t > 0) {
+      const pk_t Btop = beta[top * 64 + L.lane];
+      pk_t       vb   = Btop, dummy = 0;
+      for (int i = t - 1; i >= 1; i--) {
+        const int2 in = my[k0 + i];
+        switch ((k0 + i) % 3) {
+          case 0: win_step<0, 0, W>(L, vb, in, 0, dummy); break;
+          case 1: win_step<1, 0, W>(L, vb, in, 0, dummy); break;
+          default: win_step<2, 0, W>(L, vb, in, 0, dummy); break;
+        }
+        seg[i * 64 + L.lane] = vb;
+        if (((k0 + i) & 1) == 0) win_normalize(vb);
+      }
+      for (int i = 0; i < t; i++) {
+        const int2 in = my[k0 + i];
+        const pk_t B  = i == t - 1 ? Btop : seg[(i + 1) * 64 + L.lane];
+        pk_t       o  = 0;
+        switch ((k0 + i) % 3) {
+          case 0: win_step<0, 2, W>(L, v, in, B, o); break;
+          case 1: win_step<1, 2, W>(L, v, in, B, o); break;
+          default: win_step<2, 2, W>(L, v, in, B, o); break;
+        }
+        if (L.p == 0) store_out<W>(out, k0 + i, L.g, o);
+        if (((k0 + i) & 1) == 0 && k0 + i != 0) win_normalize(v);
+      }
+    }
   }
 }
 
@@ -391,8 +480,9 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
   int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
-  pk_t* beta = a.beta + (size_t)cb * a.beta_stride;
-  int2* xy   = a.xy + (size_t)cb * a.K;
+  __shared__ pk_t beta[(SRSLTE_HIP_MAX_K / 8 / CKPT + 2) * 64]; // beta checkpoints (lane-private columns)
+  __shared__ pk_t seg[(CKPT + 1) * 64];                          // beta metrics of the segment being consumed
+  int2*           xy = a.xy + (size_t)cb * a.K;
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91); tails live at [K..K+2]
   const int tb = a.sb_layout ? 3 * (K + 32) : 3 * K;
@@ -433,10 +523,10 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
             [&](int i, I3 t) { app1[i] = (int16_t)(t.a - t.b); }); // srslte_vec_sub_sss, wrapping
         __syncthreads();
       }
-      win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, xy, K);
+      if (!(a.dbg & 1)) win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, seg, xy, K);
       dec = ext1;
     } else {
-      const bool sub = n_iter > 1; // ext1 -= app1 (srslte_vec_sub_sss) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut_sss)
+      const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub_sss) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut_sss)
       batched<8>(
           L.lane, K, [&](int i) { return I3{ext1[i], sub ? app1[i] : 0, a.t.deinter[i]}; },
           [&](int i, I3 t) {
@@ -445,7 +535,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
             app2[t.c] = e;
           });
       __syncthreads();
-      win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, xy, K);
+      if (!(a.dbg & 1)) win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, seg, xy, K);
       __syncthreads();
       batched<8>(
           L.lane, K, [&](int i) { return I3{ext2[i], a.t.inter[i], 0}; }, [&](int i, I3 t) { app1[t.b] = (int16_t)t.a; });
@@ -458,7 +548,7 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
       batched<8>(
           L.lane, K, [&](int i) { return I3{dec[i], (int)a.t.crc_rem[i], 0}; }, [&](int i, I3 t) { syn ^= t.a > 0 ? (uint32_t)t.b : 0u; });
       for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
-      ok = syn == 0;
+      ok = syn == 0 && !(a.dbg & 1);
     }
   }
   // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838)
@@ -747,6 +837,7 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_s
   TdecArgs a;
   a.in = d_input; a.in_stride = in_stride; a.sb_layout = sb_layout; a.K = K; a.nof_cb = nof_cb; a.nof_iter = nof_iterations;
   a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy;
+  a.dbg = getenv("SRSLTE_HIP_TDEC_DBG") ? atoi(getenv("SRSLTE_HIP_TDEC_DBG")) : 0;
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
