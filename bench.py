@@ -18,6 +18,7 @@ Extra objects on that line:
                 the oracle restatement (kind "port"); timed on a bounded sample of the same subframes
 """
 import argparse
+import ctypes
 import importlib
 import json
 import os
@@ -61,6 +62,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (whole passes over the batch)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -170,6 +172,40 @@ def main():
         kernels[name] = {"ms": round(ms, 4), "algorithmic_MB": round(alg[name] / 1e6, 3), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
     torch.cuda.synchronize()
 
+    # ---- streaming kernels on a batch large enough to leave the launch/latency regime ("per streaming kernel
+    #      measured in isolation on a large batch"); same kernels, same per-subframe algorithmic bytes
+    big = {}
+    if args.stream_batch > 0:
+        nb = args.stream_batch
+        N, nre, Qm = 1536, 1200, 6
+        t_iq = torch.randn(nb, 15 * N * 2, device=dev, dtype=torch.float32)
+        t_grid = torch.empty(nb, 14 * nre * 2, device=dev, dtype=torch.float32)
+        t_ce = torch.empty_like(t_grid)
+        t_res = torch.empty(nb, 10, device=dev, dtype=torch.float32)
+        t_llr = torch.empty(nb, 14 * nre * Qm, device=dev, dtype=torch.int16)
+        ofdm = pkg.Ofdm(NOF_PRB, True, rx=True)
+        est = pkg.ChestDl(ue["cell_id"], NOF_PRB)
+
+        def timed(fn, nbytes):
+            a, b = L.srslte_hip_event_create(), L.srslte_hip_event_create()
+            fn()
+            L.srslte_hip_event_record(a, stream)
+            for _ in range(5):
+                fn()
+            L.srslte_hip_event_record(b, stream)
+            ms = L.srslte_hip_event_elapsed_ms(a, b) / 5
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            return {"ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
+
+        big["ofdm_rx"] = timed(lambda: L.srslte_hip_ofdm_rx_sf_batch(ofdm.h, t_iq.data_ptr(), t_grid.data_ptr(), nb, stream), nb * 318720)
+        big["chest_dl"] = timed(lambda: L.srslte_hip_chest_dl_estimate_batch(est.h, ctypes.byref(hc), 0, t_grid.data_ptr(), t_ce.data_ptr(),
+                                                                            t_res.data_ptr(), nb, stream), nb * 179200)
+        big["demod_soft_s_64qam"] = timed(lambda: L.srslte_hip_demod_soft_demodulate_s_batch(MOD, t_grid.data_ptr(), t_llr.data_ptr(), 14 * nre, nb, stream),
+                                          nb * 14 * nre * (8 + 2 * Qm))
+        big["batch"] = nb
+        torch.cuda.synchronize()
+        del t_iq, t_grid, t_ce, t_res, t_llr
+
     # ---- CPU baseline on a bounded sample of the same subframes, one core
     cpu = None
     if not args.no_cpu:
@@ -206,6 +242,7 @@ def main():
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,
                      "note": "serial-trellis integer kernel: not HBM-bound by construction (SURVEY §8d); streaming kernels are in 'kernels'"},
         "kernels": kernels,
+        "kernels_large_batch": big,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))

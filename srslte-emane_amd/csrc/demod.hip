@@ -61,6 +61,42 @@ __global__ __launch_bounds__(256) void demod_kernel(int mod, const cf32* __restr
   }
 }
 
+
+// int16 fast path: 4 symbols per thread (two 16-B loads, 4*Qm int16 = 1..4 16-B stores): same per-symbol arithmetic,
+// wider memory instructions. Needs nsym % 4 == 0 so that a group never straddles two calls.
+template <int QM>
+__global__ __launch_bounds__(256) void demod_s_x4_kernel(int mod, const float4* __restrict__ sym, uint4* __restrict__ llr, int nsym, long groups,
+                                                         const uint32_t* __restrict__ scr, int scr_words, int tti0)
+{
+  for (long gi = (long)blockIdx.x * blockDim.x + threadIdx.x; gi < groups; gi += (long)gridDim.x * blockDim.x) {
+    const long   s0   = gi * 4;
+    const int    call = (int)(s0 / nsym), i0 = (int)(s0 - (long)call * nsym);
+    const float4 a = sym[2 * gi], b = sym[2 * gi + 1];
+    const cf32   sv[4] = {make_float2(a.x, a.y), make_float2(a.z, a.w), make_float2(b.x, b.y), make_float2(b.z, b.w)};
+    union {
+      short h[4 * QM];
+      uint4 v[QM / 2];
+    } out;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      short o[8];
+      demod_s(mod, sv[t], i0 + t, nsym, o);
+#pragma unroll
+      for (int j = 0; j < QM; j++) out.h[t * QM + j] = o[j];
+    }
+    if (scr) {
+      const uint32_t* c = scr + (size_t)((tti0 + call) % 10) * scr_words;
+#pragma unroll
+      for (int j = 0; j < 4 * QM; j++) {
+        const int bit = i0 * QM + j;
+        if ((c[bit >> 5] >> (bit & 31)) & 1) out.h[j] = (short)-out.h[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < QM / 2; j++) llr[gi * (QM / 2) + j] = out.v[j];
+  }
+}
+
 } // namespace
 
 int demod_launch(int type, int mod, const void* d_sym, void* d_llr, int nsym, int ncalls, const uint32_t* d_scr, int scr_words, int tti0,
@@ -75,6 +111,21 @@ int demod_launch(int type, int mod, const void* d_sym, void* d_llr, int nsym, in
   if (total == 0) return SRSLTE_SUCCESS;
   long blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
+  if (type == 1 && mod >= MOD_QPSK && nsym % 4 == 0 && ((uintptr_t)d_sym % 16) == 0 && ((uintptr_t)d_llr % 16) == 0) {
+    const long groups = total / 4;
+    long       gb     = (groups + 255) / 256;
+    if (gb > 16384) gb = 16384;
+    const float4* s4 = (const float4*)d_sym;
+    uint4*        l4 = (uint4*)d_llr;
+    switch (mod) {
+      case MOD_QPSK: hipLaunchKernelGGL(demod_s_x4_kernel<2>, dim3((unsigned)gb), dim3(256), 0, st, mod, s4, l4, nsym, groups, d_scr, scr_words, tti0); break;
+      case MOD_16QAM: hipLaunchKernelGGL(demod_s_x4_kernel<4>, dim3((unsigned)gb), dim3(256), 0, st, mod, s4, l4, nsym, groups, d_scr, scr_words, tti0); break;
+      case MOD_64QAM: hipLaunchKernelGGL(demod_s_x4_kernel<6>, dim3((unsigned)gb), dim3(256), 0, st, mod, s4, l4, nsym, groups, d_scr, scr_words, tti0); break;
+      default: hipLaunchKernelGGL(demod_s_x4_kernel<8>, dim3((unsigned)gb), dim3(256), 0, st, mod, s4, l4, nsym, groups, d_scr, scr_words, tti0); break;
+    }
+    LAUNCH_CHECK();
+    return SRSLTE_SUCCESS;
+  }
   switch (type) {
     case 0: hipLaunchKernelGGL(demod_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, st, mod, (const cf32*)d_sym, d_llr, nsym, ncalls, d_scr, scr_words, tti0); break;
     case 1: hipLaunchKernelGGL(demod_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, mod, (const cf32*)d_sym, d_llr, nsym, ncalls, d_scr, scr_words, tti0); break;

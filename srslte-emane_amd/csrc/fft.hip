@@ -17,16 +17,17 @@
 
 namespace {
 
-constexpr int FFT_THREADS = 256;
-
 __device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return make_float2(a.x - b.x, a.y - b.y); }
 // a * (j*s)
 __device__ __forceinline__ cf32 cmulj(cf32 a, float s) { return make_float2(-s * a.y, s * a.x); }
+// a * (c + j*sgn*s): multiplication by exp(sgn * j * theta) with cos/sin given
+__device__ __forceinline__ cf32 cmulw(cf32 a, float c, float s, float sgn) { return make_float2(a.x * c - sgn * s * a.y, a.y * c + sgn * s * a.x); }
 
+// Natural-order R-point DFT in registers: v[r] <- sum_q v[q] exp(sgn*j*2*pi*q*r/R).
 template <int R>
-__device__ __forceinline__ void butterfly(cf32* v, float sgn)
+__device__ __forceinline__ void dft_r(cf32* v, float sgn)
 {
   if constexpr (R == 2) {
     cf32 a = v[0], b = v[1];
@@ -45,7 +46,7 @@ __device__ __forceinline__ void butterfly(cf32* v, float sgn)
     v[0]   = cadd(v[0], t);
     v[1]   = cadd(m, u);
     v[2]   = csub(m, u);
-  } else { // 5
+  } else if constexpr (R == 5) {
     const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f, s1 = 0.95105651629515357212f,
                 s2 = 0.58778525229247312917f;
     cf32 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]), d1 = csub(v[1], v[4]), d2 = csub(v[2], v[3]);
@@ -58,57 +59,173 @@ __device__ __forceinline__ void butterfly(cf32* v, float sgn)
     v[4]    = csub(m1, u1);
     v[2]    = cadd(m2, u2);
     v[3]    = csub(m2, u2);
+  } else if constexpr (R == 6) { // 6 = 2 x 3: n = 3 n1 + n2, k = k1 + 2 k2
+    cf32 a[3], b[3];           // a: k1 = 0, b: k1 = 1 (index n2)
+#pragma unroll
+    for (int n2 = 0; n2 < 3; n2++) {
+      a[n2] = cadd(v[n2], v[3 + n2]);
+      b[n2] = csub(v[n2], v[3 + n2]);
+    }
+    b[1] = cmulw(b[1], 0.5f, 0.86602540378443864676f, sgn);  // W6^1
+    b[2] = cmulw(b[2], -0.5f, 0.86602540378443864676f, sgn); // W6^2
+    dft_r<3>(a, sgn);
+    dft_r<3>(b, sgn);
+#pragma unroll
+    for (int k2 = 0; k2 < 3; k2++) {
+      v[2 * k2]     = a[k2];
+      v[2 * k2 + 1] = b[k2];
+    }
+  } else if constexpr (R == 8) { // even/odd split
+    cf32 e[4] = {v[0], v[2], v[4], v[6]}, o[4] = {v[1], v[3], v[5], v[7]};
+    dft_r<4>(e, sgn);
+    dft_r<4>(o, sgn);
+    const float h = 0.70710678118654752440f;
+    o[1] = cmulw(o[1], h, h, sgn);
+    o[2] = cmulj(o[2], sgn);
+    o[3] = cmulw(o[3], -h, h, sgn);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      v[k]     = cadd(e[k], o[k]);
+      v[k + 4] = csub(e[k], o[k]);
+    }
+  } else { // 16 = 4 x 4: n = 4 n1 + n2, k = k1 + 4 k2
+    static_assert(R == 16, "unsupported radix");
+    cf32 a[4][4]; // a[n2][k1]
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) {
+      cf32 t[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+      dft_r<4>(t, sgn);
+#pragma unroll
+      for (int k1 = 0; k1 < 4; k1++) a[n2][k1] = t[k1];
+    }
+    // W16^(n2*k1): cos/sin of 2*pi*m/16
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+    a[1][1] = cmulw(a[1][1], c1, s1, sgn);   // m=1
+    a[1][2] = cmulw(a[1][2], h, h, sgn);     // m=2
+    a[1][3] = cmulw(a[1][3], s1, c1, sgn);   // m=3
+    a[2][1] = cmulw(a[2][1], h, h, sgn);     // m=2
+    a[2][2] = cmulj(a[2][2], sgn);           // m=4
+    a[2][3] = cmulw(a[2][3], -h, h, sgn);    // m=6
+    a[3][1] = cmulw(a[3][1], s1, c1, sgn);   // m=3
+    a[3][2] = cmulw(a[3][2], -h, h, sgn);    // m=6
+    a[3][3] = cmulw(a[3][3], -c1, -s1, sgn); // m=9: cos = -c1, sin = -s1
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) {
+      cf32 t[4] = {a[0][k1], a[1][k1], a[2][k1], a[3][k1]};
+      dft_r<4>(t, sgn);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; k2++) v[k1 + 4 * k2] = t[k2];
+    }
   }
 }
 
-// One Stockham pass of radix R over the whole N-point sequence held in LDS: src -> dst.
-// tw[k] = exp(-j 2 pi k / N); the backward transform conjugates it.
-template <int R>
-__device__ __forceinline__ void stockham_pass(const cf32* __restrict__ src, cf32* __restrict__ dst, int N, int Ns,
-                                              const cf32* __restrict__ tw, float sgn)
+// LDS index with one pad element per 16: the radix-16 pass writes with a stride of 16 elements across lanes, which would
+// put a whole wave on two banks; i + i/16 spreads it over all of them (cdna_hip_programming.md Guideline 4).
+__device__ __forceinline__ int pad16(int i) { return i + (i >> 4); }
+
+// One Stockham autosort pass of radix R: butterfly j reads x[j + r*N/R], multiplies by w^(r*k), k = j mod Ns, and writes
+// y[(j/Ns)*Ns*R + k + r*Ns]. Ld/St abstract where x and y live: the FIRST pass reads the caller's global input and the
+// LAST writes the caller's global output (with whatever index mapping the caller fuses in), the others use LDS.
+template <int R, bool MID_INPLACE, typename Ld, typename St>
+__device__ __forceinline__ void stockham_pass(int N, int Ns, const cf32* __restrict__ tw, float sgn, Ld ld, St st)
 {
-  const int nb   = N / R;
-  const int tstep = N / (Ns * R);
-  for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+  const int nb = N / R, tstep = N / (Ns * R);
+  auto      body = [&](int j, cf32* v) {
     const int k = j % Ns;
-    cf32      v[R];
+    if (k != 0) {
+      cf32 w1 = tw[k * tstep]; // exp(-j*2*pi*k/(Ns*R)); powers by repeated multiplication (<= 15 products, ~1e-6 relative)
+      w1.y    = -sgn * w1.y;
+      cf32 w  = w1;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-      cf32 x = src[j + r * nb];
-      if (r == 0 || k == 0) {
-        v[r] = x;
-      } else {
-        cf32 w = tw[r * k * tstep]; // < N because k < Ns, r < R
-        w.y    = -sgn * w.y; // forward (sgn=-1): table as is; backward: conjugate
-        v[r]   = cmul(x, w);
+      for (int r = 1; r < R; r++) {
+        v[r] = cmul(v[r], w);
+        if (r + 1 < R) w = cmul(w, w1);
       }
     }
-    butterfly<R>(v, sgn);
+    dft_r<R>(v, sgn);
     const int j0 = (j / Ns) * Ns * R + k;
 #pragma unroll
-    for (int r = 0; r < R; r++) dst[j0 + r * Ns] = v[r];
+    for (int r = 0; r < R; r++) st(j0 + r * Ns, v[r]);
+  };
+  if constexpr (MID_INPLACE) { // LDS -> same LDS buffer, at most one butterfly per thread: everyone loads, barrier, everyone stores
+    const int  j      = threadIdx.x;
+    const bool active = j < nb;
+    cf32       v[R];
+    if (active) {
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = ld(j + r * nb);
+    }
+    __syncthreads();
+    if (active) body(j, v);
+  } else {
+    for (int j = threadIdx.x; j < nb; j += blockDim.x) {
+      cf32 v[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) v[r] = ld(j + r * nb);
+      body(j, v);
+    }
   }
 }
 
-// Runs all passes; returns the LDS buffer that holds the result.
-__device__ __forceinline__ cf32* fft_in_lds(cf32* a, cf32* b, const FftFactors& f, const cf32* __restrict__ tw, float sgn)
+// Generic plan (any N = 2^a 3^b 5^c, run-time radix list, radices 2..5 only to keep the code small): two LDS buffers.
+// gld(n): element n of the input sequence; gst(n, v): element n of the transform.
+template <typename GLd, typename GSt>
+__device__ __forceinline__ void fft_passes(const FftFactors& f, const cf32* __restrict__ tw, float sgn, cf32* lds, GLd gld, GSt gst)
 {
-  int Ns = 1;
+  const int N = f.N, Np = pad16(N) + 1;
+  int       Ns = 1;
   for (int i = 0; i < f.nf; i++) {
-    __syncthreads();
+    const bool first = i == 0, last = i == f.nf - 1;
+    cf32*      src   = lds + ((i + 1) & 1) * Np;
+    cf32*      dst   = lds + (i & 1) * Np;
+    auto       ld    = [&](int n) { return first ? gld(n) : src[pad16(n)]; };
+    auto       st    = [&](int n, cf32 v) {
+      if (last) {
+        gst(n, v);
+      } else {
+        dst[pad16(n)] = v;
+      }
+    };
     switch (f.radix[i]) {
-      case 4: stockham_pass<4>(a, b, f.N, Ns, tw, sgn); break;
-      case 2: stockham_pass<2>(a, b, f.N, Ns, tw, sgn); break;
-      case 3: stockham_pass<3>(a, b, f.N, Ns, tw, sgn); break;
-      default: stockham_pass<5>(a, b, f.N, Ns, tw, sgn); break;
+      case 5: stockham_pass<5, false>(N, Ns, tw, sgn, ld, st); break;
+      case 4: stockham_pass<4, false>(N, Ns, tw, sgn, ld, st); break;
+      case 3: stockham_pass<3, false>(N, Ns, tw, sgn, ld, st); break;
+      default: stockham_pass<2, false>(N, Ns, tw, sgn, ld, st); break;
     }
     Ns *= f.radix[i];
-    cf32* t = a;
-    a       = b;
-    b       = t;
+    if (!last) __syncthreads();
   }
+}
+
+// Fixed plan N = R0*R1*R2 (R2 = 1: two passes) for the OFDM sizes: global -> registers -> LDS, LDS -> LDS in place
+// (one radix-R1 butterfly per thread), LDS -> registers -> global. One LDS buffer, two barriers-and-a-half, no run-time
+// dispatch: everything about the plan is a compile-time constant.
+template <int R0, int R1, int R2, typename GLd, typename GSt>
+__device__ __forceinline__ void fft_fixed(const cf32* __restrict__ tw, float sgn, cf32* lds, GLd gld, GSt gst)
+{
+  constexpr int N = R0 * R1 * R2;
+  auto lld = [&](int n) { return lds[pad16(n)]; };
+  auto lst = [&](int n, cf32 v) { lds[pad16(n)] = v; };
+  stockham_pass<R0, false>(N, 1, tw, sgn, gld, lst);
   __syncthreads();
-  return a;
+  if constexpr (R2 == 1) {
+    stockham_pass<R1, false>(N, R0, tw, sgn, lld, gst);
+  } else {
+    stockham_pass<R1, true>(N, R0, tw, sgn, lld, lst);
+    __syncthreads();
+    stockham_pass<R2, false>(N, R0 * R1, tw, sgn, lld, gst);
+  }
+}
+
+// Runs the fixed plan when the launch was made for one (R0 != 0), the generic plan otherwise.
+template <int R0, int R1, int R2, typename GLd, typename GSt>
+__device__ __forceinline__ void fft_any(const FftFactors& f, const cf32* __restrict__ tw, float sgn, cf32* lds, GLd gld, GSt gst)
+{
+  if constexpr (R0 != 0) {
+    fft_fixed<R0, R1, R2>(tw, sgn, lds, gld, gst);
+  } else {
+    fft_passes(f, tw, sgn, lds, gld, gst);
+  }
 }
 
 struct OfdmGeom {
@@ -119,71 +236,75 @@ struct OfdmGeom {
   int        cp_len[14];
 };
 
+constexpr int FFT_THREADS = 128;
+#define FFT_BOUNDS __launch_bounds__(FFT_THREADS)
+
 // grid = (nsym, nof_sf). in: [nof_sf][sf_len] time samples; out: [nof_sf][nsym][nof_re] resource grid.
-__global__ __launch_bounds__(FFT_THREADS) void ofdm_rx_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, OfdmGeom g,
+// CP strip and the half-carrier shift ride on the first pass's global loads; guard/DC strip, half swap and 1/sqrt(N) on
+// the last pass's global stores (ofdm.c:410-416): every sample is read once and every used bin written once.
+template <int R0, int R1, int R2>
+__global__ FFT_BOUNDS void ofdm_rx_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, OfdmGeom g,
                                                               const cf32* __restrict__ tw, const cf32* __restrict__ shift)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  cf32*     a   = reinterpret_cast<cf32*>(lds_raw);
-  cf32*     b   = a + g.f.N;
-  const int s = blockIdx.x, sf = blockIdx.y, N = g.f.N;
+  const int   s = blockIdx.x, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2;
   const cf32* src = in + (size_t)sf * g.sf_len + g.sym_off[s] + g.cp_len[s];
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    cf32 v = src[n];
-    if (shift) v = cmul(v, shift[g.cp_max + n]); // ofdm.c:369-371 with t - cplen = n
-    a[n] = v;
-  }
-  cf32* r   = fft_in_lds(a, b, g.f, tw, -1.0f);
-  cf32* dst = out + ((size_t)sf * g.nsym + s) * g.nof_re;
-  const int half = g.nof_re / 2;
-  for (int i = threadIdx.x; i < g.nof_re; i += blockDim.x) {
-    cf32 v = i < half ? r[N - half + i] : r[g.dc + i - half]; // ofdm.c:411-412
-    dst[i] = make_float2(v.x * g.norm, v.y * g.norm);
-  }
+  cf32*       dst = out + ((size_t)sf * g.nsym + s) * g.nof_re;
+  fft_any<R0, R1, R2>(
+      g.f, tw, -1.0f, reinterpret_cast<cf32*>(lds_raw),
+      [&](int n) {
+        cf32 v = src[n];
+        if (shift) v = cmul(v, shift[g.cp_max + n]); // ofdm.c:369-371 with t - cplen = n
+        return v;
+      },
+      [&](int n, cf32 v) { // ofdm.c:411-412
+        v = make_float2(v.x * g.norm, v.y * g.norm);
+        if (n >= N - half) {
+          dst[n - (N - half)] = v;
+        } else if (n >= g.dc && n < g.dc + half) {
+          dst[half + n - g.dc] = v;
+        }
+      });
 }
 
 // in: [nof_sf][nsym][nof_re] grid; out: [nof_sf][sf_len] time samples with CP.
-__global__ __launch_bounds__(FFT_THREADS) void ofdm_tx_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, OfdmGeom g,
+template <int R0, int R1, int R2>
+__global__ FFT_BOUNDS void ofdm_tx_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, OfdmGeom g,
                                                               const cf32* __restrict__ tw, const cf32* __restrict__ shift)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  cf32*     a   = reinterpret_cast<cf32*>(lds_raw);
-  cf32*     b   = a + g.f.N;
-  const int s = blockIdx.x, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2;
+  const int   s = blockIdx.x, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2, cp = g.cp_len[s];
   const cf32* src = in + ((size_t)sf * g.nsym + s) * g.nof_re;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) { // ofdm.c:509-515 (guards and DC stay zero)
-    cf32 v = make_float2(0.f, 0.f);
-    if (n >= g.dc && n < g.dc + half) {
-      v = src[half + n - g.dc];
-    } else if (n >= N - half) {
-      v = src[n - (N - half)];
-    }
-    a[n] = v;
-  }
-  cf32* r   = fft_in_lds(a, b, g.f, tw, 1.0f);
-  cf32* dst = out + (size_t)sf * g.sf_len + g.sym_off[s];
-  const int cp = g.cp_len[s];
-  for (int t = threadIdx.x; t < cp + N; t += blockDim.x) { // ofdm.c:519-529: body then CP = tail copy
-    cf32 v = t < cp ? r[N - cp + t] : r[t - cp];
-    v      = make_float2(v.x * g.norm, v.y * g.norm);
-    if (shift) v = cmul(v, shift[g.cp_max + t - cp]);
-    dst[t] = v;
-  }
+  cf32*       dst = out + (size_t)sf * g.sf_len + g.sym_off[s];
+  fft_any<R0, R1, R2>(
+      g.f, tw, 1.0f, reinterpret_cast<cf32*>(lds_raw),
+      [&](int n) { // ofdm.c:509-515 (guards and DC stay zero)
+        if (n >= g.dc && n < g.dc + half) return src[half + n - g.dc];
+        if (n >= N - half) return src[n - (N - half)];
+        return make_float2(0.f, 0.f);
+      },
+      [&](int n, cf32 v) { // ofdm.c:519-529: body, and the tail again as cyclic prefix
+        v = make_float2(v.x * g.norm, v.y * g.norm);
+        dst[cp + n] = shift ? cmul(v, shift[g.cp_max + n]) : v;
+        if (n >= N - cp) {
+          const int t = n - (N - cp);
+          dst[t]      = shift ? cmul(v, shift[g.cp_max + t - cp]) : v;
+        }
+      });
 }
 
 // Generic batched c2c transform: howmany transforms, element strides 1, distances idist/odist, output * scale.
-__global__ __launch_bounds__(FFT_THREADS) void dft_batch_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, FftFactors f,
+template <int R0, int R1, int R2>
+__global__ FFT_BOUNDS void dft_batch_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, FftFactors f,
                                                                 int idist, int odist, float sgn, float scale,
                                                                 const cf32* __restrict__ tw)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  cf32*       a   = reinterpret_cast<cf32*>(lds_raw);
-  cf32*       b   = a + f.N;
   const cf32* src = in + (size_t)blockIdx.x * idist;
-  for (int n = threadIdx.x; n < f.N; n += blockDim.x) a[n] = src[n];
-  cf32* r   = fft_in_lds(a, b, f, tw, sgn);
-  cf32* dst = out + (size_t)blockIdx.x * odist;
-  for (int n = threadIdx.x; n < f.N; n += blockDim.x) dst[n] = make_float2(r[n].x * scale, r[n].y * scale);
+  cf32*       dst = out + (size_t)blockIdx.x * odist;
+  fft_any<R0, R1, R2>(
+      f, tw, sgn, reinterpret_cast<cf32*>(lds_raw), [&](int n) { return src[n]; },
+      [&](int n, cf32 v) { dst[n] = make_float2(v.x * scale, v.y * scale); });
 }
 
 // ---------------------------------------------------------------- host side: twiddle cache
@@ -194,8 +315,13 @@ struct TwEntry {
 std::mutex             g_tw_mutex;
 std::map<long, TwEntry> g_tw_cache; // key: device*65536 + N
 
+static int fft_threads(int N) { return N >= 1024 ? 128 : 64; }
+
+// N with a compile-time plan (the OFDM symbol sizes of phy_common.c:304-345)
+static bool fft_is_fixed(int N) { return N == 128 || N == 256 || N == 384 || N == 512 || N == 768 || N == 1024 || N == 1536 || N == 2048; }
+
 int factorize(int N, FftFactors* f)
-{
+{ // generic plan: 4s, then 2, 3s, 5s
   f->N  = N;
   f->nf = 0;
   int n = N;
@@ -203,8 +329,25 @@ int factorize(int N, FftFactors* f)
   while (n % 2 == 0 && f->nf < 8) { f->radix[f->nf++] = 2; n /= 2; }
   while (n % 3 == 0 && f->nf < 8) { f->radix[f->nf++] = 3; n /= 3; }
   while (n % 5 == 0 && f->nf < 8) { f->radix[f->nf++] = 5; n /= 5; }
+  f->inplace = fft_is_fixed(N) ? 1 : 0;
   return n == 1 ? 0 : -1;
 }
+
+static size_t fft_lds_bytes(const FftFactors& f) { return (f.inplace ? 1 : 2) * sizeof(cf32) * (size_t)(f.N + f.N / 16 + 2); }
+
+// launches KERNEL<plan> for the transform size: fixed plans for the OFDM sizes, <0,0,0> = generic otherwise
+#define FFT_DISPATCH(KERNEL, N, GRID, BLOCK, LDS, STREAM, ...)                                                        \
+  switch (N) {                                                                                                        \
+    case 128: hipLaunchKernelGGL((KERNEL<16, 8, 1>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                   \
+    case 256: hipLaunchKernelGGL((KERNEL<16, 16, 1>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                  \
+    case 384: hipLaunchKernelGGL((KERNEL<16, 8, 3>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                   \
+    case 512: hipLaunchKernelGGL((KERNEL<16, 16, 2>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                  \
+    case 768: hipLaunchKernelGGL((KERNEL<16, 16, 3>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                  \
+    case 1024: hipLaunchKernelGGL((KERNEL<16, 16, 4>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                 \
+    case 1536: hipLaunchKernelGGL((KERNEL<16, 16, 6>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                 \
+    case 2048: hipLaunchKernelGGL((KERNEL<16, 16, 8>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                 \
+    default: hipLaunchKernelGGL((KERNEL<0, 0, 0>), GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                     \
+  }
 
 } // namespace
 
@@ -316,8 +459,8 @@ extern "C" int srslte_hip_ofdm_rx_sf_batch(srslte_hip_ofdm_t* q, const void* d_i
   if (!q || !d_in_time || !d_out_grid || nof_sf < 0 || !q->is_rx) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   dim3 grid(q->g.nsym, nof_sf);
-  hipLaunchKernelGGL(ofdm_rx_kernel, grid, dim3(FFT_THREADS), 2 * sizeof(cf32) * q->g.f.N, (hipStream_t)stream,
-                     (const cf32*)d_in_time, (cf32*)d_out_grid, q->g, q->d_tw, (const cf32*)q->d_shift);
+  FFT_DISPATCH(ofdm_rx_kernel, q->g.f.N, grid, dim3(fft_threads(q->g.f.N)), fft_lds_bytes(q->g.f), (hipStream_t)stream,
+               (const cf32*)d_in_time, (cf32*)d_out_grid, q->g, q->d_tw, (const cf32*)q->d_shift);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
@@ -327,8 +470,8 @@ extern "C" int srslte_hip_ofdm_tx_sf_batch(srslte_hip_ofdm_t* q, const void* d_i
   if (!q || !d_in_grid || !d_out_time || nof_sf < 0 || q->is_rx) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   dim3 grid(q->g.nsym, nof_sf);
-  hipLaunchKernelGGL(ofdm_tx_kernel, grid, dim3(FFT_THREADS), 2 * sizeof(cf32) * q->g.f.N, (hipStream_t)stream,
-                     (const cf32*)d_in_grid, (cf32*)d_out_time, q->g, q->d_tw, (const cf32*)q->d_shift);
+  FFT_DISPATCH(ofdm_tx_kernel, q->g.f.N, grid, dim3(fft_threads(q->g.f.N)), fft_lds_bytes(q->g.f), (hipStream_t)stream,
+               (const cf32*)d_in_grid, (cf32*)d_out_time, q->g, q->d_tw, (const cf32*)q->d_shift);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
@@ -346,9 +489,8 @@ extern "C" int srslte_hip_dft_batch(const void* d_in, void* d_out, int N, int ho
   const cf32* d_tw;
   int         r = fft_get_plan(N, &f, &d_tw);
   if (r) return r;
-  hipLaunchKernelGGL(dft_batch_kernel, dim3(howmany), dim3(N >= 4 * FFT_THREADS ? FFT_THREADS : (N >= 256 ? 128 : 64)),
-                     2 * sizeof(cf32) * N, (hipStream_t)stream, (const cf32*)d_in, (cf32*)d_out, f, idist, odist,
-                     forward ? -1.0f : 1.0f, scale, d_tw);
+  FFT_DISPATCH(dft_batch_kernel, N, dim3(howmany), dim3(fft_threads(N)), fft_lds_bytes(f), (hipStream_t)stream, (const cf32*)d_in,
+               (cf32*)d_out, f, idist, odist, forward ? -1.0f : 1.0f, scale, d_tw);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }

@@ -7,6 +7,7 @@
 struct FftFactors {
   int N, nf;
   int radix[8];
+  int inplace; // LDS->LDS passes fit one butterfly per thread: single LDS buffer
 };
 
 // Returns (creating on first use, per device) the factorisation and the device twiddle table exp(-j2*pi*k/N).
