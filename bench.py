@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (whole passes over the batch)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--streams", type=int, default=3, help="pipeline instances / HIP streams that consecutive steps alternate over")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --force-device 0 rehearses N>1 on a one-GPU box")
+    ap.add_argument("--force-device", type=int, default=-1, help="use this GPU for every rank (rehearsal only)")
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
     args = ap.parse_args()
 
@@ -73,11 +76,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl")  # RCCL on ROCm
+        dist.init_process_group(backend=args.backend)  # "nccl" is RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = args.force_device if args.force_device >= 0 else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")  # where collective operands live
 
     pkg = importlib.import_module("srslte-emane_amd")
     sharding = importlib.import_module("srslte-emane_amd.sharding")
@@ -101,12 +106,17 @@ def main():
 
     hc = pkg.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0  # phy_dl_test.c:587-595
-    rx = pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc)
-    stream = torch.cuda.current_stream().cuda_stream
+    # Two pipeline instances on two HIP streams: consecutive steps (independent batches) alternate between them, so the
+    # next batch's kernels fill the SIMDs that the previous batch's turbo-decoder tail (blocks needing all 6 passes) leaves idle.
+    nstreams = max(1, args.streams)
+    rxs = [pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc) for _ in range(nstreams)]
+    tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
+    streams = [t.cuda_stream for t in tstreams]
+    rx, stream = rxs[0], streams[0]
 
-    def step():
+    def step(k=0):
         for s in range(6):
-            rc = rx.stage(s, d_iq.data_ptr(), 0, B, stream)
+            rc = rxs[k % nstreams].stage(s, d_iq.data_ptr(), 0, B, streams[k % nstreams])
             if rc:
                 raise RuntimeError("stage %d failed: %d" % (s, rc))
 
@@ -116,8 +126,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(max(args.warmup, nstreams)):
+        step(k)
     barrier()
     # HIP events around the dominant kernel, on the stream it is launched on
     ev = [(L.srslte_hip_event_create(), L.srslte_hip_event_create()) for _ in range(args.steps)]
@@ -125,17 +135,17 @@ def main():
     for k in range(args.steps):
         for s in range(6):
             if s == 4:
-                L.srslte_hip_event_record(ev[k][0], stream)
-            rc = rx.stage(s, d_iq.data_ptr(), 0, B, stream)
+                L.srslte_hip_event_record(ev[k][0], streams[k % nstreams])
+            rc = rxs[k % nstreams].stage(s, d_iq.data_ptr(), 0, B, streams[k % nstreams])
             if s == 4:
-                L.srslte_hip_event_record(ev[k][1], stream)
+                L.srslte_hip_event_record(ev[k][1], streams[k % nstreams])
             if rc:
                 raise RuntimeError("stage %d failed: %d" % (s, rc))
     barrier()
     elapsed = time.perf_counter() - t0
     t_max = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_max = float(t.item())
     tdec_ms = float(np.mean([L.srslte_hip_event_elapsed_ms(a, b) for a, b in ev]))
@@ -147,7 +157,7 @@ def main():
     good = int(sum(bool(ok[b]) and np.array_equal(tb[b, :TBS // 8], data_list[b]) for b in range(B)))
     wrong = int(sum(bool(ok[b]) and not np.array_equal(tb[b, :TBS // 8], data_list[b]) for b in range(B)))
     # the one collective of a run: BLER accounting over all UEs (srslte-emane_amd/sharding.py)
-    good_all, wrong_all, n_all, it_all = sharding.reduce_counts([good, wrong, B, int(iters.sum())], dist if world > 1 else None, dev)
+    good_all, wrong_all, n_all, it_all = sharding.reduce_counts([good, wrong, B, int(iters.sum())], dist if world > 1 else None, cdev)
 
     if rank != 0:
         if world > 1:
@@ -236,7 +246,8 @@ def main():
         "config": {"workload": "20 MHz (100 PRB) DL subframe batch=%d per GPU, 64QAM MCS 28 (TBS 75376, 13 x K=5824), OFDM RX + chest_dl + MMSE + "
                                "soft demap + rate dematch + turbo max 6 SISO passes with CRC early stop + TB CRC" % B,
                    "snr_db": args.snr, "bler": round(1 - good_all / n_all, 4), "undetected_errors": wrong_all,
-                   "avg_siso_passes_per_cb": round(it_all / (n_all * 13), 3), "sharding": "one UE per GPU, no data-path collective"},
+                   "avg_siso_passes_per_cb": round(it_all / (n_all * 13), 3), "sharding": "one UE per GPU, no data-path collective",
+                   "streams": nstreams},
         "roofline": {"kernel": "tdec_win_kernel<16>", "bound": "hbm", "achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,

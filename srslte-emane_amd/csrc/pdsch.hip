@@ -107,32 +107,41 @@ struct TbGeom {
   int C, K, tbs, rlen, cb_stride, tb_stride;
 };
 
-// one workgroup per subframe: assemble the payload (sch.c:360,:401-410) and check CRC24A (sch.c:470-488)
-__global__ __launch_bounds__(256) void tb_crc_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok,
+// one workgroup per subframe: assemble the payload (sch.c:360,:401-410) and check CRC24A (sch.c:470-488).
+// The CRC is the XOR over set bits of precomputed x^(n-1-j) mod g: branch-free, every lookup independent.
+__global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok,
                                                      const uint32_t* __restrict__ crc_rem, uint8_t* __restrict__ tb, uint8_t* __restrict__ tb_ok,
                                                      TbGeom g)
 {
-  __shared__ uint32_t red[4];
-  const int sf = blockIdx.x, nbytes = g.tbs / 8 + 3;
+  __shared__ uint32_t red[8];
+  const int sf = blockIdx.x, nbytes = g.tbs / 8 + 3, rb = g.rlen / 8;
   uint8_t*  dst = tb + (size_t)sf * g.tb_stride;
   uint32_t  syn = 0;
-  for (int b = threadIdx.x; b < nbytes + 3; b += blockDim.x) {
-    int cb = b / (g.rlen / 8);
-    if (cb > g.C - 1) cb = g.C - 1;
-    const int     off = b - cb * (g.rlen / 8);
-    const uint8_t v   = off < g.K / 8 ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : 0;
-    dst[b]            = v;
-    if (b < nbytes) {
-      for (int j = 0; j < 8; j++) {
-        if ((v >> (7 - j)) & 1) syn ^= crc_rem[8 * b + j];
-      }
+  for (int b0 = threadIdx.x * 4; b0 < nbytes + 3; b0 += blockDim.x * 4) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int b = b0 + t;
+      int       cb = b / rb;
+      if (cb > g.C - 1) cb = g.C - 1;
+      const int     off = b - cb * rb;
+      const uint8_t v   = (b < nbytes + 3 && off < g.K / 8) ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : 0;
+      if (b < nbytes + 3) dst[b] = v;
+      word |= (uint32_t)(b < nbytes ? v : 0) << (8 * t);
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) { // bit j of byte t = message bit 8*(b0+t) + (7 - j%8)
+      const int      t = j >> 3, bit = 8 * (b0 + t) + 7 - (j & 7);
+      const uint32_t m = 0u - ((word >> j) & 1u);
+      syn ^= (bit < 8 * nbytes ? crc_rem[bit] : 0u) & m;
     }
   }
   for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = syn;
   __syncthreads();
   if (threadIdx.x == 0) {
-    syn = red[0] ^ red[1] ^ red[2] ^ red[3];
+    syn = 0;
+    for (int i = 0; i < (int)blockDim.x / 64; i++) syn ^= red[i];
     bool ok = syn == 0;
     for (int c = 0; c < g.C; c++) ok = ok && cb_ok[sf * g.C + c];
     // par_rx == par_tx && par_rx != 0 (sch.c:481): a zero parity with zero syndrome is rejected upstream
@@ -355,7 +364,7 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       if (!d_tb || !d_tb_ok || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
       TbGeom g    = q->tg;
       g.tb_stride = (int)tb_stride;
-      hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+      hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
                          (const uint32_t*)q->d_tbcrc, d_tb, d_tb_ok, g);
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;
