@@ -225,11 +225,16 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
     win_step<PH, MODE, W>(L, v, c[j6 + J], cb[j6 + J], o);                        \
     if constexpr (MODE == 1) {                                                    \
       const int kq = k0 + DIR * (j6 + J);                                         \
-      if (kq % CKPT == 0) beta[(kq / CKPT) * 64 + L.lane] = v; /* checkpoint */   \
+      if constexpr (BLK == CKPT) { /* aligned blocks end on a multiple of CKPT */ \
+        if (j6 + J == BLK - 1) beta[(kq / CKPT) * 64 + L.lane] = v;               \
+      } else {                                                                    \
+        if (kq % CKPT == 0) beta[(kq / CKPT) * 64 + L.lane] = v;                  \
+      }                                                                           \
     }                                                                             \
     if constexpr (MODE == 2) keep = L.p == J ? o : keep;                          \
     if constexpr (((NPAR0 + J) & 1) == 0) {                                       \
-      if (n0 + DIR * (j6 + J) != 0) win_normalize(v);                             \
+      /* no normalisation at counter 0; in the beta main pass that is the very last step, whose result nobody reads */ \
+      if (MODE == 1 || n0 + DIR * (j6 + J) != 0) win_normalize(v);                \
     }                                                                             \
   }
       STEP6(0) STEP6(1) STEP6(2) STEP6(3) STEP6(4) STEP6(5)
@@ -426,7 +431,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
           default: win_step<2, 2, W>(L, v, c[kk], B, o); break;
         }
         keep = L.p == i ? o : keep;
-        if ((kk & 1) == 0 && k0 + kk != 0) win_normalize(v);
+        if ((kk & 1) == 0 && (kk != 0 || k0 != 0)) win_normalize(v);
       }
       if (L.p < 6) store_out<W>(out, k0 + i6 + L.p, L.g, keep);
     }
