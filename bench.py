@@ -239,6 +239,13 @@ def main():
     ms_per_step = t_max / args.steps * 1e3
     value = world * B * args.steps / t_max
     tdec_alg = alg["tdec"]
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so this is the value of
+    # the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc/final_traffic.json), valid for B=128.
+    traffic = None
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc", "final_traffic.json")
+    if os.path.exists(pmc) and B == 128:
+        with open(pmc) as f:
+            traffic = json.load(f)["kernels"].get("tdec_win_kernel<16>", {}).get("traffic_bytes")
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
@@ -249,7 +256,7 @@ def main():
                    "avg_siso_passes_per_cb": round(it_all / (n_all * 13), 3), "sharding": "one UE per GPU, no data-path collective",
                    "streams": nstreams},
         "roofline": {"kernel": "tdec_win_kernel<16>", "bound": "hbm", "achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,
                      "note": "serial-trellis integer kernel: not HBM-bound by construction (SURVEY §8d); streaming kernels are in 'kernels'"},
         "kernels": kernels,
