@@ -51,6 +51,13 @@ int                srslte_hip_ofdm_symbol_sz(const srslte_hip_ofdm_t* q);
 int                srslte_hip_ofdm_sf_len(const srslte_hip_ofdm_t* q);
 int srslte_hip_ofdm_rx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_time, void* d_out_grid, int nof_sf, void* stream); /* ofdm.c:453-467 */
 int srslte_hip_ofdm_tx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_grid, void* d_out_time, int nof_sf, void* stream); /* ofdm.c:580-594 */
+/* MBSFN subframe layout on an extended-CP object (srslte_ofdm_{rx,tx}_init_mbsfn + srslte_ofdm_set_non_mbsfn_region,
+ * ofdm.c:120-137,:248-258,:286-305; slot layout of srslte_ofdm_rx_slot_mbsfn :424-437 / srslte_ofdm_tx_slot_mbsfn :558-574).
+ * The samples of the guard between the two regions are neither read (rx) nor written (tx). */
+int srslte_hip_ofdm_set_mbsfn(srslte_hip_ofdm_t* q, int enable, int non_mbsfn_region);
+/* one slot of each subframe (srslte_ofdm_rx_slot/_tx_slot ofdm.c:398-422,:488-530; mbsfn_layout=1: the MBSFN slot-0 layout);
+ * rx or tx according to the object; d_in/d_out are subframe bases as in the _sf_batch calls */
+int srslte_hip_ofdm_slot_batch(srslte_hip_ofdm_t* q, const void* d_in, void* d_out, int nof_sf, int slot_in_sf, int mbsfn_layout, void* stream);
 
 /* generic batched c2c DFT (replaces srslte_dft_run_guru_c, dft.h:137-152, dft_fftw.c:137-165,307-313) */
 int srslte_hip_dft_batch(const void* d_in, void* d_out, int N, int howmany, int idist, int odist, int forward, float scale, void* stream);
@@ -114,6 +121,11 @@ int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int16_t* d_inpu
 /* ------------------------------------------------------------------ turbo encoder (replaces srslte_tcod_encode, fec/turbocoder.h:44-76,
  * turbocoder.c:76-186): bits in (one per byte) -> 3K+12 bits out ([s p0 p1] triplets + 12 tail), nof_cb blocks */
 int srslte_hip_tcod_encode_batch(const uint8_t* d_input, uint8_t* d_output, uint32_t long_cb, uint32_t nof_cb, void* stream);
+/* byte-packed form (replaces the encoder proper of srslte_tcod_encode_lut, turbocoder.c:189-367; the CRC attachment of that
+ * call stays with the caller): d_input [nof_cb][in_stride] K/8 bytes MSB first; d_parity [nof_cb][par_stride] K/4+1 bytes =
+ * p1[K] t1[4] p2[K] t2[4] as one bit stream; d_sys_tail [nof_cb] = the byte the reference stores in input[K/8] */
+int srslte_hip_tcod_encode_bytes_batch(const uint8_t* d_input, uint32_t in_stride, uint8_t* d_parity, uint32_t par_stride, uint8_t* d_sys_tail,
+                                       uint32_t long_cb, uint32_t nof_cb, void* stream);
 
 /* ------------------------------------------------------------------ segmentation / interleaver (host, replaces cbsegm.c, tc_interl_lte.c) */
 typedef struct { /* same members and order as srslte_cbsegm_t (cbsegm.h:33-44) */

@@ -11,8 +11,8 @@
  * (srslte_dft_plan_t.p, srslte_tdec_t.dec16_hdlr[0], srslte_chest_dl_t.tmp_noise ...).
  * tests/test_abi_layout.py checks sizeof/offsetof of every struct below against the reference headers.
  *
- * Not provided (documented in DESIGN.md): real-to-real plans (srslte_dft_plan_r), MBSFN slots, 8-bit LLR decoders,
- * srslte_tcod_encode_lut, multi-port / multi-antenna estimation.
+ * Not provided (documented in DESIGN.md): 8-bit LLR decoders, MBSFN channel estimation, multi-port / multi-antenna
+ * estimation; those calls return SRSLTE_ERROR with a message.
  */
 #ifndef SRSLTE_HIP_SRSLTE_COMPAT_H
 #define SRSLTE_HIP_SRSLTE_COMPAT_H
@@ -67,6 +67,10 @@ typedef struct {
 void srslte_dft_load(void);
 void srslte_dft_exit(void);
 int  srslte_dft_plan(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, srslte_dft_mode_t type);
+int  srslte_dft_plan_r(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir); /* FFTW R2HC / HC2R half-complex layout */
+int  srslte_dft_replan(srslte_dft_plan_t* plan, int new_dft_points);
+int  srslte_dft_replan_r(srslte_dft_plan_t* plan, int new_dft_points);
+void srslte_dft_run_r(srslte_dft_plan_t* plan, const float* in, float* out);
 int  srslte_dft_plan_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir);
 int  srslte_dft_plan_guru_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, cf_t* in_buffer, cf_t* out_buffer, int istride,
                             int ostride, int how_many, int idist, int odist);
@@ -102,6 +106,15 @@ void srslte_ofdm_tx_slot(srslte_ofdm_t* q, int slot_in_sf);
 void srslte_ofdm_rx_sf(srslte_ofdm_t* q);
 void srslte_ofdm_tx_sf(srslte_ofdm_t* q);
 void srslte_ofdm_rx_sf_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output);
+void srslte_ofdm_rx_slot_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output);
+int  srslte_ofdm_init_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir);
+int  srslte_ofdm_init_mbsfn_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir,
+                             srslte_sf_t sf_type);
+int  srslte_ofdm_rx_init_mbsfn(srslte_ofdm_t* q, srslte_cp_t cp_type, cf_t* in_buffer, cf_t* out_buffer, uint32_t max_prb);
+int  srslte_ofdm_tx_init_mbsfn(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb);
+void srslte_ofdm_set_non_mbsfn_region(srslte_ofdm_t* q, uint8_t non_mbsfn_region);
+void srslte_ofdm_rx_slot_mbsfn(srslte_ofdm_t* q, cf_t* input, cf_t* output); /* extended-CP objects, region 1 or 2, no frequency shift */
+void srslte_ofdm_tx_slot_mbsfn(srslte_ofdm_t* q, cf_t* input, cf_t* output);
 int  srslte_ofdm_set_freq_shift(srslte_ofdm_t* q, float freq_shift);
 void srslte_ofdm_set_normalize(srslte_ofdm_t* q, bool normalize_enable);
 
@@ -131,6 +144,12 @@ typedef struct { uint32_t max_long_cb; uint8_t* temp; } srslte_tcod_t;
 int  srslte_tcod_init(srslte_tcod_t* h, uint32_t max_long_cb);
 void srslte_tcod_free(srslte_tcod_t* h);
 int  srslte_tcod_encode(srslte_tcod_t* h, uint8_t* input, uint8_t* output, uint32_t long_cb);
+typedef struct { /* srslte_crc_t, fec/crc.h:38-46 (crc.c itself stays in the reference library) */
+  uint64_t table[256]; int polynom; int order; uint64_t crcinit; uint64_t crcmask; uint64_t crchighbit; uint32_t srslte_crc_out;
+} srslte_crc_t;
+int  srslte_tcod_encode_lut(srslte_tcod_t* h, srslte_crc_t* crc_tb, srslte_crc_t* crc_cb, uint8_t* input, uint8_t* parity, uint32_t cblen_idx,
+                            bool last_cb);
+void srslte_tcod_gentable(void);
 
 /* ------------------------------------------------------------------ turbo decoder (turbodecoder.h:63-135) */
 typedef enum { SRSLTE_TDEC_8, SRSLTE_TDEC_16 } srslte_tdec_llr_type_t;
@@ -193,6 +212,7 @@ void srslte_chest_dl_res_set_identity(srslte_chest_dl_res_t* q);
 void srslte_chest_dl_res_set_ones(srslte_chest_dl_res_t* q);
 void srslte_chest_dl_res_free(srslte_chest_dl_res_t* q);
 int  srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell);
+int  srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id); /* SRSLTE_ERROR: MBSFN estimation not provided */
 int  srslte_chest_dl_estimate(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res);
 int  srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg, cf_t* input[SRSLTE_MAX_PORTS],
                                   srslte_chest_dl_res_t* res);

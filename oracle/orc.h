@@ -84,11 +84,13 @@ int orc_tdec_run_w(const int16_t* input, bool in_is_sb, uint32_t K, uint32_t W, 
 /* ---------------------------------------------------------------- DFT / OFDM (dft_fftw.c, ofdm.c, dft_precoding.c) */
 void orc_dft_exact(const orc_cf_t* in, orc_cf_t* out, int N, int forward); /* O(N^2), double precision */
 int  orc_fft(const orc_cf_t* in, orc_cf_t* out, int N, int forward);      /* mixed radix 2/3/4/5, float */
+void orc_dft_r2hc(const float* in, float* out, int N, int forward);       /* FFTW R2HC / HC2R via the exact DFT (dft_fftw.c:209-232) */
 typedef struct {
   int nof_prb, symbol_sz, nof_re, nof_symbols, sf_sz, slot_sz, cp_norm;
   bool normalize, freq_shift;
   float freq_shift_f;
   bool exact; /* use orc_dft_exact instead of orc_fft */
+  int  non_mbsfn_region; /* 0: regular subframe; 1|2: MBSFN subframe (extended-CP object), ofdm.c:424-437,:558-574 */
 } orc_ofdm_t;
 int  orc_ofdm_init(orc_ofdm_t* q, int nof_prb, bool cp_norm);
 void orc_ofdm_rx_sf(const orc_ofdm_t* q, const orc_cf_t* in_time, orc_cf_t* out_grid);

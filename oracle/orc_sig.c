@@ -236,6 +236,29 @@ static void dft_any(const orc_cf_t* in, orc_cf_t* out, int N, int forward, bool 
   }
 }
 
+void orc_dft_r2hc(const float* in, float* out, int N, int forward)
+{ /* dft_fftw.c:209-232 plans FFTW_R2HC (forward) / FFTW_HC2R (backward); FFTW's half-complex layout is
+     r0 r1 .. r[N/2] i[(N+1)/2-1] .. i1, the backward transform is unnormalised */
+  orc_cf_t *a = calloc((size_t)N, sizeof(orc_cf_t)), *b = calloc((size_t)N, sizeof(orc_cf_t));
+  if (forward) {
+    for (int i = 0; i < N; i++) a[i].re = in[i];
+    orc_dft_exact(a, b, N, 1);
+    for (int k = 0; k <= N / 2; k++) out[k] = b[k].re;
+    for (int k = 1; k < N - k; k++) out[N - k] = b[k].im;
+  } else {
+    a[0].re = in[0];
+    for (int k = 1; k < N - k; k++) {
+      a[k]     = (orc_cf_t){in[k], in[N - k]};
+      a[N - k] = (orc_cf_t){in[k], -in[N - k]};
+    }
+    if (N % 2 == 0) a[N / 2].re = in[N / 2];
+    orc_dft_exact(a, b, N, 0);
+    for (int i = 0; i < N; i++) out[i] = b[i].re;
+  }
+  free(a);
+  free(b);
+}
+
 /* ------------------------------------------------------------------ OFDM */
 
 int orc_ofdm_init(orc_ofdm_t* q, int nof_prb, bool cp_norm)
@@ -254,14 +277,35 @@ static orc_cf_t shift_val(const orc_ofdm_t* q, int t, int cplen)
   return (orc_cf_t){(float)cos(ph), (float)sin(ph)};
 }
 
+static void sym_layout(const orc_ofdm_t* q, int s, int* pos_out, int* cpl_out)
+{ /* first sample and CP length of symbol s. Regular: ofdm.c:384-393. MBSFN subframe (rx ofdm.c:424-437, tx :558-574): slot 0
+     = non_mbsfn_region normal-CP symbols, a guard of SRSLTE_NON_MBSFN_REGION_GUARD_LENGTH (phy_common.h:147), then
+     extended-CP symbols; slot 1 is a plain extended-CP slot (ofdm.c:463-465,:588-590). */
+  int N = q->symbol_sz, pos = 0, cpl = 0, reg = q->non_mbsfn_region;
+  for (int i = 0; i <= s; i++) {
+    int l = i % q->nof_symbols;
+    pos += i ? cpl + N : 0;
+    if (reg && i < q->nof_symbols) {
+      if (i == reg) {
+        pos += reg == 1 ? orc_cp_len_ext(N) - orc_cp_len_norm(0, N) : 2 * orc_cp_len_ext(N) - orc_cp_len_norm(0, N) - orc_cp_len_norm(1, N);
+      }
+      cpl = i >= reg ? orc_cp_len_ext(N) : orc_cp_len_norm(i, N);
+    } else {
+      cpl = q->cp_norm ? orc_cp_len_norm(l, N) : orc_cp_len_ext(N);
+    }
+  }
+  *pos_out = pos;
+  *cpl_out = cpl;
+}
+
 void orc_ofdm_rx_sf(const orc_ofdm_t* q, const orc_cf_t* in_time, orc_cf_t* out_grid)
 { /* ofdm.c:398-422 (rx_slot, guru path) + :453-457 (time-domain shift); dc = !freq_shift (ofdm.c:374) */
   int       N = q->symbol_sz, nre = q->nof_re, dc = q->freq_shift ? 0 : 1;
   float     norm = 1.0f / sqrtf((float)N);
   orc_cf_t *tin = malloc(sizeof(orc_cf_t) * N), *tout = malloc(sizeof(orc_cf_t) * N);
-  int       pos = 0;
   for (int s = 0; s < 2 * q->nof_symbols; s++) {
-    int l = s % q->nof_symbols, cpl = q->cp_norm ? orc_cp_len_norm(l, N) : orc_cp_len_ext(N);
+    int pos, cpl;
+    sym_layout(q, s, &pos, &cpl);
     for (int n = 0; n < N; n++) {
       orc_cf_t v = in_time[pos + cpl + n];
       tin[n]     = q->freq_shift ? cmul(v, shift_val(q, cpl + n, cpl)) : v;
@@ -275,7 +319,6 @@ void orc_ofdm_rx_sf(const orc_ofdm_t* q, const orc_cf_t* in_time, orc_cf_t* out_
     if (q->normalize) {
       for (int i = 0; i < nre; i++) { o[i].re *= norm; o[i].im *= norm; }
     }
-    pos += cpl + N;
   }
   free(tin);
   free(tout);
@@ -286,9 +329,9 @@ void orc_ofdm_tx_sf(const orc_ofdm_t* q, const orc_cf_t* in_grid, orc_cf_t* out_
   int       N = q->symbol_sz, nre = q->nof_re, dc = q->freq_shift ? 0 : 1;
   float     norm = 1.0f / sqrtf((float)N);
   orc_cf_t *tin = malloc(sizeof(orc_cf_t) * N), *tout = malloc(sizeof(orc_cf_t) * N);
-  int       pos = 0;
   for (int s = 0; s < 2 * q->nof_symbols; s++) {
-    int l = s % q->nof_symbols, cpl = q->cp_norm ? orc_cp_len_norm(l, N) : orc_cp_len_ext(N);
+    int pos, cpl;
+    sym_layout(q, s, &pos, &cpl);
     memset(tin, 0, sizeof(orc_cf_t) * N);
     const orc_cf_t* g = &in_grid[s * nre];
     for (int i = 0; i < nre / 2; i++) {
@@ -310,7 +353,6 @@ void orc_ofdm_tx_sf(const orc_ofdm_t* q, const orc_cf_t* in_grid, orc_cf_t* out_
         o[n] = cmul(o[n], shift_val(q, n, cpl));
       }
     }
-    pos += cpl + N;
   }
   free(tin);
   free(tout);

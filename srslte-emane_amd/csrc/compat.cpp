@@ -64,6 +64,7 @@ struct OfdmState {
   DevStage           in, out;
   bool               is_rx = true, norm = false, shift = false;
   float              shift_f = 0.f;
+  int                mbsfn_region = 0; // 0 = regular layout on the device object
 };
 
 struct TdecState {
@@ -107,11 +108,26 @@ int srslte_dft_plan_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t 
   return SRSLTE_SUCCESS;
 }
 
+int srslte_dft_plan_r(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir)
+{ // dft_fftw.c:209-232: FFTW r2r plan, R2HC (forward) / HC2R (backward); served by the complex kernel
+  if (!plan) return SRSLTE_ERROR_INVALID_INPUTS;
+  FftFactors  f;
+  const cf32* tw;
+  if (fft_get_plan(dft_points, &f, &tw)) return SRSLTE_ERROR;
+  memset(plan, 0, sizeof(*plan));
+  plan->in  = host_alloc(sizeof(float) * dft_points);
+  plan->out = host_alloc(sizeof(float) * dft_points);
+  plan->p   = new DftState();
+  plan->size = plan->init_size = dft_points;
+  plan->mode    = SRSLTE_REAL;
+  plan->dir     = dir;
+  plan->forward = dir == SRSLTE_DFT_FORWARD;
+  return SRSLTE_SUCCESS;
+}
+
 int srslte_dft_plan(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, srslte_dft_mode_t mode)
 { // dft_fftw.c:80-85
-  if (mode == SRSLTE_DFT_COMPLEX) return srslte_dft_plan_c(plan, dft_points, dir);
-  ERROR("real (r2r) DFT plans are not provided by the HIP build");
-  return SRSLTE_ERROR;
+  return mode == SRSLTE_DFT_COMPLEX ? srslte_dft_plan_c(plan, dft_points, dir) : srslte_dft_plan_r(plan, dft_points, dir);
 }
 
 int srslte_dft_plan_guru_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_dir_t dir, cf_t* in_buffer, cf_t* out_buffer, int istride,
@@ -155,6 +171,31 @@ int srslte_dft_replan_c(srslte_dft_plan_t* plan, int new_dft_points)
   }
   plan->size = new_dft_points;
   return SRSLTE_SUCCESS;
+}
+
+int srslte_dft_replan_r(srslte_dft_plan_t* plan, int new_dft_points)
+{ // dft_fftw.c:193-207 (the host buffers keep their init-time size upstream; grown here when needed)
+  FftFactors  f;
+  const cf32* tw;
+  if (!plan || fft_get_plan(new_dft_points, &f, &tw)) return SRSLTE_ERROR;
+  if (new_dft_points > plan->init_size) {
+    free(plan->in);
+    free(plan->out);
+    plan->in        = host_alloc(sizeof(float) * new_dft_points);
+    plan->out       = host_alloc(sizeof(float) * new_dft_points);
+    plan->init_size = new_dft_points;
+  }
+  plan->size = new_dft_points;
+  return SRSLTE_SUCCESS;
+}
+
+int srslte_dft_replan(srslte_dft_plan_t* plan, int new_dft_points)
+{ // dft_fftw.c:66-78
+  if (new_dft_points <= plan->init_size) {
+    return plan->mode == SRSLTE_DFT_COMPLEX ? srslte_dft_replan_c(plan, new_dft_points) : srslte_dft_replan_r(plan, new_dft_points);
+  }
+  ERROR("DFT: Error calling replan: new_dft_points (%d) must be lower or equal dft_size passed initially (%d)", new_dft_points, plan->init_size);
+  return SRSLTE_ERROR;
 }
 
 int srslte_dft_replan_guru_c(srslte_dft_plan_t* plan, int new_dft_points, cf_t* in_buffer, cf_t* out_buffer, int istride, int ostride,
@@ -239,12 +280,44 @@ void srslte_dft_run_c(srslte_dft_plan_t* plan, const cf_t* in, cf_t* out)
   }
 }
 
+void srslte_dft_run_r(srslte_dft_plan_t* plan, const float* in, float* out)
+{ // dft_fftw.c:315-334. R2HC: out = r0 r1 .. r[N/2] i[(N+1)/2-1] .. i1 of the forward DFT; HC2R: its unnormalised inverse.
+  const int         N = plan->size;
+  std::vector<cf_t> a(N), b(N);
+  if (plan->forward) {
+    for (int i = 0; i < N; i++) a[i] = {in[i], 0.f};
+  } else {
+    a[0] = {in[0], 0.f};
+    for (int k = 1; k < N - k; k++) {
+      a[k]     = {in[k], in[N - k]};
+      a[N - k] = {in[k], -in[N - k]};
+    }
+    if (N % 2 == 0) a[N / 2] = {in[N / 2], 0.f};
+  }
+  dft_exec(plan, a.data(), b.data(), 1, N, N);
+  float* f = (float*)plan->out;
+  if (plan->forward) {
+    for (int k = 0; k <= N / 2; k++) f[k] = b[k].re;
+    for (int k = 1; k < N - k; k++) f[N - k] = b[k].im;
+  } else {
+    for (int i = 0; i < N; i++) f[i] = b[i].re;
+  }
+  if (plan->norm) {
+    const float norm = 1.0f / N;
+    for (int i = 0; i < N; i++) f[i] *= norm;
+  }
+  if (plan->db) {
+    for (int i = 0; i < N; i++) f[i] = 10.0f * log10f(f[i]);
+  }
+  memcpy(out, f, sizeof(float) * N);
+}
+
 void srslte_dft_run(srslte_dft_plan_t* plan, const void* in, void* out)
-{
+{ // dft_fftw.c:269-275
   if (plan->mode == SRSLTE_DFT_COMPLEX) {
     srslte_dft_run_c(plan, (const cf_t*)in, (cf_t*)out);
   } else {
-    ERROR("real DFT plans are not provided by the HIP build");
+    srslte_dft_run_r(plan, (const float*)in, (float*)out);
   }
 }
 
@@ -259,7 +332,7 @@ void srslte_dft_run_guru_c(srslte_dft_plan_t* plan)
 }
 
 // ====================================================================================================== OFDM
-static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb, bool rx)
+static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb, bool rx, srslte_sf_t sf_type)
 { // ofdm.c:43-133
   const int N = lte_symbol_sz((int)nof_prb);
   if (!q || N < 0) {
@@ -285,11 +358,32 @@ static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* ou
   }
   q->fft_plan.p = st;
   if (in_buffer) bzero(in_buffer, sizeof(cf_t) * (rx ? q->sf_sz : 2 * q->nof_symbols * q->nof_re)); // ofdm.c:80-84
+  if (sf_type == SRSLTE_SF_MBSFN) { // ofdm.c:123-130
+    q->mbsfn_subframe   = true;
+    q->non_mbsfn_region = 2;
+  }
   return SRSLTE_SUCCESS;
 }
 
-int srslte_ofdm_rx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t max_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, max_prb, true); }
-int srslte_ofdm_tx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, nof_prb, false); }
+int srslte_ofdm_init_mbsfn_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir,
+                            srslte_sf_t sf_type)
+{ // ofdm.c:43-133; the symbol size is a function of nof_prb in every upstream caller
+  if (symbol_sz != lte_symbol_sz(nof_prb)) {
+    ERROR("Error: symbol_sz=%d does not match nof_prb=%d", symbol_sz, nof_prb);
+    return SRSLTE_ERROR;
+  }
+  return ofdm_init(q, cp, in_buffer, out_buffer, (uint32_t)nof_prb, dir == SRSLTE_DFT_FORWARD, sf_type);
+}
+int srslte_ofdm_init_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir)
+{ // ofdm.c:38-40
+  return srslte_ofdm_init_mbsfn_(q, cp, in_buffer, out_buffer, symbol_sz, nof_prb, dir, SRSLTE_SF_NORM);
+}
+
+int srslte_ofdm_rx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t max_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, max_prb, true, SRSLTE_SF_NORM); }
+int srslte_ofdm_tx_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, nof_prb, false, SRSLTE_SF_NORM); }
+int srslte_ofdm_rx_init_mbsfn(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t max_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, max_prb, true, SRSLTE_SF_MBSFN); }   // ofdm.c:246-256
+int srslte_ofdm_tx_init_mbsfn(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb) { return ofdm_init(q, cp, in_buffer, out_buffer, nof_prb, false, SRSLTE_SF_MBSFN); } // ofdm.c:284-305
+void srslte_ofdm_set_non_mbsfn_region(srslte_ofdm_t* q, uint8_t non_mbsfn_region) { q->non_mbsfn_region = non_mbsfn_region; }                                                                      // ofdm.c:133-136
 
 static void ofdm_free(srslte_ofdm_t* q)
 { // ofdm.c:214-233
@@ -314,12 +408,14 @@ static int ofdm_set_prb(srslte_ofdm_t* q, srslte_cp_t cp, uint32_t nof_prb, bool
   }
   const uint32_t max_prb = q->max_prb;
   cf_t *         in = q->in_buffer, *out = q->out_buffer;
-  const bool     norm = q->fft_plan.norm, shift = q->freq_shift;
+  const bool     norm = q->fft_plan.norm, shift = q->freq_shift, mbsfn = q->mbsfn_subframe;
   const float    sf = q->freq_shift_f;
+  const uint8_t  region = q->non_mbsfn_region;
   ofdm_free(q);
-  if (ofdm_init(q, cp, in, out, nof_prb, rx)) return SRSLTE_ERROR;
-  q->max_prb       = max_prb;
-  q->fft_plan.norm = norm;
+  if (ofdm_init(q, cp, in, out, nof_prb, rx, mbsfn ? SRSLTE_SF_MBSFN : SRSLTE_SF_NORM)) return SRSLTE_ERROR;
+  q->max_prb          = max_prb;
+  q->fft_plan.norm    = norm;
+  q->non_mbsfn_region = region;
   if (shift) srslte_ofdm_set_freq_shift(q, sf);
   return SRSLTE_SUCCESS;
 }
@@ -346,40 +442,89 @@ static bool ofdm_sync_state(srslte_ofdm_t* q, OfdmState* st)
     st->shift_f = q->freq_shift_f;
     if (srslte_hip_ofdm_set_freq_shift(st->h, st->shift_f)) return false;
   }
+  const int region = q->mbsfn_subframe ? q->non_mbsfn_region : 0;
+  if (region != st->mbsfn_region) {
+    if (srslte_hip_ofdm_set_mbsfn(st->h, region != 0, region)) return false;
+    st->mbsfn_region = region;
+  }
   return true;
 }
 
-static void ofdm_run_sf(srslte_ofdm_t* q, cf_t* input, cf_t* output)
+// Guard between the non-MBSFN and the MBSFN region of slot 0 (phy_common.h:147): never written by the transmitter (ofdm.c:570-572)
+static void mbsfn_gap(const srslte_ofdm_t* q, size_t* begin, size_t* len)
+{
+  const int N = (int)q->symbol_sz, ext = lte_cp_len_ext(N), n0 = lte_cp_len_norm(0, N), n1 = lte_cp_len_norm(1, N);
+  if (q->non_mbsfn_region == 1) {
+    *begin = (size_t)(n0 + N);
+    *len   = (size_t)(ext - n0);
+  } else {
+    *begin = (size_t)(n0 + N + n1 + N);
+    *len   = (size_t)(2 * ext - n0 - n1);
+  }
+}
+
+// One launch over `slots` (0 = slot 0, 1 = slot 1, 2 = both). host_in/host_out point at the first processed slot;
+// dev_slot is where that slot sits in the device staging (the geometry is relative to the subframe base).
+static void ofdm_run(srslte_ofdm_t* q, const cf_t* host_in, cf_t* host_out, int slots, int dev_slot, bool mbsfn_layout)
 {
   auto* st = (OfdmState*)q->fft_plan.p;
   if (!st || !ofdm_sync_state(q, st)) return;
-  const size_t n_time = sizeof(cf_t) * q->sf_sz, n_grid = sizeof(cf_t) * 2 * q->nof_symbols * q->nof_re;
-  const size_t nin = st->is_rx ? n_time : n_grid, nout = st->is_rx ? n_grid : n_time;
-  void *       di = st->in.get(nin), *dout = st->out.get(nout);
-  if (!di || !dout || !h2d(di, input, nin)) return;
-  int r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
-  if (r == SRSLTE_SUCCESS) d2h(output, dout, nout);
-}
-
-void srslte_ofdm_rx_sf(srslte_ofdm_t* q) { ofdm_run_sf(q, q->in_buffer, q->out_buffer); }                    // ofdm.c:453-467
-void srslte_ofdm_tx_sf(srslte_ofdm_t* q) { ofdm_run_sf(q, q->in_buffer, q->out_buffer); }                    // ofdm.c:580-594
-void srslte_ofdm_rx_sf_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output) { ofdm_run_sf(q, input, output); }   // ofdm.c:469-483
-
-static void ofdm_run_slot(srslte_ofdm_t* q, int slot)
-{ // a slot call processes the whole subframe on the device and returns the requested half (ofdm.c:398-422,:488-530)
-  auto* st = (OfdmState*)q->fft_plan.p;
-  if (!st || !ofdm_sync_state(q, st)) return;
-  const size_t n_time = sizeof(cf_t) * q->sf_sz, n_grid = sizeof(cf_t) * 2 * q->nof_symbols * q->nof_re;
-  const size_t nin = st->is_rx ? n_time : n_grid, nout = st->is_rx ? n_grid : n_time;
-  void *       di = st->in.get(nin), *dout = st->out.get(nout);
-  if (!di || !dout || !h2d(di, q->in_buffer, nin)) return;
-  int r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
+  const size_t t_slot = sizeof(cf_t) * q->slot_sz, g_slot = sizeof(cf_t) * q->nof_symbols * q->nof_re;
+  const size_t in_slot = st->is_rx ? t_slot : g_slot, out_slot = st->is_rx ? g_slot : t_slot;
+  const int    nslots = slots == 2 ? 2 : 1;
+  char *       di = (char*)st->in.get(2 * in_slot), *dout = (char*)st->out.get(2 * out_slot);
+  if (!di || !dout || !h2d(di + dev_slot * in_slot, host_in, nslots * in_slot)) return;
+  int r;
+  if (slots == 2) {
+    r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
+  } else {
+    r = srslte_hip_ofdm_slot_batch(st->h, di, dout, 1, dev_slot, mbsfn_layout, nullptr);
+  }
   if (r) return;
-  const size_t half = nout / 2;
-  d2h((char*)q->out_buffer + slot * half, (char*)dout + slot * half, half);
+  if (!st->is_rx && mbsfn_layout && dev_slot == 0) { // leave the caller's guard samples untouched, as upstream
+    size_t gb, gl;
+    mbsfn_gap(q, &gb, &gl);
+    d2h(host_out, dout, sizeof(cf_t) * gb);
+    d2h(host_out + gb + gl, dout + sizeof(cf_t) * (gb + gl), nslots * out_slot - sizeof(cf_t) * (gb + gl));
+  } else {
+    d2h(host_out, dout + dev_slot * out_slot, nslots * out_slot);
+  }
 }
-void srslte_ofdm_rx_slot(srslte_ofdm_t* q, int slot_in_sf) { ofdm_run_slot(q, slot_in_sf); }
-void srslte_ofdm_tx_slot(srslte_ofdm_t* q, int slot_in_sf) { ofdm_run_slot(q, slot_in_sf); }
+
+void srslte_ofdm_rx_sf(srslte_ofdm_t* q) { ofdm_run(q, q->in_buffer, q->out_buffer, 2, 0, q->mbsfn_subframe); } // ofdm.c:453-467
+void srslte_ofdm_tx_sf(srslte_ofdm_t* q) { ofdm_run(q, q->in_buffer, q->out_buffer, 2, 0, q->mbsfn_subframe); } // ofdm.c:580-594
+void srslte_ofdm_rx_sf_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output)
+{ // ofdm.c:469-483: the MBSFN branch upstream ignores the arguments and works on the bound buffers
+  if (q->mbsfn_subframe) {
+    ofdm_run(q, q->in_buffer, q->out_buffer, 2, 0, true);
+  } else {
+    ofdm_run(q, input, output, 2, 0, false);
+  }
+}
+void srslte_ofdm_rx_slot(srslte_ofdm_t* q, int slot_in_sf)
+{ // ofdm.c:398-422
+  ofdm_run(q, q->in_buffer + slot_in_sf * q->slot_sz, q->out_buffer + slot_in_sf * q->nof_re * q->nof_symbols, slot_in_sf ? 1 : 0, slot_in_sf ? 1 : 0, false);
+}
+void srslte_ofdm_tx_slot(srslte_ofdm_t* q, int slot_in_sf)
+{ // ofdm.c:488-530
+  ofdm_run(q, q->in_buffer + slot_in_sf * q->nof_re * q->nof_symbols, q->out_buffer + slot_in_sf * q->slot_sz, slot_in_sf ? 1 : 0, slot_in_sf ? 1 : 0, false);
+}
+void srslte_ofdm_rx_slot_ng(srslte_ofdm_t* q, cf_t* input, cf_t* output) { ofdm_run(q, input, output, 0, 0, false); } // ofdm.c:384-393
+
+static bool mbsfn_ready(srslte_ofdm_t* q)
+{
+  if (q->mbsfn_subframe) return true;
+  ERROR("MBSFN slot call on an object that was not initialised with srslte_ofdm_%s_init_mbsfn", q->fft_plan.forward ? "rx" : "tx");
+  return false;
+}
+void srslte_ofdm_rx_slot_mbsfn(srslte_ofdm_t* q, cf_t* input, cf_t* output)
+{ // ofdm.c:424-437
+  if (mbsfn_ready(q)) ofdm_run(q, input, output, 0, 0, true);
+}
+void srslte_ofdm_tx_slot_mbsfn(srslte_ofdm_t* q, cf_t* input, cf_t* output)
+{ // ofdm.c:558-574
+  if (mbsfn_ready(q)) ofdm_run(q, input, output, 0, 0, true);
+}
 
 // ====================================================================================================== transform precoding
 bool srslte_dft_precoding_valid_prb(uint32_t nof_prb) { return srslte_hip_dft_precoding_valid_prb(nof_prb) != 0; }
@@ -487,6 +632,55 @@ int srslte_tcod_encode(srslte_tcod_t* h, uint8_t* input, uint8_t* output, uint32
   if (!di || !dout || !h2d(di, input, long_cb)) return SRSLTE_ERROR;
   if (srslte_hip_tcod_encode_batch((const uint8_t*)di, (uint8_t*)dout, long_cb, 1, nullptr)) return SRSLTE_ERROR;
   return d2h(output, dout, 3 * long_cb + 12) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+
+void srslte_tcod_gentable(void) {} // turbocoder.c:369-425 builds host LUTs; the device tables are built on first use per K
+
+static inline void crc_put_byte(srslte_crc_t* h, uint8_t byte)
+{ // crc.h:67-75
+  const int ord = h->order - 8;
+  uint64_t  crc = h->crcinit;
+  h->crcinit    = (crc << 8) ^ h->table[((crc >> ord) & 0xff) ^ byte];
+}
+
+int srslte_tcod_encode_lut(srslte_tcod_t* h, srslte_crc_t* crc_tb, srslte_crc_t* crc_cb, uint8_t* input, uint8_t* parity, uint32_t cblen_idx,
+                           bool last_cb)
+{ // turbocoder.c:189-367: CRC attachment on the host exactly as upstream (running TB checksum across calls), encoder on the device
+  if (cblen_idx >= 188) return SRSLTE_ERROR;
+  const uint32_t long_cb = (uint32_t)lte_qpp_table[cblen_idx].K, nbytes = long_cb / 8;
+  if (h && long_cb > h->max_long_cb) {
+    ERROR("Turbo coder initiated for max_long_cb=%u", h->max_long_cb);
+    return SRSLTE_ERROR;
+  }
+  if (!crc_tb || long_cb < (uint32_t)((crc_cb ? crc_cb->order : 0) + (last_cb ? crc_tb->order : 0))) return SRSLTE_ERROR_INVALID_INPUTS;
+  auto append = [&](srslte_crc_t* c, uint32_t at, bool into_cb) { // :231-258 / :279-290: checksum bytes MSB first
+    const uint32_t checksum = (uint32_t)(c->crcinit & c->crcmask);
+    for (int i = 0; i < c->order / 8; i++) {
+      const uint8_t in = (uint8_t)((checksum >> (8 * (c->order / 8 - i - 1))) & 0xff);
+      if (into_cb) crc_put_byte(crc_cb, in);
+      input[at + i] = in;
+    }
+  };
+  if (crc_cb) {
+    crc_cb->crcinit = 0; // srslte_crc_set_init(crc_cb, 0), :207-209
+    const uint32_t n = (long_cb - crc_cb->order - (last_cb ? crc_tb->order : 0)) / 8;
+    for (uint32_t i = 0; i < n; i++) {
+      crc_put_byte(crc_tb, input[i]);
+      crc_put_byte(crc_cb, input[i]);
+    }
+    if (last_cb) append(crc_tb, n, true);
+    append(crc_cb, (long_cb - crc_cb->order) / 8, false);
+  } else {
+    const uint32_t n = (long_cb - (last_cb ? crc_tb->order : 0)) / 8;
+    for (uint32_t i = 0; i < n; i++) crc_put_byte(crc_tb, input[i]);
+    if (last_cb) append(crc_tb, n, false);
+  }
+  const uint32_t npar = long_cb / 4 + 1;
+  uint8_t *      di = (uint8_t*)g_tcod_in.get(nbytes), *dout = (uint8_t*)g_tcod_out.get(npar + 1);
+  if (!di || !dout || !h2d(di, input, nbytes)) return SRSLTE_ERROR;
+  if (srslte_hip_tcod_encode_bytes_batch(di, nbytes, dout, npar, dout + npar, long_cb, 1, nullptr)) return SRSLTE_ERROR;
+  if (!d2h(parity, dout, npar) || !d2h(&input[nbytes], dout + npar, 1)) return SRSLTE_ERROR;
+  return (int)(3 * long_cb + 12);
 }
 
 // ====================================================================================================== turbo decoder
@@ -642,6 +836,13 @@ int srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell)
       return SRSLTE_ERROR;
   }
   return SRSLTE_SUCCESS;
+}
+
+int srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id)
+{ // chest_dl.c:195-210 builds the MBSFN reference signal; the MBSFN estimator (:718-745) is SURVEY §8f N4
+  (void)q;
+  ERROR("MBSFN channel estimation (area id %u) is not provided by the HIP build", (unsigned)mbsfn_area_id);
+  return SRSLTE_ERROR;
 }
 
 int srslte_chest_dl_res_init(srslte_chest_dl_res_t* q, uint32_t max_prb)

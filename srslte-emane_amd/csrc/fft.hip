@@ -230,7 +230,7 @@ __device__ __forceinline__ void fft_any(const FftFactors& f, const cf32* __restr
 
 struct OfdmGeom {
   FftFactors f;
-  int        nof_re, nsym, sf_len, dc, cp_max;
+  int        nof_re, nsym, sf_len, dc, cp_max, sym0; // sym0: first symbol of this launch (slot calls)
   float      norm; // 1 or 1/sqrt(N)
   int        sym_off[14]; // first sample (start of CP) of each symbol in the subframe
   int        cp_len[14];
@@ -247,7 +247,7 @@ __global__ FFT_BOUNDS void ofdm_rx_kernel(const cf32* __restrict__ in, cf32* __r
                                                               const cf32* __restrict__ tw, const cf32* __restrict__ shift)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const int   s = blockIdx.x, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2;
+  const int   s = blockIdx.x + g.sym0, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2;
   const cf32* src = in + (size_t)sf * g.sf_len + g.sym_off[s] + g.cp_len[s];
   cf32*       dst = out + ((size_t)sf * g.nsym + s) * g.nof_re;
   fft_any<R0, R1, R2>(
@@ -273,7 +273,7 @@ __global__ FFT_BOUNDS void ofdm_tx_kernel(const cf32* __restrict__ in, cf32* __r
                                                               const cf32* __restrict__ tw, const cf32* __restrict__ shift)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const int   s = blockIdx.x, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2, cp = g.cp_len[s];
+  const int   s = blockIdx.x + g.sym0, sf = blockIdx.y, N = g.f.N, half = g.nof_re / 2, cp = g.cp_len[s];
   const cf32* src = in + ((size_t)sf * g.nsym + s) * g.nof_re;
   cf32*       dst = out + (size_t)sf * g.sf_len + g.sym_off[s];
   fft_any<R0, R1, R2>(
@@ -380,7 +380,9 @@ int fft_get_plan(int N, FftFactors* f, const cf32** d_tw)
 
 // ---------------------------------------------------------------- OFDM object
 struct srslte_hip_ofdm {
-  OfdmGeom    g;
+  OfdmGeom    g;  // regular subframe
+  OfdmGeom    gm; // MBSFN subframe (slot 0: non-MBSFN region + guard + extended-CP symbols), valid when mbsfn
+  bool        mbsfn;
   const cf32* d_tw;
   cf32*       d_shift; // [cp_max + N], exp(j 2 pi m f / N), m = -cp_max .. N-1; nullptr when no shift
   bool        is_rx, normalize;
@@ -407,6 +409,8 @@ extern "C" srslte_hip_ofdm_t* srslte_hip_ofdm_create(int nof_prb, int cp_is_norm
   q->g.dc     = 1; // srslte_dft_plan_set_dc(true), ofdm.c:111
   q->g.norm   = 1.0f;
   q->g.cp_max = 0;
+  q->g.sym0   = 0;
+  q->mbsfn    = false;
   int pos = 0;
   for (int s = 0; s < q->g.nsym; s++) {
     const int cp   = cp_is_norm ? lte_cp_len_norm(s % nsym_slot, N) : lte_cp_len_ext(N);
@@ -428,12 +432,49 @@ extern "C" int srslte_hip_ofdm_set_normalize(srslte_hip_ofdm_t* q, int enable)
   if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
   q->normalize = enable != 0;
   q->g.norm    = enable ? 1.0f / sqrtf((float)q->g.f.N) : 1.0f;
+  q->gm.norm   = q->g.norm;
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" int srslte_hip_ofdm_set_mbsfn(srslte_hip_ofdm_t* q, int enable, int non_mbsfn_region)
+{ // ofdm.c:424-437 (rx) and :558-574 (tx): slot 0 = `region` normal-CP symbols, a guard, then extended-CP symbols;
+  // slot 1 = plain extended-CP slot (ofdm.c:453-466,:580-594). Only meaningful on an extended-CP object (6 symbols/slot).
+  if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!enable) {
+    q->mbsfn = false;
+    return SRSLTE_SUCCESS;
+  }
+  if (q->g.nsym != 12 || non_mbsfn_region < 1 || non_mbsfn_region > 2) {
+    fprintf(stderr, "[srslte_hip] MBSFN layout needs an extended-CP object and non_mbsfn_region 1 or 2 (got %d symbols, region %d)\n", q->g.nsym,
+            non_mbsfn_region);
+    return SRSLTE_ERROR;
+  }
+  if (q->d_shift) {
+    fprintf(stderr, "[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
+    return SRSLTE_ERROR;
+  }
+  const int N = q->g.f.N, ext = lte_cp_len_ext(N);
+  q->gm       = q->g;
+  int guard = non_mbsfn_region == 1 ? ext - lte_cp_len_norm(0, N) : 2 * ext - lte_cp_len_norm(0, N) - lte_cp_len_norm(1, N); // phy_common.h:147
+  int pos   = 0;
+  for (int i = 0; i < 6; i++) {
+    if (i == non_mbsfn_region) pos += guard;
+    const int cp     = i >= non_mbsfn_region ? ext : lte_cp_len_norm(i, N);
+    q->gm.sym_off[i] = pos;
+    q->gm.cp_len[i]  = cp;
+    pos += cp + N;
+  }
+  q->mbsfn = true;
   return SRSLTE_SUCCESS;
 }
 
 extern "C" int srslte_hip_ofdm_set_freq_shift(srslte_hip_ofdm_t* q, float freq_shift)
 { // ofdm.c:360-378: builds the shift table and disables DC handling
   if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->mbsfn) {
+    fprintf(stderr, "[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
+    return SRSLTE_ERROR;
+  }
   const int         N = q->g.f.N, len = q->g.cp_max + N;
   std::vector<cf32> tab(len);
   for (int i = 0; i < len; i++) {
@@ -454,26 +495,40 @@ extern "C" void srslte_hip_ofdm_destroy(srslte_hip_ofdm_t* q)
   delete q;
 }
 
+static int ofdm_launch(srslte_hip_ofdm_t* q, const void* d_in, void* d_out, int nof_sf, int sym0, int nsym, bool mbsfn_layout, void* stream)
+{
+  if (nof_sf == 0 || nsym == 0) return SRSLTE_SUCCESS;
+  OfdmGeom g = mbsfn_layout ? q->gm : q->g;
+  g.sym0     = sym0;
+  dim3 grid(nsym, nof_sf);
+  if (q->is_rx) {
+    FFT_DISPATCH(ofdm_rx_kernel, g.f.N, grid, dim3(fft_threads(g.f.N)), fft_lds_bytes(g.f), (hipStream_t)stream, (const cf32*)d_in,
+                 (cf32*)d_out, g, q->d_tw, (const cf32*)q->d_shift);
+  } else {
+    FFT_DISPATCH(ofdm_tx_kernel, g.f.N, grid, dim3(fft_threads(g.f.N)), fft_lds_bytes(g.f), (hipStream_t)stream, (const cf32*)d_in,
+                 (cf32*)d_out, g, q->d_tw, (const cf32*)q->d_shift);
+  }
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
 extern "C" int srslte_hip_ofdm_rx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_time, void* d_out_grid, int nof_sf, void* stream)
 {
   if (!q || !d_in_time || !d_out_grid || nof_sf < 0 || !q->is_rx) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (nof_sf == 0) return SRSLTE_SUCCESS;
-  dim3 grid(q->g.nsym, nof_sf);
-  FFT_DISPATCH(ofdm_rx_kernel, q->g.f.N, grid, dim3(fft_threads(q->g.f.N)), fft_lds_bytes(q->g.f), (hipStream_t)stream,
-               (const cf32*)d_in_time, (cf32*)d_out_grid, q->g, q->d_tw, (const cf32*)q->d_shift);
-  LAUNCH_CHECK();
-  return SRSLTE_SUCCESS;
+  return ofdm_launch(q, d_in_time, d_out_grid, nof_sf, 0, q->g.nsym, q->mbsfn, stream);
 }
 
 extern "C" int srslte_hip_ofdm_tx_sf_batch(srslte_hip_ofdm_t* q, const void* d_in_grid, void* d_out_time, int nof_sf, void* stream)
 {
   if (!q || !d_in_grid || !d_out_time || nof_sf < 0 || q->is_rx) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (nof_sf == 0) return SRSLTE_SUCCESS;
-  dim3 grid(q->g.nsym, nof_sf);
-  FFT_DISPATCH(ofdm_tx_kernel, q->g.f.N, grid, dim3(fft_threads(q->g.f.N)), fft_lds_bytes(q->g.f), (hipStream_t)stream,
-               (const cf32*)d_in_grid, (cf32*)d_out_time, q->g, q->d_tw, (const cf32*)q->d_shift);
-  LAUNCH_CHECK();
-  return SRSLTE_SUCCESS;
+  return ofdm_launch(q, d_in_grid, d_out_time, nof_sf, 0, q->g.nsym, q->mbsfn, stream);
+}
+
+extern "C" int srslte_hip_ofdm_slot_batch(srslte_hip_ofdm_t* q, const void* d_in, void* d_out, int nof_sf, int slot_in_sf, int mbsfn_layout,
+                                          void* stream)
+{ // one slot of every subframe; pointers are subframe bases with the subframe strides of the _sf_batch calls
+  if (!q || !d_in || !d_out || nof_sf < 0 || slot_in_sf < 0 || slot_in_sf > 1 || (mbsfn_layout && !q->mbsfn)) return SRSLTE_ERROR_INVALID_INPUTS;
+  return ofdm_launch(q, d_in, d_out, nof_sf, slot_in_sf * q->g.nsym / 2, q->g.nsym / 2, mbsfn_layout != 0, stream);
 }
 
 extern "C" int srslte_hip_ofdm_symbol_sz(const srslte_hip_ofdm_t* q) { return q ? q->g.f.N : -1; }

@@ -81,37 +81,125 @@ __global__ __launch_bounds__(64) void tcod_kernel(const uint8_t* __restrict__ in
   }
 }
 
+// Byte-packed variant (srslte_tcod_encode_lut, turbocoder.c:189-367, without its CRC bookkeeping): K/8 input bytes MSB first;
+// parity = p1[K] | t1[4] | p2[K] | t2[4] as one MSB-first bit stream (K/4+1 bytes), sys_tail = the nibble the reference
+// stores in input[K/8]. Same chunked GF(2) scheme with whole bytes per lane.
+__global__ __launch_bounds__(64) void tcod_bytes_kernel(const uint8_t* __restrict__ in, uint32_t in_stride, uint8_t* __restrict__ parity,
+                                                        uint32_t par_stride, uint8_t* __restrict__ sys_tail,
+                                                        const uint16_t* __restrict__ perm, int K)
+{
+  __shared__ uint8_t xs[768], p2[768];
+  __shared__ int     zmap[8], resp[2][64], start[2][65], tails[12];
+  const int          cb = blockIdx.x, lane = threadIdx.x, nbytes = K / 8;
+  const uint8_t*     x = in + (size_t)cb * in_stride;
+  uint8_t*           par = parity + (size_t)cb * par_stride;
+  const int          cB = (nbytes + 63) / 64, lo = min(nbytes, lane * cB), hi = min(nbytes, lo + cB);
+  for (int i = lane; i < nbytes; i += 64) xs[i] = x[i];
+  if (lane < 8) {
+    int s = lane;
+    for (int i = 0; i < 8 * cB; i++) rsc_step(s, 0);
+    zmap[lane] = s;
+  }
+  __syncthreads();
+  auto bit_at = [&](int i) { return (xs[i >> 3] >> (7 - (i & 7))) & 1; };
+  int  sa = 0, sb = 0;
+  for (int i = 8 * lo; i < 8 * hi; i++) {
+    rsc_step(sa, bit_at(i));
+    rsc_step(sb, bit_at(perm[i]));
+  }
+  resp[0][lane] = sa;
+  resp[1][lane] = sb;
+  __syncthreads();
+  if (lane < 2) {
+    int s = 0;
+    for (int l = 0; l < 64; l++) {
+      start[lane][l] = s;
+      const int n    = min(nbytes, (l + 1) * cB) - min(nbytes, l * cB);
+      if (n == cB) {
+        s = zmap[s] ^ resp[lane][l];
+      } else if (n > 0) {
+        int z = s;
+        for (int i = 0; i < 8 * n; i++) rsc_step(z, 0);
+        s = z ^ resp[lane][l];
+      }
+    }
+    // termination (turbocoder.c:294-335): tails[6*enc + 2j] = x, [.. + 2j + 1] = z
+    for (int j = 0; j < 3; j++) {
+      const int bit          = (s & 1) ^ ((s >> 1) & 1);
+      tails[6 * lane + 2 * j]     = bit;
+      tails[6 * lane + 2 * j + 1] = rsc_step(s, bit);
+    }
+  }
+  __syncthreads();
+  sa = start[0][lane];
+  sb = start[1][lane];
+  for (int b = lo; b < hi; b++) {
+    int o1 = 0, o2 = 0;
+    for (int j = 0; j < 8; j++) {
+      o1 = (o1 << 1) | rsc_step(sa, bit_at(8 * b + j));
+      o2 = (o2 << 1) | rsc_step(sb, bit_at(perm[8 * b + j]));
+    }
+    par[b] = (uint8_t)o1;
+    p2[b]  = (uint8_t)o2;
+  }
+  __syncthreads();
+  auto nib = [&](int j) { return (tails[j] << 3) | (tails[j + 3] << 2) | (tails[j + 6] << 1) | tails[j + 9]; }; // turbocoder.c:337-349
+  for (int j = lane; j <= nbytes; j += 64) {
+    const int hi4 = j == 0 ? nib(1) : (p2[j - 1] & 0xf);
+    const int lo4 = j == nbytes ? nib(2) : (p2[j] >> 4);
+    par[nbytes + j] = (uint8_t)((hi4 << 4) | lo4);
+  }
+  if (lane == 0) sys_tail[cb] = (uint8_t)(nib(0) << 4);
+}
+
 std::mutex                     g_mtx;
 std::map<long, uint16_t*>      g_perm; // device*8192 + K -> device QPP table
 
 } // namespace
 
-extern "C" int srslte_hip_tcod_encode_batch(const uint8_t* d_input, uint8_t* d_output, uint32_t long_cb, uint32_t nof_cb, void* stream)
+static int tcod_perm(uint32_t long_cb, uint16_t** d_perm_out)
 {
-  if (!d_input || !d_output) return SRSLTE_ERROR_INVALID_INPUTS;
   const int idx = lte_cb_index(long_cb);
   if (idx < 0 || lte_qpp_table[idx].K != long_cb) {
     fprintf(stderr, "[srslte_hip] Invalid CB size %u\n", long_cb); // turbocoder.c:89-93
     return SRSLTE_ERROR;
   }
-  if (nof_cb == 0) return SRSLTE_SUCCESS;
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
-  uint16_t* d_perm = nullptr;
-  {
-    std::lock_guard<std::mutex> lk(g_mtx);
-    auto it = g_perm.find((long)dev * 8192 + long_cb);
-    if (it == g_perm.end()) {
-      std::vector<uint16_t> f, r;
-      lte_qpp_tables(long_cb, 1, f, r);
-      HIP_TRY(hipMalloc((void**)&d_perm, long_cb * 2));
-      HIP_TRY(hipMemcpy(d_perm, f.data(), long_cb * 2, hipMemcpyHostToDevice));
-      g_perm[(long)dev * 8192 + long_cb] = d_perm;
-    } else {
-      d_perm = it->second;
-    }
+  std::lock_guard<std::mutex> lk(g_mtx);
+  auto it = g_perm.find((long)dev * 8192 + long_cb);
+  if (it == g_perm.end()) {
+    std::vector<uint16_t> f, r;
+    lte_qpp_tables(long_cb, 1, f, r);
+    uint16_t* d_perm = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_perm, long_cb * 2));
+    HIP_TRY(hipMemcpy(d_perm, f.data(), long_cb * 2, hipMemcpyHostToDevice));
+    it = g_perm.emplace((long)dev * 8192 + long_cb, d_perm).first;
   }
+  *d_perm_out = it->second;
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" int srslte_hip_tcod_encode_batch(const uint8_t* d_input, uint8_t* d_output, uint32_t long_cb, uint32_t nof_cb, void* stream)
+{
+  if (!d_input || !d_output) return SRSLTE_ERROR_INVALID_INPUTS;
+  uint16_t* d_perm = nullptr;
+  if (int r = tcod_perm(long_cb, &d_perm)) return r;
+  if (nof_cb == 0) return SRSLTE_SUCCESS;
   hipLaunchKernelGGL(tcod_kernel, dim3(nof_cb), dim3(64), 0, (hipStream_t)stream, d_input, d_output, (const uint16_t*)d_perm, (int)long_cb);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" int srslte_hip_tcod_encode_bytes_batch(const uint8_t* d_input, uint32_t in_stride, uint8_t* d_parity, uint32_t par_stride,
+                                                  uint8_t* d_sys_tail, uint32_t long_cb, uint32_t nof_cb, void* stream)
+{
+  if (!d_input || !d_parity || !d_sys_tail || in_stride < long_cb / 8 || par_stride < long_cb / 4 + 1) return SRSLTE_ERROR_INVALID_INPUTS;
+  uint16_t* d_perm = nullptr;
+  if (int r = tcod_perm(long_cb, &d_perm)) return r;
+  if (nof_cb == 0) return SRSLTE_SUCCESS;
+  hipLaunchKernelGGL(tcod_bytes_kernel, dim3(nof_cb), dim3(64), 0, (hipStream_t)stream, d_input, in_stride, d_parity, par_stride, d_sys_tail,
+                     (const uint16_t*)d_perm, (int)long_cb);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }

@@ -97,7 +97,7 @@ class OrcChestRes(C.Structure):
 class OrcOfdm(C.Structure):
     _fields_ = [("nof_prb", C.c_int), ("symbol_sz", C.c_int), ("nof_re", C.c_int), ("nof_symbols", C.c_int), ("sf_sz", C.c_int),
                 ("slot_sz", C.c_int), ("cp_norm", C.c_int), ("normalize", C.c_bool), ("freq_shift", C.c_bool),
-                ("freq_shift_f", C.c_float), ("exact", C.c_bool)]
+                ("freq_shift_f", C.c_float), ("exact", C.c_bool), ("non_mbsfn_region", C.c_int)]
 
 
 class OrcSchCfg(C.Structure):
@@ -139,3 +139,25 @@ class RefChestCfg(C.Structure):
 def opaque(nbytes=1 << 20):
     """Zeroed storage for a reference object struct the harness never inspects (srslte_tdec_t, srslte_chest_dl_t ...)."""
     return C.create_string_buffer(nbytes)
+
+
+class SrslteCrc(C.Structure):
+    """srslte_crc_t (fec/crc.h:38-46)."""
+    _fields_ = [("table", C.c_uint64 * 256), ("polynom", C.c_int), ("order", C.c_int), ("crcinit", C.c_uint64), ("crcmask", C.c_uint64),
+                ("crchighbit", C.c_uint64), ("srslte_crc_out", C.c_uint32)]
+
+
+def make_crc(poly, order):
+    """What srslte_crc_init leaves in the struct (crc.c:30-46,:70-96), for calls that take a caller-initialised srslte_crc_t."""
+    h = SrslteCrc()
+    h.polynom, h.order, h.crcinit = poly, order, 0
+    h.crcmask, h.crchighbit = (1 << order) - 1, 1 << (order - 1)
+    for i in range(256):
+        crc = i << (order - 8)
+        for _ in range(8):
+            bit = crc & h.crchighbit
+            crc <<= 1
+            if bit:
+                crc ^= poly
+        h.table[i] = crc & h.crcmask
+    return h

@@ -158,5 +158,31 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
 
 
+def extra():
+    """Fixtures added after the first set; each draws from its own generator so the files above stay byte-identical."""
+    from _libs import make_crc
+    R = ref()
+    assert R is not None, "build oracle/_ref first"
+    # ---------------- byte encoder with fused CRC attachment (srslte_tcod_encode_lut, turbocoder.c:189-367, as sch.c:260 drives it)
+    rng = np.random.default_rng(2026100301)
+    tcod = opaque(4096)
+    R.srslte_tcod_init(tcod, 6144)
+    lut = {}
+    for n, (idx, with_cb, last, tb_init) in enumerate(((0, False, False, 0), (17, True, False, 0x123456), (59, True, True, 0xabcdef),
+                                                       (100, False, True, 0x5a5a5a), (183, True, False, 0), (187, True, True, 0x00ff00))):
+        K = R.srslte_cbsegm_cbsize(idx)
+        data = rng.integers(0, 256, K // 8 + 1).astype(np.uint8)
+        buf, par = data.copy(), np.zeros(K // 4 + 2, np.uint8)
+        crc_tb, crc_cb = make_crc(0x1864CFB, 24), make_crc(0x1800063, 24)
+        crc_tb.crcinit = tb_init
+        assert R.srslte_tcod_encode_lut(tcod, C.byref(crc_tb), C.byref(crc_cb) if with_cb else None, p(buf), p(par), idx, last) == 3 * K + 12
+        lut["meta_%d" % n] = np.array([idx, K, with_cb, last, tb_init, crc_tb.crcinit], np.uint64)
+        lut["in_%d" % n], lut["sys_%d" % n], lut["par_%d" % n] = data, buf, par[: K // 4 + 1]
+    np.savez_compressed(os.path.join(OUT, "tcod_lut.npz"), **lut)
+    print("tcod_lut.npz", os.path.getsize(os.path.join(OUT, "tcod_lut.npz")), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "--extra-only" not in sys.argv:
+        main()
+    extra()

@@ -23,6 +23,7 @@ STRUCTS = {
     "srslte_cbsegm_t": ["F", "C", "K1", "K2", "K1_idx", "K2_idx", "C1", "C2", "tbs"],
     "srslte_tc_interl_t": ["forward", "reverse", "max_long_cb"],
     "srslte_tcod_t": ["max_long_cb", "temp"],
+    "srslte_crc_t": ["table", "polynom", "order", "crcinit", "crcmask", "crchighbit", "srslte_crc_out"],
     "srslte_tdec_t": ["max_long_cb", "dec8_hdlr", "dec16_hdlr", "dec8", "dec16", "nof_blocks8", "nof_blocks16", "app1", "app2", "ext1", "ext2", "syst0",
                       "parity0", "parity1", "input_conv", "force_not_sb", "dec_type", "current_llr_type", "current_dec", "current_long_cb",
                       "current_inter_idx", "current_cbidx", "interleaver", "n_iter"],

@@ -49,6 +49,122 @@ def test_ofdm_objects(prb):
     assert L.srslte_ofdm_rx_init(rx, 0, p(time_buf), p(grid_out), 111) == -1  # ofdm.c:237-240
 
 
+def test_ofdm_slot_calls():
+    """srslte_ofdm_rx_slot/_tx_slot/_rx_slot_ng (ofdm.c:384-422,:488-530) give the same halves as the subframe calls."""
+    L, rng, prb = hip(), np.random.default_rng(11), 25
+    N = L.srslte_symbol_sz(prb)
+    nre, sf = 14 * 12 * prb, 15 * N
+    grid_in, time_buf, grid_out = aligned(2 * nre, np.float32), aligned(2 * sf, np.float32), aligned(2 * nre, np.float32)
+    tx, rx = opaque(4096), opaque(4096)
+    assert L.srslte_ofdm_tx_init(tx, 0, p(grid_in), p(time_buf), prb) == 0 and L.srslte_ofdm_rx_init(rx, 0, p(time_buf), p(grid_out), prb) == 0
+    g = (rng.standard_normal(nre) + 1j * rng.standard_normal(nre)).astype(np.complex64)
+    grid_in.view(np.complex64)[:] = g
+    L.srslte_ofdm_tx_sf(tx)
+    whole = time_buf.view(np.complex64).copy()
+    time_buf[:] = 0
+    L.srslte_ofdm_tx_slot(tx, 1)
+    assert np.all(time_buf.view(np.complex64)[: sf // 2] == 0) and np.array_equal(time_buf.view(np.complex64)[sf // 2:], whole[sf // 2:])
+    L.srslte_ofdm_tx_slot(tx, 0)
+    assert np.array_equal(time_buf.view(np.complex64), whole)
+    L.srslte_ofdm_rx_sf(rx)
+    full = grid_out.view(np.complex64).copy()
+    grid_out[:] = 0
+    L.srslte_ofdm_rx_slot(rx, 1)
+    assert np.all(grid_out.view(np.complex64)[: nre // 2] == 0) and np.array_equal(grid_out.view(np.complex64)[nre // 2:], full[nre // 2:])
+    ng = np.zeros(nre // 2, np.complex64)
+    second = np.ascontiguousarray(whole[sf // 2:])
+    L.srslte_ofdm_rx_slot_ng(rx, p(second), p(ng))
+    assert np.array_equal(ng, full[nre // 2:])
+    out2 = np.zeros(nre, np.complex64)
+    L.srslte_ofdm_rx_sf_ng(rx, p(whole), p(out2))
+    assert np.array_equal(out2, full)
+    L.srslte_ofdm_tx_free(tx)
+    L.srslte_ofdm_rx_free(rx)
+
+
+@pytest.mark.parametrize("prb,region", [(6, 1), (25, 2), (100, 2)])
+def test_ofdm_mbsfn(prb, region):
+    """MBSFN subframe objects (ofdm.c:246-305 init, :424-437 rx slot, :558-574 tx slot, :453-467/:580-594 subframe)."""
+    L, rng = hip(), np.random.default_rng(prb + region)
+    N = L.srslte_symbol_sz(prb)
+    nre, sf = 12 * 12 * prb, 15 * N
+    grid_in, time_buf, grid_out = aligned(2 * nre, np.float32), aligned(2 * sf, np.float32), aligned(2 * nre, np.float32)
+    tx, rx = opaque(4096), opaque(4096)
+    assert L.srslte_ofdm_tx_init_mbsfn(tx, 1, p(grid_in), p(time_buf), prb) == 0
+    assert L.srslte_ofdm_rx_init_mbsfn(rx, 1, p(time_buf), p(grid_out), prb) == 0
+    for o in (tx, rx):
+        L.srslte_ofdm_set_non_mbsfn_region(o, region)
+        L.srslte_ofdm_set_normalize(o, True)
+    g = (rng.standard_normal(nre) + 1j * rng.standard_normal(nre)).astype(np.complex64)
+    grid_in.view(np.complex64)[:] = g
+    time_buf.view(np.complex64)[:] = 7 + 7j
+    L.srslte_ofdm_tx_sf(tx)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, False)
+    q.normalize, q.exact, q.non_mbsfn_region = True, True, region
+    ref_t = np.full(sf, 7 + 7j, np.complex64)
+    oracle().orc_ofdm_tx_sf(C.byref(q), p(g), p(ref_t))
+    t = time_buf.view(np.complex64)
+    gap = ref_t == 7 + 7j
+    assert gap.sum() > 0 and np.all(t[gap] == 7 + 7j)  # the guard between the regions is left untouched (ofdm.c:570-572)
+    assert close(t, ref_t)
+    L.srslte_ofdm_rx_sf(rx)
+    assert np.mean(np.abs(grid_out.view(np.complex64) - g) ** 2) < 1e-9
+    ref_g = np.zeros(nre, np.complex64)
+    oracle().orc_ofdm_rx_sf(C.byref(q), p(t.copy()), p(ref_g))
+    assert close(grid_out.view(np.complex64), ref_g)
+    # slot-level MBSFN calls on caller pointers
+    slot0_t, slot0_g = np.full(sf // 2, 7 + 7j, np.complex64), np.zeros(nre // 2, np.complex64)
+    L.srslte_ofdm_tx_slot_mbsfn(tx, p(np.ascontiguousarray(g[: nre // 2])), p(slot0_t))
+    assert np.array_equal(slot0_t, t[: sf // 2])
+    L.srslte_ofdm_rx_slot_mbsfn(rx, p(slot0_t), p(slot0_g))
+    assert np.array_equal(slot0_g, grid_out.view(np.complex64)[: nre // 2])
+    L.srslte_ofdm_tx_free(tx)
+    L.srslte_ofdm_rx_free(rx)
+
+
+@pytest.mark.parametrize("N", [128, 300, 1536])
+def test_dft_plan_r(N):
+    """srslte_dft_plan_r / srslte_dft_run_r (dft_fftw.c:209-232,:315-334): FFTW half-complex layout, 1/N norm."""
+    L, rng = hip(), np.random.default_rng(N)
+    x = rng.standard_normal(N).astype(np.float32)
+    fwd, bwd = DftPlan(), DftPlan()
+    assert L.srslte_dft_plan(C.byref(fwd), N, 0, 1) == 0 and L.srslte_dft_plan_r(C.byref(bwd), N, 1) == 0
+    assert fwd.mode == 1 and bwd.mode == 1
+    hc, ref_hc, back = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros(N, np.float32)
+    L.srslte_dft_run(C.byref(fwd), p(x), p(hc))
+    oracle().orc_dft_r2hc(p(x), p(ref_hc), N, 1)
+    assert close(hc, ref_hc)
+    L.srslte_dft_plan_set_norm(C.byref(bwd), True)
+    L.srslte_dft_run_r(C.byref(bwd), p(hc), p(back))
+    assert np.abs(back - x).max() < 1e-4 * np.abs(x).max() * 10
+    assert L.srslte_dft_replan(C.byref(fwd), N // 2) == 0 and fwd.size == N // 2
+    assert L.srslte_dft_replan(C.byref(fwd), 2 * N) == -1
+    L.srslte_dft_plan_free(C.byref(fwd))
+    L.srslte_dft_plan_free(C.byref(bwd))
+
+
+def test_tcod_encode_lut_golden():
+    """srslte_tcod_encode_lut (turbocoder.c:189-367) incl. its in-place CRC attachment, against reference outputs."""
+    import os
+    from _libs import make_crc
+    L = hip()
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tcod_lut.npz"))
+    tcod = opaque(64)
+    assert L.srslte_tcod_init(tcod, 6144) == 0
+    L.srslte_tcod_gentable()
+    for n in range(6):
+        idx, K, with_cb, last, tb_init, tb_final = (int(v) for v in g["meta_%d" % n])
+        buf, par = g["in_%d" % n].copy(), np.zeros(K // 4 + 2, np.uint8)
+        crc_tb, crc_cb = make_crc(0x1864CFB, 24), make_crc(0x1800063, 24)
+        crc_tb.crcinit = tb_init
+        r = L.srslte_tcod_encode_lut(tcod, C.byref(crc_tb), C.byref(crc_cb) if with_cb else None, p(buf), p(par), idx, bool(last))
+        assert r == 3 * K + 12
+        assert np.array_equal(buf, g["sys_%d" % n]) and np.array_equal(par[: K // 4 + 1], g["par_%d" % n]) and crc_tb.crcinit == tb_final
+    assert L.srslte_tcod_encode_lut(tcod, C.byref(crc_tb), None, p(buf), p(par), 188, False) == -1
+    L.srslte_tcod_free(tcod)
+
+
 @pytest.mark.parametrize("N", [128, 1536, 12 * 25])
 def test_dft_plan_options(N):
     """dft_test.c:80-130: forward o backward identity for the mirror/dc/norm option combinations + direct check."""

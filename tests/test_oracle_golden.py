@@ -33,6 +33,61 @@ def test_tcod_golden_and_kat():
     assert np.array_equal(np.unpackbits(hard), g["kat_in"])
 
 
+def test_tcod_lut_golden():
+    """Byte encoder layout + CB CRC of srslte_tcod_encode_lut's outputs (tests/gen_golden.py:extra)."""
+    g = load("tcod_lut.npz")
+    oracle().orc_crc_bytes.restype = C.c_uint32
+    for n in range(6):
+        idx, K, with_cb, last, tb_init, tb_final = (int(v) for v in g["meta_%d" % n])
+        sys_, par = g["sys_%d" % n].copy(), np.zeros(K // 4 + 2, np.uint8)
+        assert oracle().orc_tcod_encode_bytes(p(sys_), p(par), K) == 3 * K + 12
+        assert np.array_equal(sys_, g["sys_%d" % n]) and np.array_equal(par[: K // 4 + 1], g["par_%d" % n])
+        if with_cb:  # turbocoder.c:247-258: CRC24B over everything before it
+            body = np.ascontiguousarray(sys_[: K // 8 - 3])
+            crc = oracle().orc_crc_bytes(0x1800063, 24, p(body), K - 24)
+            assert [crc >> 16 & 0xff, crc >> 8 & 0xff, crc & 0xff] == list(sys_[K // 8 - 3: K // 8])
+
+
+def test_ofdm_mbsfn_and_r2hc_definitions():
+    """The oracle's MBSFN symbol layout (ofdm.c:424-437,:558-574) and half-complex DFT against numpy on first principles."""
+    from _libs import OrcOfdm
+    rng = np.random.default_rng(5)
+    for prb, region in ((6, 1), (6, 2), (25, 2)):
+        q = OrcOfdm()
+        assert oracle().orc_ofdm_init(C.byref(q), prb, False) == 0
+        q.exact, q.normalize, q.non_mbsfn_region = True, False, region
+        N, nre = q.symbol_sz, 12 * prb
+        ext, n0, n1 = -(-512 * N // 2048), -(-160 * N // 2048), -(-144 * N // 2048)
+        g = (rng.standard_normal(12 * nre) + 1j * rng.standard_normal(12 * nre)).astype(np.complex64)
+        t = np.full(15 * N, 7 + 7j, np.complex64)
+        oracle().orc_ofdm_tx_sf(C.byref(q), p(g), p(t))
+        pos, exp, touched = 0, np.full(15 * N, 7 + 7j, np.complex64), np.zeros(15 * N, bool)
+        for s in range(12):
+            if s == region:
+                pos += (ext - n0) if region == 1 else (2 * ext - n0 - n1)
+            cp = ext if (s >= region) else (n0 if s == 0 else n1)
+            X = np.zeros(N, np.complex128)
+            X[1: nre // 2 + 1], X[N - nre // 2:] = g[s * nre + nre // 2: (s + 1) * nre], g[s * nre: s * nre + nre // 2]
+            x = np.fft.ifft(X) * N
+            exp[pos: pos + cp], exp[pos + cp: pos + cp + N] = x[N - cp:], x
+            touched[pos: pos + cp + N] = True
+            pos += cp + N
+        assert pos == 15 * N and np.abs(t - exp).max() < 1e-4 * np.abs(exp).max()
+        assert np.all(t[~touched] == 7 + 7j) and (~touched).sum() == ((ext - n0) if region == 1 else (2 * ext - n0 - n1))
+        back = np.zeros(12 * nre, np.complex64)
+        oracle().orc_ofdm_rx_sf(C.byref(q), p(t), p(back))
+        assert np.abs(back / N - g).max() < 1e-4
+    for N in (8, 15, 128, 300):
+        x = rng.standard_normal(N).astype(np.float32)
+        hc, back = np.zeros(N, np.float32), np.zeros(N, np.float32)
+        oracle().orc_dft_r2hc(p(x), p(hc), N, 1)
+        X = np.fft.fft(x.astype(np.float64))
+        exp = np.concatenate([X.real[: N // 2 + 1], X.imag[1: (N + 1) // 2][::-1]])
+        assert np.abs(hc - exp).max() < 1e-4 * np.abs(exp).max()
+        oracle().orc_dft_r2hc(p(hc), p(back), N, 0)
+        assert np.abs(back / N - x).max() < 1e-4
+
+
 @pytest.mark.parametrize("K", [40, 176, 504, 1008, 5824, 6144])
 def test_tdec_golden(K):
     g = load("tdec.npz")

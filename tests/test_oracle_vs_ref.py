@@ -36,6 +36,35 @@ def test_turbo_encoder_all_188_sizes():
         assert np.array_equal(a, b), K
 
 
+def test_turbo_encoder_lut_bytes():
+    """srslte_tcod_encode_lut (turbocoder.c:189-367) as turbocoder_test.c:103 calls it, plus the CRC-fusing forms sch.c:260 uses:
+    packed parity/tail layout of the oracle's byte encoder and make_crc() vs the reference's srslte_crc_init."""
+    from _libs import SrslteCrc, make_crc
+    R, rng = ref(), np.random.default_rng(2)
+    tcod = opaque(4096)
+    R.srslte_tcod_init(tcod, 6144)
+    mine = make_crc(0x1864CFB, 24)
+    theirs = SrslteCrc()
+    assert R.srslte_crc_init(C.byref(theirs), 0x1864CFB, 24) == 0
+    assert bytes(mine) == bytes(theirs)
+    for idx in list(range(0, 188, 9)) + [187]:
+        K = R.srslte_cbsegm_cbsize(idx)
+        for with_cb, last in ((False, False), (True, False), (True, True), (False, True)):
+            if with_cb and last and K < 56:
+                continue  # both CRCs do not fit (upstream would index input[-1]); a CB CRC implies C > 1 and a large K
+            data = rng.integers(0, 256, K // 8 + 1).astype(np.uint8)
+            a_in, b_in = data.copy(), data.copy()
+            a_par, b_par = np.zeros(K // 4 + 2, np.uint8), np.zeros(K // 4 + 2, np.uint8)
+            crc_tb, crc_cb = make_crc(0x1864CFB, 24), make_crc(0x1800063, 24)
+            crc_tb.crcinit = 0x5a5a5a  # a running TB checksum, as in the middle of a transport block
+            r = R.srslte_tcod_encode_lut(tcod, C.byref(crc_tb), C.byref(crc_cb) if with_cb else None, p(a_in), p(a_par), idx, last)
+            assert r == 3 * K + 12
+            # oracle: the caller attaches the CRCs (orc_dlsch_encode does the same), then the byte encoder runs
+            b_in[: K // 8] = a_in[: K // 8]
+            assert oracle().orc_tcod_encode_bytes(p(b_in), p(b_par), K) == 3 * K + 12
+            assert np.array_equal(a_in, b_in) and np.array_equal(a_par[: K // 4 + 1], b_par[: K // 4 + 1]), (K, with_cb, last)
+
+
 @pytest.mark.parametrize("K", ALL_K[::6] + [400, 408, 800, 816, 6144])
 def test_turbo_decoder_vs_ref(K):
     """Both input layouts, 1..6 passes, three SNR/scale points (turbodecoder_test.c:117-311 style stimulus)."""
