@@ -80,6 +80,8 @@ uint32_t orc_tdec_autoimp_subblocks_8bit(uint32_t K); /* turbodecoder.c:421-436 
 int orc_tdec_run(const int16_t* input, bool in_is_sb, uint32_t K, uint32_t nof_iter, uint8_t* out, uint8_t* hard_per_iter);
 /* force a numerics: W = 0 (generic, wrapping), 8 (sse16: >>1), 16 (avx16) */
 int orc_tdec_run_w(const int16_t* input, bool in_is_sb, uint32_t K, uint32_t W, uint32_t nof_iter, uint8_t* out, uint8_t* hard_per_iter);
+/* 8-bit LLRs, AUTO back-end selection of an AVX2 host (srslte_tdec_run_all_8bit, turbodecoder.c:421-487,:565-593) */
+int orc_tdec_run_8bit(const int8_t* input, bool in_is_sb, uint32_t K, uint32_t nof_iter, uint8_t* out, uint8_t* hard_per_iter);
 
 /* ---------------------------------------------------------------- DFT / OFDM (dft_fftw.c, ofdm.c, dft_precoding.c) */
 void orc_dft_exact(const orc_cf_t* in, orc_cf_t* out, int N, int forward); /* O(N^2), double precision */
@@ -138,6 +140,7 @@ int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, 
 int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms,
                  bool put);
 void orc_scramble_s(int16_t* llr, const uint8_t* c, int len); /* scrambling.c:45-48 */
+void orc_scramble_b(int8_t* llr, const uint8_t* c, int len);  /* scrambling.c:48-51 */
 uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t cell_id); /* 36.211 6.3.1; sequences.c */
 
 typedef struct {
@@ -147,6 +150,7 @@ typedef struct {
 int orc_dlsch_encode(const orc_sch_cfg_t* cfg, const uint8_t* data, uint8_t* e_bits);
 /* sch.c:299-500 decode with CRC early stop; returns 0 when TB CRC ok; cb_iters[C] optional */
 int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok);
+int orc_dlsch_decode_8bit(const orc_sch_cfg_t* cfg, const int8_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok);
 
 #ifdef __cplusplus
 }

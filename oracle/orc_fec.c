@@ -625,6 +625,250 @@ int orc_tdec_run(const int16_t* input, bool in_is_sb, uint32_t K, uint32_t nof_i
   return orc_tdec_run_w(input, in_is_sb, K, orc_tdec_autoimp_subblocks(K), nof_iter, out, hard_per_iter);
 }
 
+/* --- 8-bit windowed decoders (turbodecoder_win.h with WINIMP sse8: W = 16, avx8: W = 32): saturating int8, INF = 0,
+       max-normalisation after every step but the one with counter 0, extrinsic output >> 1 */
+static inline int8_t sat8(int v) { return (int8_t)(v > 127 ? 127 : (v < -128 ? -128 : v)); }
+static inline int8_t sadd8(int8_t a, int8_t b) { return sat8((int)a + (int)b); }
+static inline int8_t ssub8(int8_t a, int8_t b) { return sat8((int)a - (int)b); }
+static inline int8_t smax8(int8_t a, int8_t b) { return a > b ? a : b; }
+static inline int8_t tail_sadd8(int8_t x, int8_t y)
+{ /* turbodecoder_win.h:322-330 with use_saturated_add: clamps at +127 only, the negative side wraps in the cast */
+  int16_t z = (int16_t)(x + y);
+  return z > 127 ? 127 : (int8_t)z;
+}
+
+static inline void win_normalize8(uint32_t k, int8_t old[8][WMAX], uint32_t W)
+{ /* turbodecoder_win.h:332-349 with normalize_max, normalize_period 1 */
+  if (k != 0) {
+    for (uint32_t w = 0; w < W; w++) {
+      int8_t m = smax8(old[0][w], old[1][w]);
+      for (int i = 2; i < 8; i++) {
+        m = smax8(m, old[i][w]);
+      }
+      for (int i = 0; i < 8; i++) {
+        old[i][w] = ssub8(old[i][w], m);
+      }
+    }
+  }
+}
+
+static void win_beta_tail8(const int8_t* input, const int8_t* parity, uint32_t K, int8_t old[8])
+{ /* turbodecoder_win.h:351-395 with INF = 0 */
+  int8_t m_b[8], nw[8];
+  for (int i = 0; i < 8; i++) {
+    old[i] = 0;
+  }
+  for (int k = (int)K + 2; k >= (int)K; k--) {
+    int8_t x = input[k], y = parity[k], xy = tail_sadd8(x, y);
+#define TA tail_sadd8
+    m_b[0] = TA(old[4], xy); m_b[1] = old[4];         m_b[2] = TA(old[5], y);  m_b[3] = TA(old[5], x);
+    m_b[4] = TA(old[6], x);  m_b[5] = TA(old[6], y);  m_b[6] = old[7];         m_b[7] = TA(old[7], xy);
+    nw[0] = old[0];          nw[1] = TA(old[0], xy);  nw[2] = TA(old[1], x);   nw[3] = TA(old[1], y);
+    nw[4] = TA(old[2], y);   nw[5] = TA(old[2], x);   nw[6] = TA(old[3], xy);  nw[7] = old[3];
+#undef TA
+    for (int i = 0; i < 8; i++) {
+      old[i] = m_b[i] > nw[i] ? m_b[i] : nw[i];
+    }
+  }
+}
+
+static void win_dec8(const int8_t* input, const int8_t* app, const int8_t* parity, int8_t* output, uint32_t K, uint32_t W,
+                     int8_t* beta /* 8*(K/W+1)*W */)
+{
+  uint32_t L = K / W;
+  int8_t   old[8][WMAX], m_b[8], nw[8];
+
+  /* ---- beta (turbodecoder_win.h:398-526) */
+  for (int pass = 0; pass < 2; pass++) {
+    uint32_t len = pass == 0 ? WIN_OVERLAP : L;
+    if (pass == 0) {
+      memset(old, 0, sizeof(old)); /* -INF = 0 */
+    } else {
+      int8_t tail[8];
+      win_beta_tail8(input, parity, K, tail);
+      for (int i = 0; i < 8; i++) {
+        for (uint32_t w = 0; w + 1 < W; w++) {
+          old[i][w] = old[i][w + 1]; /* move_right (+ the 128-bit lane fix-up of avx8, :417-447) */
+        }
+        old[i][W - 1] = tail[i];
+      }
+      for (int i = 0; i < 8; i++) {
+        for (uint32_t w = 0; w < W; w++) {
+          beta[(8 * L + i) * W + w] = old[i][w];
+        }
+      }
+    }
+    for (int k = (int)len - 1; k >= 0; k--) {
+      for (uint32_t w = 0; w < W; w++) {
+        int8_t x = input[k * W + w], y = parity[k * W + w];
+        if (app) {
+          x = sadd8(app[k * W + w], x);
+        }
+        int8_t xy = sadd8(x, y);
+        int8_t o[8];
+        for (int i = 0; i < 8; i++) {
+          o[i] = old[i][w];
+        }
+        m_b[0] = sadd8(o[4], xy); m_b[1] = o[4];           m_b[2] = sadd8(o[5], y);  m_b[3] = sadd8(o[5], x);
+        m_b[4] = sadd8(o[6], x);  m_b[5] = sadd8(o[6], y); m_b[6] = o[7];            m_b[7] = sadd8(o[7], xy);
+        nw[0] = o[0];             nw[1] = sadd8(o[0], xy); nw[2] = sadd8(o[1], x);   nw[3] = sadd8(o[1], y);
+        nw[4] = sadd8(o[2], y);   nw[5] = sadd8(o[2], x);  nw[6] = sadd8(o[3], xy);  nw[7] = o[3];
+        for (int i = 0; i < 8; i++) {
+          old[i][w] = smax8(m_b[i], nw[i]);
+          if (pass == 1) {
+            beta[(8 * k + i) * W + w] = old[i][w];
+          }
+        }
+      }
+      win_normalize8((uint32_t)k, old, W);
+    }
+  }
+
+  /* ---- alpha + output (turbodecoder_win.h:529-679) */
+  for (int pass = 0; pass < 2; pass++) {
+    uint32_t len = pass == 0 ? WIN_OVERLAP : L;
+    if (pass == 0) {
+      memset(old, 0, sizeof(old));
+    } else {
+      for (int i = 0; i < 8; i++) {
+        for (uint32_t w = W - 1; w > 0; w--) {
+          old[i][w] = old[i][w - 1]; /* move_left */
+        }
+        old[i][0] = 0; /* known state 0 and -INF are both 0 */
+      }
+    }
+    uint32_t base = L - len;
+    for (uint32_t k = 0; k < len; k++) {
+      for (uint32_t w = 0; w < W; w++) {
+        uint32_t p = (base + k) * W + w;
+        int8_t   x = input[p], y = parity[p];
+        if (app) {
+          x = sadd8(app[p], x);
+        }
+        int8_t xy = sadd8(x, y);
+        int8_t o[8];
+        for (int i = 0; i < 8; i++) {
+          o[i] = old[i][w];
+        }
+        m_b[0] = o[0];            m_b[1] = sadd8(o[3], y); m_b[2] = sadd8(o[4], y);  m_b[3] = o[7];
+        m_b[4] = o[1];            m_b[5] = sadd8(o[2], y); m_b[6] = sadd8(o[5], y);  m_b[7] = o[6];
+        nw[0] = sadd8(o[1], xy);  nw[1] = sadd8(o[2], x);  nw[2] = sadd8(o[5], x);   nw[3] = sadd8(o[6], xy);
+        nw[4] = sadd8(o[0], xy);  nw[5] = sadd8(o[3], x);  nw[6] = sadd8(o[4], x);   nw[7] = sadd8(o[7], xy);
+        if (pass == 1) {
+          const int8_t* b  = &beta[(8 * (k + 1)) * W + w];
+          int8_t        m0 = sadd8(b[0], m_b[0]), m1 = sadd8(b[0], nw[0]);
+          for (int i = 1; i < 8; i++) {
+            m0 = smax8(m0, sadd8(b[i * W], m_b[i]));
+            m1 = smax8(m1, sadd8(b[i * W], nw[i]));
+          }
+          output[k * W + w] = (int8_t)(ssub8(m1, m0) >> 1); /* divide_output, simd_rb_shift (:143-147,:657-659) */
+        }
+        for (int i = 0; i < 8; i++) {
+          old[i][w] = smax8(m_b[i], nw[i]);
+        }
+      }
+      win_normalize8(k, old, W);
+    }
+  }
+}
+
+static void decide8(const int8_t* llr, uint8_t* out, uint32_t K, uint32_t W)
+{
+  memset(out, 0, K / 8);
+  for (uint32_t j = 0; j < K; j++) {
+    if (llr[win_of_nat(j, K, W)] > 0) {
+      out[j >> 3] |= (uint8_t)(0x80 >> (j & 7));
+    }
+  }
+}
+
+static void vec_sub8(int8_t* x, const int8_t* y, uint32_t len)
+{ /* srslte_vec_sub_bbb_simd (vector_simd.c:158-185), aligned buffers, AVX2 build: saturating in the 32-wide body,
+     wrapping in the scalar tail */
+  uint32_t body = len / 32 * 32;
+  for (uint32_t i = 0; i < body; i++) {
+    x[i] = ssub8(x[i], y[i]);
+  }
+  for (uint32_t i = body; i < len; i++) {
+    x[i] = (int8_t)(x[i] - y[i]);
+  }
+}
+
+int orc_tdec_run_8bit(const int8_t* input, bool in_is_sb, uint32_t K, uint32_t nof_iter, uint8_t* out, uint8_t* hard_per_iter)
+{ /* turbodecoder.c:421-487,:565-593: AUTO selection for 8-bit LLRs on an AVX2 host. K > 2048 (K%32==0): avx8, W = 32;
+     800 < K (K%16==0): sse8, W = 16; otherwise the LLRs are widened and a 16-bit back-end runs (:465-469).
+     Upstream widens only 3K+12 elements even when the buffer is in the 3(K+32)+12 "SB" layout (:466), leaving the end of
+     parity 1 and the tail LLRs to stale memory for 400 < K <= 800; here the whole buffer is widened. */
+  uint32_t W = orc_tdec_autoimp_subblocks_8bit(K);
+  int      idx = orc_cb_index(K);
+  if (idx < 0 || orc_qpp_table[idx].K != K || (in_is_sb && !W)) {
+    return -1;
+  }
+  if (W < 16) {
+    uint32_t n    = in_is_sb ? 3 * (K + 32) + 12 : 3 * K + 12;
+    int16_t* conv = malloc(n * 2);
+    for (uint32_t i = 0; i < n; i++) {
+      conv[i] = input[i];
+    }
+    int r = orc_tdec_run_w(conv, in_is_sb, K, W, nof_iter, out, hard_per_iter);
+    free(conv);
+    return r;
+  }
+  uint32_t  len = K + 16;
+  int8_t   *syst = calloc(len, 1), *par0 = calloc(len, 1), *par1 = calloc(len, 1);
+  int8_t   *app1 = calloc(len, 1), *app2 = calloc(len, 1), *ext1 = calloc(len, 1), *ext2 = calloc(len, 1);
+  int8_t*   beta = calloc(8 * (size_t)(K + 16) + 8 * WMAX, 1);
+  uint16_t *inter = malloc(K * 2), *deinter = malloc(K * 2);
+  orc_qpp(K, W, inter, deinter);
+  uint32_t tb = in_is_sb ? 3 * (K + 32) : 3 * K;
+  if (in_is_sb) {
+    memcpy(syst, input, K);
+    memcpy(par0, input + (K + 32), K);
+    memcpy(par1, input + 2 * (K + 32), K);
+  } else {
+    for (uint32_t n = 0; n < K; n++) {
+      uint32_t x = win_of_nat(n, K, W);
+      syst[x]    = input[3 * n];
+      par0[x]    = input[3 * n + 1];
+      par1[x]    = input[3 * n + 2];
+    }
+  }
+  for (uint32_t j = 0; j < 3; j++) {
+    syst[K + j] = input[tb + 2 * j];
+    par0[K + j] = input[tb + 2 * j + 1];
+    app2[K + j] = input[tb + 6 + 2 * j];
+    par1[K + j] = input[tb + 6 + 2 * j + 1];
+  }
+  for (uint32_t n_iter = 0; n_iter < nof_iter; n_iter++) {
+    if ((n_iter % 2) == 0) {
+      if (n_iter) {
+        vec_sub8(app1, ext1, K);
+      }
+      win_dec8(syst, n_iter ? app1 : NULL, par0, ext1, K, W, beta);
+    } else {
+      if (n_iter > 1) {
+        vec_sub8(ext1, app1, K);
+      }
+      for (uint32_t i = 0; i < K; i++) {
+        app2[deinter[i]] = ext1[i]; /* srslte_vec_lut_bbb */
+      }
+      win_dec8(app2, NULL, par1, ext2, K, W, beta);
+      for (uint32_t i = 0; i < K; i++) {
+        app1[inter[i]] = ext2[i];
+      }
+    }
+    const int8_t* src = ((n_iter + 1) % 2) == 0 ? app1 : ext1;
+    if (hard_per_iter) {
+      decide8(src, &hard_per_iter[(size_t)n_iter * (K / 8)], K, W);
+    }
+    if (n_iter + 1 == nof_iter && out) {
+      decide8(src, out, K, W);
+    }
+  }
+  free(syst); free(par0); free(par1); free(app1); free(app2); free(ext1); free(ext2); free(beta); free(inter); free(deinter);
+  return 0;
+}
+
 /* ------------------------------------------------------------------ DL-SCH (sch.c) */
 
 int orc_dlsch_encode(const orc_sch_cfg_t* cfg, const uint8_t* data, uint8_t* e_bits)
@@ -662,8 +906,10 @@ int orc_dlsch_encode(const orc_sch_cfg_t* cfg, const uint8_t* data, uint8_t* e_b
   return 0;
 }
 
-int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
-{ /* sch.c:299-414 (decode_tb_cb, first transmission: soft buffer zeroed) + :429-500 (decode_tb) */
+static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
+{ /* sch.c:299-414 (decode_tb_cb, first transmission: soft buffer zeroed) + :429-500 (decode_tb); llr8: the q->llr_is_8bit branches */
+  const int16_t* e = e_any;
+  const int8_t*  e8 = e_any;
   orc_cbsegm_t s;
   if (orc_cbsegm(&s, cfg->tbs) || s.F) {
     return -2;
@@ -680,14 +926,19 @@ int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, 
       n_e2 = n_e + cfg->Qm;
       rp   = (s.C - gamma) * n_e + (cb - (s.C - gamma)) * n_e2;
     }
-    uint32_t W = orc_tdec_autoimp_subblocks(K);
+    uint32_t W = llr8 ? orc_tdec_autoimp_subblocks_8bit(K) : orc_tdec_autoimp_subblocks(K);
     memset(w, 0, (3 * (K + 32) + 12) * 2);
-    orc_rm_turbo_rx(&e[rp], w, n_e2, K, cfg->rv, W);
     bool     ok  = false;
     uint32_t noi = 0;
     /* hard decisions after each pass are independent of later passes, so run them one at a time */
     uint8_t* per = malloc((size_t)cfg->max_iter * (K / 8));
-    orc_tdec_run_w(w, W != 0, K, W, cfg->max_iter, hard, per);
+    if (llr8) {
+      orc_rm_turbo_rx_8bit(&e8[rp], (int8_t*)w, n_e2, K, cfg->rv, W);
+      orc_tdec_run_8bit((int8_t*)w, W != 0, K, cfg->max_iter, hard, per);
+    } else {
+      orc_rm_turbo_rx(&e[rp], w, n_e2, K, cfg->rv, W);
+      orc_tdec_run_w(w, W != 0, K, W, cfg->max_iter, hard, per);
+    }
     do {
       memcpy(&data[cb * rlen / 8], &per[(size_t)noi * (K / 8)], K / 8);
       noi++;
@@ -712,4 +963,14 @@ int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, 
   uint32_t par_rx = orc_crc_bytes(ORC_CRC24A, 24, data, (int)cfg->tbs);
   uint32_t par_tx = ((uint32_t)data[cfg->tbs / 8] << 16) | ((uint32_t)data[cfg->tbs / 8 + 1] << 8) | data[cfg->tbs / 8 + 2];
   return (par_rx == par_tx && par_rx) ? 0 : -1;
+}
+
+int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
+{
+  return dlsch_decode(cfg, e, false, data, cb_iters, cb_crc_ok);
+}
+
+int orc_dlsch_decode_8bit(const orc_sch_cfg_t* cfg, const int8_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
+{
+  return dlsch_decode(cfg, e, true, data, cb_iters, cb_crc_ok);
 }

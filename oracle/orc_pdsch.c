@@ -67,6 +67,13 @@ void orc_scramble_s(int16_t* llr, const uint8_t* c, int len)
   }
 }
 
+void orc_scramble_b(int8_t* llr, const uint8_t* c, int len)
+{ /* scrambling.c:48-51 -> srslte_vec_neg_bbb (_mm256_sign_epi8 with c_char = 1-2c, never 0): -(-128) stays -128 */
+  for (int i = 0; i < len; i++) {
+    if (c[i]) llr[i] = (int8_t)-llr[i];
+  }
+}
+
 uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t cell_id)
 { /* sequences.c:58-60 with nslot = 2*sf_idx (pdsch.c:469) */
   return ((uint32_t)rnti << 14) + (cw << 13) + (((2 * sf_idx) / 2) << 9) + cell_id;

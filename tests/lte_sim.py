@@ -17,9 +17,10 @@ MOD_BITS = {0: 1, 1: 2, 2: 4, 3: 6, 4: 8}
 class DlConfig:
     """One PDSCH configuration: single port, full-band grant, rv 0."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
+        self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.cell = OrcCell(cell_id, nof_prb, 1, True)
         self.nre = 12 * nof_prb
         self.grid_len = 14 * self.nre
@@ -97,14 +98,19 @@ def oracle_rx(cfg, iq, tti, keep=False):
     d = np.zeros(len(idx), np.complex64)
     orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
     nbits = len(idx) * cfg.Qm
-    e = np.zeros(nbits, np.int16)
-    orc.orc_demod_soft_s(cfg.mod, p(d), p(e), len(idx))
-    orc.orc_scramble_s(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
+    e = np.zeros(nbits, np.int8 if cfg.llr8 else np.int16)
     sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
     tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
     iters = np.zeros(cfg.seg.C, np.uint32)
     cbok = np.zeros(cfg.seg.C, np.uint8)
-    rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+    if cfg.llr8:
+        orc.orc_demod_soft_b(cfg.mod, p(d), p(e), len(idx))
+        orc.orc_scramble_b(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
+        rc = orc.orc_dlsch_decode_8bit(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+    else:
+        orc.orc_demod_soft_s(cfg.mod, p(d), p(e), len(idx))
+        orc.orc_scramble_s(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
+        rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
     if keep:
         out.update(grid=grid, ce=ce, noise=res.noise_estimate, d=d, e=e, res=res)
@@ -163,12 +169,13 @@ class RefRx:
         h.view(np.complex64)[:] = self.ce.view(np.complex64)[idx]
         R.srslte_predecoding_single(p(y), p(h), p(d), None, n, 1.0, self.res.noise_estimate)
         nbits = n * cfg.Qm
-        e = self.aligned(nbits + 64, np.int16)
-        R.srslte_demod_soft_demodulate_s(cfg.mod, p(d), p(e), n)
+        lt = np.int8 if cfg.llr8 else np.int16
+        e = self.aligned(nbits + 64, lt)
+        (R.srslte_demod_soft_demodulate_b if cfg.llr8 else R.srslte_demod_soft_demodulate_s)(cfg.mod, p(d), p(e), n)
         if (sf_idx, nbits) not in self.scr:
             self.scr[(sf_idx, nbits)] = scramble_seq(cfg, sf_idx, nbits).astype(bool)
         ev = e[:nbits]
-        ev[self.scr[(sf_idx, nbits)]] *= -1
+        ev[self.scr[(sf_idx, nbits)]] *= -1  # wraps -(-128) / -(-32768) like the reference's sign instructions
         s = cfg.seg
         tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
         iters, all_ok = np.zeros(s.C, np.uint32), True
@@ -181,15 +188,15 @@ class RefRx:
             if cb > s.C - gamma:
                 n_e2 = n_e + cfg.Qm
                 rp = (s.C - gamma) * n_e + (cb - (s.C - gamma)) * n_e2
-            w = self.aligned(3 * (K + 32) + 12 + 64, np.int16)
-            ein = self.aligned(n_e2 + 64, np.int16)
+            w = self.aligned(3 * (K + 32) + 12 + 64, lt)
+            ein = self.aligned(n_e2 + 64, lt)
             ein[:n_e2] = e[rp:rp + n_e2]
-            assert R.srslte_rm_turbo_rx_lut(p(ein), p(w), n_e2, R.srslte_cbsegm_cbindex(K), 0) == 0
+            assert (R.srslte_rm_turbo_rx_lut_8bit if cfg.llr8 else R.srslte_rm_turbo_rx_lut)(p(ein), p(w), n_e2, R.srslte_cbsegm_cbindex(K), 0) == 0
             assert R.srslte_tdec_new_cb(self.tdec, K) == 0
             out = tb[cb * rlen // 8:]
             ok, noi = False, 0
             while noi < cfg.max_iter and not ok:
-                R.srslte_tdec_iteration(self.tdec, p(w), p(out))
+                (R.srslte_tdec_iteration_8bit if cfg.llr8 else R.srslte_tdec_iteration)(self.tdec, p(w), p(out))
                 noi += 1
                 if s.C > 1:
                     ok = R.srslte_crc_checksum_byte(self.crc_cb, p(out), K) == 0

@@ -12,6 +12,52 @@ pytestmark = pytest.mark.skipif(ref() is None, reason="oracle/_ref/libsrslte_ref
 ALL_K = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))
 
 
+@pytest.mark.parametrize("K", [40, 400, 408, 504, 800, 816, 1008, 2048, 2112, 3136, 5824, 6144])
+def test_turbo_decoder_8bit_vs_ref(K):
+    """srslte_tdec_run_all_8bit (turbodecoder.c:565-593): avx8 (K > 2048), sse8 (K > 800) and the widening fall-backs; plain
+    [s p0 p1] input for every K, and the rate-dematcher's SB layout where upstream handles it consistently (K > 800)."""
+    R, rng = ref(), np.random.default_rng(8000 + K)
+    R.srslte_cbsegm_cbindex.restype = C.c_int
+    tcod = opaque(4096)
+    R.srslte_tcod_init(tcod, 6144)
+    bits = rng.integers(0, 2, K).astype(np.uint8)
+    enc = np.zeros(3 * K + 12, np.uint8)
+    R.srslte_tcod_encode(tcod, p(bits), p(enc), K)
+    assert oracle().orc_tdec_autoimp_subblocks_8bit(K) == R.srslte_tdec_autoimp_get_subblocks_8bit(K)
+    for snr, scale in ((1.0, 12), (3.0, 25), (-2.0, 60)):
+        llr = acopy((scale * ((2.0 * enc - 1) + 10 ** (-snr / 20) * rng.standard_normal(enc.shape))).clip(-128, 127).astype(np.int8))
+        tdec = opaque(1 << 20)
+        assert R.srslte_tdec_init(tdec, 6144) == 0
+        R.srslte_tdec_force_not_sb(tdec)
+        for nit in (1, 2, 3, 6):
+            a, b = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8)
+            R.srslte_tdec_run_all_8bit(tdec, p(llr), p(a), nit, K)
+            assert oracle().orc_tdec_run_8bit(p(llr), False, K, nit, p(b), None) == 0
+            assert np.array_equal(a, b), (K, snr, nit)
+        R.srslte_tdec_free(tdec)
+    if K > 800:  # SB layout through the reference's 8-bit rate de-matcher (sch.c:336-338)
+        n_e = 3 * K + 12 + 500
+        W = oracle().orc_tdec_autoimp_subblocks_8bit(K)
+        e_bits = np.zeros(n_e, np.uint8)
+        oracle().orc_rm_turbo_tx_bits(p(enc), p(e_bits), n_e, K, 0)
+        e = acopy((20 * ((2.0 * e_bits - 1) + 0.8 * rng.standard_normal(n_e))).clip(-128, 127).astype(np.int8))
+        w, w2 = aligned(3 * (K + 32) + 12 + 64, np.int8), np.zeros(3 * (K + 32) + 12 + 64, np.int8)
+        assert R.srslte_rm_turbo_rx_lut_8bit(p(e), p(w), n_e, R.srslte_cbsegm_cbindex(K), 0) == 0
+        assert oracle().orc_rm_turbo_rx_8bit(p(e), p(w2), n_e, K, 0, W) == 0
+        assert np.array_equal(np.array(w), w2)
+        tdec = opaque(1 << 20)
+        assert R.srslte_tdec_init(tdec, 6144) == 0 and R.srslte_tdec_new_cb(tdec, K) == 0
+        per = np.zeros((6, K // 8), np.uint8)
+        for it in range(6):
+            hard = np.zeros(K // 8, np.uint8)
+            R.srslte_tdec_iteration_8bit(tdec, p(w), p(hard))
+            per[it] = hard
+        mine = np.zeros((6, K // 8), np.uint8)
+        assert oracle().orc_tdec_run_8bit(p(w2), True, K, 6, None, p(mine)) == 0
+        assert np.array_equal(per, mine), K
+        R.srslte_tdec_free(tdec)
+
+
 def test_cbsegm_all_tbs_sample():
     from _libs import OrcCbsegm
     R = ref()
@@ -217,3 +263,20 @@ def test_whole_chain_vs_reference_code(prb, mod, tbs, snr):
         iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
         r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
         assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr", [(6, 1, 936, 4.0), (100, 3, 75376, 19.0), (100, 4, 97896, 29.0)])
+def test_whole_chain_8bit_vs_reference_code(prb, mod, tbs, snr):
+    """8-bit LLR path (pdsch.c:760-779, sch.c:336-356): demod_b, int8 descrambling, srslte_rm_turbo_rx_lut_8bit,
+    srslte_tdec_iteration_8bit (sse8 for K=960, avx8 for K=5824/6144) - same TBs and pass counts as the oracle chain."""
+    rng = np.random.default_rng(80 + prb + mod)
+    cfg = DlConfig(prb, 1, mod, tbs, llr8=True)
+    chain = RefRx(cfg)
+    ttis = (1, 2, 3) if prb == 6 else (0, 5, 7)
+    nok = 0
+    for t in ttis:
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
+        nok += r["ok"]
+    assert nok > 0
