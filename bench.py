@@ -42,13 +42,14 @@ def algorithmic_bytes(pkg_cfg, nof_re_by_sf, ttis):
     """Per-batch algorithmic bytes of each kernel (SURVEY §8d per-unit figures x units per launch)."""
     n = len(ttis)
     N, nre, K, C, Qm = 1536, 1200, 5824, 13, 6
+    L = 1 if pkg_cfg.llr8 else 2  # bytes per LLR
     re = sum(nof_re_by_sf[t % 10] for t in ttis)
     return {
         "ofdm_rx": n * (15 * N * 8 + 14 * nre * 8),                       # 318 720 B / subframe
         "chest_dl": n * (4 * nre * 8 + 800 * 8 + 14 * nre * 8),            # 179 200 B / subframe
-        "pdsch_demod": re * (16 + 2 * Qm),                                 # gather y,h + write int16 LLRs
-        "rm_rx": re * Qm * 2 + n * C * (3 * K + 12) * 2,                   # read e, write w
-        "tdec": n * C * ((3 * K + 12) * 2 + K // 8),                       # 35 696 B / code block
+        "pdsch_demod": re * (16 + L * Qm),                                 # gather y,h + write LLRs
+        "rm_rx": re * Qm * L + n * C * (3 * K + 12) * L,                   # read e, write w
+        "tdec": n * C * ((3 * K + 12) * L + K // 8),                       # 35 696 B / code block (16-bit LLRs)
         "tb_crc": n * (C * K // 8 + TBS // 8 + 6),
     }
 
@@ -62,6 +63,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (whole passes over the batch)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--llr8", action="store_true", help="8-bit LLR path (SURVEY §8f N2: demod_b, rm_turbo_rx_lut_8bit, avx8 decoder) instead of the 16-bit one")
     ap.add_argument("--streams", type=int, default=3, help="pipeline instances / HIP streams that consecutive steps alternate over")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --force-device 0 rehearses N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="use this GPU for every rank (rehearsal only)")
@@ -93,7 +95,7 @@ def main():
     # ---- synthetic input: `batch` subframes of this rank's UE, TTIs 0..batch-1 (sf 0/5 carry PSS/SSS/PBCH holes)
     rng = np.random.default_rng(1000 + rank)
     ue = sharding.ue_for_rank(rank)  # cfg4: UE u on GPU u, distinct RNTI / cell id
-    cfg = DlConfig(NOF_PRB, ue["cell_id"], MOD, TBS, cfi=CFI, rnti=ue["rnti"], max_iter=MAX_ITER)
+    cfg = DlConfig(NOF_PRB, ue["cell_id"], MOD, TBS, cfi=CFI, rnti=ue["rnti"], max_iter=MAX_ITER, llr8=args.llr8)
     B = args.batch
     ttis = list(range(B))
     iq_list, data_list = [], []
@@ -109,7 +111,7 @@ def main():
     # Two pipeline instances on two HIP streams: consecutive steps (independent batches) alternate between them, so the
     # next batch's kernels fill the SIMDs that the previous batch's turbo-decoder tail (blocks needing all 6 passes) leaves idle.
     nstreams = max(1, args.streams)
-    rxs = [pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc) for _ in range(nstreams)]
+    rxs = [pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc, llr_8bit=args.llr8) for _ in range(nstreams)]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     streams = [t.cuda_stream for t in tstreams]
     rx, stream = rxs[0], streams[0]
@@ -243,19 +245,19 @@ def main():
     # the committed rocprofv3 --pmc passes of this same command (profiles/r01_pmc/final_traffic.json), valid for B=128.
     traffic = None
     pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc", "final_traffic.json")
-    if os.path.exists(pmc) and B == 128:
+    if os.path.exists(pmc) and B == 128 and not args.llr8:
         with open(pmc) as f:
-            traffic = json.load(f)["kernels"].get("tdec_win_kernel<16>", {}).get("traffic_bytes")
+            traffic = json.load(f)["kernels"].get("tdec_win_kernel<16>", {})  # name of the kernel before it gained its arithmetic template argument.get("traffic_bytes")
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (OFDM/chest/eq) + i16 (LLR/turbo)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (OFDM/chest/eq) + %s (LLR/turbo)" % ("i8" if args.llr8 else "i16"), "data": "synthetic",
         "config": {"workload": "20 MHz (100 PRB) DL subframe batch=%d per GPU, 64QAM MCS 28 (TBS 75376, 13 x K=5824), OFDM RX + chest_dl + MMSE + "
                                "soft demap + rate dematch + turbo max 6 SISO passes with CRC early stop + TB CRC" % B,
                    "snr_db": args.snr, "bler": round(1 - good_all / n_all, 4), "undetected_errors": wrong_all,
                    "avg_siso_passes_per_cb": round(it_all / (n_all * 13), 3), "sharding": "one UE per GPU, no data-path collective",
                    "streams": nstreams},
-        "roofline": {"kernel": "tdec_win_kernel<16>", "bound": "hbm", "achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+        "roofline": {"kernel": "tdec_win_kernel<32, 1>" if args.llr8 else "tdec_win_kernel<16, 0>", "bound": "hbm", "achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,
                      "note": "serial-trellis integer kernel: not HBM-bound by construction (SURVEY §8d); streaming kernels are in 'kernels'"},

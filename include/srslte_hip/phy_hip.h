@@ -118,6 +118,15 @@ int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int16_t* d_inpu
                                      uint32_t nof_subblocks, uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits,
                                      uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream);
 
+/* 8-bit LLRs (replaces srslte_tdec_run_all_8bit / srslte_tdec_iteration_8bit, turbodecoder.h:117-135, turbodecoder.c:438-469,
+ * :565-593). Back-end per K as AUTO selects on an AVX2 host: K > 2048 avx8 (32 windows), K > 800 sse8 (16 windows)
+ * - saturating int8, max-normalisation every step, output >> 1 (turbodecoder_win.h:92-173) - and below that the LLRs are widened
+ * and the 16-bit back-ends run. sb_layout as above with 8-bit elements (srslte_rm_turbo_rx_lut_8bit output). */
+uint32_t srslte_hip_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb); /* turbodecoder.c:421-436 */
+int srslte_hip_tdec_run_batch_8bit(srslte_hip_tdec_t* q, const int8_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
+                                   uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
+                                   uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream);
+
 /* ------------------------------------------------------------------ turbo encoder (replaces srslte_tcod_encode, fec/turbocoder.h:44-76,
  * turbocoder.c:76-186): bits in (one per byte) -> 3K+12 bits out ([s p0 p1] triplets + 12 tail), nof_cb blocks */
 int srslte_hip_tcod_encode_batch(const uint8_t* d_input, uint8_t* d_output, uint32_t long_cb, uint32_t nof_cb, void* stream);
@@ -149,6 +158,8 @@ typedef struct {
   uint32_t max_batch;      /* subframes per call */
   int      mmse;           /* 1: noise_estimate from chest (pdsch.c:862), 0: ZF */
   srslte_hip_chest_dl_cfg_t chest_cfg;
+  int      llr_8bit;       /* 1: the 8-bit LLR path the applications select (q->llr_is_8bit: pdsch.c:760-779 demod_b + int8
+                              descrambling, sch.c:336-356 srslte_rm_turbo_rx_lut_8bit + srslte_tdec_iteration_8bit) */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);

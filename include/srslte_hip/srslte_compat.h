@@ -11,8 +11,8 @@
  * (srslte_dft_plan_t.p, srslte_tdec_t.dec16_hdlr[0], srslte_chest_dl_t.tmp_noise ...).
  * tests/test_abi_layout.py checks sizeof/offsetof of every struct below against the reference headers.
  *
- * Not provided (documented in DESIGN.md): 8-bit LLR decoders, MBSFN channel estimation, multi-port / multi-antenna
- * estimation; those calls return SRSLTE_ERROR with a message.
+ * Not provided (documented in DESIGN.md): MBSFN channel estimation, multi-port / multi-antenna estimation; those calls
+ * return SRSLTE_ERROR with a message.
  */
 #ifndef SRSLTE_HIP_SRSLTE_COMPAT_H
 #define SRSLTE_HIP_SRSLTE_COMPAT_H
@@ -177,6 +177,9 @@ int      srslte_tdec_get_nof_iterations(srslte_tdec_t* h);
 uint32_t srslte_tdec_autoimp_get_subblocks(uint32_t long_cb);
 void     srslte_tdec_iteration(srslte_tdec_t* h, int16_t* input, uint8_t* output);
 int      srslte_tdec_run_all(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb);
+uint32_t srslte_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb);
+void srslte_tdec_iteration_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output);
+int  srslte_tdec_run_all_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb);
 
 /* ------------------------------------------------------------------ DL channel estimator (chest_dl.h:49-156, refsignal_dl.h:49-54, interp.h:63-112) */
 typedef struct { cf_t* diff_vec; uint32_t vector_len; uint32_t max_vector_len; } srslte_interp_linsrslte_vec_t;

@@ -40,7 +40,8 @@ class Cbsegm(C.Structure):
 
 class DlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int),
-                ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg)]
+                ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg),
+                ("llr_8bit", C.c_int)]
 
 
 def lib():
@@ -91,6 +92,8 @@ def lib():
                                                 vp, C.c_uint32, vp, vp, vp]
         L.srslte_hip_tdec_run_batch_manual.argtypes = [vp, vp, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                                        C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp, vp]
+        L.srslte_hip_tdec_run_batch_8bit.argtypes = L.srslte_hip_tdec_run_batch.argtypes
+        L.srslte_hip_tdec_autoimp_get_subblocks_8bit.restype = C.c_uint32
         L.srslte_hip_tcod_encode_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
         L.srslte_hip_cbsegm.argtypes = [C.POINTER(Cbsegm), C.c_uint32]
         L.srslte_hip_tc_interl_LTE_gen_interl.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
@@ -272,13 +275,17 @@ class Tdec:
         if not self.h:
             raise RuntimeError("srslte_hip_tdec_create failed")
 
-    def run_all(self, llr, long_cb, nof_iterations, sb_layout=False, crc_poly=0, crc_nbits=0, force_subblocks=None):
-        x = np.ascontiguousarray(llr, np.int16)
+    def run_all(self, llr, long_cb, nof_iterations, sb_layout=False, crc_poly=0, crc_nbits=0, force_subblocks=None, llr8=False):
+        """llr8: int8 LLRs through srslte_hip_tdec_run_batch_8bit (srslte_tdec_run_all_8bit, turbodecoder.c:573-588)."""
+        x = np.ascontiguousarray(llr, np.int8 if llr8 else np.int16)
         x = x.reshape(-1, x.shape[-1])
         ncb = x.shape[0]
         din, dout = DevBuf.from_host(x), DevBuf(ncb * (long_cb // 8))
         dit, dok = DevBuf(4 * ncb), DevBuf(ncb)
-        if force_subblocks is None:
+        if llr8:
+            rc = lib().srslte_hip_tdec_run_batch_8bit(self.h, din.ptr, x.shape[1], 1 if sb_layout else 0, long_cb, ncb, nof_iterations, crc_poly,
+                                                      crc_nbits, dout.ptr, long_cb // 8, dit.ptr, dok.ptr, None)
+        elif force_subblocks is None:
             rc = lib().srslte_hip_tdec_run_batch(self.h, din.ptr, x.shape[1], 1 if sb_layout else 0, long_cb, ncb, nof_iterations, crc_poly,
                                                  crc_nbits, dout.ptr, long_cb // 8, dit.ptr, dok.ptr, None)
         else:
@@ -321,8 +328,9 @@ def tc_interl(long_cb, win=1):
 class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
-    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None):
-        self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg())
+    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False):
+        self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
+                           1 if llr_8bit else 0)
         self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
         if not self.h:
             raise RuntimeError("srslte_hip_dl_rx_create failed")

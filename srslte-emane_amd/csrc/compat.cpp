@@ -685,16 +685,19 @@ int srslte_tcod_encode_lut(srslte_tcod_t* h, srslte_crc_t* crc_tb, srslte_crc_t*
 
 // ====================================================================================================== turbo decoder
 uint32_t srslte_tdec_autoimp_get_subblocks(uint32_t long_cb) { return srslte_hip_tdec_autoimp_get_subblocks(long_cb); }
+uint32_t srslte_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb) { return srslte_hip_tdec_autoimp_get_subblocks_8bit(long_cb); }
 
 int srslte_tdec_init_manual(srslte_tdec_t* h, uint32_t max_long_cb, srslte_tdec_impl_type_t dec_type)
-{ // turbodecoder.c:165-330: 16-bit back-ends only; the device object replaces app/ext/beta work buffers
+{ // turbodecoder.c:165-330; the device object replaces app/ext/beta work buffers
   if (!h) return SRSLTE_ERROR_INVALID_INPUTS;
   memset(h, 0, sizeof(*h));
   switch (dec_type) {
     case SRSLTE_TDEC_AUTO:
     case SRSLTE_TDEC_GENERIC:
     case SRSLTE_TDEC_SSE_WINDOW:
-    case SRSLTE_TDEC_AVX_WINDOW: break;
+    case SRSLTE_TDEC_AVX_WINDOW:
+    case SRSLTE_TDEC_SSE8_WINDOW:
+    case SRSLTE_TDEC_AVX8_WINDOW: break;
     default: ERROR("Error decoder %d not supported", (int)dec_type); return SRSLTE_ERROR;
   }
   auto* st = new TdecState();
@@ -706,7 +709,7 @@ int srslte_tdec_init_manual(srslte_tdec_t* h, uint32_t max_long_cb, srslte_tdec_
   h->dec16_hdlr[0]    = st;
   h->max_long_cb      = max_long_cb;
   h->dec_type         = dec_type;
-  h->current_llr_type = SRSLTE_TDEC_16;
+  h->current_llr_type = dec_type >= SRSLTE_TDEC_SSE8_WINDOW ? SRSLTE_TDEC_8 : SRSLTE_TDEC_16;
   h->current_cbidx    = -1;
   return SRSLTE_SUCCESS;
 }
@@ -743,41 +746,74 @@ int srslte_tdec_new_cb(srslte_tdec_t* h, uint32_t long_cb)
   return SRSLTE_SUCCESS;
 }
 
-static int tdec_passes(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t passes)
+// One call = `passes` SISO passes from the unchanged input. The back-end follows turbodecoder.c:438-520: AUTO picks per K
+// and per LLR width; a manual type fixes width and window count, and the other API width is converted with a C cast
+// (convert_8_to_16 / convert_16_to_8, :451-463).
+static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t passes)
 {
   auto*          st = (TdecState*)h->dec16_hdlr[0];
   const uint32_t K  = h->current_long_cb;
-  int            W  = -1; // AUTO (turbodecoder.c:408-420)
-  if (h->dec_type == SRSLTE_TDEC_GENERIC) W = 0;
-  if (h->dec_type == SRSLTE_TDEC_SSE_WINDOW) W = 8;
-  if (h->dec_type == SRSLTE_TDEC_AVX_WINDOW) W = 16;
-  const uint32_t nsb = W < 0 ? srslte_hip_tdec_autoimp_get_subblocks(K) : (uint32_t)W;
-  const int      sb  = (!h->force_not_sb && nsb > 0) ? 1 : 0; // turbodecoder_iter.h:84
+  int            W  = -1;   // AUTO
+  bool           dec8 = api8;
+  switch (h->dec_type) {
+    case SRSLTE_TDEC_GENERIC: W = 0; dec8 = false; break;
+    case SRSLTE_TDEC_SSE_WINDOW: W = 8; dec8 = false; break;
+    case SRSLTE_TDEC_AVX_WINDOW: W = 16; dec8 = false; break;
+    case SRSLTE_TDEC_SSE8_WINDOW: W = 16; dec8 = true; break;
+    case SRSLTE_TDEC_AVX8_WINDOW: W = 32; dec8 = true; break;
+    default: break;
+  }
+  const uint32_t nsb = W >= 0 ? (uint32_t)W : (api8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K));
+  // SB input layout (turbodecoder_iter.h:84 input_is_interleaved): AUTO window back-ends and every 8-bit back-end
+  const bool interleaved = W < 0 ? nsb > 0 : dec8;
+  const int  sb  = (!h->force_not_sb && interleaved && nsb > 0) ? 1 : 0;
   const uint32_t len = srslte_hip_tdec_input_len(K, sb);
-  void *         di = st->in.get(len * sizeof(int16_t)), *dout = st->out.get(K / 8);
-  if (!di || !dout || !h2d(di, input, len * sizeof(int16_t))) return SRSLTE_ERROR;
-  if (tdec_run_batch_w(st->h, (const int16_t*)di, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, nullptr))
+  const size_t   esz = dec8 ? 1 : 2;
+  void *         di = st->in.get(len * esz), *dout = st->out.get(K / 8);
+  if (!di || !dout) return SRSLTE_ERROR;
+  if (dec8 == api8) {
+    if (!h2d(di, input, len * esz)) return SRSLTE_ERROR;
+  } else if (dec8) { // 16-bit API on a manual 8-bit back-end
+    std::vector<int8_t> c(len);
+    for (uint32_t i = 0; i < len; i++) c[i] = (int8_t)((const int16_t*)input)[i];
+    if (!h2d(di, c.data(), len)) return SRSLTE_ERROR;
+  } else { // 8-bit API on a manual 16-bit back-end
+    std::vector<int16_t> c(len);
+    for (uint32_t i = 0; i < len; i++) c[i] = ((const int8_t*)input)[i];
+    if (!h2d(di, c.data(), len * 2)) return SRSLTE_ERROR;
+  }
+  if (tdec_run_batch_w(st->h, di, dec8 ? 1 : 0, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, nullptr))
     return SRSLTE_ERROR;
   return d2h(output, dout, K / 8) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 
-void srslte_tdec_iteration(srslte_tdec_t* h, int16_t* input, uint8_t* output)
-{ // turbodecoder.c:539-545. One more SISO pass: the device re-runs passes 1..n_iter+1 from the unchanged input, which is
+static void tdec_one_more(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output)
+{ // turbodecoder.c:539-545,:565-571. One more SISO pass: the device re-runs passes 1..n_iter+1 from the unchanged input, which is
   // bit-identical to continuing the previous state (the schedule is deterministic) and keeps the object stateless on device.
   if (h->current_cbidx >= 0) {
-    if (tdec_passes(h, input, output, (uint32_t)h->n_iter + 1) == SRSLTE_SUCCESS) h->n_iter++;
+    if (tdec_passes(h, input, api8, output, (uint32_t)h->n_iter + 1) == SRSLTE_SUCCESS) h->n_iter++;
   } else {
     ERROR("Error CB index not set (call srslte_tdec_new_cb() first");
   }
 }
+void srslte_tdec_iteration(srslte_tdec_t* h, int16_t* input, uint8_t* output) { tdec_one_more(h, input, false, output); }
+void srslte_tdec_iteration_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output) { tdec_one_more(h, input, true, output); }
 
-int srslte_tdec_run_all(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
-{ // turbodecoder.c:547-562
+static int tdec_all(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{ // turbodecoder.c:547-562,:573-588
   if (srslte_tdec_new_cb(h, long_cb)) return SRSLTE_ERROR;
   if (nof_iterations == 0) nof_iterations = 1; // do { } while: at least one pass
-  if (tdec_passes(h, input, output, nof_iterations)) return SRSLTE_ERROR;
+  if (tdec_passes(h, input, api8, output, nof_iterations)) return SRSLTE_ERROR;
   h->n_iter = (int)nof_iterations;
   return SRSLTE_SUCCESS;
+}
+int srslte_tdec_run_all(srslte_tdec_t* h, int16_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{
+  return tdec_all(h, input, false, output, nof_iterations, long_cb);
+}
+int srslte_tdec_run_all_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
+{
+  return tdec_all(h, input, true, output, nof_iterations, long_cb);
 }
 
 // ====================================================================================================== channel estimator

@@ -41,10 +41,12 @@ struct PdschGeom {
 
 __device__ __forceinline__ int sf_class(int sf_idx) { return sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2); }
 
-// grid = (ceil(max_re/256), nof_sf)
+// grid = (ceil(max_re/256), nof_sf). LLR = int16_t (srslte_demod_soft_demodulate_s + srslte_scrambling_s_offset) or int8_t
+// (srslte_demod_soft_demodulate_b + srslte_scrambling_sb_offset, the q->llr_is_8bit branch of pdsch.c:760-779)
+template <typename LLR>
 __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
                                                           const ChestResDev* __restrict__ res, const uint32_t* __restrict__ scr,
-                                                          cf32* __restrict__ d_out, int16_t* __restrict__ e_out, PdschGeom g)
+                                                          cf32* __restrict__ d_out, LLR* __restrict__ e_out, PdschGeom g)
 {
   const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
   const SfClass c  = g.cls[sf_class(sf_idx)];
@@ -57,14 +59,18 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
   const cf32  x  = make_float2(re * 1.0f / csi, im * 1.0f / csi);
   if (d_out) d_out[(size_t)sf * g.max_re + i] = x;
-  short o[8];
-  demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+  LLR o[8];
+  if constexpr (sizeof(LLR) == 1) {
+    demod_dev::demod_b(g.mod, x, i, c.nof_re, o);
+  } else {
+    demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+  }
   const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
-  int16_t*        dst = e_out + (size_t)sf * g.max_bits + (size_t)i * g.Qm;
+  LLR*            dst = e_out + (size_t)sf * g.max_bits + (size_t)i * g.Qm;
   for (int j = 0; j < g.Qm; j++) {
     const int bit = i * g.Qm + j;
-    short     v   = o[j];
-    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (short)-v; // scrambling.c:45-48
+    LLR       v   = o[j];
+    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (LLR)-v; // scrambling.c:45-51: sign instruction, -(-min) stays min
     dst[j] = v;
   }
 }
@@ -78,11 +84,13 @@ struct RmGeom {
 // inv[j] = circular-buffer position n that lands on soft-buffer slot j (0xffffffff for padding); a thread owns two
 // adjacent slots, sums their <= ceil(n_e/out_len) wraps from e and writes one dword: stores are coalesced and every
 // slot, padding included, is written exactly once (no memset, no atomics).
-__global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ inv,
-                                                    RmGeom g)
+// LLR = int8_t (srslte_rm_turbo_rx_lut_8bit, rm_turbo.c:428-465: wrapping int8 sums): a thread owns four adjacent slots.
+template <typename LLR>
+__global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, LLR* __restrict__ w, const uint32_t* __restrict__ inv, RmGeom g)
 {
+  constexpr int PER = 4 / (int)sizeof(LLR); // slots per dword
   const int cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C;
-  const int j = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+  const int j = PER * (blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= g.w_stride) return;
   const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)]; // nof_bits / Qm
   const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
@@ -91,16 +99,24 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const int16_t* __restrict__ 
     n_e2 = n_e + g.Qm;
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
-  const int16_t* src = e + (size_t)sf * g.max_bits + rp;
-  const uint2    n   = *reinterpret_cast<const uint2*>(inv + j);
-  int            a0 = 0, a1 = 0;
-  if (n.x != 0xffffffffu) {
-    for (int i = (int)n.x; i < n_e2; i += g.out_len) a0 += src[i];
+  const LLR* src = e + (size_t)sf * g.max_bits + rp;
+  uint32_t   n[PER], word = 0;
+  if constexpr (PER == 2) {
+    const uint2 t = *reinterpret_cast<const uint2*>(inv + j);
+    n[0] = t.x; n[1] = t.y;
+  } else {
+    const uint4 t = *reinterpret_cast<const uint4*>(inv + j);
+    n[0] = t.x; n[1] = t.y; n[2] = t.z; n[3] = t.w;
   }
-  if (n.y != 0xffffffffu) {
-    for (int i = (int)n.y; i < n_e2; i += g.out_len) a1 += src[i];
+#pragma unroll
+  for (int s = 0; s < PER; s++) {
+    int acc = 0;
+    if (n[s] != 0xffffffffu) {
+      for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += src[i];
+    }
+    word |= ((uint32_t)acc & ((1u << (8 * sizeof(LLR))) - 1u)) << (8 * sizeof(LLR) * s);
   }
-  *reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j) = ((uint32_t)a0 & 0xffffu) | ((uint32_t)a1 << 16);
+  *reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j) = word;
 }
 
 struct TbGeom {
@@ -260,7 +276,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
   }
   // rate-dematching table in the decoder's input layout (rm_turbo.c:160-260)
-  q->W         = srslte_hip_tdec_autoimp_get_subblocks(K);
+  q->W         = cfg->llr_8bit ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
   q->in_stride = (srslte_hip_tdec_input_len(K, q->W != 0) + 31) & ~31u;
   if (ok) {
     std::vector<uint32_t> t;
@@ -344,21 +360,31 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     case 2: {
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
-      hipLaunchKernelGGL(pdsch_demod_kernel, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
-                         (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
+      if (q->cfg.llr_8bit) {
+        hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
+                           (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
+      } else {
+        hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
+                           (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
+      }
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;
     }
     case 3: {
       RmGeom g = q->rg;
       g.tti0   = (int)tti0;
-      hipLaunchKernelGGL(rm_rx_kernel, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w,
-                         (const uint32_t*)q->d_rm_tbl, g);
+      if (q->cfg.llr_8bit) {
+        hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div(g.w_stride, 1024), nof_sf * C), dim3(256), 0, st, (const int8_t*)q->d_e,
+                           (int8_t*)q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+      } else {
+        hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e,
+                           q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+      }
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;
     }
     case 4:
-      return tdec_run_batch_w(q->tdec, q->d_w, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
+      return tdec_run_batch_w(q->tdec, q->d_w, q->cfg.llr_8bit ? 1 : 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
                               C > 1 ? 0x1800063u : 0x1864CFBu, C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
     case 5: {
       if (!d_tb || !d_tb_ok || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;

@@ -28,7 +28,8 @@ int  lte_cb_index(uint32_t K);
 void lte_qpp_tables(uint32_t K, uint32_t W, std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);
 void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); // circular-buffer order -> 3*i+s
 
-// tdec.hip: srslte_hip_tdec_run_batch with an optional forced back-end (force_w = -1 auto, 0 generic, 8, 16)
-int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
+// tdec.hip: srslte_hip_tdec_run_batch with an optional forced back-end (force_w = -1 auto, 0 generic, 8, 16, 32 with llr8);
+// llr8: d_input is int8 and the 8-bit numerics / fall-backs of turbodecoder.c:438-487 apply
+int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
                      uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
                      uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st);

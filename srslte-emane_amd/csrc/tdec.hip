@@ -23,6 +23,7 @@
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -50,6 +51,22 @@ __device__ __forceinline__ pk_t pk_sub(pk_t a, pk_t b)
   return as_p(as_v(a) - as_v(b));
 }
 __device__ __forceinline__ pk_t pk_max(pk_t a, pk_t b) { return as_p(__builtin_elementwise_max(as_v(a), as_v(b))); }
+// AR = 1: the 8-bit back-ends (sse8/avx8). An int8 metric lives in the HIGH byte of its int16 half (value << 8): the packed
+// int16 saturating add/sub then saturates exactly where _mm_adds_epi8/_mm_subs_epi8 do, except that the positive limit
+// comes out as 0x7fff instead of 0x7f00 - one v_and restores it. max needs nothing.
+constexpr pk_t M8 = (pk_t)0xFF00FF00;
+template <int AR>
+__device__ __forceinline__ pk_t s_add(pk_t a, pk_t b)
+{
+  const pk_t r = pk_add<true>(a, b);
+  return AR ? (r & M8) : r;
+}
+template <int AR>
+__device__ __forceinline__ pk_t s_sub(pk_t a, pk_t b)
+{
+  const pk_t r = pk_sub<true>(a, b);
+  return AR ? (r & M8) : r;
+}
 __device__ __forceinline__ pk_t pk_make(int lo, int hi) { return (pk_t)((lo & 0xffff) | (hi << 16)); }
 __device__ __forceinline__ int  pk_lo(pk_t a) { return (int)(short)(a & 0xffff); }
 __device__ __forceinline__ int  pk_hi(pk_t a) { return a >> 16; }
@@ -103,7 +120,7 @@ __device__ __forceinline__ int rotl3(int s, int n)
 // One add-compare-select step for the slot's state at phase PH = time % 3 (time of the OLD metrics for the forward
 // recursion, of the NEW metrics for the backward one - the same code serves both, see header comment).
 // Branch metrics: (own, partner) = (0,xy) (x,y) (y,x) (xy,0) for state>>1 = 0..3 (turbodecoder_win.h:471-491,:621-641).
-template <int PH, bool SAT>
+template <int PH, bool SAT, int AR = 0>
 __device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y, pk_t xy, pk_t* t_own, pk_t* t_par)
 {
   const int  b1 = PH == 0 ? L.m2 : (PH == 1 ? L.m0 : L.m1); // state bit 2 of this slot at this phase, as a mask
@@ -113,8 +130,13 @@ __device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y,
   const pk_t g_par = BFI(b1, x & ~b0, BFI(b0, y, xy));
 #undef BFI
   const pk_t po    = dpp_partner<PH>(old);
-  *t_own           = pk_add<SAT>(old, g_own);
-  *t_par           = pk_add<SAT>(po, g_par);
+  if constexpr (AR) {
+    *t_own = s_add<1>(old, g_own);
+    *t_par = s_add<1>(po, g_par);
+  } else {
+    *t_own = pk_add<SAT>(old, g_own);
+    *t_par = pk_add<SAT>(po, g_par);
+  }
   return pk_max(*t_own, *t_par);
 }
 
@@ -154,40 +176,56 @@ struct TdecArgs {
 // ------------------------------------------------------------------------------------------------------------------
 // Windowed SISO (W = 16: packed pairs w = 2g+h; W = 8: w = g in the low half, high half idle)
 // ------------------------------------------------------------------------------------------------------------------
-template <int W>
-__device__ __forceinline__ pk_t ld_pair(const int16_t* a, int k, int g)
+// i-th window pair of a window-interleaved int16 array (i = step * pairs-per-step + pair). AR: the array holds int8 values in
+// int16 containers; they move to the high bytes.
+template <int W, int AR>
+__device__ __forceinline__ pk_t ld_pair(const int16_t* a, int i)
 {
-  if constexpr (W == 16) return reinterpret_cast<const pk_t*>(a)[k * 8 + g];
-  return (pk_t)(uint16_t)a[k * 8 + g];
+  if constexpr (W == 8) return (pk_t)(uint16_t)a[i];
+  const pk_t v = reinterpret_cast<const pk_t*>(a)[i];
+  return AR ? ((v & 0x00FF00FF) << 8) : v;
 }
 
 // ---- one trellis step on prepared inputs: in.x = systematic (+ a-priori, already added with saturation), in.y = parity
 // MODE 0: warm-up, 1: beta main pass, 2: alpha main pass (also forms the extrinsic output o from beta value B)
-template <int PH, int MODE, int W>
+template <int PH, int MODE, int W, int AR>
 __device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, int2 in, pk_t B, pk_t& o)
 {
   constexpr bool SAT = true;
   pk_t           to, tp;
-  const pk_t     x = in.x, y = in.y, xy = pk_add<SAT>(x, y);
-  v = acs<PH, SAT>(L, v, x, y, xy, &to, &tp);
+  const pk_t     x = in.x, y = in.y, xy = s_add<AR>(x, y);
+  v = acs<PH, SAT, AR>(L, v, x, y, xy, &to, &tp);
   if constexpr (MODE == 2) {
     const int  b0 = PH == 0 ? L.m1 : (PH == 1 ? L.m2 : L.m0); // own transition carries info bit b0
-    const pk_t m0 = group_max(pk_add<SAT>(B, (tp & b0) | (to & ~b0)));
-    const pk_t m1 = group_max(pk_add<SAT>(B, (to & b0) | (tp & ~b0)));
+    const pk_t m0 = group_max(s_add<AR>(B, (tp & b0) | (to & ~b0)));
+    const pk_t m1 = group_max(s_add<AR>(B, (to & b0) | (tp & ~b0)));
     o             = pk_sub<SAT>(m1, m0);
     if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
+    // AR: back to an int8 value in an int16 container and divide_output (>> 1, :143-147) in one shift; the 0x7fff of a
+    // positive saturation gives 63 = 127 >> 1 without a mask
+    if constexpr (AR) o = as_p(as_v(o) >> (short)9);
   }
 }
 
-__device__ __forceinline__ void win_normalize(pk_t& v) { v = pk_sub<true>(v, bcast_slot0(v)); } // turbodecoder_win.h:332-349
-
-template <int W>
-__device__ __forceinline__ void store_out(int16_t* out, int k, int g, pk_t o)
+// turbodecoder_win.h:332-349: subtract state 0 (16-bit) / the maximum over the 8 states (normalize_max, 8-bit)
+template <int AR>
+__device__ __forceinline__ void win_normalize(pk_t& v)
 {
-  if constexpr (W == 16) {
-    reinterpret_cast<pk_t*>(out)[k * 8 + g] = o;
+  if constexpr (AR) {
+    v = s_sub<1>(v, group_max(v));
   } else {
-    out[k * 8 + g] = (int16_t)pk_lo(o);
+    v = pk_sub<true>(v, bcast_slot0(v));
+  }
+}
+
+// gg = window pair within the step (0..7, or 0..15 for 32 windows)
+template <int W>
+__device__ __forceinline__ void store_out(int16_t* out, int k, int gg, pk_t o)
+{
+  if constexpr (W == 8) {
+    out[k * 8 + gg] = (int16_t)pk_lo(o);
+  } else {
+    reinterpret_cast<pk_t*>(out)[k * (W / 2) + gg] = o;
   }
 }
 
@@ -197,9 +235,9 @@ __device__ __forceinline__ void store_out(int16_t* out, int k, int g, pk_t o)
 // steps instead of once per step, and the second wavefront of the SIMD computes meanwhile. (Prefetching across the
 // loop back-edge does not survive hipcc's waitcnt insertion, which drains vmcnt(0) there; in-flight registers managed
 // by hand from inline asm were tried and are unsafe at this register pressure: the allocator copies them.)
-template <int W, int BLK, int PH0, int DIR, int MODE, int NPAR0>
+template <int W, int BLK, int PH0, int DIR, int MODE, int NPAR0, int AR>
 __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
-                                        int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out, int& sink)
+                                        int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out, int gg, int& sink)
 {
   for (int b = 0; b < nb; b++) {
     const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b;
@@ -222,7 +260,7 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
   {                                                                               \
     constexpr int PH = DIR > 0 ? (PH0 + J) % 3 : (PH0 + 18 - J) % 3;              \
     pk_t          o  = 0;                                                         \
-    win_step<PH, MODE, W>(L, v, c[j6 + J], cb[j6 + J], o);                        \
+    win_step<PH, MODE, W, AR>(L, v, c[j6 + J], cb[j6 + J], o);                    \
     if constexpr (MODE == 1) {                                                    \
       const int kq = k0 + DIR * (j6 + J);                                         \
       if constexpr (BLK == CKPT) { /* aligned blocks end on a multiple of CKPT */ \
@@ -232,15 +270,15 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
       }                                                                           \
     }                                                                             \
     if constexpr (MODE == 2) keep = L.p == J ? o : keep;                          \
-    if constexpr (((NPAR0 + J) & 1) == 0) {                                       \
+    if constexpr (AR || ((NPAR0 + J) & 1) == 0) { /* 8-bit: every step; 16-bit: every second one */ \
       /* no normalisation at counter 0; in the beta main pass that is the very last step, whose result nobody reads */ \
-      if (MODE == 1 || n0 + DIR * (j6 + J) != 0) win_normalize(v);                \
+      if (MODE == 1 || n0 + DIR * (j6 + J) != 0) win_normalize<AR>(v);            \
     }                                                                             \
   }
       STEP6(0) STEP6(1) STEP6(2) STEP6(3) STEP6(4) STEP6(5)
 #undef STEP6
       if constexpr (MODE == 2) { // after the group reduction every slot holds the step's output: slot j keeps step j
-        if (L.p < 6) store_out<W>(out, k0 + j6 + L.p, L.g, keep);
+        if (L.p < 6) store_out<W>(out, k0 + j6 + L.p, gg, keep);
       }
     }
     sink ^= pf;
@@ -248,9 +286,9 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
 }
 
 // up to 5 left-over steps with run-time phase; their loads are issued together up front
-template <int W, int DIR, int MODE>
+template <int W, int DIR, int MODE, int AR>
 __device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
-                                        int n_first, int ph_first, int r, pk_t* __restrict__ beta, int16_t* __restrict__ out)
+                                        int n_first, int ph_first, int r, pk_t* __restrict__ beta, int16_t* __restrict__ out, int gg)
 {
   int2 in[5];
   pk_t B[5];
@@ -269,17 +307,17 @@ __device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const int2* 
       const int k = k_first + DIR * j, n = n_first + DIR * j, ph = ((ph_first + DIR * j) % 3 + 3) % 3;
       pk_t      o = 0;
       switch (ph) {
-        case 0: win_step<0, MODE, W>(L, v, in[j], B[j], o); break;
-        case 1: win_step<1, MODE, W>(L, v, in[j], B[j], o); break;
-        default: win_step<2, MODE, W>(L, v, in[j], B[j], o); break;
+        case 0: win_step<0, MODE, W, AR>(L, v, in[j], B[j], o); break;
+        case 1: win_step<1, MODE, W, AR>(L, v, in[j], B[j], o); break;
+        default: win_step<2, MODE, W, AR>(L, v, in[j], B[j], o); break;
       }
       if constexpr (MODE == 1) {
         if (k % CKPT == 0) beta[(k / CKPT) * 64 + L.lane] = v; // checkpoint
       }
       if constexpr (MODE == 2) {
-        if (L.p == 0) store_out<W>(out, k, L.g, o);
+        if (L.p == 0) store_out<W>(out, k, gg, o);
       }
-      if ((n & 1) == 0 && n != 0) win_normalize(v);
+      if ((AR || (n & 1) == 0) && n != 0) win_normalize<AR>(v);
     }
   }
 }
@@ -305,168 +343,214 @@ __device__ __forceinline__ void batched(int lane, int n, Ld ld, St st)
 }
 struct I3 { int a, b, c; };
 
-template <int W>
+// One SISO pass over W windows. W = 8/16 (AR = 0: sse16/avx16; AR = 1, W = 16: sse8): one pass of the wave over its 8 window
+// pairs. W = 32 (avx8): the wave handles the windows as NH = 2 halves of 16, one after the other in every phase - the windows
+// only meet in the two hand-overs, which see both halves' registers.
+template <int W, int AR>
 __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
                          pk_t* __restrict__ beta, pk_t* __restrict__ seg, int2* __restrict__ xy, int K)
 {
-  const int  Lw  = K / W;
-  const pk_t NEG = pk_make(-TD_INF, -TD_INF);
-  pk_t       v;
-  int        sink = 0; // keeps the prefetch touches alive (see win_run)
+  constexpr int NH = W == 32 ? 2 : 1;
+  constexpr int G  = 8 * NH; // window pairs per step
+  const int     Lw = K / W;
+  const pk_t    NEG = AR ? 0 : pk_make(-TD_INF, -TD_INF); // INF = 0 for the 8-bit back-ends (turbodecoder_win.h:120,:152)
+  pk_t          v[NH];
+  int           sink = 0; // keeps the prefetch touches alive (see win_run)
+  const int     top = (Lw + CKPT - 1) / CKPT; // checkpoint slot of the start metrics beta[Lw]
+  const int     bstride = (top + 1) * 64;     // checkpoint columns of one half
 
-  // ---- combine pass: xy[g][k] = (sat(app + syst), parity) for the window pair g at step k, so that one 8-byte load
+  // ---- combine pass: xy[gg][k] = (sat(app + syst), parity) for the window pair gg at step k, so that one 8-byte load
   //      per step feeds the recursion (turbodecoder_win.h:472-478: x = adds(ap, x))
   batched<8>(
-      L.lane, 8 * Lw,
-      [&](int i) { return I3{ld_pair<W>(in, i >> 3, i & 7), app ? ld_pair<W>(app, i >> 3, i & 7) : 0, ld_pair<W>(par, i >> 3, i & 7)}; },
-      [&](int i, I3 t) { xy[(i & 7) * Lw + (i >> 3)] = make_int2(app ? pk_add<true>(t.b, t.a) : t.a, t.c); });
+      L.lane, G * Lw, [&](int i) { return I3{ld_pair<W, AR>(in, i), app ? ld_pair<W, AR>(app, i) : 0, ld_pair<W, AR>(par, i)}; },
+      [&](int i, I3 t) { xy[(i % G) * Lw + (i / G)] = make_int2(app ? s_add<AR>(t.b, t.a) : t.a, t.c); });
   __syncthreads();
-  const int2* my = xy + L.g * Lw;
   const pk_t* bl = beta + L.lane;
 
   // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464); positions are fixed: all static
-  v = NEG;
   static_assert(WIN_OVERLAP == 40, "block plan below is written for the 40-step overlap");
-  win_run<W, 24, 39 % 3, -1, 0, 1>(L, v, my, bl, 39, 39, 1, beta, out, sink);  // steps 39..16
-  win_run<W, 12, 15 % 3, -1, 0, 1>(L, v, my, bl, 15, 15, 1, beta, out, sink);  // steps 15..4
-  win_rem<W, -1, 0>(L, v, my, bl, 3, 3, 0, 4, beta, out);                // steps 3..0
-  // ---- tail trellis for the last window: scalar, wrapping adds (turbodecoder_win.h:351-395)
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int2* my = xy + (h * 8 + L.g) * Lw;
+    v[h]           = NEG;
+    win_run<W, 24, 39 % 3, -1, 0, 1, AR>(L, v[h], my, bl, 39, 39, 1, beta, out, 0, sink); // steps 39..16
+    win_run<W, 12, 15 % 3, -1, 0, 1, AR>(L, v[h], my, bl, 15, 15, 1, beta, out, 0, sink); // steps 15..4
+    win_rem<W, -1, 0, AR>(L, v[h], my, bl, 3, 3, 0, 4, beta, out, 0);                      // steps 3..0
+  }
+  // ---- tail trellis for the last window: scalar (turbodecoder_win.h:351-395). 16-bit: wrapping adds; 8-bit: sadd() clamps
+  //      at +127 and wraps below (:322-330), INF = 0
   int tail[8];
   {
     int o[8] = {0, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF};
+    if constexpr (AR) {
+      for (int i = 1; i < 8; i++) o[i] = 0;
+    }
+    auto WA = [](int a, int b) -> int {
+      if constexpr (AR) {
+        const int z = (int)(short)(a + b);
+        return z > 127 ? 127 : (int)(signed char)z;
+      } else {
+        return (int)(short)(a + b);
+      }
+    };
     for (int j = 2; j >= 0; j--) {
-      const int x = tail_in[j], y = tail_par[j], xy_ = (short)(x + y);
-#define WA(a, b) ((int)(short)((a) + (b)))
+      const int x = tail_in[j], y = tail_par[j], xy_ = WA(x, y);
       int m[8] = {WA(o[4], xy_), o[4], WA(o[5], y), WA(o[5], x), WA(o[6], x), WA(o[6], y), o[7], WA(o[7], xy_)};
       int n[8] = {o[0], WA(o[0], xy_), WA(o[1], x), WA(o[1], y), WA(o[2], y), WA(o[2], x), WA(o[3], xy_), o[3]};
-#undef WA
       for (int i = 0; i < 8; i++) o[i] = m[i] > n[i] ? m[i] : n[i];
     }
-    for (int i = 0; i < 8; i++) tail[i] = o[i];
+    for (int i = 0; i < 8; i++) tail[i] = AR ? o[i] * 256 : o[i];
   }
   // ---- window shift: window w starts from the warm-up of window w+1, the last one from the tail (:428-448)
   {
-    const int s    = rotr3(L.p, Lw % 3);                 // state this slot holds at time Lw
-    const pk_t a   = __shfl(v, lane_of(L.g, s), 64);       // same group
-    const pk_t b   = __shfl(v, lane_of((L.g + 1) & 7, s), 64);
-    int        ts  = tail[0];
+    const int s = rotr3(L.p, Lw % 3); // state this slot holds at time Lw
+    pk_t      a[NH], b[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      a[h] = __shfl(v[h], lane_of(L.g, s), 64); // same group
+      b[h] = __shfl(v[h], lane_of((L.g + 1) & 7, s), 64);
+    }
+    int ts = tail[0];
     for (int i = 1; i < 8; i++) ts = s == i ? tail[i] : ts;
-    if constexpr (W == 16) {
-      v = pk_make(pk_hi(a), L.g == 7 ? ts : pk_lo(b));
+    if constexpr (W == 8) {
+      v[0] = pk_make(L.g == 7 ? ts : pk_lo(b[0]), 0);
     } else {
-      v = pk_make(L.g == 7 ? ts : pk_lo(b), 0);
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const int nxt = L.g < 7 ? pk_lo(b[h]) : (h + 1 < NH ? pk_lo(b[(h + 1) % NH]) : ts);
+        v[h]          = pk_make(pk_hi(a[h]), nxt);
+      }
     }
   }
-  const int top = (Lw + CKPT - 1) / CKPT; // checkpoint slot of the start metrics beta[Lw]
-  beta[top * 64 + L.lane] = v;
   // ---- beta main pass (:466-526). Only every CKPT-th metric set is kept (in LDS, `beta`); the alpha pass recomputes the
   //      rest segment by segment. Left-over steps first, then aligned blocks.
-  {
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int2* my = xy + (h * 8 + L.g) * Lw;
+    pk_t*       bh = beta + h * bstride;
+    bh[top * 64 + L.lane] = v[h];
     const int r = Lw % 6, n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
-    win_rem<W, -1, 1>(L, v, my, bl, Lw - 1, Lw - 1, (Lw - 1) % 3, r, beta, out);
-    win_run<W, 6, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1, Lw - r - 1, r6, beta, out, sink); // first step index = 5 (mod 6)
-    win_run<W, 24, 2, -1, 1, 1>(L, v, my, bl, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, beta, out, sink);
+    win_rem<W, -1, 1, AR>(L, v[h], my, bl, Lw - 1, Lw - 1, (Lw - 1) % 3, r, bh, out, 0);
+    win_run<W, 6, 2, -1, 1, 1, AR>(L, v[h], my, bl, Lw - r - 1, Lw - r - 1, r6, bh, out, 0, sink); // first step index = 5 (mod 6)
+    win_run<W, 24, 2, -1, 1, 1, AR>(L, v[h], my, bl, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, bh, out, 0, sink);
   }
 
   // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter j = 0..39
-  v = NEG;
-  {
+#pragma unroll
+  for (int h = 0; h < NH; h++) {
+    const int2* my = xy + (h * 8 + L.g) * Lw;
+    v[h]           = NEG;
     const int k0 = Lw - WIN_OVERLAP, ph0 = k0 % 3;
     switch (ph0) {
-      case 0: win_run<W, 24, 0, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 0, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
-      case 1: win_run<W, 24, 1, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 1, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
-      default: win_run<W, 24, 2, 1, 0, 0>(L, v, my, bl, k0, 0, 1, beta, out, sink); win_run<W, 12, 2, 1, 0, 0>(L, v, my, bl, k0 + 24, 24, 1, beta, out, sink); break;
+      case 0: win_run<W, 24, 0, 1, 0, 0, AR>(L, v[h], my, bl, k0, 0, 1, beta, out, 0, sink); win_run<W, 12, 0, 1, 0, 0, AR>(L, v[h], my, bl, k0 + 24, 24, 1, beta, out, 0, sink); break;
+      case 1: win_run<W, 24, 1, 1, 0, 0, AR>(L, v[h], my, bl, k0, 0, 1, beta, out, 0, sink); win_run<W, 12, 1, 1, 0, 0, AR>(L, v[h], my, bl, k0 + 24, 24, 1, beta, out, 0, sink); break;
+      default: win_run<W, 24, 2, 1, 0, 0, AR>(L, v[h], my, bl, k0, 0, 1, beta, out, 0, sink); win_run<W, 12, 2, 1, 0, 0, AR>(L, v[h], my, bl, k0 + 24, 24, 1, beta, out, 0, sink); break;
     }
     const int done = 36;
-    win_rem<W, 1, 0>(L, v, my, bl, k0 + done, done, (ph0 + done) % 3, WIN_OVERLAP - done, beta, out);
+    win_rem<W, 1, 0, AR>(L, v[h], my, bl, k0 + done, done, (ph0 + done) % 3, WIN_OVERLAP - done, beta, out, 0);
   }
   // ---- window shift: window w starts from the end of window w-1, window 0 from the known state (:560-583)
   {
-    const int  sp   = rotl3(L.p, Lw % 3);                 // slot that holds state p at time Lw
-    const pk_t a    = __shfl(v, lane_of(L.g, sp), 64);
-    const pk_t b    = __shfl(v, lane_of((L.g + 7) & 7, sp), 64);
-    const int  init = L.p == 0 ? 0 : -TD_INF;
-    if constexpr (W == 16) {
-      v = pk_make(L.g == 0 ? init : pk_hi(b), pk_lo(a));
+    const int sp = rotl3(L.p, Lw % 3); // slot that holds state p at time Lw
+    pk_t      a[NH], b[NH];
+#pragma unroll
+    for (int h = 0; h < NH; h++) {
+      a[h] = __shfl(v[h], lane_of(L.g, sp), 64);
+      b[h] = __shfl(v[h], lane_of((L.g + 7) & 7, sp), 64);
+    }
+    const int init = (AR || L.p == 0) ? 0 : -TD_INF;
+    if constexpr (W == 8) {
+      v[0] = pk_make(L.g == 0 ? init : pk_lo(b[0]), 0);
     } else {
-      v = pk_make(L.g == 0 ? init : pk_lo(b), 0);
+#pragma unroll
+      for (int h = 0; h < NH; h++) {
+        const int prv = L.g > 0 ? pk_hi(b[h]) : (h > 0 ? pk_hi(b[(h + NH - 1) % NH]) : init);
+        v[h]          = pk_make(prv, pk_lo(a[h]));
+      }
     }
   }
   // ---- alpha main pass with extrinsic output (:605-679), CKPT steps at a time: the beta metrics of the segment are
   //      recomputed from its checkpoint into LDS (`seg`, one dword per lane and step: lane-private, no barrier), using
   //      the very operands the alpha steps need, then consumed. No beta traffic leaves the CU.
   const int nf = Lw / CKPT;
-  for (int j = 0; j < nf; j++) {
-    const int k0 = CKPT * j;
-    int2      c[CKPT];
 #pragma unroll
-    for (int i = 0; i < CKPT; i++) c[i] = my[k0 + i];
-    int pf = 0;
-    if (k0 + 2 * CKPT <= Lw) pf = my[k0 + CKPT + min(3 * L.p, CKPT - 1)].x; // touch the next segment's operands
-    const pk_t Btop = beta[(j + 1) * 64 + L.lane]; // beta[k0 + CKPT], as stored (before its normalisation)
-    pk_t       vb   = Btop, dummy = 0;
-    if (k0 + CKPT < Lw) win_normalize(vb); // the recursion continued from the normalised value (k even, != 0); beta[Lw] is a start value
+  for (int h = 0; h < NH; h++) {
+    const int2* my = xy + (h * 8 + L.g) * Lw;
+    const pk_t* bh = beta + h * bstride;
+    const int   gg = h * 8 + L.g;
+    pk_t        va = v[h];
+    for (int j = 0; j < nf; j++) {
+      const int k0 = CKPT * j;
+      int2      c[CKPT];
 #pragma unroll
-    for (int i = CKPT - 1; i >= 1; i--) { // beta[k0+i], i = 23..1 (phase (k0+i)%3 = i%3)
-      switch (i % 3) {
-        case 0: win_step<0, 0, W>(L, vb, c[i], 0, dummy); break;
-        case 1: win_step<1, 0, W>(L, vb, c[i], 0, dummy); break;
-        default: win_step<2, 0, W>(L, vb, c[i], 0, dummy); break;
-      }
-      seg[i * 64 + L.lane] = vb;
-      if ((i & 1) == 0) win_normalize(vb);
-    }
-#pragma unroll
-    for (int i6 = 0; i6 < CKPT; i6 += 6) {
-      pk_t keep = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++) {
-        const int  kk = i6 + i;
-        const pk_t B  = kk == CKPT - 1 ? Btop : seg[(kk + 1) * 64 + L.lane];
-        pk_t       o  = 0;
-        switch (i % 3) {
-          case 0: win_step<0, 2, W>(L, v, c[kk], B, o); break;
-          case 1: win_step<1, 2, W>(L, v, c[kk], B, o); break;
-          default: win_step<2, 2, W>(L, v, c[kk], B, o); break;
-        }
-        keep = L.p == i ? o : keep;
-        if ((kk & 1) == 0 && (kk != 0 || k0 != 0)) win_normalize(v);
-      }
-      if (L.p < 6) store_out<W>(out, k0 + i6 + L.p, L.g, keep);
-    }
-    sink ^= pf;
-  }
-  asm volatile("" ::"v"(sink)); // keeps the touches live without any observable effect
-  { // last, shorter segment [CKPT*nf, Lw): run-time phases, same scheme
-    const int k0 = CKPT * nf, t = Lw - k0;
-    if (t > 0) {
-      const pk_t Btop = beta[top * 64 + L.lane];
+      for (int i = 0; i < CKPT; i++) c[i] = my[k0 + i];
+      int pf = 0;
+      if (k0 + 2 * CKPT <= Lw) pf = my[k0 + CKPT + min(3 * L.p, CKPT - 1)].x; // touch the next segment's operands
+      const pk_t Btop = bh[(j + 1) * 64 + L.lane]; // beta[k0 + CKPT], as stored (before its normalisation)
       pk_t       vb   = Btop, dummy = 0;
-      for (int i = t - 1; i >= 1; i--) {
-        const int2 in = my[k0 + i];
-        switch ((k0 + i) % 3) {
-          case 0: win_step<0, 0, W>(L, vb, in, 0, dummy); break;
-          case 1: win_step<1, 0, W>(L, vb, in, 0, dummy); break;
-          default: win_step<2, 0, W>(L, vb, in, 0, dummy); break;
+      if (k0 + CKPT < Lw) win_normalize<AR>(vb); // the recursion continued from the normalised value (counter != 0); beta[Lw] is a start value
+#pragma unroll
+      for (int i = CKPT - 1; i >= 1; i--) { // beta[k0+i], i = 23..1 (phase (k0+i)%3 = i%3)
+        switch (i % 3) {
+          case 0: win_step<0, 0, W, AR>(L, vb, c[i], 0, dummy); break;
+          case 1: win_step<1, 0, W, AR>(L, vb, c[i], 0, dummy); break;
+          default: win_step<2, 0, W, AR>(L, vb, c[i], 0, dummy); break;
         }
         seg[i * 64 + L.lane] = vb;
-        if (((k0 + i) & 1) == 0) win_normalize(vb);
+        if (AR || (i & 1) == 0) win_normalize<AR>(vb);
       }
-      for (int i = 0; i < t; i++) {
-        const int2 in = my[k0 + i];
-        const pk_t B  = i == t - 1 ? Btop : seg[(i + 1) * 64 + L.lane];
-        pk_t       o  = 0;
-        switch ((k0 + i) % 3) {
-          case 0: win_step<0, 2, W>(L, v, in, B, o); break;
-          case 1: win_step<1, 2, W>(L, v, in, B, o); break;
-          default: win_step<2, 2, W>(L, v, in, B, o); break;
+#pragma unroll
+      for (int i6 = 0; i6 < CKPT; i6 += 6) {
+        pk_t keep = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const int  kk = i6 + i;
+          const pk_t B  = kk == CKPT - 1 ? Btop : seg[(kk + 1) * 64 + L.lane];
+          pk_t       o  = 0;
+          switch (i % 3) {
+            case 0: win_step<0, 2, W, AR>(L, va, c[kk], B, o); break;
+            case 1: win_step<1, 2, W, AR>(L, va, c[kk], B, o); break;
+            default: win_step<2, 2, W, AR>(L, va, c[kk], B, o); break;
+          }
+          keep = L.p == i ? o : keep;
+          if ((AR || (kk & 1) == 0) && (kk != 0 || k0 != 0)) win_normalize<AR>(va);
         }
-        if (L.p == 0) store_out<W>(out, k0 + i, L.g, o);
-        if (((k0 + i) & 1) == 0 && k0 + i != 0) win_normalize(v);
+        if (L.p < 6) store_out<W>(out, k0 + i6 + L.p, gg, keep);
+      }
+      sink ^= pf;
+    }
+    { // last, shorter segment [CKPT*nf, Lw): run-time phases, same scheme
+      const int k0 = CKPT * nf, t = Lw - k0;
+      if (t > 0) {
+        const pk_t Btop = bh[top * 64 + L.lane];
+        pk_t       vb   = Btop, dummy = 0;
+        for (int i = t - 1; i >= 1; i--) {
+          const int2 in2 = my[k0 + i];
+          switch ((k0 + i) % 3) {
+            case 0: win_step<0, 0, W, AR>(L, vb, in2, 0, dummy); break;
+            case 1: win_step<1, 0, W, AR>(L, vb, in2, 0, dummy); break;
+            default: win_step<2, 0, W, AR>(L, vb, in2, 0, dummy); break;
+          }
+          seg[i * 64 + L.lane] = vb;
+          if (AR || ((k0 + i) & 1) == 0) win_normalize<AR>(vb);
+        }
+        for (int i = 0; i < t; i++) {
+          const int2 in2 = my[k0 + i];
+          const pk_t B   = i == t - 1 ? Btop : seg[(i + 1) * 64 + L.lane];
+          pk_t       o   = 0;
+          switch ((k0 + i) % 3) {
+            case 0: win_step<0, 2, W, AR>(L, va, in2, B, o); break;
+            case 1: win_step<1, 2, W, AR>(L, va, in2, B, o); break;
+            default: win_step<2, 2, W, AR>(L, va, in2, B, o); break;
+          }
+          if (L.p == 0) store_out<W>(out, k0 + i, gg, o);
+          if ((AR || ((k0 + i) & 1) == 0) && k0 + i != 0) win_normalize<AR>(va);
+        }
       }
     }
   }
+  asm volatile("" ::"v"(sink)); // keeps the touches live without any observable effect
 }
 
 template <int W>
@@ -476,12 +560,14 @@ __device__ __forceinline__ int win_pos(int n, int K)
   return (n % Lw) * W + n / Lw;
 }
 
-template <int W>
+// AR = 1: int8 LLRs in (a.in is an int8 array), the work arrays hold int8 values in int16 containers
+template <int W, int AR>
 __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
 {
+  using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
   const int      cb = blockIdx.x, K = (int)a.K;
   const LaneGeom L  = lane_geom();
-  const int16_t* in = a.in + (size_t)cb * a.in_stride;
+  const in_t*    in = reinterpret_cast<const in_t*>(a.in) + (size_t)cb * a.in_stride;
   int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
@@ -517,6 +603,17 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
   }
   __syncthreads();
 
+  // srslte_vec_sub_sss: wrapping int16. srslte_vec_sub_bbb (vector_simd.c:158-185, AVX2 build, aligned buffers): saturating
+  // int8 in the 32-wide body, wrapping in the scalar tail
+  const int sat_body = K / 32 * 32;
+  auto      vsub     = [&](int i, int x, int y) -> int16_t {
+    if constexpr (AR) {
+      const int d = x - y;
+      return (int16_t)(i < sat_body ? max(-128, min(127, d)) : (int)(signed char)d);
+    } else {
+      return (int16_t)(x - y);
+    }
+  };
   uint32_t       n_iter = 0;
   bool           ok     = false;
   const int16_t* dec    = ext1;
@@ -524,23 +621,22 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
     if ((n_iter & 1) == 0) {
       if (n_iter) {
         batched<8>(
-            L.lane, K, [&](int i) { return I3{app1[i], ext1[i], 0}; },
-            [&](int i, I3 t) { app1[i] = (int16_t)(t.a - t.b); }); // srslte_vec_sub_sss, wrapping
+            L.lane, K, [&](int i) { return I3{app1[i], ext1[i], 0}; }, [&](int i, I3 t) { app1[i] = vsub(i, t.a, t.b); });
         __syncthreads();
       }
-      if (!(a.dbg & 1)) win_siso<W>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, seg, xy, K);
+      if (!(a.dbg & 1)) win_siso<W, AR>(L, syst, n_iter ? app1 : nullptr, par0, syst + K, par0 + K, ext1, beta, seg, xy, K);
       dec = ext1;
     } else {
-      const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub_sss) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut_sss)
+      const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
       batched<8>(
           L.lane, K, [&](int i) { return I3{ext1[i], sub ? app1[i] : 0, a.t.deinter[i]}; },
           [&](int i, I3 t) {
-            const int16_t e = (int16_t)(t.a - t.b);
+            const int16_t e = sub ? vsub(i, t.a, t.b) : (int16_t)t.a;
             if (sub) ext1[i] = e;
             app2[t.c] = e;
           });
       __syncthreads();
-      if (!(a.dbg & 1)) win_siso<W>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, seg, xy, K);
+      if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1, app2 + K, par1 + K, ext2, beta, seg, xy, K);
       __syncthreads();
       batched<8>(
           L.lane, K, [&](int i) { return I3{ext2[i], a.t.inter[i], 0}; }, [&](int i, I3 t) { app1[t.b] = (int16_t)t.a; });
@@ -708,6 +804,12 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
   }
 }
 
+// int8 -> int16 widening for the 8-bit API's 16-bit fall-backs (convert_8_to_16, turbodecoder.c:451-456)
+__global__ void widen_kernel(const int8_t* __restrict__ in, int16_t* __restrict__ out, size_t n)
+{
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
@@ -727,6 +829,7 @@ struct srslte_hip_tdec {
   int16_t*                 d_work;
   pk_t*                    d_beta;
   int2*                    d_xy;
+  int16_t*                 d_conv; // widened LLRs of the 8-bit API's 16-bit fall-backs, allocated on first use
   uint32_t                 beta_stride;
   std::map<TabKey, TabDev> tabs;
   std::mutex               mtx;
@@ -734,6 +837,14 @@ struct srslte_hip_tdec {
 
 extern "C" uint32_t srslte_hip_tdec_autoimp_get_subblocks(uint32_t K)
 { // turbodecoder.c:394-406 on an AVX2 host
+  if (!(K % 16) && K > 800) return 16;
+  if (!(K % 8) && K > 400) return 8;
+  return 0;
+}
+
+extern "C" uint32_t srslte_hip_tdec_autoimp_get_subblocks_8bit(uint32_t K)
+{ // turbodecoder.c:421-436 on an AVX2 host
+  if (!(K % 32) && K > 2048) return 32;
   if (!(K % 16) && K > 800) return 16;
   if (!(K % 8) && K > 400) return 8;
   return 0;
@@ -755,6 +866,7 @@ extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint3
   q->d_work       = nullptr;
   q->d_beta       = nullptr;
   q->d_xy         = nullptr;
+  q->d_conv       = nullptr;
   // windowed kernels need (K/W+1)*64 dwords per block; the generic one (K+4)*64 per 8 blocks: size for the worst
   const size_t beta_words = (size_t)max_nof_cb * (max_long_cb / 8 + 2) * 64;
   const size_t gen_words  = (size_t)((max_nof_cb + 7) / 8) * (max_long_cb + 8) * 64;
@@ -780,6 +892,7 @@ extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
   (void)hipFree(q->d_work);
   (void)hipFree(q->d_beta);
   (void)hipFree(q->d_xy);
+  if (q->d_conv) (void)hipFree(q->d_conv);
   delete q;
 }
 
@@ -819,10 +932,11 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
   return SRSLTE_SUCCESS;
 }
 
-int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
+int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
                      uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
                      uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st)
 {
+  const int16_t* d_input = (const int16_t*)d_input_any;
   if (!q || !d_input || !d_output) return SRSLTE_ERROR_INVALID_INPUTS;
   if (K > q->max_long_cb) {
     fprintf(stderr, "[srslte_hip] TDEC was initialized for max_long_cb=%u\n", q->max_long_cb); // turbodecoder.c:524-527
@@ -837,8 +951,24 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_s
       (crc_poly && (crc_nbits > K || (crc_poly >> 24) != 1)))
     return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_cb == 0) return SRSLTE_SUCCESS;
-  const uint32_t W = force_w >= 0 ? (uint32_t)force_w : srslte_hip_tdec_autoimp_get_subblocks(K);
-  if ((W != 0 && W != 8 && W != 16) || (W && (K % W || K / W < WIN_OVERLAP)) || (sb_layout && !W)) return SRSLTE_ERROR_INVALID_INPUTS;
+  const uint32_t W = force_w >= 0 ? (uint32_t)force_w : (llr8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K));
+  if ((W != 0 && W != 8 && W != 16 && !(llr8 && W == 32)) || (W && (K % W || K / W < WIN_OVERLAP)) || (sb_layout && !W))
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  const bool ar8 = llr8 && W >= 16; // sse8 / avx8 numerics; below that the 8-bit API widens and runs a 16-bit back-end (turbodecoder.c:465-469)
+  if (llr8 && !ar8) {
+    // upstream widens 3K+12 elements whatever the layout (turbodecoder.c:466), which leaves part of an SB-layout buffer stale;
+    // the whole buffer is widened here
+    const size_t per = in_stride, n = (size_t)nof_cb * per;
+    if (!q->d_conv) {
+      const size_t cap = (size_t)q->max_nof_cb * (3 * (q->max_long_cb + 32) + 12);
+      HIP_TRY(hipMalloc((void**)&q->d_conv, cap * sizeof(int16_t)));
+    }
+    if (per > 3 * (q->max_long_cb + 32) + 12) return SRSLTE_ERROR_INVALID_INPUTS;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, st, (const int8_t*)d_input_any,
+                       q->d_conv, n);
+    LAUNCH_CHECK();
+    d_input = q->d_conv;
+  }
   TdecArgs a;
   a.in = d_input; a.in_stride = in_stride; a.sb_layout = sb_layout; a.K = K; a.nof_cb = nof_cb; a.nof_iter = nof_iterations;
   a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy;
@@ -846,12 +976,16 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const int16_t* d_input, uint32_t in_s
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
-  if (W == 16) {
+  if (ar8 && W == 32) {
+    hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(nof_cb), dim3(64), 0, st, a);
+  } else if (ar8) {
+    hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a);
+  } else if (W == 16) {
     a.beta_stride = (K / 16 + 1) * 64;
-    hipLaunchKernelGGL(tdec_win_kernel<16>, dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<16, 0>), dim3(nof_cb), dim3(64), 0, st, a);
   } else if (W == 8) {
     a.beta_stride = (K / 8 + 1) * 64;
-    hipLaunchKernelGGL(tdec_win_kernel<8>, dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(nof_cb), dim3(64), 0, st, a);
   } else {
     a.beta_stride = (K + 4) * 64;
     hipLaunchKernelGGL(tdec_gen_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a);
@@ -864,7 +998,16 @@ extern "C" int srslte_hip_tdec_run_batch(srslte_hip_tdec_t* q, const int16_t* d_
                                          uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits,
                                          uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream)
 {
-  return tdec_run_batch_w(q, d_input, in_stride, sb_layout, long_cb, -1, nof_cb, nof_iterations, crc_poly, crc_nbits, d_output, out_stride,
+  return tdec_run_batch_w(q, d_input, 0, in_stride, sb_layout, long_cb, -1, nof_cb, nof_iterations, crc_poly, crc_nbits, d_output, out_stride,
+                          d_iters, d_crc_ok, (hipStream_t)stream);
+}
+
+// 8-bit LLRs (srslte_tdec_run_all_8bit / srslte_tdec_iteration_8bit, turbodecoder.c:565-593): back-end per K as on an AVX2 host
+extern "C" int srslte_hip_tdec_run_batch_8bit(srslte_hip_tdec_t* q, const int8_t* d_input, uint32_t in_stride, int sb_layout, uint32_t long_cb,
+                                              uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits,
+                                              uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, void* stream)
+{
+  return tdec_run_batch_w(q, d_input, 1, in_stride, sb_layout, long_cb, -1, nof_cb, nof_iterations, crc_poly, crc_nbits, d_output, out_stride,
                           d_iters, d_crc_ok, (hipStream_t)stream);
 }
 
@@ -874,6 +1017,6 @@ extern "C" int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int1
                                                 uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output, uint32_t out_stride,
                                                 uint32_t* d_iters, uint8_t* d_crc_ok, void* stream)
 {
-  return tdec_run_batch_w(q, d_input, in_stride, sb_layout, long_cb, (int)nof_subblocks, nof_cb, nof_iterations, crc_poly, crc_nbits,
+  return tdec_run_batch_w(q, d_input, 0, in_stride, sb_layout, long_cb, (int)nof_subblocks, nof_cb, nof_iterations, crc_poly, crc_nbits,
                           d_output, out_stride, d_iters, d_crc_ok, (hipStream_t)stream);
 }

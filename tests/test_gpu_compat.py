@@ -237,6 +237,39 @@ def test_tdec_object(K):
     L.srslte_tcod_free(tcod)
 
 
+@pytest.mark.parametrize("K", [504, 1008, 5824])
+def test_tdec_object_8bit(K):
+    """srslte_tdec_iteration_8bit / srslte_tdec_run_all_8bit (turbodecoder.c:565-593) and the manual 8-bit back-ends
+    (SRSLTE_TDEC_SSE8_WINDOW / AVX8_WINDOW, turbodecoder.c:183-186,:209-212) fed through the 16-bit API."""
+    L, rng = hip(), np.random.default_rng(K + 8)
+    tdec = opaque(1 << 16)
+    assert L.srslte_tdec_init(tdec, 6144) == 0
+    bits = rng.integers(0, 2, K).astype(np.uint8)
+    enc = np.zeros(3 * K + 12, np.uint8)
+    oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+    llr = (20 * ((2.0 * enc - 1) + 0.8 * rng.standard_normal(enc.shape))).clip(-128, 127).astype(np.int8)
+    assert L.srslte_tdec_autoimp_get_subblocks_8bit(K) == oracle().orc_tdec_autoimp_subblocks_8bit(K)
+    L.srslte_tdec_force_not_sb(tdec)
+    out, ref, per = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8), np.zeros((6, K // 8), np.uint8)
+    assert L.srslte_tdec_run_all_8bit(tdec, p(llr), p(out), 4, K) == 0
+    oracle().orc_tdec_run_8bit(p(llr), False, K, 4, p(ref), None)
+    assert np.array_equal(out, ref) and L.srslte_tdec_get_nof_iterations(tdec) == 4
+    oracle().orc_tdec_run_8bit(p(llr), False, K, 6, None, p(per))
+    assert L.srslte_tdec_new_cb(tdec, K) == 0
+    for it in range(6):
+        L.srslte_tdec_iteration_8bit(tdec, p(llr), p(out))
+        assert np.array_equal(out, per[it])
+    L.srslte_tdec_free(tdec)
+    if K == 5824:  # manual avx8 back-end behind the 16-bit API: LLRs narrowed with a C cast (convert_16_to_8, :458-463)
+        man = opaque(1 << 16)
+        assert L.srslte_tdec_init_manual(man, 6144, 7) == 0  # SRSLTE_TDEC_AVX8_WINDOW
+        L.srslte_tdec_force_not_sb(man)
+        assert L.srslte_tdec_run_all(man, p(llr.astype(np.int16)), p(out), 3, K) == 0
+        oracle().orc_tdec_run_8bit(p(llr), False, K, 3, p(ref), None)
+        assert np.array_equal(out, ref)
+        L.srslte_tdec_free(man)
+
+
 def test_chest_dl_object():
     """chest_test_dl.c:78-255: init, set_cell, res_init, estimate with the default configuration."""
     L, rng = hip(), np.random.default_rng(4)

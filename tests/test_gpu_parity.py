@@ -276,6 +276,63 @@ def test_tdec_sb_layout_and_early_stop(hp, K):
     dec.free()
 
 
+@pytest.mark.parametrize("K", [40, 408, 800, 816, 1008, 2048, 2112, 3136, 5824, 6144])
+def test_tdec_run_all_8bit(hp, K):
+    """srslte_tdec_run_all_8bit (turbodecoder.c:573-588): avx8 for K > 2048, sse8 for K > 800, widening fall-backs below."""
+    rng = np.random.default_rng(8 * K)
+    ncb = 9
+    dec = hp.Tdec(6144, 16)
+    bits = rng.integers(0, 2, (ncb, K)).astype(np.uint8)
+    enc = np.zeros((ncb, 3 * K + 12), np.uint8)
+    for i in range(ncb):
+        oracle().orc_tcod_encode_bits(p(bits[i]), p(enc[i]), K)
+    for snr, scale in ((1.0, 12), (3.0, 25), (0.0, 40), (-2.0, 90)):
+        llr = (scale * ((2.0 * enc - 1) + 10 ** (-snr / 20) * rng.standard_normal(enc.shape))).clip(-128, 127).astype(np.int8)
+        for nit in (1, 2, 3, 6):
+            rc, out, _, _ = dec.run_all(llr, K, nit, llr8=True)
+            assert rc == 0
+            for i in range(ncb):
+                ref = np.zeros(K // 8, np.uint8)
+                assert oracle().orc_tdec_run_8bit(p(llr[i]), False, K, nit, p(ref), None) == 0
+                assert np.array_equal(out[i], ref), "tdec8 K=%d snr=%s nit=%d cb=%d: %d byte mismatches" % (K, snr, nit, i, (out[i] != ref).sum())
+    dec.free()
+
+
+@pytest.mark.parametrize("K", [504, 816, 2112, 5824, 6144])
+def test_tdec_8bit_sb_layout_and_early_stop(hp, K):
+    """srslte_rm_turbo_rx_lut_8bit layout in, CRC early stop as sch.c:348-383 with srslte_tdec_iteration_8bit."""
+    rng = np.random.default_rng(K + 8)
+    ncb, W = 6, oracle().orc_tdec_autoimp_subblocks_8bit(K)
+    dec = hp.Tdec(6144, 8)
+    n_e = (3 * K * 9 // 10) // 6 * 6
+    stride = 3 * (K + 32) + 12
+    w = np.zeros((ncb, stride), np.int8)
+    for i in range(ncb):
+        payload = rng.integers(0, 256, (K - 24) // 8, dtype=np.uint8)
+        crc = oracle().orc_crc_bytes(0x1800063, 24, p(payload), K - 24)
+        cb = np.concatenate([payload, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)])
+        enc = np.zeros(3 * K + 12, np.uint8)
+        oracle().orc_tcod_encode_bits(p(np.unpackbits(cb)), p(enc), K)
+        e = np.zeros(n_e, np.uint8)
+        oracle().orc_rm_turbo_tx_bits(p(enc), p(e), n_e, K, 0)
+        snr = [8.0, 3.0, 1.5, 1.0, 0.5, -2.0][i]
+        llr = (20 * ((2.0 * e - 1) + 10 ** (-snr / 20) * rng.standard_normal(n_e))).clip(-128, 127).astype(np.int8)
+        oracle().orc_rm_turbo_rx_8bit(p(llr), p(w[i]), n_e, K, 0, W)
+    rc, out, iters, ok = dec.run_all(w, K, 6, sb_layout=True, crc_poly=hp.CRC24B, crc_nbits=K, llr8=True)
+    assert rc == 0
+    for i in range(ncb):
+        per = np.zeros((6, K // 8), np.uint8)
+        assert oracle().orc_tdec_run_8bit(p(w[i]), True, K, 6, None, p(per)) == 0
+        n, good = 0, False
+        while n < 6 and not good:
+            good = oracle().orc_crc_bytes(0x1800063, 24, p(per[n]), K) == 0
+            n += 1
+        assert iters[i] == n and bool(ok[i]) == good, (K, i, iters[i], n, ok[i], good)
+        assert np.array_equal(out[i], per[n - 1])
+    assert ok[0] == 1 and ok[-1] == 0
+    dec.free()
+
+
 def test_tdec_errors(hp):
     dec = hp.Tdec(1024, 4)
     rc, *_ = dec.run_all(np.zeros((1, 3 * 2048 + 12), np.int16), 2048, 1)
@@ -336,4 +393,38 @@ def test_dl_rx_chain(hp, prb, mod, tbs, snr, tti0, nsf):
         if r["ok"]:
             assert np.array_equal(tb[b][:tbs // 8], data[b])
     assert n_diff <= 1e-3 * n_tot, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
+    rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr,tti0,nsf", [(6, 1, 936, 12.0, 1, 4), (6, 1, 936, 4.0, 1, 4), (100, 3, 75376, 30.0, 8, 4),
+                                                       (100, 3, 75376, 19.5, 9, 3), (100, 4, 97896, 35.0, 4, 3)])
+def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
+    """8-bit LLR path (pdsch.c:760-779, sch.c:336-356) on the device vs the oracle's 8-bit chain."""
+    rng = np.random.default_rng(80 + prb + mod + int(snr * 10))
+    cfg = DlConfig(prb, 1, mod, tbs, llr8=True)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.05 / np.sqrt(prb) * 20) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=True)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    e_all = rx.debug(4, np.int8, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    n_diff = n_tot = n_ok = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        diff = np.abs(e_all[b, :nre * cfg.Qm].astype(np.int32) - r["e"].astype(np.int32))
+        assert diff.max() <= 1, "LLR differs by more than 1 LSB (sf %d: %d)" % (b, diff.max())
+        n_diff += int((diff != 0).sum())
+        n_tot += diff.size
+        assert bool(ok[b]) == r["ok"], "tb_ok sf %d" % b
+        assert np.array_equal(it[b], r["iters"]), "iterations sf %d: %s vs %s" % (b, it[b], r["iters"])
+        assert np.array_equal(tb[b], r["tb"]), "TB bytes sf %d" % b
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_diff <= 1e-3 * n_tot, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
+    assert n_ok > 0 or snr < 10
     rx.free()
