@@ -53,7 +53,9 @@ __device__ __forceinline__ pk_t pk_sub(pk_t a, pk_t b)
 __device__ __forceinline__ pk_t pk_max(pk_t a, pk_t b) { return as_p(__builtin_elementwise_max(as_v(a), as_v(b))); }
 // AR = 1: the 8-bit back-ends (sse8/avx8). An int8 metric lives in the HIGH byte of its int16 half (value << 8): the packed
 // int16 saturating add/sub then saturates exactly where _mm_adds_epi8/_mm_subs_epi8 do, except that the positive limit
-// comes out as 0x7fff instead of 0x7f00 - one v_and restores it. max needs nothing.
+// comes out as 0x7fff instead of 0x7f00 - one v_and restores it. max needs nothing. A stray 0xff low byte is harmless as long
+// as the other operand of the next add has a clean low byte (no carry into the metric) and the value is masked before it is
+// subtracted or stored: the trellis step therefore masks only the new state metric and the two reduced LLR candidates.
 constexpr pk_t M8 = (pk_t)0xFF00FF00;
 template <int AR>
 __device__ __forceinline__ pk_t s_add(pk_t a, pk_t b)
@@ -130,14 +132,10 @@ __device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y,
   const pk_t g_par = BFI(b1, x & ~b0, BFI(b0, y, xy));
 #undef BFI
   const pk_t po    = dpp_partner<PH>(old);
-  if constexpr (AR) {
-    *t_own = s_add<1>(old, g_own);
-    *t_par = s_add<1>(po, g_par);
-  } else {
-    *t_own = pk_add<SAT>(old, g_own);
-    *t_par = pk_add<SAT>(po, g_par);
-  }
-  return pk_max(*t_own, *t_par);
+  *t_own = pk_add<SAT>(old, g_own);
+  *t_par = pk_add<SAT>(po, g_par);
+  const pk_t nv = pk_max(*t_own, *t_par);
+  return AR ? (nv & M8) : nv;
 }
 
 // max over the 8 slots of a group
@@ -193,13 +191,17 @@ __device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, int2 in, pk
 {
   constexpr bool SAT = true;
   pk_t           to, tp;
-  const pk_t     x = in.x, y = in.y, xy = s_add<AR>(x, y);
+  const pk_t     x = in.x, y = in.y, xy = pk_add<SAT>(x, y);
   v = acs<PH, SAT, AR>(L, v, x, y, xy, &to, &tp);
   if constexpr (MODE == 2) {
     const int  b0 = PH == 0 ? L.m1 : (PH == 1 ? L.m2 : L.m0); // own transition carries info bit b0
-    const pk_t m0 = group_max(s_add<AR>(B, (tp & b0) | (to & ~b0)));
-    const pk_t m1 = group_max(s_add<AR>(B, (to & b0) | (tp & ~b0)));
-    o             = pk_sub<SAT>(m1, m0);
+    pk_t m0 = group_max(pk_add<SAT>(B, (tp & b0) | (to & ~b0)));
+    pk_t m1 = group_max(pk_add<SAT>(B, (to & b0) | (tp & ~b0)));
+    if constexpr (AR) {
+      m0 &= M8;
+      m1 &= M8;
+    }
+    o = pk_sub<SAT>(m1, m0);
     if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
     // AR: back to an int8 value in an int16 container and divide_output (>> 1, :143-147) in one shift; the 0x7fff of a
     // positive saturation gives 63 = 127 >> 1 without a mask
@@ -212,7 +214,7 @@ template <int AR>
 __device__ __forceinline__ void win_normalize(pk_t& v)
 {
   if constexpr (AR) {
-    v = s_sub<1>(v, group_max(v));
+    v = pk_sub<true>(v, group_max(v)); // v <= max: the difference never saturates upwards, no mask
   } else {
     v = pk_sub<true>(v, bcast_slot0(v));
   }

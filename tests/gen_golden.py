@@ -181,6 +181,36 @@ def extra():
     np.savez_compressed(os.path.join(OUT, "tcod_lut.npz"), **lut)
     print("tcod_lut.npz", os.path.getsize(os.path.join(OUT, "tcod_lut.npz")), "bytes")
 
+    # ---------------- 8-bit LLR path: per-pass hard decisions of srslte_tdec_iteration_8bit (sse8: K=1008, avx8: K=2112,
+    # 6144; widening fall-back: K=504) and the whole receive chain with q->llr_is_8bit semantics (pdsch.c:760-779, sch.c:336-356)
+    rng = np.random.default_rng(2026100302)
+    g8 = {}
+    for K in (504, 1008, 2112, 6144):
+        bits = rng.integers(0, 2, K).astype(np.uint8)
+        enc = np.zeros(3 * K + 12, np.uint8)
+        R.srslte_tcod_encode(tcod, p(bits), p(enc), K)
+        llr = acopy((22 * ((2.0 * enc - 1) + 0.85 * rng.standard_normal(enc.shape))).clip(-128, 127).astype(np.int8))
+        tdec = opaque(1 << 20)
+        assert R.srslte_tdec_init(tdec, 6144) == 0 and R.srslte_tdec_new_cb(tdec, K) == 0
+        R.srslte_tdec_force_not_sb(tdec)
+        hard = np.zeros((6, K // 8), np.uint8)
+        for it in range(6):
+            R.srslte_tdec_iteration_8bit(tdec, p(llr), p(hard[it]))
+        g8["llr_%d" % K], g8["hard_%d" % K], g8["bits_%d" % K] = np.array(llr), hard, bits
+        R.srslte_tdec_free(tdec)
+    for tag, (prb, mod, tbs, snr, ttis) in {"cfg1": (6, 1, 936, 5.0, (1, 2)), "cfg2": (100, 3, 75376, 19.5, (5,))}.items():
+        cfg = DlConfig(prb, 1, mod, tbs, llr8=True)
+        chain = RefRx(cfg)
+        for t in ttis:
+            iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+            r = chain.run(iq, t)
+            g8["%s_iq_%d" % (tag, t)] = iq.astype(np.complex64)
+            g8["%s_tb_%d" % (tag, t)] = r["tb"].copy()
+            g8["%s_ok_%d" % (tag, t)] = np.array([r["ok"]], np.uint8)
+            g8["%s_iters_%d" % (tag, t)] = r["iters"].copy()
+    np.savez_compressed(os.path.join(OUT, "llr8.npz"), **g8)
+    print("llr8.npz", os.path.getsize(os.path.join(OUT, "llr8.npz")), "bytes")
+
 
 if __name__ == "__main__":
     if "--extra-only" not in sys.argv:

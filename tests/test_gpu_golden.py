@@ -92,3 +92,24 @@ def test_dl_chain_golden(hp):
             assert np.array_equal(it[i], g["%s_iters_%d" % (tag, t)])
             assert np.array_equal(tb[i], g["%s_tb_%d" % (tag, t)])
         rx.free()
+
+
+def test_llr8_golden(hp):
+    """8-bit LLR path on the device against reference outputs (tests/gen_golden.py:extra)."""
+    g = load("llr8.npz")
+    dec = hp.Tdec(6144, 2)
+    for K in (504, 1008, 2112, 6144):
+        for nit in range(1, 7):
+            rc, out, _, _ = dec.run_all(g["llr_%d" % K], K, nit, llr8=True)
+            assert rc == 0 and np.array_equal(out[0], g["hard_%d" % K][nit - 1]), (K, nit)
+    dec.free()
+    for tag, prb, mod, tbs, ttis in (("cfg1", 6, 1, 936, (1, 2)), ("cfg2", 100, 3, 75376, (5,))):
+        hc = hp.ChestDlCfg()
+        hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+        rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, 1, True, hc, llr_8bit=True)
+        C_ = 13 if prb == 100 else 1
+        for t in ttis:
+            tb, ok = rx.decode(g["%s_iq_%d" % (tag, t)][None, :], t)
+            assert bool(ok[0]) == bool(g["%s_ok_%d" % (tag, t)][0]) and np.array_equal(tb[0], g["%s_tb_%d" % (tag, t)])
+            assert np.array_equal(rx.debug(6, np.uint32, C_), g["%s_iters_%d" % (tag, t)])
+        rx.free()

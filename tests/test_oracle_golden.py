@@ -152,3 +152,19 @@ def test_dl_chain_golden(tag, prb, mod, tbs, ttis):
         assert r["ok"] == bool(g["%s_ok_%d" % (tag, t)][0])
         assert np.array_equal(r["iters"], g["%s_iters_%d" % (tag, t)])
         assert np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)])
+
+
+def test_llr8_golden():
+    """8-bit LLR path against reference outputs: per-pass decisions of srslte_tdec_iteration_8bit and whole chains."""
+    g = load("llr8.npz")
+    for K in (504, 1008, 2112, 6144):
+        per = np.zeros((6, K // 8), np.uint8)
+        assert oracle().orc_tdec_run_8bit(p(g["llr_%d" % K]), False, K, 6, None, p(per)) == 0
+        assert np.array_equal(per, g["hard_%d" % K]), K
+        assert np.array_equal(np.unpackbits(per[5]), g["bits_%d" % K])
+    for tag, prb, mod, tbs, ttis in (("cfg1", 6, 1, 936, (1, 2)), ("cfg2", 100, 3, 75376, (5,))):
+        cfg = DlConfig(prb, 1, mod, tbs, llr8=True)
+        for t in ttis:
+            r = oracle_rx(cfg, g["%s_iq_%d" % (tag, t)], t)
+            assert r["ok"] == bool(g["%s_ok_%d" % (tag, t)][0]) and np.array_equal(r["iters"], g["%s_iters_%d" % (tag, t)])
+            assert np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)])
