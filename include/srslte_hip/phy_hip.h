@@ -167,6 +167,10 @@ uint32_t            srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_
 /* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf] */
 int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                            uint8_t* d_tb_ok, void* stream);
+/* same from frequency-domain grids d_grid [nof_sf][14][12*nof_prb] (the part of srslte_ue_dl_decode after srslte_ofdm_rx_sf,
+ * ue_dl.c:375-397; SURVEY §8d cfg5 feeds grids) */
+int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
+                                uint8_t* d_tb_ok, void* stream);
 /* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,

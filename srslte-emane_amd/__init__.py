@@ -95,6 +95,7 @@ def lib():
         L.srslte_hip_tdec_run_batch_8bit.argtypes = L.srslte_hip_tdec_run_batch.argtypes
         L.srslte_hip_tdec_autoimp_get_subblocks_8bit.restype = C.c_uint32
         L.srslte_hip_tcod_encode_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp]
+        L.srslte_hip_tcod_encode_bytes_batch.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp]
         L.srslte_hip_cbsegm.argtypes = [C.POINTER(Cbsegm), C.c_uint32]
         L.srslte_hip_tc_interl_LTE_gen_interl.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
         L.srslte_hip_dl_rx_create.restype = vp
@@ -103,6 +104,7 @@ def lib():
         L.srslte_hip_dl_rx_nof_re.restype = C.c_uint32
         L.srslte_hip_dl_rx_nof_re.argtypes = [vp, C.c_uint32]
         L.srslte_hip_dl_rx_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.srslte_hip_dl_rx_grid_batch.argtypes = L.srslte_hip_dl_rx_batch.argtypes
         L.srslte_hip_dl_rx_stage.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
         L.srslte_hip_dl_rx_debug_buffer.restype = vp
         L.srslte_hip_dl_rx_debug_buffer.argtypes = [vp, C.c_int]
@@ -352,6 +354,16 @@ class DlRx:
         x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
         din = DevBuf.from_host(x)
         _check(self.run_device(din.ptr, tti0, x.shape[0]), "dl_rx_batch")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def decode_grid(self, grid, tti0=0):
+        """Frequency-domain input [nsf][14*12*nof_prb] (srslte_hip_dl_rx_grid_batch)."""
+        x = np.ascontiguousarray(grid, np.complex64)
+        x = x.reshape(-1, x.shape[-1])
+        din = DevBuf.from_host(x)
+        _check(lib().srslte_hip_dl_rx_grid_batch(self.h, din.ptr, tti0, x.shape[0], self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "dl_rx_grid_batch")
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]

@@ -216,6 +216,7 @@ struct srslte_hip_dl_rx {
   int16_t *              d_e, *d_w;
   uint8_t *              d_cb_bytes, *d_cb_ok;
   uint32_t*              d_cb_iters;
+  const cf32*            grid_in; // resource grids supplied by the caller (srslte_hip_dl_rx_grid_batch) instead of d_grid
 };
 
 extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
@@ -354,17 +355,18 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t    st = (hipStream_t)stream;
   const uint32_t C = q->seg.C, K = q->seg.K1;
+  const cf32*    grid = q->grid_in ? q->grid_in : q->d_grid;
   switch (stage) {
     case 0: return srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
-    case 1: return srslte_hip_chest_dl_estimate_batch(q->chest, &q->cfg.chest_cfg, tti0, q->d_grid, q->d_ce, q->d_res, (int)nof_sf, stream);
+    case 1: return srslte_hip_chest_dl_estimate_batch(q->chest, &q->cfg.chest_cfg, tti0, grid, q->d_ce, q->d_res, (int)nof_sf, stream);
     case 2: {
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
       if (q->cfg.llr_8bit) {
-        hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
+        hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, grid,
                            (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
       } else {
-        hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, (const cf32*)q->d_grid,
+        hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, grid,
                            (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
       }
       LAUNCH_CHECK();
@@ -408,4 +410,16 @@ extern "C" int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, u
     if (r) return r;
   }
   return SRSLTE_SUCCESS;
+}
+
+// Same chain from resource grids already in the frequency domain (what follows srslte_ofdm_rx_sf in ue_dl.c:375-397): stages 1..5
+extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,
+                                           uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_grid || !d_tb || !d_tb_ok) return SRSLTE_ERROR_INVALID_INPUTS;
+  q->grid_in = (const cf32*)d_grid;
+  int r      = SRSLTE_SUCCESS;
+  for (int s = 1; s < 6 && r == SRSLTE_SUCCESS; s++) r = srslte_hip_dl_rx_stage(q, s, nullptr, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+  q->grid_in = nullptr;
+  return r;
 }

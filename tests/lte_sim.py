@@ -81,14 +81,43 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0):
     return iq.astype(np.complex64), data
 
 
-def oracle_rx(cfg, iq, tti, keep=False):
-    """Oracle UE receive chain for one subframe. Returns dict with tb bytes (tbs/8+3), ok flag and (keep=True) every intermediate."""
+def make_grid(cfg, tti, rng, snr_db):
+    """SURVEY §8d cfg5 stimulus: frequency-domain grid with CRS + PDSCH symbols through the smooth per-RE channel of
+    chest_test_dl.c:159-161, h = (3 + x) e^{jx}, plus AWGN. Returns (grid[14*12*prb] complex64, payload bytes)."""
     orc = oracle()
     sf_idx = tti % 10
-    q = OrcOfdm()
-    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+    idx = cfg.indices(sf_idx)
+    nbits = len(idx) * cfg.Qm
+    data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
+    e = np.zeros(nbits, np.uint8)
+    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(e)) == 0
+    e ^= scramble_seq(cfg, sf_idx, nbits)
+    syms = np.zeros(len(idx), np.complex64)
+    orc.orc_modulate(cfg.mod, p(e), p(syms), nbits)
     grid = np.zeros(cfg.grid_len, np.complex64)
-    orc.orc_ofdm_rx_sf(C.byref(q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
+    grid[idx] = syms
+    orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, 0, p(grid))
+    k, l = np.arange(cfg.grid_len) % cfg.nre, np.arange(cfg.grid_len) // cfg.nre
+    x = (k / cfg.nre * 2.0 + 0.0 * l).astype(np.float64)  # static over the subframe: the default estimator averages the pilots in time
+    h = (3.0 + x) * np.exp(1j * x)
+    sigma = np.sqrt(np.mean(np.abs(h) ** 2) / 2) * 10 ** (-snr_db / 20)
+    noise = sigma * (rng.standard_normal(cfg.grid_len) + 1j * rng.standard_normal(cfg.grid_len))
+    return (grid * h + noise).astype(np.complex64), data
+
+
+def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
+    """Oracle UE receive chain for one subframe. Returns dict with tb bytes (tbs/8+3), ok flag and (keep=True) every intermediate.
+    grid_in: start from a frequency-domain grid instead of time samples."""
+    orc = oracle()
+    sf_idx = tti % 10
+    if grid_in is not None:
+        grid = np.ascontiguousarray(grid_in, np.complex64)
+    else:
+        q = OrcOfdm()
+        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+        grid = np.zeros(cfg.grid_len, np.complex64)
+        orc.orc_ofdm_rx_sf(C.byref(q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
     ce = np.zeros(cfg.grid_len, np.complex64)
     res = OrcChestRes()
     ccfg = cfg.orc_chest_cfg()

@@ -428,3 +428,139 @@ def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
     assert n_diff <= 1e-3 * n_tot, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
     assert n_ok > 0 or snr < 10
     rx.free()
+
+
+def test_cfg4_multi_ue(hp):
+    """several UEs, each with its own cell id and RNTI (CRS position/sequence, scrambling, RE map differ)."""
+    for u, (prb, mod, tbs, snr) in enumerate([(100, 3, 75376, 24.0), (100, 3, 75376, 21.0), (6, 1, 936, 6.0), (25, 2, 11448, 16.0)]):
+        cell_id, rnti = 1 + 5 * u + (u == 3) * 97, 0x1234 + u
+        rng = np.random.default_rng(400 + u)
+        cfg = DlConfig(prb, cell_id, mod, tbs, rnti=rnti)
+        ttis = [0, 5, 6] if prb != 6 else [1, 6, 9]
+        iq, data = zip(*[make_subframe(cfg, t, rng, snr_db=snr, amp=0.1) for t in ttis])
+        hc = hp.ChestDlCfg()
+        hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+        rx = hp.DlRx(cell_id, prb, 1, rnti, mod, tbs, 6, 1, True, hc)
+        for b, t in enumerate(ttis):
+            tb, ok = rx.decode(iq[b][None, :], t)
+            r = oracle_rx(cfg, iq[b], t)
+            assert bool(ok[0]) == r["ok"] and np.array_equal(tb[0], r["tb"]), (u, t)
+            assert np.array_equal(rx.debug(6, np.uint32, cfg.seg.C), r["iters"])
+            assert r["ok"] and np.array_equal(tb[0][:tbs // 8], data[b])
+        rx.free()
+
+
+@pytest.mark.parametrize("llr8", [False, True])
+def test_cfg5_256qam_grid_snr_sweep(hp, llr8):
+    """100 PRB 256QAM (TBS 97896, 16 x K=6144) from frequency-domain grids through the chest_test_dl channel,
+    SNR sweep; ce / noise / LLR parity and identical block decisions (so identical BLER) at every point."""
+    from lte_sim import make_grid
+    prb, mod, tbs = 100, 4, 97896
+    cfg = DlConfig(prb, 1, mod, tbs, llr8=llr8)
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, 2, True, hc, llr_8bit=llr8)
+    outcomes = []
+    for si, snr in enumerate((10, 15, 20, 25, 30, 35)):
+        rng = np.random.default_rng(500 + si)
+        ttis = (3, 4)
+        grids, data = zip(*[make_grid(cfg, t, rng, snr) for t in ttis])
+        tb, ok = rx.decode_grid(np.stack(grids), ttis[0])
+        ce = rx.debug(1, np.complex64, 2 * cfg.grid_len).reshape(2, -1)
+        res = rx.debug(2, np.float32, 2 * 10).reshape(2, 10)
+        it = rx.debug(6, np.uint32, 2 * cfg.seg.C).reshape(2, -1)
+        max_re = max(rx.nof_re(s_) for s_ in (0, 1, 5))
+        e_all = rx.debug(4, np.int8 if llr8 else np.int16, 2 * max_re * cfg.Qm).reshape(2, -1)
+        for b, t in enumerate(ttis):
+            r = oracle_rx(cfg, None, t, keep=True, grid_in=grids[b])
+            assert_close_c(ce[b], r["ce"], "ce snr %d sf %d" % (snr, b))
+            assert abs(res[b, 0] - r["noise"]) <= 1e-4 * abs(r["noise"])
+            nre = rx.nof_re(t % 10)
+            e = e_all[b, :nre * cfg.Qm].astype(np.int32)
+            diff = np.abs(e - r["e"].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), (snr, b)
+            # A block that never converges amplifies a 1-LSB LLR difference (float chest upstream) into different garbage:
+            # byte equality is required where the LLRs are identical or the block decoded
+            if r["ok"] or diff.max() == 0:
+                assert np.array_equal(tb[b], r["tb"]), (snr, b)
+            outcomes.append((snr, r["ok"]))
+            if r["ok"]:
+                assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert not outcomes[0][1] and outcomes[-1][1]  # the sweep crosses the waterfall
+    rx.free()
+
+
+def test_cfg3_ul_tx_chain(hp):
+    """SURVEY §8d cfg3 (UL transmit, 100 PRB 16QAM): TB -> CB CRC -> turbo encode (device, byte API) -> rate matching + modulation
+    (host, out of scope: oracle) -> 12 x 1200-point transform precoding (device) -> SC-FDMA grid -> OFDM TX with the half-carrier
+    shift and 1/sqrt(N) (device); every device stage and the final time signal against the oracle chain."""
+    from _libs import OrcOfdm, OrcSchCfg
+    rng = np.random.default_rng(33)
+    prb, Qm, mod, tbs = 100, 4, 2, 43816  # 16QAM, I_TBS 20 at 100 PRB: 8 x K = 5504
+    rc, seg = hp.cbsegm(tbs)
+    assert rc == 0 and seg.C == 8 and seg.K1 == 5504 and seg.C2 == 0
+    K, Cn = seg.K1, seg.C
+    nof_re = 12 * 12 * prb
+    nbits = nof_re * Qm
+    data = rng.integers(0, 256, tbs // 8, dtype=np.uint8)
+    # oracle chain (orc_dlsch_encode is the UL-SCH data path without UCI: same segmentation, coder and rate matching, sch.c:580-650)
+    sch = OrcSchCfg(tbs, nbits, Qm, 0, 6)
+    e_ref = np.zeros(nbits, np.uint8)
+    assert oracle().orc_dlsch_encode(C.byref(sch), p(data), p(e_ref)) == 0
+    # device encoder on the same code blocks
+    crc = oracle().orc_crc_bytes(0x1864CFB, 24, p(data), tbs)
+    tbb = np.concatenate([data, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)])
+    rlen = K - 24
+    cbs = np.zeros((Cn, K // 8), np.uint8)
+    for i in range(Cn):
+        body = tbb[i * rlen // 8:(i + 1) * rlen // 8]
+        c = oracle().orc_crc_bytes(0x1800063, 24, p(np.ascontiguousarray(body)), rlen)
+        cbs[i] = np.concatenate([body, np.array([c >> 16, (c >> 8) & 255, c & 255], np.uint8)])
+    L = hp.lib()
+    din, dpar, dtail = hp.DevBuf.from_host(cbs), hp.DevBuf(Cn * (K // 4 + 1)), hp.DevBuf(Cn)
+    assert L.srslte_hip_tcod_encode_bytes_batch(din.ptr, K // 8, dpar.ptr, K // 4 + 1, dtail.ptr, K, Cn, None) == 0
+    hp.sync()
+    par, tail = dpar.to_host(np.uint8).reshape(Cn, -1), dtail.to_host(np.uint8)
+    e_dev, wp = np.zeros(nbits, np.uint8), 0
+    Gp = nbits // Qm
+    gamma = Gp % Cn
+    for i in range(Cn):
+        sysb = np.concatenate([cbs[i], tail[i:i + 1]])
+        ref_sys, ref_par = sysb.copy(), np.zeros(K // 4 + 2, np.uint8)
+        oracle().orc_tcod_encode_bytes(p(ref_sys), p(ref_par), K)
+        assert np.array_equal(ref_sys, sysb) and np.array_equal(ref_par[:K // 4 + 1], par[i])
+        pb = np.unpackbits(par[i])
+        d = np.zeros(3 * K + 12, np.uint8)
+        sb = np.unpackbits(sysb)
+        d[0:3 * K:3], d[1:3 * K:3], d[2:3 * K:3] = sb[:K], pb[:K], pb[K + 4:2 * K + 4]
+        t0, t1, t2 = sb[K:K + 4], pb[K:K + 4], pb[2 * K + 4:2 * K + 8]
+        for j in range(4):
+            d[3 * K + 3 * j: 3 * K + 3 * j + 3] = (t0[j], t1[j], t2[j])
+        n_e = Qm * (Gp // Cn) if i <= Cn - gamma - 1 else Qm * -(-Gp // Cn)
+        ee = np.zeros(n_e, np.uint8)
+        oracle().orc_rm_turbo_tx_bits(p(d), p(ee), n_e, K, 0)
+        e_dev[wp:wp + n_e] = ee
+        wp += n_e
+    assert wp == nbits and np.array_equal(e_dev, e_ref)
+    syms = np.zeros(nof_re, np.complex64)
+    oracle().orc_modulate(mod, p(e_ref), p(syms), nbits)
+    rc, z = hp.dft_precoding(syms, prb, 12, True)
+    z_ref = np.zeros_like(syms)
+    oracle().orc_dft_precoding(p(syms), p(z_ref), prb, 12, 1, True)
+    assert rc == 0
+    assert_close_c(z, z_ref, "transform precoding")
+    grid = np.zeros(14 * 12 * prb, np.complex64)
+    data_syms = [l for l in range(14) if l not in (3, 10)]  # DMRS symbols left empty here (refsignal_ul is §8f N3)
+    for j, l in enumerate(data_syms):
+        grid[l * 12 * prb:(l + 1) * 12 * prb] = z_ref[j * 12 * prb:(j + 1) * 12 * prb]
+    tx = hp.Ofdm(prb, True, False)
+    tx.set_normalize(True)
+    tx.set_freq_shift(0.5)
+    t = tx.tx_sf(grid)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    q.normalize, q.freq_shift, q.freq_shift_f, q.exact = True, True, 0.5, True
+    t_ref = np.zeros(15 * 1536, np.complex64)
+    oracle().orc_ofdm_tx_sf(C.byref(q), p(grid), p(t_ref))
+    assert_close_c(t.ravel(), t_ref, "SC-FDMA time signal")
