@@ -73,18 +73,21 @@ __device__ __forceinline__ pk_t pk_make(int lo, int hi) { return (pk_t)((lo & 0x
 __device__ __forceinline__ int  pk_lo(pk_t a) { return (int)(short)(a & 0xffff); }
 __device__ __forceinline__ int  pk_hi(pk_t a) { return a >> 16; }
 
+// A DPP move whose every destination lane has a source lane (quad_perm, row_ror): no `old` operand, so the compiler does not
+// have to copy the source into the destination first.
+#define DPP_MOV(v, ctrl) __builtin_amdgcn_mov_dpp((v), (ctrl), 0xf, 0xf, false)
 // lane ^ 1, ^ 2, ^ 8 as DPP moves
 template <int PH>
 __device__ __forceinline__ pk_t dpp_partner(pk_t v)
 {
-  if constexpr (PH == 0) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
-  if constexpr (PH == 1) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
-  return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);                        // row_ror:8
+  if constexpr (PH == 0) return DPP_MOV(v, 0xB1);  // quad_perm [1,0,3,2]
+  if constexpr (PH == 1) return DPP_MOV(v, 0x4E);  // quad_perm [2,3,0,1]
+  return DPP_MOV(v, 0x128);                        // row_ror:8
 }
 // value of slot 0 (state 0 at every time step) broadcast to the 8 slots of the group
 __device__ __forceinline__ pk_t bcast_slot0(pk_t v)
 {
-  pk_t t = __builtin_amdgcn_update_dpp(v, v, 0x00, 0xf, 0xf, false);  // quad_perm [0,0,0,0]
+  pk_t t = DPP_MOV(v, 0x00);                                          // quad_perm [0,0,0,0]
   return __builtin_amdgcn_update_dpp(t, t, 0x118, 0xf, 0xf, false);   // row_shr:8, lanes 0..7 of the row keep t
 }
 
@@ -92,6 +95,8 @@ struct LaneGeom {
   int  lane, p, g;
   bool p0, p1, p2;
   int  m0, m1, m2; // all-ones where slot bit 0 / 1 / 2 is set: VGPR masks for v_bfi selections (no SGPR mask traffic)
+  int  io[3];      // per trellis phase: which of the four branch metrics {0, x, y, x+y} is this slot's own one
+  int  mk0, mk1;   // LLR reduction (win_step): b0 ^ lane-bit-0 at phase 0 / 1 (phase 2: always 0)
 };
 __device__ __forceinline__ LaneGeom lane_geom()
 {
@@ -105,6 +110,12 @@ __device__ __forceinline__ LaneGeom lane_geom()
   L.m0   = L.p0 ? -1 : 0;
   L.m1   = L.p1 ? -1 : 0;
   L.m2   = L.p2 ? -1 : 0;
+  // (b1, b0) = state bits 2, 1 of the slot's state at the phase (see acs): own metric index 2*b1 + b0
+  L.io[0] = 2 * L.p2 + L.p1;
+  L.io[1] = 2 * L.p0 + L.p2;
+  L.io[2] = 2 * L.p1 + L.p0;
+  L.mk0   = L.m1 ^ L.m0;
+  L.mk1   = L.m2 ^ L.m0;
   return L;
 }
 __device__ __forceinline__ int lane_of(int g, int p) { return (p & 3) | ((g & 1) << 2) | (((p >> 2) & 1) << 3) | ((g >> 1) << 4); }
@@ -122,6 +133,27 @@ __device__ __forceinline__ int rotl3(int s, int n)
 // One add-compare-select step for the slot's state at phase PH = time % 3 (time of the OLD metrics for the forward
 // recursion, of the NEW metrics for the backward one - the same code serves both, see header comment).
 // Branch metrics: (own, partner) = (0,xy) (x,y) (y,x) (xy,0) for state>>1 = 0..3 (turbodecoder_win.h:471-491,:621-641).
+// Windowed decoders: the combine pass stores {0, x, y, x+y} per step and each lane loads its own branch metric g_own
+// (index LaneGeom::io[PH]); the partner's is the complementary entry, held by the lane whose two (b1, b0) slot bits are
+// flipped: one or two DPP moves instead of six select operations.
+template <int PH>
+__device__ __forceinline__ pk_t dpp_complement(pk_t g)
+{
+  if constexpr (PH == 2) return DPP_MOV(g, 0x1B);          // slot bits 1,0: quad_perm [3,2,1,0]
+  const pk_t t = PH == 0 ? DPP_MOV(g, 0x4E) : DPP_MOV(g, 0xB1); // slot bit 1 (lane ^ 2) / slot bit 0 (lane ^ 1)
+  return DPP_MOV(t, 0x128);                                // slot bit 2 (lane ^ 8)
+}
+template <int PH, int AR>
+__device__ __forceinline__ pk_t acs_tab(pk_t old, pk_t g_own, pk_t* t_own, pk_t* t_par)
+{
+  const pk_t g_par = dpp_complement<PH>(g_own);
+  const pk_t po    = dpp_partner<PH>(old);
+  *t_own           = pk_add<true>(old, g_own);
+  *t_par           = pk_add<true>(po, g_par);
+  const pk_t nv    = pk_max(*t_own, *t_par);
+  return AR ? (nv & M8) : nv;
+}
+
 template <int PH, bool SAT, int AR = 0>
 __device__ __forceinline__ pk_t acs(const LaneGeom& L, pk_t old, pk_t x, pk_t y, pk_t xy, pk_t* t_own, pk_t* t_par)
 {
@@ -161,7 +193,7 @@ struct TdecArgs {
   int16_t*       work;         // per block: 7 arrays of Kp int16
   uint32_t       Kp;
   pk_t*          beta;         // per wave: (steps+1) * 64 dwords
-  int2*          xy;           // per block: K int2 (combine-pass scratch of the windowed decoders)
+  int4*          xy;           // per block: K int4 (combine-pass scratch of the windowed decoders: branch metrics per step)
   uint32_t       beta_stride;  // dwords per wave
   uint8_t*       out;
   uint32_t       out_stride;
@@ -186,22 +218,28 @@ __device__ __forceinline__ pk_t ld_pair(const int16_t* a, int i)
 
 // ---- one trellis step on prepared inputs: in.x = systematic (+ a-priori, already added with saturation), in.y = parity
 // MODE 0: warm-up, 1: beta main pass, 2: alpha main pass (also forms the extrinsic output o from beta value B)
-template <int PH, int MODE, int W, int AR>
-__device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, int2 in, pk_t B, pk_t& o)
+// JPAR: parity of the slot that keeps this step's extrinsic output (MODE 2): only lanes with that lane-bit-0 get a valid o.
+template <int PH, int MODE, int W, int AR, int JPAR = 0>
+__device__ __forceinline__ void win_step(const LaneGeom& L, pk_t& v, pk_t g_own, pk_t B, pk_t& o)
 {
-  constexpr bool SAT = true;
-  pk_t           to, tp;
-  const pk_t     x = in.x, y = in.y, xy = pk_add<SAT>(x, y);
-  v = acs<PH, SAT, AR>(L, v, x, y, xy, &to, &tp);
+  pk_t to, tp;
+  v = acs_tab<PH, AR>(v, g_own, &to, &tp);
   if constexpr (MODE == 2) {
-    const int  b0 = PH == 0 ? L.m1 : (PH == 1 ? L.m2 : L.m0); // own transition carries info bit b0
-    pk_t m0 = group_max(pk_add<SAT>(B, (tp & b0) | (to & ~b0)));
-    pk_t m1 = group_max(pk_add<SAT>(B, (to & b0) | (tp & ~b0)));
-    if constexpr (AR) {
-      m0 &= M8;
-      m1 &= M8;
+    // Max-log LLR (turbodecoder_win.h:643-659): m0/m1 = max over the 8 states of beta + the transition with info bit 0/1.
+    // The own transition carries info bit b0. Lanes with lane bit 0 clear reduce the bit-0 candidates, the others the bit-1
+    // ones: each lane keeps one candidate and hands the other to its lane^1 neighbour, so one reduction serves both.
+    pk_t keep = to, send = tp; // phase 2: b0 is lane bit 0 itself
+    if constexpr (PH != 2) {
+      const int q = PH == 0 ? L.mk0 : L.mk1; // b0 ^ lane bit 0
+      keep        = (tp & q) | (to & ~q);
+      send        = (to & q) | (tp & ~q);
     }
-    o = pk_sub<SAT>(m1, m0);
+    pk_t r = pk_max(pk_add<true>(B, keep), dpp_partner<0>(pk_add<true>(B, send)));
+    r      = pk_max(r, dpp_partner<1>(r));
+    r      = pk_max(r, dpp_partner<2>(r));
+    if constexpr (AR) r &= M8;
+    const pk_t other = dpp_partner<0>(r);
+    o                = JPAR ? pk_sub<true>(r, other) : pk_sub<true>(other, r); // m1 - m0
     if constexpr (W == 8) o = as_p(as_v(o) >> (short)1); // divide_output, turbodecoder_win.h:56,:657-659
     // AR: back to an int8 value in an int16 container and divide_output (>> 1, :143-147) in one shift; the 0x7fff of a
     // positive saturation gives 63 = 127 >> 1 without a mask
@@ -238,23 +276,23 @@ __device__ __forceinline__ void store_out(int16_t* out, int k, int gg, pk_t o)
 // loop back-edge does not survive hipcc's waitcnt insertion, which drains vmcnt(0) there; in-flight registers managed
 // by hand from inline asm were tried and are unsafe at this register pressure: the allocator copies them.)
 template <int W, int BLK, int PH0, int DIR, int MODE, int NPAR0, int AR>
-__device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
+__device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const pk_t* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
                                         int n_first, int nb, pk_t* __restrict__ beta, int16_t* __restrict__ out, int gg, int& sink)
 {
   for (int b = 0; b < nb; b++) {
     const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b;
-    int2      c[BLK];
-    pk_t      cb[BLK];
+    pk_t      c[BLK], cb[BLK];
 #pragma unroll
     for (int j = 0; j < BLK; j++) {
-      c[j]  = my[k0 + DIR * j];
+      const int ph = DIR > 0 ? (PH0 + j) % 3 : (PH0 + 3 * BLK - j) % 3; // static after unrolling
+      c[j]  = my[(k0 + DIR * j) * 4 + L.io[ph]];
       cb[j] = 0;
       if constexpr (MODE == 2) cb[j] = bl[(k0 + DIR * j + 1) * 64];
     }
     // touch the next block's operands now (slot p takes every 3rd step: all of its cache lines) so that its loads hit L1/L2;
     // the value is only consumed after this block's steps, i.e. the request never stalls the trellis chain
     int pf = 0;
-    if (BLK >= 24 && b + 1 < nb) pf = my[k0 + DIR * (BLK + min(3 * L.p, BLK - 1))].x;
+    if (BLK >= 24 && b + 1 < nb) pf = my[(k0 + DIR * (BLK + min(3 * L.p, BLK - 1))) * 4];
     pk_t keep = 0;
 #pragma unroll
     for (int j6 = 0; j6 < BLK; j6 += 6) {
@@ -262,7 +300,7 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
   {                                                                               \
     constexpr int PH = DIR > 0 ? (PH0 + J) % 3 : (PH0 + 18 - J) % 3;              \
     pk_t          o  = 0;                                                         \
-    win_step<PH, MODE, W, AR>(L, v, c[j6 + J], cb[j6 + J], o);                    \
+    win_step<PH, MODE, W, AR, (J & 1)>(L, v, c[j6 + J], cb[j6 + J], o);           \
     if constexpr (MODE == 1) {                                                    \
       const int kq = k0 + DIR * (j6 + J);                                         \
       if constexpr (BLK == CKPT) { /* aligned blocks end on a multiple of CKPT */ \
@@ -289,17 +327,17 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const int2* 
 
 // up to 5 left-over steps with run-time phase; their loads are issued together up front
 template <int W, int DIR, int MODE, int AR>
-__device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const int2* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
+__device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const pk_t* __restrict__ my, const pk_t* __restrict__ bl, int k_first,
                                         int n_first, int ph_first, int r, pk_t* __restrict__ beta, int16_t* __restrict__ out, int gg)
 {
-  int2 in[5];
-  pk_t B[5];
+  pk_t in[5], B[5];
 #pragma unroll
   for (int j = 0; j < 5; j++) {
-    in[j] = make_int2(0, 0);
+    in[j] = 0;
     B[j]  = 0;
     if (j < r) {
-      in[j] = my[k_first + DIR * j];
+      const int ph = ((ph_first + DIR * j) % 3 + 3) % 3;
+      in[j]        = my[(k_first + DIR * j) * 4 + (ph == 0 ? L.io[0] : (ph == 1 ? L.io[1] : L.io[2]))];
       if constexpr (MODE == 2) B[j] = bl[(k_first + DIR * j + 1) * 64];
     }
   }
@@ -351,7 +389,7 @@ struct I3 { int a, b, c; };
 template <int W, int AR>
 __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
-                         pk_t* __restrict__ beta, pk_t* __restrict__ seg, int2* __restrict__ xy, int K)
+                         pk_t* __restrict__ beta, pk_t* __restrict__ seg, int4* __restrict__ xy, int K)
 {
   constexpr int NH = W == 32 ? 2 : 1;
   constexpr int G  = 8 * NH; // window pairs per step
@@ -362,11 +400,14 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   const int     top = (Lw + CKPT - 1) / CKPT; // checkpoint slot of the start metrics beta[Lw]
   const int     bstride = (top + 1) * 64;     // checkpoint columns of one half
 
-  // ---- combine pass: xy[gg][k] = (sat(app + syst), parity) for the window pair gg at step k, so that one 8-byte load
-  //      per step feeds the recursion (turbodecoder_win.h:472-478: x = adds(ap, x))
+  // ---- combine pass: xy[gg][k] = {0, x, y, x + y} with x = sat(app + syst), y = parity for the window pair gg at step k:
+  //      the four branch metrics of the step (turbodecoder_win.h:472-491); each lane later loads the one its state needs
   batched<8>(
       L.lane, G * Lw, [&](int i) { return I3{ld_pair<W, AR>(in, i), app ? ld_pair<W, AR>(app, i) : 0, ld_pair<W, AR>(par, i)}; },
-      [&](int i, I3 t) { xy[(i % G) * Lw + (i / G)] = make_int2(app ? s_add<AR>(t.b, t.a) : t.a, t.c); });
+      [&](int i, I3 t) {
+        const pk_t x = app ? s_add<AR>(t.b, t.a) : t.a;
+        xy[(i % G) * Lw + (i / G)] = make_int4(0, x, t.c, pk_add<true>(x, t.c)); // AR: a 0x7fff in x + y is harmless (see M8)
+      });
   __syncthreads();
   const pk_t* bl = beta + L.lane;
 
@@ -374,7 +415,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   static_assert(WIN_OVERLAP == 40, "block plan below is written for the 40-step overlap");
 #pragma unroll
   for (int h = 0; h < NH; h++) {
-    const int2* my = xy + (h * 8 + L.g) * Lw;
+    const pk_t* my = reinterpret_cast<const pk_t*>(xy + (h * 8 + L.g) * Lw);
     v[h]           = NEG;
     win_run<W, 24, 39 % 3, -1, 0, 1, AR>(L, v[h], my, bl, 39, 39, 1, beta, out, 0, sink); // steps 39..16
     win_run<W, 12, 15 % 3, -1, 0, 1, AR>(L, v[h], my, bl, 15, 15, 1, beta, out, 0, sink); // steps 15..4
@@ -429,7 +470,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   //      rest segment by segment. Left-over steps first, then aligned blocks.
 #pragma unroll
   for (int h = 0; h < NH; h++) {
-    const int2* my = xy + (h * 8 + L.g) * Lw;
+    const pk_t* my = reinterpret_cast<const pk_t*>(xy + (h * 8 + L.g) * Lw);
     pk_t*       bh = beta + h * bstride;
     bh[top * 64 + L.lane] = v[h];
     const int r = Lw % 6, n6 = Lw / 6, n24 = n6 / 4, r6 = n6 % 4;
@@ -441,7 +482,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter j = 0..39
 #pragma unroll
   for (int h = 0; h < NH; h++) {
-    const int2* my = xy + (h * 8 + L.g) * Lw;
+    const pk_t* my = reinterpret_cast<const pk_t*>(xy + (h * 8 + L.g) * Lw);
     v[h]           = NEG;
     const int k0 = Lw - WIN_OVERLAP, ph0 = k0 % 3;
     switch (ph0) {
@@ -478,17 +519,17 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   const int nf = Lw / CKPT;
 #pragma unroll
   for (int h = 0; h < NH; h++) {
-    const int2* my = xy + (h * 8 + L.g) * Lw;
+    const pk_t* my = reinterpret_cast<const pk_t*>(xy + (h * 8 + L.g) * Lw);
     const pk_t* bh = beta + h * bstride;
     const int   gg = h * 8 + L.g;
     pk_t        va = v[h];
     for (int j = 0; j < nf; j++) {
       const int k0 = CKPT * j;
-      int2      c[CKPT];
+      pk_t      c[CKPT];
 #pragma unroll
-      for (int i = 0; i < CKPT; i++) c[i] = my[k0 + i];
+      for (int i = 0; i < CKPT; i++) c[i] = my[(k0 + i) * 4 + L.io[i % 3]]; // phase (k0 + i) % 3 = i % 3
       int pf = 0;
-      if (k0 + 2 * CKPT <= Lw) pf = my[k0 + CKPT + min(3 * L.p, CKPT - 1)].x; // touch the next segment's operands
+      if (k0 + 2 * CKPT <= Lw) pf = my[(k0 + CKPT + min(3 * L.p, CKPT - 1)) * 4]; // touch the next segment's operands
       const pk_t Btop = bh[(j + 1) * 64 + L.lane]; // beta[k0 + CKPT], as stored (before its normalisation)
       pk_t       vb   = Btop, dummy = 0;
       if (k0 + CKPT < Lw) win_normalize<AR>(vb); // the recursion continued from the normalised value (counter != 0); beta[Lw] is a start value
@@ -510,10 +551,13 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
           const int  kk = i6 + i;
           const pk_t B  = kk == CKPT - 1 ? Btop : seg[(kk + 1) * 64 + L.lane];
           pk_t       o  = 0;
-          switch (i % 3) {
-            case 0: win_step<0, 2, W, AR>(L, va, c[kk], B, o); break;
-            case 1: win_step<1, 2, W, AR>(L, va, c[kk], B, o); break;
-            default: win_step<2, 2, W, AR>(L, va, c[kk], B, o); break;
+          switch (i) { // slot i keeps this step: parity i & 1
+            case 0: win_step<0, 2, W, AR, 0>(L, va, c[kk], B, o); break;
+            case 1: win_step<1, 2, W, AR, 1>(L, va, c[kk], B, o); break;
+            case 2: win_step<2, 2, W, AR, 0>(L, va, c[kk], B, o); break;
+            case 3: win_step<0, 2, W, AR, 1>(L, va, c[kk], B, o); break;
+            case 4: win_step<1, 2, W, AR, 0>(L, va, c[kk], B, o); break;
+            default: win_step<2, 2, W, AR, 1>(L, va, c[kk], B, o); break;
           }
           keep = L.p == i ? o : keep;
           if ((AR || (kk & 1) == 0) && (kk != 0 || k0 != 0)) win_normalize<AR>(va);
@@ -528,8 +572,9 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
         const pk_t Btop = bh[top * 64 + L.lane];
         pk_t       vb   = Btop, dummy = 0;
         for (int i = t - 1; i >= 1; i--) {
-          const int2 in2 = my[k0 + i];
-          switch ((k0 + i) % 3) {
+          const int  ph  = (k0 + i) % 3;
+          const pk_t in2 = my[(k0 + i) * 4 + (ph == 0 ? L.io[0] : (ph == 1 ? L.io[1] : L.io[2]))];
+          switch (ph) {
             case 0: win_step<0, 0, W, AR>(L, vb, in2, 0, dummy); break;
             case 1: win_step<1, 0, W, AR>(L, vb, in2, 0, dummy); break;
             default: win_step<2, 0, W, AR>(L, vb, in2, 0, dummy); break;
@@ -538,10 +583,11 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
           if (AR || ((k0 + i) & 1) == 0) win_normalize<AR>(vb);
         }
         for (int i = 0; i < t; i++) {
-          const int2 in2 = my[k0 + i];
+          const int  ph  = (k0 + i) % 3;
+          const pk_t in2 = my[(k0 + i) * 4 + (ph == 0 ? L.io[0] : (ph == 1 ? L.io[1] : L.io[2]))];
           const pk_t B   = i == t - 1 ? Btop : seg[(i + 1) * 64 + L.lane];
           pk_t       o   = 0;
-          switch ((k0 + i) % 3) {
+          switch (ph) {
             case 0: win_step<0, 2, W, AR>(L, va, in2, B, o); break;
             case 1: win_step<1, 2, W, AR>(L, va, in2, B, o); break;
             default: win_step<2, 2, W, AR>(L, va, in2, B, o); break;
@@ -562,9 +608,13 @@ __device__ __forceinline__ int win_pos(int n, int K)
   return (n % Lw) * W + n / Lw;
 }
 
+#ifndef TDEC_WAVES
+#define TDEC_WAVES 2
+#endif
+#define TDEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TDEC_WAVES, TDEC_WAVES)))
 // AR = 1: int8 LLRs in (a.in is an int8 array), the work arrays hold int8 values in int16 containers
 template <int W, int AR>
-__global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
+__global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a)
 {
   using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
   const int      cb = blockIdx.x, K = (int)a.K;
@@ -573,9 +623,11 @@ __global__ __launch_bounds__(64) void tdec_win_kernel(TdecArgs a)
   int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
-  __shared__ pk_t beta[(SRSLTE_HIP_MAX_K / 8 / CKPT + 2) * 64]; // beta checkpoints (lane-private columns)
+  // beta checkpoints (lane-private columns): ceil(Lw / CKPT) + 1 rows per half; Lw <= MAX_K / W (two halves for W = 32)
+  constexpr int BETA_ROWS = (W == 32 ? 2 : 1) * (SRSLTE_HIP_MAX_K / W / CKPT + 2);
+  __shared__ pk_t beta[BETA_ROWS * 64];
   __shared__ pk_t seg[(CKPT + 1) * 64];                          // beta metrics of the segment being consumed
-  int2*           xy = a.xy + (size_t)cb * a.K;
+  int4*           xy = a.xy + (size_t)cb * a.K;
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91); tails live at [K..K+2]
   const int tb = a.sb_layout ? 3 * (K + 32) : 3 * K;
@@ -830,7 +882,7 @@ struct srslte_hip_tdec {
   uint32_t                 max_long_cb, max_nof_cb, Kp;
   int16_t*                 d_work;
   pk_t*                    d_beta;
-  int2*                    d_xy;
+  int4*                    d_xy;
   int16_t*                 d_conv; // widened LLRs of the 8-bit API's 16-bit fall-backs, allocated on first use
   uint32_t                 beta_stride;
   std::map<TabKey, TabDev> tabs;
@@ -874,7 +926,7 @@ extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint3
   const size_t gen_words  = (size_t)((max_nof_cb + 7) / 8) * (max_long_cb + 8) * 64;
   if (hipMalloc((void**)&q->d_work, (size_t)max_nof_cb * 7 * q->Kp * sizeof(int16_t)) != hipSuccess ||
       hipMalloc((void**)&q->d_beta, sizeof(pk_t) * (beta_words > gen_words ? beta_words : gen_words)) != hipSuccess ||
-      hipMalloc((void**)&q->d_xy, sizeof(int2) * (size_t)max_nof_cb * max_long_cb) != hipSuccess) {
+      hipMalloc((void**)&q->d_xy, sizeof(int4) * (size_t)max_nof_cb * max_long_cb) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] tdec: device allocation failed\n");
     if (q->d_work) (void)hipFree(q->d_work);
     delete q;
