@@ -247,7 +247,7 @@ def main():
     pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc", "final_traffic.json")
     if os.path.exists(pmc) and B == 128 and not args.llr8:
         with open(pmc) as f:
-            traffic = json.load(f)["kernels"].get("tdec_win_kernel<16>", {})  # name of the kernel before it gained its arithmetic template argument.get("traffic_bytes")
+            traffic = json.load(f)["kernels"].get("tdec_win_kernel<16, 0>", {}).get("traffic_bytes")
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
