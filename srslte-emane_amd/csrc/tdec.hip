@@ -439,6 +439,16 @@ __device__ __forceinline__ void batched(int lane, int n, Ld ld, St st)
   }
 }
 struct I3 { int a, b, c; };
+// Eight consecutive int16 elements per lane and memory instruction (the CU issues one wavefront memory instruction per four
+// cycles: the element-wise phases are bound by their number, not by bytes)
+typedef short          v8s __attribute__((ext_vector_type(8)));
+typedef unsigned short v8u __attribute__((ext_vector_type(8)));
+typedef unsigned int   v4w __attribute__((ext_vector_type(4)));
+struct V8x3 { v8s a, b; v8u c; };
+struct V8W { v8s a; v4w t0, t1; };
+__device__ __forceinline__ v8s ld8(const int16_t* p, int i8) { return *reinterpret_cast<const v8s*>(p + 8 * i8); }
+__device__ __forceinline__ v8u ld8u(const uint16_t* p, int i8) { return *reinterpret_cast<const v8u*>(p + 8 * i8); }
+__device__ __forceinline__ void st8(int16_t* p, int i8, v8s v) { *reinterpret_cast<v8s*>(p + 8 * i8) = v; }
 
 // One SISO pass over W windows. W = 8/16 (AR = 0: sse16/avx16; AR = 1, W = 16: sse8): one pass of the wave over its 8 window
 // pairs. W = 32 (avx8): the wave handles the windows as NH = 2 halves of 16, one after the other in every phase - the windows
@@ -464,14 +474,32 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   pk_t *         XY = scratch, *Xb = scratch + NE, *Yb = scratch + 2 * NE;
   const pk_t*    Xs = DIRECT && !app ? reinterpret_cast<const pk_t*>(in) : Xb;
   const pk_t*    Ys = DIRECT ? reinterpret_cast<const pk_t*>(par) : Yb;
-  batched<8>(
-      L.lane, NE, [&](int i) { return I3{ld_pair<W, AR>(in, i), app ? ld_pair<W, AR>(app, i) : 0, ld_pair<W, AR>(par, i)}; },
-      [&](int i, I3 t) {
-        const pk_t x = app ? s_add<AR>(t.b, t.a) : t.a;
-        if (!DIRECT || app) Xb[i] = x;
-        if (!DIRECT) Yb[i] = t.c;
-        XY[i] = pk_add<true>(x, t.c); // AR: a 0x7fff in x + y is harmless (see M8)
-      });
+  if constexpr (W == 8) {
+    batched<8>(
+        L.lane, NE, [&](int i) { return I3{ld_pair<W, AR>(in, i), app ? ld_pair<W, AR>(app, i) : 0, ld_pair<W, AR>(par, i)}; },
+        [&](int i, I3 t) {
+          const pk_t x = app ? s_add<AR>(t.b, t.a) : t.a;
+          Xb[i]        = x;
+          Yb[i]        = t.c;
+          XY[i]        = pk_add<true>(x, t.c);
+        });
+  } else { // four window pairs (16 bytes) per lane and memory instruction; NE is a multiple of 4
+    struct Q3 { int4 a, b, c; };
+    auto hi8 = [](int4 v) { // AR: int8 values in int16 containers -> high bytes (see ld_pair)
+      return AR ? make_int4((v.x & 0x00FF00FF) << 8, (v.y & 0x00FF00FF) << 8, (v.z & 0x00FF00FF) << 8, (v.w & 0x00FF00FF) << 8) : v;
+    };
+    const int4 *in4 = reinterpret_cast<const int4*>(in), *app4 = reinterpret_cast<const int4*>(app), *par4 = reinterpret_cast<const int4*>(par);
+    int4 *      X4 = reinterpret_cast<int4*>(Xb), *Y4 = reinterpret_cast<int4*>(Yb), *XY4 = reinterpret_cast<int4*>(XY);
+    batched<2>(
+        L.lane, NE / 4, [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), hi8(par4[i])}; },
+        [&](int i, Q3 t) {
+          const int4 x = app ? make_int4(s_add<AR>(t.b.x, t.a.x), s_add<AR>(t.b.y, t.a.y), s_add<AR>(t.b.z, t.a.z), s_add<AR>(t.b.w, t.a.w)) : t.a;
+          if (!DIRECT || app) X4[i] = x;
+          if (!DIRECT) Y4[i] = t.c;
+          // AR: a 0x7fff in x + y is harmless (see M8)
+          XY4[i] = make_int4(pk_add<true>(x.x, t.c.x), pk_add<true>(x.y, t.c.y), pk_add<true>(x.z, t.c.z), pk_add<true>(x.w, t.c.w));
+        });
+  }
   __syncthreads();
   Src S[NH];
 #pragma unroll
@@ -735,48 +763,68 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   // srslte_vec_sub_sss: wrapping int16. srslte_vec_sub_bbb (vector_simd.c:158-185, AVX2 build, aligned buffers): saturating
   // int8 in the 32-wide body, wrapping in the scalar tail
   const int sat_body = K / 32 * 32;
-  auto      vsub     = [&](int i, int x, int y) -> int16_t {
+  auto      vsub8    = [&](int i8, v8s x, v8s y) -> v8s { // eight elements starting at 8 * i8
     if constexpr (AR) {
-      const int d = x - y;
-      return (int16_t)(i < sat_body ? max(-128, min(127, d)) : (int)(signed char)d);
+      v8s r;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const int d = (int)x[e] - (int)y[e];
+        r[e]        = (short)(8 * i8 + e < sat_body ? max(-128, min(127, d)) : (int)(signed char)d);
+      }
+      return r;
     } else {
-      return (int16_t)(x - y);
+      return x - y; // wrapping, v_pk_sub_i16
     }
   };
+  const int K8 = K / 8;
   uint32_t       n_iter = 0;
   bool           ok     = false;
   const int16_t* dec    = ext1;
   while (n_iter < a.nof_iter && !ok) {
     if ((n_iter & 1) == 0) {
       if (n_iter) {
-        batched<8>(
-            L.lane, K, [&](int i) { return I3{app1[i], ext1[i], 0}; }, [&](int i, I3 t) { app1[i] = vsub(i, t.a, t.b); });
+        batched<2>(
+            L.lane, K8, [&](int i8) { return V8x3{ld8(app1, i8), ld8(ext1, i8), v8u{}}; },
+            [&](int i8, V8x3 t) { st8(app1, i8, vsub8(i8, t.a, t.b)); });
         __syncthreads();
       }
       if (!(a.dbg & 1)) win_siso<W, AR>(L, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, beta, seg, xy, st, K);
       dec = ext1;
     } else {
       const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
-      batched<8>(
-          L.lane, K, [&](int i) { return I3{ext1[i], sub ? app1[i] : 0, (a.dbg & 4) ? i : (int)a.t.deinter[i]}; },
-          [&](int i, I3 t) {
-            const int16_t e = sub ? vsub(i, t.a, t.b) : (int16_t)t.a;
-            if (sub) ext1[i] = e;
-            app2[t.c] = e;
+      batched<2>(
+          L.lane, K8, [&](int i8) { return V8x3{ld8(ext1, i8), sub ? ld8(app1, i8) : v8s{}, ld8u(a.t.deinter, i8)}; },
+          [&](int i8, V8x3 t) {
+            const v8s e = sub ? vsub8(i8, t.a, t.b) : t.a;
+            if (sub) st8(ext1, i8, e);
+#pragma unroll
+            for (int j = 0; j < 8; j++) app2[t.c[j]] = e[j];
           });
       __syncthreads();
       if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K);
       __syncthreads();
-      batched<8>(
-          L.lane, K, [&](int i) { return I3{ext2[i], (a.dbg & 4) ? i : (int)a.t.inter[i], 0}; }, [&](int i, I3 t) { app1[t.b] = (int16_t)t.a; });
+      batched<2>(
+          L.lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
+          [&](int i8, V8x3 t) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) app1[t.c[j]] = t.a[j];
+          });
       dec = app1;
     }
     __syncthreads();
     n_iter++;
     if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
       uint32_t syn = 0;
-      batched<8>(
-          L.lane, K, [&](int i) { return I3{dec[i], (int)a.t.crc_rem[i], 0}; }, [&](int i, I3 t) { syn ^= t.a > 0 ? (uint32_t)t.b : 0u; });
+      batched<2>(
+          L.lane, K8,
+          [&](int i8) {
+            const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
+            return V8W{ld8(dec, i8), tp[0], tp[1]};
+          },
+          [&](int i8, V8W t) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) syn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+          });
       for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
       ok = syn == 0 && !(a.dbg & (1 | 16)); // 16: never stop early (timing experiments at a fixed pass count)
     }
