@@ -167,6 +167,34 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
   }
 }
 
+// Same result from the per-block syndrome shares the windowed turbo decoders emit (tdec_set_tb_syndrome): the CRC is linear,
+// so the TB syndrome is the XOR of the C shares; what is left is the payload copy.
+__global__ __launch_bounds__(256) void tb_asm_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok,
+                                                     const uint32_t* __restrict__ cb_syn, uint8_t* __restrict__ tb, uint8_t* __restrict__ tb_ok,
+                                                     TbGeom g)
+{
+  const int sf = blockIdx.x, nbytes = g.tbs / 8 + 3, rb = g.rlen / 8;
+  uint8_t*  dst = tb + (size_t)sf * g.tb_stride;
+  auto      src = [&](int b) -> uint8_t {
+    int cb = b / rb;
+    if (cb > g.C - 1) cb = g.C - 1;
+    const int off = b - cb * rb;
+    return off < g.K / 8 ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : (uint8_t)0;
+  };
+  for (int b = threadIdx.x; b < nbytes + 3; b += blockDim.x) dst[b] = src(b);
+  if (threadIdx.x == 0) {
+    uint32_t syn = 0;
+    bool     ok  = true;
+    for (int c = 0; c < g.C; c++) {
+      syn ^= cb_syn[sf * g.C + c];
+      ok = ok && cb_ok[sf * g.C + c];
+    }
+    // par_rx == par_tx && par_rx != 0 (sch.c:481): a zero parity with zero syndrome is rejected upstream
+    ok        = ok && syn == 0 && (src(g.tbs / 8) | src(g.tbs / 8 + 1) | src(g.tbs / 8 + 2));
+    tb_ok[sf] = ok ? 1 : 0;
+  }
+}
+
 // pdsch.c:81-206 as a per-RE rule (see oracle/orc_pdsch.c for the derivation): symbol-major, sub-carrier ascending,
 // skipping CRS, and the central 72 sub-carriers of the PSS/SSS symbols (slot 0, l >= 5, sf 0/5) and PBCH symbols (slot 1, l < 4, sf 0)
 void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t sf_idx, uint32_t lstart, std::vector<uint32_t>& idx)
@@ -216,6 +244,7 @@ struct srslte_hip_dl_rx {
   int16_t *              d_e, *d_w;
   uint8_t *              d_cb_bytes, *d_cb_ok;
   uint32_t*              d_cb_iters;
+  uint32_t *             d_tb_rem, *d_cb_syn; // TB CRC shares from the windowed decoders ([C][K] table, [B*C] out); null for W = 0
   const cf32*            grid_in; // resource grids supplied by the caller (srslte_hip_dl_rx_grid_batch) instead of d_grid
 };
 
@@ -226,7 +255,7 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   srslte_hip_chest_dl_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_idx[0], q->d_idx[1], q->d_idx[2], q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_grid, q->d_ce, q->d_d,
-                  q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters};
+                  q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters, q->d_tb_rem, q->d_cb_syn};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -301,6 +330,17 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
       if (v & 0x1000000) v ^= 0x1864CFB;
     }
     ok = upload(&q->d_tbcrc, rem) == SRSLTE_SUCCESS;
+    if (ok && q->W) { // per code block, in the decoder's array order (window-interleaved); 0 on the CB CRC bits
+      const uint32_t        rlen = C == 1 ? K : K - 24, Lw = K / q->W;
+      std::vector<uint32_t> t((size_t)C * K, 0);
+      for (uint32_t c = 0; c < C; c++) {
+        for (uint32_t n = 0; n < rlen; n++) {
+          const uint32_t pos = c * rlen + n;
+          if (pos < cfg->tbs + 24) t[(size_t)c * K + (n % Lw) * q->W + n / Lw] = rem[pos];
+        }
+      }
+      ok = upload(&q->d_tb_rem, t) == SRSLTE_SUCCESS && hipMalloc((void**)&q->d_cb_syn, sizeof(uint32_t) * B * C) == hipSuccess;
+    }
   }
   const size_t glen = (size_t)14 * nre;
   ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess &&
@@ -386,14 +426,20 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       return SRSLTE_SUCCESS;
     }
     case 4:
+      tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
       return tdec_run_batch_w(q->tdec, q->d_w, q->cfg.llr_8bit ? 1 : 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
                               C > 1 ? 0x1800063u : 0x1864CFBu, C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
     case 5: {
       if (!d_tb || !d_tb_ok || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
       TbGeom g    = q->tg;
       g.tb_stride = (int)tb_stride;
-      hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
-                         (const uint32_t*)q->d_tbcrc, d_tb, d_tb_ok, g);
+      if (q->d_tb_rem) {
+        hipLaunchKernelGGL(tb_asm_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+                           (const uint32_t*)q->d_cb_syn, d_tb, d_tb_ok, g);
+      } else {
+        hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+                           (const uint32_t*)q->d_tbcrc, d_tb, d_tb_ok, g);
+      }
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;
     }

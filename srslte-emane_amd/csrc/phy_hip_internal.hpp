@@ -28,6 +28,9 @@ int  lte_cb_index(uint32_t K);
 void lte_qpp_tables(uint32_t K, uint32_t W, std::vector<uint16_t>& fwd, std::vector<uint16_t>& rev);
 void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); // circular-buffer order -> 3*i+s
 
+// tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).
+// d_rem: [C][K] words, x^(tbs+24-1-position in the TB) mod g for the block's payload bits in the decoder's array order, 0 elsewhere
+void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);
 // tdec.hip: srslte_hip_tdec_run_batch with an optional forced back-end (force_w = -1 auto, 0 generic, 8, 16, 32 with llr8);
 // llr8: d_input is int8 and the 8-bit numerics / fall-backs of turbodecoder.c:438-487 apply
 int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,

@@ -31,6 +31,9 @@ namespace {
 typedef short v2s __attribute__((ext_vector_type(2)));
 typedef int   pk_t; // two int16 lanes: lo = first window of the pair, hi = second
 
+#ifndef TDEC_EWU
+#define TDEC_EWU 4 // 16-byte elements in flight per lane in the element-wise phases
+#endif
 constexpr int TD_INF      = 10000;
 constexpr int SRSLTE_HIP_MAX_K = 6144;
 constexpr int WIN_OVERLAP = 40;
@@ -201,6 +204,9 @@ struct TdecArgs {
   uint32_t*      iters;
   uint8_t*       crc_ok;
   TdecTables     t;
+  const uint32_t* tb_rem;      // optional [tb_C][K] remainders for the TB CRC share of each block (array order), else nullptr
+  uint32_t        tb_C;
+  uint32_t*       tb_syn;      // [nof_cb] out
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
 };
@@ -490,7 +496,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     };
     const int4 *in4 = reinterpret_cast<const int4*>(in), *app4 = reinterpret_cast<const int4*>(app), *par4 = reinterpret_cast<const int4*>(par);
     int4 *      X4 = reinterpret_cast<int4*>(Xb), *Y4 = reinterpret_cast<int4*>(Yb), *XY4 = reinterpret_cast<int4*>(XY);
-    batched<2>(
+    batched<TDEC_EWU>(
         L.lane, NE / 4, [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), hi8(par4[i])}; },
         [&](int i, Q3 t) {
           const int4 x = app ? make_int4(s_add<AR>(t.b.x, t.a.x), s_add<AR>(t.b.y, t.a.y), s_add<AR>(t.b.z, t.a.z), s_add<AR>(t.b.w, t.a.w)) : t.a;
@@ -777,13 +783,14 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
     }
   };
   const int K8 = K / 8;
+  constexpr int EWU = TDEC_EWU; // 16-byte elements in flight per lane in the element-wise phases
   uint32_t       n_iter = 0;
   bool           ok     = false;
   const int16_t* dec    = ext1;
   while (n_iter < a.nof_iter && !ok) {
     if ((n_iter & 1) == 0) {
       if (n_iter) {
-        batched<2>(
+        batched<EWU>(
             L.lane, K8, [&](int i8) { return V8x3{ld8(app1, i8), ld8(ext1, i8), v8u{}}; },
             [&](int i8, V8x3 t) { st8(app1, i8, vsub8(i8, t.a, t.b)); });
         __syncthreads();
@@ -792,7 +799,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
       dec = ext1;
     } else {
       const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
-      batched<2>(
+      batched<EWU>(
           L.lane, K8, [&](int i8) { return V8x3{ld8(ext1, i8), sub ? ld8(app1, i8) : v8s{}, ld8u(a.t.deinter, i8)}; },
           [&](int i8, V8x3 t) {
             const v8s e = sub ? vsub8(i8, t.a, t.b) : t.a;
@@ -803,7 +810,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
       __syncthreads();
       if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K);
       __syncthreads();
-      batched<2>(
+      batched<EWU>(
           L.lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
           [&](int i8, V8x3 t) {
 #pragma unroll
@@ -815,7 +822,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
     n_iter++;
     if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
       uint32_t syn = 0;
-      batched<2>(
+      batched<EWU>(
           L.lane, K8,
           [&](int i8) {
             const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
@@ -840,9 +847,27 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
         return byte;
       },
       [&](int b, uint32_t byte) { o[b] = (uint8_t)byte; });
+  // ---- this block's share of the transport-block CRC24A syndrome (sch.c:470-488): XOR over its set payload bits of
+  //      x^(position in the TB) mod g, from a table in the decoder's array order; the TB check then is an XOR of C words
+  uint32_t tsyn = 0;
+  if (a.tb_rem) {
+    const uint32_t* tab = a.tb_rem + (size_t)(cb % a.tb_C) * K;
+    batched<TDEC_EWU>(
+        L.lane, K / 8,
+        [&](int i8) {
+          const v4w* tp = reinterpret_cast<const v4w*>(tab + 8 * i8);
+          return V8W{ld8(dec, i8), tp[0], tp[1]};
+        },
+        [&](int i8, V8W t) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) tsyn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+        });
+    for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
+  }
   if (L.lane == 0) {
     if (a.iters) a.iters[cb] = n_iter;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
+    if (a.tb_rem) a.tb_syn[cb] = tsyn;
   }
 }
 
@@ -1010,6 +1035,9 @@ struct srslte_hip_tdec {
   int16_t*                 d_conv; // widened LLRs of the 8-bit API's 16-bit fall-backs, allocated on first use
   uint32_t                 beta_stride;
   std::map<TabKey, TabDev> tabs;
+  const uint32_t*          tb_rem = nullptr; // see tdec_set_tb_syndrome
+  uint32_t                 tb_C   = 0;
+  uint32_t*                tb_syn = nullptr;
   std::mutex               mtx;
 };
 
@@ -1114,6 +1142,13 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
   return SRSLTE_SUCCESS;
 }
 
+void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn)
+{ // windowed decoders only; the caller (pdsch.hip) builds d_rem in the decoder's array order
+  q->tb_rem = d_rem;
+  q->tb_C   = C;
+  q->tb_syn = d_syn;
+}
+
 int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,
                      uint32_t nof_cb, uint32_t nof_iterations, uint32_t crc_poly, uint32_t crc_nbits, uint8_t* d_output,
                      uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st)
@@ -1156,6 +1191,7 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy; a.zeros = q->d_zeros;
   a.dbg = getenv("SRSLTE_HIP_TDEC_DBG") ? atoi(getenv("SRSLTE_HIP_TDEC_DBG")) : 0;
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
+  a.tb_rem = W ? q->tb_rem : nullptr; a.tb_C = q->tb_C ? q->tb_C : 1; a.tb_syn = q->tb_syn;
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
   if (ar8 && W == 32) {
