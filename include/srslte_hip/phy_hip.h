@@ -87,6 +87,13 @@ void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
 const void*            srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q); /* device CRS table [10][4][2*prb] (refsignal_dl.c:66-116) */
 int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                        void* d_ce, void* d_res, int nof_sf, void* stream);
+/* nof_rx receive antennas, one port (chest_dl.c:884-908 loops over antennas; fill_res :747-871 averages noise, RSSI and RSRQ over
+ * them): d_grid / d_ce are [nof_sf][nof_rx][14][12*nof_prb], d_res stays one entry per subframe */
+int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
+                                             void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream);
+/* device pointer to [nof_sf][nof_rx] x {noise_estimate, rsrp, rssi, cfo} of the last multi-antenna call (nof_rx > 1): the
+ * per-antenna terms of fill_res (chest_dl.c:860-870) */
+const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
 
 /* ------------------------------------------------------------------ soft demapper (replaces srslte_demod_soft_demodulate{,_s,_b},
  * modem/demod_soft.h:39-53, demod_soft.c:479-549). mod: 0 BPSK, 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM (srslte_mod_t).
@@ -160,6 +167,8 @@ typedef struct {
   srslte_hip_chest_dl_cfg_t chest_cfg;
   int      llr_8bit;       /* 1: the 8-bit LLR path the applications select (q->llr_is_8bit: pdsch.c:760-779 demod_b + int8
                               descrambling, sch.c:336-356 srslte_rm_turbo_rx_lut_8bit + srslte_tdec_iteration_8bit) */
+  uint32_t nof_rx_antennas; /* 0 or 1: one antenna; 2..4: per-antenna estimation + srslte_predecoding_single_multi (precoding.c:325-348,
+                               pdsch.c:890-935); d_iq / d_grid are then [nof_sf][nof_rx][...] */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);

@@ -123,6 +123,8 @@ typedef struct {
 /* single rx antenna, single port (port 0) — chest_dl.c:598-716, 845-908 */
 int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce,
                  orc_chest_res_t* res);
+int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                       orc_cf_t* const* ce, orc_chest_res_t* res); /* nof_rx receive antennas, one port */
 
 /* ---------------------------------------------------------------- modem */
 enum { ORC_MOD_BPSK = 0, ORC_MOD_QPSK, ORC_MOD_16QAM, ORC_MOD_64QAM, ORC_MOD_256QAM };
@@ -135,6 +137,8 @@ int orc_demod_soft_b(int mod, const orc_cf_t* sym, int8_t* llr, int nsym);
 /* ---------------------------------------------------------------- PDSCH glue (N1) */
 /* precoding.c:238-249,293-322 single-port one-tap equaliser */
 void orc_predecoding_single(const orc_cf_t* y, const orc_cf_t* h, orc_cf_t* x, int nsym, float scaling, float noise_estimate);
+void orc_predecoding_single_multi(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x, int nof_rx, int nsym, float scaling,
+                                  float noise_estimate); /* precoding.c:138-262,:325-348 */
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
 int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx);
 int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms,

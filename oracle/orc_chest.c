@@ -94,7 +94,8 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
   free(diff);
 }
 
-int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, orc_chest_res_t* res)
+/* estimate_port for port 0 of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo} of that antenna */
+static int chest_port0(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, float raw[4])
 {
   const uint32_t port = 0, P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
@@ -210,19 +211,54 @@ int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t*
     }
   }
 
-  if (res) { /* fill_res, chest_dl.c:845-871 (1 rx, 1 port) */
-    memset(res, 0, sizeof(*res));
-    res->noise_estimate     = noise;
-    res->noise_estimate_dbm = (float)(10 * log10(noise) + 30);
-    res->cfo                = cfo;
-    res->rsrp               = rsrp;
-    res->rsrp_dbm           = (float)(10 * log10(rsrp) + 30);
-    res->rsrq               = P * rsrp / rssi;
-    res->rsrq_db            = (float)(10 * log10(res->rsrq));
-    res->snr_db             = (float)(10 * log10(rsrp / noise));
-    res->rssi_dbm           = (float)(10 * log10(4 * rssi / P / 12) + 30);
-    res->sync_error         = NAN;
-  }
+  raw[0] = noise; raw[1] = rsrp; raw[2] = rssi; raw[3] = cfo;
   free(known); free(recv); free(est); free(avg); free(tmp);
+  return 0;
+}
+
+static void fill_res(uint32_t P, uint32_t nof_rx, float raw[][4], orc_chest_res_t* res)
+{ /* chest_dl.c:747-871 for one port: noise, RSSI and RSRQ are averaged over the receive antennas; get_rsrp (:809-819) takes the
+     maximum over "ports" indexed by the antenna counter, i.e. max(mean over antennas of port 0, 0 for every never-estimated port) */
+  float noise = 0, rssi = 0, rsrq = 0, rsrp0 = 0;
+  for (uint32_t a = 0; a < nof_rx; a++) {
+    noise += raw[a][0] / 1; /* srslte_vec_acc_ff(noise_estimate[a], nof_ports) / nof_ports with one port */
+    rssi += 4 * raw[a][2] / P / 12;
+    rsrq += P * raw[a][1] / raw[a][2];
+    rsrp0 += raw[a][1];
+  }
+  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx; rsrp0 /= nof_rx;
+  float rsrp = rsrp0;
+  if (nof_rx > 1 && rsrp < 0.0f) rsrp = 0.0f;
+  memset(res, 0, sizeof(*res));
+  res->noise_estimate     = noise;
+  res->noise_estimate_dbm = (float)(10 * log10(noise) + 30);
+  res->cfo                = raw[0][3];
+  res->rsrp               = rsrp;
+  res->rsrp_dbm           = (float)(10 * log10(rsrp) + 30);
+  res->rsrq               = rsrq;
+  res->rsrq_db            = (float)(10 * log10(rsrq));
+  res->snr_db             = (float)(10 * log10(rsrp / noise));
+  res->rssi_dbm           = (float)(10 * log10(rssi) + 30);
+  res->sync_error         = NAN;
+}
+
+int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, orc_chest_res_t* res)
+{
+  float raw[1][4];
+  int   r = chest_port0(cell, sf_idx, cfg, grid, ce, raw[0]);
+  if (r == 0 && res) fill_res(cell->nof_prb, 1, raw, res);
+  return r;
+}
+
+int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                       orc_cf_t* const* ce, orc_chest_res_t* res)
+{ /* srslte_chest_dl_estimate_cfg with nof_rx_antennas receive antennas, one port (chest_dl.c:884-908) */
+  float raw[4][4];
+  if (nof_rx < 1 || nof_rx > 4) return -1;
+  for (uint32_t a = 0; a < nof_rx; a++) {
+    int r = chest_port0(cell, sf_idx, cfg, grid[a], ce ? ce[a] : NULL, raw[a]);
+    if (r) return r;
+  }
+  if (res) fill_res(cell->nof_prb, nof_rx, raw, res);
   return 0;
 }

@@ -60,6 +60,24 @@ void orc_predecoding_single(const orc_cf_t* y, const orc_cf_t* h, orc_cf_t* x, i
   }
 }
 
+void orc_predecoding_single_multi(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x, int nof_rx, int nsym, float scaling,
+                                  float noise_estimate)
+{ /* srslte_predecoding_single_multi (precoding.c:138-262): maximum-ratio combining, exact division in every code path */
+  for (int i = 0; i < nsym; i++) {
+    float re = 0, im = 0, hh = 0;
+    for (int p = 0; p < nof_rx; p++) {
+      const orc_cf_t Y = y[p][i], H = h[p][i];
+      float pr = Y.re * H.re + Y.im * H.im, pi = Y.im * H.re - Y.re * H.im, ph = H.re * H.re + H.im * H.im;
+      re = p ? re + pr : pr;
+      im = p ? im + pi : pi;
+      hh = p ? hh + ph : ph;
+    }
+    if (noise_estimate > 0) hh += noise_estimate;
+    x[i].re = re / hh * (1 / scaling);
+    x[i].im = im / hh * (1 / scaling);
+  }
+}
+
 void orc_scramble_s(int16_t* llr, const uint8_t* c, int len)
 { /* scrambling.c:45-48 -> srslte_vec_neg_sss: negate where c_short = 1-2c is negative */
   for (int i = 0; i < len; i++) {

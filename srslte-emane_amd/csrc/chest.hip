@@ -23,7 +23,9 @@ struct ChestParams {
   int   noise_alg, filter_type, interpolate_subframe, cfo_enable;
   float coef0, coef1;
   int   symbol_sz, cp1; // for CFO
+  int   nof_rx;         // receive antennas: block v handles subframe v / nof_rx, antenna v % nof_rx ([sf][rx][grid] layouts)
 };
+struct ChestRaw { float noise, rsrp, rssi, cfo; }; // per (subframe, antenna), combined by chest_fill_res_kernel
 
 struct ChestResDev { // mirrors the scalar tail of srslte_chest_dl_res_t (chest_dl.h:49-67) for 1 port / 1 antenna
   float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
@@ -83,7 +85,8 @@ __device__ __forceinline__ cf32 interp_offset_at(const cf32* in, int L, int M, i
 }
 
 __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __restrict__ grid, cf32* __restrict__ ce,
-                                                             ChestResDev* __restrict__ res, const cf32* __restrict__ pilots,
+                                                             ChestResDev* __restrict__ res, ChestRaw* __restrict__ raw,
+                                                             const cf32* __restrict__ pilots,
                                                              ChestParams p)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   __shared__ float red[CH_THREADS / 64];
   __shared__ float filt[64];
 
-  const int   sf     = blockIdx.x, sf_idx = (p.tti0 + sf) % 10, tid = threadIdx.x;
+  const int   sf     = blockIdx.x, sf_idx = (p.tti0 + sf / p.nof_rx) % 10, tid = threadIdx.x; // sf: (subframe, antenna) index
   const cf32* g      = grid + (size_t)sf * 14 * nre;
   const cf32* known  = pilots + (size_t)sf_idx * npil;
 
@@ -235,7 +238,8 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     }
   }
 
-  if (tid == 0 && res) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
+  if (tid == 0 && raw) raw[sf] = ChestRaw{noise, rsrp, rssi, cfo};
+  if (tid == 0 && res && p.nof_rx == 1) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
     ChestResDev r;
     r.noise_estimate     = noise;
     r.noise_estimate_dbm = (float)(10 * log10((double)noise) + 30);
@@ -249,6 +253,36 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     r.sync_error         = NAN;
     res[sf]              = r;
   }
+}
+
+// fill_res (chest_dl.c:747-871) for nof_rx > 1, one port: noise, RSSI and RSRQ averaged over the antennas; get_rsrp (:809-819)
+// indexes ports with the antenna counter, so it is max(mean RSRP of port 0, 0); CFO of antenna 0
+__global__ void chest_fill_res_kernel(const ChestRaw* __restrict__ raw, ChestResDev* __restrict__ res, int nof_sf, int nof_rx, int P)
+{
+  const int sf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sf >= nof_sf) return;
+  float noise = 0, rssi = 0, rsrq = 0, rsrp = 0;
+  for (int a = 0; a < nof_rx; a++) {
+    const ChestRaw r = raw[sf * nof_rx + a];
+    noise += r.noise;
+    rssi += 4 * r.rssi / P / 12;
+    rsrq += P * r.rsrp / r.rssi;
+    rsrp += r.rsrp;
+  }
+  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx; rsrp /= nof_rx;
+  if (rsrp < 0.f) rsrp = 0.f;
+  ChestResDev o;
+  o.noise_estimate     = noise;
+  o.noise_estimate_dbm = (float)(10 * log10((double)noise) + 30);
+  o.cfo                = raw[sf * nof_rx].cfo;
+  o.rsrp               = rsrp;
+  o.rsrp_dbm           = (float)(10 * log10((double)rsrp) + 30);
+  o.rsrq               = rsrq;
+  o.rsrq_db            = (float)(10 * log10((double)rsrq));
+  o.snr_db             = (float)(10 * log10((double)(rsrp / noise)));
+  o.rssi_dbm           = (float)(10 * log10((double)rssi) + 30);
+  o.sync_error         = NAN;
+  res[sf]              = o;
 }
 
 // Gold sequence (sequence.c:48-79) and CRS values (refsignal_dl.c:66-116) — init-time host tables.
@@ -271,8 +305,10 @@ void gold(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c)
 void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) { gold(c_init, len, c); }
 
 struct srslte_hip_chest_dl {
-  int   cell_id, nof_prb;
-  cf32* d_pilots; // [10][4][2*nof_prb], port 0
+  int       cell_id, nof_prb;
+  cf32*     d_pilots; // [10][4][2*nof_prb], port 0
+  ChestRaw* d_raw;    // per (subframe, antenna) scalars of multi-antenna calls, grown on demand
+  size_t    raw_cap;
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
@@ -301,6 +337,8 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   q->cell_id  = cell_id;
   q->nof_prb  = nof_prb;
   q->d_pilots = nullptr;
+  q->d_raw    = nullptr;
+  q->raw_cap  = 0;
   if (hipMalloc((void**)&q->d_pilots, sizeof(cf32) * pil.size()) != hipSuccess ||
       hipMemcpy(q->d_pilots, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] chest_dl: device allocation failed\n");
@@ -314,17 +352,18 @@ extern "C" void srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q)
 {
   if (!q) return;
   if (q->d_pilots) (void)hipFree(q->d_pilots);
+  if (q->d_raw) (void)hipFree(q->d_raw);
   delete q;
 }
 
 extern "C" const void* srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q) { return q ? q->d_pilots : nullptr; }
 
-// d_grid: [nof_sf][14][12*prb]; d_ce: same shape or NULL (measurements only); d_res: [nof_sf] srslte_hip_chest_res_t or NULL.
+// d_grid: [nof_sf][nof_rx][14][12*prb]; d_ce: same shape or NULL (measurements only); d_res: [nof_sf] srslte_hip_chest_res_t or NULL.
 // Subframe b of the batch is TTI tti0 + b (sf_idx = TTI mod 10).
-extern "C" int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
-                                                  const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
+                                                        const void* d_grid, void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream)
 {
-  if (!q || !cfg || !d_grid || nof_sf < 0) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->noise_alg != 0) {
     fprintf(stderr, "[srslte_hip] chest_dl: only SRSLTE_NOISE_ALG_REFS is implemented on device\n");
     return SRSLTE_ERROR;
@@ -338,10 +377,37 @@ extern "C" int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, cons
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
   p.symbol_sz = lte_symbol_sz(q->nof_prb);
   p.cp1 = lte_cp_len_norm(1, p.symbol_sz);
+  p.nof_rx = nof_rx;
+  ChestRaw* raw = nullptr;
+  if (nof_rx > 1 && d_res) {
+    const size_t need = (size_t)nof_sf * nof_rx;
+    if (need > q->raw_cap) {
+      if (q->d_raw) (void)hipFree(q->d_raw);
+      q->d_raw = nullptr;
+      HIP_TRY(hipMalloc((void**)&q->d_raw, sizeof(ChestRaw) * need));
+      q->raw_cap = need;
+    }
+    raw = q->d_raw;
+  }
   const int nref = 2 * q->nof_prb, nre = 12 * q->nof_prb;
   size_t lds = sizeof(cf32) * (8 * nref + (cfg->interpolate_subframe ? 4 * nre : 0));
-  hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
-                     (ChestResDev*)d_res, (const cf32*)q->d_pilots, p);
+  hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf * nof_rx), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
+                     (ChestResDev*)d_res, raw, (const cf32*)q->d_pilots, p);
   LAUNCH_CHECK();
+  if (raw) {
+    hipLaunchKernelGGL(chest_fill_res_kernel, dim3((nof_sf + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ChestRaw*)raw,
+                       (ChestResDev*)d_res, nof_sf, nof_rx, q->nof_prb);
+    LAUNCH_CHECK();
+  }
   return SRSLTE_SUCCESS;
+}
+
+// [nof_sf][nof_rx] x {noise, rsrp, rssi, cfo} of the last multi-antenna call with d_res != NULL (device memory owned by q): what
+// the per-antenna fields of srslte_chest_dl_res_t are made of (chest_dl.c:860-870)
+extern "C" const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q) { return q ? (const float*)q->d_raw : nullptr; }
+
+extern "C" int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
+                                                  const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+{
+  return srslte_hip_chest_dl_estimate_batch_multi(q, cfg, tti0, d_grid, d_ce, d_res, nof_sf, 1, stream);
 }

@@ -36,7 +36,7 @@ struct SfClass { // RE list per subframe class: 0 = sf 0 (PSS/SSS+PBCH), 1 = sf 
 struct PdschGeom {
   SfClass cls[3];
   int     grid_len;   // 14 * 12 * nof_prb
-  int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0;
+  int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx;
 };
 
 __device__ __forceinline__ int sf_class(int sf_idx) { return sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2); }
@@ -52,12 +52,27 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   const SfClass c  = g.cls[sf_class(sf_idx)];
   const int     i  = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= c.nof_re) return;
-  const uint32_t k = c.idx[i];
-  const cf32     y = grid[(size_t)sf * g.grid_len + k], h = ce[(size_t)sf * g.grid_len + k];
+  const uint32_t k  = c.idx[i];
   const float    n0 = g.mmse ? res[sf].noise_estimate : 0.f;
-  // precoding.c:277-288 with scaling = 1 (pdsch.c:852-858, power_scale off)
-  const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
-  const cf32  x  = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+  cf32           x;
+  if (g.nof_rx == 1) {
+    const cf32 y = grid[(size_t)sf * g.grid_len + k], h = ce[(size_t)sf * g.grid_len + k];
+    // precoding.c:277-288 with scaling = 1 (pdsch.c:852-858, power_scale off)
+    const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
+    x = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+  } else { // srslte_predecoding_single_multi (precoding.c:138-262): maximum-ratio combining over the receive antennas
+    float re = 0.f, im = 0.f, hh = 0.f;
+    for (int a = 0; a < g.nof_rx; a++) {
+      const size_t o = ((size_t)sf * g.nof_rx + a) * g.grid_len + k;
+      const cf32   y = grid[o], h = ce[o];
+      const float  pr = y.x * h.x + y.y * h.y, pi = y.y * h.x - y.x * h.y, ph = h.x * h.x + h.y * h.y;
+      re = a ? re + pr : pr;
+      im = a ? im + pi : pi;
+      hh = a ? hh + ph : ph;
+    }
+    if (n0 > 0.f) hh += n0;
+    x = make_float2(re / hh * 1.0f, im / hh * 1.0f);
+  }
   if (d_out) d_out[(size_t)sf * g.max_re + i] = x;
   LLR o[8];
   if constexpr (sizeof(LLR) == 1) {
@@ -264,7 +279,7 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
 
 extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0) {
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4) {
     fprintf(stderr, "[srslte_hip] dl_rx: invalid configuration\n");
     return nullptr;
   }
@@ -278,6 +293,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   }
   const uint32_t P = cfg->nof_prb, nre = 12 * P, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod;
   const uint32_t lstart = cfg->cfi + (P < 10 ? 1 : 0); // SRSLTE_NOF_CTRL_SYMBOLS, phy_common.h:143
+  const uint32_t nrx    = cfg->nof_rx_antennas ? cfg->nof_rx_antennas : 1;
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
   q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, 1, 1);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
@@ -343,8 +359,8 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     }
   }
   const size_t glen = (size_t)14 * nre;
-  ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess &&
-       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B) == hipSuccess &&
+  ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
+       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
        hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)max_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
        hipMalloc((void**)&q->d_e, sizeof(int16_t) * (size_t)max_bits * B) == hipSuccess &&
@@ -358,7 +374,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     return nullptr;
   }
   q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
-  q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words;
+  q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
@@ -397,8 +413,9 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
   const uint32_t C = q->seg.C, K = q->seg.K1;
   const cf32*    grid = q->grid_in ? q->grid_in : q->d_grid;
   switch (stage) {
-    case 0: return srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
-    case 1: return srslte_hip_chest_dl_estimate_batch(q->chest, &q->cfg.chest_cfg, tti0, grid, q->d_ce, q->d_res, (int)nof_sf, stream);
+    case 0: return srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf * q->pg.nof_rx, stream); // [sf][rx] = nof_sf * nof_rx subframes
+    case 1:
+      return srslte_hip_chest_dl_estimate_batch_multi(q->chest, &q->cfg.chest_cfg, tti0, grid, q->d_ce, q->d_res, (int)nof_sf, q->pg.nof_rx, stream);
     case 2: {
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;

@@ -17,9 +17,10 @@ MOD_BITS = {0: 1, 1: 2, 2: 4, 3: 6, 4: 8}
 class DlConfig:
     """One PDSCH configuration: single port, full-band grant, rv 0."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
+        self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.cell = OrcCell(cell_id, nof_prb, 1, True)
         self.nre = 12 * nof_prb
@@ -74,11 +75,16 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0):
     iq = np.zeros(cfg.sf_len, np.complex64)
     orc.orc_ofdm_tx_sf(C.byref(q), p(grid), p(iq))
     iq *= np.float32(amp)
-    if snr_db is not None:
-        # signal power per time sample with a normalised IFFT: nof_re/N per unit-power RE
-        sigma = np.sqrt(amp * amp * cfg.nre / cfg.N / 2) * 10 ** (-snr_db / 20)
-        iq = iq + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
-    return iq.astype(np.complex64), data
+    # signal power per time sample with a normalised IFFT: nof_re/N per unit-power RE
+    sigma = 0.0 if snr_db is None else np.sqrt(amp * amp * cfg.nre / cfg.N / 2) * 10 ** (-snr_db / 20)
+
+    def noisy(x):
+        return x if snr_db is None else x + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
+
+    if cfg.nof_rx == 1:
+        return noisy(iq).astype(np.complex64), data
+    gains = (1.0, 0.6 * np.exp(1j * 1.0), 0.8 * np.exp(-1j * 2.0), 0.4j)[:cfg.nof_rx]  # flat per-antenna channels, own noise each
+    return np.stack([noisy(np.complex64(g) * iq) for g in gains]).astype(np.complex64), data
 
 
 def make_grid(cfg, tti, rng, snr_db):
@@ -111,21 +117,33 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
     grid_in: start from a frequency-domain grid instead of time samples."""
     orc = oracle()
     sf_idx = tti % 10
+    nrx = cfg.nof_rx
     if grid_in is not None:
-        grid = np.ascontiguousarray(grid_in, np.complex64)
+        grid = np.ascontiguousarray(grid_in, np.complex64).reshape(nrx, cfg.grid_len)
     else:
         q = OrcOfdm()
         orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
-        grid = np.zeros(cfg.grid_len, np.complex64)
-        orc.orc_ofdm_rx_sf(C.byref(q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
-    ce = np.zeros(cfg.grid_len, np.complex64)
+        grid = np.zeros((nrx, cfg.grid_len), np.complex64)
+        iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+        for a in range(nrx):
+            orc.orc_ofdm_rx_sf(C.byref(q), p(iq2[a]), p(grid[a]))
+    ce = np.zeros((nrx, cfg.grid_len), np.complex64)
     res = OrcChestRes()
     ccfg = cfg.orc_chest_cfg()
-    assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid), p(ce), C.byref(res)) == 0
     idx = cfg.indices(sf_idx)
-    y, h = np.ascontiguousarray(grid[idx]), np.ascontiguousarray(ce[idx])
     d = np.zeros(len(idx), np.complex64)
-    orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
+    if nrx == 1:
+        assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid[0]), p(ce[0]), C.byref(res)) == 0
+        y, h = np.ascontiguousarray(grid[0][idx]), np.ascontiguousarray(ce[0][idx])
+        orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
+        grid, ce = grid[0], ce[0]
+    else:  # pdsch.c:890-935 with nof_rx_antennas > 1: srslte_predecoding_single_multi
+        gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * nrx)(*[c.ctypes.data for c in ce])
+        assert orc.orc_chest_dl_multi(C.byref(cfg.cell), sf_idx, C.byref(ccfg), nrx, gp, cp, C.byref(res)) == 0
+        ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
+        yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * nrx)(*[v.ctypes.data for v in hs])
+        orc.orc_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        orc.orc_predecoding_single_multi(yp, hp, p(d), nrx, len(idx), 1.0, res.noise_estimate)
     nbits = len(idx) * cfg.Qm
     e = np.zeros(nbits, np.int8 if cfg.llr8 else np.int16)
     sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
@@ -160,7 +178,7 @@ class RefRx:
         self.cfg = cfg
         self.aligned = aligned
         self.chest = opaque(1 << 20)
-        assert self.R.srslte_chest_dl_init(self.chest, cfg.nof_prb, 1) == 0
+        assert self.R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0
         assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
         self.rc = RefChestCfg()
         for k, v in cfg.chest.items():
@@ -169,8 +187,11 @@ class RefRx:
             else:
                 setattr(self.rc, k, v)
         self.res, self.sf = RefChestRes(), RefDlSfCfg()
-        self.ce = aligned(2 * cfg.grid_len, np.float32)
-        self.res.ce[0][0] = self.ce.ctypes.data
+        self.ces = [aligned(2 * cfg.grid_len, np.float32) for _ in range(cfg.nof_rx)]
+        for a_, c_ in enumerate(self.ces):
+            self.res.ce[0][a_] = c_.ctypes.data
+        self.ce = self.ces[0]
+        self.R.srslte_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         self.tdec = opaque(1 << 20)
         assert self.R.srslte_tdec_init(self.tdec, 6144) == 0
         self.crc_tb, self.crc_cb = opaque(4096), opaque(4096)
@@ -186,17 +207,28 @@ class RefRx:
     def run(self, iq, tti):
         cfg, R, orc = self.cfg, self.R, oracle()
         sf_idx = tti % 10
-        grid = self.aligned(2 * cfg.grid_len, np.float32)
-        orc.orc_ofdm_rx_sf(C.byref(self.q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
+        nrx = cfg.nof_rx
+        grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(nrx)]
+        iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+        for a_ in range(nrx):
+            orc.orc_ofdm_rx_sf(C.byref(self.q), p(iq2[a_]), p(grids[a_]))
+        grid = grids[0]
         self.sf.tti = sf_idx
-        inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+        inp = (C.c_void_p * 4)(*([g.ctypes.data for g in grids] + [0] * (4 - nrx)))
         assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
         idx = self.idx[sf_idx]
         n = len(idx)
-        y, h, d = self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32)
-        y.view(np.complex64)[:] = grid.view(np.complex64)[idx]
-        h.view(np.complex64)[:] = self.ce.view(np.complex64)[idx]
-        R.srslte_predecoding_single(p(y), p(h), p(d), None, n, 1.0, self.res.noise_estimate)
+        d = self.aligned(2 * n, np.float32)
+        ys, hs = [self.aligned(2 * n, np.float32) for _ in range(nrx)], [self.aligned(2 * n, np.float32) for _ in range(nrx)]
+        for a_ in range(nrx):
+            ys[a_].view(np.complex64)[:] = grids[a_].view(np.complex64)[idx]
+            hs[a_].view(np.complex64)[:] = self.ces[a_].view(np.complex64)[idx]
+        if nrx == 1:
+            R.srslte_predecoding_single(p(ys[0]), p(hs[0]), p(d), None, n, 1.0, self.res.noise_estimate)
+        else:
+            yp = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))
+            hp = (C.c_void_p * 4)(*([v.ctypes.data for v in hs] + [0] * (4 - nrx)))
+            R.srslte_predecoding_single_multi(yp, hp, p(d), None, nrx, n, 1.0, self.res.noise_estimate)
         nbits = n * cfg.Qm
         lt = np.int8 if cfg.llr8 else np.int16
         e = self.aligned(nbits + 64, lt)

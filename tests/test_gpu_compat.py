@@ -312,3 +312,39 @@ def test_demod_calls(mod):
         getattr(oracle(), on)(mod, p(x), p(b), nsym)
         assert np.array_equal(a, b) if dt != np.float32 else np.abs(a - b).max() < 1e-6
     assert L.srslte_demod_soft_demodulate_s(9, p(x), p(a), nsym) == -1
+
+
+def test_chest_dl_object_two_rx_antennas():
+    """srslte_chest_dl_init(q, prb, 2) + estimate_cfg with two input grids (chest_dl.c:884-908): per-antenna estimates, antenna-averaged
+    scalars and the per-antenna SNR / RSRP / RSRQ fields of fill_res (:860-870)."""
+    L, rng = hip(), np.random.default_rng(44)
+    prb, cid, sf_idx = 25, 9, 3
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 2) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+    k = np.arange(n) % nre
+    grids = [acopy((g * (amp * np.exp(1j * (ph + k / 80.0))) + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+             for amp, ph, nz in ((2.0, 0.2, 0.1), (0.7, -0.9, 0.25))]
+    ce = [aligned(2 * n, np.float32) for _ in range(2)]
+    res.ce[0][0], res.ce[0][1] = ce[0].ctypes.data, ce[1].ctypes.data
+    sf, rc, oc = RefDlSfCfg(), RefChestCfg(), OrcChestCfg()
+    sf.tti = sf_idx
+    rc.filter_coef[0], rc.filter_coef[1], oc.filter_coef[0], oc.filter_coef[1] = 4.0, 1.0, 4.0, 1.0
+    inp = (C.c_void_p * 4)(grids[0].ctypes.data, grids[1].ctypes.data, 0, 0)
+    assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+    ce_o, ores, single = [np.zeros(n, np.complex64) for _ in range(2)], OrcChestRes(), [OrcChestRes(), OrcChestRes()]
+    gp, cp = (C.c_void_p * 2)(grids[0].ctypes.data, grids[1].ctypes.data), (C.c_void_p * 2)(ce_o[0].ctypes.data, ce_o[1].ctypes.data)
+    assert oracle().orc_chest_dl_multi(C.byref(cell), sf_idx, C.byref(oc), 2, gp, cp, C.byref(ores)) == 0
+    for a in range(2):
+        assert close(ce[a].view(np.complex64), ce_o[a])
+        assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grids[a]), None, C.byref(single[a])) == 0
+        assert abs(res.snr_ant_port_db[a][0] - single[a].snr_db) < 1e-3
+        assert abs(res.rsrp_ant_port_dbm[a][0] - single[a].rsrp_dbm) < 1e-3
+        assert abs(res.rsrq_ant_port_db[a][0] - single[a].rsrq_db) < 1e-3
+    for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm"):
+        x, y = getattr(res, nm), getattr(ores, nm)
+        assert abs(x - y) <= 1e-4 * abs(y) + 1e-5, (nm, x, y)
+    L.srslte_chest_dl_free(est)

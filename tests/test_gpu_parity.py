@@ -564,3 +564,41 @@ def test_cfg3_ul_tx_chain(hp):
     t_ref = np.zeros(15 * 1536, np.complex64)
     oracle().orc_ofdm_tx_sf(C.byref(q), p(grid), p(t_ref))
     assert_close_c(t.ravel(), t_ref, "SC-FDMA time signal")
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr,tti0,nsf,llr8", [(6, 1, 936, 0.0, 1, 4, False), (100, 3, 75376, 17.5, 9, 3, False), (100, 3, 75376, 19.0, 4, 2, True)])
+def test_dl_rx_chain_two_rx_antennas(hp, prb, mod, tbs, snr, tti0, nsf, llr8):
+    """SURVEY §8f N4, two receive antennas: per-antenna chest_dl, antenna-averaged noise, srslte_predecoding_single_multi (MRC), then the
+    usual chain - vs the oracle on identical IQ [nsf][2][sf_len]."""
+    rng = np.random.default_rng(700 + prb + mod + int(snr * 10))
+    cfg = DlConfig(prb, 1, mod, tbs, nof_rx=2, llr8=llr8)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.05 / np.sqrt(prb) * 20) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=2)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    ce = rx.debug(1, np.complex64, nsf * 2 * cfg.grid_len).reshape(nsf, 2, -1)
+    res = rx.debug(2, np.float32, nsf * 10).reshape(nsf, 10)
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        for a in range(2):
+            assert_close_c(ce[b, a], r["ce"][a], "ce sf %d antenna %d" % (b, a))
+        for j, nm in enumerate(("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm")):
+            x = getattr(r["res"], nm)
+            assert abs(res[b, j] - x) <= 1e-4 * abs(x) + 1e-5, (nm, res[b, j], x)
+        diff = np.abs(e_all[b, :nre * cfg.Qm].astype(np.int32) - r["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"] or diff.max() == 0:
+            assert np.array_equal(tb[b], r["tb"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0
+    rx.free()

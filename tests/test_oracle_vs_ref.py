@@ -241,6 +241,65 @@ def test_chest_dl_vs_ref(prb, cid):
             R.srslte_chest_dl_free(q)
 
 
+@pytest.mark.parametrize("prb,cid", [(6, 0), (25, 7), (100, 301)])
+def test_chest_dl_two_rx_antennas_vs_ref(prb, cid):
+    """srslte_chest_dl_estimate_cfg with nof_rx_antennas = 2 (chest_dl.c:884-908 + fill_res :845-871): per-antenna estimates and the
+    antenna-averaged scalars."""
+    R, rng = ref(), np.random.default_rng(2000 + prb + cid)
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    for sf_idx, kw in ((0, CHEST_CFGS[0]), (4, CHEST_CFGS[-1]), (5, {"filter_coef": (4.0, 1.0)})):
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        k = np.arange(n) % nre
+        grids = []
+        for a_, (amp, ph, nz) in enumerate(((2.5, 0.3, 0.08), (0.9, -1.1, 0.2))):
+            h = (amp * (1 + 0.3 * np.sin(k / 35.0 + a_)) * np.exp(1j * (ph + k / 90.0))).astype(np.complex64)
+            grids.append(acopy((g * h + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32)))
+        q = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(q, prb, 2) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+        rc, oc = RefChestCfg(), OrcChestCfg()
+        for kk, v in kw.items():
+            if kk == "filter_coef":
+                rc.filter_coef[0], rc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(rc, kk, v)
+                setattr(oc, kk, v)
+        rc.cfo_estimate_sf_mask = 0x3FF
+        ce_r, res, sf = [aligned(2 * n, np.float32) for _ in range(2)], RefChestRes(), RefDlSfCfg()
+        res.ce[0][0], res.ce[0][1] = ce_r[0].ctypes.data, ce_r[1].ctypes.data
+        sf.tti = sf_idx
+        inp = (C.c_void_p * 4)(grids[0].ctypes.data, grids[1].ctypes.data, 0, 0)
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+        ce_o, ores = [np.zeros(n, np.complex64) for _ in range(2)], OrcChestRes()
+        gp, cp = (C.c_void_p * 2)(grids[0].ctypes.data, grids[1].ctypes.data), (C.c_void_p * 2)(ce_o[0].ctypes.data, ce_o[1].ctypes.data)
+        assert oracle().orc_chest_dl_multi(C.byref(cell), sf_idx, C.byref(oc), 2, gp, cp, C.byref(ores)) == 0
+        for a_ in range(2):
+            x = ce_r[a_].view(np.complex64)
+            assert np.abs(x - ce_o[a_]).max() <= 1e-4 * max(np.abs(x).max(), np.sqrt((np.abs(x) ** 2).mean())), (prb, cid, a_)
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+        R.srslte_chest_dl_free(q)
+
+
+def test_equaliser_two_rx_vs_ref():
+    """srslte_predecoding_single_multi (precoding.c:325-348): AVX body and scalar tail both divide exactly."""
+    R, rng = ref(), np.random.default_rng(19)
+    R.srslte_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+    oracle().orc_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+    for n in (20, 1003):
+        ys = [acopy(rng.standard_normal(2 * n).astype(np.float32)) for _ in range(2)]
+        hs = [acopy((rng.standard_normal(2 * n) + 1.5).astype(np.float32)) for _ in range(2)]
+        a, b = aligned(2 * n, np.float32), aligned(2 * n, np.float32)
+        yp, hp = (C.c_void_p * 4)(ys[0].ctypes.data, ys[1].ctypes.data, 0, 0), (C.c_void_p * 4)(hs[0].ctypes.data, hs[1].ctypes.data, 0, 0)
+        for noise in (0.0, 0.07):
+            R.srslte_predecoding_single_multi(yp, hp, p(a), None, 2, n, 1.0, noise)
+            oracle().orc_predecoding_single_multi(yp, hp, p(b), 2, n, 1.0, noise)
+            assert np.abs(np.array(a) - np.array(b)).max() <= 2e-6 * np.abs(np.array(b)).max(), (n, noise)
+
+
 def test_equaliser_vs_ref_rcp_tolerance():
     """The reference's AVX body uses _mm256_rcp_ps (12-bit): parity at 1e-3, see oracle/orc_pdsch.c."""
     R, rng = ref(), np.random.default_rng(9)
@@ -275,6 +334,22 @@ def test_whole_chain_8bit_vs_reference_code(prb, mod, tbs, snr):
     ttis = (1, 2, 3) if prb == 6 else (0, 5, 7)
     nok = 0
     for t in ttis:
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
+        nok += r["ok"]
+    assert nok > 0
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr", [(6, 1, 936, 0.0), (100, 3, 75376, 17.5)])
+def test_whole_chain_two_rx_vs_reference_code(prb, mod, tbs, snr):
+    """Two receive antennas: per-antenna chest_dl + srslte_predecoding_single_multi in the reference-code chain
+    vs the oracle chain; the SNR is below the single-antenna waterfall, so decoding relies on the combining gain."""
+    rng = np.random.default_rng(300 + prb + mod)
+    cfg = DlConfig(prb, 1, mod, tbs, nof_rx=2)
+    chain = RefRx(cfg)
+    nok = 0
+    for t in ((1, 2, 3) if prb == 6 else (0, 5, 7)):
         iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
         r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
         assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
