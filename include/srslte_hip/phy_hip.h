@@ -95,6 +95,27 @@ int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srs
  * per-antenna terms of fill_res (chest_dl.c:860-870) */
 const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
 
+/* ------------------------------------------------------------------ UL channel estimator (replaces
+ * srslte_chest_ul_init/_set_cell/_pregen/_estimate_pusch, ch_estimation/chest_ul.h:47-104, chest_ul.c:51-327, and the PUSCH DMRS of
+ * refsignal_ul.c:118-487). Normal CP, grants of >= 3 PRB (the 1- and 2-PRB base sequences are tabulated, not provided), same
+ * allocation in both slots (the reference's estimator does not support intra-subframe hopping either, chest_ul.c:297-299). */
+typedef struct srslte_hip_chest_ul srslte_hip_chest_ul_t;
+typedef struct { /* srslte_refsignal_dmrs_pusch_cfg_t, refsignal_ul.h:46-51 */
+  uint32_t cyclic_shift, delta_ss;
+  int      group_hopping_en, sequence_hopping_en;
+} srslte_hip_dmrs_pusch_cfg_t;
+typedef struct { /* scalar part of srslte_chest_ul_res_t */
+  float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo;
+} srslte_hip_chest_ul_res_t;
+srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, uint32_t nof_prb, int cp_is_norm, const srslte_hip_dmrs_pusch_cfg_t* cfg);
+void                   srslte_hip_chest_ul_destroy(srslte_hip_chest_ul_t* q);
+/* srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): r_host [2][12*L_prb] cf32 in HOST memory */
+int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t sf_idx, uint32_t n_dmrs, void* r_host);
+/* d_grid [nof_sf][14][12*nof_prb]; d_ce same shape or NULL - only the granted PRBs are written, as upstream; d_res [nof_sf] or NULL;
+ * subframe b is TTI tti0 + b; one grant (L_prb, n_prb, n_dmrs) for the batch */
+int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
+                                             const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream);
+
 /* ------------------------------------------------------------------ soft demapper (replaces srslte_demod_soft_demodulate{,_s,_b},
  * modem/demod_soft.h:39-53, demod_soft.c:479-549). mod: 0 BPSK, 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM (srslte_mod_t).
  * ncalls independent calls of nsymbols each (the scalar-tail rounding of the reference depends on nsymbols). */

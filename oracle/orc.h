@@ -159,4 +159,22 @@ int orc_dlsch_decode_8bit(const orc_sch_cfg_t* cfg, const int8_t* e, uint8_t* da
 #ifdef __cplusplus
 }
 #endif
+/* ---------------------------------------------------------------- UL reference signal + PUSCH channel estimator */
+typedef struct {
+  uint32_t cell_id, n_prs[30][20], f_gh[20], v[20][30];
+} orc_ul_dmrs_t;
+typedef struct { /* srslte_refsignal_dmrs_pusch_cfg_t, refsignal_ul.h:46-51 */
+  uint32_t cyclic_shift, delta_ss;
+  bool     group_hopping_en, sequence_hopping_en;
+} orc_ul_dmrs_cfg_t;
+typedef struct { /* scalar part of srslte_chest_ul_res_t, chest_ul.h:47-55 */
+  float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo;
+} orc_chest_ul_res_t;
+int orc_ul_dmrs_init(orc_ul_dmrs_t* q, uint32_t cell_id);
+/* r: [2][12*nof_prb] (slot-major); -2 for the tabulated 1- and 2-PRB sequences */
+int orc_ul_dmrs_pusch_gen(const orc_ul_dmrs_t* q, const orc_ul_dmrs_cfg_t* cfg, uint32_t nof_prb, uint32_t sf_idx, uint32_t n_dmrs, orc_cf_t* r);
+/* grid, ce: [14][12*cell_nof_prb]; only the granted PRBs of ce are written, as upstream */
+int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb, const orc_cf_t* grid, orc_cf_t* ce,
+                       orc_chest_ul_res_t* res);
+
 #endif

@@ -262,3 +262,116 @@ int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_
   if (res) fill_res(cell->nof_prb, nof_rx, raw, res);
   return 0;
 }
+
+/* ------------------------------------------------------------------ UL: PUSCH DMRS (refsignal_ul.c) and srslte_chest_ul_estimate_pusch
+ * (chest_ul.c), SURVEY §8f N3. Grants of 1 and 2 PRB use the tabulated QPSK base sequences of 36.211 Tables 5.5.1.2-1/-2 and are
+ * not restated (orc_ul_dmrs_pusch_gen returns -2); from 3 PRB on the base sequence is a Zadoff-Chu extension. */
+
+static const uint32_t N_DMRS_1[8] = {0, 2, 3, 4, 6, 8, 9, 10}; /* 36.211 Table 5.5.2.1.1-2 (refsignal_ul.c:42) */
+static const uint32_t N_DMRS_2[8] = {0, 6, 3, 4, 2, 8, 10, 9}; /* 36.211 Table 5.5.2.1.1-1 (refsignal_ul.c:39) */
+
+int orc_ul_dmrs_init(orc_ul_dmrs_t* q, uint32_t cell_id)
+{ /* srslte_refsignal_ul_set_cell (refsignal_ul.c:206-238), normal CP */
+  memset(q, 0, sizeof(*q));
+  q->cell_id = cell_id;
+  uint8_t c[8 * 7 * 20];
+  for (uint32_t ds = 0; ds < 30; ds++) { /* generate_n_prs :118-141 and generate_srslte_sequence_hopping_v :149-163 share the seed */
+    uint32_t c_init = ((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30);
+    orc_gold(c_init, 8 * 7 * 20, c);
+    for (uint32_t ns = 0; ns < 20; ns++) {
+      uint32_t n = 0;
+      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * 7 * ns + i] << i;
+      q->n_prs[ds][ns] = n;
+      q->v[ns][ds]     = c[ns];
+    }
+  }
+  orc_gold(cell_id / 30, 160, c); /* srslte_group_hopping_f_gh, phy_common.c:419-436 */
+  for (uint32_t ns = 0; ns < 20; ns++) {
+    q->f_gh[ns] = 0;
+    for (int i = 0; i < 8; i++) q->f_gh[ns] += (uint32_t)c[8 * ns + i] << i;
+  }
+  return 0;
+}
+
+static uint32_t largest_prime_below(uint32_t x)
+{ /* refsignal_ul.c:240-249 looks the value up in a table of primes */
+  for (uint32_t p = x - 1; p >= 2; p--) {
+    int prime = 1;
+    for (uint32_t d = 2; d * d <= p; d++) {
+      if (p % d == 0) { prime = 0; break; }
+    }
+    if (prime) return p;
+  }
+  return 0;
+}
+
+int orc_ul_dmrs_pusch_gen(const orc_ul_dmrs_t* q, const orc_ul_dmrs_cfg_t* cfg, uint32_t nof_prb, uint32_t sf_idx, uint32_t n_dmrs, orc_cf_t* r)
+{ /* srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487) with compute_r :352-371, arg_r_uv_mprb :271-283, get_q :257-269,
+     pusch_alpha :296-304. The float/double mix of the reference is kept operation by operation: at 100 PRB the argument reaches
+     4e6 rad, where a float has a resolution of 0.5 rad, so every rounding is visible in the sequence. */
+  if (cfg->cyclic_shift >= 8 || cfg->delta_ss >= 30 || n_dmrs >= 8 || sf_idx >= 10) return -1;
+  if (nof_prb < 3) return -2;
+  const uint32_t M_sc = 12 * nof_prb, N_sz = largest_prime_below(M_sc);
+  for (uint32_t ns = 2 * sf_idx; ns < 2 * (sf_idx + 1); ns++) {
+    uint32_t u = ((cfg->group_hopping_en ? q->f_gh[ns] : 0) + (q->cell_id % 30) + cfg->delta_ss) % 30;
+    uint32_t v = (nof_prb >= 6 && cfg->sequence_hopping_en) ? q->v[ns][cfg->delta_ss] : 0;
+    float    n_sz = (float)N_sz, q_hat = n_sz * (u + 1) / 31, qf;
+    if ((((uint32_t)(2 * q_hat)) % 2) == 0) {
+      qf = (float)(q_hat + 0.5 + v);
+    } else {
+      qf = (float)(q_hat + 0.5 - v);
+    }
+    float    qq    = (float)(uint32_t)qf;
+    uint32_t n_cs  = (N_DMRS_1[cfg->cyclic_shift] + N_DMRS_2[n_dmrs] + q->n_prs[cfg->delta_ss][ns]) % 12;
+    float    alpha = (float)(2 * M_PI * n_cs / 12);
+    for (uint32_t i = 0; i < M_sc; i++) {
+      float m   = (float)(i % N_sz);
+      float arg = (float)(-M_PI * qq * m * (m + 1) / n_sz);
+#ifdef ORC_DMRS_NO_FMA
+      float x = arg + alpha * (float)i;
+#else
+      float x = fmaf(alpha, (float)i, arg); /* the reference's -Ofast -mfma build contracts tmp_arg[i] + alpha*i */
+#endif
+      r[(ns % 2) * M_sc + i] = (orc_cf_t){cosf(x), sinf(x)};
+    }
+  }
+  return 0;
+}
+
+int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb, const orc_cf_t* grid, orc_cf_t* ce,
+                       orc_chest_ul_res_t* res)
+{ /* srslte_chest_ul_estimate_pusch (chest_ul.c:268-327) with the defaults of srslte_chest_ul_init (:101-102: 3-tap filter, w = 0.3333),
+     same allocation in both slots, no linear interpolation (DO_LINEAR_INTERPOLATION is not defined, :244-258) */
+  const uint32_t nre = 12 * cell_nof_prb, nrefs = 12 * L_prb;
+  cf *           recv = malloc(sizeof(cf) * 2 * nrefs), *est = malloc(sizeof(cf) * 2 * nrefs), *tmp = malloc(sizeof(cf) * nrefs);
+  float          filter[3];
+  const float    w = 0.3333f;
+  filter[0] = w; filter[2] = w; filter[1] = 1 - 2 * w;
+  for (uint32_t s = 0; s < 2; s++) {
+    const uint32_t L = (s + 1) * 7 - 4; /* SRSLTE_REFSIGNAL_UL_L */
+    for (uint32_t i = 0; i < nrefs; i++) {
+      recv[s * nrefs + i] = grid[L * nre + n_prb * 12 + i];
+      est[s * nrefs + i]  = c_mulconj(recv[s * nrefs + i], r_dmrs[s * nrefs + i]);
+    }
+  }
+  float power = 0;
+  for (uint32_t s = 0; s < 2; s++) {
+    const uint32_t L = (s + 1) * 7 - 4;
+    cf*            dst = &ce[L * nre + n_prb * 12];
+    conv_same_cf(&est[s * nrefs], filter, dst, nrefs, 3);
+    for (uint32_t l = 0; l < 7; l++) {
+      if (s * 7 + l != L) memcpy(&ce[(s * 7 + l) * nre + n_prb * 12], dst, sizeof(cf) * nrefs);
+    }
+    for (uint32_t i = 0; i < nrefs; i++) tmp[i] = c_sub(dst[i], est[s * nrefs + i]); /* srslte_chest_estimate_noise_pilots */
+    power += avg_power(tmp, nrefs);
+  }
+  power /= 2;
+  float a = (float)(7.419 * w * w + 0.1117 * w - 0.005387); /* chest_ul.c:217-221, "calibrated for filter length 3" */
+  res->noise_estimate     = (float)(power / (a * 0.8));
+  res->snr                = res->noise_estimate ? avg_power(recv, 2 * nrefs) / res->noise_estimate : NAN;
+  res->snr_db             = (float)(10 * log10(res->snr));
+  res->noise_estimate_dbm = (float)(10 * log10(res->noise_estimate) + 30);
+  res->cfo                = 0;
+  free(recv); free(est); free(tmp);
+  return 0;
+}

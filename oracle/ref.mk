@@ -6,8 +6,9 @@
 #
 # What is NOT built, and why (see DESIGN.md "Oracle"):
 #   * lib/src/phy/dft/dft_fftw.c needs <fftw3.h>/libfftw3f, absent from this image -> unbuildable.
-#     Everything that reaches srslte_dft_* (ofdm.c, dft_precoding.c, pss/sss FFT helpers, prach,
-#     fading, conv_fft) is dropped by --gc-sections because the export map does not root it.
+#     Everything that reaches srslte_dft_* (ofdm.c, pss/sss FFT helpers, prach, fading, conv_fft) is dropped by
+#     --gc-sections because the export map does not root it. dft/dft_precoding.c is compiled for its one pure
+#     function, srslte_dft_precoding_valid_prb (which chest_ul.c calls); its FFTW-dependent functions are dropped too.
 #   * Nothing is stubbed: no stand-in headers, libraries or generated files are written.
 #     `srslte/srslte.h` pulls the cmake-generated `srslte/version.h` (version macros only); the
 #     recipe pre-defines srslte.h's own include guard so that umbrella header contributes
@@ -23,7 +24,8 @@ OBJ      := $(OUT)/obj
 
 REF_DIRS := ch_estimation common fec mimo modem phch resampling scrambling utils sync
 REF_C    := $(foreach d,$(REF_DIRS),$(wildcard $(RLIB)/src/phy/$(d)/*.c)) \
-            $(RLIB)/src/phy/channel/ch_awgn.c $(RLIB)/src/phy/channel/gauss.c
+            $(RLIB)/src/phy/channel/ch_awgn.c $(RLIB)/src/phy/channel/gauss.c \
+            $(RLIB)/src/phy/dft/dft_precoding.c
 REF_CXX  := $(RLIB)/src/phy/utils/random.cpp
 # NEON-only translation unit: not part of an x86 build of the reference
 REF_C    := $(filter-out %viterbi37_neon.c,$(REF_C))

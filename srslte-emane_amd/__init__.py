@@ -327,6 +327,54 @@ def tc_interl(long_cb, win=1):
     return rc, f, r
 
 
+class DmrsPuschCfg(C.Structure):
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("group_hopping_en", C.c_int), ("sequence_hopping_en", C.c_int)]
+
+
+class ChestUlRes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("noise_estimate", "noise_estimate_dbm", "snr", "snr_db", "cfo")]
+
+
+class ChestUl:
+    """srslte_chest_ul_t: init + set_cell + pregen + estimate_pusch (chest_ul.h:78-104), batched over subframes tti0, tti0+1, ..."""
+
+    def __init__(self, cell_id, nof_prb, cyclic_shift=0, delta_ss=0, group_hopping=False, sequence_hopping=False):
+        self.cfg = DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0)
+        lib().srslte_hip_chest_ul_create.restype = C.c_void_p
+        lib().srslte_hip_chest_ul_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(DmrsPuschCfg)]
+        self.h = lib().srslte_hip_chest_ul_create(cell_id, nof_prb, 1, C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("srslte_hip_chest_ul_create failed")
+        self.nof_prb = nof_prb
+
+    def dmrs(self, L_prb, sf_idx, n_dmrs):
+        r = np.zeros(2 * 12 * L_prb, np.complex64)
+        lib().srslte_hip_refsignal_dmrs_pusch_gen.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        rc = lib().srslte_hip_refsignal_dmrs_pusch_gen(self.h, L_prb, sf_idx, n_dmrs, r.ctypes.data)
+        return rc, r
+
+    def estimate_pusch(self, grid, tti0, L_prb, n_prb, n_dmrs, ce_init=None):
+        x = np.ascontiguousarray(grid, np.complex64).reshape(-1, 14 * 12 * self.nof_prb)
+        n = x.shape[0]
+        dg = DevBuf.from_host(x)
+        dce = DevBuf.from_host(np.zeros_like(x) if ce_init is None else np.ascontiguousarray(ce_init, np.complex64))
+        dres = DevBuf(n * C.sizeof(ChestUlRes))
+        f = lib().srslte_hip_chest_ul_estimate_pusch_batch
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        rc = f(self.h, tti0, L_prb, n_prb, n_dmrs, dg.ptr, dce.ptr, dres.ptr, n, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None
+        sync()
+        res = np.frombuffer(dres.to_host(np.uint8).tobytes(), dtype=np.float32).reshape(n, 5)
+        return rc, dce.to_host(np.complex64).reshape(x.shape), res
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_chest_ul_destroy.argtypes = [C.c_void_p]
+            lib().srslte_hip_chest_ul_destroy(self.h)
+            self.h = None
+
+
 class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 

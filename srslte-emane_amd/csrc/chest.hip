@@ -411,3 +411,210 @@ extern "C" int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, cons
 {
   return srslte_hip_chest_dl_estimate_batch_multi(q, cfg, tti0, d_grid, d_ce, d_res, nof_sf, 1, stream);
 }
+
+// ====================================================================================================================
+// Uplink: PUSCH DMRS (refsignal_ul.c) and srslte_chest_ul_estimate_pusch (chest_ul.c) - SURVEY §8f N3
+// ====================================================================================================================
+namespace {
+
+const uint32_t N_DMRS_1[8] = {0, 2, 3, 4, 6, 8, 9, 10}; // 36.211 Table 5.5.2.1.1-2 (refsignal_ul.c:42)
+const uint32_t N_DMRS_2[8] = {0, 6, 3, 4, 2, 8, 10, 9}; // 36.211 Table 5.5.2.1.1-1 (refsignal_ul.c:39)
+
+uint32_t largest_prime_below(uint32_t x)
+{
+  for (uint32_t p = x - 1; p >= 2; p--) {
+    bool prime = true;
+    for (uint32_t d = 2; d * d <= p; d++) {
+      if (p % d == 0) {
+        prime = false;
+        break;
+      }
+    }
+    if (prime) return p;
+  }
+  return 0;
+}
+
+struct ChestUlGeom {
+  int   cell_nre, L_prb, n_prb, tti0; // 12 * cell nof_prb; grant
+  float w;                            // 3-tap smoothing filter {w, 1-2w, w} (chest_ul.c:101-102)
+};
+struct ChestUlResDev { float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo; };
+
+// One workgroup per subframe (chest_ul.c:268-327): LS estimates at the two DMRS symbols, 3-tap "same" convolution with the
+// edge extrapolation of srslte_conv_same_cf (convolution.c:180-218), the result copied to the 7 symbols of its slot
+// (DO_LINEAR_INTERPOLATION is not defined upstream), noise from the difference smoothed - raw, SNR from the pilot power.
+// d_r: [10][2][12 * L_prb] DMRS of the grant per subframe index.
+__global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __restrict__ grid, cf32* __restrict__ ce,
+                                                             ChestUlResDev* __restrict__ res, const cf32* __restrict__ d_r, ChestUlGeom g)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  __shared__ float red[CH_THREADS / 64];
+  const int   sf = blockIdx.x, sf_idx = (g.tti0 + sf) % 10, tid = threadIdx.x, nrefs = 12 * g.L_prb;
+  cf32*       est = reinterpret_cast<cf32*>(lds_raw); // [2][nrefs]
+  const cf32* gs  = grid + (size_t)sf * 14 * g.cell_nre;
+  cf32*       cs  = ce ? ce + (size_t)sf * 14 * g.cell_nre : nullptr;
+  const cf32* r   = d_r + (size_t)sf_idx * 2 * nrefs;
+  float       pw  = 0.f;
+  for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
+    const int  s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
+    const cf32 y = gs[L * g.cell_nre + g.n_prb * 12 + k];
+    est[i]       = c_mulconj(y, r[i]);
+    pw += y.x * y.x + y.y * y.y;
+  }
+  __syncthreads();
+  const float pilot_power = block_sum(pw, red) / (float)(2 * nrefs);
+  const float f0 = g.w, f1 = 1 - 2 * g.w;
+  float       npw[2] = {0.f, 0.f};
+  for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
+    const int   s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
+    const cf32* e = est + s * nrefs;
+    // conv_same with M = 3: out[k] = f0 * in[k-1] + f1 * in[k] + f0 * in[k+1]; at the two ends the missing neighbour is upstream's
+    // "extrapolated" value 3 * in[1] - 2 * in[0] resp. 3 * in[N-1] - 2 * in[N-2] (convolution.c:180-218, reproduced as it is)
+    cf32 o;
+    if (nrefs < 3) {
+      o = e[k];
+    } else if (k == 0) {
+      const cf32 first = c_sub(c_scale(e[1], 3.0f), c_scale(e[0], 2.0f));
+      o = c_add(c_add(c_scale(first, f0), c_scale(e[0], f1)), c_scale(e[1], f0));
+    } else if (k == nrefs - 1) {
+      const cf32 last = c_sub(c_scale(e[nrefs - 1], 3.0f), c_scale(e[nrefs - 2], 2.0f));
+      o = c_add(c_add(c_scale(e[nrefs - 2], f0), c_scale(e[nrefs - 1], f1)), c_scale(last, f0));
+    } else {
+      o = c_add(c_add(c_scale(e[k - 1], f0), c_scale(e[k], f1)), c_scale(e[k + 1], f0));
+    }
+    if (cs) {
+      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + g.n_prb * 12 + k] = o;
+    }
+    const cf32 d = c_sub(o, e[k]);
+    npw[s] += d.x * d.x + d.y * d.y;
+    (void)L;
+  }
+  const float p0 = block_sum(npw[0], red) / (float)nrefs, p1 = block_sum(npw[1], red) / (float)nrefs;
+  if (tid == 0 && res) {
+    const float power = (p0 + p1) / 2;
+    const float a     = (float)(7.419 * g.w * g.w + 0.1117 * g.w - 0.005387); // chest_ul.c:217-221
+    ChestUlResDev o;
+    o.noise_estimate     = (float)(power / (a * 0.8));
+    o.snr                = o.noise_estimate ? pilot_power / o.noise_estimate : NAN;
+    o.snr_db             = (float)(10 * log10((double)o.snr));
+    o.noise_estimate_dbm = (float)(10 * log10((double)o.noise_estimate) + 30);
+    o.cfo                = 0.f;
+    res[sf]              = o;
+  }
+}
+
+} // namespace
+
+struct srslte_hip_chest_ul {
+  uint32_t cell_id, nof_prb;
+  srslte_hip_dmrs_pusch_cfg_t cfg;
+  uint32_t n_prs[30][20], f_gh[20], v[20][30];
+  // device DMRS of the grant last used: [10][2][12 * L_prb]
+  cf32*    d_r;
+  uint32_t r_L, r_n_dmrs;
+};
+
+extern "C" srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, uint32_t nof_prb, int cp_is_norm, const srslte_hip_dmrs_pusch_cfg_t* cfg)
+{ // srslte_chest_ul_init + srslte_chest_ul_set_cell (chest_ul.c:51-194, refsignal_ul.c:206-238) + srslte_chest_ul_pregen
+  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || !cp_is_norm || !cfg || cfg->cyclic_shift >= 8 || cfg->delta_ss >= 30) {
+    fprintf(stderr, "[srslte_hip] chest_ul: unsupported cell / DMRS configuration (id=%u prb=%u cp_norm=%d)\n", cell_id, nof_prb, cp_is_norm);
+    return nullptr;
+  }
+  auto* q    = new srslte_hip_chest_ul();
+  q->cell_id = cell_id;
+  q->nof_prb = nof_prb;
+  q->cfg     = *cfg;
+  q->d_r     = nullptr;
+  q->r_L = q->r_n_dmrs = 0xffffffffu;
+  std::vector<uint8_t> c;
+  for (uint32_t ds = 0; ds < 30; ds++) { // generate_n_prs :118-141 and generate_srslte_sequence_hopping_v :149-163 share the seed
+    gold(((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30), 8 * 7 * 20, c);
+    for (uint32_t ns = 0; ns < 20; ns++) {
+      uint32_t n = 0;
+      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * 7 * ns + i] << i;
+      q->n_prs[ds][ns] = n;
+      q->v[ns][ds]     = c[ns];
+    }
+  }
+  gold(cell_id / 30, 160, c); // srslte_group_hopping_f_gh, phy_common.c:419-436
+  for (uint32_t ns = 0; ns < 20; ns++) {
+    q->f_gh[ns] = 0;
+    for (int i = 0; i < 8; i++) q->f_gh[ns] += (uint32_t)c[8 * ns + i] << i;
+  }
+  return q;
+}
+
+extern "C" void srslte_hip_chest_ul_destroy(srslte_hip_chest_ul_t* q)
+{
+  if (!q) return;
+  if (q->d_r) (void)hipFree(q->d_r);
+  delete q;
+}
+
+// srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): r_host [2][12 * L_prb]. The float / double mix of the reference is kept
+// operation by operation (at 100 PRB the exponent's argument reaches 4e6 rad, where a float resolves 0.5 rad), including the
+// fused multiply-add its -Ofast -mfma build makes of tmp_arg[i] + alpha * i.
+extern "C" int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t sf_idx, uint32_t n_dmrs, void* r_host)
+{
+  if (!q || !r_host || n_dmrs >= 8 || sf_idx >= 10 || L_prb > q->nof_prb) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (L_prb < 3) {
+    fprintf(stderr, "[srslte_hip] PUSCH DMRS for 1- and 2-PRB grants (tabulated base sequences) is not provided\n");
+    return SRSLTE_ERROR;
+  }
+  cf32*          r    = (cf32*)r_host;
+  const uint32_t M_sc = 12 * L_prb, N_sz = largest_prime_below(M_sc);
+  for (uint32_t ns = 2 * sf_idx; ns < 2 * (sf_idx + 1); ns++) {
+    const uint32_t u = ((q->cfg.group_hopping_en ? q->f_gh[ns] : 0) + (q->cell_id % 30) + q->cfg.delta_ss) % 30;
+    const uint32_t v = (L_prb >= 6 && q->cfg.sequence_hopping_en) ? q->v[ns][q->cfg.delta_ss] : 0;
+    const float    n_sz = (float)N_sz, q_hat = n_sz * (u + 1) / 31;
+    float          qf;
+    if ((((uint32_t)(2 * q_hat)) % 2) == 0) { // get_q :257-269
+      qf = (float)(q_hat + 0.5 + v);
+    } else {
+      qf = (float)(q_hat + 0.5 - v);
+    }
+    const float    qq    = (float)(uint32_t)qf;
+    const uint32_t n_cs  = (N_DMRS_1[q->cfg.cyclic_shift] + N_DMRS_2[n_dmrs] + q->n_prs[q->cfg.delta_ss][ns]) % 12; // pusch_alpha :296-304
+    const float    alpha = (float)(2 * M_PI * n_cs / 12);
+    for (uint32_t i = 0; i < M_sc; i++) {
+      const float m   = (float)(i % N_sz);
+      const float arg = (float)(-M_PI * qq * m * (m + 1) / n_sz); // arg_r_uv_mprb :271-283
+      const float x   = fmaf(alpha, (float)i, arg);
+      r[(ns % 2) * M_sc + i] = make_float2(cosf(x), sinf(x));
+    }
+  }
+  return SRSLTE_SUCCESS;
+}
+
+// d_grid: [nof_sf][14][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
+// d_res: [nof_sf] srslte_hip_chest_ul_res_t or NULL. Same grant (L_prb, n_prb in both slots, n_dmrs) for every subframe of the batch.
+extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
+                                                        const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+{
+  if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!srslte_hip_dft_precoding_valid_prb(L_prb)) {
+    fprintf(stderr, "[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  if (q->r_L != L_prb || q->r_n_dmrs != n_dmrs) { // what srslte_chest_ul_pregen keeps for every (n_dmrs, sf, L): built per grant here
+    std::vector<cf32> r((size_t)10 * 2 * 12 * L_prb);
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      int rc = srslte_hip_refsignal_dmrs_pusch_gen(q, L_prb, sf, n_dmrs, r.data() + (size_t)sf * 2 * 12 * L_prb);
+      if (rc) return rc;
+    }
+    if (q->d_r) (void)hipFree(q->d_r);
+    q->d_r = nullptr;
+    HIP_TRY(hipMalloc((void**)&q->d_r, sizeof(cf32) * r.size()));
+    HIP_TRY(hipMemcpy(q->d_r, r.data(), sizeof(cf32) * r.size(), hipMemcpyHostToDevice));
+    q->r_L      = L_prb;
+    q->r_n_dmrs = n_dmrs;
+  }
+  ChestUlGeom g;
+  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.tti0 = (int)tti0; g.w = 0.3333f;
+  hipLaunchKernelGGL(chest_ul_kernel, dim3(nof_sf), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, (hipStream_t)stream, (const cf32*)d_grid,
+                     (cf32*)d_ce, (ChestUlResDev*)d_res, (const cf32*)q->d_r, g);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}

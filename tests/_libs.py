@@ -161,3 +161,40 @@ def make_crc(poly, order):
                 crc ^= poly
         h.table[i] = crc & h.crcmask
     return h
+
+
+class OrcUlDmrs(C.Structure):
+    _fields_ = [("cell_id", C.c_uint32), ("n_prs", (C.c_uint32 * 20) * 30), ("f_gh", C.c_uint32 * 20), ("v", (C.c_uint32 * 30) * 20)]
+
+
+class OrcUlDmrsCfg(C.Structure):
+    """Also the layout of srslte_refsignal_dmrs_pusch_cfg_t (refsignal_ul.h:46-51)."""
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("group_hopping_en", C.c_bool), ("sequence_hopping_en", C.c_bool)]
+
+
+class OrcChestUlRes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("noise_estimate", "noise_estimate_dbm", "snr", "snr_db", "cfo")]
+
+
+class RefChestUlRes(C.Structure):
+    """srslte_chest_ul_res_t (chest_ul.h:47-55)."""
+    _fields_ = [("ce", C.c_void_p), ("nof_re", C.c_uint32), ("noise_estimate", C.c_float), ("noise_estimate_dbm", C.c_float), ("snr", C.c_float),
+                ("snr_db", C.c_float), ("cfo", C.c_float)]
+
+
+def ref_pusch_cfg(L_prb, n_prb, n_dmrs):
+    """A zeroed srslte_pusch_cfg_t (pusch_cfg.h:62-86) with the grant fields the UL estimator reads; offsets from the reference headers
+    (checked by tests/test_abi_layout.py where those headers are available)."""
+    buf = (C.c_uint8 * 520)()
+    u32 = C.cast(buf, C.POINTER(C.c_uint32))
+    u32[388 // 4] = L_prb
+    u32[392 // 4], u32[396 // 4] = n_prb, n_prb          # n_prb[2]
+    u32[400 // 4], u32[404 // 4] = n_prb, n_prb          # n_prb_tilde[2]
+    u32[476 // 4] = n_dmrs
+    return buf
+
+
+def ref_ul_sf_cfg(tti):
+    buf = (C.c_uint8 * 20)()
+    C.cast(buf, C.POINTER(C.c_uint32))[12 // 4] = tti
+    return buf

@@ -211,6 +211,42 @@ def extra():
     np.savez_compressed(os.path.join(OUT, "llr8.npz"), **g8)
     print("llr8.npz", os.path.getsize(os.path.join(OUT, "llr8.npz")), "bytes")
 
+    # ---------------- UL: PUSCH DMRS sequences and srslte_chest_ul_estimate_pusch outputs of the reference
+    from _libs import OrcUlDmrsCfg, RefChestUlRes, ref_pusch_cfg, ref_ul_sf_cfg
+    rng = np.random.default_rng(2026100303)
+    ul = {}
+    for n, (cell_id, prb, L, n_prb, cs, ds, gh, sh, tti, n_dmrs) in enumerate(((1, 6, 4, 1, 0, 0, 0, 0, 4, 3), (77, 25, 25, 0, 3, 7, 1, 0, 19, 0),
+                                                                              (301, 100, 100, 0, 5, 13, 1, 1, 7, 6), (12, 50, 20, 17, 7, 29, 0, 1, 2, 5))):
+        q = opaque(1 << 16)
+        assert R.srslte_chest_ul_init(q, prb) == 0 and R.srslte_chest_ul_set_cell(q, RefCell(prb, 1, cell_id, 0, 0, 0, 0)) == 0
+        dcfg = OrcUlDmrsCfg(cs, ds, bool(gh), bool(sh))
+        R.srslte_chest_ul_pregen(q, C.byref(dcfg))
+        rs = opaque(1 << 16)
+        assert R.srslte_refsignal_ul_init(rs, prb) == 0 and R.srslte_refsignal_ul_set_cell(rs, RefCell(prb, 1, cell_id, 0, 0, 0, 0)) == 0
+        r = aligned(2 * 2 * 12 * L, np.float32)
+        assert R.srslte_refsignal_dmrs_pusch_gen(rs, C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        r = np.array(r).view(np.complex64)
+        nre, ng = 12 * prb, 14 * 12 * prb
+        grid = (0.5 * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))).astype(np.complex64)
+        k = np.arange(12 * L)
+        h = ((1.5 + 0.4 * np.sin(k / 30.0)) * np.exp(1j * (0.4 + k / 150.0))).astype(np.complex64)
+        for s_, sym in enumerate((3, 10)):
+            grid[sym * nre + 12 * n_prb: sym * nre + 12 * (n_prb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grid = acopy((grid + 0.1 * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))).astype(np.complex64).view(np.float32))
+        ce, res = aligned(2 * ng, np.float32), RefChestUlRes()
+        ce[:] = 0
+        res.ce = ce.ctypes.data
+        assert R.srslte_chest_ul_estimate_pusch(q, ref_ul_sf_cfg(tti), ref_pusch_cfg(L, n_prb, n_dmrs), p(grid), C.byref(res)) == 0
+        ul["meta_%d" % n] = np.array([cell_id, prb, L, n_prb, cs, ds, gh, sh, tti, n_dmrs], np.int32)
+        ul["r_%d" % n], ul["grid_%d" % n] = r.copy(), np.array(grid).view(np.complex64).copy()
+        sel = np.concatenate([np.arange(l * nre + 12 * n_prb, l * nre + 12 * (n_prb + L)) for l in range(14)])
+        ul["ce_%d" % n] = np.array(ce).view(np.complex64)[sel].copy()  # the granted PRBs of the 14 symbols (everything else stays untouched)
+        ul["scal_%d" % n] = np.array([res.noise_estimate, res.noise_estimate_dbm, res.snr, res.snr_db], np.float32)
+        R.srslte_chest_ul_free(q)
+        R.srslte_refsignal_ul_free(rs)
+    np.savez_compressed(os.path.join(OUT, "chest_ul.npz"), **ul)
+    print("chest_ul.npz", os.path.getsize(os.path.join(OUT, "chest_ul.npz")), "bytes")
+
 
 if __name__ == "__main__":
     if "--extra-only" not in sys.argv:

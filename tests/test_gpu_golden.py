@@ -113,3 +113,26 @@ def test_llr8_golden(hp):
             assert bool(ok[0]) == bool(g["%s_ok_%d" % (tag, t)][0]) and np.array_equal(tb[0], g["%s_tb_%d" % (tag, t)])
             assert np.array_equal(rx.debug(6, np.uint32, C_), g["%s_iters_%d" % (tag, t)])
         rx.free()
+
+
+def test_chest_ul_golden(hp):
+    """UL DMRS (host table) and chest_ul kernel against reference outputs."""
+    g = load("chest_ul.npz")
+    for n in range(4):
+        cell_id, prb, L, n_prb, cs, ds, gh, sh, tti, n_dmrs = (int(v) for v in g["meta_%d" % n])
+        q = hp.ChestUl(cell_id, prb, cs, ds, bool(gh), bool(sh))
+        rc, r = q.dmrs(L, tti % 10, n_dmrs)
+        assert rc == 0 and np.abs(r - g["r_%d" % n]).max() <= 2e-6
+        rc, ce, res = q.estimate_pusch(g["grid_%d" % n], tti, L, n_prb, n_dmrs)
+        assert rc == 0
+        nre = 12 * prb
+        sel = np.concatenate([np.arange(l * nre + 12 * n_prb, l * nre + 12 * (n_prb + L)) for l in range(14)])
+        ref = g["ce_%d" % n]
+        assert np.abs(ce[0][sel] - ref).max() <= 1e-4 * np.abs(ref).max()
+        mask = np.ones(14 * nre, bool)
+        mask[sel] = False
+        assert np.all(ce[0][mask] == 0)
+        for x, y in zip(res[0, :4], g["scal_%d" % n]):
+            assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
+        assert q.dmrs(2, 0, 0)[0] == hp.SRSLTE_ERROR  # tabulated 1-/2-PRB sequences are not provided
+        q.free()

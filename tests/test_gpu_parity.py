@@ -602,3 +602,39 @@ def test_dl_rx_chain_two_rx_antennas(hp, prb, mod, tbs, snr, tti0, nsf, llr8):
             assert np.array_equal(tb[b][:tbs // 8], data[b])
     assert n_ok > 0
     rx.free()
+
+
+@pytest.mark.parametrize("cell_id,prb,L,n_prb", [(3, 6, 6, 0), (150, 50, 45, 2), (1, 100, 100, 0), (9, 100, 3, 60)])
+def test_chest_ul_pusch_batch(hp, cell_id, prb, L, n_prb):
+    """srslte_chest_ul_estimate_pusch on a batch of subframes vs the oracle: DMRS of every subframe index, ce, noise, SNR."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg
+    rng = np.random.default_rng(cell_id + prb + L)
+    cs, ds, gh, sh, n_dmrs, tti0, nsf = 4, 11, True, L >= 6, 2, 7, 5
+    q = hp.ChestUl(cell_id, prb, cs, ds, gh, sh)
+    o, cfg = OrcUlDmrs(), OrcUlDmrsCfg(cs, ds, gh, sh)
+    oracle().orc_ul_dmrs_init(C.byref(o), cell_id)
+    nre, ng = 12 * prb, 14 * 12 * prb
+    grids, refs = np.zeros((nsf, ng), np.complex64), []
+    for b in range(nsf):
+        r = np.zeros(2 * 12 * L, np.complex64)
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), L, (tti0 + b) % 10, n_dmrs, p(r)) == 0
+        rc, r_dev = q.dmrs(L, (tti0 + b) % 10, n_dmrs)
+        assert rc == 0 and np.array_equal(r, r_dev)  # same host arithmetic: identical floats
+        g = (0.5 * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))).astype(np.complex64)
+        k = np.arange(12 * L)
+        h = ((1.0 + 0.5 * np.cos(k / 25.0 + b)) * np.exp(1j * (b + k / 120.0))).astype(np.complex64)
+        for s_, sym in enumerate((3, 10)):
+            g[sym * nre + 12 * n_prb: sym * nre + 12 * (n_prb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grids[b] = g + (0.02 + 0.05 * b) * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))
+        refs.append(r)
+    rc, ce, res = q.estimate_pusch(grids, tti0, L, n_prb, n_dmrs)
+    assert rc == 0
+    for b in range(nsf):
+        ce_o, ores = np.zeros(ng, np.complex64), OrcChestUlRes()
+        assert oracle().orc_chest_ul_pusch(p(refs[b]), prb, L, n_prb, p(np.ascontiguousarray(grids[b])), p(ce_o), C.byref(ores)) == 0
+        assert_close_c(ce[b], ce_o, "ce sf %d" % b)
+        for j, nm in enumerate(("noise_estimate", "noise_estimate_dbm", "snr", "snr_db")):
+            x = getattr(ores, nm)
+            assert abs(res[b, j] - x) <= 1e-4 * abs(x) + 1e-5, (nm, res[b, j], x)
+    assert q.estimate_pusch(grids, tti0, 7, 0, 0)[0] == hp.SRSLTE_ERROR_INVALID_INPUTS  # 7 PRB is not a valid SC-FDMA size (chest_ul.c:278-281)
+    q.free()

@@ -168,3 +168,30 @@ def test_llr8_golden():
             r = oracle_rx(cfg, g["%s_iq_%d" % (tag, t)], t)
             assert r["ok"] == bool(g["%s_ok_%d" % (tag, t)][0]) and np.array_equal(r["iters"], g["%s_iters_%d" % (tag, t)])
             assert np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)])
+
+
+def test_chest_ul_golden():
+    """UL DMRS and PUSCH channel estimates against reference outputs (tests/gen_golden.py:extra)."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg
+    g = load("chest_ul.npz")
+    for n in range(4):
+        cell_id, prb, L, n_prb, cs, ds, gh, sh, tti, n_dmrs = (int(v) for v in g["meta_%d" % n])
+        o = OrcUlDmrs()
+        assert oracle().orc_ul_dmrs_init(C.byref(o), cell_id) == 0
+        cfg = OrcUlDmrsCfg(cs, ds, bool(gh), bool(sh))
+        r = np.zeros(2 * 12 * L, np.complex64)
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), L, tti % 10, n_dmrs, p(r)) == 0
+        assert np.abs(r - g["r_%d" % n]).max() <= 2e-6
+        nre = 12 * prb
+        ce, res = np.zeros(14 * nre, np.complex64), OrcChestUlRes()
+        assert oracle().orc_chest_ul_pusch(p(r), prb, L, n_prb, p(np.ascontiguousarray(g["grid_%d" % n])), p(ce), C.byref(res)) == 0
+        sel = np.concatenate([np.arange(l * nre + 12 * n_prb, l * nre + 12 * (n_prb + L)) for l in range(14)])
+        ref = g["ce_%d" % n]
+        assert np.abs(ce[sel] - ref).max() <= 1e-4 * np.abs(ref).max()
+        mask = np.ones(14 * nre, bool)
+        mask[sel] = False
+        assert np.all(ce[mask] == 0)  # nothing outside the grant is written
+        for x, y in zip((res.noise_estimate, res.noise_estimate_dbm, res.snr, res.snr_db), g["scal_%d" % n]):
+            assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
+    bad = np.zeros(48, np.complex64)
+    assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), 2, 0, 0, p(bad)) == -2

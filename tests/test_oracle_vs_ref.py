@@ -355,3 +355,61 @@ def test_whole_chain_two_rx_vs_reference_code(prb, mod, tbs, snr):
         assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]) and np.array_equal(r["tb"], o["tb"])
         nok += r["ok"]
     assert nok > 0
+
+
+@pytest.mark.parametrize("cell_id,prb", [(1, 6), (77, 25), (301, 100)])
+def test_ul_dmrs_pusch_vs_ref(cell_id, prb):
+    """srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): every float of the sequence, incl. group / sequence hopping and all
+    cyclic shifts. At 100 PRB the exponent's argument reaches 4e6 rad: one different rounding is a 0.5 rad phase error, so this pins the
+    exact operation order of the reference build."""
+    from _libs import OrcUlDmrs, OrcUlDmrsCfg
+    R = ref()
+    q = opaque(1 << 16)
+    assert R.srslte_refsignal_ul_init(q, prb) == 0 and R.srslte_refsignal_ul_set_cell(q, RefCell(prb, 1, cell_id, 0, 0, 0, 0)) == 0
+    o = OrcUlDmrs()
+    assert oracle().orc_ul_dmrs_init(C.byref(o), cell_id) == 0
+    worst = 0.0
+    for cfg in (OrcUlDmrsCfg(0, 0, False, False), OrcUlDmrsCfg(3, 7, True, False), OrcUlDmrsCfg(7, 29, False, True), OrcUlDmrsCfg(5, 13, True, True)):
+        for L in sorted({3, 4, 6, prb // 2 // 1 if oracle().orc_dft_precoding_valid_prb(prb // 2) else 3, prb if oracle().orc_dft_precoding_valid_prb(prb) else 6}):
+            for sf_idx, n_dmrs in ((0, 0), (3, 5), (9, 7)):
+                a, b = aligned(2 * 2 * 12 * L, np.float32), np.zeros(2 * 12 * L, np.complex64)
+                assert R.srslte_refsignal_dmrs_pusch_gen(q, C.byref(cfg), L, sf_idx, n_dmrs, p(a)) == 0
+                assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), L, sf_idx, n_dmrs, p(b)) == 0
+                worst = max(worst, float(np.abs(a.view(np.complex64) - b).max()))
+    assert worst <= 2e-6, worst
+    R.srslte_refsignal_ul_free(q)
+
+
+@pytest.mark.parametrize("cell_id,prb,L,n_prb", [(1, 6, 4, 1), (77, 25, 25, 0), (301, 100, 100, 0), (12, 50, 20, 17)])
+def test_chest_ul_pusch_vs_ref(cell_id, prb, L, n_prb):
+    """srslte_chest_ul_estimate_pusch (chest_ul.c:268-327) with the init defaults: ce on the granted PRBs of all 14 symbols, noise, SNR."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg, RefChestUlRes, ref_pusch_cfg, ref_ul_sf_cfg
+    R, rng = ref(), np.random.default_rng(cell_id + prb)
+    q = opaque(1 << 16)
+    assert R.srslte_chest_ul_init(q, prb) == 0 and R.srslte_chest_ul_set_cell(q, RefCell(prb, 1, cell_id, 0, 0, 0, 0)) == 0
+    dcfg = OrcUlDmrsCfg(2, 4, True, False)
+    R.srslte_chest_ul_pregen(q, C.byref(dcfg))
+    o = OrcUlDmrs()
+    oracle().orc_ul_dmrs_init(C.byref(o), cell_id)
+    nre, n = 12 * prb, 14 * 12 * prb
+    for tti, n_dmrs, nz in ((4, 3, 0.05), (19, 0, 0.3)):
+        r = np.zeros(2 * 12 * L, np.complex64)
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        grid = (0.5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        k = np.arange(12 * L)
+        h = ((1.5 + 0.4 * np.sin(k / 30.0)) * np.exp(1j * (0.4 + k / 150.0))).astype(np.complex64)
+        for s_, sym in enumerate((3, 10)):
+            grid[sym * nre + 12 * n_prb: sym * nre + 12 * (n_prb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grid = acopy((grid + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        ce_r, res = aligned(2 * n, np.float32), RefChestUlRes()
+        ce_r[:] = 0
+        res.ce = ce_r.ctypes.data
+        assert R.srslte_chest_ul_estimate_pusch(q, ref_ul_sf_cfg(tti), ref_pusch_cfg(L, n_prb, n_dmrs), p(grid), C.byref(res)) == 0
+        ce_o, ores = np.zeros(n, np.complex64), OrcChestUlRes()
+        assert oracle().orc_chest_ul_pusch(p(r), prb, L, n_prb, p(grid), p(ce_o), C.byref(ores)) == 0
+        a = ce_r.view(np.complex64)
+        assert np.abs(a - ce_o).max() <= 1e-4 * np.abs(a).max()
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr", "snr_db"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+    R.srslte_chest_ul_free(q)
