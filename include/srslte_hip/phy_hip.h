@@ -208,6 +208,30 @@ int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, u
 /* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d, 4 e (LLRs), 5 w, 6 cb iters */
 const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which);
 
+/* ------------------------------------------------------------------ PUSCH receive pipeline (eNB side): OFDM RX with the
+ * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +
+ * descramble + UL channel de-interleaver (pusch.c:423-520, sch.c:891-913,:991-1066) -> rate de-matching -> turbo decode -> TB CRC.
+ * UL-SCH data only (no UCI multiplexing), same allocation in both slots, normal CP, subframe not shortened, rv 0, 16-bit LLRs. */
+typedef struct srslte_hip_ul_rx srslte_hip_ul_rx_t;
+typedef struct {
+  uint32_t cell_id, nof_prb;
+  uint16_t rnti;
+  int      mod;            /* srslte_mod_t: QPSK, 16QAM, 64QAM */
+  uint32_t tbs;
+  uint32_t L_prb, n_prb, n_dmrs; /* grant: srslte_pusch_grant_t.L_prb / n_prb_tilde / n_dmrs (pusch_cfg.h:47-60) */
+  uint32_t max_iterations, max_batch;
+  int      mmse;           /* 1: noise_estimate from chest_ul (pusch.c:475) */
+  srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;
+} srslte_hip_ul_rx_cfg_t;
+srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
+void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
+/* d_iq: [nof_sf][15*N]; d_tb [nof_sf][tb_stride] (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf]; subframe b is TTI tti0 + b */
+int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
+                           uint8_t* d_tb_ok, void* stream);
+/* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest_ul res, 3 d (after de-precoding), 4 g (LLRs after
+ * the de-interleaver), 5 w, 6 cb iters, 7 cb ok, 8 cb bytes, 9 z (equalised) */
+const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q, int which);
+
 #ifdef __cplusplus
 }
 #endif

@@ -427,3 +427,51 @@ class DlRx:
         if self.h:
             lib().srslte_hip_dl_rx_destroy(self.h)
             self.h = None
+
+
+class UlRxCfg(C.Structure):
+    _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
+                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
+                ("dmrs_cfg", DmrsPuschCfg)]
+
+
+class UlRx:
+    """Batched PUSCH receive chain (enb_ul.c + pusch.c:423-520 + the UL-SCH part of sch.c:991-1066)."""
+
+    def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
+                 group_hopping=False, sequence_hopping=False, mmse=True):
+        self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0))
+        L = lib()
+        L.srslte_hip_ul_rx_create.restype = C.c_void_p
+        L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
+        L.srslte_hip_ul_rx_destroy.argtypes = [C.c_void_p]
+        L.srslte_hip_ul_rx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.srslte_hip_ul_rx_debug_buffer.restype = C.c_void_p
+        L.srslte_hip_ul_rx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
+        self.h = L.srslte_hip_ul_rx_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("srslte_hip_ul_rx_create failed")
+        self.tbs, self.max_batch = tbs, max_batch
+        self.tb_stride = (tbs // 8 + 6 + 15) & ~15
+        self.sf_len = 15 * symbol_sz(nof_prb)
+        self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+
+    def decode(self, iq, tti0=0):
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
+        din = DevBuf.from_host(x)
+        _check(lib().srslte_hip_ul_rx_batch(self.h, din.ptr, tti0, x.shape[0], self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "ul_rx_batch")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def debug(self, which, dtype, count):
+        ptr = lib().srslte_hip_ul_rx_debug_buffer(self.h, which)
+        out = np.empty(count, dtype)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_ul_rx_destroy(self.h)
+            self.h = None

@@ -486,3 +486,235 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
   q->grid_in = nullptr;
   return r;
 }
+
+// ====================================================================================================================
+// PUSCH receive pipeline (eNB side): OFDM RX with the -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul ->
+// RE extraction + one-tap MMSE (pusch.c:461-475) -> inverse transform precoding (:477-478) -> soft demap + descramble + UL
+// channel de-interleaver (:480-503, sch.c:891-913) -> rate de-matching -> turbo decode -> TB CRC (decode_tb, sch.c:429-500).
+// UL-SCH data only (no UCI multiplexing), same allocation in both slots, normal CP, not shortened, rv 0.
+// ====================================================================================================================
+namespace {
+
+struct PuschGeom {
+  int cell_nre, M_sc, n_prb, mod, Qm, tti0, scr_words, mmse;
+};
+
+__device__ __forceinline__ int pusch_data_symbol(int n) { return n < 3 ? n : (n < 9 ? n + 1 : n + 2); } // 12 data symbols skip l = 3, 10
+
+// grid = (ceil(M_sc/256), 12, nof_sf): z[sf][n][k] = y h* / (|h|^2 + noise) on the granted PRBs of data symbol n
+__global__ __launch_bounds__(256) void pusch_eq_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                       const float* __restrict__ noise /* stride 5 floats */, cf32* __restrict__ z, PuschGeom g)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z;
+  if (k >= g.M_sc) return;
+  const size_t o  = ((size_t)sf * 14 + pusch_data_symbol(n)) * g.cell_nre + g.n_prb * 12 + k;
+  const cf32   y = grid[o], h = ce[o];
+  const float  n0 = g.mmse ? noise[sf * 5] : 0.f;
+  const float  re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0; // precoding.c:277-288, scaling 1
+  z[((size_t)sf * 12 + n) * g.M_sc + k] = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+}
+
+// grid = (ceil(M_sc/256), 12, nof_sf): demap symbol (n, k), descramble in the received (symbol-major) bit order, and store at the
+// de-interleaved position: g[(k * 12 + n) * Qm + b] = q[(n * M_sc + k) * Qm + b] (36.212 5.2.2.8 without UCI)
+__global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict__ d, const uint32_t* __restrict__ scr, int16_t* __restrict__ gout,
+                                                          PuschGeom g)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
+  if (k >= g.M_sc) return;
+  const int nsym = 12 * g.M_sc, i = n * g.M_sc + k;
+  short     o[8];
+  demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
+  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
+  int16_t*        dst = gout + (size_t)sf * nsym * g.Qm + (size_t)(k * 12 + n) * g.Qm;
+  for (int b = 0; b < g.Qm; b++) {
+    const int bit = i * g.Qm + b;
+    short     v   = o[b];
+    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (short)-v;
+    dst[b] = v;
+  }
+}
+
+} // namespace
+
+struct srslte_hip_ul_rx {
+  srslte_hip_ul_rx_cfg_t cfg;
+  srslte_hip_ofdm_t*     ofdm;
+  srslte_hip_chest_ul_t* chest;
+  srslte_hip_tdec_t*     tdec;
+  srslte_hip_cbsegm_t    seg;
+  PuschGeom              pg;
+  RmGeom                 rg;
+  TbGeom                 tg;
+  uint32_t               W, in_stride;
+  uint32_t *             d_scr, *d_rm_tbl, *d_tbcrc, *d_tb_rem, *d_cb_syn, *d_cb_iters;
+  cf32 *                 d_grid, *d_ce, *d_z, *d_d;
+  float*                 d_res; // [B] x srslte_hip_chest_ul_res_t
+  int16_t *              d_g, *d_w;
+  uint8_t *              d_cb_bytes, *d_cb_ok;
+};
+
+extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
+{
+  if (!q) return;
+  srslte_hip_ofdm_destroy(q->ofdm);
+  srslte_hip_chest_ul_destroy(q->chest);
+  srslte_hip_tdec_destroy(q->tdec);
+  void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
+                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok};
+  for (void* b : bufs) {
+    if (b) (void)hipFree(b);
+  }
+  delete q;
+}
+
+extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg)
+{
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->max_iterations == 0 || cfg->L_prb < 3 ||
+      cfg->n_prb + cfg->L_prb > cfg->nof_prb || !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
+    fprintf(stderr, "[srslte_hip] ul_rx: invalid configuration\n");
+    return nullptr;
+  }
+  auto* q = new srslte_hip_ul_rx();
+  memset(q, 0, sizeof(*q));
+  q->cfg = *cfg;
+  if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
+    fprintf(stderr, "[srslte_hip] ul_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    delete q;
+    return nullptr;
+  }
+  const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
+  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
+  q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
+  q->chest = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
+  q->tdec  = srslte_hip_tdec_create(K, B * C);
+  bool ok  = q->ofdm && q->chest && q->tdec && srslte_hip_ofdm_set_freq_shift(q->ofdm, -0.5f) == SRSLTE_SUCCESS; // enb_ul.c:62-63 (no normalisation)
+  if (ok) { // srslte_sequence_pusch (sequences.c:65-67), one sequence per subframe index
+    std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
+    std::vector<uint8_t>  c;
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, nbits, c);
+      for (uint32_t i = 0; i < nbits; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
+    }
+    ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
+  }
+  q->W         = srslte_hip_tdec_autoimp_get_subblocks(K);
+  q->in_stride = (srslte_hip_tdec_input_len(K, q->W != 0) + 31) & ~31u;
+  if (ok) { // rate-dematching table in the decoder's input layout (rm_turbo.c:160-260), as for the PDSCH
+    std::vector<uint32_t> t;
+    lte_rm_rx_table(K, 0, t);
+    if (q->W) {
+      for (auto& v : t) {
+        v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
+      }
+    }
+    std::vector<uint32_t> inv(q->in_stride, 0xffffffffu);
+    for (uint32_t n = 0; n < t.size(); n++) inv[t[n]] = n;
+    ok = upload(&q->d_rm_tbl, inv) == SRSLTE_SUCCESS;
+  }
+  if (ok) {
+    std::vector<uint32_t> rem(cfg->tbs + 24);
+    uint32_t              v = 1;
+    for (int j = (int)cfg->tbs + 23; j >= 0; j--) {
+      rem[j] = v;
+      v <<= 1;
+      if (v & 0x1000000) v ^= 0x1864CFB;
+    }
+    ok = upload(&q->d_tbcrc, rem) == SRSLTE_SUCCESS;
+    if (ok && q->W) {
+      const uint32_t        rlen = C == 1 ? K : K - 24, Lw = K / q->W;
+      std::vector<uint32_t> t((size_t)C * K, 0);
+      for (uint32_t c = 0; c < C; c++) {
+        for (uint32_t n = 0; n < rlen; n++) {
+          const uint32_t pos = c * rlen + n;
+          if (pos < cfg->tbs + 24) t[(size_t)c * K + (n % Lw) * q->W + n / Lw] = rem[pos];
+        }
+      }
+      ok = upload(&q->d_tb_rem, t) == SRSLTE_SUCCESS && hipMalloc((void**)&q->d_cb_syn, sizeof(uint32_t) * B * C) == hipSuccess;
+    }
+  }
+  const size_t glen = (size_t)14 * 12 * P;
+  ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B) == hipSuccess && hipMemset(q->d_ce, 0, sizeof(cf32) * glen * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_z, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_res, sizeof(float) * 5 * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_g, sizeof(int16_t) * (size_t)nbits * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[srslte_hip] ul_rx: initialisation failed\n");
+    srslte_hip_ul_rx_destroy(q);
+    return nullptr;
+  }
+  q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
+  q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse;
+  q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride;
+  q->rg.out_len = (int)(3 * K + 12);
+  q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re;
+  q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
+  return q;
+}
+
+extern "C" const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q, int which)
+{
+  if (!q) return nullptr;
+  switch (which) {
+    case 0: return q->d_grid;
+    case 1: return q->d_ce;
+    case 2: return q->d_res;
+    case 3: return q->d_d;
+    case 4: return q->d_g;
+    case 5: return q->d_w;
+    case 6: return q->d_cb_iters;
+    case 7: return q->d_cb_ok;
+    case 8: return q->d_cb_bytes;
+    case 9: return q->d_z;
+  }
+  return nullptr;
+}
+
+// d_iq: [nof_sf][15*N]; outputs as srslte_hip_dl_rx_batch. Subframe b is TTI tti0 + b.
+extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
+                                      uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  hipStream_t    st = (hipStream_t)stream;
+  const uint32_t C = q->seg.C, K = q->seg.K1;
+  int            r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
+  if (r) return r;
+  r = srslte_hip_chest_ul_estimate_pusch_batch(q->chest, tti0, q->cfg.L_prb, q->cfg.n_prb, q->cfg.n_dmrs, q->d_grid, q->d_ce, q->d_res, (int)nof_sf,
+                                               stream);
+  if (r) return r;
+  PuschGeom g = q->pg;
+  g.tti0      = (int)tti0;
+  const dim3 grid(ceil_div(g.M_sc, 256), 12, nof_sf);
+  hipLaunchKernelGGL(pusch_eq_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_grid, (const cf32*)q->d_ce, (const float*)q->d_res, q->d_z, g);
+  LAUNCH_CHECK();
+  r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, 12 * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
+  if (r) return r;
+  hipLaunchKernelGGL(pusch_demod_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
+  LAUNCH_CHECK();
+  RmGeom rg = q->rg;
+  rg.tti0   = (int)tti0;
+  hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(rg.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w,
+                     (const uint32_t*)q->d_rm_tbl, rg);
+  LAUNCH_CHECK();
+  tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
+  r = tdec_run_batch_w(q->tdec, q->d_w, 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations, C > 1 ? 0x1800063u : 0x1864CFBu,
+                       C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
+  if (r) return r;
+  TbGeom tg    = q->tg;
+  tg.tb_stride = (int)tb_stride;
+  if (q->d_tb_rem) {
+    hipLaunchKernelGGL(tb_asm_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+                       (const uint32_t*)q->d_cb_syn, d_tb, d_tb_ok, tg);
+  } else {
+    hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)q->d_cb_bytes, (const uint8_t*)q->d_cb_ok,
+                       (const uint32_t*)q->d_tbcrc, d_tb, d_tb_ok, tg);
+  }
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}

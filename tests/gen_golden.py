@@ -247,6 +247,23 @@ def extra():
     np.savez_compressed(os.path.join(OUT, "chest_ul.npz"), **ul)
     print("chest_ul.npz", os.path.getsize(os.path.join(OUT, "chest_ul.npz")), "bytes")
 
+    # ---------------- PUSCH receive chain on reference code (RefUlRx): IQ in, TB / CRC / per-block passes out
+    from lte_sim import RefUlRx, UlConfig, make_ul_subframe
+    rng = np.random.default_rng(2026100304)
+    uc = {}
+    for tag, (prb, L, n_prb, mod, tbs, snr, ttis) in {"a": (6, 6, 0, 1, 1000, 4.0, (2, 7)), "b": (25, 10, 5, 2, 4008, 10.0, (9,)),
+                                                      "c": (100, 48, 20, 3, 30576, 17.5, (4,))}.items():
+        cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True)
+        chain = RefUlRx(cfg)
+        for t in ttis:
+            iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j))
+            r = chain.run(iq, t)
+            assert r["ok"], "fixture subframes are chosen to decode (a failing block amplifies the reference's 12-bit reciprocal)"
+            uc["%s_iq_%d" % (tag, t)], uc["%s_tb_%d" % (tag, t)] = iq.astype(np.complex64), r["tb"].copy()
+            uc["%s_iters_%d" % (tag, t)], uc["%s_data_%d" % (tag, t)] = r["iters"].copy(), data
+    np.savez_compressed(os.path.join(OUT, "ul_chain.npz"), **uc)
+    print("ul_chain.npz", os.path.getsize(os.path.join(OUT, "ul_chain.npz")), "bytes")
+
 
 if __name__ == "__main__":
     if "--extra-only" not in sys.argv:

@@ -237,6 +237,15 @@ class RefRx:
             self.scr[(sf_idx, nbits)] = scramble_seq(cfg, sf_idx, nbits).astype(bool)
         ev = e[:nbits]
         ev[self.scr[(sf_idx, nbits)]] *= -1  # wraps -(-128) / -(-32768) like the reference's sign instructions
+        return ref_sch_decode(self, e, nbits)
+
+
+def ref_sch_decode(self, e, nbits):
+    """decode_tb / decode_tb_cb (sch.c:299-500) on the reference's rm_turbo / tdec / crc objects held by `self` (a RefRx or RefUlRx)."""
+    cfg, R = self.cfg, self.R
+    llr8 = getattr(cfg, "llr8", False)
+    lt = np.int8 if llr8 else np.int16
+    if True:
         s = cfg.seg
         tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
         iters, all_ok = np.zeros(s.C, np.uint32), True
@@ -252,12 +261,12 @@ class RefRx:
             w = self.aligned(3 * (K + 32) + 12 + 64, lt)
             ein = self.aligned(n_e2 + 64, lt)
             ein[:n_e2] = e[rp:rp + n_e2]
-            assert (R.srslte_rm_turbo_rx_lut_8bit if cfg.llr8 else R.srslte_rm_turbo_rx_lut)(p(ein), p(w), n_e2, R.srslte_cbsegm_cbindex(K), 0) == 0
+            assert (R.srslte_rm_turbo_rx_lut_8bit if llr8 else R.srslte_rm_turbo_rx_lut)(p(ein), p(w), n_e2, R.srslte_cbsegm_cbindex(K), 0) == 0
             assert R.srslte_tdec_new_cb(self.tdec, K) == 0
             out = tb[cb * rlen // 8:]
             ok, noi = False, 0
             while noi < cfg.max_iter and not ok:
-                (R.srslte_tdec_iteration_8bit if cfg.llr8 else R.srslte_tdec_iteration)(self.tdec, p(w), p(out))
+                (R.srslte_tdec_iteration_8bit if llr8 else R.srslte_tdec_iteration)(self.tdec, p(w), p(out))
                 noi += 1
                 if s.C > 1:
                     ok = R.srslte_crc_checksum_byte(self.crc_cb, p(out), K) == 0
@@ -270,3 +279,158 @@ class RefRx:
             par_tx = (int(tb[cfg.tbs // 8]) << 16) | (int(tb[cfg.tbs // 8 + 1]) << 8) | int(tb[cfg.tbs // 8 + 2])
             all_ok = par_rx == par_tx and par_rx != 0
         return {"tb": tb[:cfg.tbs // 8 + 3], "ok": all_ok, "iters": iters}
+
+
+# ------------------------------------------------------------------------------------------------------------------ UL
+class UlConfig:
+    """One PUSCH configuration: UL-SCH data only (no UCI), same allocation in both slots, rv 0, normal CP, not shortened."""
+
+    def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0,
+                 group_hopping=False, sequence_hopping=False):
+        from _libs import OrcUlDmrs, OrcUlDmrsCfg
+        self.nof_prb, self.cell_id, self.mod, self.tbs, self.L_prb, self.n_prb, self.n_dmrs = nof_prb, cell_id, mod, tbs, L_prb, n_prb, n_dmrs
+        self.rnti, self.max_iter = rnti, max_iter
+        self.Qm = MOD_BITS[mod]
+        self.nre = 12 * nof_prb
+        self.grid_len = 14 * self.nre
+        self.M_sc = 12 * L_prb
+        self.nof_re = 12 * self.M_sc          # 12 data symbols (pusch.c:52-91)
+        self.nbits = self.nof_re * self.Qm
+        self.N = oracle().orc_symbol_sz(nof_prb)
+        self.sf_len = 15 * self.N
+        self.dmrs_cfg = OrcUlDmrsCfg(cyclic_shift, delta_ss, group_hopping, sequence_hopping)
+        self.dmrs = OrcUlDmrs()
+        assert oracle().orc_ul_dmrs_init(C.byref(self.dmrs), cell_id) == 0
+        self.seg = OrcCbsegm()
+        assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
+        self.data_syms = [l for l in range(14) if l not in (3, 10)]
+        # UL channel interleaver without UCI (36.212 5.2.2.8, sch.c:580-598,:891-913): q[(i*R + j)*Qm + k] = g[(j*12 + i)*Qm + k]
+        j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(12), np.arange(self.Qm), indexing="ij")
+        self.q_of_g = ((i * self.M_sc + j) * self.Qm + k).reshape(-1)  # g index (j, i, k) row-major -> q index
+
+    def r_dmrs(self, sf_idx):
+        r = np.zeros(2 * self.M_sc, np.complex64)
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(self.dmrs), C.byref(self.dmrs_cfg), self.L_prb, sf_idx, self.n_dmrs, p(r)) == 0
+        return r
+
+    def scramble(self, sf_idx):
+        c = np.zeros(self.nbits, np.uint8)
+        oracle().orc_gold(C.c_uint32(oracle().orc_pdsch_cinit(self.rnti, 0, sf_idx, self.cell_id)), self.nbits, p(c))  # sequences.c:65-67
+        return c
+
+
+def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j):
+    """UE transmit side of pusch.c:314-421 (UL-SCH only): returns (iq[sf_len], payload bytes)."""
+    orc = oracle()
+    sf_idx = tti % 10
+    data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+    g = np.zeros(cfg.nbits, np.uint8)
+    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(g)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
+    q = np.zeros(cfg.nbits, np.uint8)
+    q[cfg.q_of_g] = g
+    q ^= cfg.scramble(sf_idx)
+    d = np.zeros(cfg.nof_re, np.complex64)
+    orc.orc_modulate(cfg.mod, p(q), p(d), cfg.nbits)
+    z = np.zeros_like(d)
+    orc.orc_dft_precoding(p(d), p(z), cfg.L_prb, 12, 1, True)
+    grid = np.zeros(cfg.grid_len, np.complex64)
+    for n, l in enumerate(cfg.data_syms):
+        grid[l * cfg.nre + 12 * cfg.n_prb: l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc] = z[n * cfg.M_sc:(n + 1) * cfg.M_sc]
+    r = cfg.r_dmrs(sf_idx)
+    for s_, l in enumerate((3, 10)):
+        grid[l * cfg.nre + 12 * cfg.n_prb: l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc] = r[s_ * cfg.M_sc:(s_ + 1) * cfg.M_sc]
+    tx = OrcOfdm()
+    orc.orc_ofdm_init(C.byref(tx), cfg.nof_prb, True)
+    tx.normalize, tx.freq_shift, tx.freq_shift_f = True, True, 0.5  # ue_ul.c:63-64
+    iq = np.zeros(cfg.sf_len, np.complex64)
+    orc.orc_ofdm_tx_sf(C.byref(tx), p(grid), p(iq))
+    iq = iq * np.complex64(amp * gain)
+    if snr_db is not None:
+        sigma = np.sqrt(amp * amp * abs(gain) ** 2 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr_db / 20)
+        iq = iq + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
+    return iq.astype(np.complex64), data
+
+
+def oracle_ul_rx(cfg, iq, tti, keep=False):
+    """eNB receive side: enb_ul.c:58-63 OFDM settings, srslte_chest_ul_estimate_pusch, srslte_pusch_decode (pusch.c:423-520) and the
+    UL-SCH part of srslte_ulsch_decode (sch.c:991-1066) without UCI."""
+    from _libs import OrcChestUlRes
+    orc = oracle()
+    sf_idx = tti % 10
+    rxo = OrcOfdm()
+    orc.orc_ofdm_init(C.byref(rxo), cfg.nof_prb, True)
+    rxo.normalize, rxo.freq_shift, rxo.freq_shift_f = False, True, -0.5
+    grid = np.zeros(cfg.grid_len, np.complex64)
+    orc.orc_ofdm_rx_sf(C.byref(rxo), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
+    ce, res = np.zeros(cfg.grid_len, np.complex64), OrcChestUlRes()
+    assert orc.orc_chest_ul_pusch(p(cfg.r_dmrs(sf_idx)), cfg.nof_prb, cfg.L_prb, cfg.n_prb, p(grid), p(ce), C.byref(res)) == 0
+    sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prb, l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc) for l in cfg.data_syms])
+    y, h = np.ascontiguousarray(grid[sel]), np.ascontiguousarray(ce[sel])
+    z, d = np.zeros(cfg.nof_re, np.complex64), np.zeros(cfg.nof_re, np.complex64)
+    orc.orc_predecoding_single(p(y), p(h), p(z), cfg.nof_re, 1.0, res.noise_estimate)
+    orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, 12, 0, True)
+    qllr = np.zeros(cfg.nbits, np.int16)
+    orc.orc_demod_soft_s(cfg.mod, p(d), p(qllr), cfg.nof_re)
+    orc.orc_scramble_s(p(qllr), p(cfg.scramble(sf_idx)), cfg.nbits)
+    g = np.ascontiguousarray(qllr[cfg.q_of_g])  # ulsch_deinterleave: g[n] = q[lut^-1]
+    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+    tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+    rc = orc.orc_dlsch_decode(C.byref(sch), p(g), p(tb), p(iters), p(cbok))
+    out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
+    if keep:
+        out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res)
+    return out
+
+
+class RefUlRx:
+    """eNB PUSCH receive chain on the REFERENCE's compiled code for every stage it holds (srslte_chest_ul_estimate_pusch,
+    srslte_predecoding_single, srslte_demod_soft_demodulate_s, rm_turbo / tdec / crc); the FFT and the transform de-precoding are the
+    oracle's (FFTW is absent), RE extraction, descrambling and the UL deinterleaver are numpy one-liners."""
+
+    def __init__(self, cfg):
+        from _libs import RefCell, RefChestUlRes, aligned, opaque, ref, ref_pusch_cfg
+        self.R = ref()
+        assert self.R is not None, "oracle/_ref/libsrslte_ref.so is not built"
+        R = self.R
+        self.cfg, self.aligned = cfg, aligned
+        self.chest = opaque(1 << 16)
+        assert R.srslte_chest_ul_init(self.chest, cfg.nof_prb) == 0
+        assert R.srslte_chest_ul_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
+        R.srslte_chest_ul_pregen(self.chest, C.byref(cfg.dmrs_cfg))
+        self.pcfg = ref_pusch_cfg(cfg.L_prb, cfg.n_prb, cfg.n_dmrs)
+        self.res = RefChestUlRes()
+        self.ce = aligned(2 * cfg.grid_len, np.float32)
+        self.res.ce = self.ce.ctypes.data
+        self.tdec = opaque(1 << 20)
+        assert R.srslte_tdec_init(self.tdec, 6144) == 0
+        self.crc_tb, self.crc_cb = opaque(4096), opaque(4096)
+        R.srslte_crc_init(self.crc_tb, 0x1864CFB, 24)
+        R.srslte_crc_init(self.crc_cb, 0x1800063, 24)
+        R.srslte_crc_checksum_byte.restype = C.c_uint32
+        R.srslte_cbsegm_cbindex.restype = C.c_int
+        self.q = OrcOfdm()
+        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, True)
+        self.q.normalize, self.q.freq_shift, self.q.freq_shift_f = False, True, -0.5
+        self.sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prb, l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc) for l in cfg.data_syms])
+
+    def run(self, iq, tti):
+        from _libs import ref_ul_sf_cfg
+        cfg, R, orc = self.cfg, self.R, oracle()
+        grid = self.aligned(2 * cfg.grid_len, np.float32)
+        orc.orc_ofdm_rx_sf(C.byref(self.q), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
+        self.ce[:] = 0
+        assert R.srslte_chest_ul_estimate_pusch(self.chest, ref_ul_sf_cfg(tti), self.pcfg, p(grid), C.byref(self.res)) == 0
+        n = cfg.nof_re
+        y, h, z = self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32), self.aligned(2 * n, np.float32)
+        y.view(np.complex64)[:] = grid.view(np.complex64)[self.sel]
+        h.view(np.complex64)[:] = self.ce.view(np.complex64)[self.sel]
+        R.srslte_predecoding_single(p(y), p(h), p(z), None, n, 1.0, self.res.noise_estimate)
+        d = self.aligned(2 * n, np.float32)
+        orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, 12, 0, True)
+        q = self.aligned(cfg.nbits + 64, np.int16)
+        R.srslte_demod_soft_demodulate_s(cfg.mod, p(d), p(q), n)
+        qv = q[:cfg.nbits]
+        qv[cfg.scramble(tti % 10).astype(bool)] *= -1
+        g = np.ascontiguousarray(qv[cfg.q_of_g])
+        return ref_sch_decode(self, g, cfg.nbits)

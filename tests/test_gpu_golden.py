@@ -136,3 +136,19 @@ def test_chest_ul_golden(hp):
             assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
         assert q.dmrs(2, 0, 0)[0] == hp.SRSLTE_ERROR  # tabulated 1-/2-PRB sequences are not provided
         q.free()
+
+
+UL_CASES = (("a", 6, 6, 0, 1, 1000, (2, 7)), ("b", 25, 10, 5, 2, 4008, (9,)), ("c", 100, 48, 20, 3, 30576, (4,)))
+
+
+def test_ul_chain_golden(hp):
+    """PUSCH receive chain on the device against the reference-code chain's outputs."""
+    g = load("ul_chain.npz")
+    for tag, prb, L, n_prb, mod, tbs, ttis in UL_CASES:
+        rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, 1, 2, 5, True, False)
+        rc, seg = hp.cbsegm(tbs)
+        for t in ttis:
+            tb, ok = rx.decode(g["%s_iq_%d" % (tag, t)][None, :], t)
+            assert ok[0] == 1 and np.array_equal(tb[0], g["%s_tb_%d" % (tag, t)])
+            assert np.array_equal(rx.debug(6, np.uint32, seg.C), g["%s_iters_%d" % (tag, t)])
+        rx.free()

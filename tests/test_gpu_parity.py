@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from _libs import OrcCell, OrcChestCfg, OrcChestRes, OrcOfdm, acopy, oracle, p
-from lte_sim import DlConfig, make_subframe, oracle_rx
+from lte_sim import DlConfig, UlConfig, make_subframe, make_ul_subframe, oracle_rx, oracle_ul_rx
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -638,3 +638,40 @@ def test_chest_ul_pusch_batch(hp, cell_id, prb, L, n_prb):
             assert abs(res[b, j] - x) <= 1e-4 * abs(x) + 1e-5, (nm, res[b, j], x)
     assert q.estimate_pusch(grids, tti0, 7, 0, 0)[0] == hp.SRSLTE_ERROR_INVALID_INPUTS  # 7 PRB is not a valid SC-FDMA size (chest_ul.c:278-281)
     q.free()
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf", [(6, 6, 0, 1, 1000, 3.5, 2, 4), (25, 10, 5, 2, 4008, 9.5, 8, 4), (100, 100, 0, 2, 43816, 12.5, 0, 3),
+                                                                (100, 48, 20, 3, 30576, 17.0, 7, 3), (100, 100, 0, 2, 43816, 9.0, 5, 2)])
+def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
+    """eNB PUSCH receive chain on the device (cfg3's receive side) vs the oracle chain on identical IQ: grid, ce, noise,
+    equalised and de-precoded symbols, de-interleaved LLRs, per-block pass counts, CRC flags and TB bytes."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(1100 + prb + L + int(snr * 10))
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j)) for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    grid = rx.debug(0, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    ce = rx.debug(1, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    res = rx.debug(2, np.float32, nsf * 5).reshape(nsf, 5)
+    d = rx.debug(3, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True)
+        assert_close_c(grid[b], r["grid"], "grid sf %d" % b)
+        assert_close_c(ce[b], r["ce"], "ce sf %d" % b)
+        assert abs(res[b, 0] - r["noise"]) <= 1e-4 * abs(r["noise"])
+        assert_close_c(d[b], r["d"], "d sf %d" % b)
+        diff = np.abs(g[b].astype(np.int32) - r["g"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"] or diff.max() == 0:
+            assert np.array_equal(tb[b], r["tb"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0 or snr < 9.5
+    rx.free()

@@ -195,3 +195,18 @@ def test_chest_ul_golden():
             assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
     bad = np.zeros(48, np.complex64)
     assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), 2, 0, 0, p(bad)) == -2
+
+
+UL_CASES = (("a", 6, 6, 0, 1, 1000, (2, 7)), ("b", 25, 10, 5, 2, 4008, (9,)), ("c", 100, 48, 20, 3, 30576, (4,)))
+
+
+def test_ul_chain_golden():
+    """PUSCH receive chain against the reference-code chain's outputs (tests/gen_golden.py:extra)."""
+    from lte_sim import UlConfig, oracle_ul_rx
+    g = load("ul_chain.npz")
+    for tag, prb, L, n_prb, mod, tbs, ttis in UL_CASES:
+        cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True)
+        for t in ttis:
+            r = oracle_ul_rx(cfg, g["%s_iq_%d" % (tag, t)], t)
+            assert r["ok"] and np.array_equal(r["iters"], g["%s_iters_%d" % (tag, t)]) and np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)])
+            assert np.array_equal(r["tb"][:tbs // 8], g["%s_data_%d" % (tag, t)])
