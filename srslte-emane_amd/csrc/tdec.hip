@@ -722,9 +722,15 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
           *ext2 = wk + 6 * a.Kp;
   // beta checkpoints (lane-private columns): ceil(Lw / CKPT) + 1 rows per half; Lw <= MAX_K / W (two halves for W = 32)
   constexpr int BETA_ROWS = (W == 32 ? 2 : 1) * (SRSLTE_HIP_MAX_K / W / CKPT + 2);
-  __shared__ pk_t beta[BETA_ROWS * 64];
-  __shared__ pk_t seg[(CKPT + 1) * 64];                          // beta metrics of the segment being consumed
-  __shared__ __attribute__((aligned(16))) pk_t mt[ST_TOTAL];     // branch-metric staging (Stage)
+  // One LDS pool: beta checkpoints | beta metrics of the segment being consumed | branch-metric staging (Stage). Between SISO
+  // passes the front of it (everything but the staging area's constant zero region) doubles as the buffer in which the
+  // interleaver permutations are done: a 2-byte scatter costs the L1 one cache line per lane (64 cycles per wavefront
+  // instruction), an LDS scatter a few bank-conflict cycles.
+  constexpr int POOL_BETA = BETA_ROWS * 64, POOL_SEG = (CKPT + 1) * 64;
+  __shared__ __attribute__((aligned(16))) pk_t pool[POOL_BETA + POOL_SEG + ST_TOTAL];
+  pk_t *                                       beta = pool, *seg = pool + POOL_BETA, *mt = pool + POOL_BETA + POOL_SEG;
+  int16_t*                                     perm = reinterpret_cast<int16_t*>(pool);
+  static_assert(2 * (POOL_BETA + POOL_SEG + 2 * ST_BUF) >= SRSLTE_HIP_MAX_K, "permutation buffer must hold one code block");
   Stage st;
   stage_init(st, mt, L);
   pk_t*           xy = reinterpret_cast<pk_t*>(a.xy + (size_t)cb * a.K); // 16 B per trellis step: room for the x, y and x + y arrays
@@ -805,8 +811,10 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
             const v8s e = sub ? vsub8(i8, t.a, t.b) : t.a;
             if (sub) st8(ext1, i8, e);
 #pragma unroll
-            for (int j = 0; j < 8; j++) app2[t.c[j]] = e[j];
+            for (int j = 0; j < 8; j++) perm[t.c[j]] = e[j];
           });
+      __syncthreads();
+      for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app2, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
       __syncthreads();
       if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K);
       __syncthreads();
@@ -814,8 +822,10 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
           L.lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
           [&](int i8, V8x3 t) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) app1[t.c[j]] = t.a[j];
+            for (int j = 0; j < 8; j++) perm[t.c[j]] = t.a[j];
           });
+      __syncthreads();
+      for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app1, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
       dec = app1;
     }
     __syncthreads();
