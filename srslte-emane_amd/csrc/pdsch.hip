@@ -134,6 +134,45 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   *reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j) = word;
 }
 
+// Same result with the code block's LLR segment staged in LDS: one workgroup per code block copies its n_e LLRs with 16-byte
+// loads, then every thread produces eight adjacent soft-buffer slots (one 16-byte store) from LDS gathers. A 2-byte global gather
+// costs the L1 one cache line per lane; the LDS gather a few bank-conflict cycles. Used when the segment fits (RM_LDS_MAX LLRs).
+constexpr int RM_LDS_MAX = 16 * 1024; // int16 LLRs: 32 KB of LDS
+__global__ __launch_bounds__(256) void rm_rx_lds_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ inv,
+                                                        RmGeom g)
+{
+  __shared__ __attribute__((aligned(16))) int16_t seg[RM_LDS_MAX + 8];
+  const int cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C;
+  const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)];
+  const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
+  int       rp = cb * n_e, n_e2 = n_e;
+  if (cb > g.C - gamma) { // sch.c:331-334
+    n_e2 = n_e + g.Qm;
+    rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
+  }
+  const int16_t* src = e + (size_t)sf * g.max_bits + rp;
+  // the segment starts at an arbitrary (even) LLR index: copy from the 16-byte boundary below it
+  const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / 2);
+  const int4* s4 = reinterpret_cast<const int4*>(src - mis);
+  for (int i = threadIdx.x; i < (n_e2 + mis + 7) / 8; i += blockDim.x) reinterpret_cast<int4*>(seg)[i] = s4[i];
+  __syncthreads();
+  const int16_t* ls = seg + mis;
+  for (int j8 = threadIdx.x; j8 < g.w_stride / 8; j8 += blockDim.x) {
+    const uint4 t0 = *reinterpret_cast<const uint4*>(inv + 8 * j8), t1 = *reinterpret_cast<const uint4*>(inv + 8 * j8 + 4);
+    const uint32_t n[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+    uint32_t       o[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+      int acc = 0;
+      if (n[s] != 0xffffffffu) {
+        for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += ls[i];
+      }
+      o[s >> 1] |= ((uint32_t)acc & 0xffffu) << (16 * (s & 1));
+    }
+    *reinterpret_cast<uint4*>(w + (size_t)cbg * g.w_stride + 8 * j8) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 struct TbGeom {
   int C, K, tbs, rlen, cb_stride, tb_stride;
 };
@@ -208,6 +247,14 @@ __global__ __launch_bounds__(256) void tb_asm_kernel(const uint8_t* __restrict__
     ok        = ok && syn == 0 && (src(g.tbs / 8) | src(g.tbs / 8 + 1) | src(g.tbs / 8 + 2));
     tb_ok[sf] = ok ? 1 : 0;
   }
+}
+
+// largest segment of any subframe class + the Qm extra LLRs of the last blocks must fit the LDS kernel; w_stride is a multiple of 32
+bool rm_fits_lds(const RmGeom& g)
+{
+  int mx = g.nof_re[0] > g.nof_re[1] ? g.nof_re[0] : g.nof_re[1];
+  mx     = mx > g.nof_re[2] ? mx : g.nof_re[2];
+  return g.Qm * (mx / g.C) + g.Qm + 8 <= RM_LDS_MAX;
 }
 
 // pdsch.c:81-206 as a per-RE rule (see oracle/orc_pdsch.c for the derivation): symbol-major, sub-carrier ascending,
@@ -363,7 +410,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
        hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
        hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)max_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
-       hipMalloc((void**)&q->d_e, sizeof(int16_t) * (size_t)max_bits * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_e, sizeof(int16_t) * ((size_t)max_bits * B + 16)) == hipSuccess /* +16: rm_rx_lds_kernel reads whole 16-byte words */ &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
@@ -436,8 +483,12 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
         hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div(g.w_stride, 1024), nof_sf * C), dim3(256), 0, st, (const int8_t*)q->d_e,
                            (int8_t*)q->d_w, (const uint32_t*)q->d_rm_tbl, g);
       } else {
-        hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e,
-                           q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+        if (rm_fits_lds(g)) {
+          hipLaunchKernelGGL(rm_rx_lds_kernel, dim3(nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+        } else {
+          hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e,
+                             q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+        }
       }
       LAUNCH_CHECK();
       return SRSLTE_SUCCESS;
@@ -638,7 +689,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_z, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_res, sizeof(float) * 5 * B) == hipSuccess &&
-       hipMalloc((void**)&q->d_g, sizeof(int16_t) * (size_t)nbits * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_g, sizeof(int16_t) * ((size_t)nbits * B + 16)) == hipSuccess &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
@@ -699,8 +750,12 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   LAUNCH_CHECK();
   RmGeom rg = q->rg;
   rg.tti0   = (int)tti0;
-  hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(rg.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w,
-                     (const uint32_t*)q->d_rm_tbl, rg);
+  if (rm_fits_lds(rg)) {
+    hipLaunchKernelGGL(rm_rx_lds_kernel, dim3(nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w, (const uint32_t*)q->d_rm_tbl, rg);
+  } else {
+    hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(rg.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w,
+                       (const uint32_t*)q->d_rm_tbl, rg);
+  }
   LAUNCH_CHECK();
   tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
   r = tdec_run_batch_w(q->tdec, q->d_w, 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations, C > 1 ? 0x1800063u : 0x1864CFBu,
