@@ -34,6 +34,23 @@ typedef int   pk_t; // two int16 lanes: lo = first window of the pair, hi = seco
 #ifndef TDEC_EWU
 #define TDEC_EWU 4 // 16-byte elements in flight per lane in the element-wise phases
 #endif
+// -DTDEC_PROF: per-phase s_memtime accounting of the windowed kernels (diagnostic build only; stamps cost ~10 %)
+#ifdef TDEC_PROF
+#define PROF_DECL unsigned long long prof_t0 = __builtin_readcyclecounter(), prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i)                                               \
+  {                                                           \
+    const unsigned long long t_ = __builtin_readcyclecounter(); \
+    prof_acc[i] += t_ - prof_t0;                              \
+    prof_t0 = t_;                                             \
+  }
+#define PROF_ARGS , unsigned long long& prof_t0, unsigned long long* prof_acc
+#define PROF_PASS , prof_t0, prof_acc
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_ARGS
+#define PROF_PASS
+#endif
 constexpr int TD_INF      = 10000;
 constexpr int SRSLTE_HIP_MAX_K = 6144;
 constexpr int WIN_OVERLAP = 40;
@@ -207,6 +224,7 @@ struct TdecArgs {
   const uint32_t* tb_rem;      // optional [tb_C][K] remainders for the TB CRC share of each block (array order), else nullptr
   uint32_t        tb_C;
   uint32_t*       tb_syn;      // [nof_cb] out
+  unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
 };
@@ -334,7 +352,10 @@ __device__ __forceinline__ void stage_store(const Stage& st, int buf, int n, con
     *reinterpret_cast<int4*>(d + ST_ARR)     = r.b;
     *reinterpret_cast<int4*>(d + 2 * ST_ARR) = r.c;
   }
-  __syncthreads(); // one wavefront per workgroup: orders the LDS writes before the reads that follow
+  // One wavefront per workgroup and the LDS executes a wave's instructions in order: the reads that follow see these writes.
+  // Only the compiler has to be kept from reordering them; a __syncthreads() here would also drain vmcnt, i.e. wait for the
+  // row loads that were just put in flight for the next blocks.
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 // metric of the step staged at row jj, phase ph
 __device__ __forceinline__ pk_t stage_get(const Stage& st, int buf, int ph, int jj)
@@ -357,11 +378,14 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const Src& S
   if (nb <= 0) return;
   // staged rows of block b: [k0 - (BLK-1), k0] (DIR < 0) or [k0, k0 + BLK) (DIR > 0); row jj of step j
   auto   lo  = [&](int b) { return DIR > 0 ? k_first + BLK * b : k_first - BLK * b - (BLK - 1); };
-  StRegs r   = stage_load<G>(S, st, lo(0), BLK);
+  // two blocks of rows in flight: a block computes in ~1500 cycles at two waves per SIMD, a load from HBM takes longer
+  StRegs r = stage_load<G>(S, st, lo(0), BLK), r2 = r;
+  if (nb > 1) r2 = stage_load<G>(S, st, lo(1), BLK);
   for (int b = 0; b < nb; b++) {
     const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b, buf = b & 1;
     stage_store(st, buf, BLK, r);
-    if (b + 1 < nb) r = stage_load<G>(S, st, lo(b + 1), BLK); // in flight while this block computes
+    r = r2;
+    if (b + 2 < nb) r2 = stage_load<G>(S, st, lo(b + 2), BLK);
     pk_t c[BLK];
 #pragma unroll
     for (int j = 0; j < BLK; j++) {
@@ -462,7 +486,7 @@ __device__ __forceinline__ void st8(int16_t* p, int i8, v8s v) { *reinterpret_ca
 template <int W, int AR>
 __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
-                         pk_t* __restrict__ beta, pk_t* __restrict__ seg, pk_t* __restrict__ scratch, const Stage& st, int K)
+                         pk_t* __restrict__ beta, pk_t* __restrict__ seg, pk_t* __restrict__ scratch, const Stage& st, int K PROF_ARGS)
 {
   constexpr int NH = W == 32 ? 2 : 1;
   constexpr int G  = 8 * NH; // window pairs per step
@@ -510,6 +534,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   Src S[NH];
 #pragma unroll
   for (int h = 0; h < NH; h++) S[h] = Src{Xs + h * 8, Ys + h * 8, XY + h * 8};
+  PROF(2)
 
   // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464); positions are fixed: all static
   static_assert(WIN_OVERLAP == 40, "block plan below is written for the 40-step overlap");
@@ -520,6 +545,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     win_run<W, 12, 15 % 3, -1, 0, 1, AR>(L, v[h], S[h], st, 15, 15, 1, beta); // steps 15..4
     win_rem<W, -1, 0, AR>(L, v[h], S[h], st, 3, 3, 0, 4, beta);                      // steps 3..0
   }
+  PROF(3)
   // ---- tail trellis for the last window: scalar (turbodecoder_win.h:351-395). 16-bit: wrapping adds; 8-bit: sadd() clamps
   //      at +127 and wraps below (:322-330), INF = 0
   int tail[8];
@@ -577,6 +603,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     win_run<W, 24, 2, -1, 1, 1, AR>(L, v[h], S[h], st, Lw - r - 1 - 6 * r6, Lw - r - 1 - 6 * r6, n24, bh);
   }
 
+  PROF(4)
   // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter j = 0..39
 #pragma unroll
   for (int h = 0; h < NH; h++) {
@@ -610,6 +637,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
       }
     }
   }
+  PROF(5)
   // ---- alpha main pass with extrinsic output (:605-679), CKPT steps at a time: the beta metrics of the segment are
   //      recomputed from its checkpoint into LDS (`seg`, one dword per lane and step: lane-private, no barrier), using
   //      the very operands the alpha steps need, then consumed. No beta traffic leaves the CU.
@@ -619,12 +647,14 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     const pk_t* bh = beta + h * bstride;
     const int   gg = h * 8 + L.g;
     pk_t        va = v[h];
-    StRegs sr;
-    if (nf > 0) sr = stage_load<G>(S[h], st, 0, CKPT);
+    StRegs sr, sr2;
+    if (nf > 0) sr = sr2 = stage_load<G>(S[h], st, 0, CKPT);
+    if (nf > 1) sr2 = stage_load<G>(S[h], st, CKPT, CKPT);
     for (int j = 0; j < nf; j++) {
       const int k0 = CKPT * j, buf = j & 1;
       stage_store(st, buf, CKPT, sr);
-      if (j + 1 < nf) sr = stage_load<G>(S[h], st, k0 + CKPT, CKPT); // the next segment's rows, in flight during this one
+      sr = sr2;
+      if (j + 2 < nf) sr2 = stage_load<G>(S[h], st, k0 + 2 * CKPT, CKPT); // two segments of rows in flight
       pk_t c[CKPT];
 #pragma unroll
       for (int i = 0; i < CKPT; i++) c[i] = st.lds[st.rb[buf][i % 3] + i * 8]; // phase (k0 + i) % 3 = i % 3
@@ -696,6 +726,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
       }
     }
   }
+  PROF(6)
 }
 
 template <int W>
@@ -733,6 +764,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   static_assert(2 * (POOL_BETA + POOL_SEG + 2 * ST_BUF) >= SRSLTE_HIP_MAX_K, "permutation buffer must hold one code block");
   Stage st;
   stage_init(st, mt, L);
+  PROF_DECL;
   pk_t*           xy = reinterpret_cast<pk_t*>(a.xy + (size_t)cb * a.K); // 16 B per trellis step: room for the x, y and x + y arrays
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91). The 12 tail LLRs go to LDS. A 16-bit
@@ -772,6 +804,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   }
   __syncthreads();
 
+  PROF(0)
   // srslte_vec_sub_sss: wrapping int16. srslte_vec_sub_bbb (vector_simd.c:158-185, AVX2 build, aligned buffers): saturating
   // int8 in the 32-wide body, wrapping in the scalar tail
   const int sat_body = K / 32 * 32;
@@ -801,7 +834,8 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
             [&](int i8, V8x3 t) { st8(app1, i8, vsub8(i8, t.a, t.b)); });
         __syncthreads();
       }
-      if (!(a.dbg & 1)) win_siso<W, AR>(L, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, beta, seg, xy, st, K);
+      PROF(1)
+      if (!(a.dbg & 1)) win_siso<W, AR>(L, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, beta, seg, xy, st, K PROF_PASS);
       dec = ext1;
     } else {
       const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
@@ -816,7 +850,8 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
       __syncthreads();
       for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app2, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
       __syncthreads();
-      if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K);
+      PROF(1)
+      if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K PROF_PASS);
       __syncthreads();
       batched<EWU>(
           L.lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
@@ -830,6 +865,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
     }
     __syncthreads();
     n_iter++;
+    PROF(1)
     if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
       uint32_t syn = 0;
       batched<EWU>(
@@ -846,6 +882,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
       ok = syn == 0 && !(a.dbg & (1 | 16)); // 16: never stop early (timing experiments at a fixed pass count)
     }
   }
+  PROF(7)
   // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838)
   uint8_t* o = a.out + (size_t)cb * a.out_stride;
   batched<2>(
@@ -874,10 +911,16 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
         });
     for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
   }
+  PROF(8)
   if (L.lane == 0) {
     if (a.iters) a.iters[cb] = n_iter;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
     if (a.tb_rem) a.tb_syn[cb] = tsyn;
+#ifdef TDEC_PROF
+    if (a.prof) {
+      for (int i = 0; i < 10; i++) a.prof[(size_t)cb * 10 + i] = prof_acc[i];
+    }
+#endif
   }
 }
 
@@ -1202,6 +1245,12 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   a.dbg = getenv("SRSLTE_HIP_TDEC_DBG") ? atoi(getenv("SRSLTE_HIP_TDEC_DBG")) : 0;
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   a.tb_rem = W ? q->tb_rem : nullptr; a.tb_C = q->tb_C ? q->tb_C : 1; a.tb_syn = q->tb_syn;
+  a.prof = nullptr;
+#ifdef TDEC_PROF
+  static unsigned long long* d_prof = nullptr;
+  if (!d_prof) HIP_TRY(hipMalloc((void**)&d_prof, sizeof(unsigned long long) * 10 * 65536));
+  if (nof_cb <= 65536) a.prof = d_prof;
+#endif
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
   if (ar8 && W == 32) {
@@ -1219,6 +1268,22 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
     hipLaunchKernelGGL(tdec_gen_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a);
   }
   LAUNCH_CHECK();
+#ifdef TDEC_PROF
+  if (a.prof && getenv("SRSLTE_HIP_TDEC_PROF")) {
+    std::vector<unsigned long long> h((size_t)nof_cb * 10);
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipMemcpy(h.data(), a.prof, h.size() * 8, hipMemcpyDeviceToHost));
+    double tot[10] = {0}, all = 0;
+    for (uint32_t c = 0; c < nof_cb; c++) {
+      for (int i = 0; i < 10; i++) tot[i] += (double)h[(size_t)c * 10 + i];
+    }
+    for (int i = 0; i < 10; i++) all += tot[i];
+    static const char* nm[10] = {"extract", "elementwise", "combine", "beta warm-up", "tail+shift+beta main", "alpha warm-up", "alpha main", "crc", "decision+tb", "-"};
+    fprintf(stderr, "[tdec prof] K=%u W=%u blocks=%u mean cycles/block %.0f:", K, W, nof_cb, all / nof_cb);
+    for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / all);
+    fprintf(stderr, "\n");
+  }
+#endif
   return SRSLTE_SUCCESS;
 }
 
