@@ -232,6 +232,30 @@ int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti
  * the de-interleaver), 5 w, 6 cb iters, 7 cb ok, 8 cb bytes, 9 z (equalised) */
 const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q, int which);
 
+/* ------------------------------------------------------------------ PUSCH transmit pipeline (UE side): TB CRC24A +
+ * segmentation + CB CRC24B -> turbo encoder -> rate matching + UL channel interleaver + scrambling + modulation -> transform precoding
+ * -> RE mapping with the DMRS -> OFDM TX with 1/sqrt(N) and the +1/2 carrier shift (srslte_ue_ul_encode ue_ul.c:300-340 with
+ * srslte_pusch_encode pusch.c:314-421, the UL-SCH part of srslte_ulsch_encode sch.c:1068-1160, srslte_refsignal_dmrs_pusch_put and
+ * srslte_ofdm_tx_sf). Same restrictions as the receive pipeline. */
+typedef struct srslte_hip_ul_tx srslte_hip_ul_tx_t;
+typedef struct {
+  uint32_t cell_id, nof_prb;
+  uint16_t rnti;
+  int      mod;            /* srslte_mod_t: QPSK, 16QAM, 64QAM */
+  uint32_t tbs;
+  uint32_t L_prb, n_prb, n_dmrs;
+  uint32_t max_batch;
+  srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;
+} srslte_hip_ul_tx_cfg_t;
+srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
+void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);
+/* d_tb: [nof_sf][tb_stride] payload bytes (tbs/8 used); d_iq: [nof_sf][15*N] cf32 time samples; subframe b is TTI tti0 + b */
+int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, void* d_iq,
+                           void* stream);
+/* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
+ * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
+const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);
+
 #ifdef __cplusplus
 }
 #endif

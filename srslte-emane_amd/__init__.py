@@ -475,3 +475,50 @@ class UlRx:
         if self.h:
             lib().srslte_hip_ul_rx_destroy(self.h)
             self.h = None
+
+
+class UlTxCfg(C.Structure):
+    _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
+                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg)]
+
+
+class UlTx:
+    """Batched PUSCH transmit chain (srslte_ue_ul_encode ue_ul.c:300-340: srslte_pusch_encode pusch.c:314-421 with the UL-SCH part of
+    srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
+
+    def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
+                 sequence_hopping=False):
+        self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0))
+        L = lib()
+        L.srslte_hip_ul_tx_create.restype = C.c_void_p
+        L.srslte_hip_ul_tx_create.argtypes = [C.POINTER(UlTxCfg)]
+        L.srslte_hip_ul_tx_destroy.argtypes = [C.c_void_p]
+        L.srslte_hip_ul_tx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.srslte_hip_ul_tx_debug_buffer.restype = C.c_void_p
+        L.srslte_hip_ul_tx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
+        self.h = L.srslte_hip_ul_tx_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("srslte_hip_ul_tx_create failed")
+        self.tbs, self.max_batch = tbs, max_batch
+        self.sf_len = 15 * symbol_sz(nof_prb)
+        self.d_iq = DevBuf(8 * self.sf_len * max_batch)
+
+    def encode(self, tb, tti0=0):
+        """tb: [nof_sf][tbs/8] payload bytes -> iq [nof_sf][sf_len] (left on the device in self.d_iq as well)."""
+        x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
+        din = DevBuf.from_host(x)
+        _check(lib().srslte_hip_ul_tx_batch(self.h, din.ptr, self.tbs // 8, tti0, x.shape[0], self.d_iq.ptr, None), "ul_tx_batch")
+        sync()
+        return self.d_iq.to_host(np.complex64).reshape(self.max_batch, self.sf_len)[:x.shape[0]]
+
+    def debug(self, which, dtype, count):
+        ptr = lib().srslte_hip_ul_tx_debug_buffer(self.h, which)
+        out = np.empty(count, dtype)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_ul_tx_destroy(self.h)
+            self.h = None

@@ -16,7 +16,6 @@
 namespace {
 
 constexpr int CH_THREADS = 256;
-constexpr int MAX_NREF   = 220; // 2 * 110 PRB
 
 struct ChestParams {
   int   cell_id, nof_prb, tti0;
@@ -587,18 +586,10 @@ extern "C" int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* 
   return SRSLTE_SUCCESS;
 }
 
-// d_grid: [nof_sf][14][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
-// d_res: [nof_sf] srslte_hip_chest_ul_res_t or NULL. Same grant (L_prb, n_prb in both slots, n_dmrs) for every subframe of the batch.
-extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
-                                                        const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+// Device DMRS of a grant, [10][2][12 * L_prb] (what srslte_chest_ul_pregen keeps for every (n_dmrs, sf, L): built per grant here)
+int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r)
 {
-  if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (!srslte_hip_dft_precoding_valid_prb(L_prb)) {
-    fprintf(stderr, "[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
-    return SRSLTE_ERROR_INVALID_INPUTS;
-  }
-  if (nof_sf == 0) return SRSLTE_SUCCESS;
-  if (q->r_L != L_prb || q->r_n_dmrs != n_dmrs) { // what srslte_chest_ul_pregen keeps for every (n_dmrs, sf, L): built per grant here
+  if (q->r_L != L_prb || q->r_n_dmrs != n_dmrs) {
     std::vector<cf32> r((size_t)10 * 2 * 12 * L_prb);
     for (uint32_t sf = 0; sf < 10; sf++) {
       int rc = srslte_hip_refsignal_dmrs_pusch_gen(q, L_prb, sf, n_dmrs, r.data() + (size_t)sf * 2 * 12 * L_prb);
@@ -611,6 +602,23 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q
     q->r_L      = L_prb;
     q->r_n_dmrs = n_dmrs;
   }
+  *d_r = q->d_r;
+  return SRSLTE_SUCCESS;
+}
+
+// d_grid: [nof_sf][14][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
+// d_res: [nof_sf] srslte_hip_chest_ul_res_t or NULL. Same grant (L_prb, n_prb in both slots, n_dmrs) for every subframe of the batch.
+extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
+                                                        const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+{
+  if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!srslte_hip_dft_precoding_valid_prb(L_prb)) {
+    fprintf(stderr, "[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  const void* d_r = nullptr;
+  if (int rc = chest_ul_dmrs_table(q, L_prb, n_dmrs, &d_r)) return rc;
   ChestUlGeom g;
   g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.tti0 = (int)tti0; g.w = 0.3333f;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(nof_sf), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, (hipStream_t)stream, (const cf32*)d_grid,

@@ -773,3 +773,289 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
+
+// ====================================================================================================================
+// PUSCH transmit pipeline (UE side): TB CRC24A + segmentation + CB CRC24B (sch.c:183-297 as used by
+// srslte_ulsch_encode :1068-1160) -> turbo encoder -> rate matching + UL channel interleaver + scrambling + modulation
+// (rm_turbo.c:100-158, sch.c:580-598, pusch.c:380-400) -> transform precoding (:406) -> RE mapping with the DMRS
+// (pusch_put :52-91, ue_ul.c:320-326) -> OFDM TX with 1/sqrt(N) and the +1/2 carrier shift (ue_ul.c:59-64).
+// Same restrictions as the receive side: UL-SCH data only, same allocation in both slots, normal CP, rv 0.
+// ====================================================================================================================
+namespace {
+
+__device__ __forceinline__ uint32_t gf24_mul(uint32_t a, uint32_t b, uint32_t poly)
+{ // a(x) b(x) mod g(x), deg g = 24 (poly carries the x^24 term)
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r <<= 1;
+    if (r & 0x1000000u) r ^= poly;
+    if ((b >> i) & 1) r ^= a;
+  }
+  return r;
+}
+
+// CRC24 (init 0, MSB first) of nbytes bytes by a 256-thread block: the message is zero-extended at the FRONT to 256 equal chunks
+// (leading zeros do not change the remainder), every thread runs the byte-table recursion over its chunk, and the chunk
+// remainders are folded pairwise with x^(8*chunk*2^level) mod g. tab/red: 256 words of LDS each. Result valid in every thread.
+template <typename Byte>
+__device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_t* tab, uint32_t* red)
+{
+  const int t = threadIdx.x;
+  {
+    uint32_t v = (uint32_t)t << 16;
+    for (int i = 0; i < 8; i++) {
+      v <<= 1;
+      if (v & 0x1000000u) v ^= poly;
+    }
+    tab[t] = v;
+  }
+  __syncthreads();
+  const int cB = (nbytes + 255) / 256, pad = 256 * cB - nbytes;
+  uint32_t  crc = 0;
+  for (int i = 0; i < cB; i++) {
+    const int v = t * cB + i - pad;
+    if (v >= 0) crc = ((crc << 8) & 0xffffffu) ^ tab[((crc >> 16) & 0xff) ^ byte_at(v)];
+  }
+  uint32_t m = 1; // x^(8 cB) mod g
+  for (int i = 0; i < 8 * cB; i++) {
+    m <<= 1;
+    if (m & 0x1000000u) m ^= poly;
+  }
+  red[t] = crc;
+  __syncthreads();
+  for (int s = 1; s < 256; s <<= 1) {
+    uint32_t v = 0;
+    if ((t & (2 * s - 1)) == 0) v = gf24_mul(red[t], m, poly) ^ red[t + s];
+    __syncthreads();
+    if ((t & (2 * s - 1)) == 0) red[t] = v;
+    m = gf24_mul(m, m, poly);
+    __syncthreads();
+  }
+  return red[0];
+}
+
+struct PuschTxGeom {
+  int   cell_nre, M_sc, n_prb, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
+  float lvl[16];
+};
+
+// grid = nof_sf, 256 threads: CRC24A of each transport block (sch.c:470-488 on the transmit side :1104-1110)
+__global__ __launch_bounds__(256) void pusch_tx_tbcrc_kernel(const uint8_t* __restrict__ tb, uint32_t* __restrict__ crc_out, PuschTxGeom g)
+{
+  __shared__ uint32_t tab[256], red[256];
+  const uint8_t*      x = tb + (size_t)blockIdx.x * g.tb_stride;
+  const uint32_t      c = block_crc24([&](int i) { return (uint32_t)x[i]; }, g.tbs / 8, 0x1864CFBu, tab, red);
+  if (threadIdx.x == 0) crc_out[blockIdx.x] = c;
+}
+
+// grid = (C, nof_sf), 256 threads: code block r = bytes [r*rlenB, (r+1)*rlenB) of TB | CRC24A, then its CRC24B when C > 1 (sch.c:222-262)
+__global__ __launch_bounds__(256) void pusch_tx_seg_kernel(const uint8_t* __restrict__ tb, const uint32_t* __restrict__ tbcrc, uint8_t* __restrict__ cb,
+                                                           PuschTxGeom g)
+{
+  __shared__ uint32_t tab[256], red[256];
+  __shared__ uint8_t  xs[768];
+  const int           r = blockIdx.x, sf = blockIdx.y, t = threadIdx.x, tbB = g.tbs / 8;
+  const uint8_t*      x   = tb + (size_t)sf * g.tb_stride;
+  const uint32_t      crc = tbcrc[sf];
+  uint8_t*            out = cb + ((size_t)sf * g.C + r) * g.cb_stride;
+  for (int i = t; i < g.rlenB; i += 256) {
+    const int j = r * g.rlenB + i;
+    xs[i]       = j < tbB ? x[j] : (uint8_t)(crc >> (8 * (2 - (j - tbB))));
+  }
+  __syncthreads();
+  for (int i = t; i < g.rlenB; i += 256) out[i] = xs[i];
+  if (g.C > 1) {
+    const uint32_t c = block_crc24([&](int i) { return (uint32_t)xs[i]; }, g.rlenB, 0x1800063u, tab, red);
+    if (t < 3) out[g.rlenB + t] = (uint8_t)(c >> (8 * (2 - t)));
+  }
+}
+
+// grid = (ceil(M_sc/256), 12, nof_sf): modulation symbol (n, k) of the interleaved, scrambled stream: its Qm bits are
+// g[(k*12 + n)*Qm + b] (36.212 5.2.2.8 without UCI), all from one code block; bit e of a block = coded bit rm[e mod (3K+12)]
+// (rm: circular-buffer order with the NULLs removed; source 0 = systematic byte stream, 1 = its tail nibble, 2 = parity stream)
+__global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
+                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ d, PuschTxGeom g)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
+  if (k >= g.M_sc) return;
+  const int s = k * 12 + n; // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
+  int       r, e0;
+  if (s < g.C_lo * g.syms_lo) {
+    r  = s / g.syms_lo;
+    e0 = (s - r * g.syms_lo) * g.Qm;
+  } else {
+    const int u = s - g.C_lo * g.syms_lo;
+    r           = g.C_lo + u / (g.syms_lo + 1);
+    e0          = (u % (g.syms_lo + 1)) * g.Qm;
+  }
+  const size_t    cbi = (size_t)sf * g.C + r;
+  const uint8_t * xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
+  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
+  const int       q0  = (n * g.M_sc + k) * g.Qm;
+  int             re = 0, im = 0;
+  for (int b = 0; b < g.Qm; b++) {
+    const uint32_t src = rm[(e0 + b) % g.rm_len], pos = src & 0x3fffffffu;
+    const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
+    int            bit  = (byte >> (7 - (pos & 7))) & 1;
+    bit ^= (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
+    if (b & 1) im = (im << 1) | bit;
+    else re = (re << 1) | bit;
+  }
+  d[((size_t)sf * 12 + n) * g.M_sc + k] = make_float2(g.lvl[re], g.lvl[im]);
+}
+
+// grid = (ceil(cell_nre/256), 14, nof_sf): resource grid of the subframe: z on the granted PRBs of the 12 data symbols, DMRS on
+// l = 3, 10, zero elsewhere (the caller's memset + pusch_put + srslte_refsignal_dmrs_pusch_put)
+__global__ __launch_bounds__(256) void pusch_tx_map_kernel(const cf32* __restrict__ z, const cf32* __restrict__ dmrs, cf32* __restrict__ grid,
+                                                           PuschTxGeom g)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
+  if (k >= g.cell_nre) return;
+  const int kk = k - 12 * g.n_prb;
+  cf32      v  = make_float2(0.f, 0.f);
+  if (kk >= 0 && kk < g.M_sc) {
+    if (l == 3 || l == 10) {
+      v = dmrs[((size_t)sf_idx * 2 + (l == 10)) * g.M_sc + kk];
+    } else {
+      const int n = l < 3 ? l : (l < 10 ? l - 1 : l - 2);
+      v           = z[((size_t)sf * 12 + n) * g.M_sc + kk];
+    }
+  }
+  grid[((size_t)sf * 14 + l) * g.cell_nre + k] = v;
+}
+
+} // namespace
+
+struct srslte_hip_ul_tx {
+  srslte_hip_ul_tx_cfg_t cfg;
+  srslte_hip_ofdm_t*     ofdm;
+  srslte_hip_chest_ul_t* dmrs;
+  srslte_hip_cbsegm_t    seg;
+  PuschTxGeom            g;
+  uint32_t *             d_scr, *d_rm, *d_tbcrc;
+  uint8_t *              d_cb, *d_parity, *d_sys_tail;
+  cf32 *                 d_d, *d_z, *d_grid;
+};
+
+extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
+{
+  if (!q) return;
+  srslte_hip_ofdm_destroy(q->ofdm);
+  srslte_hip_chest_ul_destroy(q->dmrs);
+  void* bufs[] = {q->d_scr, q->d_rm, q->d_tbcrc, q->d_cb, q->d_parity, q->d_sys_tail, q->d_d, q->d_z, q->d_grid};
+  for (void* b : bufs) {
+    if (b) (void)hipFree(b);
+  }
+  delete q;
+}
+
+extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg)
+{
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->L_prb < 3 || cfg->n_prb + cfg->L_prb > cfg->nof_prb ||
+      !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
+    fprintf(stderr, "[srslte_hip] ul_tx: invalid configuration\n");
+    return nullptr;
+  }
+  auto* q = new srslte_hip_ul_tx();
+  memset(q, 0, sizeof(*q));
+  q->cfg = *cfg;
+  if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
+    fprintf(stderr, "[srslte_hip] ul_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    delete q;
+    return nullptr;
+  }
+  const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
+  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
+  PuschTxGeom&   g = q->g;
+  g.cell_nre = 12 * (int)P; g.M_sc = (int)M_sc; g.n_prb = (int)cfg->n_prb; g.Qm = (int)Qm; g.scr_words = (int)scr_words; g.C = (int)C; g.K = (int)K;
+  g.tbs = (int)cfg->tbs; g.rlenB = (int)((C == 1 ? K : K - 24) / 8); g.cb_stride = (int)((K / 8 + 15) & ~15u);
+  g.par_stride = (int)((K / 4 + 1 + 15) & ~15u); g.rm_len = (int)(3 * K + 12);
+  g.syms_lo = (int)(nof_re / C); g.C_lo = (int)(C - nof_re % C); // G' = nof_re, gamma = G' mod C (sch.c:205-207)
+  for (uint32_t idx = 0; idx < (1u << cfg->mod); idx++) { // 36.211 7.1.2-7.1.4, one axis: bits b0 b2 b4 of the symbol (lte_tables.c:57-182)
+    const int    nb = cfg->mod;
+    double       v  = 1.0;
+    for (int i = nb - 1; i >= 1; i--) v = (double)(1 << (nb - i)) - (1 - 2 * (int)((idx >> (nb - 1 - i)) & 1)) * v;
+    const double norm = nb == 1 ? sqrt(2.0) : (nb == 2 ? sqrt(10.0) : sqrt(42.0));
+    g.lvl[idx]        = (float)((1 - 2 * (int)((idx >> (nb - 1)) & 1)) * v / norm);
+  }
+  q->ofdm = srslte_hip_ofdm_create((int)P, 1, 0);
+  q->dmrs = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
+  bool ok = q->ofdm && q->dmrs && srslte_hip_ofdm_set_normalize(q->ofdm, 1) == SRSLTE_SUCCESS &&
+            srslte_hip_ofdm_set_freq_shift(q->ofdm, 0.5f) == SRSLTE_SUCCESS; // ue_ul.c:63-64
+  if (ok) { // srslte_sequence_pusch (sequences.c:65-67)
+    std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
+    std::vector<uint8_t>  c;
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, nbits, c);
+      for (uint32_t i = 0; i < nbits; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
+    }
+    ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
+  }
+  if (ok) { // rate matching, rv 0 (rm_turbo.c:100-158): coded bit of each circular-buffer position, addressed in the encoder's byte streams
+    std::vector<uint32_t> t;
+    lte_rm_rx_table(K, 0, t);
+    for (auto& v : t) {
+      const uint32_t p = v / 3, s = v % 3;
+      v = s == 0 ? (p < K ? p : (1u << 30) | (p - K)) : (2u << 30) | (s == 1 ? p : K + 4 + p);
+    }
+    ok = upload(&q->d_rm, t) == SRSLTE_SUCCESS;
+  }
+  const size_t glen = (size_t)14 * 12 * P;
+  ok = ok && hipMalloc((void**)&q->d_tbcrc, sizeof(uint32_t) * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb, (size_t)g.cb_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_parity, (size_t)g.par_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_sys_tail, (size_t)B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_z, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[srslte_hip] ul_tx: initialisation failed\n");
+    srslte_hip_ul_tx_destroy(q);
+    return nullptr;
+  }
+  return q;
+}
+
+extern "C" const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which)
+{
+  if (!q) return nullptr;
+  switch (which) {
+    case 0: return q->d_cb;
+    case 1: return q->d_parity;
+    case 2: return q->d_d;
+    case 3: return q->d_z;
+    case 4: return q->d_grid;
+    case 5: return q->d_tbcrc;
+  }
+  return nullptr;
+}
+
+extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, void* d_iq,
+                                      void* stream)
+{
+  if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  const void* d_r = nullptr;
+  if (int r = chest_ul_dmrs_table(q->dmrs, q->cfg.L_prb, q->cfg.n_dmrs, &d_r)) return r;
+  PuschTxGeom g = q->g;
+  g.tti0        = (int)tti0;
+  g.tb_stride   = (int)tb_stride;
+  hipLaunchKernelGGL(pusch_tx_tbcrc_kernel, dim3(nof_sf), dim3(256), 0, st, d_tb, q->d_tbcrc, g);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(pusch_tx_seg_kernel, dim3(g.C, nof_sf), dim3(256), 0, st, d_tb, (const uint32_t*)q->d_tbcrc, q->d_cb, g);
+  LAUNCH_CHECK();
+  int r = srslte_hip_tcod_encode_bytes_batch(q->d_cb, (uint32_t)g.cb_stride, q->d_parity, (uint32_t)g.par_stride, q->d_sys_tail, (uint32_t)g.K,
+                                             nof_sf * (uint32_t)g.C, stream);
+  if (r) return r;
+  hipLaunchKernelGGL(pusch_tx_mod_kernel, dim3(ceil_div(g.M_sc, 256), 12, nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
+                     (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, (const uint32_t*)q->d_rm, (const uint32_t*)q->d_scr, q->d_d, g);
+  LAUNCH_CHECK();
+  r = srslte_hip_dft_precoding_batch(q->d_d, q->d_z, q->cfg.L_prb, 12 * nof_sf, 1, stream); // srslte_dft_precoding_init_tx: forward, 1/sqrt(N)
+  if (r) return r;
+  hipLaunchKernelGGL(pusch_tx_map_kernel, dim3(ceil_div(g.cell_nre, 256), 14, nof_sf), dim3(256), 0, st, (const cf32*)q->d_z, (const cf32*)d_r,
+                     q->d_grid, g);
+  LAUNCH_CHECK();
+  return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf, stream);
+}

@@ -319,11 +319,12 @@ class UlConfig:
         return c
 
 
-def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j):
-    """UE transmit side of pusch.c:314-421 (UL-SCH only): returns (iq[sf_len], payload bytes)."""
+def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None):
+    """UE transmit side of pusch.c:314-421 (UL-SCH only): returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid."""
     orc = oracle()
     sf_idx = tti % 10
-    data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    if data is None:
+        data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
     sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
     g = np.zeros(cfg.nbits, np.uint8)
     assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(g)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
@@ -345,6 +346,8 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j):
     tx.normalize, tx.freq_shift, tx.freq_shift_f = True, True, 0.5  # ue_ul.c:63-64
     iq = np.zeros(cfg.sf_len, np.complex64)
     orc.orc_ofdm_tx_sf(C.byref(tx), p(grid), p(iq))
+    if keep is not None:
+        keep.update(g=g, d=d, z=z, grid=grid)
     iq = iq * np.complex64(amp * gain)
     if snr_db is not None:
         sigma = np.sqrt(amp * amp * abs(gain) ** 2 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr_db / 20)

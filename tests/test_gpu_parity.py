@@ -675,3 +675,41 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
             assert np.array_equal(tb[b][:tbs // 8], data[b])
     assert n_ok > 0 or snr < 9.5
     rx.free()
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf", [(6, 6, 0, 1, 1000, 2, 4), (25, 10, 5, 2, 4008, 8, 11), (100, 100, 0, 2, 43816, 0, 3),
+                                                            (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2)])
+def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf):
+    """UE PUSCH transmit chain on the device vs the oracle's: code blocks with both CRCs, modulated symbols (exact: the
+    bits are exact and the levels are table values), transform-precoded symbols, resource grid with DMRS, time samples."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(1300 + prb + L + mod)
+    hop = dict(n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, **hop)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6)
+    iq = tx.encode(data, tti0)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    z = tx.debug(3, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    grid = tx.debug(4, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    for b in range(nsf):
+        k = {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k)
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), "modulated symbols sf %d" % b
+        assert_close_c(z[b], k["z"], "z sf %d" % b)
+        assert_close_c(grid[b], k["grid"], "grid sf %d" % b)
+        assert_close_c(iq[b], iq_o, "iq sf %d" % b)
+    tx.free()
+
+
+def test_ul_tx_rx_loop(hp):
+    """Device transmit chain into the device receive chain (noise-free, flat gain): every transport block comes back, one pass per block."""
+    prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
+    rng = np.random.default_rng(77)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.UlTx(3, prb, 0x77, mod, tbs, L, n_prb, 1, nsf)
+    rx = hp.UlRx(3, prb, 0x77, mod, tbs, L, n_prb, 1, 6, nsf)
+    tb, ok = rx.decode(tx.encode(data, 5), 5)
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data)
+    tx.free()
+    rx.free()
