@@ -214,8 +214,16 @@ def main():
                                                                             t_res.data_ptr(), nb, stream), nb * 179200)
         big["demod_soft_s_64qam"] = timed(lambda: L.srslte_hip_demod_soft_demodulate_s_batch(MOD, t_grid.data_ptr(), t_llr.data_ptr(), 14 * nre, nb, stream),
                                           nb * 14 * nre * (8 + 2 * Qm))
+        # the two fused glue kernels of the pipeline on the same large batch, through the pipeline's own stages
+        rxb = pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, nb, True, hc, llr_8bit=args.llr8)
+        algb = algorithmic_bytes(cfg, nof_re, list(range(nb)))
+        for s in (0, 1):
+            rxb.stage(s, t_iq.data_ptr(), 0, nb, stream)
+        big["pdsch_demod"] = timed(lambda: rxb.stage(2, t_iq.data_ptr(), 0, nb, stream), algb["pdsch_demod"])
+        big["rm_rx"] = timed(lambda: rxb.stage(3, t_iq.data_ptr(), 0, nb, stream), algb["rm_rx"])
         big["batch"] = nb
         torch.cuda.synchronize()
+        rxb.free()
         del t_iq, t_grid, t_ce, t_res, t_llr
 
     # ---- CPU baseline on a bounded sample of the same subframes, one core

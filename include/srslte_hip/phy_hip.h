@@ -205,8 +205,11 @@ int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint3
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,
                            uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
-/* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d, 4 e (LLRs), 5 w, 6 cb iters */
+/* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d (NULL unless
+ * srslte_hip_dl_rx_keep_symbols(q, 1): the equalised symbols are otherwise never written to memory), 4 e (LLRs, per-subframe stride
+ * = max nof_re * Qm rounded up to 16), 5 w, 6 cb iters */
 const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which);
+int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
 
 /* ------------------------------------------------------------------ PUSCH receive pipeline (eNB side): OFDM RX with the
  * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +

@@ -108,6 +108,7 @@ def lib():
         L.srslte_hip_dl_rx_stage.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
         L.srslte_hip_dl_rx_debug_buffer.restype = vp
         L.srslte_hip_dl_rx_debug_buffer.argtypes = [vp, C.c_int]
+        L.srslte_hip_dl_rx_keep_symbols.argtypes = [vp, C.c_int]
         _lib = L
     return _lib
 
@@ -389,9 +390,15 @@ class DlRx:
         self.tb_stride = (tbs // 8 + 6 + 15) & ~15
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+        # per-subframe stride of the LLR buffer e (debug buffer 4)
+        self.e_stride = (max(self.nof_re(s) for s in (0, 1, 5)) * {1: 2, 2: 4, 3: 6, 4: 8}[mod] + 15) & ~15
 
     def nof_re(self, sf_idx):
         return lib().srslte_hip_dl_rx_nof_re(self.h, sf_idx)
+
+    def keep_symbols(self, enable=True):
+        """Also write the equalised symbols d (debug buffer 3); off by default: the fused kernel never stores them."""
+        _check(lib().srslte_hip_dl_rx_keep_symbols(self.h, 1 if enable else 0), "dl_rx_keep_symbols")
 
     def run_device(self, d_iq_ptr, tti0, nof_sf, stream=None):
         return lib().srslte_hip_dl_rx_batch(self.h, d_iq_ptr, tti0, nof_sf, self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, stream)

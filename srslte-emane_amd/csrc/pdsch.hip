@@ -48,11 +48,13 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
                                                           const ChestResDev* __restrict__ res, const uint32_t* __restrict__ scr,
                                                           cf32* __restrict__ d_out, LLR* __restrict__ e_out, PdschGeom g)
 {
+  __shared__ __attribute__((aligned(16))) LLR stage[256 * 8]; // the workgroup's LLRs, written out with 16-byte stores
   const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
   const SfClass c  = g.cls[sf_class(sf_idx)];
-  const int     i  = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= c.nof_re) return;
-  const uint32_t k  = c.idx[i];
+  const int     base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
+  if (base >= c.nof_re) return;
+  const bool     live = i < c.nof_re;
+  const uint32_t k  = c.idx[live ? i : c.nof_re - 1];
   const float    n0 = g.mmse ? res[sf].noise_estimate : 0.f;
   cf32           x;
   if (g.nof_rx == 1) {
@@ -73,21 +75,29 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
     if (n0 > 0.f) hh += n0;
     x = make_float2(re / hh * 1.0f, im / hh * 1.0f);
   }
-  if (d_out) d_out[(size_t)sf * g.max_re + i] = x;
+  if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x;
   LLR o[8];
   if constexpr (sizeof(LLR) == 1) {
     demod_dev::demod_b(g.mod, x, i, c.nof_re, o);
   } else {
     demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
   }
-  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
-  LLR*            dst = e_out + (size_t)sf * g.max_bits + (size_t)i * g.Qm;
+  const uint32_t* cs   = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+  const int       bit0 = (live ? i : 0) * g.Qm;
+  const uint32_t  c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
   for (int j = 0; j < g.Qm; j++) {
-    const int bit = i * g.Qm + j;
-    LLR       v   = o[j];
-    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (LLR)-v; // scrambling.c:45-51: sign instruction, -(-min) stays min
-    dst[j] = v;
+    LLR v = o[j];
+    if ((c2 >> j) & 1) v = (LLR)-v; // scrambling.c:45-51: sign instruction, -(-min) stays min
+    stage[threadIdx.x * g.Qm + j] = v;
   }
+  __syncthreads();
+  // max_bits is a multiple of 16 and so is 256 * Qm: the workgroup's output starts on a 16-byte boundary
+  const int   nbytes = min(256, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const char* src    = reinterpret_cast<const char*>(stage);
+  for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+  const int rem = nbytes & 15;
+  if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
 }
 
 struct RmGeom {
@@ -135,13 +145,16 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
 }
 
 // Same result with the code block's LLR segment staged in LDS: one workgroup per code block copies its n_e LLRs with 16-byte
-// loads, then every thread produces eight adjacent soft-buffer slots (one 16-byte store) from LDS gathers. A 2-byte global gather
-// costs the L1 one cache line per lane; the LDS gather a few bank-conflict cycles. Used when the segment fits (RM_LDS_MAX LLRs).
-constexpr int RM_LDS_MAX = 16 * 1024; // int16 LLRs: 32 KB of LDS
-__global__ __launch_bounds__(256) void rm_rx_lds_kernel(const int16_t* __restrict__ e, int16_t* __restrict__ w, const uint32_t* __restrict__ inv,
-                                                        RmGeom g)
+// loads, then every thread produces 16 bytes of adjacent soft-buffer slots per step from LDS gathers. A 2-byte global gather
+// costs the L1 one cache line per lane; the LDS gather a few bank-conflict cycles. The slot table is the 16-bit copy behind the
+// 32-bit one (inv + w_stride), four steps' worth of it loaded ahead; LDS is sized to the segment (rm_lds_bytes) so that eight
+// workgroups share a CU. Used when the segment fits 64 KB.
+template <typename LLR>
+__global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ e, LLR* __restrict__ w, const uint32_t* __restrict__ inv, RmGeom g)
 {
-  __shared__ __attribute__((aligned(16))) int16_t seg[RM_LDS_MAX + 8];
+  extern __shared__ __attribute__((aligned(16))) char seg_raw[];
+  constexpr int PER = 16 / (int)sizeof(LLR), NV = PER / 8; // slots per 16 bytes; uint4 loads of 16-bit table entries per step
+  LLR*          seg = reinterpret_cast<LLR*>(seg_raw);
   const int cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C;
   const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)];
   const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
@@ -150,26 +163,43 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const int16_t* __restric
     n_e2 = n_e + g.Qm;
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
-  const int16_t* src = e + (size_t)sf * g.max_bits + rp;
-  // the segment starts at an arbitrary (even) LLR index: copy from the 16-byte boundary below it
-  const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / 2);
+  const LLR* src = e + (size_t)sf * g.max_bits + rp;
+  // the segment starts at an arbitrary LLR index: copy from the 16-byte boundary below it
+  const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / sizeof(LLR));
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
-  for (int i = threadIdx.x; i < (n_e2 + mis + 7) / 8; i += blockDim.x) reinterpret_cast<int4*>(seg)[i] = s4[i];
+  const int   n16 = (n_e2 + mis + PER - 1) / PER;
+#pragma unroll 4
+  for (int i = threadIdx.x; i < n16; i += 256) reinterpret_cast<int4*>(seg)[i] = s4[i];
   __syncthreads();
-  const int16_t* ls = seg + mis;
-  for (int j8 = threadIdx.x; j8 < g.w_stride / 8; j8 += blockDim.x) {
-    const uint4 t0 = *reinterpret_cast<const uint4*>(inv + 8 * j8), t1 = *reinterpret_cast<const uint4*>(inv + 8 * j8 + 4);
-    const uint32_t n[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-    uint32_t       o[4] = {0, 0, 0, 0};
+  const LLR*   ls    = seg + mis;
+  const uint4* inv16 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(inv + g.w_stride));
+  uint4*       dst   = reinterpret_cast<uint4*>(w + (size_t)cbg * g.w_stride);
+  const int    ngroups = g.w_stride / PER;
+  for (int j0 = threadIdx.x; j0 < ngroups; j0 += 4 * 256) {
+    uint4 tt[4][NV];
 #pragma unroll
-    for (int s = 0; s < 8; s++) {
-      int acc = 0;
-      if (n[s] != 0xffffffffu) {
-        for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += ls[i];
-      }
-      o[s >> 1] |= ((uint32_t)acc & 0xffffu) << (16 * (s & 1));
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + 256 * u;
+#pragma unroll
+      for (int v = 0; v < NV; v++) tt[u][v] = j < ngroups ? inv16[j * NV + v] : make_uint4(~0u, ~0u, ~0u, ~0u);
     }
-    *reinterpret_cast<uint4*>(w + (size_t)cbg * g.w_stride + 8 * j8) = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + 256 * u;
+      if (j >= ngroups) break;
+      uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int s = 0; s < PER; s++) {
+        const uint32_t pair = (&tt[u][s / 8].x)[(s / 2) & 3], n = (s & 1) ? pair >> 16 : pair & 0xffffu;
+        int            acc  = 0;
+        if (n != 0xffffu) {
+          for (int i = (int)n; i < n_e2; i += g.out_len) acc += ls[i];
+        }
+        constexpr int BITS = 8 * (int)sizeof(LLR);
+        o[s * BITS / 32] |= ((uint32_t)acc & ((1u << BITS) - 1u)) << ((s * BITS) & 31);
+      }
+      dst[j] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
   }
 }
 
@@ -250,11 +280,24 @@ __global__ __launch_bounds__(256) void tb_asm_kernel(const uint8_t* __restrict__
 }
 
 // largest segment of any subframe class + the Qm extra LLRs of the last blocks must fit the LDS kernel; w_stride is a multiple of 32
-bool rm_fits_lds(const RmGeom& g)
+int rm_lds_bytes(const RmGeom& g, int llr_bytes)
 {
   int mx = g.nof_re[0] > g.nof_re[1] ? g.nof_re[0] : g.nof_re[1];
   mx     = mx > g.nof_re[2] ? mx : g.nof_re[2];
-  return g.Qm * (mx / g.C) + g.Qm + 8 <= RM_LDS_MAX;
+  return ((g.Qm * (mx / g.C) + g.Qm) * llr_bytes + 32 + 15) & ~15; // + the bytes below the 16-byte boundary and the rounded-up last load
+}
+bool rm_fits_lds(const RmGeom& g, int llr_bytes = 2) { return rm_lds_bytes(g, llr_bytes) <= 64 * 1024; }
+
+// slot -> circular-buffer position: 32-bit entries [w_stride] for the generic kernels, then the same as 16-bit entries for the LDS kernel
+std::vector<uint32_t> rm_slot_table(const std::vector<uint32_t>& t, uint32_t w_stride)
+{
+  std::vector<uint32_t> inv(w_stride + w_stride / 2, 0xffffffffu);
+  uint16_t*             inv16 = reinterpret_cast<uint16_t*>(inv.data() + w_stride);
+  for (uint32_t n = 0; n < t.size(); n++) {
+    inv[t[n]]   = n;
+    inv16[t[n]] = (uint16_t)n; // n < 3 * 6144 + 12
+  }
+  return inv;
 }
 
 // pdsch.c:81-206 as a per-RE rule (see oracle/orc_pdsch.c for the derivation): symbol-major, sub-carrier ascending,
@@ -357,14 +400,14 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     ok                  = upload(&q->d_idx[c], idx) == SRSLTE_SUCCESS;
     q->pg.cls[c].idx    = q->d_idx[c];
   }
-  const uint32_t max_bits = max_re * Qm, scr_words = (max_bits + 31) / 32;
+  const uint32_t max_bits = (max_re * Qm + 15) & ~15u, scr_words = (max_re * Qm + 31) / 32 + 1; // spare word: the demapper reads two per RE
   // scrambling sequences, one per subframe index (sequences.c:58-60, pdsch.c:469)
   if (ok) {
     std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
     std::vector<uint8_t>  c;
     for (uint32_t sf = 0; sf < 10; sf++) {
-      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, max_bits, c);
-      for (uint32_t i = 0; i < max_bits; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, max_re * Qm, c);
+      for (uint32_t i = 0; i < max_re * Qm; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
     }
     ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
   }
@@ -379,9 +422,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
         v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
       }
     }
-    std::vector<uint32_t> inv(q->in_stride, 0xffffffffu); // slot -> circular-buffer position (in_stride is a multiple of 32)
-    for (uint32_t n = 0; n < t.size(); n++) inv[t[n]] = n;
-    ok = upload(&q->d_rm_tbl, inv) == SRSLTE_SUCCESS;
+    ok = upload(&q->d_rm_tbl, rm_slot_table(t, q->in_stride)) == SRSLTE_SUCCESS; // in_stride is a multiple of 32
   }
   // TB CRC24A remainders x^(tbs+24-1-j) mod g
   if (ok) {
@@ -408,7 +449,6 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   const size_t glen = (size_t)14 * nre;
   ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
        hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
-       hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)max_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
        hipMalloc((void**)&q->d_e, sizeof(int16_t) * ((size_t)max_bits * B + 16)) == hipSuccess /* +16: rm_rx_lds_kernel reads whole 16-byte words */ &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
@@ -426,6 +466,18 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
   return q;
+}
+
+extern "C" int srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable)
+{
+  if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (enable && !q->d_d) {
+    HIP_TRY(hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)q->pg.max_re * q->cfg.max_batch));
+  } else if (!enable && q->d_d) {
+    HIP_TRY(hipFree(q->d_d));
+    q->d_d = nullptr;
+  }
+  return SRSLTE_SUCCESS;
 }
 
 extern "C" uint32_t srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_t sf_idx)
@@ -480,11 +532,17 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       RmGeom g = q->rg;
       g.tti0   = (int)tti0;
       if (q->cfg.llr_8bit) {
-        hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div(g.w_stride, 1024), nof_sf * C), dim3(256), 0, st, (const int8_t*)q->d_e,
-                           (int8_t*)q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+        if (rm_fits_lds(g, 1)) {
+          hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(g, 1), st, (const int8_t*)q->d_e, (int8_t*)q->d_w,
+                             (const uint32_t*)q->d_rm_tbl, g);
+        } else {
+          hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div(g.w_stride, 1024), nof_sf * C), dim3(256), 0, st, (const int8_t*)q->d_e,
+                             (int8_t*)q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+        }
       } else {
         if (rm_fits_lds(g)) {
-          hipLaunchKernelGGL(rm_rx_lds_kernel, dim3(nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e, q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+          hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(g, 2), st, (const int16_t*)q->d_e, q->d_w,
+                             (const uint32_t*)q->d_rm_tbl, g);
         } else {
           hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e,
                              q->d_w, (const uint32_t*)q->d_rm_tbl, g);
@@ -658,9 +716,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
         v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
       }
     }
-    std::vector<uint32_t> inv(q->in_stride, 0xffffffffu);
-    for (uint32_t n = 0; n < t.size(); n++) inv[t[n]] = n;
-    ok = upload(&q->d_rm_tbl, inv) == SRSLTE_SUCCESS;
+    ok = upload(&q->d_rm_tbl, rm_slot_table(t, q->in_stride)) == SRSLTE_SUCCESS;
   }
   if (ok) {
     std::vector<uint32_t> rem(cfg->tbs + 24);
@@ -751,7 +807,8 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   RmGeom rg = q->rg;
   rg.tti0   = (int)tti0;
   if (rm_fits_lds(rg)) {
-    hipLaunchKernelGGL(rm_rx_lds_kernel, dim3(nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w, (const uint32_t*)q->d_rm_tbl, rg);
+    hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(rg, 2), st, (const int16_t*)q->d_g, q->d_w,
+                       (const uint32_t*)q->d_rm_tbl, rg);
   } else {
     hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(rg.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w,
                        (const uint32_t*)q->d_rm_tbl, rg);

@@ -374,7 +374,7 @@ def test_dl_rx_chain(hp, prb, mod, tbs, snr, tti0, nsf):
     max_re = max(rx.nof_re(s) for s in (0, 1, 5))
     grid = rx.debug(0, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
     ce = rx.debug(1, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
-    e_all = rx.debug(4, np.int16, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int16, nsf * rx.e_stride).reshape(nsf, -1)
     n_diff = n_tot = 0
     for b in range(nsf):
         r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
@@ -410,7 +410,7 @@ def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
     C_ = cfg.seg.C
     it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
     max_re = max(rx.nof_re(s) for s in (0, 1, 5))
-    e_all = rx.debug(4, np.int8, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int8, nsf * rx.e_stride).reshape(nsf, -1)
     n_diff = n_tot = n_ok = 0
     for b in range(nsf):
         r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
@@ -470,7 +470,7 @@ def test_cfg5_256qam_grid_snr_sweep(hp, llr8):
         res = rx.debug(2, np.float32, 2 * 10).reshape(2, 10)
         it = rx.debug(6, np.uint32, 2 * cfg.seg.C).reshape(2, -1)
         max_re = max(rx.nof_re(s_) for s_ in (0, 1, 5))
-        e_all = rx.debug(4, np.int8 if llr8 else np.int16, 2 * max_re * cfg.Qm).reshape(2, -1)
+        e_all = rx.debug(4, np.int8 if llr8 else np.int16, 2 * rx.e_stride).reshape(2, -1)
         for b, t in enumerate(ttis):
             r = oracle_rx(cfg, None, t, keep=True, grid_in=grids[b])
             assert_close_c(ce[b], r["ce"], "ce snr %d sf %d" % (snr, b))
@@ -582,7 +582,7 @@ def test_dl_rx_chain_two_rx_antennas(hp, prb, mod, tbs, snr, tti0, nsf, llr8):
     max_re = max(rx.nof_re(s) for s in (0, 1, 5))
     ce = rx.debug(1, np.complex64, nsf * 2 * cfg.grid_len).reshape(nsf, 2, -1)
     res = rx.debug(2, np.float32, nsf * 10).reshape(nsf, 10)
-    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * max_re * cfg.Qm).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
     n_ok = 0
     for b in range(nsf):
         r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
