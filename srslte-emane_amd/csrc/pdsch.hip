@@ -623,24 +623,32 @@ __global__ __launch_bounds__(256) void pusch_eq_kernel(const cf32* __restrict__ 
   z[((size_t)sf * 12 + n) * g.M_sc + k] = make_float2(re * 1.0f / csi, im * 1.0f / csi);
 }
 
-// grid = (ceil(M_sc/256), 12, nof_sf): demap symbol (n, k), descramble in the received (symbol-major) bit order, and store at the
-// de-interleaved position: g[(k * 12 + n) * Qm + b] = q[(n * M_sc + k) * Qm + b] (36.212 5.2.2.8 without UCI)
+// grid = (ceil(M_sc/64), nof_sf), 256 threads: demap the 12 symbols of 64 sub-carriers, descramble in the received (symbol-major)
+// bit order and store at the de-interleaved position g[(k * 12 + n) * Qm + b] = q[(n * M_sc + k) * Qm + b] (36.212 5.2.2.8 without
+// UCI). The 64 x 12 x Qm LLRs of a workgroup are contiguous in g: they are collected in LDS and leave with 16-byte stores
+// (a 2-byte store per lane at a 24 Qm byte stride costs the L1 one cache line per lane).
 __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict__ d, const uint32_t* __restrict__ scr, int16_t* __restrict__ gout,
                                                           PuschGeom g)
 {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
-  if (k >= g.M_sc) return;
-  const int nsym = 12 * g.M_sc, i = n * g.M_sc + k;
-  short     o[8];
-  demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
-  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
-  int16_t*        dst = gout + (size_t)sf * nsym * g.Qm + (size_t)(k * 12 + n) * g.Qm;
-  for (int b = 0; b < g.Qm; b++) {
-    const int bit = i * g.Qm + b;
-    short     v   = o[b];
-    if ((cs[bit >> 5] >> (bit & 31)) & 1) v = (short)-v;
-    dst[b] = v;
+  __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
+  const int k0 = blockIdx.x * 64, sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = 12 * g.M_sc;
+  const int nk = min(64, g.M_sc - k0);
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+  for (int t = threadIdx.x; t < 64 * 12; t += 256) {
+    const int n = t >> 6, kl = t & 63;
+    if (kl >= nk) continue;
+    const int i = n * g.M_sc + k0 + kl;
+    short     o[8];
+    demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
+    const int      bit0 = i * g.Qm;
+    const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
+    for (int b = 0; b < g.Qm; b++) stage[(kl * 12 + n) * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
   }
+  __syncthreads();
+  const int    nbytes = nk * 12 * g.Qm * 2; // a multiple of 48
+  char*        dst    = reinterpret_cast<char*>(gout + (size_t)sf * nsym * g.Qm + (size_t)k0 * 12 * g.Qm);
+  const char*  src    = reinterpret_cast<const char*>(stage);
+  for (int o16 = threadIdx.x * 16; o16 < nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
 }
 
 } // namespace
@@ -692,7 +700,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
     return nullptr;
   }
   const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
-  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
+  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32 + 1; // spare word: the demapper reads two per symbol
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
   q->chest = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
@@ -802,7 +810,7 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   LAUNCH_CHECK();
   r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, 12 * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
   if (r) return r;
-  hipLaunchKernelGGL(pusch_demod_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
+  hipLaunchKernelGGL(pusch_demod_kernel, dim3(ceil_div(g.M_sc, 64), nof_sf), dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
   LAUNCH_CHECK();
   RmGeom rg = q->rg;
   rg.tti0   = (int)tti0;
