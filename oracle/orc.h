@@ -125,6 +125,9 @@ int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t*
                  orc_chest_res_t* res);
 int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res); /* nof_rx receive antennas, one port */
+/* cell->nof_ports in {1, 2} tx ports x nof_rx antennas: ce[port * nof_rx + antenna]; raw_out [antenna][port]{noise, rsrp, rssi, cfo} */
+int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                       orc_cf_t* const* ce, orc_chest_res_t* res, float* raw_out);
 
 /* ---------------------------------------------------------------- modem */
 enum { ORC_MOD_BPSK = 0, ORC_MOD_QPSK, ORC_MOD_16QAM, ORC_MOD_64QAM, ORC_MOD_256QAM };
@@ -138,7 +141,12 @@ int orc_demod_soft_b(int mod, const orc_cf_t* sym, int8_t* llr, int nsym);
 /* precoding.c:238-249,293-322 single-port one-tap equaliser */
 void orc_predecoding_single(const orc_cf_t* y, const orc_cf_t* h, orc_cf_t* x, int nsym, float scaling, float noise_estimate);
 void orc_predecoding_single_multi(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x, int nof_rx, int nsym, float scaling,
-                                  float noise_estimate); /* precoding.c:138-262,:325-348 */
+                                  float noise_estimate);
+/* 2-port transmit diversity: layer mapping + SFBC precoding (layermap.c:36-44, precoding.c:1848-1861) and the receive side
+ * srslte_predecoding_diversity_csi + srslte_layerdemap_diversity (precoding.c:564-598, layermap.c:140-148); h[port * nof_rx + antenna] */
+void orc_precoding_diversity2(const orc_cf_t* d, orc_cf_t* y0, orc_cf_t* y1, int nof_symbols, float scaling);
+void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* d, float* csi, int nof_rx, int nof_symbols,
+                                float scaling); /* precoding.c:138-262,:325-348 */
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
 int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx);
 int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms,

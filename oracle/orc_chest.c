@@ -94,12 +94,14 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
   free(diff);
 }
 
-/* estimate_port for port 0 of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo} of that antenna */
-static int chest_port0(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, float raw[4])
+/* estimate_port for port 0 or 1 of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo} of that (antenna, port).
+   Ports 2 and 3 (two pilot symbols per subframe, different time interpolation) are not restated. */
+static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, uint32_t port,
+                      float raw[4])
 {
-  const uint32_t port = 0, P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
+  const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
-  if (!cell->cp_norm) return -1; /* extended CP time interpolation not restated */
+  if (!cell->cp_norm || port > 1) return -1; /* extended CP time interpolation not restated */
   cf* known = malloc(sizeof(cf) * npil);
   cf* recv  = malloc(sizeof(cf) * npil);
   cf* est   = malloc(sizeof(cf) * npil);
@@ -216,23 +218,32 @@ static int chest_port0(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_
   return 0;
 }
 
-static void fill_res(uint32_t P, uint32_t nof_rx, float raw[][4], orc_chest_res_t* res)
-{ /* chest_dl.c:747-871 for one port: noise, RSSI and RSRQ are averaged over the receive antennas; get_rsrp (:809-819) takes the
-     maximum over "ports" indexed by the antenna counter, i.e. max(mean over antennas of port 0, 0 for every never-estimated port) */
-  float noise = 0, rssi = 0, rsrq = 0, rsrp0 = 0;
+static void fill_res(uint32_t P, uint32_t nof_rx, uint32_t nof_ports, float raw[4][4][4] /* [antenna][port] */, bool cfo_enable, orc_chest_res_t* res)
+{ /* chest_dl.c:747-871: noise is averaged over ports and antennas; RSSI and RSRQ use port 0 and are averaged over the antennas;
+     get_rsrp (:809-819) takes the maximum over "ports" indexed by the ANTENNA counter of the antenna-mean RSRP of that port (0 for a
+     port that was never estimated); q->cfo is overwritten by every (antenna, port) estimate in turn, so the last one survives */
+  float noise = 0, rssi = 0, rsrq = 0;
   for (uint32_t a = 0; a < nof_rx; a++) {
-    noise += raw[a][0] / 1; /* srslte_vec_acc_ff(noise_estimate[a], nof_ports) / nof_ports with one port */
-    rssi += 4 * raw[a][2] / P / 12;
-    rsrq += P * raw[a][1] / raw[a][2];
-    rsrp0 += raw[a][1];
+    float n = 0;
+    for (uint32_t p = 0; p < nof_ports; p++) n += raw[a][p][0];
+    noise += n / nof_ports;
+    rssi += 4 * raw[a][0][2] / P / 12;
+    rsrq += P * raw[a][0][1] / raw[a][0][2];
   }
-  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx; rsrp0 /= nof_rx;
-  float rsrp = rsrp0;
-  if (nof_rx > 1 && rsrp < 0.0f) rsrp = 0.0f;
+  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx;
+  float rsrp = -1e9f;
+  for (uint32_t i = 0; i < nof_rx; i++) {
+    float v = 0;
+    if (i < nof_ports) {
+      for (uint32_t a = 0; a < nof_rx; a++) v += raw[a][i][1];
+      v /= nof_rx;
+    }
+    if (v > rsrp) rsrp = v;
+  }
   memset(res, 0, sizeof(*res));
   res->noise_estimate     = noise;
   res->noise_estimate_dbm = (float)(10 * log10(noise) + 30);
-  res->cfo                = raw[0][3];
+  res->cfo                = cfo_enable ? raw[nof_rx - 1][nof_ports - 1][3] : 0.f;
   res->rsrp               = rsrp;
   res->rsrp_dbm           = (float)(10 * log10(rsrp) + 30);
   res->rsrq               = rsrq;
@@ -242,25 +253,40 @@ static void fill_res(uint32_t P, uint32_t nof_rx, float raw[][4], orc_chest_res_
   res->sync_error         = NAN;
 }
 
+int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                       orc_cf_t* const* ce /* [port * nof_rx + antenna] */, orc_chest_res_t* res, float* raw_out /* [antenna][port][4] or NULL */)
+{ /* srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for cell->nof_ports in {1, 2} and nof_rx receive antennas */
+  float raw[4][4][4];
+  memset(raw, 0, sizeof(raw));
+  if (nof_rx < 1 || nof_rx > 4 || cell->nof_ports < 1 || cell->nof_ports > 2) return -1;
+  for (uint32_t a = 0; a < nof_rx; a++) {
+    for (uint32_t p = 0; p < cell->nof_ports; p++) {
+      int r = chest_port(cell, sf_idx, cfg, grid[a], ce ? ce[p * nof_rx + a] : NULL, p, raw[a][p]);
+      if (r) return r;
+    }
+  }
+  if (res) fill_res(cell->nof_prb, nof_rx, cell->nof_ports, raw, cfg->cfo_estimate_enable, res);
+  if (raw_out) {
+    for (uint32_t a = 0; a < nof_rx; a++) {
+      for (uint32_t p = 0; p < cell->nof_ports; p++) memcpy(&raw_out[(a * cell->nof_ports + p) * 4], raw[a][p], sizeof(float) * 4);
+    }
+  }
+  return 0;
+}
+
 int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, orc_chest_res_t* res)
-{
-  float raw[1][4];
-  int   r = chest_port0(cell, sf_idx, cfg, grid, ce, raw[0]);
-  if (r == 0 && res) fill_res(cell->nof_prb, 1, raw, res);
-  return r;
+{ /* one antenna, one port */
+  orc_cell_t c1 = *cell;
+  c1.nof_ports  = 1;
+  return orc_chest_dl_ports(&c1, sf_idx, cfg, 1, &grid, ce ? &ce : NULL, res, NULL);
 }
 
 int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res)
-{ /* srslte_chest_dl_estimate_cfg with nof_rx_antennas receive antennas, one port (chest_dl.c:884-908) */
-  float raw[4][4];
-  if (nof_rx < 1 || nof_rx > 4) return -1;
-  for (uint32_t a = 0; a < nof_rx; a++) {
-    int r = chest_port0(cell, sf_idx, cfg, grid[a], ce ? ce[a] : NULL, raw[a]);
-    if (r) return r;
-  }
-  if (res) fill_res(cell->nof_prb, nof_rx, raw, res);
-  return 0;
+{ /* nof_rx receive antennas, one port */
+  orc_cell_t c1 = *cell;
+  c1.nof_ports  = 1;
+  return orc_chest_dl_ports(&c1, sf_idx, cfg, nof_rx, grid, ce, res, NULL);
 }
 
 /* ------------------------------------------------------------------ UL: PUSCH DMRS (refsignal_ul.c) and srslte_chest_ul_estimate_pusch

@@ -5,6 +5,7 @@
  * (precoding.c:238-322), LLR descrambling (scrambling.c:45-48, sequences.c:58-60).
  */
 #include "orc.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -95,4 +96,48 @@ void orc_scramble_b(int8_t* llr, const uint8_t* c, int len)
 uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t cell_id)
 { /* sequences.c:58-60 with nslot = 2*sf_idx (pdsch.c:469) */
   return ((uint32_t)rnti << 14) + (cw << 13) + (((2 * sf_idx) / 2) << 9) + cell_id;
+}
+
+/* ------------------------------------------------------------------ 2-port transmit diversity (SFBC), SURVEY §8f N4 */
+
+void orc_precoding_diversity2(const orc_cf_t* d, orc_cf_t* y0, orc_cf_t* y1, int nof_symbols, float scaling)
+{ /* srslte_layermap_diversity (layermap.c:36-44) + srslte_precoding_diversity for 2 ports (precoding.c:1848-1861): d[nof_symbols]
+     -> layers x0 = d[2i], x1 = d[2i+1] -> y0[2i] = x0, y1[2i] = -x1*, y0[2i+1] = x1, y1[2i+1] = x0*, all times scaling / sqrt(2) */
+  const float g = scaling / sqrtf(2);
+  for (int i = 0; i < nof_symbols / 2; i++) {
+    const orc_cf_t x0 = d[2 * i], x1 = d[2 * i + 1];
+    y0[2 * i]     = (orc_cf_t){x0.re * g, x0.im * g};
+    y1[2 * i]     = (orc_cf_t){-x1.re * g, x1.im * g};
+    y0[2 * i + 1] = (orc_cf_t){x1.re * g, x1.im * g};
+    y1[2 * i + 1] = (orc_cf_t){x0.re * g, -x0.im * g};
+  }
+}
+
+void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const* h /* [port * nof_rx + antenna] */, orc_cf_t* d, float* csi,
+                                int nof_rx, int nof_symbols, float scaling)
+{ /* srslte_predecoding_diversity_csi for 2 ports (precoding.c:564-598; the variant srslte_pdsch_decode reaches because the UE object
+     always carries a csi buffer) followed by srslte_layerdemap_diversity (layermap.c:140-148): d[2i] = x0[i], d[2i+1] = x1[i].
+     The upstream accumulates hh across antennas BEFORE testing it for zero, inside the antenna loop; reproduced. */
+  for (int i = 0; i < nof_symbols / 2; i++) {
+    float hh = 0, x0r = 0, x0i = 0, x1r = 0, x1i = 0;
+    for (int p = 0; p < nof_rx; p++) {
+      const orc_cf_t h00 = h[p][2 * i], h01 = h[p][2 * i + 1], h10 = h[nof_rx + p][2 * i], h11 = h[nof_rx + p][2 * i + 1];
+      const orc_cf_t r0 = y[p][2 * i], r1 = y[p][2 * i + 1];
+      hh += h00.re * h00.re + h00.im * h00.im + h11.re * h11.re + h11.im * h11.im;
+      if (hh == 0) hh = 1e-4f;
+      /* x0 += conj(h00) r0 + h11 conj(r1) */
+      x0r += h00.re * r0.re + h00.im * r0.im + h11.re * r1.re + h11.im * r1.im;
+      x0i += h00.re * r0.im - h00.im * r0.re + h11.im * r1.re - h11.re * r1.im;
+      /* x1 += -h10 conj(r0) + conj(h01) r1 */
+      x1r += -(h10.re * r0.re + h10.im * r0.im) + h01.re * r1.re + h01.im * r1.im;
+      x1i += -(h10.im * r0.re - h10.re * r0.im) + h01.re * r1.im - h01.im * r1.re;
+    }
+    if (csi) {
+      csi[2 * i]     = hh;
+      csi[2 * i + 1] = hh;
+    }
+    hh *= scaling;
+    d[2 * i]     = (orc_cf_t){(float)((double)(x0r / hh) * sqrt(2)), (float)((double)(x0i / hh) * sqrt(2))};
+    d[2 * i + 1] = (orc_cf_t){(float)((double)(x1r / hh) * sqrt(2)), (float)((double)(x1i / hh) * sqrt(2))};
+  }
 }

@@ -284,6 +284,73 @@ def test_chest_dl_two_rx_antennas_vs_ref(prb, cid):
         R.srslte_chest_dl_free(q)
 
 
+@pytest.mark.parametrize("prb,cid,nrx", [(6, 0, 1), (25, 7, 1), (100, 301, 1), (50, 4, 2), (100, 149, 2)])
+def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
+    """srslte_chest_dl_estimate_cfg for a 2-port cell (ports 0/1 share the pilot values, refsignal_dl.c pilots[port / 2], at v-shifted
+    positions) with 1 and 2 receive antennas: every ce[port][antenna], the aggregated scalars incl. the port-by-antenna-index quirk
+    of get_rsrp and the last-estimate-wins CFO."""
+    R, rng = ref(), np.random.default_rng(3000 + prb + cid + nrx)
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, 2, True)
+    oracle().orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2]), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3]), (4, CHEST_CFGS[4])):
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        tx = []
+        for port in range(2):  # each port: its own CRS (zeros at the other port's positions) and some data
+            g = np.zeros(n, np.complex64)
+            oracle().orc_crs_put_sf(C.byref(cell), sf_idx, port, p(g))
+            tx.append(g)
+        hole = (tx[0] != 0) | (tx[1] != 0)
+        data = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        grids = []
+        for a_ in range(nrx):
+            rxg = np.where(hole, 0, data).astype(np.complex64) * (1.5 - 0.4 * a_)
+            for port in range(2):
+                h = ((2.0 - 0.7 * port + 0.3 * a_) * (1 + 0.25 * np.sin(k / 30.0 + port + 2 * a_)) *
+                     np.exp(1j * (0.4 * port - 0.9 * a_ + k / 80.0 + 0.05 * l))).astype(np.complex64)
+                rxg = rxg + tx[port] * h
+            rxg = rxg + (0.05 + 0.1 * a_) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+            grids.append(acopy(rxg.astype(np.complex64).view(np.float32)))
+        q = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(q, prb, nrx) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 2, cid, 0, 0, 0, 0)) == 0
+        rc, oc = RefChestCfg(), OrcChestCfg()
+        for kk, v in kw.items():
+            if kk == "filter_coef":
+                rc.filter_coef[0], rc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(rc, kk, v)
+                setattr(oc, kk, v)
+        rc.cfo_estimate_sf_mask = 0x3FF
+        res, sf = RefChestRes(), RefDlSfCfg()
+        ce_r = [[aligned(2 * n, np.float32) for _ in range(nrx)] for _ in range(2)]
+        for port in range(2):
+            for a_ in range(nrx):
+                res.ce[port][a_] = ce_r[port][a_].ctypes.data
+        sf.tti = sf_idx
+        inp = (C.c_void_p * 4)(*([g.ctypes.data for g in grids] + [0] * (4 - nrx)))
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+        ce_o, ores = [np.zeros(n, np.complex64) for _ in range(2 * nrx)], OrcChestRes()
+        gp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grids])
+        cp = (C.c_void_p * (2 * nrx))(*[c.ctypes.data for c in ce_o])
+        raw = np.zeros(nrx * 2 * 4, np.float32)
+        assert oracle().orc_chest_dl_ports(C.byref(cell), sf_idx, C.byref(oc), nrx, gp, cp, C.byref(ores), p(raw)) == 0
+        for port in range(2):
+            for a_ in range(nrx):
+                x = ce_r[port][a_].view(np.complex64)
+                assert np.abs(x - ce_o[port * nrx + a_]).max() <= 1e-4 * max(np.abs(x).max(), np.sqrt((np.abs(x) ** 2).mean())), (prb, cid, port, a_)
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y, sf_idx)
+        raw = raw.reshape(nrx, 2, 4)
+        for port in range(2):  # per-port fields of fill_res (chest_dl.c:860-870) from the per-(antenna, port) scalars
+            assert abs(res.rsrp_port_dbm[port] - (10 * np.log10(raw[:, port, 1].mean()) + 30)) <= 1e-3
+            for a_ in range(nrx):
+                assert abs(res.snr_ant_port_db[a_][port] - 10 * np.log10(raw[a_, port, 1] / raw[a_, port, 0])) <= 1e-3
+                assert abs(res.rsrq_ant_port_db[a_][port] - 10 * np.log10(prb * raw[a_, port, 1] / raw[a_, port, 2])) <= 1e-3
+        R.srslte_chest_dl_free(q)
+
+
 def test_equaliser_two_rx_vs_ref():
     """srslte_predecoding_single_multi (precoding.c:325-348): AVX body and scalar tail both divide exactly."""
     R, rng = ref(), np.random.default_rng(19)
@@ -298,6 +365,92 @@ def test_equaliser_two_rx_vs_ref():
             R.srslte_predecoding_single_multi(yp, hp, p(a), None, 2, n, 1.0, noise)
             oracle().orc_predecoding_single_multi(yp, hp, p(b), 2, n, 1.0, noise)
             assert np.abs(np.array(a) - np.array(b)).max() <= 2e-6 * np.abs(np.array(b)).max(), (n, noise)
+
+
+def test_tx_diversity_vs_ref():
+    """2-port SFBC: srslte_layermap_diversity + srslte_precoding_diversity on the transmit side, srslte_predecoding_diversity_multi with a
+    csi buffer (the path srslte_pdsch_decode takes) and without one (SSE body) + srslte_layerdemap_diversity on the receive side."""
+    R, rng, orc = ref(), np.random.default_rng(23), oracle()
+    R.srslte_precoding_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    R.srslte_layermap_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    R.srslte_layerdemap_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    R.srslte_predecoding_diversity_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+    orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    orc.orc_predecoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    for n in (24, 1000, 14052):
+        d = acopy(rng.standard_normal(2 * n).astype(np.float32))
+        x = [aligned(n, np.float32), aligned(n, np.float32)]
+        xp = (C.c_void_p * 4)(x[0].ctypes.data, x[1].ctypes.data, 0, 0)
+        assert R.srslte_layermap_diversity(p(d), xp, 2, n) == n // 2
+        y_r = [aligned(2 * n, np.float32), aligned(2 * n, np.float32)]
+        yp = (C.c_void_p * 4)(y_r[0].ctypes.data, y_r[1].ctypes.data, 0, 0)
+        assert R.srslte_precoding_diversity(xp, yp, 2, n // 2, 1.0) == n
+        y_o = [np.zeros(n, np.complex64), np.zeros(n, np.complex64)]
+        orc.orc_precoding_diversity2(p(d), p(y_o[0]), p(y_o[1]), n, 1.0)
+        for port in range(2):
+            assert np.abs(y_r[port].view(np.complex64) - y_o[port]).max() <= 1e-6
+        for nrx in (1, 2):
+            hs = []  # [port * nrx + antenna]; nearly constant over each sub-carrier pair, as SFBC assumes
+            for _ in range(2 * nrx):
+                hc = np.repeat(rng.standard_normal(n // 2) + 1j * rng.standard_normal(n // 2) + 0.5, 2)
+                hc = hc * (1 + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+                hs.append(acopy(hc.astype(np.complex64).view(np.float32)))
+            ys = []
+            for a_ in range(nrx):
+                rx = sum(y_o[port] * hs[port * nrx + a_].view(np.complex64) for port in range(2))
+                rx = rx + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+                ys.append(acopy(rx.astype(np.complex64).view(np.float32)))
+            yp2 = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))
+            hp = ((C.c_void_p * 4) * 4)()
+            for port in range(2):
+                for a_ in range(nrx):
+                    hp[port][a_] = hs[port * nrx + a_].ctypes.data
+            d_o, csi_o = np.zeros(n, np.complex64), np.zeros(n, np.float32)
+            yo = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys])
+            ho = (C.c_void_p * (2 * nrx))(*[v.ctypes.data for v in hs])
+            orc.orc_predecoding_diversity2(yo, ho, p(d_o), p(csi_o), nrx, n, 1.0)
+            for with_csi in (True, False):
+                xr = [aligned(n, np.float32), aligned(n, np.float32)]
+                xrp = (C.c_void_p * 4)(xr[0].ctypes.data, xr[1].ctypes.data, 0, 0)
+                csi_r = aligned(n, np.float32)
+                csip = (C.c_void_p * 2)(csi_r.ctypes.data if with_csi else 0, 0)
+                R.srslte_predecoding_diversity_multi(yp2, hp, xrp, csip, nrx, 2, n, 1.0)
+                d_r = aligned(2 * n, np.float32)
+                assert R.srslte_layerdemap_diversity(xrp, p(d_r), 2, n // 2) == n
+                a = d_r.view(np.complex64)
+                assert np.abs(a - d_o).max() <= 2e-6 * max(1.0, np.abs(a).max()), (n, nrx, with_csi)
+                if with_csi:
+                    assert np.abs(np.array(csi_r) - csi_o).max() <= 1e-6 * csi_o.max()
+            # the transmitted symbols come back (noise- and mismatch-limited)
+            assert np.sqrt(np.mean(np.abs(d_o - d.view(np.complex64)) ** 2)) < 0.25
+
+
+PDSCH_GRANT_OFF = {"prb_idx": 8, "nof_prb": 228, "nof_re": 232, "nof_symb_slot": 236}  # srslte_pdsch_grant_t (pdsch_cfg.h:37-49), SRSLTE_MAX_PRB 110
+
+
+@pytest.mark.parametrize("prb,cid,ports,cfi", [(6, 0, 1, 3), (6, 3, 2, 3), (15, 7, 2, 2), (25, 11, 1, 1), (25, 150, 2, 1), (100, 301, 2, 1), (75, 2, 2, 3)])
+def test_pdsch_re_mapping_vs_ref(prb, cid, ports, cfi):
+    """srslte_pdsch_cp (pdsch.c:81-206) on a grid of running indices = orc_pdsch_indices: 1- and 2-port CRS holes, PSS/SSS/PBCH, odd
+    bandwidths, for subframes 0, 5 and an ordinary one."""
+    R = ref()
+    n = 14 * 12 * prb
+    q = opaque(1 << 16)
+    C.memmove(q, C.byref(RefCell(prb, ports, cid, 0, 0, 0, 0)), C.sizeof(RefCell))  # srslte_pdsch_t begins with its srslte_cell_t (pdsch.h:53-54)
+    grant = np.zeros(4096, np.uint8)
+    grant[PDSCH_GRANT_OFF["prb_idx"]:PDSCH_GRANT_OFF["prb_idx"] + 220].reshape(2, 110)[:, :prb] = 1
+    grant[PDSCH_GRANT_OFF["nof_symb_slot"]:PDSCH_GRANT_OFF["nof_symb_slot"] + 8].view(np.uint32)[:] = 7
+    lstart = cfi + (1 if prb < 10 else 0)
+    cell = OrcCell(cid, prb, ports, True)
+    src = acopy(np.arange(2 * n, dtype=np.float32))
+    src.view(np.complex64).real[:] = np.arange(n)
+    R.srslte_pdsch_get.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    for sf_idx in (0, 5, 7):
+        out = aligned(2 * n, np.float32)
+        cnt = R.srslte_pdsch_get(q, p(src), p(out), p(grant), lstart, sf_idx)
+        idx = np.zeros(n, np.uint32)
+        cnt_o = oracle().orc_pdsch_indices(C.byref(cell), sf_idx, lstart, None, p(idx))
+        assert cnt == cnt_o and np.array_equal(out.view(np.complex64).real[:cnt].astype(np.uint32), idx[:cnt]), (sf_idx, cnt, cnt_o)
+        assert ports == 1 or cnt % 2 == 0
 
 
 def test_equaliser_vs_ref_rcp_tolerance():
