@@ -87,12 +87,13 @@ void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
 const void*            srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q); /* device CRS table [10][4][2*prb] (refsignal_dl.c:66-116) */
 int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                        void* d_ce, void* d_res, int nof_sf, void* stream);
-/* nof_rx receive antennas, one port (chest_dl.c:884-908 loops over antennas; fill_res :747-871 averages noise, RSSI and RSRQ over
- * them): d_grid / d_ce are [nof_sf][nof_rx][14][12*nof_prb], d_res stays one entry per subframe */
+/* nof_rx receive antennas x the object's 1 or 2 tx ports (chest_dl.c:884-908 loops over antennas and ports; fill_res :747-871
+ * combines them): d_grid is [nof_sf][nof_rx][14][12*nof_prb], d_ce [nof_sf][nof_ports][nof_rx][14][12*nof_prb], d_res stays one
+ * entry per subframe. Ports 2 and 3 of a 4-port cell are not implemented (create refuses nof_ports > 2). */
 int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                              void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream);
-/* device pointer to [nof_sf][nof_rx] x {noise_estimate, rsrp, rssi, cfo} of the last multi-antenna call (nof_rx > 1): the
- * per-antenna terms of fill_res (chest_dl.c:860-870) */
+/* device pointer to [nof_sf][nof_ports][nof_rx] x {noise_estimate, rsrp, rssi, cfo} of the last call with more than one (port,
+ * antenna): the per-antenna / per-port terms of fill_res (chest_dl.c:860-870) */
 const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
 
 /* ------------------------------------------------------------------ UL channel estimator (replaces
@@ -175,7 +176,8 @@ int srslte_hip_tc_interl_LTE_gen_interl(uint16_t* forward, uint16_t* reverse, ui
 
 /* ------------------------------------------------------------------ PDSCH receive pipeline (SURVEY §8f N1 glue fused on device):
  * OFDM RX -> chest_dl -> RE extraction + one-tap MMSE -> soft demap + descramble -> turbo rate de-matching ->
- * turbo decode with CRC early stop -> TB CRC. Single port, single rx antenna, full-band grant, rv 0, FDD, normal CP. */
+ * turbo decode with CRC early stop -> TB CRC. One codeword, TM1 (single port) or TM2 (2-port transmit diversity), 1..4 rx antennas,
+ * full-band grant, rv 0, FDD, normal CP. */
 typedef struct srslte_hip_dl_rx srslte_hip_dl_rx_t;
 typedef struct {
   uint32_t cell_id, nof_prb, cfi;
@@ -190,6 +192,9 @@ typedef struct {
                               descrambling, sch.c:336-356 srslte_rm_turbo_rx_lut_8bit + srslte_tdec_iteration_8bit) */
   uint32_t nof_rx_antennas; /* 0 or 1: one antenna; 2..4: per-antenna estimation + srslte_predecoding_single_multi (precoding.c:325-348,
                                pdsch.c:890-935); d_iq / d_grid are then [nof_sf][nof_rx][...] */
+  uint32_t nof_ports;       /* 0 or 1: single antenna port (TM1); 2: 2-port cell with transmit diversity (TM2): 2-port chest_dl, 2-port RE
+                               mapping, srslte_predecoding_diversity_multi + srslte_layerdemap_diversity (precoding.c:564-598,
+                               layermap.c:140-148), for nof_rx_antennas 1..4 */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);

@@ -1,5 +1,5 @@
 // Downlink channel estimator for gfx950: srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for FDD normal
-// subframes, one tx port / one rx antenna per launch slice, batched over subframes.
+// subframes, tx ports 0/1 x up to 4 rx antennas, one (subframe, port, antenna) per workgroup, batched over subframes.
 //
 // One workgroup per subframe fuses what the reference does in ~30 short vector calls: pilot gather + LS
 // (refsignal_dl.c:275-295, chest_dl.c:689-690), RSRP/RSSI/CFO reductions (:558-596, :710-711), noise from
@@ -22,9 +22,10 @@ struct ChestParams {
   int   noise_alg, filter_type, interpolate_subframe, cfo_enable;
   float coef0, coef1;
   int   symbol_sz, cp1; // for CFO
-  int   nof_rx;         // receive antennas: block v handles subframe v / nof_rx, antenna v % nof_rx ([sf][rx][grid] layouts)
+  int   nof_rx;         // receive antennas, tx ports: block v = (sf * nof_ports + port) * nof_rx + antenna reads grid [sf][antenna]
+  int   nof_ports;      // and writes ce [sf][port][antenna]
 };
-struct ChestRaw { float noise, rsrp, rssi, cfo; }; // per (subframe, antenna), combined by chest_fill_res_kernel
+struct ChestRaw { float noise, rsrp, rssi, cfo; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
 
 struct ChestResDev { // mirrors the scalar tail of srslte_chest_dl_res_t (chest_dl.h:49-67) for 1 port / 1 antenna
   float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
@@ -36,7 +37,7 @@ __device__ __forceinline__ cf32 c_scale(cf32 a, float s) { return make_float2(a.
 __device__ __forceinline__ cf32 c_mulconj(cf32 a, cf32 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
 __device__ __forceinline__ int crs_nsymbol(int l) { return (l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7; } // refsignal_dl.c:234-249, normal CP, port<2
-__device__ __forceinline__ int crs_fidx(int cell_id, int l) { return (((l & 1) ? 3 : 0) + (cell_id % 6)) % 6; } // port 0
+__device__ __forceinline__ int crs_fidx(int cell_id, int l, int port) { return ((((l + port) & 1) ? 3 : 0) + (cell_id % 6)) % 6; } // refsignal_dl.c:134-168, ports 0/1
 
 __device__ float block_sum(float v, float* red)
 {
@@ -96,15 +97,16 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   __shared__ float red[CH_THREADS / 64];
   __shared__ float filt[64];
 
-  const int   sf     = blockIdx.x, sf_idx = (p.tti0 + sf / p.nof_rx) % 10, tid = threadIdx.x; // sf: (subframe, antenna) index
-  const cf32* g      = grid + (size_t)sf * 14 * nre;
-  const cf32* known  = pilots + (size_t)sf_idx * npil;
+  const int   sf = blockIdx.x, tid = threadIdx.x; // sf: (subframe, port, antenna) index
+  const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
+  const cf32* g      = grid + ((size_t)sfn * p.nof_rx + ant) * 14 * nre;
+  const cf32* known  = pilots + (size_t)sf_idx * npil; // ports 0 and 1 carry the same values (refsignal_dl.c pilots[port / 2])
 
   // ---- pilots, LS, RSRP
   float acc = 0;
   for (int i = tid; i < npil; i += CH_THREADS) {
     const int l = i / nref, k = i - l * nref;
-    cf32      r = g[crs_nsymbol(l) * nre + crs_fidx(p.cell_id, l) + 6 * k];
+    cf32      r = g[crs_nsymbol(l) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
     est[i]      = c_mulconj(r, known[i]);
     acc += r.x * r.x + r.y * r.y;
   }
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   // ---- noise from pilots (REFS): residual of the last pilot symbol only (chest_dl.c:352-378)
   float noise = 0;
   if (p.noise_alg == 0) {
-    const int   off = crs_fidx(p.cell_id, 0) < 3 ? 0 : 1;
+    const int   off = crs_fidx(p.cell_id, 0, port) < 3 ? 0 : 1;
     const cf32 *r0 = est, *r2 = est + 2 * nref, *r3 = est + 3 * nref;
     acc = 0;
     for (int k = tid; k < nref; k += CH_THREADS) {
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     if (p.filter_type != 2) { // average_pilots
       int n = nref, ns = 4;
       if (!p.interpolate_subframe) {
-        const bool first_low = crs_fidx(p.cell_id, 0) < 3;
+        const bool first_low = crs_fidx(p.cell_id, 0, port) < 3;
         for (int k = tid; k < nref; k += CH_THREADS) {
           cf32 a = c_add(est[k], est[2 * nref + k]), b = c_add(est[nref + k], est[3 * nref + k]);
           avg[2 * k]     = c_scale(first_low ? a : b, 2.0f / 4.0f);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     } else { // chest_dl.c:456-495
       for (int i = tid; i < 4 * nre; i += CH_THREADS) {
         const int l = i / nre;
-        fr[i]       = interp_offset_at(pil + nref * l, nref, 6, crs_fidx(p.cell_id, l), i - l * nre);
+        fr[i]       = interp_offset_at(pil + nref * l, nref, 6, crs_fidx(p.cell_id, l, port), i - l * nre);
       }
       __syncthreads();
       for (int k = tid; k < nre; k += CH_THREADS) {
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   }
 
   if (tid == 0 && raw) raw[sf] = ChestRaw{noise, rsrp, rssi, cfo};
-  if (tid == 0 && res && p.nof_rx == 1) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
+  if (tid == 0 && res && p.nof_rx * p.nof_ports == 1) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
     ChestResDev r;
     r.noise_estimate     = noise;
     r.noise_estimate_dbm = (float)(10 * log10((double)noise) + 30);
@@ -254,26 +256,36 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   }
 }
 
-// fill_res (chest_dl.c:747-871) for nof_rx > 1, one port: noise, RSSI and RSRQ averaged over the antennas; get_rsrp (:809-819)
-// indexes ports with the antenna counter, so it is max(mean RSRP of port 0, 0); CFO of antenna 0
-__global__ void chest_fill_res_kernel(const ChestRaw* __restrict__ raw, ChestResDev* __restrict__ res, int nof_sf, int nof_rx, int P)
+// fill_res (chest_dl.c:747-871) for more than one (antenna, port): noise averaged over ports and antennas; RSSI and RSRQ from port 0,
+// averaged over the antennas; get_rsrp (:809-819) indexes ports with the ANTENNA counter: max over i < nof_rx of the antenna-mean RSRP
+// of port i (0 for a port that was never estimated); q->cfo is overwritten by every estimate in turn: the last (antenna, port) survives
+__global__ void chest_fill_res_kernel(const ChestRaw* __restrict__ raw, ChestResDev* __restrict__ res, int nof_sf, int nof_rx, int nof_ports, int P)
 {
   const int sf = blockIdx.x * blockDim.x + threadIdx.x;
   if (sf >= nof_sf) return;
-  float noise = 0, rssi = 0, rsrq = 0, rsrp = 0;
+  const ChestRaw* r = raw + (size_t)sf * nof_ports * nof_rx; // [port][antenna]
+  float noise = 0, rssi = 0, rsrq = 0;
   for (int a = 0; a < nof_rx; a++) {
-    const ChestRaw r = raw[sf * nof_rx + a];
-    noise += r.noise;
-    rssi += 4 * r.rssi / P / 12;
-    rsrq += P * r.rsrp / r.rssi;
-    rsrp += r.rsrp;
+    float n = 0;
+    for (int pt = 0; pt < nof_ports; pt++) n += r[pt * nof_rx + a].noise;
+    noise += n / nof_ports;
+    rssi += 4 * r[a].rssi / P / 12;
+    rsrq += P * r[a].rsrp / r[a].rssi;
   }
-  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx; rsrp /= nof_rx;
-  if (rsrp < 0.f) rsrp = 0.f;
+  noise /= nof_rx; rssi /= nof_rx; rsrq /= nof_rx;
+  float rsrp = -1e9f;
+  for (int i = 0; i < nof_rx; i++) {
+    float v = 0;
+    if (i < nof_ports) {
+      for (int a = 0; a < nof_rx; a++) v += r[i * nof_rx + a].rsrp;
+      v /= nof_rx;
+    }
+    rsrp = v > rsrp ? v : rsrp;
+  }
   ChestResDev o;
   o.noise_estimate     = noise;
   o.noise_estimate_dbm = (float)(10 * log10((double)noise) + 30);
-  o.cfo                = raw[sf * nof_rx].cfo;
+  o.cfo                = r[(nof_ports - 1) * nof_rx + nof_rx - 1].cfo;
   o.rsrp               = rsrp;
   o.rsrp_dbm           = (float)(10 * log10((double)rsrp) + 30);
   o.rsrq               = rsrq;
@@ -304,16 +316,16 @@ void gold(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c)
 void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) { gold(c_init, len, c); }
 
 struct srslte_hip_chest_dl {
-  int       cell_id, nof_prb;
-  cf32*     d_pilots; // [10][4][2*nof_prb], port 0
-  ChestRaw* d_raw;    // per (subframe, antenna) scalars of multi-antenna calls, grown on demand
+  int       cell_id, nof_prb, nof_ports;
+  cf32*     d_pilots; // [10][4][2*nof_prb], ports 0 and 1
+  ChestRaw* d_raw;    // per (subframe, port, antenna) scalars of multi-antenna / multi-port calls, grown on demand
   size_t    raw_cap;
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
 {
-  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || nof_ports != 1 || !cp_is_norm) {
-    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); single-port normal CP only\n", cell_id,
+  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || nof_ports < 1 || nof_ports > 2 || !cp_is_norm) {
+    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1 or 2 ports, normal CP only\n", cell_id,
             nof_prb, nof_ports, cp_is_norm);
     return nullptr;
   }
@@ -335,6 +347,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   auto* q     = new srslte_hip_chest_dl();
   q->cell_id  = cell_id;
   q->nof_prb  = nof_prb;
+  q->nof_ports = (int)nof_ports;
   q->d_pilots = nullptr;
   q->d_raw    = nullptr;
   q->raw_cap  = 0;
@@ -357,7 +370,8 @@ extern "C" void srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q)
 
 extern "C" const void* srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q) { return q ? q->d_pilots : nullptr; }
 
-// d_grid: [nof_sf][nof_rx][14][12*prb]; d_ce: same shape or NULL (measurements only); d_res: [nof_sf] srslte_hip_chest_res_t or NULL.
+// d_grid: [nof_sf][nof_rx][14][12*prb]; d_ce: [nof_sf][nof_ports][nof_rx][14][12*prb] or NULL (measurements only); d_res: [nof_sf]
+// srslte_hip_chest_res_t or NULL.
 // Subframe b of the batch is TTI tti0 + b (sf_idx = TTI mod 10).
 extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
                                                         const void* d_grid, void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream)
@@ -377,9 +391,11 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.symbol_sz = lte_symbol_sz(q->nof_prb);
   p.cp1 = lte_cp_len_norm(1, p.symbol_sz);
   p.nof_rx = nof_rx;
+  p.nof_ports = q->nof_ports;
+  const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
-  if (nof_rx > 1 && d_res) {
-    const size_t need = (size_t)nof_sf * nof_rx;
+  if (nslice > 1 && d_res) {
+    const size_t need = (size_t)nof_sf * nslice;
     if (need > q->raw_cap) {
       if (q->d_raw) (void)hipFree(q->d_raw);
       q->d_raw = nullptr;
@@ -390,18 +406,18 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   }
   const int nref = 2 * q->nof_prb, nre = 12 * q->nof_prb;
   size_t lds = sizeof(cf32) * (8 * nref + (cfg->interpolate_subframe ? 4 * nre : 0));
-  hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf * nof_rx), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
+  hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf * nslice), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
                      (ChestResDev*)d_res, raw, (const cf32*)q->d_pilots, p);
   LAUNCH_CHECK();
   if (raw) {
     hipLaunchKernelGGL(chest_fill_res_kernel, dim3((nof_sf + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ChestRaw*)raw,
-                       (ChestResDev*)d_res, nof_sf, nof_rx, q->nof_prb);
+                       (ChestResDev*)d_res, nof_sf, nof_rx, q->nof_ports, q->nof_prb);
     LAUNCH_CHECK();
   }
   return SRSLTE_SUCCESS;
 }
 
-// [nof_sf][nof_rx] x {noise, rsrp, rssi, cfo} of the last multi-antenna call with d_res != NULL (device memory owned by q): what
+// [nof_sf][nof_ports][nof_rx] x {noise, rsrp, rssi, cfo} of the last multi-antenna / multi-port call with d_res != NULL (device memory owned by q): what
 // the per-antenna fields of srslte_chest_dl_res_t are made of (chest_dl.c:860-870)
 extern "C" const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q) { return q ? (const float*)q->d_raw : nullptr; }
 

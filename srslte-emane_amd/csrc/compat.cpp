@@ -922,19 +922,19 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
 { // chest_dl.c:884-908
   auto* st = q ? (ChestState*)q->tmp_noise : nullptr;
   if (!st || !st->h || !sf || !cfg || !input || !res) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->cell.nof_ports != 1 || sf->sf_type != SRSLTE_SF_NORM) {
-    ERROR("chest_dl: only 1 tx port / normal subframes are implemented on device");
+  if (q->cell.nof_ports > 2 || sf->sf_type != SRSLTE_SF_NORM) {
+    ERROR("chest_dl: only 1 or 2 tx ports / normal subframes are implemented on device");
     return SRSLTE_ERROR;
   }
-  const uint32_t nrx = q->nof_rx_antennas;
+  const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
   const size_t   n   = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
-  char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx);
+  char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx * npt);
   void*          dres = st->res.get(sizeof(srslte_hip_chest_dl_res_t));
   if (!dg || !dce || !dres) return SRSLTE_ERROR;
   bool want_ce = false;
   for (uint32_t a = 0; a < nrx; a++) {
     if (!input[a] || !h2d(dg + a * n, input[a], n)) return SRSLTE_ERROR_INVALID_INPUTS;
-    want_ce = want_ce || res->ce[0][a];
+    for (uint32_t pt = 0; pt < npt; pt++) want_ce = want_ce || res->ce[pt][a];
   }
   srslte_hip_chest_dl_cfg_t hc;
   memset(&hc, 0, sizeof(hc));
@@ -945,8 +945,10 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, nullptr)) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
   if (!d2h(&r, dres, sizeof(r))) return SRSLTE_ERROR;
-  for (uint32_t a = 0; a < nrx; a++) {
-    if (res->ce[0][a] && !d2h(res->ce[0][a], dce + a * n, n)) return SRSLTE_ERROR;
+  for (uint32_t pt = 0; pt < npt; pt++) {
+    for (uint32_t a = 0; a < nrx; a++) {
+      if (res->ce[pt][a] && !d2h(res->ce[pt][a], dce + (pt * nrx + a) * n, n)) return SRSLTE_ERROR;
+    }
   }
   // fill_res, chest_dl.c:845-871
   if (hc.cfo_estimate_enable) q->cfo = r.cfo;
@@ -954,25 +956,28 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   res->noise_estimate = r.noise_estimate; res->noise_estimate_dbm = r.noise_estimate_dbm; res->snr_db = r.snr_db;
   res->rsrp = r.rsrp; res->rsrp_dbm = r.rsrp_dbm; res->rsrq = r.rsrq; res->rsrq_db = r.rsrq_db; res->rssi_dbm = r.rssi_dbm;
   res->cfo = q->cfo; res->sync_error = NAN; res->rsrp_neigh = 0.f;
-  if (nrx == 1) {
+  if (nrx * npt == 1) {
     q->noise_estimate[0][0] = r.noise_estimate;
     q->rsrp[0][0]           = r.rsrp;
     res->rsrp_port_dbm[0] = r.rsrp_dbm; res->snr_ant_port_db[0][0] = r.snr_db; res->rsrp_ant_port_dbm[0][0] = r.rsrp_dbm;
     res->rsrq_ant_port_db[0][0] = r.rsrq_db;
-  } else { // per-antenna fields (chest_dl.c:860-870) from the per-antenna scalars the device kept
-    float raw[SRSLTE_MAX_PORTS][4];
-    if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 4 * nrx)) return SRSLTE_ERROR;
-    float mean_rsrp = 0.f;
-    for (uint32_t a = 0; a < nrx; a++) {
-      q->noise_estimate[a][0] = raw[a][0];
-      q->rsrp[a][0]           = raw[a][1];
-      q->rssi[a][0]           = raw[a][2];
-      mean_rsrp += raw[a][1] / nrx;
-      res->snr_ant_port_db[a][0]   = (float)(10 * log10(raw[a][1] / raw[a][0]));
-      res->rsrp_ant_port_dbm[a][0] = (float)(10 * log10(raw[a][1]) + 30);
-      res->rsrq_ant_port_db[a][0]  = (float)(10 * log10(q->cell.nof_prb * raw[a][1] / raw[a][2]));
+  } else { // per-antenna / per-port fields (chest_dl.c:860-870) from the per-(port, antenna) scalars the device kept
+    float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][4]; // [port][antenna]
+    if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 4 * nrx * npt)) return SRSLTE_ERROR;
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      float mean_rsrp = 0.f;
+      for (uint32_t a = 0; a < nrx; a++) {
+        const float* v = raw[pt * nrx + a];
+        q->noise_estimate[a][pt] = v[0];
+        q->rsrp[a][pt]           = v[1];
+        q->rssi[a][pt]           = v[2];
+        mean_rsrp += v[1] / nrx;
+        res->snr_ant_port_db[a][pt]   = (float)(10 * log10(v[1] / v[0]));
+        res->rsrp_ant_port_dbm[a][pt] = (float)(10 * log10(v[1]) + 30);
+        res->rsrq_ant_port_db[a][pt]  = (float)(10 * log10(q->cell.nof_prb * v[1] / v[2]));
+      }
+      res->rsrp_port_dbm[pt] = (float)(10 * log10(mean_rsrp) + 30);
     }
-    res->rsrp_port_dbm[0] = (float)(10 * log10(mean_rsrp) + 30);
   }
   return SRSLTE_SUCCESS;
 }

@@ -36,7 +36,7 @@ struct SfClass { // RE list per subframe class: 0 = sf 0 (PSS/SSS+PBCH), 1 = sf 
 struct PdschGeom {
   SfClass cls[3];
   int     grid_len;   // 14 * 12 * nof_prb
-  int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx;
+  int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx, nof_ports;
 };
 
 __device__ __forceinline__ int sf_class(int sf_idx) { return sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2); }
@@ -93,6 +93,61 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   __syncthreads();
   // max_bits is a multiple of 16 and so is 256 * Qm: the workgroup's output starts on a 16-byte boundary
   const int   nbytes = min(256, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const char* src    = reinterpret_cast<const char*>(stage);
+  for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+  const int rem = nbytes & 15;
+  if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
+}
+
+// 2-port transmit diversity (TM2): srslte_predecoding_diversity_csi for 2 ports + srslte_layerdemap_diversity (precoding.c:564-598,
+// layermap.c:140-148; pdsch.c:890-935 with tx_scheme DIVERSITY) fused with the demapper and descrambler. One thread per PAIR of
+// consecutive PDSCH REs (2i, 2i+1) = one SFBC block: x0 = sum_a h00* r0 + h11 r1*, x1 = sum_a -h10 r0* + h01* r1, both divided by
+// sum_a |h00|^2 + |h11|^2 and scaled by sqrt(2); d[2i] = x0, d[2i+1] = x1. ce is [sf][port][antenna][grid]. grid = (ceil(max_re/512), nof_sf).
+template <typename LLR>
+__global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                              const uint32_t* __restrict__ scr, cf32* __restrict__ d_out, LLR* __restrict__ e_out,
+                                                              PdschGeom g)
+{
+  __shared__ __attribute__((aligned(16))) LLR stage[512 * 8];
+  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int     base = blockIdx.x * 512, i0 = base + 2 * threadIdx.x; // nof_re is even for a 2-port cell
+  if (base >= c.nof_re) return;
+  const bool     live = i0 < c.nof_re;
+  const uint32_t k0 = c.idx[live ? i0 : c.nof_re - 2], k1 = c.idx[live ? i0 + 1 : c.nof_re - 1];
+  float          hh = 0.f, x0r = 0.f, x0i = 0.f, x1r = 0.f, x1i = 0.f;
+  for (int a = 0; a < g.nof_rx; a++) {
+    const cf32* y  = grid + ((size_t)sf * g.nof_rx + a) * g.grid_len;
+    const cf32* h0 = ce + (((size_t)sf * 2 + 0) * g.nof_rx + a) * g.grid_len;
+    const cf32* h1 = ce + (((size_t)sf * 2 + 1) * g.nof_rx + a) * g.grid_len;
+    const cf32  r0 = y[k0], r1 = y[k1], h00 = h0[k0], h01 = h0[k1], h10 = h1[k0], h11 = h1[k1];
+    hh += h00.x * h00.x + h00.y * h00.y + h11.x * h11.x + h11.y * h11.y;
+    if (hh == 0.f) hh = 1e-4f;
+    x0r += h00.x * r0.x + h00.y * r0.y + h11.x * r1.x + h11.y * r1.y;
+    x0i += h00.x * r0.y - h00.y * r0.x + h11.y * r1.x - h11.x * r1.y;
+    x1r += -(h10.x * r0.x + h10.y * r0.y) + h01.x * r1.x + h01.y * r1.y;
+    x1i += -(h10.y * r0.x - h10.x * r0.y) + h01.x * r1.y - h01.y * r1.x;
+  }
+  const cf32 x[2] = {make_float2((float)((double)(x0r / hh) * 1.4142135623730951), (float)((double)(x0i / hh) * 1.4142135623730951)),
+                     make_float2((float)((double)(x1r / hh) * 1.4142135623730951), (float)((double)(x1i / hh) * 1.4142135623730951))};
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const int i = (live ? i0 : 0) + t;
+    if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x[t];
+    LLR o[8];
+    if constexpr (sizeof(LLR) == 1) {
+      demod_dev::demod_b(g.mod, x[t], i, c.nof_re, o);
+    } else {
+      demod_dev::demod_s(g.mod, x[t], i, c.nof_re, o);
+    }
+    const int      bit0 = i * g.Qm;
+    const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
+    for (int j = 0; j < g.Qm; j++) stage[(2 * threadIdx.x + t) * g.Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
+  }
+  __syncthreads();
+  const int   nbytes = min(512, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
   char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
   const char* src    = reinterpret_cast<const char*>(stage);
   for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
@@ -302,9 +357,9 @@ std::vector<uint32_t> rm_slot_table(const std::vector<uint32_t>& t, uint32_t w_s
 
 // pdsch.c:81-206 as a per-RE rule (see oracle/orc_pdsch.c for the derivation): symbol-major, sub-carrier ascending,
 // skipping CRS, and the central 72 sub-carriers of the PSS/SSS symbols (slot 0, l >= 5, sf 0/5) and PBCH symbols (slot 1, l < 4, sf 0)
-void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t sf_idx, uint32_t lstart, std::vector<uint32_t>& idx)
+void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, uint32_t sf_idx, uint32_t lstart, std::vector<uint32_t>& idx)
 {
-  const uint32_t nre = 12 * nof_prb;
+  const uint32_t nre = 12 * nof_prb, step = nof_ports == 1 ? 6 : 3; // 2 ports: the other port's CRS positions are left empty too (pdsch.c:103-107)
   idx.clear();
   for (uint32_t s = 0; s < 2; s++) {
     for (uint32_t l = (s == 0 ? lstart : 0); l < 7; l++) {
@@ -313,7 +368,7 @@ void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t sf_idx, uint3
       const bool     sync    = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
       for (uint32_t k = 0; k < nre; k++) {
         if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) continue;
-        if (has_ref && (k % 6) == offset % 6) continue;
+        if (has_ref && (k % step) == offset % step) continue;
         idx.push_back((s * 7 + l) * nre + k);
       }
     }
@@ -369,7 +424,7 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
 
 extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4) {
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4 || cfg->nof_ports > 2) {
     fprintf(stderr, "[srslte_hip] dl_rx: invalid configuration\n");
     return nullptr;
   }
@@ -384,8 +439,9 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   const uint32_t P = cfg->nof_prb, nre = 12 * P, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod;
   const uint32_t lstart = cfg->cfi + (P < 10 ? 1 : 0); // SRSLTE_NOF_CTRL_SYMBOLS, phy_common.h:143
   const uint32_t nrx    = cfg->nof_rx_antennas ? cfg->nof_rx_antennas : 1;
+  const uint32_t npt    = cfg->nof_ports ? cfg->nof_ports : 1;
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
-  q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, 1, 1);
+  q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, npt, 1);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
   bool ok  = q->ofdm && q->chest && q->tdec;
   // RE lists
@@ -393,7 +449,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   const uint32_t rep_sf[3] = {0, 5, 1};
   for (int c = 0; c < 3 && ok; c++) {
     std::vector<uint32_t> idx;
-    pdsch_re_indices(cfg->cell_id, P, rep_sf[c], lstart, idx);
+    pdsch_re_indices(cfg->cell_id, P, npt, rep_sf[c], lstart, idx);
     q->pg.cls[c].nof_re = (int)idx.size();
     q->rg.nof_re[c]     = (int)idx.size();
     max_re              = idx.size() > max_re ? (uint32_t)idx.size() : max_re;
@@ -448,7 +504,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   }
   const size_t glen = (size_t)14 * nre;
   ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
-       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
+       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx * npt) == hipSuccess &&
        hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
        hipMalloc((void**)&q->d_e, sizeof(int16_t) * ((size_t)max_bits * B + 16)) == hipSuccess /* +16: rm_rx_lds_kernel reads whole 16-byte words */ &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
@@ -461,7 +517,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     return nullptr;
   }
   q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
-  q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx;
+  q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx; q->pg.nof_ports = (int)npt;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
@@ -518,7 +574,15 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     case 2: {
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
-      if (q->cfg.llr_8bit) {
+      if (g.nof_ports == 2) {
+        if (q->cfg.llr_8bit) {
+          hipLaunchKernelGGL(pdsch_demod_div_kernel<int8_t>, dim3(ceil_div(g.max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
+        } else {
+          hipLaunchKernelGGL(pdsch_demod_div_kernel<int16_t>, dim3(ceil_div(g.max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
+        }
+      } else if (q->cfg.llr_8bit) {
         hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, grid,
                            (const cf32*)q->d_ce, (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
       } else {

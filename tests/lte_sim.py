@@ -15,14 +15,16 @@ MOD_BITS = {0: 1, 1: 2, 2: 4, 3: 6, 4: 8}
 
 
 class DlConfig:
-    """One PDSCH configuration: single port, full-band grant, rv 0."""
+    """One PDSCH configuration: full-band grant, rv 0; nof_ports = 1: single antenna port (TM1),
+    nof_ports = 2: 2-port transmit diversity (TM2)."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
-        self.cell = OrcCell(cell_id, nof_prb, 1, True)
+        self.nof_ports = nof_ports
+        self.cell = OrcCell(cell_id, nof_prb, nof_ports, True)
         self.nre = 12 * nof_prb
         self.grid_len = 14 * self.nre
         self.lstart = cfi + (1 if nof_prb < 10 else 0)
@@ -66,12 +68,14 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0):
     e ^= scramble_seq(cfg, sf_idx, nbits)
     syms = np.zeros(len(idx), np.complex64)
     orc.orc_modulate(cfg.mod, p(e), p(syms), nbits)
-    grid = np.zeros(cfg.grid_len, np.complex64)
-    grid[idx] = syms
-    orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, 0, p(grid))
     q = OrcOfdm()
     orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
     q.normalize = True
+    if cfg.nof_ports == 2:
+        return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp), data
+    grid = np.zeros(cfg.grid_len, np.complex64)
+    grid[idx] = syms
+    orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, 0, p(grid))
     iq = np.zeros(cfg.sf_len, np.complex64)
     orc.orc_ofdm_tx_sf(C.byref(q), p(grid), p(iq))
     iq *= np.float32(amp)
@@ -85,6 +89,37 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0):
         return noisy(iq).astype(np.complex64), data
     gains = (1.0, 0.6 * np.exp(1j * 1.0), 0.8 * np.exp(-1j * 2.0), 0.4j)[:cfg.nof_rx]  # flat per-antenna channels, own noise each
     return np.stack([noisy(np.complex64(g) * iq) for g in gains]).astype(np.complex64), data
+
+
+def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp):
+    """eNB side of pdsch.c:1150-1175 for 2-port transmit diversity: layer mapping + SFBC precoding, RE mapping and CRS per port; every
+    (antenna, port) path has its own smooth frequency response (a gain and a delay), applied in the frequency domain."""
+    orc = oracle()
+    orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    y = [np.zeros(len(idx), np.complex64), np.zeros(len(idx), np.complex64)]
+    orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), 1.0)
+    tx = []
+    for port in range(2):
+        g = np.zeros(cfg.grid_len, np.complex64)
+        g[idx] = y[port]
+        orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, port, p(g))
+        tx.append(g)
+    k = (np.arange(cfg.grid_len) % cfg.nre) - cfg.nre / 2
+    sigma = 0.0 if snr_db is None else np.sqrt(amp * amp * cfg.nre / cfg.N / 2) * 10 ** (-snr_db / 20)
+    out = []
+    for a in range(cfg.nof_rx):
+        rxg = np.zeros(cfg.grid_len, np.complex128)
+        for port in range(2):
+            gain = (1.0, 0.8 * np.exp(0.9j), 0.7 * np.exp(-2.0j), 0.9 * np.exp(2.4j))[2 * a + port]
+            rxg += tx[port] * gain * np.exp(-2j * np.pi * k * (0.6 + 0.9 * port + 0.5 * a) / cfg.N)
+        rxg = np.ascontiguousarray(rxg.astype(np.complex64))
+        iq = np.zeros(cfg.sf_len, np.complex64)
+        orc.orc_ofdm_tx_sf(C.byref(q), p(rxg), p(iq))
+        iq *= np.float32(amp)
+        if snr_db is not None:
+            iq = iq + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
+        out.append(iq.astype(np.complex64))
+    return out[0] if cfg.nof_rx == 1 else np.stack(out)
 
 
 def make_grid(cfg, tti, rng, snr_db):
@@ -132,7 +167,16 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
     ccfg = cfg.orc_chest_cfg()
     idx = cfg.indices(sf_idx)
     d = np.zeros(len(idx), np.complex64)
-    if nrx == 1:
+    if cfg.nof_ports == 2:  # pdsch.c:890-935 with tx_scheme DIVERSITY: srslte_predecoding_diversity_multi (csi variant) + layer demapping
+        ce = np.zeros((2 * nrx, cfg.grid_len), np.complex64)  # [port * nrx + antenna]
+        gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * (2 * nrx))(*[c.ctypes.data for c in ce])
+        orc.orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert orc.orc_chest_dl_ports(C.byref(cfg.cell), sf_idx, C.byref(ccfg), nrx, gp, cp, C.byref(res), None) == 0
+        ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
+        yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (2 * nrx))(*[v.ctypes.data for v in hs])
+        orc.orc_predecoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        orc.orc_predecoding_diversity2(yp, hp, p(d), None, nrx, len(idx), 1.0)
+    elif nrx == 1:
         assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid[0]), p(ce[0]), C.byref(res)) == 0
         y, h = np.ascontiguousarray(grid[0][idx]), np.ascontiguousarray(ce[0][idx])
         orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
@@ -179,7 +223,7 @@ class RefRx:
         self.aligned = aligned
         self.chest = opaque(1 << 20)
         assert self.R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0
-        assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
+        assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)) == 0
         self.rc = RefChestCfg()
         for k, v in cfg.chest.items():
             if k == "filter_coef":
@@ -187,10 +231,12 @@ class RefRx:
             else:
                 setattr(self.rc, k, v)
         self.res, self.sf = RefChestRes(), RefDlSfCfg()
-        self.ces = [aligned(2 * cfg.grid_len, np.float32) for _ in range(cfg.nof_rx)]
-        for a_, c_ in enumerate(self.ces):
-            self.res.ce[0][a_] = c_.ctypes.data
+        self.ces = [aligned(2 * cfg.grid_len, np.float32) for _ in range(cfg.nof_rx * cfg.nof_ports)]  # [port * nof_rx + antenna]
+        for i_, c_ in enumerate(self.ces):
+            self.res.ce[i_ // cfg.nof_rx][i_ % cfg.nof_rx] = c_.ctypes.data
         self.ce = self.ces[0]
+        self.R.srslte_predecoding_diversity_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+        self.R.srslte_layerdemap_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         self.R.srslte_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         self.tdec = opaque(1 << 20)
         assert self.R.srslte_tdec_init(self.tdec, 6144) == 0
@@ -219,11 +265,22 @@ class RefRx:
         idx = self.idx[sf_idx]
         n = len(idx)
         d = self.aligned(2 * n, np.float32)
-        ys, hs = [self.aligned(2 * n, np.float32) for _ in range(nrx)], [self.aligned(2 * n, np.float32) for _ in range(nrx)]
+        ys, hs = [self.aligned(2 * n, np.float32) for _ in range(nrx)], [self.aligned(2 * n, np.float32) for _ in range(nrx * cfg.nof_ports)]
         for a_ in range(nrx):
             ys[a_].view(np.complex64)[:] = grids[a_].view(np.complex64)[idx]
-            hs[a_].view(np.complex64)[:] = self.ces[a_].view(np.complex64)[idx]
-        if nrx == 1:
+        for i_ in range(nrx * cfg.nof_ports):
+            hs[i_].view(np.complex64)[:] = self.ces[i_].view(np.complex64)[idx]
+        if cfg.nof_ports == 2:
+            yp = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))
+            hp = ((C.c_void_p * 4) * 4)()
+            for i_ in range(2 * nrx):
+                hp[i_ // nrx][i_ % nrx] = hs[i_].ctypes.data
+            x = [self.aligned(n, np.float32), self.aligned(n, np.float32)]
+            xp = (C.c_void_p * 4)(x[0].ctypes.data, x[1].ctypes.data, 0, 0)
+            csi = self.aligned(n, np.float32)
+            R.srslte_predecoding_diversity_multi(yp, hp, xp, (C.c_void_p * 2)(csi.ctypes.data, 0), nrx, 2, n, 1.0)
+            R.srslte_layerdemap_diversity(xp, p(d), 2, n // 2)
+        elif nrx == 1:
             R.srslte_predecoding_single(p(ys[0]), p(hs[0]), p(d), None, n, 1.0, self.res.noise_estimate)
         else:
             yp = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))

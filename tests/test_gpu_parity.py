@@ -713,3 +713,46 @@ def test_ul_tx_rx_loop(hp):
     assert ok.all() and np.array_equal(tb[:, :tbs // 8], data)
     tx.free()
     rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,nrx,snr,llr8,tti0,nsf", [(6, 1, 152, 1, 4.0, False, 0, 10), (25, 2, 4008, 1, 11.0, False, 8, 4), (25, 3, 9912, 2, 13.5, False, 3, 4),
+                                                              (100, 3, 75376, 1, 19.5, False, 4, 3), (50, 2, 11448, 2, 7.0, True, 9, 3),
+                                                              (100, 4, 97896, 2, 24.0, False, 5, 2)])
+def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf):
+    """TM2 (2-port transmit diversity) receive chain on the device vs the oracle chain on identical IQ: estimates of
+    both ports on every antenna, noise, SFBC-combined + layer-demapped symbols, LLRs, pass counts, CRC flags, TB bytes."""
+    from lte_sim import DlConfig, make_subframe, oracle_rx
+    rng = np.random.default_rng(1500 + prb + mod + nrx)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=2, llr8=llr8)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=2)
+    rx.keep_symbols()
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    ce = rx.debug(1, np.complex64, nsf * 2 * nrx * cfg.grid_len).reshape(nsf, 2 * nrx, -1)
+    res = rx.debug(2, np.float32, nsf * 10).reshape(nsf, 10)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    d_all = rx.debug(3, np.complex64, nsf * max_re).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        assert nre == len(r["d"]) and nre % 2 == 0
+        for i in range(2 * nrx):
+            assert_close_c(ce[b, i], r["ce"][i], "ce[port %d][antenna %d] sf %d" % (i // nrx, i % nrx, b))
+        assert abs(res[b, 0] - r["noise"]) <= 1e-4 * abs(r["noise"])
+        assert_close_c(d_all[b, :nre], r["d"], "d sf %d" % b)
+        diff = np.abs(e_all[b, :nre * cfg.Qm].astype(np.int32) - r["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"] or diff.max() == 0:
+            assert np.array_equal(tb[b], r["tb"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0
+    rx.free()

@@ -510,6 +510,25 @@ def test_whole_chain_two_rx_vs_reference_code(prb, mod, tbs, snr):
     assert nok > 0
 
 
+@pytest.mark.parametrize("prb,mod,tbs,nrx,snr,llr8", [(6, 1, 152, 1, 4.0, False), (25, 2, 4008, 1, 11.0, False), (25, 3, 9912, 2, 13.5, False),
+                                                        (100, 3, 75376, 1, 19.5, False), (50, 2, 11448, 2, 7.0, True)])
+def test_whole_chain_tx_diversity_vs_reference_code(prb, mod, tbs, nrx, snr, llr8):
+    """2-port transmit diversity (TM2): 2-port chest_dl + srslte_predecoding_diversity_multi + layer demapping in the
+    reference-code chain vs the oracle chain, 1 and 2 receive antennas, near the waterfall."""
+    rng = np.random.default_rng(400 + prb + mod)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=2, llr8=llr8)
+    chain = RefRx(cfg)
+    nok = 0
+    for t in (0, 5, 7, 8):
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"]), t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        nok += r["ok"]
+    assert nok > 0
+
+
 @pytest.mark.parametrize("cell_id,prb", [(1, 6), (77, 25), (301, 100)])
 def test_ul_dmrs_pusch_vs_ref(cell_id, prb):
     """srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): every float of the sequence, incl. group / sequence hopping and all
