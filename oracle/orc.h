@@ -148,6 +148,12 @@ void orc_precoding_diversity2(const orc_cf_t* d, orc_cf_t* y0, orc_cf_t* y1, int
 void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* d, float* csi, int nof_rx, int nof_symbols,
                                 float scaling); /* precoding.c:138-262,:325-348 */
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
+/* CSI weighting of the LLRs when srslte_pdsch_cfg_t.csi_enable is set (the srsUE default): the csi side output of
+ * srslte_predecoding_single_csi (precoding.c:251-291; the diversity one is orc_predecoding_diversity2's) and csi_correction
+ * (pdsch.c:574-690) for 16-bit (SSE body + scalar tail) and 8-bit LLRs */
+void orc_predecoding_csi(const orc_cf_t* const* h, float* csi, int nof_rx, int nsym, float noise_estimate);
+void orc_csi_correction_s(int16_t* e, const float* csi, int nsym, int mod);
+void orc_csi_correction_b(int8_t* e, const float* csi, int nsym, int mod);
 int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx);
 int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, orc_cf_t* grid, orc_cf_t* syms,
                  bool put);

@@ -141,3 +141,93 @@ void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const*
     d[2 * i + 1] = (orc_cf_t){(float)((double)(x1r / hh) * sqrt(2)), (float)((double)(x1i / hh) * sqrt(2))};
   }
 }
+
+/* ------------------------------------------------------------------ CSI weighting of the LLRs (pdsch.c:574-690, cfg->csi_enable) */
+
+void orc_predecoding_csi(const orc_cf_t* const* h, float* csi, int nof_rx, int nsym, float noise_estimate)
+{ /* the csi side output of srslte_predecoding_single_csi (precoding.c:251-291): sum over antennas of |h|^2, plus the noise estimate */
+  for (int i = 0; i < nsym; i++) {
+    float hh = 0;
+    for (int p = 0; p < nof_rx; p++) hh += h[p][i].re * h[p][i].re + h[p][i].im * h[p][i].im;
+    csi[i] = hh + noise_estimate;
+  }
+}
+
+static int16_t csi_weight(float csi, float scale)
+{ /* _mm_cvtps_pi16: round to nearest even, then saturate to int16 */
+  float v = nearbyintf(csi * scale);
+  return (int16_t)(v > 32767.0f ? 32767 : (v < -32768.0f ? -32768 : (int)v));
+}
+
+void orc_csi_correction_s(int16_t* e, const float* csi, int nsym, int mod)
+{ /* pdsch.c:599-603,:615-689, 16-bit LLRs on an SSE host: weights w = round(csi * 32767 / csi_max), e <- (e * w) >> 16 for whole groups of
+     4 (QPSK: two symbols; 16QAM: one), 12 (64QAM: two symbols) or 8 (256QAM: one) LLRs; the symbols a group does not cover get
+     e <- (int16)(e * csi / csi_max) instead - without the factor 1/2 the high-half multiplication implies; reproduced.
+     In the two-symbol groups _mm_blend_ps(a, b, 3) takes its LOW two lanes from b: QPSK weighs symbol 2j with csi[2j+1] and vice versa,
+     64QAM weighs LLRs 4,5 of a group (symbol 2j) with csi[2j+1] and LLRs 6,7 (symbol 2j+1) with csi[2j]; reproduced. */
+  const int qm = orc_mod_bits(mod), nbits = nsym * qm;
+  float     csi_max = 1.0f;
+  if (nsym > 0) {
+    int imax = 0;
+    for (int i = 1; i < nsym; i++) {
+      if (csi[i] > csi[imax]) imax = i;
+    }
+    csi_max = csi[imax];
+  }
+  const float scale = 32767.0f / csi_max;
+  int         i = 0, s = 0; /* LLR index, symbol index */
+#define MULHI(idx, w) e[idx] = (int16_t)(((int)e[idx] * (int)(w)) >> 16)
+  switch (mod) {
+    case ORC_MOD_QPSK:
+      for (; i < nbits - 3; i += 4, s += 2) {
+        const int16_t w1 = csi_weight(csi[s], scale), w2 = csi_weight(csi[s + 1], scale);
+        MULHI(i, w2); MULHI(i + 1, w2); MULHI(i + 2, w1); MULHI(i + 3, w1);
+      }
+      break;
+    case ORC_MOD_16QAM:
+      for (; i < nbits - 3; i += 4, s++) {
+        const int16_t w = csi_weight(csi[s], scale);
+        for (int k = 0; k < 4; k++) MULHI(i + k, w);
+      }
+      break;
+    case ORC_MOD_64QAM:
+      for (; i < nbits - 11; i += 12, s += 2) {
+        const int16_t w1 = csi_weight(csi[s], scale), w3 = csi_weight(csi[s + 1], scale);
+        for (int k = 0; k < 4; k++) MULHI(i + k, w1);
+        MULHI(i + 4, w3); MULHI(i + 5, w3); MULHI(i + 6, w1); MULHI(i + 7, w1);
+        for (int k = 8; k < 12; k++) MULHI(i + k, w3);
+      }
+      break;
+    case ORC_MOD_256QAM:
+      for (; i < nbits - 7; i += 8, s++) {
+        const int16_t w = csi_weight(csi[s], scale);
+        for (int k = 0; k < 8; k++) MULHI(i + k, w);
+      }
+      break;
+    default: break;
+  }
+#undef MULHI
+  const float inv = 1.0f / csi_max; /* the -Ofast build multiplies by the hoisted reciprocal */
+  for (i /= qm; i < nsym; i++) {
+    const float c = csi[i] * inv;
+    for (int k = 0; k < qm; k++) e[qm * i + k] = (int16_t)((float)e[qm * i + k] * c);
+  }
+}
+
+void orc_csi_correction_b(int8_t* e, const float* csi, int nsym, int mod)
+{ /* pdsch.c:607-614, 8-bit LLRs: e <- (int8)(e * (csi / csi_max)), truncating */
+  const int qm = orc_mod_bits(mod);
+  float     csi_max = 1.0f;
+  if (nsym > 0) {
+    int imax = 0;
+    for (int i = 1; i < nsym; i++) {
+      if (csi[i] > csi[imax]) imax = i;
+    }
+    csi_max = csi[imax];
+  }
+  const float inv = 1.0f / csi_max; /* the -Ofast build multiplies by the hoisted reciprocal */
+  for (int i = 0; i < nsym; i++) {
+    const float c = csi[i] * inv;
+    for (int k = 0; k < qm; k++) e[qm * i + k] = (int8_t)((float)e[qm * i + k] * c);
+  }
+}

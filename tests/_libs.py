@@ -198,3 +198,27 @@ def ref_ul_sf_cfg(tti):
     buf = (C.c_uint8 * 20)()
     C.cast(buf, C.POINTER(C.c_uint32))[12 // 4] = tti
     return buf
+
+
+_ref_layout_cache = {}
+
+
+def ref_layout(structs, includes):
+    """{"struct": [fields]} -> {"struct": sizeof, "struct.field": offsetof} from the REFERENCE headers (compiled on the fly with gcc;
+    only where /root/reference exists). For driving reference functions that take configuration structs by pointer."""
+    import subprocess
+    import tempfile
+    key = repr((sorted((k, tuple(v)) for k, v in structs.items()), tuple(includes)))
+    if key in _ref_layout_cache:
+        return _ref_layout_cache[key]
+    body = "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (st, st) + "".join('  printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (st, f, st, f) for f in fs)
+                   for st, fs in structs.items())
+    src = "#include <stdio.h>\n#include <stddef.h>\n" + "".join('#include "%s"\n' % i for i in includes) + "int main(void) {\n" + body + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c, exe = os.path.join(d, "l.c"), os.path.join(d, "l")
+        with open(c, "w") as f:
+            f.write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-D_GNU_SOURCE", "-w", "-I/root/reference/lib/include", c, "-o", exe])
+        out = {a: int(b) for a, b in (line.split() for line in subprocess.check_output([exe]).decode().splitlines())}
+    _ref_layout_cache[key] = out
+    return out

@@ -18,12 +18,13 @@ class DlConfig:
     """One PDSCH configuration: full-band grant, rv 0; nof_ports = 1: single antenna port (TM1),
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.nof_ports = nof_ports
+        self.csi = csi  # srslte_pdsch_cfg_t.csi_enable: LLRs weighted by the channel gain (pdsch.c:574-690), the srsUE default
         self.cell = OrcCell(cell_id, nof_prb, nof_ports, True)
         self.nre = 12 * nof_prb
         self.grid_len = 14 * self.nre
@@ -175,11 +176,13 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
         ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
         yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (2 * nrx))(*[v.ctypes.data for v in hs])
         orc.orc_predecoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
-        orc.orc_predecoding_diversity2(yp, hp, p(d), None, nrx, len(idx), 1.0)
+        csi = np.zeros(len(idx), np.float32)
+        orc.orc_predecoding_diversity2(yp, hp, p(d), p(csi), nrx, len(idx), 1.0)
     elif nrx == 1:
         assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid[0]), p(ce[0]), C.byref(res)) == 0
         y, h = np.ascontiguousarray(grid[0][idx]), np.ascontiguousarray(ce[0][idx])
         orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
+        hs = [h]
         grid, ce = grid[0], ce[0]
     else:  # pdsch.c:890-935 with nof_rx_antennas > 1: srslte_predecoding_single_multi
         gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * nrx)(*[c.ctypes.data for c in ce])
@@ -188,6 +191,10 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
         yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * nrx)(*[v.ctypes.data for v in hs])
         orc.orc_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
         orc.orc_predecoding_single_multi(yp, hp, p(d), nrx, len(idx), 1.0, res.noise_estimate)
+    if cfg.nof_ports == 1:
+        csi = np.zeros(len(idx), np.float32)
+        orc.orc_predecoding_csi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        orc.orc_predecoding_csi((C.c_void_p * nrx)(*[v.ctypes.data for v in hs]), p(csi), nrx, len(idx), res.noise_estimate)
     nbits = len(idx) * cfg.Qm
     e = np.zeros(nbits, np.int8 if cfg.llr8 else np.int16)
     sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
@@ -197,14 +204,20 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
     if cfg.llr8:
         orc.orc_demod_soft_b(cfg.mod, p(d), p(e), len(idx))
         orc.orc_scramble_b(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
+        e_raw = e.copy()
+        if cfg.csi:
+            orc.orc_csi_correction_b(p(e), p(csi), len(idx), cfg.mod)
         rc = orc.orc_dlsch_decode_8bit(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
     else:
         orc.orc_demod_soft_s(cfg.mod, p(d), p(e), len(idx))
         orc.orc_scramble_s(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
+        e_raw = e.copy()
+        if cfg.csi:
+            orc.orc_csi_correction_s(p(e), p(csi), len(idx), cfg.mod)
         rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
     if keep:
-        out.update(grid=grid, ce=ce, noise=res.noise_estimate, d=d, e=e, res=res)
+        out.update(grid=grid, ce=ce, noise=res.noise_estimate, d=d, e=e, e_raw=e_raw, csi=csi, res=res)
     return out
 
 
@@ -295,6 +308,101 @@ class RefRx:
         ev = e[:nbits]
         ev[self.scr[(sf_idx, nbits)]] *= -1  # wraps -(-128) / -(-32768) like the reference's sign instructions
         return ref_sch_decode(self, e, nbits)
+
+
+class RefPdsch:
+    """The reference's own srslte_pdsch_decode (pdsch.c:833-997) on its compiled code: srslte_pdsch_init_ue / set_cell / set_rnti, a
+    hand-filled srslte_pdsch_cfg_t (grant: full band, one codeword, TM1 or TM2) and the srslte_chest_dl_res_t of
+    srslte_chest_dl_estimate_cfg. Only the FFT in front of it is the oracle's. Struct offsets come from the reference headers at run
+    time (_libs.ref_layout). Pins the stage-by-stage chains (RefRx, oracle_rx) and the CSI weighting of the LLRs."""
+
+    def __init__(self, cfg, csi_enable=False):
+        from _libs import RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, aligned, opaque, ref, ref_layout
+        R = self.R = ref()
+        self.cfg, self.aligned = cfg, aligned
+        L = self.L = ref_layout({"srslte_pdsch_t": ["llr_is_8bit", "d", "e", "csi", "dl_sch"], "srslte_sch_t": ["llr_is_8bit"],
+                                 "srslte_pdsch_cfg_t": ["rnti", "max_nof_iterations", "decoder_type", "csi_enable", "softbuffers"],
+                                 "srslte_pdsch_grant_t": ["tx_scheme", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
+                                 "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
+                                 "srslte_softbuffer_rx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]}, ["srslte/phy/phch/pdsch.h"])
+        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
+        self.chest = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_chest_dl_set_cell(self.chest, cell) == 0
+        self.rc = RefChestCfg()
+        for k, v in cfg.chest.items():
+            if k == "filter_coef":
+                self.rc.filter_coef[0], self.rc.filter_coef[1] = v
+            else:
+                setattr(self.rc, k, v)
+        self.res, self.sf = RefChestRes(), RefDlSfCfg()
+        self.ces = [aligned(2 * cfg.grid_len, np.float32) for _ in range(cfg.nof_rx * cfg.nof_ports)]
+        for i_, c_ in enumerate(self.ces):
+            self.res.ce[i_ // cfg.nof_rx][i_ % cfg.nof_rx] = c_.ctypes.data
+        self.q = opaque(L["srslte_pdsch_t"] + 64)
+        assert R.srslte_pdsch_init_ue(self.q, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_pdsch_set_cell(self.q, cell) == 0
+        R.srslte_pdsch_set_rnti.argtypes = [C.c_void_p, C.c_uint16]
+        assert R.srslte_pdsch_set_rnti(self.q, cfg.rnti) == 0
+        for off in (L["srslte_pdsch_t.llr_is_8bit"], L["srslte_pdsch_t.dl_sch"] + L["srslte_sch_t.llr_is_8bit"]):  # srsue cc_worker.cc:101-102
+            self.q[off] = b"\x01" if cfg.llr8 else b"\x00"
+        self.sb = opaque(L["srslte_softbuffer_rx_t"] + 64)
+        assert R.srslte_softbuffer_rx_init(self.sb, cfg.nof_prb) == 0
+        self.pc = np.zeros(L["srslte_pdsch_cfg_t"], np.uint8)
+        g = self.pc  # grant at offset 0
+
+        def u32(off, v):
+            g[off:off + 4].view(np.uint32)[0] = v
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports == 2 else 0)
+        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
+        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
+        u32(L["srslte_pdsch_grant_t.nof_tb"], 1)
+        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_ports)
+        self.tb0 = L["srslte_pdsch_grant_t.tb"]
+        u32(self.tb0 + L["srslte_ra_tb_t.mod"], cfg.mod)
+        u32(self.tb0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
+        g[self.tb0 + L["srslte_ra_tb_t.enabled"]] = 1
+        g[L["srslte_pdsch_cfg_t.rnti"]:L["srslte_pdsch_cfg_t.rnti"] + 2].view(np.uint16)[0] = cfg.rnti
+        u32(L["srslte_pdsch_cfg_t.max_nof_iterations"], cfg.max_iter)
+        u32(L["srslte_pdsch_cfg_t.decoder_type"], 1)  # SRSLTE_MIMO_DECODER_MMSE
+        g[L["srslte_pdsch_cfg_t.csi_enable"]] = 1 if csi_enable else 0
+        g[L["srslte_pdsch_cfg_t.softbuffers"]:L["srslte_pdsch_cfg_t.softbuffers"] + 8].view(np.uint64)[0] = C.addressof(self.sb)
+        self.u32 = u32
+        self.ofdm = OrcOfdm()
+        oracle().orc_ofdm_init(C.byref(self.ofdm), cfg.nof_prb, True)
+        self.nre = {s_: len(cfg.indices(s_)) for s_ in (0, 5, 1)}
+
+    def _ptr(self, name, dtype, count):
+        addr = np.frombuffer(self.q, np.uint64, 1, self.L["srslte_pdsch_t." + name])[0]
+        nbytes = count * np.dtype(dtype).itemsize
+        return np.frombuffer(C.string_at(int(addr), nbytes), dtype).copy()
+
+    def run(self, iq, tti, grid_in=None):
+        cfg, R, L = self.cfg, self.R, self.L
+        sf_idx, nrx = tti % 10, cfg.nof_rx
+        grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(nrx)]
+        if grid_in is not None:
+            for a_ in range(nrx):
+                grids[a_].view(np.complex64)[:] = np.asarray(grid_in, np.complex64).reshape(nrx, -1)[a_]
+        else:
+            iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+            for a_ in range(nrx):
+                oracle().orc_ofdm_rx_sf(C.byref(self.ofdm), p(iq2[a_]), p(grids[a_]))
+        self.sf.tti, self.sf.cfi = tti, cfg.cfi
+        inp = (C.c_void_p * 4)(*([g_.ctypes.data for g_ in grids] + [0] * (4 - nrx)))
+        assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
+        nre = self.nre[0 if sf_idx == 0 else (5 if sf_idx == 5 else 1)]
+        self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
+        self.u32(self.tb0 + L["srslte_ra_tb_t.nof_bits"], nre * cfg.Qm)
+        R.srslte_softbuffer_rx_reset(self.sb)
+        payload = np.zeros(cfg.tbs // 8 + 64, np.uint8)
+        data = np.zeros(2 * L["srslte_pdsch_res_t"], np.uint8)
+        data[:8].view(np.uint64)[0] = payload.ctypes.data
+        assert R.srslte_pdsch_decode(self.q, C.byref(self.sf), p(self.pc), C.byref(self.res), inp, p(data)) == 0
+        ok = bool(data[L["srslte_pdsch_res_t.crc"]])
+        e = self._ptr("e", np.int8 if cfg.llr8 else np.int16, nre * cfg.Qm)
+        return {"tb": payload[:cfg.tbs // 8 + 3].copy(), "ok": ok, "d": self._ptr("d", np.complex64, nre), "e": e,
+                "csi": self._ptr("csi", np.float32, nre), "noise": self.res.noise_estimate}
 
 
 def ref_sch_decode(self, e, nbits):

@@ -529,6 +529,35 @@ def test_whole_chain_tx_diversity_vs_reference_code(prb, mod, tbs, nrx, snr, llr
     assert nok > 0
 
 
+@pytest.mark.parametrize("csi", [False, True])
+@pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(6, 1, 152, 1, 1, 4.0, False), (15, 1, 1000, 1, 2, 2.0, False), (25, 2, 4008, 1, 1, 9.0, False),
+                                                            (25, 3, 9912, 2, 2, 13.5, False), (100, 3, 75376, 1, 1, 18.0, False),
+                                                            (25, 2, 4008, 1, 2, 9.0, True), (100, 4, 97896, 2, 1, 24.0, False), (50, 3, 11448, 2, 1, 8.0, True)])
+def test_pdsch_decode_function_vs_oracle_chain(prb, mod, tbs, nrx, npt, snr, llr8, csi):
+    """The reference's own srslte_pdsch_decode (pdsch.c:833-997; UE object, so the csi variants of the equalisers run) on the output of
+    its srslte_chest_dl_estimate_cfg, against the oracle chain on identical IQ: TM1 / TM2, 1-2 antennas, 16- and 8-bit LLRs, with and
+    without the CSI weighting of the LLRs (cfg->csi_enable, the srsUE default). The reference's single-port equaliser multiplies by the
+    AVX reciprocal approximation, the oracle divides: symbols agree to 1e-3, LLRs to one LSB on a few percent of the values (6 % for 256QAM), CRC results
+    and transport blocks exactly. TM2 divides exactly in both."""
+    from lte_sim import RefPdsch
+    rng = np.random.default_rng(500 + prb + mod + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, llr8=llr8, csi=csi)
+    chain = RefPdsch(cfg, csi_enable=csi)
+    nok = 0
+    for t in (0, 3, 5, 8):
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t, keep=True)
+        assert np.abs(r["d"] - o["d"]).max() <= (2e-6 if npt == 2 else 1e-3) * max(1.0, np.abs(o["d"]).max())
+        assert np.abs(r["csi"] - o["csi"]).max() <= 2e-6 * o["csi"].max()
+        diff = np.abs(r["e"].astype(np.int32) - o["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= (0.005 if npt == 2 else 0.08), (t, diff.max(), (diff != 0).mean())
+        assert r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        nok += r["ok"]
+    assert nok > 0
+
+
 @pytest.mark.parametrize("cell_id,prb", [(1, 6), (77, 25), (301, 100)])
 def test_ul_dmrs_pusch_vs_ref(cell_id, prb):
     """srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): every float of the sequence, incl. group / sequence hopping and all
