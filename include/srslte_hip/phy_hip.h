@@ -195,6 +195,9 @@ typedef struct {
   uint32_t nof_ports;       /* 0 or 1: single antenna port (TM1); 2: 2-port cell with transmit diversity (TM2): 2-port chest_dl, 2-port RE
                                mapping, srslte_predecoding_diversity_multi + srslte_layerdemap_diversity (precoding.c:564-598,
                                layermap.c:140-148), for nof_rx_antennas 1..4 */
+  int      csi_enable;      /* srslte_pdsch_cfg_t.csi_enable (pdsch_cfg.h:63; the srsUE default): LLRs weighted by each symbol's channel
+                               gain relative to the subframe's largest (csi_correction, pdsch.c:574-690, applied inside the rate
+                               de-matching kernels as they read the LLRs) */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -212,7 +215,8 @@ int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, u
                            uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest res, 3 d (NULL unless
  * srslte_hip_dl_rx_keep_symbols(q, 1): the equalised symbols are otherwise never written to memory), 4 e (LLRs, per-subframe stride
- * = max nof_re * Qm rounded up to 16), 5 w, 6 cb iters */
+ * = max nof_re * Qm rounded up to 16; before the CSI weighting), 5 w, 6 cb iters, 7 cb ok, 8 cb bytes, 9 csi [nof_sf][max nof_re] (csi_enable),
+ * 10 the subframes' largest csi [nof_sf] */
 const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which);
 int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
 

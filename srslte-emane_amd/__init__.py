@@ -41,7 +41,7 @@ class Cbsegm(C.Structure):
 class DlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int),
                 ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg),
-                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32)]
+                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int)]
 
 
 def lib():
@@ -380,9 +380,9 @@ class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
     def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False, nof_rx=1,
-                 nof_ports=1):
+                 nof_ports=1, csi=False):
         self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
-                           1 if llr_8bit else 0, nof_rx, nof_ports)
+                           1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0)
         self.nof_rx = nof_rx
         self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
         if not self.h:

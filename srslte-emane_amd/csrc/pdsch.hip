@@ -37,7 +37,16 @@ struct PdschGeom {
   SfClass cls[3];
   int     grid_len;   // 14 * 12 * nof_prb
   int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx, nof_ports;
+  float*    csi;     // [nof_sf][max_re] channel gain per RE, or null (cfg.csi_enable)
+  uint32_t* csi_max; // [nof_sf] bit pattern of the largest gain of each subframe (non-negative floats order like their bits), zeroed per call
 };
+
+// the subframe's largest csi: wavefront maximum, one atomic per wavefront
+__device__ __forceinline__ void csi_note_max(uint32_t* dst, float v)
+{
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(dst, __float_as_uint(v));
+}
 
 __device__ __forceinline__ int sf_class(int sf_idx) { return sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2); }
 
@@ -57,11 +66,13 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   const uint32_t k  = c.idx[live ? i : c.nof_re - 1];
   const float    n0 = g.mmse ? res[sf].noise_estimate : 0.f;
   cf32           x;
+  float          gain; // srslte_predecoding_single_csi's side output (precoding.c:251-291)
   if (g.nof_rx == 1) {
     const cf32 y = grid[(size_t)sf * g.grid_len + k], h = ce[(size_t)sf * g.grid_len + k];
     // precoding.c:277-288 with scaling = 1 (pdsch.c:852-858, power_scale off)
     const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
     x = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+    gain = csi;
   } else { // srslte_predecoding_single_multi (precoding.c:138-262): maximum-ratio combining over the receive antennas
     float re = 0.f, im = 0.f, hh = 0.f;
     for (int a = 0; a < g.nof_rx; a++) {
@@ -74,6 +85,11 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
     }
     if (n0 > 0.f) hh += n0;
     x = make_float2(re / hh * 1.0f, im / hh * 1.0f);
+    gain = hh;
+  }
+  if (g.csi) {
+    if (live) g.csi[(size_t)sf * g.max_re + i] = gain;
+    csi_note_max(g.csi_max + sf, live ? gain : 0.f);
   }
   if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x;
   LLR o[8];
@@ -129,6 +145,10 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
     x1r += -(h10.x * r0.x + h10.y * r0.y) + h01.x * r1.x + h01.y * r1.y;
     x1i += -(h10.y * r0.x - h10.x * r0.y) + h01.x * r1.y - h01.y * r1.x;
   }
+  if (g.csi) { // csi[2i] = csi[2i + 1] = hh (precoding.c:590-591)
+    if (live) *reinterpret_cast<float2*>(g.csi + (size_t)sf * g.max_re + i0) = make_float2(hh, hh);
+    csi_note_max(g.csi_max + sf, live ? hh : 0.f);
+  }
   const cf32 x[2] = {make_float2((float)((double)(x0r / hh) * 1.4142135623730951), (float)((double)(x0i / hh) * 1.4142135623730951)),
                      make_float2((float)((double)(x1r / hh) * 1.4142135623730951), (float)((double)(x1i / hh) * 1.4142135623730951))};
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
@@ -158,7 +178,58 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
 struct RmGeom {
   int C, K, Qm, tti0, max_bits, w_stride, out_len; // out_len = 3K+12
   int nof_re[3];
+  int             max_re, mod;
+  const float*    csi;     // as PdschGeom; null = no CSI weighting
+  const uint32_t* csi_max;
 };
+
+// csi_correction (pdsch.c:574-690) applied to LLR number b of a subframe as it is read: 16-bit LLRs: (e * w) >> 16 with w = the gain of
+// "its" symbol scaled to 32767 at the subframe's maximum, rounded to nearest even and saturated, for the whole groups of 4 / 4 / 12 / 8
+// LLRs the SSE loops cover, (int16)(e * gain / max) for the symbols behind them; in the two-symbol groups (QPSK, 64QAM) the reference's
+// _mm_blend_ps takes the low lanes from the SECOND symbol: reproduced. 8-bit LLRs: (int8)(e * (gain / max)).
+struct CsiW {
+  const float* csi; // the subframe's gains
+  float        scale, inv;
+  int          Qm, mod, body_bits, nsym;
+};
+__device__ __forceinline__ CsiW csi_setup(const RmGeom& g, int sf, int nsym)
+{
+  CsiW c;
+  c.csi = g.csi + (size_t)sf * g.max_re;
+  const float mx = nsym > 0 ? __uint_as_float(g.csi_max[sf]) : 1.0f;
+  c.scale = 32767.0f / mx;
+  c.inv   = 1.0f / mx;
+  c.Qm = g.Qm; c.mod = g.mod; c.nsym = nsym;
+  const int G = g.mod == 3 ? 12 : (g.mod == 4 ? 8 : 4);
+  c.body_bits = (nsym * g.Qm / G) * G;
+  return c;
+}
+template <typename LLR>
+__device__ __forceinline__ LLR csi_apply(const CsiW& c, LLR v, int b)
+{
+  if constexpr (sizeof(LLR) == 1) {
+    const int s = min(b / c.Qm, c.nsym - 1);
+    return (LLR)((float)v * (c.csi[s] * c.inv));
+  } else {
+    if (b >= c.body_bits) {
+      const int s = min(b / c.Qm, c.nsym - 1);
+      return (LLR)((float)v * (c.csi[s] * c.inv));
+    }
+    int s;
+    if (c.mod == 1) { // QPSK: LLRs 0,1 of a group of 4 take the second symbol's gain
+      s = 2 * (b >> 2) + (((b & 3) < 2) ? 1 : 0);
+    } else if (c.mod == 3) { // 64QAM: 0-3 first, 4,5 second, 6,7 first, 8-11 second
+      const int r = b % 12;
+      s = 2 * (b / 12) + ((r < 4 || r == 6 || r == 7) ? 0 : 1);
+    } else {
+      s = b / c.Qm;
+    }
+    const float f = rintf(c.csi[s] * c.scale);
+    const int   w = f > 32767.0f ? 32767 : (int)f;
+    return (LLR)(((int)v * w) >> 16);
+  }
+}
+
 
 // grid = (ceil(w_stride/512), nof_sf*C): gather form of w[deint[i]] += e[i] (wrapping int16, rm_turbo.c:407-409).
 // inv[j] = circular-buffer position n that lands on soft-buffer slot j (0xffffffff for padding); a thread owns two
@@ -180,6 +251,8 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
   const LLR* src = e + (size_t)sf * g.max_bits + rp;
+  CsiW       cw;
+  if (g.csi) cw = csi_setup(g, sf, Gp);
   uint32_t   n[PER], word = 0;
   if constexpr (PER == 2) {
     const uint2 t = *reinterpret_cast<const uint2*>(inv + j);
@@ -192,7 +265,7 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   for (int s = 0; s < PER; s++) {
     int acc = 0;
     if (n[s] != 0xffffffffu) {
-      for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += src[i];
+      for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += g.csi ? csi_apply<LLR>(cw, src[i], rp + i) : src[i];
     }
     word |= ((uint32_t)acc & ((1u << (8 * sizeof(LLR))) - 1u)) << (8 * sizeof(LLR) * s);
   }
@@ -223,8 +296,22 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / sizeof(LLR));
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
   const int   n16 = (n_e2 + mis + PER - 1) / PER;
+  if (g.csi) { // weigh while staging: element j of 16-byte word i is LLR rp - mis + PER * i + j of the subframe
+    const CsiW cw = csi_setup(g, sf, Gp);
+    for (int i = threadIdx.x; i < n16; i += 256) {
+      union {
+        int4 v;
+        LLR  h[PER];
+      } u;
+      u.v = s4[i];
+#pragma unroll
+      for (int j = 0; j < PER; j++) u.h[j] = csi_apply<LLR>(cw, u.h[j], rp - mis + PER * i + j);
+      reinterpret_cast<int4*>(seg)[i] = u.v;
+    }
+  } else {
 #pragma unroll 4
-  for (int i = threadIdx.x; i < n16; i += 256) reinterpret_cast<int4*>(seg)[i] = s4[i];
+    for (int i = threadIdx.x; i < n16; i += 256) reinterpret_cast<int4*>(seg)[i] = s4[i];
+  }
   __syncthreads();
   const LLR*   ls    = seg + mis;
   const uint4* inv16 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(inv + g.w_stride));
@@ -405,6 +492,8 @@ struct srslte_hip_dl_rx {
   uint8_t *              d_cb_bytes, *d_cb_ok;
   uint32_t*              d_cb_iters;
   uint32_t *             d_tb_rem, *d_cb_syn; // TB CRC shares from the windowed decoders ([C][K] table, [B*C] out); null for W = 0
+  float*                 d_csi;     // [B][max_re], cfg.csi_enable
+  uint32_t*              d_csi_max; // [B]
   const cf32*            grid_in; // resource grids supplied by the caller (srslte_hip_dl_rx_grid_batch) instead of d_grid
 };
 
@@ -415,7 +504,8 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   srslte_hip_chest_dl_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_idx[0], q->d_idx[1], q->d_idx[2], q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_grid, q->d_ce, q->d_d,
-                  q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters, q->d_tb_rem, q->d_cb_syn};
+                  q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters, q->d_tb_rem, q->d_cb_syn,
+                  q->d_csi,    q->d_csi_max};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -511,6 +601,10 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess;
+  if (ok && cfg->csi_enable) {
+    ok = hipMalloc((void**)&q->d_csi, sizeof(float) * (size_t)max_re * B) == hipSuccess &&
+         hipMalloc((void**)&q->d_csi_max, sizeof(uint32_t) * B) == hipSuccess;
+  }
   if (!ok) {
     fprintf(stderr, "[srslte_hip] dl_rx: initialisation failed\n");
     srslte_hip_dl_rx_destroy(q);
@@ -518,6 +612,8 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   }
   q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx; q->pg.nof_ports = (int)npt;
+  q->pg.csi = q->d_csi; q->pg.csi_max = q->d_csi_max;
+  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
@@ -554,6 +650,8 @@ extern "C" const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q
     case 6: return q->d_cb_iters;
     case 7: return q->d_cb_ok;
     case 8: return q->d_cb_bytes;
+    case 9: return q->d_csi;
+    case 10: return q->d_csi_max;
   }
   return nullptr;
 }
@@ -574,6 +672,7 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     case 2: {
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
+      if (g.csi_max) HIP_TRY(hipMemsetAsync(g.csi_max, 0, sizeof(uint32_t) * nof_sf, st));
       if (g.nof_ports == 2) {
         if (q->cfg.llr_8bit) {
           hipLaunchKernelGGL(pdsch_demod_div_kernel<int8_t>, dim3(ceil_div(g.max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,

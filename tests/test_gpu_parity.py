@@ -756,3 +756,42 @@ def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf):
             assert np.array_equal(tb[b][:tbs // 8], data[b])
     assert n_ok > 0
     rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8,tti0,nsf", [(6, 1, 152, 1, 1, 3.0, False, 0, 10), (15, 1, 1000, 1, 2, 1.5, False, 4, 4), (25, 2, 4008, 1, 1, 9.0, False, 8, 4),
+                                                                  (25, 3, 9912, 2, 2, 12.5, False, 3, 4), (100, 3, 75376, 1, 1, 18.0, False, 4, 3),
+                                                                  (25, 2, 4008, 1, 2, 8.5, True, 9, 3), (100, 4, 97896, 2, 1, 23.0, False, 5, 2),
+                                                                  (50, 3, 11448, 2, 1, 7.5, True, 0, 3), (25, 1, 1000, 1, 1, -1.0, False, 2, 3)])
+def test_dl_rx_chain_csi_weighting(hp, prb, mod, tbs, nrx, npt, snr, llr8, tti0, nsf):
+    """cfg.csi_enable (the srsUE default; csi_correction, pdsch.c:574-690): per-RE channel gains and their subframe maximum from the
+    equaliser kernels, the weighting applied inside the rate de-matching kernels; pass counts, CRC flags and TB bytes vs the oracle
+    chain with the same switch (itself checked against the reference's srslte_pdsch_decode)."""
+    from lte_sim import DlConfig, make_subframe, oracle_rx
+    rng = np.random.default_rng(1700 + prb + mod + nrx + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, llr8=llr8, csi=True)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=npt, csi=True)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    csi = rx.debug(9, np.float32, nsf * max_re).reshape(nsf, -1)
+    cmax = rx.debug(10, np.float32, nsf)
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        assert np.abs(csi[b, :nre] - r["csi"]).max() <= 1e-4 * r["csi"].max() and abs(cmax[b] - r["csi"].max()) <= 1e-4 * cmax[b]
+        diff = np.abs(e_all[b, :nre * cfg.Qm].astype(np.int32) - r["e_raw"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"] or diff.max() == 0:
+            assert np.array_equal(tb[b], r["tb"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0
+    rx.free()
