@@ -205,6 +205,12 @@ uint32_t            srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_
 /* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf] */
 int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                            uint8_t* d_tb_ok, void* stream);
+/* HARQ (decode_tb_cb sch.c:299-414 on a srslte_softbuffer_rx_t per transport block, softbuffer.c:46-150): slot b of the object keeps
+ * its blocks' soft buffers, CRC flags and decoded bytes between calls. new_data != 0: new transport blocks (the MAC's
+ * srslte_softbuffer_rx_reset_tbs on a toggled NDI). new_data == 0: retransmission with redundancy version rv, de-matched LLRs are
+ * added to the kept soft buffers (rm_turbo.c:407-409), blocks whose CRC already passed are left alone (sch.c:317-318) */
+int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data,
+                                uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* same from frequency-domain grids d_grid [nof_sf][14][12*nof_prb] (the part of srslte_ue_dl_decode after srslte_ofdm_rx_sf,
  * ue_dl.c:375-397; SURVEY §8d cfg5 feeds grids) */
 int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,

@@ -169,6 +169,12 @@ int orc_dlsch_encode(const orc_sch_cfg_t* cfg, const uint8_t* data, uint8_t* e_b
 /* sch.c:299-500 decode with CRC early stop; returns 0 when TB CRC ok; cb_iters[C] optional */
 int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok);
 int orc_dlsch_decode_8bit(const orc_sch_cfg_t* cfg, const int8_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok);
+/* HARQ (decode_tb_cb sch.c:299-414 on a srslte_softbuffer_rx_t, softbuffer.c:46-150): softbuf [C][orc_harq_softbuffer_stride()] int16 (int8
+ * values when llr8), sb_cb_crc [C], sb_data [C][768] persist between the calls of one transport block; new_data: the MAC reset them;
+ * cfg->rv selects the redundancy version of THIS transmission; blocks whose CRC passed earlier are copied, cb_iters 0 */
+uint32_t orc_harq_softbuffer_stride(void);
+int orc_dlsch_decode_harq(const orc_sch_cfg_t* cfg, const void* e, int llr8, int new_data, int16_t* softbuf, uint8_t* sb_cb_crc, uint8_t* sb_data,
+                          uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok);
 
 #ifdef __cplusplus
 }

@@ -906,8 +906,13 @@ int orc_dlsch_encode(const orc_sch_cfg_t* cfg, const uint8_t* data, uint8_t* e_b
   return 0;
 }
 
-static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
-{ /* sch.c:299-414 (decode_tb_cb, first transmission: soft buffer zeroed) + :429-500 (decode_tb); llr8: the q->llr_is_8bit branches */
+#define ORC_SB_STRIDE (3 * (ORC_MAX_K + 32) + 12) /* int16 per code block of a HARQ soft buffer (softbuffer.h:50 reserves 18600) */
+
+static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok,
+                        int16_t* sb, uint8_t* sb_crc, uint8_t* sb_data, bool new_data)
+{ /* sch.c:299-414 (decode_tb_cb) + :429-500 (decode_tb); llr8: the q->llr_is_8bit branches. sb == NULL: first transmission into a zeroed
+     soft buffer. Otherwise sb / sb_crc / sb_data are the srslte_softbuffer_rx_t of this transport block (buffer_f, cb_crc, data;
+     softbuffer.c:46-150) and new_data says whether the MAC reset it (srslte_softbuffer_rx_reset_tbs) before this call. */
   const int16_t* e = e_any;
   const int8_t*  e8 = e_any;
   orc_cbsegm_t s;
@@ -915,19 +920,27 @@ static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, 
     return -2;
   }
   data[cfg->tbs / 8] = data[cfg->tbs / 8 + 1] = data[cfg->tbs / 8 + 2] = 0;
-  int16_t* w    = malloc((3 * (ORC_MAX_K + 32) + 12) * 2);
+  int16_t* wtmp = malloc(ORC_SB_STRIDE * 2);
   uint8_t* hard = malloc(ORC_MAX_K / 8);
   bool     all_ok = true;
+  if (sb && new_data) memset(sb_crc, 0, s.C);
   for (uint32_t cb = 0; cb < s.C; cb++) {
     uint32_t K    = cb < s.C1 ? s.K1 : s.K2; /* decoder order quirk: K+ blocks first (sch.c:320-321) */
     uint32_t rlen = s.C == 1 ? K : K - 24;
+    if (sb && sb_crc[cb]) { /* "Do not process blocks with CRC Ok" (sch.c:317-318,:392-396) */
+      memcpy(&data[cb * rlen / 8], &sb_data[cb * (ORC_MAX_K / 8)], rlen / 8);
+      if (cb_iters) cb_iters[cb] = 0;
+      if (cb_crc_ok) cb_crc_ok[cb] = 1;
+      continue;
+    }
+    int16_t* w = sb ? sb + (size_t)cb * ORC_SB_STRIDE : wtmp;
     uint32_t Gp = cfg->nof_bits / cfg->Qm, gamma = Gp % s.C, n_e = cfg->Qm * (Gp / s.C), rp = cb * n_e, n_e2 = n_e;
     if (cb > s.C - gamma) { /* quirk: '>' where the encoder uses '>=' (sch.c:331-334 vs :232-236) */
       n_e2 = n_e + cfg->Qm;
       rp   = (s.C - gamma) * n_e + (cb - (s.C - gamma)) * n_e2;
     }
     uint32_t W = llr8 ? orc_tdec_autoimp_subblocks_8bit(K) : orc_tdec_autoimp_subblocks(K);
-    memset(w, 0, (3 * (K + 32) + 12) * 2);
+    if (!sb || new_data) memset(w, 0, (3 * (K + 32) + 12) * 2);
     bool     ok  = false;
     uint32_t noi = 0;
     /* hard decisions after each pass are independent of later passes, so run them one at a time */
@@ -954,10 +967,17 @@ static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, 
       cb_crc_ok[cb] = ok;
     }
     all_ok = all_ok && ok;
+    if (sb) sb_crc[cb] = ok;
   }
-  free(w);
+  free(wtmp);
   free(hard);
   if (!all_ok) {
+    if (sb) { /* save the blocks that passed for the next retransmission (sch.c:404-412) */
+      for (uint32_t cb = 0; cb < s.C; cb++) {
+        uint32_t K = cb < s.C1 ? s.K1 : s.K2, rlen = s.C == 1 ? K : K - 24;
+        if (sb_crc[cb]) memcpy(&sb_data[cb * (ORC_MAX_K / 8)], &data[cb * rlen / 8], rlen / 8);
+      }
+    }
     return -1;
   }
   uint32_t par_rx = orc_crc_bytes(ORC_CRC24A, 24, data, (int)cfg->tbs);
@@ -967,10 +987,18 @@ static int dlsch_decode(const orc_sch_cfg_t* cfg, const void* e_any, bool llr8, 
 
 int orc_dlsch_decode(const orc_sch_cfg_t* cfg, const int16_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
 {
-  return dlsch_decode(cfg, e, false, data, cb_iters, cb_crc_ok);
+  return dlsch_decode(cfg, e, false, data, cb_iters, cb_crc_ok, NULL, NULL, NULL, true);
 }
 
 int orc_dlsch_decode_8bit(const orc_sch_cfg_t* cfg, const int8_t* e, uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
 {
-  return dlsch_decode(cfg, e, true, data, cb_iters, cb_crc_ok);
+  return dlsch_decode(cfg, e, true, data, cb_iters, cb_crc_ok, NULL, NULL, NULL, true);
+}
+
+uint32_t orc_harq_softbuffer_stride(void) { return ORC_SB_STRIDE; }
+
+int orc_dlsch_decode_harq(const orc_sch_cfg_t* cfg, const void* e, int llr8, int new_data, int16_t* softbuf, uint8_t* sb_cb_crc, uint8_t* sb_data,
+                          uint8_t* data, uint32_t* cb_iters, uint8_t* cb_crc_ok)
+{
+  return dlsch_decode(cfg, e, llr8 != 0, data, cb_iters, cb_crc_ok, softbuf, sb_cb_crc, sb_data, new_data != 0);
 }

@@ -415,6 +415,18 @@ class DlRx:
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
 
+    def decode_harq(self, iq, tti0, rv, new_data):
+        """srslte_hip_dl_rx_batch_harq: slot b keeps its soft buffers / CRC flags / bytes between calls."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * self.sf_len)
+        din = DevBuf.from_host(x)
+        lib().srslte_hip_dl_rx_batch_harq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32,
+                                                      C.c_void_p, C.c_void_p]
+        _check(lib().srslte_hip_dl_rx_batch_harq(self.h, din.ptr, tti0, x.shape[0], rv, 1 if new_data else 0, self.d_tb.ptr, self.tb_stride,
+                                                 self.d_ok.ptr, None), "dl_rx_batch_harq")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
     def decode_grid(self, grid, tti0=0):
         """Frequency-domain input [nsf][14*12*nof_prb] (srslte_hip_dl_rx_grid_batch)."""
         x = np.ascontiguousarray(grid, np.complex64)

@@ -179,9 +179,24 @@ struct RmGeom {
   int C, K, Qm, tti0, max_bits, w_stride, out_len; // out_len = 3K+12
   int nof_re[3];
   int             max_re, mod;
+  int             Nl;      // the code-block split counts in units of Qm * N_L bits, N_L = 2 for transmit diversity (sch.c:507-531)
   const float*    csi;     // as PdschGeom; null = no CSI weighting
   const uint32_t* csi_max;
+  int             combine; // HARQ: add to the soft buffer kept from earlier transmissions (rm_turbo.c:407-409 accumulates) instead of writing it
+  const uint8_t*  skip;    // HARQ: [B*C] blocks whose CRC already passed are not touched (sch.c:317-318)
 };
+
+// wrapping lane-wise add of packed int16 / int8 (the soft buffer accumulates with plain C '+=' on int16_t / int8_t)
+template <typename LLR>
+__device__ __forceinline__ uint32_t add_wrap(uint32_t a, uint32_t b)
+{
+  if constexpr (sizeof(LLR) == 2) {
+    return (((a & 0xffffu) + (b & 0xffffu)) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
+  } else {
+    const uint32_t lo = ((a & 0x00ff00ffu) + (b & 0x00ff00ffu)) & 0x00ff00ffu, hi = ((a & 0xff00ff00u) >> 8) + ((b & 0xff00ff00u) >> 8);
+    return lo | ((hi & 0x00ff00ffu) << 8);
+  }
+}
 
 // csi_correction (pdsch.c:574-690) applied to LLR number b of a subframe as it is read: 16-bit LLRs: (e * w) >> 16 with w = the gain of
 // "its" symbol scaled to 32767 at the subframe's maximum, rounded to nearest even and saturated, for the whole groups of 4 / 4 / 12 / 8
@@ -242,17 +257,17 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   constexpr int PER = 4 / (int)sizeof(LLR); // slots per dword
   const int cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C;
   const int j = PER * (blockIdx.x * blockDim.x + threadIdx.x);
-  if (j >= g.w_stride) return;
-  const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)]; // nof_bits / Qm
-  const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
+  if (j >= g.w_stride || (g.skip && g.skip[cbg])) return;
+  const int nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], QmL = g.Qm * g.Nl, Gp = nre / g.Nl; // Gp = nof_bits / (Qm N_L)
+  const int gamma = Gp % g.C, n_e = QmL * (Gp / g.C);
   int       rp = cb * n_e, n_e2 = n_e;
   if (cb > g.C - gamma) { // sch.c:331-334 (the '>' quirk is upstream's)
-    n_e2 = n_e + g.Qm;
+    n_e2 = n_e + QmL;
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
   const LLR* src = e + (size_t)sf * g.max_bits + rp;
   CsiW       cw;
-  if (g.csi) cw = csi_setup(g, sf, Gp);
+  if (g.csi) cw = csi_setup(g, sf, nre);
   uint32_t   n[PER], word = 0;
   if constexpr (PER == 2) {
     const uint2 t = *reinterpret_cast<const uint2*>(inv + j);
@@ -269,7 +284,8 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
     }
     word |= ((uint32_t)acc & ((1u << (8 * sizeof(LLR))) - 1u)) << (8 * sizeof(LLR) * s);
   }
-  *reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j) = word;
+  uint32_t* dst = reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j);
+  *dst          = g.combine ? add_wrap<LLR>(*dst, word) : word;
 }
 
 // Same result with the code block's LLR segment staged in LDS: one workgroup per code block copies its n_e LLRs with 16-byte
@@ -284,11 +300,12 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   constexpr int PER = 16 / (int)sizeof(LLR), NV = PER / 8; // slots per 16 bytes; uint4 loads of 16-bit table entries per step
   LLR*          seg = reinterpret_cast<LLR*>(seg_raw);
   const int cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C;
-  const int Gp = g.nof_re[sf_class((g.tti0 + sf) % 10)];
-  const int gamma = Gp % g.C, n_e = g.Qm * (Gp / g.C);
+  if (g.skip && g.skip[cbg]) return;
+  const int nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], QmL = g.Qm * g.Nl, Gp = nre / g.Nl;
+  const int gamma = Gp % g.C, n_e = QmL * (Gp / g.C);
   int       rp = cb * n_e, n_e2 = n_e;
   if (cb > g.C - gamma) { // sch.c:331-334
-    n_e2 = n_e + g.Qm;
+    n_e2 = n_e + QmL;
     rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
   }
   const LLR* src = e + (size_t)sf * g.max_bits + rp;
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
   const int   n16 = (n_e2 + mis + PER - 1) / PER;
   if (g.csi) { // weigh while staging: element j of 16-byte word i is LLR rp - mis + PER * i + j of the subframe
-    const CsiW cw = csi_setup(g, sf, Gp);
+    const CsiW cw = csi_setup(g, sf, nre);
     for (int i = threadIdx.x; i < n16; i += 256) {
       union {
         int4 v;
@@ -340,7 +357,12 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
         constexpr int BITS = 8 * (int)sizeof(LLR);
         o[s * BITS / 32] |= ((uint32_t)acc & ((1u << BITS) - 1u)) << ((s * BITS) & 31);
       }
-      dst[j] = make_uint4(o[0], o[1], o[2], o[3]);
+      if (g.combine) {
+        const uint4 old = dst[j];
+        dst[j] = make_uint4(add_wrap<LLR>(old.x, o[0]), add_wrap<LLR>(old.y, o[1]), add_wrap<LLR>(old.z, o[2]), add_wrap<LLR>(old.w, o[3]));
+      } else {
+        dst[j] = make_uint4(o[0], o[1], o[2], o[3]);
+      }
     }
   }
 }
@@ -426,7 +448,7 @@ int rm_lds_bytes(const RmGeom& g, int llr_bytes)
 {
   int mx = g.nof_re[0] > g.nof_re[1] ? g.nof_re[0] : g.nof_re[1];
   mx     = mx > g.nof_re[2] ? mx : g.nof_re[2];
-  return ((g.Qm * (mx / g.C) + g.Qm) * llr_bytes + 32 + 15) & ~15; // + the bytes below the 16-byte boundary and the rounded-up last load
+  return ((g.Qm * (mx / g.C) + 2 * g.Qm) * llr_bytes + 32 + 15) & ~15; // + the bytes below the 16-byte boundary and the rounded-up last load
 }
 bool rm_fits_lds(const RmGeom& g, int llr_bytes = 2) { return rm_lds_bytes(g, llr_bytes) <= 64 * 1024; }
 
@@ -484,7 +506,10 @@ struct srslte_hip_dl_rx {
   uint32_t               W, in_stride;
   uint32_t*              d_idx[3];
   uint32_t*              d_scr;
-  uint32_t*              d_rm_tbl;
+  uint32_t*              d_rm_tbl;      // rv 0
+  uint32_t*              d_rm_tbl_rv[4]; // [0] aliases d_rm_tbl; 1..3 built on first use (srslte_hip_dl_rx_batch_harq)
+  uint32_t               harq_rv;
+  int                    harq_combine;
   uint32_t*              d_tbcrc;
   cf32 *                 d_grid, *d_ce, *d_d;
   ChestResDev*           d_res;
@@ -505,11 +530,25 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_idx[0], q->d_idx[1], q->d_idx[2], q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_grid, q->d_ce, q->d_d,
                   q->d_res,    q->d_e,      q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_cb_iters, q->d_tb_rem, q->d_cb_syn,
-                  q->d_csi,    q->d_csi_max};
+                  q->d_csi,    q->d_csi_max, q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3]};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
   delete q;
+}
+
+// rate de-matching table of redundancy version rv in the decoder's input layout (rm_turbo.c:160-260)
+static int dl_rx_rm_table(srslte_hip_dl_rx_t* q, uint32_t rv, uint32_t** d_tbl)
+{
+  const uint32_t        K = q->seg.K1;
+  std::vector<uint32_t> t;
+  lte_rm_rx_table(K, rv, t);
+  if (q->W) {
+    for (auto& v : t) {
+      v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
+    }
+  }
+  return upload(d_tbl, rm_slot_table(t, q->in_stride)); // in_stride is a multiple of 32
 }
 
 extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
@@ -561,14 +600,8 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->W         = cfg->llr_8bit ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
   q->in_stride = (srslte_hip_tdec_input_len(K, q->W != 0) + 31) & ~31u;
   if (ok) {
-    std::vector<uint32_t> t;
-    lte_rm_rx_table(K, 0, t);
-    if (q->W) {
-      for (auto& v : t) {
-        v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
-      }
-    }
-    ok = upload(&q->d_rm_tbl, rm_slot_table(t, q->in_stride)) == SRSLTE_SUCCESS; // in_stride is a multiple of 32
+    ok                = dl_rx_rm_table(q, 0, &q->d_rm_tbl) == SRSLTE_SUCCESS;
+    q->d_rm_tbl_rv[0] = q->d_rm_tbl;
   }
   // TB CRC24A remainders x^(tbs+24-1-j) mod g
   if (ok) {
@@ -613,7 +646,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx; q->pg.nof_ports = (int)npt;
   q->pg.csi = q->d_csi; q->pg.csi_max = q->d_csi_max;
-  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod;
+  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = npt == 2 ? 2 : 1;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
@@ -694,21 +727,23 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     case 3: {
       RmGeom g = q->rg;
       g.tti0   = (int)tti0;
+      g.combine = q->harq_combine;
+      g.skip    = q->harq_combine ? q->d_cb_ok : nullptr;
+      const uint32_t* tbl = q->d_rm_tbl_rv[q->harq_rv];
       if (q->cfg.llr_8bit) {
         if (rm_fits_lds(g, 1)) {
           hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(g, 1), st, (const int8_t*)q->d_e, (int8_t*)q->d_w,
-                             (const uint32_t*)q->d_rm_tbl, g);
+                             tbl, g);
         } else {
           hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div(g.w_stride, 1024), nof_sf * C), dim3(256), 0, st, (const int8_t*)q->d_e,
-                             (int8_t*)q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+                             (int8_t*)q->d_w, tbl, g);
         }
       } else {
         if (rm_fits_lds(g)) {
-          hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(g, 2), st, (const int16_t*)q->d_e, q->d_w,
-                             (const uint32_t*)q->d_rm_tbl, g);
+          hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(g, 2), st, (const int16_t*)q->d_e, q->d_w, tbl, g);
         } else {
           hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(g.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_e,
-                             q->d_w, (const uint32_t*)q->d_rm_tbl, g);
+                             q->d_w, tbl, g);
         }
       }
       LAUNCH_CHECK();
@@ -716,6 +751,7 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
     }
     case 4:
       tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
+      tdec_set_skip(q->tdec, q->harq_combine ? q->d_cb_ok : nullptr);
       return tdec_run_batch_w(q->tdec, q->d_w, q->cfg.llr_8bit ? 1 : 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
                               C > 1 ? 0x1800063u : 0x1864CFBu, C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
     case 5: {
@@ -745,6 +781,27 @@ extern "C" int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, u
     if (r) return r;
   }
   return SRSLTE_SUCCESS;
+}
+
+// HARQ (decode_tb_cb, sch.c:299-414, on a srslte_softbuffer_rx_t per transport block, softbuffer.c:46-150): slot b of the object keeps
+// its code blocks' soft buffers, CRC flags and decoded bytes between calls. new_data != 0 starts new transport blocks (what the MAC's
+// srslte_softbuffer_rx_reset_tbs does on a toggled NDI): buffers are overwritten, every block is decoded. new_data == 0 is a
+// retransmission with redundancy version rv: the de-matched LLRs are ADDED to the kept soft buffers (rm_turbo.c:407-409), blocks whose
+// CRC already passed are neither combined nor decoded again. srslte_hip_dl_rx_batch is rv 0 / new data.
+extern "C" int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data,
+                                           uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !d_tb || !d_tb_ok || rv > 3) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!q->d_rm_tbl_rv[rv]) {
+    if (int r = dl_rx_rm_table(q, rv, &q->d_rm_tbl_rv[rv])) return r;
+  }
+  q->harq_rv      = rv;
+  q->harq_combine = new_data ? 0 : 1;
+  int r = SRSLTE_SUCCESS;
+  for (int s = 0; s < 6 && !r; s++) r = srslte_hip_dl_rx_stage(q, s, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+  q->harq_rv      = 0;
+  q->harq_combine = 0;
+  return r;
 }
 
 // Same chain from resource grids already in the frequency domain (what follows srslte_ofdm_rx_sf in ue_dl.c:375-397): stages 1..5
@@ -928,7 +985,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   }
   q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse;
-  q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride;
+  q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride; q->rg.Nl = 1;
   q->rg.out_len = (int)(3 * K + 12);
   q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re;
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);

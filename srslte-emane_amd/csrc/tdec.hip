@@ -224,6 +224,7 @@ struct TdecArgs {
   const uint32_t* tb_rem;      // optional [tb_C][K] remainders for the TB CRC share of each block (array order), else nullptr
   uint32_t        tb_C;
   uint32_t*       tb_syn;      // [nof_cb] out
+  const uint8_t*  skip;        // optional [nof_cb]: blocks whose CRC passed in an earlier transmission keep their bytes and flags (sch.c:317-318)
   unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
@@ -746,6 +747,10 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
 {
   using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
   const int      cb = blockIdx.x, K = (int)a.K;
+  if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
+    if (threadIdx.x == 0 && a.iters) a.iters[cb] = 0;
+    return;
+  }
   const LaneGeom L  = lane_geom();
   const in_t*    in = reinterpret_cast<const in_t*>(a.in) + (size_t)cb * a.in_stride;
   int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
@@ -973,8 +978,9 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
   const LaneGeom L      = lane_geom();
   const int      K      = (int)a.K;
   const uint32_t cb_raw = blockIdx.x * 8 + L.g;
-  const bool     active = cb_raw < a.nof_cb;
-  const uint32_t cb     = active ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
+  const bool     skipped = cb_raw < a.nof_cb && a.skip && a.skip[cb_raw]; // sch.c:317-318
+  const bool     active = cb_raw < a.nof_cb && !skipped;
+  const uint32_t cb     = cb_raw < a.nof_cb ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
   const int16_t* in     = a.in + (size_t)cb * a.in_stride;
   int16_t*       wk     = a.work + (size_t)cb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
@@ -1057,6 +1063,7 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
     if (a.iters) a.iters[cb] = my_iters;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
   }
+  if (L.p == 0 && skipped && a.iters) a.iters[cb] = 0;
 }
 
 // int8 -> int16 widening for the 8-bit API's 16-bit fall-backs (convert_8_to_16, turbodecoder.c:451-456)
@@ -1091,6 +1098,7 @@ struct srslte_hip_tdec {
   const uint32_t*          tb_rem = nullptr; // see tdec_set_tb_syndrome
   uint32_t                 tb_C   = 0;
   uint32_t*                tb_syn = nullptr;
+  const uint8_t*           skip   = nullptr; // see tdec_set_skip
   std::mutex               mtx;
 };
 
@@ -1195,6 +1203,8 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
   return SRSLTE_SUCCESS;
 }
 
+void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip) { q->skip = d_skip; }
+
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn)
 { // windowed decoders only; the caller (pdsch.hip) builds d_rem in the decoder's array order
   q->tb_rem = d_rem;
@@ -1245,6 +1255,7 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   a.dbg = getenv("SRSLTE_HIP_TDEC_DBG") ? atoi(getenv("SRSLTE_HIP_TDEC_DBG")) : 0;
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   a.tb_rem = W ? q->tb_rem : nullptr; a.tb_C = q->tb_C ? q->tb_C : 1; a.tb_syn = q->tb_syn;
+  a.skip = q->skip;
   a.prof = nullptr;
 #ifdef TDEC_PROF
   static unsigned long long* d_prof = nullptr;

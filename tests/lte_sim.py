@@ -21,6 +21,9 @@ class DlConfig:
     def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
+        # bits per "symbol" in the code-block split of the rate matcher: Qm * N_L, N_L = 2 for transmit diversity (36.212 5.1.4.1.2;
+        # srslte_dlsch_decode2 / _encode2, sch.c:507-531,:549-575)
+        self.Qm_sch = self.Qm * (2 if nof_ports == 2 else 1)
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.nof_ports = nof_ports
@@ -56,14 +59,15 @@ def scramble_seq(cfg, sf_idx, nbits):
     return c
 
 
-def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0):
-    """Returns (iq[sf_len] complex64, payload bytes[tbs/8]) for TTI `tti`."""
+def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None):
+    """Returns (iq[sf_len] complex64, payload bytes[tbs/8]) for TTI `tti`; rv / data: a HARQ retransmission of an earlier payload."""
     orc = oracle()
     sf_idx = tti % 10
     idx = cfg.indices(sf_idx)
     nbits = len(idx) * cfg.Qm
-    data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
-    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
+    if data is None:
+        data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm_sch, rv, cfg.max_iter)
     e = np.zeros(nbits, np.uint8)
     assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(e)) == 0
     e ^= scramble_seq(cfg, sf_idx, nbits)
@@ -131,7 +135,7 @@ def make_grid(cfg, tti, rng, snr_db):
     idx = cfg.indices(sf_idx)
     nbits = len(idx) * cfg.Qm
     data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
-    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
+    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm_sch, 0, cfg.max_iter)
     e = np.zeros(nbits, np.uint8)
     assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(e)) == 0
     e ^= scramble_seq(cfg, sf_idx, nbits)
@@ -148,9 +152,19 @@ def make_grid(cfg, tti, rng, snr_db):
     return (grid * h + noise).astype(np.complex64), data
 
 
-def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
+class OrcHarq:
+    """srslte_softbuffer_rx_t of one transport block for the oracle chain (buffer_f, cb_crc, data; softbuffer.c:46-150)."""
+
+    def __init__(self, cfg):
+        self.w = np.zeros(cfg.seg.C * oracle().orc_harq_softbuffer_stride(), np.int16)
+        self.crc = np.zeros(cfg.seg.C, np.uint8)
+        self.data = np.zeros(cfg.seg.C * 768, np.uint8)
+
+
+def oracle_rx(cfg, iq, tti, keep=False, grid_in=None, harq=None, rv=0, new_data=True):
     """Oracle UE receive chain for one subframe. Returns dict with tb bytes (tbs/8+3), ok flag and (keep=True) every intermediate.
-    grid_in: start from a frequency-domain grid instead of time samples."""
+    grid_in: start from a frequency-domain grid instead of time samples. harq: an OrcHarq that persists between the transmissions
+    of one transport block (rv, new_data as the MAC would set them)."""
     orc = oracle()
     sf_idx = tti % 10
     nrx = cfg.nof_rx
@@ -197,7 +211,7 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
         orc.orc_predecoding_csi((C.c_void_p * nrx)(*[v.ctypes.data for v in hs]), p(csi), nrx, len(idx), res.noise_estimate)
     nbits = len(idx) * cfg.Qm
     e = np.zeros(nbits, np.int8 if cfg.llr8 else np.int16)
-    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm, 0, cfg.max_iter)
+    sch = OrcSchCfg(cfg.tbs, nbits, cfg.Qm_sch, rv, cfg.max_iter)
     tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
     iters = np.zeros(cfg.seg.C, np.uint32)
     cbok = np.zeros(cfg.seg.C, np.uint8)
@@ -207,13 +221,18 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None):
         e_raw = e.copy()
         if cfg.csi:
             orc.orc_csi_correction_b(p(e), p(csi), len(idx), cfg.mod)
-        rc = orc.orc_dlsch_decode_8bit(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
     else:
         orc.orc_demod_soft_s(cfg.mod, p(d), p(e), len(idx))
         orc.orc_scramble_s(p(e), p(scramble_seq(cfg, sf_idx, nbits)), nbits)
         e_raw = e.copy()
         if cfg.csi:
             orc.orc_csi_correction_s(p(e), p(csi), len(idx), cfg.mod)
+    if harq is not None:
+        rc = orc.orc_dlsch_decode_harq(C.byref(sch), p(e), 1 if cfg.llr8 else 0, 1 if new_data else 0, p(harq.w), p(harq.crc), p(harq.data),
+                                       p(tb), p(iters), p(cbok))
+    elif cfg.llr8:
+        rc = orc.orc_dlsch_decode_8bit(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+    else:
         rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
     if keep:
@@ -377,7 +396,7 @@ class RefPdsch:
         nbytes = count * np.dtype(dtype).itemsize
         return np.frombuffer(C.string_at(int(addr), nbytes), dtype).copy()
 
-    def run(self, iq, tti, grid_in=None):
+    def run(self, iq, tti, grid_in=None, rv=0, new_data=True):
         cfg, R, L = self.cfg, self.R, self.L
         sf_idx, nrx = tti % 10, cfg.nof_rx
         grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(nrx)]
@@ -394,7 +413,9 @@ class RefPdsch:
         nre = self.nre[0 if sf_idx == 0 else (5 if sf_idx == 5 else 1)]
         self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
         self.u32(self.tb0 + L["srslte_ra_tb_t.nof_bits"], nre * cfg.Qm)
-        R.srslte_softbuffer_rx_reset(self.sb)
+        self.u32(self.tb0 + L["srslte_ra_tb_t.rv"], rv)
+        if new_data:
+            R.srslte_softbuffer_rx_reset(self.sb)
         payload = np.zeros(cfg.tbs // 8 + 64, np.uint8)
         data = np.zeros(2 * L["srslte_pdsch_res_t"], np.uint8)
         data[:8].view(np.uint64)[0] = payload.ctypes.data
@@ -414,14 +435,15 @@ def ref_sch_decode(self, e, nbits):
         s = cfg.seg
         tb = np.zeros(cfg.tbs // 8 + 16, np.uint8)
         iters, all_ok = np.zeros(s.C, np.uint32), True
-        Gp = nbits // cfg.Qm
-        gamma, n_e = Gp % s.C, cfg.Qm * (Gp // s.C)
+        qm = getattr(cfg, "Qm_sch", cfg.Qm)  # Qm * N_L (sch.c:507-531)
+        Gp = nbits // qm
+        gamma, n_e = Gp % s.C, qm * (Gp // s.C)
         for cb in range(s.C):
             K = s.K1 if cb < s.C1 else s.K2
             rlen = K if s.C == 1 else K - 24
             rp, n_e2 = cb * n_e, n_e
             if cb > s.C - gamma:
-                n_e2 = n_e + cfg.Qm
+                n_e2 = n_e + qm
                 rp = (s.C - gamma) * n_e + (cb - (s.C - gamma)) * n_e2
             w = self.aligned(3 * (K + 32) + 12 + 64, lt)
             ein = self.aligned(n_e2 + 64, lt)

@@ -795,3 +795,45 @@ def test_dl_rx_chain_csi_weighting(hp, prb, mod, tbs, nrx, npt, snr, llr8, tti0,
             assert np.array_equal(tb[b][:tbs // 8], data[b])
     assert n_ok > 0
     rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(25, 2, 4008, 1, 1, 3.0, False), (100, 3, 75376, 1, 1, 17.2, False), (50, 3, 11448, 1, 2, 8.2, True),
+                                                            (100, 3, 75376, 2, 2, 12.0, False), (6, 1, 152, 1, 1, -6.0, False), (100, 2, 43816, 1, 2, 7.5, False)])
+def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
+    """HARQ on the device (srslte_hip_dl_rx_batch_harq): four slots, each its own transport block, sent with rv 0, 2, 3, 1 in different
+    subframes with fresh noise; soft buffers, per-block CRC flags and bytes persist in the object. Per transmission and slot: CRC
+    flag, per-block pass counts (0 = block carried over from an earlier transmission) and TB bytes vs the oracle's OrcHarq chain,
+    which is checked against the reference's srslte_pdsch_decode + srslte_softbuffer_rx_t."""
+    from lte_sim import DlConfig, OrcHarq, make_subframe, oracle_rx
+    rng = np.random.default_rng(1900 + prb + mod + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, llr8=llr8)
+    nsf, C_ = 4, cfg.seg.C
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=npt)
+    harq = [OrcHarq(cfg) for _ in range(nsf)]
+    data = [None] * nsf
+    done = [False] * nsf
+    n_ok_first, n_ok_retx, n_carried = 0, 0, 0
+    for n, (rv, tti0) in enumerate(((0, 1), (2, 8), (3, 14), (1, 23))):  # tti0 + b: 8..11 crosses subframe 0 (other nof_re)
+        iq = []
+        for b in range(nsf):
+            x, data[b] = make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, rv=rv, data=data[b])
+            iq.append(x)
+        tb, ok = rx.decode_harq(np.stack(iq), tti0, rv, n == 0)
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        for b in range(nsf):
+            if done[b]:
+                continue  # the MAC would not schedule a retransmission of an acknowledged block
+            r = oracle_rx(cfg, iq[b], tti0 + b, harq=harq[b], rv=rv, new_data=n == 0)
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), (n, b, it[b], r["iters"])
+            n_carried += int((r["iters"] == 0).sum())
+            if r["ok"]:
+                assert np.array_equal(tb[b], r["tb"]) and np.array_equal(tb[b][:tbs // 8], data[b])
+                done[b] = True
+                n_ok_first += n == 0
+                n_ok_retx += n > 0
+    assert n_ok_first + n_ok_retx > 0 and (n_ok_retx > 0 or llr8)
+    if prb == 100 and npt == 1:
+        assert n_carried > 0
+    rx.free()
