@@ -624,3 +624,63 @@ class RefUlRx:
         qv[cfg.scramble(tti % 10).astype(bool)] *= -1
         g = np.ascontiguousarray(qv[cfg.q_of_g])
         return ref_sch_decode(self, g, cfg.nbits)
+
+
+class RefUlsch:
+    """The reference's own srslte_ulsch_encode / srslte_ulsch_decode (sch.c:991-1160: UL-SCH coding, the UL channel interleaver of
+    36.212 5.2.2.8 and its inverse, UCI absent) on its compiled code, with a hand-filled srslte_pusch_cfg_t (offsets from the reference
+    headers at run time). Pins the UL side of the oracle chain: orc_dlsch_encode/decode used as UL-SCH coder and UlConfig.q_of_g."""
+
+    def __init__(self, cfg):
+        from _libs import opaque, ref, ref_layout
+        R = self.R = ref()
+        self.cfg = cfg
+        L = self.L = ref_layout({"srslte_sch_t": [], "srslte_pusch_cfg_t": ["grant", "max_nof_iterations", "softbuffers"],
+                                 "srslte_pusch_grant_t": ["L_prb", "nof_re", "nof_symb", "tb"],
+                                 "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "enabled"],
+                                 "srslte_softbuffer_rx_t": [], "srslte_softbuffer_tx_t": []}, ["srslte/phy/ch_estimation/chest_ul.h", "srslte/phy/phch/pusch.h"])
+        self.q = opaque(L["srslte_sch_t"] + 64)
+        assert R.srslte_sch_init(self.q) == 0
+        R.srslte_sch_set_max_noi.argtypes = [C.c_void_p, C.c_uint32]
+        R.srslte_sch_set_max_noi(self.q, cfg.max_iter)
+        self.sb_rx, self.sb_tx = opaque(L["srslte_softbuffer_rx_t"] + 64), opaque(L["srslte_softbuffer_tx_t"] + 64)
+        assert R.srslte_softbuffer_rx_init(self.sb_rx, cfg.nof_prb) == 0 and R.srslte_softbuffer_tx_init(self.sb_tx, cfg.nof_prb) == 0
+        self.pc = np.zeros(L["srslte_pusch_cfg_t"], np.uint8)
+        g0, t0 = L["srslte_pusch_cfg_t.grant"], L["srslte_pusch_cfg_t.grant"] + L["srslte_pusch_grant_t.tb"]
+
+        def u32(off, v):
+            self.pc[off:off + 4].view(np.uint32)[0] = v
+        u32(g0 + L["srslte_pusch_grant_t.L_prb"], cfg.L_prb)
+        u32(g0 + L["srslte_pusch_grant_t.nof_re"], cfg.nof_re)
+        u32(g0 + L["srslte_pusch_grant_t.nof_symb"], 12)
+        u32(t0 + L["srslte_ra_tb_t.mod"], cfg.mod)
+        u32(t0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
+        u32(t0 + L["srslte_ra_tb_t.nof_bits"], cfg.nbits)
+        self.pc[t0 + L["srslte_ra_tb_t.enabled"]] = 1
+        u32(L["srslte_pusch_cfg_t.max_nof_iterations"], cfg.max_iter)
+        self.sb_off = L["srslte_pusch_cfg_t.softbuffers"]
+
+    def encode(self, data):
+        """payload bytes -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling (pusch.c:380-395)."""
+        cfg, R = self.cfg, self.R
+        self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_tx)
+        R.srslte_softbuffer_tx_reset(self.sb_tx)
+        d = np.zeros(cfg.tbs // 8 + 64, np.uint8)
+        d[:cfg.tbs // 8] = data
+        uci = np.zeros(4096, np.uint8)
+        g, q = np.zeros(cfg.nbits // 8 + 64, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8)
+        assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) == 0
+        return np.unpackbits(g)[:cfg.nbits], np.unpackbits(q)[:cfg.nbits]
+
+    def decode(self, q_llr, c_seq):
+        """descrambled int16 LLRs in received (q) order -> {tb, ok}, as srslte_pusch_decode calls it (pusch.c:497-503)."""
+        cfg, R = self.cfg, self.R
+        self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_rx)
+        R.srslte_softbuffer_rx_reset(self.sb_rx)
+        ql = np.zeros(cfg.nbits + 64, np.int16)
+        ql[:cfg.nbits] = q_llr
+        gl = np.zeros(cfg.nbits + 64, np.int16)
+        cs = np.ascontiguousarray(c_seq, np.uint8)
+        tb, uci = np.zeros(cfg.tbs // 8 + 64, np.uint8), np.zeros(4096, np.uint8)
+        rc = R.srslte_ulsch_decode(self.q, p(self.pc), p(ql), p(gl), p(cs), p(tb), p(uci))
+        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy()}

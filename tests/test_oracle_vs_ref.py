@@ -662,3 +662,29 @@ def test_pusch_chain_vs_reference_code(prb, L, n_prb, mod, tbs, snr):
             nok += 1
             assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
     assert nok > 0
+
+
+@pytest.mark.parametrize("prb,L,mod,tbs,snr", [(6, 6, 1, 1000, 3.5), (25, 10, 2, 4008, 9.5), (100, 100, 2, 43816, 12.5), (100, 48, 3, 30576, 17.0), (50, 45, 3, 30576, 18.5)])
+def test_ulsch_functions_vs_oracle_chain(prb, L, mod, tbs, snr):
+    """The reference's own srslte_ulsch_encode and srslte_ulsch_decode (sch.c:991-1160, no UCI): coded bits g, interleaved bits q
+    (36.212 5.2.2.8) and, on the receive side, the de-interleaved LLRs, CRC result and transport block, against the oracle chain's
+    UL-SCH coder / UlConfig.q_of_g / decoder on identical inputs."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(700 + prb + L)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3)
+    chain = RefUlsch(cfg)
+    nok = 0
+    for t in (2, 7, 9):
+        k = {}
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k)
+        g_r, q_r = chain.encode(data)
+        q_o = np.zeros(cfg.nbits, np.uint8)
+        q_o[cfg.q_of_g] = k["g"]
+        assert np.array_equal(g_r, k["g"]) and np.array_equal(q_r, q_o), t
+        o = oracle_ul_rx(cfg, iq, t, keep=True)
+        r = chain.decode(o["q"], cfg.scramble(t % 10))
+        assert np.array_equal(r["g"], o["g"]) and r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        nok += r["ok"]
+    assert nok > 0
