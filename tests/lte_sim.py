@@ -59,8 +59,9 @@ def scramble_seq(cfg, sf_idx, nbits):
     return c
 
 
-def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None):
-    """Returns (iq[sf_len] complex64, payload bytes[tbs/8]) for TTI `tti`; rv / data: a HARQ retransmission of an earlier payload."""
+def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None, keep=None):
+    """Returns (iq[sf_len] complex64, payload bytes[tbs/8]) for TTI `tti`; rv / data: a HARQ retransmission of an earlier payload;
+    keep: dict that receives the per-port PDSCH symbols before RE mapping ("y": list of arrays) and the RE indices ("idx")."""
     orc = oracle()
     sf_idx = tti % 10
     idx = cfg.indices(sf_idx)
@@ -77,7 +78,9 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None):
     orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
     q.normalize = True
     if cfg.nof_ports == 2:
-        return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp), data
+        return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep), data
+    if keep is not None:
+        keep.update(y=[syms.copy()], idx=idx)
     grid = np.zeros(cfg.grid_len, np.complex64)
     grid[idx] = syms
     orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, 0, p(grid))
@@ -96,13 +99,15 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None):
     return np.stack([noisy(np.complex64(g) * iq) for g in gains]).astype(np.complex64), data
 
 
-def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp):
+def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None):
     """eNB side of pdsch.c:1150-1175 for 2-port transmit diversity: layer mapping + SFBC precoding, RE mapping and CRS per port; every
     (antenna, port) path has its own smooth frequency response (a gain and a delay), applied in the frequency domain."""
     orc = oracle()
     orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     y = [np.zeros(len(idx), np.complex64), np.zeros(len(idx), np.complex64)]
     orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), 1.0)
+    if keep is not None:
+        keep.update(y=[y[0].copy(), y[1].copy()], idx=idx)
     tx = []
     for port in range(2):
         g = np.zeros(cfg.grid_len, np.complex64)
@@ -424,6 +429,64 @@ class RefPdsch:
         e = self._ptr("e", np.int8 if cfg.llr8 else np.int16, nre * cfg.Qm)
         return {"tb": payload[:cfg.tbs // 8 + 3].copy(), "ok": ok, "d": self._ptr("d", np.complex64, nre), "e": e,
                 "csi": self._ptr("csi", np.float32, nre), "noise": self.res.noise_estimate}
+
+
+class RefPdschTx:
+    """The reference's own srslte_pdsch_encode (pdsch.c:1059-1185, eNB object): TB -> DL-SCH coding -> scrambling -> modulation -> layer
+    mapping / SFBC precoding -> RE mapping, one resource grid per port (without CRS: srslte_enb_dl_put_base adds them). Pins the
+    stimulus generator make_subframe builds from oracle pieces. p_a = 0: rho_a = 1 for one port, sqrt(2) for two (pdsch.c:525)."""
+
+    def __init__(self, cfg):
+        from _libs import RefCell, RefDlSfCfg, aligned, opaque, ref, ref_layout
+        R = self.R = ref()
+        self.cfg, self.aligned = cfg, aligned
+        L = self.L = ref_layout({"srslte_pdsch_t": [], "srslte_pdsch_cfg_t": ["rnti", "softbuffers"],
+                                 "srslte_pdsch_grant_t": ["tx_scheme", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
+                                 "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"], "srslte_softbuffer_tx_t": []},
+                                ["srslte/phy/phch/pdsch.h"])
+        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
+        self.q = opaque(L["srslte_pdsch_t"] + 64)
+        assert R.srslte_pdsch_init_enb(self.q, cfg.nof_prb) == 0 and R.srslte_pdsch_set_cell(self.q, cell) == 0
+        R.srslte_pdsch_set_rnti.argtypes = [C.c_void_p, C.c_uint16]
+        assert R.srslte_pdsch_set_rnti(self.q, cfg.rnti) == 0
+        self.sb = opaque(L["srslte_softbuffer_tx_t"] + 64)
+        assert R.srslte_softbuffer_tx_init(self.sb, cfg.nof_prb) == 0
+        self.pc = g = np.zeros(L["srslte_pdsch_cfg_t"], np.uint8)
+
+        def u32(off, v):
+            g[off:off + 4].view(np.uint32)[0] = v
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports == 2 else 0)
+        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
+        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
+        u32(L["srslte_pdsch_grant_t.nof_tb"], 1)
+        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_ports)
+        self.tb0 = L["srslte_pdsch_grant_t.tb"]
+        u32(self.tb0 + L["srslte_ra_tb_t.mod"], cfg.mod)
+        u32(self.tb0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
+        g[self.tb0 + L["srslte_ra_tb_t.enabled"]] = 1
+        g[L["srslte_pdsch_cfg_t.rnti"]:L["srslte_pdsch_cfg_t.rnti"] + 2].view(np.uint16)[0] = cfg.rnti
+        g[L["srslte_pdsch_cfg_t.softbuffers"]:L["srslte_pdsch_cfg_t.softbuffers"] + 8].view(np.uint64)[0] = C.addressof(self.sb)
+        self.u32, self.sf = u32, RefDlSfCfg()
+
+    def run(self, data, tti, rv=0):
+        cfg, R, L = self.cfg, self.R, self.L
+        nre = len(cfg.indices(tti % 10))
+        self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
+        self.u32(self.tb0 + L["srslte_ra_tb_t.nof_bits"], nre * cfg.Qm)
+        self.u32(self.tb0 + L["srslte_ra_tb_t.rv"], rv)
+        self.sf.tti, self.sf.cfi = tti, cfg.cfi
+        R.srslte_softbuffer_tx_reset(self.sb)
+        d = np.zeros(cfg.tbs // 8 + 64, np.uint8)
+        d[:cfg.tbs // 8] = data
+        dp = (C.c_void_p * 2)(d.ctypes.data, 0)
+        for v in ((0, rv) if rv else (0,)):  # a retransmission reads the circular buffer the rv 0 encode left in the soft buffer (sch.c:183-297)
+            self.u32(self.tb0 + L["srslte_ra_tb_t.rv"], v)
+            grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(cfg.nof_ports)]
+            gp = (C.c_void_p * 4)(*([g_.ctypes.data for g_ in grids] + [0] * (4 - cfg.nof_ports)))
+            assert R.srslte_pdsch_encode(self.q, C.byref(self.sf), p(self.pc), dp, gp) == 0
+        return [g_.view(np.complex64).copy() for g_ in grids]
 
 
 def ref_sch_decode(self, e, nbits):
