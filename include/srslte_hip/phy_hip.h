@@ -198,6 +198,10 @@ typedef struct {
   int      csi_enable;      /* srslte_pdsch_cfg_t.csi_enable (pdsch_cfg.h:63; the srsUE default): LLRs weighted by each symbol's channel
                                gain relative to the subframe's largest (csi_correction, pdsch.c:574-690, applied inside the rate
                                de-matching kernels as they read the LLRs) */
+  int      power_scale;     /* srslte_pdsch_cfg_t.power_scale / p_a (pdsch_cfg.h:58-62, pdsch.c:518-554,:852-858): the equaliser divides by
+                               rho_a = 10^(p_a/20) (x sqrt(2) for a 2-port cell). Only p_b values with rho_b = 1 (no rescaling of the
+                               CRS-bearing symbols) are covered */
+  float    p_a;             /* dB */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -273,6 +277,30 @@ int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t 
 /* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
  * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
 const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);
+
+/* ------------------------------------------------------------------ PDSCH transmit pipeline (eNB side): srslte_pdsch_encode
+ * (pdsch.c:1059-1185: DL-SCH coding, scrambling, modulation, layer mapping + SFBC precoding, RE mapping) + CRS
+ * (srslte_refsignal_cs_put_sf refsignal_dl.c:253-272) + srslte_ofdm_tx_sf with 1/sqrt(N) (enb_dl.c:56-62). One codeword, TM1 or 2-port
+ * TM2, full-band grant, normal CP; no control region, PSS/SSS or PBCH content (their REs stay zero). */
+typedef struct srslte_hip_dl_tx srslte_hip_dl_tx_t;
+typedef struct {
+  uint32_t cell_id, nof_prb, cfi;
+  uint16_t rnti;
+  int      mod;            /* srslte_mod_t: QPSK .. 256QAM */
+  uint32_t tbs;
+  uint32_t max_batch;
+  uint32_t nof_ports;      /* 0 or 1: TM1; 2: transmit diversity */
+  float    p_a;            /* dB; rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports), pdsch.c:518-554 with p_b giving rho_b = 1 */
+} srslte_hip_dl_tx_cfg_t;
+srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);
+void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);
+/* d_tb: [nof_sf][tb_stride] payload bytes; d_iq: [nof_sf][nof_ports][15*N] cf32, one time-domain signal per antenna port; rv: the
+ * redundancy version of the whole batch (the circular buffer is re-encoded, not kept) */
+int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, uint32_t rv, void* d_iq,
+                           void* stream);
+/* intermediate device buffers of the last call: 0 code blocks, 1 parity streams, 2 per-port symbol streams [nof_sf][nof_ports][max nof_re],
+ * 3 grids [nof_sf][nof_ports][14][12*nof_prb] */
+const void* srslte_hip_dl_tx_debug_buffer(const srslte_hip_dl_tx_t* q, int which);
 
 #ifdef __cplusplus
 }

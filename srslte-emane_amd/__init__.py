@@ -41,7 +41,7 @@ class Cbsegm(C.Structure):
 class DlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int),
                 ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg),
-                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int)]
+                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int), ("power_scale", C.c_int), ("p_a", C.c_float)]
 
 
 def lib():
@@ -380,9 +380,9 @@ class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
     def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False, nof_rx=1,
-                 nof_ports=1, csi=False):
+                 nof_ports=1, csi=False, power_scale=False, p_a=0.0):
         self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
-                           1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0)
+                           1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0, 1 if power_scale else 0, p_a)
         self.nof_rx = nof_rx
         self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
         if not self.h:
@@ -541,4 +541,48 @@ class UlTx:
     def free(self):
         if self.h:
             lib().srslte_hip_ul_tx_destroy(self.h)
+            self.h = None
+
+
+class DlTxCfg(C.Structure):
+    _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32),
+                ("max_batch", C.c_uint32), ("nof_ports", C.c_uint32), ("p_a", C.c_float)]
+
+
+class DlTx:
+    """Batched PDSCH transmit chain (srslte_pdsch_encode pdsch.c:1059-1185 + CRS + srslte_ofdm_tx_sf, enb_dl.c)."""
+
+    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports=1, p_a=0.0):
+        self.cfg = DlTxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports, p_a)
+        L = lib()
+        L.srslte_hip_dl_tx_create.restype = C.c_void_p
+        L.srslte_hip_dl_tx_create.argtypes = [C.POINTER(DlTxCfg)]
+        L.srslte_hip_dl_tx_destroy.argtypes = [C.c_void_p]
+        L.srslte_hip_dl_tx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.srslte_hip_dl_tx_debug_buffer.restype = C.c_void_p
+        L.srslte_hip_dl_tx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
+        self.h = L.srslte_hip_dl_tx_create(C.byref(self.cfg))
+        if not self.h:
+            raise RuntimeError("srslte_hip_dl_tx_create failed")
+        self.tbs, self.max_batch, self.nof_ports = tbs, max_batch, max(1, nof_ports)
+        self.sf_len = 15 * symbol_sz(nof_prb)
+        self.d_iq = DevBuf(8 * self.sf_len * max_batch * self.nof_ports)
+
+    def encode(self, tb, tti0=0, rv=0):
+        """tb: [nof_sf][tbs/8] payload bytes -> iq [nof_sf][nof_ports][sf_len]."""
+        x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
+        din = DevBuf.from_host(x)
+        _check(lib().srslte_hip_dl_tx_batch(self.h, din.ptr, self.tbs // 8, tti0, x.shape[0], rv, self.d_iq.ptr, None), "dl_tx_batch")
+        sync()
+        return self.d_iq.to_host(np.complex64).reshape(self.max_batch, self.nof_ports, self.sf_len)[:x.shape[0]]
+
+    def debug(self, which, dtype, count):
+        ptr = lib().srslte_hip_dl_tx_debug_buffer(self.h, which)
+        out = np.empty(count, dtype)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, ptr, out.nbytes), "memcpy_d2h")
+        return out
+
+    def free(self):
+        if self.h:
+            lib().srslte_hip_dl_tx_destroy(self.h)
             self.h = None

@@ -37,6 +37,7 @@ struct PdschGeom {
   SfClass cls[3];
   int     grid_len;   // 14 * 12 * nof_prb
   int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx, nof_ports;
+  float     inv_scaling; // 1 / pdsch_scaling (pdsch.c:852-858): 1, or 1 / rho_a with cfg.power_scale
   float*    csi;     // [nof_sf][max_re] channel gain per RE, or null (cfg.csi_enable)
   uint32_t* csi_max; // [nof_sf] bit pattern of the largest gain of each subframe (non-negative floats order like their bits), zeroed per call
 };
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
     const cf32 y = grid[(size_t)sf * g.grid_len + k], h = ce[(size_t)sf * g.grid_len + k];
     // precoding.c:277-288 with scaling = 1 (pdsch.c:852-858, power_scale off)
     const float re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0;
-    x = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+    x = make_float2(re * g.inv_scaling / csi, im * g.inv_scaling / csi);
     gain = csi;
   } else { // srslte_predecoding_single_multi (precoding.c:138-262): maximum-ratio combining over the receive antennas
     float re = 0.f, im = 0.f, hh = 0.f;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
       hh = a ? hh + ph : ph;
     }
     if (n0 > 0.f) hh += n0;
-    x = make_float2(re / hh * 1.0f, im / hh * 1.0f);
+    x = make_float2(re / hh * g.inv_scaling, im / hh * g.inv_scaling);
     gain = hh;
   }
   if (g.csi) {
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
     if (live) *reinterpret_cast<float2*>(g.csi + (size_t)sf * g.max_re + i0) = make_float2(hh, hh);
     csi_note_max(g.csi_max + sf, live ? hh : 0.f);
   }
+  hh *= 1.0f / g.inv_scaling; // hh *= scaling (precoding.c:593)
   const cf32 x[2] = {make_float2((float)((double)(x0r / hh) * 1.4142135623730951), (float)((double)(x0i / hh) * 1.4142135623730951)),
                      make_float2((float)((double)(x1r / hh) * 1.4142135623730951), (float)((double)(x1i / hh) * 1.4142135623730951))};
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
@@ -646,6 +648,8 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->pg.grid_len = (int)glen; q->pg.max_re = (int)max_re; q->pg.max_bits = (int)max_bits; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.mmse = cfg->mmse; q->pg.scr_words = (int)scr_words; q->pg.nof_rx = (int)nrx; q->pg.nof_ports = (int)npt;
   q->pg.csi = q->d_csi; q->pg.csi_max = q->d_csi_max;
+  // apply_power_allocation (pdsch.c:518-554) with rho_b = 1: pdsch_scaling = rho_a = 10^(p_a/20), times sqrt(2) for a 2-port cell
+  q->pg.inv_scaling = cfg->power_scale ? 1.0f / (powf(10.0f, cfg->p_a / 20.0f) * (npt == 1 ? 1.0f : sqrtf(2.0f))) : 1.0f;
   q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = npt == 2 ? 2 : 1;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
@@ -1343,4 +1347,242 @@ extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb
                      q->d_grid, g);
   LAUNCH_CHECK();
   return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf, stream);
+}
+
+// ====================================================================================================================
+// PDSCH transmit pipeline (eNB side): srslte_pdsch_encode (pdsch.c:1059-1185: DL-SCH coding sch.c:183-297 with the
+// Qm * N_L block split :549-575, scrambling, modulation, layer mapping + SFBC precoding, RE mapping) + CRS (srslte_refsignal_cs_put_sf,
+// refsignal_dl.c:253-272) + srslte_ofdm_tx_sf with 1/sqrt(N) (enb_dl.c:56-62). One codeword, TM1 or 2-port TM2, full-band grant.
+// Re-uses the PUSCH transmit kernels for CRC attachment / segmentation and the byte-stream turbo encoder.
+// ====================================================================================================================
+namespace {
+
+struct PdschTxGeom {
+  SfClass cls[3];
+  const int32_t* src[3][2]; // per subframe class and port: grid RE -> >= 0 index into the port's symbol stream, -1 zero, <= -2 CRS pilot -(v + 2)
+  int   grid_len, max_re, Qm, Nl, nof_ports, tti0, scr_words, C, K, cb_stride, par_stride, rm_len;
+  float lvl[16], gain; // constellation levels of one axis; rho_a (TM1) or rho_a / sqrt(2) (TM2)
+};
+
+// grid = (ceil(max_re / (256 * Nl)), nof_sf): one thread per layer-mapping unit (one symbol for TM1, the SFBC pair 2i, 2i+1 for TM2).
+// Bit e of a code block = coded bit rm[e mod (3K+12)] in the encoder's byte streams, as in pusch_tx_mod_kernel; the block split counts
+// in units of Qm * N_L bits. y: [nof_sf][nof_ports][max_re].
+__global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
+                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ y, PdschTxGeom g)
+{
+  const int sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nre = g.cls[sf_class(sf_idx)].nof_re;
+  const int u = blockIdx.x * blockDim.x + threadIdx.x, Gp = nre / g.Nl; // unit index; Gp = G' of 36.212 5.1.4.1.2
+  if (u >= Gp) return;
+  const int QmL = g.Qm * g.Nl, gamma = Gp % g.C, lo = Gp / g.C, C_lo = g.C - gamma; // blocks 0..C_lo-1 carry lo units, the rest lo + 1 (sch.c:232-236)
+  int       r, e0;
+  if (u < C_lo * lo) {
+    r  = u / lo;
+    e0 = (u - r * lo) * QmL;
+  } else {
+    const int v = u - C_lo * lo;
+    r           = C_lo + v / (lo + 1);
+    e0          = (v % (lo + 1)) * QmL;
+  }
+  const size_t    cbi = (size_t)sf * g.C + r;
+  const uint8_t * xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
+  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
+  cf32            d[2];
+  for (int t = 0; t < g.Nl; t++) {
+    const int q0 = (u * g.Nl + t) * g.Qm;
+    int       re = 0, im = 0;
+    for (int b = 0; b < g.Qm; b++) {
+      const uint32_t src = rm[(e0 + t * g.Qm + b) % g.rm_len], pos = src & 0x3fffffffu;
+      const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
+      int            bit  = (byte >> (7 - (pos & 7))) & 1;
+      bit ^= (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
+      if (b & 1) im = (im << 1) | bit;
+      else re = (re << 1) | bit;
+    }
+    d[t] = make_float2(g.lvl[re] * g.gain, g.lvl[im] * g.gain);
+  }
+  cf32* y0 = y + ((size_t)sf * g.nof_ports) * g.max_re;
+  if (g.Nl == 1) {
+    y0[u] = d[0];
+  } else { // srslte_precoding_diversity, 2 ports (precoding.c:1851-1861): y0 = x0, x1; y1 = -x1*, x0*
+    cf32* y1      = y0 + g.max_re;
+    y0[2 * u]     = d[0];
+    y0[2 * u + 1] = d[1];
+    y1[2 * u]     = make_float2(-d[1].x, d[1].y);
+    y1[2 * u + 1] = make_float2(d[0].x, -d[0].y);
+  }
+}
+
+// grid = (ceil(grid_len/256), nof_sf * nof_ports): the resource grid of one port: PDSCH symbols, this port's CRS, zero elsewhere
+__global__ __launch_bounds__(256) void pdsch_tx_map_kernel(const cf32* __restrict__ y, const cf32* __restrict__ pilots, cf32* __restrict__ grid,
+                                                           int nref4 /* 4 * 2 * nof_prb */, PdschTxGeom g)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, sp = blockIdx.y, sf = sp / g.nof_ports, port = sp - sf * g.nof_ports;
+  if (k >= g.grid_len) return;
+  const int sf_idx = (g.tti0 + sf) % 10, v = g.src[sf_class(sf_idx)][port][k];
+  cf32      o = make_float2(0.f, 0.f);
+  if (v >= 0) o = y[(size_t)sp * g.max_re + v];
+  else if (v <= -2) o = pilots[(size_t)sf_idx * nref4 + (-(v + 2))];
+  grid[(size_t)sp * g.grid_len + k] = o;
+}
+
+} // namespace
+
+struct srslte_hip_dl_tx {
+  srslte_hip_dl_tx_cfg_t cfg;
+  srslte_hip_ofdm_t*     ofdm;
+  srslte_hip_chest_dl_t* crs; // for its CRS table
+  srslte_hip_cbsegm_t    seg;
+  PuschTxGeom            cg; // CRC attachment / segmentation geometry (shared kernels)
+  PdschTxGeom            g;
+  uint32_t *             d_scr, *d_rm[4], *d_tbcrc, *d_idx[3];
+  int32_t*               d_src[3][2];
+  uint8_t *              d_cb, *d_parity, *d_sys_tail;
+  cf32 *                 d_y, *d_grid;
+};
+
+extern "C" void srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q)
+{
+  if (!q) return;
+  srslte_hip_ofdm_destroy(q->ofdm);
+  srslte_hip_chest_dl_destroy(q->crs);
+  void* bufs[] = {q->d_scr, q->d_rm[0], q->d_rm[1], q->d_rm[2], q->d_rm[3], q->d_tbcrc, q->d_idx[0], q->d_idx[1], q->d_idx[2],
+                  q->d_src[0][0], q->d_src[0][1], q->d_src[1][0], q->d_src[1][1], q->d_src[2][0], q->d_src[2][1],
+                  q->d_cb, q->d_parity, q->d_sys_tail, q->d_y, q->d_grid};
+  for (void* b : bufs) {
+    if (b) (void)hipFree(b);
+  }
+  delete q;
+}
+
+static int dl_tx_rm_table(srslte_hip_dl_tx_t* q, uint32_t rv)
+{ // rate matching (rm_turbo.c:100-158): coded bit of each circular-buffer position read from k0(rv), addressed in the encoder's byte streams
+  const uint32_t        K = q->seg.K1;
+  std::vector<uint32_t> t;
+  lte_rm_rx_table(K, rv, t);
+  for (auto& v : t) {
+    const uint32_t p = v / 3, s = v % 3;
+    v = s == 0 ? (p < K ? p : (1u << 30) | (p - K)) : (2u << 30) | (s == 1 ? p : K + 4 + p);
+  }
+  return upload(&q->d_rm[rv], t);
+}
+
+extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg)
+{
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->nof_ports > 2 || cfg->nof_prb < 6 || cfg->nof_prb > 110) {
+    fprintf(stderr, "[srslte_hip] dl_tx: invalid configuration\n");
+    return nullptr;
+  }
+  auto* q = new srslte_hip_dl_tx();
+  memset(q, 0, sizeof(*q));
+  q->cfg = *cfg;
+  if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
+    fprintf(stderr, "[srslte_hip] dl_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    delete q;
+    return nullptr;
+  }
+  const uint32_t P = cfg->nof_prb, nre = 12 * P, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod;
+  const uint32_t lstart = cfg->cfi + (P < 10 ? 1 : 0), npt = cfg->nof_ports ? cfg->nof_ports : 1, glen = 14 * nre;
+  q->ofdm = srslte_hip_ofdm_create((int)P, 1, 0);
+  q->crs  = srslte_hip_chest_dl_create(cfg->cell_id, P, npt, 1);
+  bool ok = q->ofdm && q->crs && srslte_hip_ofdm_set_normalize(q->ofdm, 1) == SRSLTE_SUCCESS; // enb_dl.c:61
+  uint32_t       max_re    = 0;
+  const uint32_t rep_sf[3] = {0, 5, 1};
+  PdschTxGeom&   g = q->g;
+  for (int c = 0; c < 3 && ok; c++) {
+    std::vector<uint32_t> idx;
+    pdsch_re_indices(cfg->cell_id, P, npt, rep_sf[c], lstart, idx);
+    g.cls[c].nof_re = (int)idx.size();
+    max_re          = idx.size() > max_re ? (uint32_t)idx.size() : max_re;
+    ok              = upload(&q->d_idx[c], idx) == SRSLTE_SUCCESS;
+    g.cls[c].idx    = q->d_idx[c];
+    for (uint32_t port = 0; port < npt && ok; port++) {
+      std::vector<int32_t> src(glen, -1);
+      for (size_t i = 0; i < idx.size(); i++) src[idx[i]] = (int32_t)i;
+      for (int l = 0; l < 4; l++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272), ports 0/1: symbols 0, 4, 7, 11
+        const uint32_t sym = (l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7, fidx = ((((l + port) & 1) ? 3 : 0) + cfg->cell_id % 6) % 6;
+        for (uint32_t i = 0; i < 2 * P; i++) src[sym * nre + fidx + 6 * i] = -(int32_t)(l * 2 * P + i) - 2;
+      }
+      ok             = upload(&q->d_src[c][port], src) == SRSLTE_SUCCESS;
+      g.src[c][port] = q->d_src[c][port];
+    }
+  }
+  const uint32_t max_bits = max_re * Qm, scr_words = (max_bits + 31) / 32;
+  if (ok) { // srslte_sequence_pdsch (sequences.c:58-60), codeword 0
+    std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
+    std::vector<uint8_t>  c;
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, max_bits, c);
+      for (uint32_t i = 0; i < max_bits; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
+    }
+    ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
+  }
+  ok = ok && dl_tx_rm_table(q, 0) == SRSLTE_SUCCESS;
+  PuschTxGeom& cg = q->cg;
+  cg.C = (int)C; cg.K = (int)K; cg.tbs = (int)cfg->tbs; cg.rlenB = (int)((C == 1 ? K : K - 24) / 8); cg.cb_stride = (int)((K / 8 + 15) & ~15u);
+  cg.par_stride = (int)((K / 4 + 1 + 15) & ~15u);
+  g.grid_len = (int)glen; g.max_re = (int)max_re; g.Qm = (int)Qm; g.Nl = npt == 2 ? 2 : 1; g.nof_ports = (int)npt; g.scr_words = (int)scr_words;
+  g.C = (int)C; g.K = (int)K; g.cb_stride = cg.cb_stride; g.par_stride = cg.par_stride; g.rm_len = (int)(3 * K + 12);
+  for (uint32_t idx = 0; idx < (1u << cfg->mod); idx++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
+    const int    nb = cfg->mod;
+    double       v  = 1.0;
+    for (int i = nb - 1; i >= 1; i--) v = (double)(1 << (nb - i)) - (1 - 2 * (int)((idx >> (nb - 1 - i)) & 1)) * v;
+    const double norm = nb == 1 ? sqrt(2.0) : (nb == 2 ? sqrt(10.0) : (nb == 3 ? sqrt(42.0) : sqrt(170.0)));
+    g.lvl[idx]        = (float)((1 - 2 * (int)((idx >> (nb - 1)) & 1)) * v / norm);
+  }
+  const float rho_a = powf(10.0f, cfg->p_a / 20.0f) * (npt == 1 ? 1.0f : sqrtf(2.0f)); // pdsch.c:525
+  g.gain            = npt == 1 ? rho_a : rho_a / sqrtf(2.0f);                          // precoding.c:1859-1860
+  ok = ok && hipMalloc((void**)&q->d_tbcrc, sizeof(uint32_t) * B) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb, (size_t)cg.cb_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_parity, (size_t)cg.par_stride * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_sys_tail, (size_t)B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_y, sizeof(cf32) * (size_t)max_re * B * npt) == hipSuccess &&
+       hipMalloc((void**)&q->d_grid, sizeof(cf32) * (size_t)glen * B * npt) == hipSuccess;
+  if (!ok) {
+    fprintf(stderr, "[srslte_hip] dl_tx: initialisation failed\n");
+    srslte_hip_dl_tx_destroy(q);
+    return nullptr;
+  }
+  return q;
+}
+
+extern "C" const void* srslte_hip_dl_tx_debug_buffer(const srslte_hip_dl_tx_t* q, int which)
+{
+  if (!q) return nullptr;
+  switch (which) {
+    case 0: return q->d_cb;
+    case 1: return q->d_parity;
+    case 2: return q->d_y;
+    case 3: return q->d_grid;
+  }
+  return nullptr;
+}
+
+extern "C" int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, uint32_t rv,
+                                      void* d_iq, void* stream)
+{
+  if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 || rv > 3) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  if (!q->d_rm[rv]) {
+    if (int r = dl_tx_rm_table(q, rv)) return r;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  PuschTxGeom cg = q->cg;
+  cg.tb_stride   = (int)tb_stride;
+  hipLaunchKernelGGL(pusch_tx_tbcrc_kernel, dim3(nof_sf), dim3(256), 0, st, d_tb, q->d_tbcrc, cg);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(pusch_tx_seg_kernel, dim3(cg.C, nof_sf), dim3(256), 0, st, d_tb, (const uint32_t*)q->d_tbcrc, q->d_cb, cg);
+  LAUNCH_CHECK();
+  int r = srslte_hip_tcod_encode_bytes_batch(q->d_cb, (uint32_t)cg.cb_stride, q->d_parity, (uint32_t)cg.par_stride, q->d_sys_tail, (uint32_t)cg.K,
+                                             nof_sf * (uint32_t)cg.C, stream);
+  if (r) return r;
+  PdschTxGeom g = q->g;
+  g.tti0        = (int)tti0;
+  hipLaunchKernelGGL(pdsch_tx_mod_kernel, dim3(ceil_div(g.max_re / g.Nl, 256), nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
+                     (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, (const uint32_t*)q->d_rm[rv], (const uint32_t*)q->d_scr, q->d_y, g);
+  LAUNCH_CHECK();
+  hipLaunchKernelGGL(pdsch_tx_map_kernel, dim3(ceil_div(g.grid_len, 256), nof_sf * g.nof_ports), dim3(256), 0, st, (const cf32*)q->d_y,
+                     (const cf32*)srslte_hip_chest_dl_pilots(q->crs), q->d_grid, 8 * (int)q->cfg.nof_prb, g);
+  LAUNCH_CHECK();
+  return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf * g.nof_ports, stream);
 }

@@ -18,7 +18,7 @@ class DlConfig:
     """One PDSCH configuration: full-band grant, rv 0; nof_ports = 1: single antenna port (TM1),
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         self.Qm = MOD_BITS[mod]
         # bits per "symbol" in the code-block split of the rate matcher: Qm * N_L, N_L = 2 for transmit diversity (36.212 5.1.4.1.2;
@@ -27,6 +27,10 @@ class DlConfig:
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.nof_ports = nof_ports
+        # srslte_pdsch_cfg_t.power_scale / p_a (pdsch.c:518-554,:852-858; p_b chosen so that rho_b = 1, as phy_dl_test.c:176-178): the
+        # receiver divides by rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports); None = power_scale off
+        self.p_a = p_a
+        self.scaling = 1.0 if p_a is None else float(np.float32(10.0) ** np.float32(p_a / 20.0) * (np.float32(np.sqrt(np.float32(2.0))) if nof_ports == 2 else np.float32(1.0)))
         self.csi = csi  # srslte_pdsch_cfg_t.csi_enable: LLRs weighted by the channel gain (pdsch.c:574-690), the srsUE default
         self.cell = OrcCell(cell_id, nof_prb, nof_ports, True)
         self.nre = 12 * nof_prb
@@ -79,6 +83,8 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None, keep=Non
     q.normalize = True
     if cfg.nof_ports == 2:
         return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep), data
+    if cfg.scaling != 1.0:
+        syms = syms * np.float32(cfg.scaling)  # rho_a (pdsch.c:1100-1114,:1166-1170)
     if keep is not None:
         keep.update(y=[syms.copy()], idx=idx)
     grid = np.zeros(cfg.grid_len, np.complex64)
@@ -105,7 +111,7 @@ def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None
     orc = oracle()
     orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
     y = [np.zeros(len(idx), np.complex64), np.zeros(len(idx), np.complex64)]
-    orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), 1.0)
+    orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), cfg.scaling)  # rho_a with power allocation (pdsch.c:1100-1114), else 1
     if keep is not None:
         keep.update(y=[y[0].copy(), y[1].copy()], idx=idx)
     tx = []
@@ -196,11 +202,11 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None, harq=None, rv=0, new_data=
         yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (2 * nrx))(*[v.ctypes.data for v in hs])
         orc.orc_predecoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
         csi = np.zeros(len(idx), np.float32)
-        orc.orc_predecoding_diversity2(yp, hp, p(d), p(csi), nrx, len(idx), 1.0)
+        orc.orc_predecoding_diversity2(yp, hp, p(d), p(csi), nrx, len(idx), cfg.scaling)
     elif nrx == 1:
         assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid[0]), p(ce[0]), C.byref(res)) == 0
         y, h = np.ascontiguousarray(grid[0][idx]), np.ascontiguousarray(ce[0][idx])
-        orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), 1.0, res.noise_estimate)
+        orc.orc_predecoding_single(p(y), p(h), p(d), len(idx), cfg.scaling, res.noise_estimate)
         hs = [h]
         grid, ce = grid[0], ce[0]
     else:  # pdsch.c:890-935 with nof_rx_antennas > 1: srslte_predecoding_single_multi
@@ -209,7 +215,7 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None, harq=None, rv=0, new_data=
         ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
         yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * nrx)(*[v.ctypes.data for v in hs])
         orc.orc_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
-        orc.orc_predecoding_single_multi(yp, hp, p(d), nrx, len(idx), 1.0, res.noise_estimate)
+        orc.orc_predecoding_single_multi(yp, hp, p(d), nrx, len(idx), cfg.scaling, res.noise_estimate)
     if cfg.nof_ports == 1:
         csi = np.zeros(len(idx), np.float32)
         orc.orc_predecoding_csi.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
@@ -345,7 +351,7 @@ class RefPdsch:
         R = self.R = ref()
         self.cfg, self.aligned = cfg, aligned
         L = self.L = ref_layout({"srslte_pdsch_t": ["llr_is_8bit", "d", "e", "csi", "dl_sch"], "srslte_sch_t": ["llr_is_8bit"],
-                                 "srslte_pdsch_cfg_t": ["rnti", "max_nof_iterations", "decoder_type", "csi_enable", "softbuffers"],
+                                 "srslte_pdsch_cfg_t": ["rnti", "max_nof_iterations", "decoder_type", "csi_enable", "softbuffers", "p_a", "p_b", "power_scale"],
                                  "srslte_pdsch_grant_t": ["tx_scheme", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]}, ["srslte/phy/phch/pdsch.h"])
@@ -390,6 +396,10 @@ class RefPdsch:
         u32(L["srslte_pdsch_cfg_t.max_nof_iterations"], cfg.max_iter)
         u32(L["srslte_pdsch_cfg_t.decoder_type"], 1)  # SRSLTE_MIMO_DECODER_MMSE
         g[L["srslte_pdsch_cfg_t.csi_enable"]] = 1 if csi_enable else 0
+        if cfg.p_a is not None:
+            g[L["srslte_pdsch_cfg_t.power_scale"]] = 1
+            g[L["srslte_pdsch_cfg_t.p_a"]:L["srslte_pdsch_cfg_t.p_a"] + 4].view(np.float32)[0] = cfg.p_a
+            u32(L["srslte_pdsch_cfg_t.p_b"], 1 if cfg.nof_ports > 1 else 0)  # rho_b = 1 (phy_dl_test.c:178)
         g[L["srslte_pdsch_cfg_t.softbuffers"]:L["srslte_pdsch_cfg_t.softbuffers"] + 8].view(np.uint64)[0] = C.addressof(self.sb)
         self.u32 = u32
         self.ofdm = OrcOfdm()

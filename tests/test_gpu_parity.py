@@ -837,3 +837,91 @@ def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
     if prb == 100 and npt == 1:
         assert n_carried > 0
     rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,npt,tti0,nsf,rv,p_a", [(6, 1, 152, 1, 0, 10, 0, 0.0), (25, 2, 4008, 2, 8, 4, 0, 0.0), (100, 3, 75376, 1, 4, 3, 0, -3.0),
+                                                             (100, 3, 75376, 2, 9, 3, 2, 0.0), (50, 4, 48936, 1, 5, 2, 1, 0.0), (15, 1, 1000, 2, 0, 6, 3, 1.77)])
+def test_dl_tx_chain(hp, prb, mod, tbs, npt, tti0, nsf, rv, p_a):
+    """eNB PDSCH transmit chain on the device vs the oracle's stimulus generator (pinned to the reference's
+    srslte_pdsch_encode): per-port symbol streams exactly (bits exact, levels are table values), resource grids with CRS, time samples."""
+    from lte_sim import DlConfig, make_subframe
+    from _libs import OrcOfdm
+    rng = np.random.default_rng(2100 + prb + mod + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_ports=npt, p_a=p_a)  # rho_a = 10^(p_a/20), x sqrt(2) for a 2-port cell (pdsch.c:525)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(7, prb, 1, 0x1234, mod, tbs, nsf, npt, p_a)
+    iq = tx.encode(data, tti0, rv)
+    max_re = max(len(cfg.indices(s)) for s in (0, 1, 5))
+    y = tx.debug(2, np.complex64, nsf * npt * max_re).reshape(nsf, npt, -1)
+    grid = tx.debug(3, np.complex64, nsf * npt * cfg.grid_len).reshape(nsf, npt, -1)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    q.normalize = True
+    for b in range(nsf):
+        k = {}
+        make_subframe(cfg, tti0 + b, rng, rv=rv, data=data[b], keep=k)
+        for port in range(npt):
+            ye = k["y"][port]
+            assert np.abs(y[b, port, :len(ye)] - ye).max() <= 3e-7 * max(1.0, cfg.scaling), (b, port)
+            exp = np.zeros(cfg.grid_len, np.complex64)
+            exp[k["idx"]] = ye
+            oracle().orc_crs_put_sf(C.byref(cfg.cell), (tti0 + b) % 10, port, p(exp))
+            assert np.abs(grid[b, port] - exp).max() <= 3e-7 * max(1.0, cfg.scaling), (b, port)
+            iq_o = np.zeros(cfg.sf_len, np.complex64)
+            oracle().orc_ofdm_tx_sf(C.byref(q), p(exp), p(iq_o))
+            assert_close_c(iq[b, port], iq_o, "iq sf %d port %d" % (b, port))
+    tx.free()
+
+
+@pytest.mark.parametrize("npt,nrx", [(1, 1), (2, 1), (2, 2)])
+def test_dl_tx_rx_loop(hp, npt, nrx):
+    """Device transmit chain into the device receive chain (noise-free; the ports of a 2-port cell reach the antennas with different
+    flat gains): every transport block comes back; then the same blocks as a HARQ retransmission (rv 2) into the kept soft buffers."""
+    prb, mod, tbs, nsf = 50, 3, 36696, 12
+    rng = np.random.default_rng(78)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(5, prb, 1, 0x4321, mod, tbs, nsf, npt)
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(5, prb, 1, 0x4321, mod, tbs, 6, nsf, True, hc, nof_rx=nrx, nof_ports=npt, power_scale=True, p_a=0.0)  # phy_dl_test.c:176-178,:219-221
+    gains = np.array([[1.0, 0.7 * np.exp(1.1j)], [0.8 * np.exp(-0.6j), 0.9 * np.exp(2.2j)]], np.complex64)  # [antenna][port]
+    for rv, new in ((0, True), (2, False)):
+        iq = tx.encode(data, 3, rv)  # [nsf][npt][sf_len]
+        ant = np.stack([sum(gains[a, port] * iq[:, port] for port in range(npt)) for a in range(nrx)], axis=1)  # [nsf][nrx][sf_len]
+        tb, ok = rx.decode_harq(np.ascontiguousarray(ant, np.complex64), 3, rv, new)
+        assert ok.all() and np.array_equal(tb[:, :tbs // 8], data), rv
+    tx.free()
+    rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,p_a", [(25, 2, 4008, 1, 1, 9.0, -3.0), (25, 3, 9912, 2, 2, 13.5, 0.0), (100, 3, 75376, 1, 2, 19.5, 0.0)])
+def test_dl_rx_chain_power_scaling(hp, prb, mod, tbs, nrx, npt, snr, p_a):
+    """cfg.power_scale / p_a (pdsch.c:518-554,:852-858 with rho_b = 1) vs the oracle chain with the same setting (checked against the
+    reference's srslte_pdsch_decode): equalised symbols, LLRs, pass counts, CRC flags, TB bytes."""
+    from lte_sim import DlConfig, make_subframe, oracle_rx
+    rng = np.random.default_rng(2300 + prb + mod + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, p_a=p_a)
+    nsf, tti0 = 3, 4
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, nof_rx=nrx, nof_ports=npt, power_scale=True, p_a=p_a)
+    rx.keep_symbols()
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    it = rx.debug(6, np.uint32, nsf * cfg.seg.C).reshape(nsf, -1)
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    d_all = rx.debug(3, np.complex64, nsf * max_re).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        nre = rx.nof_re((tti0 + b) % 10)
+        assert_close_c(d_all[b, :nre], r["d"], "d sf %d" % b)
+        diff = np.abs(e_all[b, :nre * cfg.Qm].astype(np.int32) - r["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b], r["tb"]) and np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0
+    rx.free()

@@ -529,6 +529,27 @@ def test_whole_chain_tx_diversity_vs_reference_code(prb, mod, tbs, nrx, snr, llr
     assert nok > 0
 
 
+@pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,p_a", [(25, 2, 4008, 1, 1, 9.0, -3.0), (25, 3, 9912, 2, 2, 13.5, 0.0), (100, 3, 75376, 1, 2, 19.5, 0.0), (15, 1, 1000, 1, 2, 2.0, 1.77)])
+def test_pdsch_decode_power_scaling_vs_oracle_chain(prb, mod, tbs, nrx, npt, snr, p_a):
+    """cfg->power_scale with p_a (pdsch.c:518-554,:852-858; p_b such that rho_b = 1 as phy_dl_test.c:176-178): srslte_pdsch_decode divides
+    the equalised symbols by rho_a; the transmitter here scales its PDSCH symbols by the same rho_a (relative to the CRS)."""
+    from lte_sim import RefPdsch
+    rng = np.random.default_rng(900 + prb + mod + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, p_a=p_a)
+    chain = RefPdsch(cfg)
+    nok = 0
+    for t in (0, 4, 5):
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t, keep=True)
+        assert np.abs(r["d"] - o["d"]).max() <= (2e-6 if npt == 2 else 1e-3) * max(1.0, np.abs(o["d"]).max())
+        diff = np.abs(r["e"].astype(np.int32) - o["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 0.05 and r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        nok += r["ok"]
+    assert nok > 0
+
+
 @pytest.mark.parametrize("csi", [False, True])
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(6, 1, 152, 1, 1, 4.0, False), (15, 1, 1000, 1, 2, 2.0, False), (25, 2, 4008, 1, 1, 9.0, False),
                                                             (25, 3, 9912, 2, 2, 13.5, False), (100, 3, 75376, 1, 1, 18.0, False),
