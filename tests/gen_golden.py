@@ -265,7 +265,42 @@ def extra():
     print("ul_chain.npz", os.path.getsize(os.path.join(OUT, "ul_chain.npz")), "bytes")
 
 
+def pdsch_function():
+    """Outputs of the reference's OWN srslte_pdsch_decode (lte_sim.RefPdsch) for the options added after the first fixtures: 2-port
+    transmit diversity, CSI weighting of the LLRs, power scaling, HARQ retransmissions into a kept soft buffer. Small cells only."""
+    from lte_sim import DlConfig, RefPdsch, make_subframe
+    rng = np.random.default_rng(2026100401)
+    out = {}
+    cases = {"tm2": dict(prb=6, mod=2, tbs=936, nrx=2, npt=2, csi=True, p_a=None, llr8=False, snr=6.0, seq=((0, 4), (0, 5))),
+             "tm1": dict(prb=6, mod=1, tbs=152, nrx=1, npt=1, csi=True, p_a=-3.0, llr8=False, snr=3.0, seq=((0, 0), (0, 7))),
+             "harq": dict(prb=6, mod=3, tbs=1736, nrx=1, npt=2, csi=False, p_a=0.0, llr8=False, snr=2.0, seq=((0, 3), (2, 11), (3, 15))),
+             "b8": dict(prb=6, mod=2, tbs=936, nrx=1, npt=2, csi=True, p_a=None, llr8=True, snr=9.5, seq=((0, 2), (0, 5)))}
+    for tag, c in cases.items():
+        cfg = DlConfig(c["prb"], 7, c["mod"], c["tbs"], nof_rx=c["nrx"], nof_ports=c["npt"], llr8=c["llr8"], csi=c["csi"], p_a=c["p_a"])
+        chain = RefPdsch(cfg, csi_enable=c["csi"])
+        harq = tag == "harq"
+        data = None
+        for n, (rv, t) in enumerate(c["seq"]):
+            iq, data = make_subframe(cfg, t, rng, snr_db=c["snr"], amp=0.1, rv=rv, data=data if harq else None)
+            r = chain.run(iq, t, rv=rv, new_data=(n == 0 or not harq))
+            out["%s_iq_%d" % (tag, n)] = np.ascontiguousarray(iq, np.complex64)
+            out["%s_e_%d" % (tag, n)] = r["e"].copy()        # LLRs after descrambling and CSI weighting, as handed to srslte_dlsch_decode2
+            out["%s_ok_%d" % (tag, n)] = np.array([r["ok"]], np.uint8)
+            out["%s_tb_%d" % (tag, n)] = r["tb"].copy() if r["ok"] else np.zeros(0, np.uint8)
+            out["%s_data_%d" % (tag, n)] = data
+        out["%s_meta" % tag] = np.array([c["prb"], c["mod"], c["tbs"], c["nrx"], c["npt"], int(c["csi"]), int(c["llr8"]), int(harq)], np.int32)
+        out["%s_pa" % tag] = np.array([np.nan if c["p_a"] is None else c["p_a"]], np.float32)
+        out["%s_seq" % tag] = np.array(c["seq"], np.int32)
+        print(tag, [int(out["%s_ok_%d" % (tag, n)][0]) for n in range(len(c["seq"]))])
+    np.savez_compressed(os.path.join(OUT, "pdsch_function.npz"), **out)
+    print("pdsch_function.npz", os.path.getsize(os.path.join(OUT, "pdsch_function.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if "--pdsch-only" in sys.argv:
+        pdsch_function()
+        sys.exit(0)
     if "--extra-only" not in sys.argv:
         main()
     extra()
+    pdsch_function()

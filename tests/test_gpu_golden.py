@@ -152,3 +152,23 @@ def test_ul_chain_golden(hp):
             assert ok[0] == 1 and np.array_equal(tb[0], g["%s_tb_%d" % (tag, t)])
             assert np.array_equal(rx.debug(6, np.uint32, seg.C), g["%s_iters_%d" % (tag, t)])
         rx.free()
+
+
+@pytest.mark.parametrize("tag", ["tm2", "tm1", "harq", "b8"])
+def test_pdsch_function_golden(hp, tag):
+    """Device pipeline vs outputs of the reference's own srslte_pdsch_decode (tests/gen_golden.py:pdsch_function): 2-port transmit
+    diversity, CSI weighting, power scaling, HARQ soft combining into kept soft buffers, 8-bit LLRs: CRC result and transport block
+    of every transmission."""
+    g = load("pdsch_function.npz")
+    prb, mod, tbs, nrx, npt, csi, llr8, harq = [int(v) for v in g[tag + "_meta"]]
+    p_a = g[tag + "_pa"][0]
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, 1, True, hc, llr_8bit=bool(llr8), nof_rx=nrx, nof_ports=npt, csi=bool(csi),
+                 power_scale=not np.isnan(p_a), p_a=0.0 if np.isnan(p_a) else float(p_a))
+    for n, (rv, t) in enumerate(g[tag + "_seq"]):
+        tb, ok = rx.decode_harq(g["%s_iq_%d" % (tag, n)][None], int(t), int(rv), n == 0 or not harq)
+        assert bool(ok[0]) == bool(g["%s_ok_%d" % (tag, n)][0]), n
+        if ok[0]:
+            assert np.array_equal(tb[0], g["%s_tb_%d" % (tag, n)]) and np.array_equal(tb[0][:tbs // 8], g["%s_data_%d" % (tag, n)])
+    rx.free()
