@@ -92,8 +92,9 @@ int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hi
  * entry per subframe. Ports 2 and 3 of a 4-port cell are not implemented (create refuses nof_ports > 2). */
 int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                              void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream);
-/* device pointer to [nof_sf][nof_ports][nof_rx] x {noise_estimate, rsrp, rssi, cfo} of the last call with more than one (port,
- * antenna): the per-antenna / per-port terms of fill_res (chest_dl.c:860-870) */
+/* device pointer to [nof_sf][nof_ports][nof_rx] x {noise_estimate, rsrp, rssi, cfo, sync_err, rsrp_corr} (6 floats) of the last call
+ * with more than one (port, antenna) or cfg.rsrp_neighbour: the per-antenna / per-port terms of fill_res (chest_dl.c:860-870) and of
+ * get_rsrp_neighbour (:821-843) */
 const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
 
 /* ------------------------------------------------------------------ UL channel estimator (replaces

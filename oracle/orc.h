@@ -118,7 +118,7 @@ typedef struct {
   bool  rsrp_neighbour, cfo_estimate_enable, sync_error_enable;
 } orc_chest_cfg_t;
 typedef struct {
-  float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
+  float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error, rsrp_neigh;
 } orc_chest_res_t;
 /* single rx antenna, single port (port 0) — chest_dl.c:598-716, 845-908 */
 int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce,

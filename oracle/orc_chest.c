@@ -97,7 +97,7 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
 /* estimate_port for port 0 or 1 of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo} of that (antenna, port).
    Ports 2 and 3 (two pilot symbols per subframe, different time interpolation) are not restated. */
 static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, uint32_t port,
-                      float raw[4])
+                      float raw[6])
 {
   const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
@@ -124,6 +124,27 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   }
   rssi /= nsym;
 
+  float sync = NAN; /* chest_dl.c:692-703 with srslte_vec_estimate_frequency (vector_simd.c:1606-1656; its SIMD body multiplies by an approximate reciprocal) */
+  if (cfg->sync_error_enable) {
+    float k = (float)orc_symbol_sz((int)P) / 6.0f, sum = 0.0f;
+    for (uint32_t l = 0; l < nsym; l++) {
+      const cf* x = &est[l * nref];
+      float     ss = 0.0f;
+      for (uint32_t i = 1; i < nref; i++) {
+        float pw = sqrtf((x[i].re * x[i].re + x[i].im * x[i].im) * (x[i - 1].re * x[i - 1].re + x[i - 1].im * x[i - 1].im));
+        ss += (x[i].re * x[i - 1].im - x[i - 1].re * x[i].im) / pw;
+      }
+      sum += asinf(ss / (float)(nref - 1)) / (2.0f * (float)M_PI) * k;
+    }
+    sync = sum / nsym;
+  }
+  float corr = 0; /* chest_dl.c:706-709 */
+  if (cfg->rsrp_neighbour) {
+    cf acc = {0, 0};
+    for (uint32_t i = 0; i < npil; i++) acc = c_add(acc, est[i]);
+    double energy = sqrt((double)(acc.re / npil) * (acc.re / npil) + (double)(acc.im / npil) * (acc.im / npil));
+    corr = (float)(energy * energy);
+  }
   float cfo = 0;
   if (cfg->cfo_estimate_enable) { /* chest_dl.c:573-596 */
     float n = (float)orc_symbol_sz((int)P), ns = 7.0f, ng = (float)orc_cp_len_norm(1, (int)n);
@@ -213,12 +234,12 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
     }
   }
 
-  raw[0] = noise; raw[1] = rsrp; raw[2] = rssi; raw[3] = cfo;
+  raw[0] = noise; raw[1] = rsrp; raw[2] = rssi; raw[3] = cfo; raw[4] = sync; raw[5] = corr;
   free(known); free(recv); free(est); free(avg); free(tmp);
   return 0;
 }
 
-static void fill_res(uint32_t P, uint32_t nof_rx, uint32_t nof_ports, float raw[4][4][4] /* [antenna][port] */, bool cfo_enable, orc_chest_res_t* res)
+static void fill_res(uint32_t P, uint32_t nof_rx, uint32_t nof_ports, float raw[4][4][6] /* [antenna][port] */, bool cfo_enable, orc_chest_res_t* res)
 { /* chest_dl.c:747-871: noise is averaged over ports and antennas; RSSI and RSRQ use port 0 and are averaged over the antennas;
      get_rsrp (:809-819) takes the maximum over "ports" indexed by the ANTENNA counter of the antenna-mean RSRP of that port (0 for a
      port that was never estimated); q->cfo is overwritten by every (antenna, port) estimate in turn, so the last one survives */
@@ -250,13 +271,21 @@ static void fill_res(uint32_t P, uint32_t nof_rx, uint32_t nof_ports, float raw[
   res->rsrq_db            = (float)(10 * log10(rsrq));
   res->snr_db             = (float)(10 * log10(rsrp / noise));
   res->rssi_dbm           = (float)(10 * log10(rssi) + 30);
-  res->sync_error         = NAN;
+  res->sync_error         = raw[0][0][4]; /* "Take only the channel used for synch" (chest_dl.c:859) */
+  float neigh = -1e9f;                    /* get_rsrp_neighbour (chest_dl.c:821-843): max over antennas of the port-mean correlation power */
+  for (uint32_t i = 0; i < nof_rx; i++) {
+    float v = 0;
+    for (uint32_t j = 0; j < nof_ports; j++) v += raw[i][j][5];
+    v /= nof_ports;
+    if (v > neigh) neigh = v;
+  }
+  res->rsrp_neigh = neigh;
 }
 
 int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce /* [port * nof_rx + antenna] */, orc_chest_res_t* res, float* raw_out /* [antenna][port][4] or NULL */)
 { /* srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for cell->nof_ports in {1, 2} and nof_rx receive antennas */
-  float raw[4][4][4];
+  float raw[4][4][6];
   memset(raw, 0, sizeof(raw));
   if (nof_rx < 1 || nof_rx > 4 || cell->nof_ports < 1 || cell->nof_ports > 2) return -1;
   for (uint32_t a = 0; a < nof_rx; a++) {

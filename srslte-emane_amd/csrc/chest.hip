@@ -19,13 +19,13 @@ constexpr int CH_THREADS = 256;
 
 struct ChestParams {
   int   cell_id, nof_prb, tti0;
-  int   noise_alg, filter_type, interpolate_subframe, cfo_enable;
+  int   noise_alg, filter_type, interpolate_subframe, cfo_enable, sync_enable, corr_enable;
   float coef0, coef1;
   int   symbol_sz, cp1; // for CFO
   int   nof_rx;         // receive antennas, tx ports: block v = (sf * nof_ports + port) * nof_rx + antenna reads grid [sf][antenna]
   int   nof_ports;      // and writes ce [sf][port][antenna]
 };
-struct ChestRaw { float noise, rsrp, rssi, cfo; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
+struct ChestRaw { float noise, rsrp, rssi, cfo, sync, corr; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
 
 struct ChestResDev { // mirrors the scalar tail of srslte_chest_dl_res_t (chest_dl.h:49-67) for 1 port / 1 antenna
   float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
@@ -120,6 +120,35 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   }
   const float rssi = block_sum(acc, red) / 4.0f;
 
+  // ---- synchronisation error (chest_dl.c:692-703; srslte_vec_estimate_frequency, vector_simd.c:1606-1656, with exact divisions)
+  float sync = NAN;
+  if (p.sync_enable) {
+    float sum = 0.f;
+    for (int l = 0; l < 4; l++) {
+      const cf32* x = est + l * nref;
+      float       ss = 0.f;
+      for (int i = 1 + tid; i < nref; i += CH_THREADS) {
+        const cf32 a = x[i], b = x[i - 1];
+        ss += (a.x * b.y - b.x * a.y) / sqrtf((a.x * a.x + a.y * a.y) * (b.x * b.x + b.y * b.y));
+      }
+      ss = block_sum(ss, red);
+      sum += asinf(ss / (float)(nref - 1)) / (2.0f * (float)M_PI) * ((float)p.symbol_sz / 6.0f);
+    }
+    sync = sum / 4.0f;
+  }
+  // ---- power of the coherent pilot mean, for neighbour-cell RSRP (chest_dl.c:706-709)
+  float corr = 0.f;
+  if (p.corr_enable) {
+    float sr = 0.f, si = 0.f;
+    for (int i = tid; i < npil; i += CH_THREADS) {
+      sr += est[i].x;
+      si += est[i].y;
+    }
+    sr = block_sum(sr, red) / npil;
+    si = block_sum(si, red) / npil;
+    const double energy = sqrt((double)sr * sr + (double)si * si);
+    corr                = (float)(energy * energy);
+  }
   float cfo = 0;
   if (p.cfo_enable) { // chest_dl.c:573-596
     float sr = 0, si = 0;
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     }
   }
 
-  if (tid == 0 && raw) raw[sf] = ChestRaw{noise, rsrp, rssi, cfo};
+  if (tid == 0 && raw) raw[sf] = ChestRaw{noise, rsrp, rssi, cfo, sync, corr};
   if (tid == 0 && res && p.nof_rx * p.nof_ports == 1) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
     ChestResDev r;
     r.noise_estimate     = noise;
@@ -251,7 +280,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     r.rsrq_db            = (float)(10 * log10((double)r.rsrq));
     r.snr_db             = (float)(10 * log10((double)(rsrp / noise)));
     r.rssi_dbm           = (float)(10 * log10((double)(4 * rssi / P / 12)) + 30);
-    r.sync_error         = NAN;
+    r.sync_error         = sync;
     res[sf]              = r;
   }
 }
@@ -292,7 +321,7 @@ __global__ void chest_fill_res_kernel(const ChestRaw* __restrict__ raw, ChestRes
   o.rsrq_db            = (float)(10 * log10((double)rsrq));
   o.snr_db             = (float)(10 * log10((double)(rsrp / noise)));
   o.rssi_dbm           = (float)(10 * log10((double)rssi) + 30);
-  o.sync_error         = NAN;
+  o.sync_error         = r[0].sync; // "Take only the channel used for synch" (chest_dl.c:859)
   res[sf]              = o;
 }
 
@@ -387,6 +416,8 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;
   p.noise_alg = cfg->noise_alg; p.filter_type = cfg->filter_type; p.interpolate_subframe = cfg->interpolate_subframe ? 1 : 0;
   p.cfo_enable = cfg->cfo_estimate_enable ? 1 : 0;
+  p.sync_enable = cfg->sync_error_enable ? 1 : 0;
+  p.corr_enable = cfg->rsrp_neighbour ? 1 : 0;
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
   p.symbol_sz = lte_symbol_sz(q->nof_prb);
   p.cp1 = lte_cp_len_norm(1, p.symbol_sz);
@@ -394,7 +425,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.nof_ports = q->nof_ports;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
-  if (nslice > 1 && d_res) {
+  if ((nslice > 1 || cfg->rsrp_neighbour) && d_res) {
     const size_t need = (size_t)nof_sf * nslice;
     if (need > q->raw_cap) {
       if (q->d_raw) (void)hipFree(q->d_raw);
@@ -409,7 +440,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf * nslice), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
                      (ChestResDev*)d_res, raw, (const cf32*)q->d_pilots, p);
   LAUNCH_CHECK();
-  if (raw) {
+  if (raw && nslice > 1) {
     hipLaunchKernelGGL(chest_fill_res_kernel, dim3((nof_sf + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ChestRaw*)raw,
                        (ChestResDev*)d_res, nof_sf, nof_rx, q->nof_ports, q->nof_prb);
     LAUNCH_CHECK();
@@ -417,7 +448,8 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   return SRSLTE_SUCCESS;
 }
 
-// [nof_sf][nof_ports][nof_rx] x {noise, rsrp, rssi, cfo} of the last multi-antenna / multi-port call with d_res != NULL (device memory owned by q): what
+// [nof_sf][nof_ports][nof_rx] x {noise, rsrp, rssi, cfo, sync, corr} of the last call with d_res != NULL and more than one (port,
+// antenna) or cfg.rsrp_neighbour (device memory owned by q): what
 // the per-antenna fields of srslte_chest_dl_res_t are made of (chest_dl.c:860-870)
 extern "C" const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q) { return q ? (const float*)q->d_raw : nullptr; }
 

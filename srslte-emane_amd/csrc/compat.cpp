@@ -952,18 +952,33 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   }
   // fill_res, chest_dl.c:845-871
   if (hc.cfo_estimate_enable) q->cfo = r.cfo;
-  q->sync_err[0][0]   = NAN;
+  q->sync_err[0][0]   = r.sync_error;
   res->noise_estimate = r.noise_estimate; res->noise_estimate_dbm = r.noise_estimate_dbm; res->snr_db = r.snr_db;
   res->rsrp = r.rsrp; res->rsrp_dbm = r.rsrp_dbm; res->rsrq = r.rsrq; res->rsrq_db = r.rsrq_db; res->rssi_dbm = r.rssi_dbm;
-  res->cfo = q->cfo; res->sync_error = NAN; res->rsrp_neigh = 0.f;
+  res->cfo = q->cfo; res->sync_error = r.sync_error;
+  float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}
+  if ((nrx * npt > 1 || hc.rsrp_neighbour) && !d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 6 * nrx * npt)) return SRSLTE_ERROR;
+  if (hc.rsrp_neighbour) {
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      for (uint32_t a = 0; a < nrx; a++) q->rsrp_corr[a][pt] = raw[pt * nrx + a][5];
+    }
+  }
+  { // get_rsrp_neighbour (chest_dl.c:821-843): max over antennas of the port-mean of q->rsrp_corr (which keeps its last enabled values)
+    float mx = -1e9f;
+    for (uint32_t a = 0; a < nrx; a++) {
+      float v = 0.f;
+      for (uint32_t pt = 0; pt < npt; pt++) v += q->rsrp_corr[a][pt];
+      v /= npt;
+      mx = v > mx ? v : mx;
+    }
+    res->rsrp_neigh = mx;
+  }
   if (nrx * npt == 1) {
     q->noise_estimate[0][0] = r.noise_estimate;
     q->rsrp[0][0]           = r.rsrp;
     res->rsrp_port_dbm[0] = r.rsrp_dbm; res->snr_ant_port_db[0][0] = r.snr_db; res->rsrp_ant_port_dbm[0][0] = r.rsrp_dbm;
     res->rsrq_ant_port_db[0][0] = r.rsrq_db;
   } else { // per-antenna / per-port fields (chest_dl.c:860-870) from the per-(port, antenna) scalars the device kept
-    float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][4]; // [port][antenna]
-    if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 4 * nrx * npt)) return SRSLTE_ERROR;
     for (uint32_t pt = 0; pt < npt; pt++) {
       float mean_rsrp = 0.f;
       for (uint32_t a = 0; a < nrx; a++) {

@@ -91,7 +91,7 @@ class OrcChestCfg(C.Structure):
 
 class OrcChestRes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db",
-                                         "rssi_dbm", "cfo", "sync_error")]
+                                         "rssi_dbm", "cfo", "sync_error", "rsrp_neigh")]
 
 
 class OrcOfdm(C.Structure):

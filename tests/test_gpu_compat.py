@@ -362,7 +362,8 @@ def test_chest_dl_object_two_ports(prb, cid, nrx):
     est, last_cfo = opaque(1 << 16), 0.0
     assert L.srslte_chest_dl_init(est, prb, nrx) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 2, cid, 0, 0, 0, 0)) == 0
     for sf_idx, kw in ((0, {}), (3, {"interpolate_subframe": True, "filter_coef": (4.0, 2.0), "cfo_estimate_enable": True}),
-                       (5, {"filter_coef": (4.0, 1.0)}), (8, {"filter_type": 1, "filter_coef": (0.1, 0.0)}), (9, {"filter_type": 2})):
+                       (5, {"filter_coef": (4.0, 1.0)}), (8, {"filter_type": 1, "filter_coef": (0.1, 0.0)}), (9, {"filter_type": 2}),
+                       (7, {"filter_coef": (4.0, 1.0), "sync_error_enable": True, "rsrp_neighbour": True})):
         k, l = np.arange(n) % nre, np.arange(n) // nre
         tx = []
         for port in range(2):
@@ -405,6 +406,11 @@ def test_chest_dl_object_two_ports(prb, cid, nrx):
         if kw.get("cfo_estimate_enable"):
             last_cfo = ores.cfo
         assert abs(res.cfo - last_cfo) <= 1e-4 * abs(last_cfo) + 1e-6  # q->cfo keeps the last enabled estimate (chest_dl.c:612-614,:849)
+        if kw.get("sync_error_enable"):  # chest_dl.c:692-703,:859 and get_rsrp_neighbour :821-843
+            assert abs(res.sync_error - ores.sync_error) <= 1e-4 * abs(ores.sync_error) + 1e-5, (res.sync_error, ores.sync_error)
+            assert abs(res.rsrp_neigh - ores.rsrp_neigh) <= 1e-4 * abs(ores.rsrp_neigh) + 1e-9, (res.rsrp_neigh, ores.rsrp_neigh)
+        else:
+            assert np.isnan(res.sync_error)
         raw = raw.reshape(nrx, 2, 4)
         for port in range(2):
             assert abs(res.rsrp_port_dbm[port] - (10 * np.log10(raw[:, port, 1].mean()) + 30)) < 1e-3
@@ -416,3 +422,34 @@ def test_chest_dl_object_two_ports(prb, cid, nrx):
     bad = opaque(1 << 16)
     assert L.srslte_chest_dl_init(bad, 25, 1) == 0
     assert L.srslte_chest_dl_set_cell(bad, RefCell(25, 4, 1, 0, 0, 0, 0)) != 0  # ports 2/3 of a 4-port cell are not implemented: refused, not mis-estimated
+
+
+def test_chest_dl_object_sync_error_and_neighbour_rsrp():
+    """Single port, single antenna: cfg.sync_error_enable (mean normalised phase slope of the pilot estimates, chest_dl.c:692-703) and
+    cfg.rsrp_neighbour (power of the coherent pilot mean, :706-709,:821-843) through the compat API, on a grid with a timing offset."""
+    L, rng = hip(), np.random.default_rng(91)
+    prb, cid = 50, 33
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    for sf_idx, delay in ((1, 0.0), (6, 3.5), (9, -2.25)):
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        k = np.arange(n) % nre
+        grid = acopy((g * 1.3 * np.exp(-2j * np.pi * k * delay / 768.0) + 0.03 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        sf, rc, oc = RefDlSfCfg(), RefChestCfg(), OrcChestCfg()
+        sf.tti = sf_idx
+        rc.filter_coef[0], rc.filter_coef[1], oc.filter_coef[0], oc.filter_coef[1] = 4.0, 1.0, 4.0, 1.0
+        rc.sync_error_enable = oc.sync_error_enable = True
+        rc.rsrp_neighbour = oc.rsrp_neighbour = True
+        inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+        assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+        ref, rres = np.zeros(n, np.complex64), OrcChestRes()
+        assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ref), C.byref(rres)) == 0
+        assert abs(res.sync_error - rres.sync_error) <= 1e-4 * abs(rres.sync_error) + 1e-5, (res.sync_error, rres.sync_error)
+        assert abs(res.rsrp_neigh - rres.rsrp_neigh) <= 1e-4 * abs(rres.rsrp_neigh) + 1e-9
+        assert abs(rres.sync_error - delay) < 0.05  # timing error in samples
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)

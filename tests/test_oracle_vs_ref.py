@@ -200,7 +200,19 @@ def test_modem_vs_ref(mod):
 
 
 CHEST_CFGS = [{}, {"filter_coef": (4.0, 1.0)}, {"interpolate_subframe": True, "filter_coef": (4.0, 2.0), "cfo_estimate_enable": True},
-              {"interpolate_subframe": True, "filter_type": 2}, {"filter_type": 1, "filter_coef": (0.1, 0.0)}, {"filter_type": 2}]
+              {"interpolate_subframe": True, "filter_type": 2}, {"filter_type": 1, "filter_coef": (0.1, 0.0)}, {"filter_type": 2},
+              {"filter_coef": (4.0, 1.0), "sync_error_enable": True, "rsrp_neighbour": True}]
+
+
+def check_sync_and_neighbour(res, ores, kw):
+    """sync_error (chest_dl.c:692-703; srslte_vec_estimate_frequency's SIMD body multiplies by an approximate reciprocal, so 1e-3) and
+    rsrp_neigh (:706-709,:821-843), when the configuration enables them."""
+    if kw.get("sync_error_enable"):
+        assert abs(res.sync_error - ores.sync_error) <= 2e-3 * abs(ores.sync_error) + 1e-4, (res.sync_error, ores.sync_error)
+    else:
+        assert np.isnan(res.sync_error) and np.isnan(ores.sync_error)
+    if kw.get("rsrp_neighbour"):
+        assert abs(res.rsrp_neigh - ores.rsrp_neigh) <= 1e-4 * abs(ores.rsrp_neigh) + 1e-9, (res.rsrp_neigh, ores.rsrp_neigh)
 
 
 @pytest.mark.parametrize("prb,cid", [(6, 1), (6, 0), (25, 2), (50, 3), (100, 1), (100, 4), (100, 5), (15, 150)])
@@ -238,6 +250,7 @@ def test_chest_dl_vs_ref(prb, cid):
             for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo"):
                 x, y = getattr(res, nm), getattr(ores, nm)
                 assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+            check_sync_and_neighbour(res, ores, kw)
             R.srslte_chest_dl_free(q)
 
 
@@ -293,7 +306,7 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
     nre, n = 12 * prb, 14 * 12 * prb
     cell = OrcCell(cid, prb, 2, True)
     oracle().orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2]), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3]), (4, CHEST_CFGS[4])):
+    for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2]), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3]), (4, CHEST_CFGS[4]), (7, CHEST_CFGS[6])):
         k, l = np.arange(n) % nre, np.arange(n) // nre
         tx = []
         for port in range(2):  # each port: its own CRS (zeros at the other port's positions) and some data
@@ -342,6 +355,7 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
         for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm", "cfo"):
             x, y = getattr(res, nm), getattr(ores, nm)
             assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y, sf_idx)
+        check_sync_and_neighbour(res, ores, kw)
         raw = raw.reshape(nrx, 2, 4)
         for port in range(2):  # per-port fields of fill_res (chest_dl.c:860-870) from the per-(antenna, port) scalars
             assert abs(res.rsrp_port_dbm[port] - (10 * np.log10(raw[:, port, 1].mean()) + 30)) <= 1e-3
