@@ -125,7 +125,7 @@ int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t*
                  orc_chest_res_t* res);
 int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res); /* nof_rx receive antennas, one port */
-/* cell->nof_ports in {1, 2} tx ports x nof_rx antennas: ce[port * nof_rx + antenna]; raw_out [antenna][port]{noise, rsrp, rssi, cfo} */
+/* cell->nof_ports in {1, 2, 4} tx ports x nof_rx antennas (4 ports: not with interpolate_subframe, returns -3): ce[port * nof_rx + antenna]; raw_out [antenna][port]{noise, rsrp, rssi, cfo} */
 int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res, float* raw_out);
 

@@ -94,18 +94,21 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
   free(diff);
 }
 
-/* estimate_port for port 0 or 1 of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo} of that (antenna, port).
-   Ports 2 and 3 (two pilot symbols per subframe, different time interpolation) are not restated. */
+/* estimate_port for one port of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo, sync, corr} of that
+   (antenna, port). Ports 0/1 have 4 pilot symbols per subframe, ports 2/3 two (symbols 1 and 8). est is the estimator's
+   q->pilot_estimates, [4][2 nof_prb], SHARED by the ports of an antenna as upstream: chest_estimate_cfo (:573-596) always pairs its
+   first and second half, so for ports 2/3 it multiplies their two symbols with what port 1 left in the second half.
+   interpolate_subframe with ports 2/3 is refused: upstream then copies the never-written symbol 0 of ce over the subframe (:467-471). */
 static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, uint32_t port,
-                      float raw[6])
+                      cf* est, float raw[6])
 {
-  const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = 4, nref = 2 * P, npil = nsym * nref;
+  const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = port < 2 ? 4 : 2, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
-  if (!cell->cp_norm || port > 1) return -1; /* extended CP time interpolation not restated */
-  cf* known = malloc(sizeof(cf) * npil);
-  cf* recv  = malloc(sizeof(cf) * npil);
-  cf* est   = malloc(sizeof(cf) * npil);
-  cf* avg   = malloc(sizeof(cf) * npil);
+  if (!cell->cp_norm || port > 3) return -1; /* extended CP time interpolation not restated */
+  if (port > 1 && ce && cfg->interpolate_subframe) return -3;
+  cf* known = malloc(sizeof(cf) * 4 * nref);
+  cf* recv  = malloc(sizeof(cf) * 4 * nref);
+  cf* avg   = malloc(sizeof(cf) * 4 * nref);
   cf* tmp   = malloc(sizeof(cf) * 3 * (nref + 2));
   orc_crs_pilots(cell, sf_idx, port, known);
 
@@ -149,8 +152,8 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   if (cfg->cfo_estimate_enable) { /* chest_dl.c:573-596 */
     float n = (float)orc_symbol_sz((int)P), ns = 7.0f, ng = (float)orc_cp_len_norm(1, (int)n);
     cf    sum = {0, 0};
-    for (uint32_t i = 0; i < 2; i++) {
-      for (uint32_t k = 0; k < npil / 4; k++) sum = c_add(sum, c_mulconj(est[i * npil / 4 + k], est[(i + 2) * npil / 4 + k]));
+    for (uint32_t i = 0; i < 2; i++) { /* npilots is port 0's whatever the port (:582) */
+      for (uint32_t k = 0; k < nref; k++) sum = c_add(sum, c_mulconj(est[i * nref + k], est[(i + 2) * nref + k]));
     }
     cfo = (float)(-atan2f(sum.im, sum.re) * n / (ns * (n + ng)) / 2 / M_PI);
   }
@@ -161,11 +164,16 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
     uint32_t fidx0 = orc_crs_fidx(cell, 0, port);
     cf*      in2d[6];
     for (uint32_t i = 0; i < nsym; i++) in2d[i + 1] = &est[i * nref];
-    in2d[0] = &tmp[nref];
-    in2d[5] = &tmp[2 * nref];
+    in2d[0]        = &tmp[nref];
+    in2d[nsym + 1] = &tmp[2 * nref];
     for (uint32_t k = 0; k < nref; k++) {
-      in2d[0][k] = c_sub(c_scale(in2d[2][k], 2.0f), in2d[4][k]);
-      in2d[5][k] = c_sub(c_scale(in2d[3][k], 2.0f), in2d[1][k]);
+      if (nsym > 3) { /* virtual rows before the first and after the last pilot symbol: linear extrapolation (:337-350) */
+        in2d[0][k]        = c_sub(c_scale(in2d[2][k], 2.0f), in2d[4][k]);
+        in2d[nsym + 1][k] = c_sub(c_scale(in2d[nsym - 1][k], 2.0f), in2d[nsym - 3][k]);
+      } else { /* two symbols: copies of the other row */
+        in2d[0][k]        = in2d[2][k];
+        in2d[nsym + 1][k] = in2d[nsym - 1][k];
+      }
     }
     float sum_power = 0;
     int   count     = 0;
@@ -204,7 +212,11 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
       if (!cfg->interpolate_subframe) {
         bool first_low = orc_crs_fidx(cell, 0, port) < 3;
         for (uint32_t k = 0; k < nref; k++) {
-          cf a = c_add(est[k], est[2 * nref + k]), b = c_add(est[nref + k], est[3 * nref + k]);
+          cf a = est[k], b = est[nref + k];
+          if (nsym == 4) {
+            a = c_add(a, est[2 * nref + k]);
+            b = c_add(b, est[3 * nref + k]);
+          }
           avg[2 * k]     = first_low ? a : b;
           avg[2 * k + 1] = first_low ? b : a;
         }
@@ -235,7 +247,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   }
 
   raw[0] = noise; raw[1] = rsrp; raw[2] = rssi; raw[3] = cfo; raw[4] = sync; raw[5] = corr;
-  free(known); free(recv); free(est); free(avg); free(tmp);
+  free(known); free(recv); free(avg); free(tmp);
   return 0;
 }
 
@@ -287,13 +299,18 @@ int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_
 { /* srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for cell->nof_ports in {1, 2} and nof_rx receive antennas */
   float raw[4][4][6];
   memset(raw, 0, sizeof(raw));
-  if (nof_rx < 1 || nof_rx > 4 || cell->nof_ports < 1 || cell->nof_ports > 2) return -1;
+  if (nof_rx < 1 || nof_rx > 4 || (cell->nof_ports != 1 && cell->nof_ports != 2 && cell->nof_ports != 4)) return -1;
+  cf* est = calloc(8 * cell->nof_prb, sizeof(cf)); /* q->pilot_estimates */
   for (uint32_t a = 0; a < nof_rx; a++) {
     for (uint32_t p = 0; p < cell->nof_ports; p++) {
-      int r = chest_port(cell, sf_idx, cfg, grid[a], ce ? ce[p * nof_rx + a] : NULL, p, raw[a][p]);
-      if (r) return r;
+      int r = chest_port(cell, sf_idx, cfg, grid[a], ce ? ce[p * nof_rx + a] : NULL, p, est, raw[a][p]);
+      if (r) {
+        free(est);
+        return r;
+      }
     }
   }
+  free(est);
   if (res) fill_res(cell->nof_prb, nof_rx, cell->nof_ports, raw, cfg->cfo_estimate_enable, res);
   if (raw_out) {
     for (uint32_t a = 0; a < nof_rx; a++) {

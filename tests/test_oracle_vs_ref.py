@@ -297,35 +297,42 @@ def test_chest_dl_two_rx_antennas_vs_ref(prb, cid):
         R.srslte_chest_dl_free(q)
 
 
-@pytest.mark.parametrize("prb,cid,nrx", [(6, 0, 1), (25, 7, 1), (100, 301, 1), (50, 4, 2), (100, 149, 2)])
-def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
+@pytest.mark.parametrize("prb,cid,nrx,npt", [(6, 0, 1, 2), (25, 7, 1, 2), (100, 301, 1, 2), (50, 4, 2, 2), (100, 149, 2, 2),
+                                             (6, 2, 1, 4), (25, 7, 1, 4), (100, 301, 1, 4), (50, 5, 2, 4), (15, 148, 2, 4)])
+def test_chest_dl_two_ports_vs_ref(prb, cid, nrx, npt):
     """srslte_chest_dl_estimate_cfg for a 2-port cell (ports 0/1 share the pilot values, refsignal_dl.c pilots[port / 2], at v-shifted
     positions) with 1 and 2 receive antennas: every ce[port][antenna], the aggregated scalars incl. the port-by-antenna-index quirk
-    of get_rsrp and the last-estimate-wins CFO."""
+    of get_rsrp and the last-estimate-wins CFO. 4-port cells add ports 2/3 (two pilot symbols, 1 and 8):
+    the two-row noise estimate, no time-averaging partner, and a CFO that pairs port 3's symbols with what port 1 left in the shared
+    pilot buffer; interpolate_subframe is left out for them (upstream replicates a never-written symbol)."""
     R, rng = ref(), np.random.default_rng(3000 + prb + cid + nrx)
     nre, n = 12 * prb, 14 * 12 * prb
-    cell = OrcCell(cid, prb, 2, True)
+    cell = OrcCell(cid, prb, npt, True)
     oracle().orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-    for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2]), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3]), (4, CHEST_CFGS[4]), (7, CHEST_CFGS[6])):
+    cfo_cfg = {"filter_coef": (4.0, 2.0), "cfo_estimate_enable": True}
+    for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2] if npt == 2 else cfo_cfg), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3] if npt == 2 else CHEST_CFGS[5]),
+                       (4, CHEST_CFGS[4]), (7, CHEST_CFGS[6])):
         k, l = np.arange(n) % nre, np.arange(n) // nre
         tx = []
-        for port in range(2):  # each port: its own CRS (zeros at the other port's positions) and some data
+        for port in range(npt):  # each port: its own CRS (zeros at the other ports' positions) and some data
             g = np.zeros(n, np.complex64)
             oracle().orc_crs_put_sf(C.byref(cell), sf_idx, port, p(g))
             tx.append(g)
-        hole = (tx[0] != 0) | (tx[1] != 0)
+        hole = np.zeros(n, bool)
+        for g in tx:
+            hole |= g != 0
         data = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
         grids = []
         for a_ in range(nrx):
             rxg = np.where(hole, 0, data).astype(np.complex64) * (1.5 - 0.4 * a_)
-            for port in range(2):
-                h = ((2.0 - 0.7 * port + 0.3 * a_) * (1 + 0.25 * np.sin(k / 30.0 + port + 2 * a_)) *
+            for port in range(npt):
+                h = ((2.0 - 0.35 * port * (2 if npt == 2 else 1) + 0.3 * a_) * (1 + 0.25 * np.sin(k / 30.0 + port + 2 * a_)) *
                      np.exp(1j * (0.4 * port - 0.9 * a_ + k / 80.0 + 0.05 * l))).astype(np.complex64)
                 rxg = rxg + tx[port] * h
             rxg = rxg + (0.05 + 0.1 * a_) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
             grids.append(acopy(rxg.astype(np.complex64).view(np.float32)))
         q = opaque(1 << 20)
-        assert R.srslte_chest_dl_init(q, prb, nrx) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 2, cid, 0, 0, 0, 0)) == 0
+        assert R.srslte_chest_dl_init(q, prb, nrx) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, npt, cid, 0, 0, 0, 0)) == 0
         rc, oc = RefChestCfg(), OrcChestCfg()
         for kk, v in kw.items():
             if kk == "filter_coef":
@@ -336,19 +343,19 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
                 setattr(oc, kk, v)
         rc.cfo_estimate_sf_mask = 0x3FF
         res, sf = RefChestRes(), RefDlSfCfg()
-        ce_r = [[aligned(2 * n, np.float32) for _ in range(nrx)] for _ in range(2)]
-        for port in range(2):
+        ce_r = [[aligned(2 * n, np.float32) for _ in range(nrx)] for _ in range(npt)]
+        for port in range(npt):
             for a_ in range(nrx):
                 res.ce[port][a_] = ce_r[port][a_].ctypes.data
         sf.tti = sf_idx
         inp = (C.c_void_p * 4)(*([g.ctypes.data for g in grids] + [0] * (4 - nrx)))
         assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
-        ce_o, ores = [np.zeros(n, np.complex64) for _ in range(2 * nrx)], OrcChestRes()
+        ce_o, ores = [np.zeros(n, np.complex64) for _ in range(npt * nrx)], OrcChestRes()
         gp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grids])
-        cp = (C.c_void_p * (2 * nrx))(*[c.ctypes.data for c in ce_o])
-        raw = np.zeros(nrx * 2 * 4, np.float32)
+        cp = (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce_o])
+        raw = np.zeros(nrx * npt * 4, np.float32)
         assert oracle().orc_chest_dl_ports(C.byref(cell), sf_idx, C.byref(oc), nrx, gp, cp, C.byref(ores), p(raw)) == 0
-        for port in range(2):
+        for port in range(npt):
             for a_ in range(nrx):
                 x = ce_r[port][a_].view(np.complex64)
                 assert np.abs(x - ce_o[port * nrx + a_]).max() <= 1e-4 * max(np.abs(x).max(), np.sqrt((np.abs(x) ** 2).mean())), (prb, cid, port, a_)
@@ -356,8 +363,8 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx):
             x, y = getattr(res, nm), getattr(ores, nm)
             assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y, sf_idx)
         check_sync_and_neighbour(res, ores, kw)
-        raw = raw.reshape(nrx, 2, 4)
-        for port in range(2):  # per-port fields of fill_res (chest_dl.c:860-870) from the per-(antenna, port) scalars
+        raw = raw.reshape(nrx, npt, 4)
+        for port in range(npt):  # per-port fields of fill_res (chest_dl.c:860-870) from the per-(antenna, port) scalars
             assert abs(res.rsrp_port_dbm[port] - (10 * np.log10(raw[:, port, 1].mean()) + 30)) <= 1e-3
             for a_ in range(nrx):
                 assert abs(res.snr_ant_port_db[a_][port] - 10 * np.log10(raw[a_, port, 1] / raw[a_, port, 0])) <= 1e-3
