@@ -36,8 +36,10 @@ __device__ __forceinline__ cf32 c_sub(cf32 a, cf32 b) { return make_float2(a.x -
 __device__ __forceinline__ cf32 c_scale(cf32 a, float s) { return make_float2(a.x * s, a.y * s); }
 __device__ __forceinline__ cf32 c_mulconj(cf32 a, cf32 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
-__device__ __forceinline__ int crs_nsymbol(int l) { return (l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7; } // refsignal_dl.c:234-249, normal CP, port<2
-__device__ __forceinline__ int crs_fidx(int cell_id, int l, int port) { return ((((l + port) & 1) ? 3 : 0) + (cell_id % 6)) % 6; } // refsignal_dl.c:134-168, ports 0/1
+// refsignal_dl.c:234-249, normal CP: ports 0/1 use symbols 0, 4, 7, 11, ports 2/3 symbols 1 and 8
+__device__ __forceinline__ int crs_nsymbol(int l, int port = 0) { return port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7); }
+// refsignal_dl.c:134-168: v = 0/3 alternating with the pilot symbol, the other way round for the odd port of each pair
+__device__ __forceinline__ int crs_fidx(int cell_id, int l, int port) { return ((((l + port) & 1) ? 3 : 0) + (cell_id % 6)) % 6; }
 
 __device__ float block_sum(float v, float* red)
 {
@@ -90,41 +92,43 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
                                                              ChestParams p)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const int P = p.nof_prb, nre = 12 * P, nref = 2 * P, npil = 4 * nref;
+  const int P = p.nof_prb, nre = 12 * P, nref = 2 * P;
   cf32*  est = reinterpret_cast<cf32*>(lds_raw); // [4][nref]
-  cf32*  avg = est + npil;                       // [4][nref]
-  cf32*  fr  = avg + npil;                       // [4][nre], only when interpolate_subframe
+  cf32*  avg = est + 4 * nref;                   // [4][nref]
+  cf32*  fr  = avg + 4 * nref;                   // [4][nre], only when interpolate_subframe
   __shared__ float red[CH_THREADS / 64];
   __shared__ float filt[64];
 
   const int   sf = blockIdx.x, tid = threadIdx.x; // sf: (subframe, port, antenna) index
   const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
   const cf32* g      = grid + ((size_t)sfn * p.nof_rx + ant) * 14 * nre;
-  const cf32* known  = pilots + (size_t)sf_idx * npil; // ports 0 and 1 carry the same values (refsignal_dl.c pilots[port / 2])
+  const int   nsym = port < 2 ? 4 : 2, npil = nsym * nref; // ports 2/3: two pilot symbols per subframe
+  // ports 0 and 1 share their values (refsignal_dl.c pilots[port / 2]), [10][4][nref]; ports 2 and 3 theirs, [10][2][nref] behind
+  const cf32* known = port < 2 ? pilots + (size_t)sf_idx * 4 * nref : pilots + (size_t)10 * 4 * nref + (size_t)sf_idx * 2 * nref;
 
   // ---- pilots, LS, RSRP
   float acc = 0;
   for (int i = tid; i < npil; i += CH_THREADS) {
     const int l = i / nref, k = i - l * nref;
-    cf32      r = g[crs_nsymbol(l) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
+    cf32      r = g[crs_nsymbol(l, port) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
     est[i]      = c_mulconj(r, known[i]);
     acc += r.x * r.x + r.y * r.y;
   }
   const float rsrp = block_sum(acc, red) / npil;
   // ---- RSSI
   acc = 0;
-  for (int i = tid; i < 4 * nre; i += CH_THREADS) {
+  for (int i = tid; i < nsym * nre; i += CH_THREADS) {
     const int l = i / nre;
-    cf32      v = g[crs_nsymbol(l) * nre + (i - l * nre)];
+    cf32      v = g[crs_nsymbol(l, port) * nre + (i - l * nre)];
     acc += v.x * v.x + v.y * v.y;
   }
-  const float rssi = block_sum(acc, red) / 4.0f;
+  const float rssi = block_sum(acc, red) / (float)nsym;
 
   // ---- synchronisation error (chest_dl.c:692-703; srslte_vec_estimate_frequency, vector_simd.c:1606-1656, with exact divisions)
   float sync = NAN;
   if (p.sync_enable) {
     float sum = 0.f;
-    for (int l = 0; l < 4; l++) {
+    for (int l = 0; l < nsym; l++) {
       const cf32* x = est + l * nref;
       float       ss = 0.f;
       for (int i = 1 + tid; i < nref; i += CH_THREADS) {
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       ss = block_sum(ss, red);
       sum += asinf(ss / (float)(nref - 1)) / (2.0f * (float)M_PI) * ((float)p.symbol_sz / 6.0f);
     }
-    sync = sum / 4.0f;
+    sync = sum / (float)nsym;
   }
   // ---- power of the coherent pilot mean, for neighbour-cell RSRP (chest_dl.c:706-709)
   float corr = 0.f;
@@ -153,7 +157,14 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   if (p.cfo_enable) { // chest_dl.c:573-596
     float sr = 0, si = 0;
     for (int i = tid; i < 2 * nref; i += CH_THREADS) {
-      cf32 v = c_mulconj(est[i], est[i + 2 * nref]);
+      cf32 second; // chest_estimate_cfo pairs the two halves of q->pilot_estimates whatever the port (chest_dl.c:582-590): for ports 2/3
+      if (port < 2) { // the second half is what port 1 of the same antenna left there: its LS estimates of symbols 7 and 11
+        second = est[i + 2 * nref];
+      } else {
+        const int l = 2 + i / nref, k = i % nref;
+        second = c_mulconj(g[crs_nsymbol(l, 1) * nre + crs_fidx(p.cell_id, l, 1) + 6 * k], pilots[(size_t)sf_idx * 4 * nref + l * nref + k]);
+      }
+      cf32 v = c_mulconj(est[i], second);
       sr += v.x;
       si += v.y;
     }
@@ -167,14 +178,16 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   float noise = 0;
   if (p.noise_alg == 0) {
     const int   off = crs_fidx(p.cell_id, 0, port) < 3 ? 0 : 1;
-    const cf32 *r0 = est, *r2 = est + 2 * nref, *r3 = est + 3 * nref;
+    // the last pilot row, its predecessor, and the row before that (4 symbols: rows 3, 2, 0; 2 symbols: rows 1, 0, -)
+    const cf32 *r0 = est, *r2 = est + (nsym - 2) * nref, *r3 = est + (nsym - 1) * nref;
     acc = 0;
     for (int k = tid; k < nref; k += CH_THREADS) {
       cf32 t = r3[k];
 #pragma unroll
       for (int side = 0; side < 2; side++) {
-        // neighbour rows: previous = row 2, next = 2*row2 - row0 (chest_dl.c:343-350)
-        auto nb = [&](int idx) { return side == 0 ? r2[idx] : c_sub(c_scale(r2[idx], 2.0f), r0[idx]); };
+        // neighbour rows: previous = the row before, next = its linear extrapolation 2*row2 - row0 (chest_dl.c:343-350) or, with only two
+        // pilot symbols, a copy of it (:346-348)
+        auto nb = [&](int idx) { return (side == 0 || nsym < 4) ? r2[idx] : c_sub(c_scale(r2[idx], 2.0f), r0[idx]); };
         if (off == 0) {
           t = c_add(t, nb(k));
           t = c_add(t, k < nref - 1 ? nb(k + 1) : c_sub(c_scale(nb(nref - 2), 2.0f), nb(nref - 1)));
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       t = c_sub(r3[k], c_scale(t, 1.0f / 5.0f));
       acc += t.x * t.x + t.y * t.y;
     }
-    noise = block_sum(acc, red) / nref / 4.0f * sqrtf(5.0f);
+    noise = block_sum(acc, red) / nref / (float)nsym * sqrtf(5.0f);
   }
 
   if (ce) {
@@ -218,9 +231,13 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       if (!p.interpolate_subframe) {
         const bool first_low = crs_fidx(p.cell_id, 0, port) < 3;
         for (int k = tid; k < nref; k += CH_THREADS) {
-          cf32 a = c_add(est[k], est[2 * nref + k]), b = c_add(est[nref + k], est[3 * nref + k]);
-          avg[2 * k]     = c_scale(first_low ? a : b, 2.0f / 4.0f);
-          avg[2 * k + 1] = c_scale(first_low ? b : a, 2.0f / 4.0f);
+          cf32 a = est[k], b = est[nref + k];
+          if (nsym == 4) {
+            a = c_add(a, est[2 * nref + k]);
+            b = c_add(b, est[3 * nref + k]);
+          }
+          avg[2 * k]     = c_scale(first_low ? a : b, 2.0f / (float)nsym);
+          avg[2 * k + 1] = c_scale(first_low ? b : a, 2.0f / (float)nsym);
         }
         __syncthreads();
         for (int k = tid; k < 2 * nref; k += CH_THREADS) est[k] = avg[k];
@@ -346,30 +363,30 @@ void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) {
 
 struct srslte_hip_chest_dl {
   int       cell_id, nof_prb, nof_ports;
-  cf32*     d_pilots; // [10][4][2*nof_prb], ports 0 and 1
+  cf32*     d_pilots; // [10][4][2*nof_prb] ports 0 and 1, then [10][2][2*nof_prb] ports 2 and 3 (4-port cells)
   ChestRaw* d_raw;    // per (subframe, port, antenna) scalars of multi-antenna / multi-port calls, grown on demand
   size_t    raw_cap;
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
 {
-  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || nof_ports < 1 || nof_ports > 2 || !cp_is_norm) {
-    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1 or 2 ports, normal CP only\n", cell_id,
+  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || (nof_ports != 1 && nof_ports != 2 && nof_ports != 4) || !cp_is_norm) {
+    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1, 2 or 4 ports, normal CP only\n", cell_id,
             nof_prb, nof_ports, cp_is_norm);
     return nullptr;
   }
   const int            nref = 2 * nof_prb, MAX_PRB = 110;
-  std::vector<cf32>    pil((size_t)10 * 4 * nref);
+  std::vector<cf32>    pil((size_t)10 * 6 * nref);
   std::vector<uint8_t> c;
   for (uint32_t ns = 0; ns < 20; ns++) {
-    for (uint32_t l = 0; l < 2; l++) {
-      const uint32_t lp     = l == 0 ? 0 : 4;
+    for (uint32_t l = 0; l < 3; l++) { // l = 0, 1: symbols 0 and 4 of the slot (ports 0/1); l = 2: symbol 1 (ports 2/3)
+      const uint32_t lp     = l == 0 ? 0 : (l == 1 ? 4 : 1);
       const uint32_t c_init = 1024 * (7 * (ns + 1) + lp + 1) * (2 * cell_id + 1) + 2 * cell_id + 1;
       gold(c_init, 4 * MAX_PRB, c);
+      cf32* dst = l < 2 ? &pil[((size_t)(ns / 2) * 4 + (ns % 2) * 2 + l) * nref] : &pil[(size_t)10 * 4 * nref + ((size_t)(ns / 2) * 2 + ns % 2) * nref];
       for (int i = 0; i < nref; i++) {
         const int mp = i + MAX_PRB - nof_prb;
-        pil[((size_t)(ns / 2) * 4 + (ns % 2) * 2 + l) * nref + i] =
-            make_float2((float)((1 - 2 * (float)c[2 * mp]) / sqrt(2.0)), (float)((1 - 2 * (float)c[2 * mp + 1]) / sqrt(2.0)));
+        dst[i]       = make_float2((float)((1 - 2 * (float)c[2 * mp]) / sqrt(2.0)), (float)((1 - 2 * (float)c[2 * mp + 1]) / sqrt(2.0)));
       }
     }
   }
@@ -411,6 +428,11 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
     return SRSLTE_ERROR;
   }
   if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->nof_ports == 4 && cfg->interpolate_subframe && d_ce) {
+    // upstream then copies symbol 0 of the ports-2/3 estimates, which nothing wrote, over the subframe (chest_dl.c:467-471): no defined result
+    fprintf(stderr, "[srslte_hip] chest_dl: interpolate_subframe is not defined for the ports 2/3 of a 4-port cell\n");
+    return SRSLTE_ERROR;
+  }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   ChestParams p;
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;

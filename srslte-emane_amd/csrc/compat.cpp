@@ -922,8 +922,8 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
 { // chest_dl.c:884-908
   auto* st = q ? (ChestState*)q->tmp_noise : nullptr;
   if (!st || !st->h || !sf || !cfg || !input || !res) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->cell.nof_ports > 2 || sf->sf_type != SRSLTE_SF_NORM) {
-    ERROR("chest_dl: only 1 or 2 tx ports / normal subframes are implemented on device");
+  if (sf->sf_type != SRSLTE_SF_NORM) {
+    ERROR("chest_dl: only normal subframes are implemented on device");
     return SRSLTE_ERROR;
   }
   const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
