@@ -146,6 +146,10 @@ void orc_predecoding_single_multi(const orc_cf_t* const* y, const orc_cf_t* cons
  * srslte_predecoding_diversity_csi + srslte_layerdemap_diversity (precoding.c:564-598, layermap.c:140-148); h[port * nof_rx + antenna] */
 void orc_precoding_diversity2(const orc_cf_t* d, orc_cf_t* y0, orc_cf_t* y1, int nof_symbols, float scaling);
 void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* d, float* csi, int nof_rx, int nof_symbols,
+                                float scaling);
+/* the same for 4 ports (precoding.c:1862-1890 and :599-650): y[4] port streams */
+void orc_precoding_diversity4(const orc_cf_t* d, orc_cf_t* const* y, int nof_symbols, float scaling);
+void orc_predecoding_diversity4(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* d, float* csi, int nof_rx, int nof_symbols,
                                 float scaling); /* precoding.c:138-262,:325-348 */
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
 /* CSI weighting of the LLRs when srslte_pdsch_cfg_t.csi_enable is set (the srsUE default): the csi side output of

@@ -231,3 +231,50 @@ void orc_csi_correction_b(int8_t* e, const float* csi, int nsym, int mod)
     for (int k = 0; k < qm; k++) e[qm * i + k] = (int8_t)((float)e[qm * i + k] * c);
   }
 }
+
+/* ------------------------------------------------------------------ 4-port transmit diversity (SFBC + FSTD), SURVEY §8f N4 */
+
+void orc_precoding_diversity4(const orc_cf_t* d, orc_cf_t* const* y /* [4] */, int nof_symbols, float scaling)
+{ /* srslte_layermap_diversity with 4 layers (layermap.c:36-44) + srslte_precoding_diversity for 4 ports (precoding.c:1862-1890):
+     ports 0/2 carry the Alamouti pair of sub-carriers 4i, 4i+1, ports 1/3 that of 4i+2, 4i+3, the other two ports stay silent */
+  const float    g = scaling / sqrtf(2);
+  const orc_cf_t z = {0, 0};
+  for (int i = 0; i < nof_symbols / 4; i++) {
+    const orc_cf_t x0 = d[4 * i], x1 = d[4 * i + 1], x2 = d[4 * i + 2], x3 = d[4 * i + 3];
+    y[0][4 * i] = (orc_cf_t){x0.re * g, x0.im * g};      y[1][4 * i] = z; y[2][4 * i] = (orc_cf_t){-x1.re * g, x1.im * g};     y[3][4 * i] = z;
+    y[0][4 * i + 1] = (orc_cf_t){x1.re * g, x1.im * g};  y[1][4 * i + 1] = z; y[2][4 * i + 1] = (orc_cf_t){x0.re * g, -x0.im * g}; y[3][4 * i + 1] = z;
+    y[0][4 * i + 2] = z; y[1][4 * i + 2] = (orc_cf_t){x2.re * g, x2.im * g};  y[2][4 * i + 2] = z; y[3][4 * i + 2] = (orc_cf_t){-x3.re * g, x3.im * g};
+    y[0][4 * i + 3] = z; y[1][4 * i + 3] = (orc_cf_t){x3.re * g, x3.im * g};  y[2][4 * i + 3] = z; y[3][4 * i + 3] = (orc_cf_t){x2.re * g, -x2.im * g};
+  }
+}
+
+void orc_predecoding_diversity4(const orc_cf_t* const* y, const orc_cf_t* const* h /* [port * nof_rx + antenna] */, orc_cf_t* d, float* csi,
+                                int nof_rx, int nof_symbols, float scaling)
+{ /* srslte_predecoding_diversity_csi for 4 ports (precoding.c:599-650) + srslte_layerdemap_diversity with 4 layers: every symbol of a
+     group of four has its own divisor (|h|^2 of the two ports at its own and its pair partner's sub-carrier); csi = divisor / nof_rx */
+  const int m_ap = (nof_symbols % 4) ? (nof_symbols - 2) / 4 : nof_symbols / 4;
+  for (int i = 0; i < m_ap; i++) {
+    float a[4] = {0, 0, 0, 0}, xr[4] = {0, 0, 0, 0}, xi[4] = {0, 0, 0, 0};
+    for (int p = 0; p < nof_rx; p++) {
+      for (int half = 0; half < 2; half++) { /* sub-carriers 4i, 4i+1 with ports 0 and 2; 4i+2, 4i+3 with ports 1 and 3 */
+        const int      k = 4 * i + 2 * half;
+        const orc_cf_t h00 = h[(0 + half) * nof_rx + p][k], h01 = h[(2 + half) * nof_rx + p][k];
+        const orc_cf_t h10 = h[(0 + half) * nof_rx + p][k + 1], h11 = h[(2 + half) * nof_rx + p][k + 1];
+        const orc_cf_t r0 = y[p][k], r1 = y[p][k + 1];
+        a[2 * half] += h00.re * h00.re + h00.im * h00.im + h11.re * h11.re + h11.im * h11.im;
+        a[2 * half + 1] += h10.re * h10.re + h10.im * h10.im + h01.re * h01.re + h01.im * h01.im;
+        /* x0 += conj(h00) r0 + h11 conj(r1) */
+        xr[2 * half] += h00.re * r0.re + h00.im * r0.im + h11.re * r1.re + h11.im * r1.im;
+        xi[2 * half] += h00.re * r0.im - h00.im * r0.re + h11.im * r1.re - h11.re * r1.im;
+        /* x1 += -h01 conj(r0) + conj(h10) r1 */
+        xr[2 * half + 1] += -(h01.re * r0.re + h01.im * r0.im) + h10.re * r1.re + h10.im * r1.im;
+        xi[2 * half + 1] += -(h01.im * r0.re - h01.re * r0.im) + h10.re * r1.im - h10.im * r1.re;
+      }
+    }
+    for (int j = 0; j < 4; j++) {
+      a[j] *= scaling;
+      if (csi) csi[4 * i + j] = a[j] / nof_rx;
+      d[4 * i + j] = (orc_cf_t){xr[j] / a[j] * sqrtf(2.0f), xi[j] / a[j] * sqrtf(2.0f)};
+    }
+  }
+}

@@ -23,14 +23,14 @@ class DlConfig:
         self.Qm = MOD_BITS[mod]
         # bits per "symbol" in the code-block split of the rate matcher: Qm * N_L, N_L = 2 for transmit diversity (36.212 5.1.4.1.2;
         # srslte_dlsch_decode2 / _encode2, sch.c:507-531,:549-575)
-        self.Qm_sch = self.Qm * (2 if nof_ports == 2 else 1)
+        self.Qm_sch = self.Qm * (2 if nof_ports > 1 else 1)
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.nof_ports = nof_ports
         # srslte_pdsch_cfg_t.power_scale / p_a (pdsch.c:518-554,:852-858; p_b chosen so that rho_b = 1, as phy_dl_test.c:176-178): the
         # receiver divides by rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports); None = power_scale off
         self.p_a = p_a
-        self.scaling = 1.0 if p_a is None else float(np.float32(10.0) ** np.float32(p_a / 20.0) * (np.float32(np.sqrt(np.float32(2.0))) if nof_ports == 2 else np.float32(1.0)))
+        self.scaling = 1.0 if p_a is None else float(np.float32(10.0) ** np.float32(p_a / 20.0) * (np.float32(np.sqrt(np.float32(2.0))) if nof_ports > 1 else np.float32(1.0)))
         self.csi = csi  # srslte_pdsch_cfg_t.csi_enable: LLRs weighted by the channel gain (pdsch.c:574-690), the srsUE default
         self.cell = OrcCell(cell_id, nof_prb, nof_ports, True)
         self.nre = 12 * nof_prb
@@ -81,7 +81,7 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None, keep=Non
     q = OrcOfdm()
     orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
     q.normalize = True
-    if cfg.nof_ports == 2:
+    if cfg.nof_ports > 1:
         return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep), data
     if cfg.scaling != 1.0:
         syms = syms * np.float32(cfg.scaling)  # rho_a (pdsch.c:1100-1114,:1166-1170)
@@ -106,16 +106,21 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None, keep=Non
 
 
 def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None):
-    """eNB side of pdsch.c:1150-1175 for 2-port transmit diversity: layer mapping + SFBC precoding, RE mapping and CRS per port; every
-    (antenna, port) path has its own smooth frequency response (a gain and a delay), applied in the frequency domain."""
+    """eNB side of pdsch.c:1150-1175 for 2- and 4-port transmit diversity: layer mapping + SFBC (+ FSTD) precoding, RE mapping and CRS
+    per port; every (antenna, port) path has its own smooth frequency response (a gain and a delay), applied in the frequency domain."""
     orc = oracle()
-    orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
-    y = [np.zeros(len(idx), np.complex64), np.zeros(len(idx), np.complex64)]
-    orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), cfg.scaling)  # rho_a with power allocation (pdsch.c:1100-1114), else 1
+    npt = cfg.nof_ports
+    y = [np.zeros(len(idx), np.complex64) for _ in range(npt)]
+    if npt == 2:
+        orc.orc_precoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        orc.orc_precoding_diversity2(p(syms), p(y[0]), p(y[1]), len(idx), cfg.scaling)  # rho_a with power allocation (pdsch.c:1100-1114), else 1
+    else:
+        orc.orc_precoding_diversity4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+        orc.orc_precoding_diversity4(p(syms), (C.c_void_p * 4)(*[v.ctypes.data for v in y]), len(idx), cfg.scaling)
     if keep is not None:
-        keep.update(y=[y[0].copy(), y[1].copy()], idx=idx)
+        keep.update(y=[v.copy() for v in y], idx=idx)
     tx = []
-    for port in range(2):
+    for port in range(npt):
         g = np.zeros(cfg.grid_len, np.complex64)
         g[idx] = y[port]
         orc.orc_crs_put_sf(C.byref(cfg.cell), sf_idx, port, p(g))
@@ -125,9 +130,10 @@ def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None
     out = []
     for a in range(cfg.nof_rx):
         rxg = np.zeros(cfg.grid_len, np.complex128)
-        for port in range(2):
-            gain = (1.0, 0.8 * np.exp(0.9j), 0.7 * np.exp(-2.0j), 0.9 * np.exp(2.4j))[2 * a + port]
-            rxg += tx[port] * gain * np.exp(-2j * np.pi * k * (0.6 + 0.9 * port + 0.5 * a) / cfg.N)
+        for port in range(npt):
+            gain = (1.0, 0.8 * np.exp(0.9j), 0.7 * np.exp(-2.0j), 0.9 * np.exp(2.4j), 0.85 * np.exp(1.7j), 0.75 * np.exp(-0.4j), 0.95 * np.exp(-2.9j),
+                    0.65 * np.exp(0.3j))[(2 * a + port) % 8]
+            rxg += tx[port] * gain * np.exp(-2j * np.pi * k * (0.6 + 0.9 * (port % 2) + 0.3 * (port // 2) + 0.5 * a) / cfg.N)
         rxg = np.ascontiguousarray(rxg.astype(np.complex64))
         iq = np.zeros(cfg.sf_len, np.complex64)
         orc.orc_ofdm_tx_sf(C.byref(q), p(rxg), p(iq))
@@ -193,16 +199,18 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None, harq=None, rv=0, new_data=
     ccfg = cfg.orc_chest_cfg()
     idx = cfg.indices(sf_idx)
     d = np.zeros(len(idx), np.complex64)
-    if cfg.nof_ports == 2:  # pdsch.c:890-935 with tx_scheme DIVERSITY: srslte_predecoding_diversity_multi (csi variant) + layer demapping
-        ce = np.zeros((2 * nrx, cfg.grid_len), np.complex64)  # [port * nrx + antenna]
-        gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * (2 * nrx))(*[c.ctypes.data for c in ce])
+    if cfg.nof_ports > 1:  # pdsch.c:890-935 with tx_scheme DIVERSITY: srslte_predecoding_diversity_multi (csi variant) + layer demapping
+        npt = cfg.nof_ports
+        ce = np.zeros((npt * nrx, cfg.grid_len), np.complex64)  # [port * nrx + antenna]
+        gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce])
         orc.orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         assert orc.orc_chest_dl_ports(C.byref(cfg.cell), sf_idx, C.byref(ccfg), nrx, gp, cp, C.byref(res), None) == 0
         ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
-        yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (2 * nrx))(*[v.ctypes.data for v in hs])
-        orc.orc_predecoding_diversity2.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+        yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (npt * nrx))(*[v.ctypes.data for v in hs])
+        fn = orc.orc_predecoding_diversity2 if npt == 2 else orc.orc_predecoding_diversity4
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
         csi = np.zeros(len(idx), np.float32)
-        orc.orc_predecoding_diversity2(yp, hp, p(d), p(csi), nrx, len(idx), cfg.scaling)
+        fn(yp, hp, p(d), p(csi), nrx, len(idx), cfg.scaling)
     elif nrx == 1:
         assert orc.orc_chest_dl(C.byref(cfg.cell), sf_idx, C.byref(ccfg), p(grid[0]), p(ce[0]), C.byref(res)) == 0
         y, h = np.ascontiguousarray(grid[0][idx]), np.ascontiguousarray(ce[0][idx])
@@ -313,16 +321,17 @@ class RefRx:
             ys[a_].view(np.complex64)[:] = grids[a_].view(np.complex64)[idx]
         for i_ in range(nrx * cfg.nof_ports):
             hs[i_].view(np.complex64)[:] = self.ces[i_].view(np.complex64)[idx]
-        if cfg.nof_ports == 2:
+        if cfg.nof_ports > 1:
+            npt = cfg.nof_ports
             yp = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))
             hp = ((C.c_void_p * 4) * 4)()
-            for i_ in range(2 * nrx):
+            for i_ in range(npt * nrx):
                 hp[i_ // nrx][i_ % nrx] = hs[i_].ctypes.data
-            x = [self.aligned(n, np.float32), self.aligned(n, np.float32)]
-            xp = (C.c_void_p * 4)(x[0].ctypes.data, x[1].ctypes.data, 0, 0)
+            x = [self.aligned(n, np.float32) for _ in range(npt)]
+            xp = (C.c_void_p * 4)(*([v.ctypes.data for v in x] + [0] * (4 - npt)))
             csi = self.aligned(n, np.float32)
-            R.srslte_predecoding_diversity_multi(yp, hp, xp, (C.c_void_p * 2)(csi.ctypes.data, 0), nrx, 2, n, 1.0)
-            R.srslte_layerdemap_diversity(xp, p(d), 2, n // 2)
+            R.srslte_predecoding_diversity_multi(yp, hp, xp, (C.c_void_p * 2)(csi.ctypes.data, 0), nrx, npt, n, 1.0)
+            R.srslte_layerdemap_diversity(xp, p(d), npt, n // npt)
         elif nrx == 1:
             R.srslte_predecoding_single(p(ys[0]), p(hs[0]), p(d), None, n, 1.0, self.res.noise_estimate)
         else:
@@ -381,7 +390,7 @@ class RefPdsch:
 
         def u32(off, v):
             g[off:off + 4].view(np.uint32)[0] = v
-        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports == 2 else 0)
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports > 1 else 0)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
@@ -465,7 +474,7 @@ class RefPdschTx:
 
         def u32(off, v):
             g[off:off + 4].view(np.uint32)[0] = v
-        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports == 2 else 0)
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports > 1 else 0)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)

@@ -446,10 +446,64 @@ def test_tx_diversity_vs_ref():
             assert np.sqrt(np.mean(np.abs(d_o - d.view(np.complex64)) ** 2)) < 0.25
 
 
+def test_tx_diversity_4_ports_vs_ref():
+    """4-port SFBC + FSTD: srslte_layermap_diversity + srslte_precoding_diversity (precoding.c:1862-1890) and
+    srslte_predecoding_diversity_multi with a csi buffer (the variant srslte_pdsch_decode reaches, :599-650) + srslte_layerdemap_diversity."""
+    R, rng, orc = ref(), np.random.default_rng(29), oracle()
+    R.srslte_precoding_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    R.srslte_layermap_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    R.srslte_layerdemap_diversity.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    R.srslte_predecoding_diversity_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+    orc.orc_precoding_diversity4.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    orc.orc_predecoding_diversity4.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float]
+    for n, scaling in ((24, 1.0), (1000, 1.4142135), (13824, 1.0)):
+        d = acopy(rng.standard_normal(2 * n).astype(np.float32))
+        x = [aligned(n // 2, np.float32) for _ in range(4)]
+        xp = (C.c_void_p * 4)(*[v.ctypes.data for v in x])
+        assert R.srslte_layermap_diversity(p(d), xp, 4, n) == n // 4
+        y_r = [aligned(2 * n, np.float32) for _ in range(4)]
+        yp = (C.c_void_p * 4)(*[v.ctypes.data for v in y_r])
+        assert R.srslte_precoding_diversity(xp, yp, 4, n // 4, scaling) == n
+        y_o = [np.zeros(n, np.complex64) for _ in range(4)]
+        orc.orc_precoding_diversity4(p(d), (C.c_void_p * 4)(*[v.ctypes.data for v in y_o]), n, scaling)
+        for port in range(4):
+            assert np.abs(y_r[port].view(np.complex64) - y_o[port]).max() <= 1e-6
+        for nrx in (1, 2):
+            hs = []  # [port * nrx + antenna], nearly constant over each group of four sub-carriers
+            for _ in range(4 * nrx):
+                hc = np.repeat(rng.standard_normal(n // 4) + 1j * rng.standard_normal(n // 4) + 0.5, 4)
+                hc = hc * (1 + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)))
+                hs.append(acopy(hc.astype(np.complex64).view(np.float32)))
+            ys = []
+            for a_ in range(nrx):
+                rx = sum(y_o[port] * hs[port * nrx + a_].view(np.complex64) for port in range(4))
+                rx = rx + 0.03 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+                ys.append(acopy(rx.astype(np.complex64).view(np.float32)))
+            yp2 = (C.c_void_p * 4)(*([v.ctypes.data for v in ys] + [0] * (4 - nrx)))
+            hp = ((C.c_void_p * 4) * 4)()
+            for port in range(4):
+                for a_ in range(nrx):
+                    hp[port][a_] = hs[port * nrx + a_].ctypes.data
+            d_o, csi_o = np.zeros(n, np.complex64), np.zeros(n, np.float32)
+            orc.orc_predecoding_diversity4((C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (4 * nrx))(*[v.ctypes.data for v in hs]),
+                                           p(d_o), p(csi_o), nrx, n, scaling)
+            xr = [aligned(n // 2, np.float32) for _ in range(4)]
+            xrp = (C.c_void_p * 4)(*[v.ctypes.data for v in xr])
+            csi_r = aligned(n, np.float32)
+            R.srslte_predecoding_diversity_multi(yp2, hp, xrp, (C.c_void_p * 2)(csi_r.ctypes.data, 0), nrx, 4, n, scaling)
+            d_r = aligned(2 * n, np.float32)
+            assert R.srslte_layerdemap_diversity(xrp, p(d_r), 4, n // 4) == n
+            a = d_r.view(np.complex64)
+            assert np.abs(a - d_o).max() <= 2e-6 * max(1.0, np.abs(a).max()), (n, nrx)
+            assert np.abs(np.array(csi_r) - csi_o).max() <= 1e-6 * csi_o.max()
+            assert np.sqrt(np.mean(np.abs(d_o - d.view(np.complex64)) ** 2)) < 0.25  # the transmitted symbols come back
+
+
 PDSCH_GRANT_OFF = {"prb_idx": 8, "nof_prb": 228, "nof_re": 232, "nof_symb_slot": 236}  # srslte_pdsch_grant_t (pdsch_cfg.h:37-49), SRSLTE_MAX_PRB 110
 
 
-@pytest.mark.parametrize("prb,cid,ports,cfi", [(6, 0, 1, 3), (6, 3, 2, 3), (15, 7, 2, 2), (25, 11, 1, 1), (25, 150, 2, 1), (100, 301, 2, 1), (75, 2, 2, 3)])
+@pytest.mark.parametrize("prb,cid,ports,cfi", [(6, 0, 1, 3), (6, 3, 2, 3), (15, 7, 2, 2), (25, 11, 1, 1), (25, 150, 2, 1), (100, 301, 2, 1), (75, 2, 2, 3),
+                                               (6, 5, 4, 1), (25, 7, 4, 2), (100, 148, 4, 1), (15, 3, 4, 3)])
 def test_pdsch_re_mapping_vs_ref(prb, cid, ports, cfi):
     """srslte_pdsch_cp (pdsch.c:81-206) on a grid of running indices = orc_pdsch_indices: 1- and 2-port CRS holes, PSS/SSS/PBCH, odd
     bandwidths, for subframes 0, 5 and an ordinary one."""
@@ -471,7 +525,7 @@ def test_pdsch_re_mapping_vs_ref(prb, cid, ports, cfi):
         idx = np.zeros(n, np.uint32)
         cnt_o = oracle().orc_pdsch_indices(C.byref(cell), sf_idx, lstart, None, p(idx))
         assert cnt == cnt_o and np.array_equal(out.view(np.complex64).real[:cnt].astype(np.uint32), idx[:cnt]), (sf_idx, cnt, cnt_o)
-        assert ports == 1 or cnt % 2 == 0
+        assert ports == 1 or cnt % ports == 0
 
 
 def test_equaliser_vs_ref_rcp_tolerance():
@@ -575,7 +629,8 @@ def test_pdsch_decode_power_scaling_vs_oracle_chain(prb, mod, tbs, nrx, npt, snr
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(6, 1, 152, 1, 1, 4.0, False), (15, 1, 1000, 1, 2, 2.0, False), (25, 2, 4008, 1, 1, 9.0, False),
                                                             (25, 3, 9912, 2, 2, 13.5, False), (100, 3, 75376, 1, 1, 18.0, False),
                                                             (25, 2, 4008, 1, 2, 9.0, True), (100, 4, 97896, 2, 1, 24.0, False), (50, 3, 11448, 2, 1, 8.0, True),
-                                                            (100, 3, 75376, 1, 2, 19.5, False), (100, 2, 43816, 2, 2, 10.5, False)])
+                                                            (100, 3, 75376, 1, 2, 19.5, False), (100, 2, 43816, 2, 2, 10.5, False),
+                                                            (25, 2, 4008, 2, 4, 9.0, False), (100, 3, 61664, 1, 4, 19.0, False), (15, 1, 1000, 1, 4, 3.0, True)])
 def test_pdsch_decode_function_vs_oracle_chain(prb, mod, tbs, nrx, npt, snr, llr8, csi):
     """The reference's own srslte_pdsch_decode (pdsch.c:833-997; UE object, so the csi variants of the equalisers run) on the output of
     its srslte_chest_dl_estimate_cfg, against the oracle chain on identical IQ: TM1 / TM2, 1-2 antennas, 16- and 8-bit LLRs, with and
@@ -591,10 +646,10 @@ def test_pdsch_decode_function_vs_oracle_chain(prb, mod, tbs, nrx, npt, snr, llr
     for t in (0, 3, 5, 8):
         iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
         r, o = chain.run(iq, t), oracle_rx(cfg, iq, t, keep=True)
-        assert np.abs(r["d"] - o["d"]).max() <= (2e-6 if npt == 2 else 1e-3) * max(1.0, np.abs(o["d"]).max())
+        assert np.abs(r["d"] - o["d"]).max() <= (2e-6 if npt > 1 else 1e-3) * max(1.0, np.abs(o["d"]).max())
         assert np.abs(r["csi"] - o["csi"]).max() <= 2e-6 * o["csi"].max()
         diff = np.abs(r["e"].astype(np.int32) - o["e"].astype(np.int32))
-        assert diff.max() <= 1 and (diff != 0).mean() <= (0.005 if npt == 2 else 0.08), (t, diff.max(), (diff != 0).mean())
+        assert diff.max() <= 1 and (diff != 0).mean() <= (0.005 if npt > 1 else 0.08), (t, diff.max(), (diff != 0).mean())
         assert r["ok"] == o["ok"], t
         if r["ok"]:
             assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
@@ -732,7 +787,8 @@ def test_ulsch_functions_vs_oracle_chain(prb, L, mod, tbs, snr):
     assert nok > 0
 
 
-@pytest.mark.parametrize("prb,mod,tbs,npt", [(6, 1, 152, 1), (25, 2, 4008, 2), (100, 3, 75376, 1), (100, 3, 75376, 2), (50, 4, 48936, 1), (15, 1, 1000, 2)])
+@pytest.mark.parametrize("prb,mod,tbs,npt", [(6, 1, 152, 1), (25, 2, 4008, 2), (100, 3, 75376, 1), (100, 3, 75376, 2), (50, 4, 48936, 1), (15, 1, 1000, 2),
+                                             (25, 2, 4008, 4), (100, 3, 61664, 4)])
 def test_pdsch_encode_function_vs_stimulus_generator(prb, mod, tbs, npt):
     """The reference's own srslte_pdsch_encode (pdsch.c:1059-1185) vs the transmit chain make_subframe builds from oracle pieces (DL-SCH
     coding incl. the Qm * N_L block split, scrambling, modulation, SFBC precoding, RE mapping), port by port on the resource grid;
@@ -747,5 +803,5 @@ def test_pdsch_encode_function_vs_stimulus_generator(prb, mod, tbs, npt):
         grids = chain.run(data, t, rv=rv)
         for port in range(npt):
             exp = np.zeros(cfg.grid_len, np.complex64)
-            exp[k["idx"]] = k["y"][port] * (np.sqrt(2.0) if npt == 2 else 1.0)
+            exp[k["idx"]] = k["y"][port] * (np.sqrt(2.0) if npt > 1 else 1.0)
             assert np.abs(grids[port] - exp).max() <= 1e-6, (t, rv, port)
