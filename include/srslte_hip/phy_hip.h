@@ -89,7 +89,7 @@ int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hi
                                        void* d_ce, void* d_res, int nof_sf, void* stream);
 /* nof_rx receive antennas x the object's 1 or 2 tx ports (chest_dl.c:884-908 loops over antennas and ports; fill_res :747-871
  * combines them): d_grid is [nof_sf][nof_rx][14][12*nof_prb], d_ce [nof_sf][nof_ports][nof_rx][14][12*nof_prb], d_res stays one
- * entry per subframe. Ports 2 and 3 of a 4-port cell are not implemented (create refuses nof_ports > 2). */
+ * entry per subframe. 4-port cells: not with cfg->interpolate_subframe (upstream's result is undefined there, chest_dl.c:467-471). */
 int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                              void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream);
 /* device pointer to [nof_sf][nof_ports][nof_rx] x {noise_estimate, rsrp, rssi, cfo, sync_err, rsrp_corr} (6 floats) of the last call
@@ -193,9 +193,10 @@ typedef struct {
                               descrambling, sch.c:336-356 srslte_rm_turbo_rx_lut_8bit + srslte_tdec_iteration_8bit) */
   uint32_t nof_rx_antennas; /* 0 or 1: one antenna; 2..4: per-antenna estimation + srslte_predecoding_single_multi (precoding.c:325-348,
                                pdsch.c:890-935); d_iq / d_grid are then [nof_sf][nof_rx][...] */
-  uint32_t nof_ports;       /* 0 or 1: single antenna port (TM1); 2: 2-port cell with transmit diversity (TM2): 2-port chest_dl, 2-port RE
-                               mapping, srslte_predecoding_diversity_multi + srslte_layerdemap_diversity (precoding.c:564-598,
-                               layermap.c:140-148), for nof_rx_antennas 1..4 */
+  uint32_t nof_ports;       /* 0 or 1: single antenna port (TM1); 2 or 4: cell with that many ports and transmit diversity (TM2): multi-port
+                               chest_dl and RE mapping, srslte_predecoding_diversity_multi + srslte_layerdemap_diversity (precoding.c:564-650,
+                               layermap.c:140-148), for nof_rx_antennas 1..4; 4 ports: not with
+                               chest_cfg.interpolate_subframe */
   int      csi_enable;      /* srslte_pdsch_cfg_t.csi_enable (pdsch_cfg.h:63; the srsUE default): LLRs weighted by each symbol's channel
                                gain relative to the subframe's largest (csi_correction, pdsch.c:574-690, applied inside the rate
                                de-matching kernels as they read the LLRs) */
@@ -290,7 +291,7 @@ typedef struct {
   int      mod;            /* srslte_mod_t: QPSK .. 256QAM */
   uint32_t tbs;
   uint32_t max_batch;
-  uint32_t nof_ports;      /* 0 or 1: TM1; 2: transmit diversity */
+  uint32_t nof_ports;      /* 0 or 1: TM1; 2 or 4: transmit diversity */
   float    p_a;            /* dB; rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports), pdsch.c:518-554 with p_b giving rho_b = 1 */
 } srslte_hip_dl_tx_cfg_t;
 srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);

@@ -177,6 +177,70 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
   if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
 }
 
+// 4-port transmit diversity (SFBC + FSTD): srslte_predecoding_diversity_csi for 4 ports + srslte_layerdemap_diversity (precoding.c:599-650,
+// layermap.c:140-148). One thread per group of four consecutive PDSCH REs: sub-carriers 4i, 4i+1 carry the Alamouti pair of ports 0/2,
+// 4i+2, 4i+3 that of ports 1/3; every symbol has its own divisor. grid = (ceil(max_re/1024), nof_sf).
+template <typename LLR>
+__global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                               const uint32_t* __restrict__ scr, cf32* __restrict__ d_out, LLR* __restrict__ e_out,
+                                                               PdschGeom g)
+{
+  __shared__ __attribute__((aligned(16))) LLR stage[1024 * 8];
+  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int     base = blockIdx.x * 1024, i0 = base + 4 * threadIdx.x; // nof_re is a multiple of 4 for a 4-port cell
+  if (base >= c.nof_re) return;
+  const bool live = i0 < c.nof_re;
+  uint32_t   k[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) k[t] = c.idx[live ? i0 + t : c.nof_re - 4 + t];
+  float a[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f}, xi[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int an = 0; an < g.nof_rx; an++) {
+    const cf32* y = grid + ((size_t)sf * g.nof_rx + an) * g.grid_len;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+      const cf32* hA = ce + (((size_t)sf * 4 + half) * g.nof_rx + an) * g.grid_len;     // port 0 / 1
+      const cf32* hB = ce + (((size_t)sf * 4 + 2 + half) * g.nof_rx + an) * g.grid_len; // port 2 / 3
+      const uint32_t k0 = k[2 * half], k1 = k[2 * half + 1];
+      const cf32     h00 = hA[k0], h01 = hB[k0], h10 = hA[k1], h11 = hB[k1], r0 = y[k0], r1 = y[k1];
+      a[2 * half] += h00.x * h00.x + h00.y * h00.y + h11.x * h11.x + h11.y * h11.y;
+      a[2 * half + 1] += h10.x * h10.x + h10.y * h10.y + h01.x * h01.x + h01.y * h01.y;
+      xr[2 * half] += h00.x * r0.x + h00.y * r0.y + h11.x * r1.x + h11.y * r1.y;
+      xi[2 * half] += h00.x * r0.y - h00.y * r0.x + h11.y * r1.x - h11.x * r1.y;
+      xr[2 * half + 1] += -(h01.x * r0.x + h01.y * r0.y) + h10.x * r1.x + h10.y * r1.y;
+      xi[2 * half + 1] += -(h01.y * r0.x - h01.x * r0.y) + h10.x * r1.y - h10.y * r1.x;
+    }
+  }
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
+  float           gmax = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int   i  = (live ? i0 : 0) + t;
+    const float at = a[t] * (1.0f / g.inv_scaling); // a *= scaling (precoding.c:634-637)
+    const cf32  x  = make_float2(xr[t] / at * 1.41421356f, xi[t] / at * 1.41421356f);
+    if (g.csi && live) g.csi[(size_t)sf * g.max_re + i] = at / g.nof_rx; // precoding.c:639-642
+    gmax = fmaxf(gmax, live ? at / g.nof_rx : 0.f);
+    if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x;
+    LLR o[8];
+    if constexpr (sizeof(LLR) == 1) {
+      demod_dev::demod_b(g.mod, x, i, c.nof_re, o);
+    } else {
+      demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+    }
+    const int      bit0 = i * g.Qm;
+    const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
+    for (int j = 0; j < g.Qm; j++) stage[(4 * threadIdx.x + t) * g.Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
+  }
+  if (g.csi) csi_note_max(g.csi_max + sf, gmax);
+  __syncthreads();
+  const int   nbytes = min(1024, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const char* src    = reinterpret_cast<const char*>(stage);
+  for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+  const int rem = nbytes & 15;
+  if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
+}
+
 struct RmGeom {
   int C, K, Qm, tti0, max_bits, w_stride, out_len; // out_len = 3K+12
   int nof_re[3];
@@ -470,11 +534,11 @@ std::vector<uint32_t> rm_slot_table(const std::vector<uint32_t>& t, uint32_t w_s
 // skipping CRS, and the central 72 sub-carriers of the PSS/SSS symbols (slot 0, l >= 5, sf 0/5) and PBCH symbols (slot 1, l < 4, sf 0)
 void pdsch_re_indices(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, uint32_t sf_idx, uint32_t lstart, std::vector<uint32_t>& idx)
 {
-  const uint32_t nre = 12 * nof_prb, step = nof_ports == 1 ? 6 : 3; // 2 ports: the other port's CRS positions are left empty too (pdsch.c:103-107)
+  const uint32_t nre = 12 * nof_prb, step = nof_ports == 1 ? 6 : 3; // 2/4 ports: the other ports' CRS positions are left empty too (pdsch.c:103-107)
   idx.clear();
   for (uint32_t s = 0; s < 2; s++) {
     for (uint32_t l = (s == 0 ? lstart : 0); l < 7; l++) {
-      const bool     has_ref = l == 0 || l == 4;
+      const bool     has_ref = l == 0 || l == 4 || (l == 1 && nof_ports == 4); // phy_common.h:139-141
       const uint32_t offset  = l == 0 ? cell_id % 6 : (cell_id + 3) % 6;
       const bool     sync    = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
       for (uint32_t k = 0; k < nre; k++) {
@@ -555,7 +619,8 @@ static int dl_rx_rm_table(srslte_hip_dl_rx_t* q, uint32_t rv, uint32_t** d_tbl)
 
 extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4 || cfg->nof_ports > 2) {
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4 || cfg->nof_ports > 4 ||
+      cfg->nof_ports == 3 || (cfg->nof_ports == 4 && cfg->chest_cfg.interpolate_subframe)) {
     fprintf(stderr, "[srslte_hip] dl_rx: invalid configuration\n");
     return nullptr;
   }
@@ -650,7 +715,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->pg.csi = q->d_csi; q->pg.csi_max = q->d_csi_max;
   // apply_power_allocation (pdsch.c:518-554) with rho_b = 1: pdsch_scaling = rho_a = 10^(p_a/20), times sqrt(2) for a 2-port cell
   q->pg.inv_scaling = cfg->power_scale ? 1.0f / (powf(10.0f, cfg->p_a / 20.0f) * (npt == 1 ? 1.0f : sqrtf(2.0f))) : 1.0f;
-  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = npt == 2 ? 2 : 1;
+  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = npt > 1 ? 2 : 1;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
@@ -710,7 +775,15 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
       if (g.csi_max) HIP_TRY(hipMemsetAsync(g.csi_max, 0, sizeof(uint32_t) * nof_sf, st));
-      if (g.nof_ports == 2) {
+      if (g.nof_ports == 4) {
+        if (q->cfg.llr_8bit) {
+          hipLaunchKernelGGL(pdsch_demod_div4_kernel<int8_t>, dim3(ceil_div(g.max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
+        } else {
+          hipLaunchKernelGGL(pdsch_demod_div4_kernel<int16_t>, dim3(ceil_div(g.max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const uint32_t*)q->d_scr, q->d_d, q->d_e, g);
+        }
+      } else if (g.nof_ports == 2) {
         if (q->cfg.llr_8bit) {
           hipLaunchKernelGGL(pdsch_demod_div_kernel<int8_t>, dim3(ceil_div(g.max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                              (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
@@ -1359,40 +1432,42 @@ namespace {
 
 struct PdschTxGeom {
   SfClass cls[3];
-  const int32_t* src[3][2]; // per subframe class and port: grid RE -> >= 0 index into the port's symbol stream, -1 zero, <= -2 CRS pilot -(v + 2)
+  const int32_t* src[3][4]; // per subframe class and port: grid RE -> >= 0 index into the port's symbol stream, -1 zero, <= -2 CRS pilot -(v + 2)
   int   grid_len, max_re, Qm, Nl, nof_ports, tti0, scr_words, C, K, cb_stride, par_stride, rm_len;
   float lvl[16], gain; // constellation levels of one axis; rho_a (TM1) or rho_a / sqrt(2) (TM2)
 };
 
-// grid = (ceil(max_re / (256 * Nl)), nof_sf): one thread per layer-mapping unit (one symbol for TM1, the SFBC pair 2i, 2i+1 for TM2).
-// Bit e of a code block = coded bit rm[e mod (3K+12)] in the encoder's byte streams, as in pusch_tx_mod_kernel; the block split counts
-// in units of Qm * N_L bits. y: [nof_sf][nof_ports][max_re].
+// grid = (ceil(max_re / (256 * G)), nof_sf), G = nof_ports: one thread per precoding group (one symbol for TM1, the SFBC pair 2i, 2i+1 for
+// 2 ports, four symbols for 4 ports). Bit e of a code block = coded bit rm[e mod (3K+12)] in the encoder's byte streams, as in
+// pusch_tx_mod_kernel; the block split counts in units of Qm * N_L bits (N_L = 2 with transmit diversity). y: [nof_sf][nof_ports][max_re].
 __global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
                                                            const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
                                                            const uint32_t* __restrict__ scr, cf32* __restrict__ y, PdschTxGeom g)
 {
   const int sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nre = g.cls[sf_class(sf_idx)].nof_re;
-  const int u = blockIdx.x * blockDim.x + threadIdx.x, Gp = nre / g.Nl; // unit index; Gp = G' of 36.212 5.1.4.1.2
-  if (u >= Gp) return;
+  const int grp = blockIdx.x * blockDim.x + threadIdx.x, G = g.nof_ports, Gp = nre / g.Nl; // Gp = G' of 36.212 5.1.4.1.2
+  if (grp * G >= nre) return;
   const int QmL = g.Qm * g.Nl, gamma = Gp % g.C, lo = Gp / g.C, C_lo = g.C - gamma; // blocks 0..C_lo-1 carry lo units, the rest lo + 1 (sch.c:232-236)
-  int       r, e0;
-  if (u < C_lo * lo) {
-    r  = u / lo;
-    e0 = (u - r * lo) * QmL;
-  } else {
-    const int v = u - C_lo * lo;
-    r           = C_lo + v / (lo + 1);
-    e0          = (v % (lo + 1)) * QmL;
-  }
-  const size_t    cbi = (size_t)sf * g.C + r;
-  const uint8_t * xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
-  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
-  cf32            d[2];
-  for (int t = 0; t < g.Nl; t++) {
-    const int q0 = (u * g.Nl + t) * g.Qm;
-    int       re = 0, im = 0;
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
+  cf32            d[4];
+  for (int t = 0; t < G; t++) {
+    const int i = grp * G + t, u = i / g.Nl; // symbol, split unit
+    int       r, e0;
+    if (u < C_lo * lo) {
+      r  = u / lo;
+      e0 = (u - r * lo) * QmL;
+    } else {
+      const int v = u - C_lo * lo;
+      r           = C_lo + v / (lo + 1);
+      e0          = (v % (lo + 1)) * QmL;
+    }
+    e0 += (i % g.Nl) * g.Qm;
+    const size_t   cbi = (size_t)sf * g.C + r;
+    const uint8_t *xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
+    const int      q0 = i * g.Qm;
+    int            re = 0, im = 0;
     for (int b = 0; b < g.Qm; b++) {
-      const uint32_t src = rm[(e0 + t * g.Qm + b) % g.rm_len], pos = src & 0x3fffffffu;
+      const uint32_t src = rm[(e0 + b) % g.rm_len], pos = src & 0x3fffffffu;
       const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
       int            bit  = (byte >> (7 - (pos & 7))) & 1;
       bit ^= (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
@@ -1401,15 +1476,23 @@ __global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __rest
     }
     d[t] = make_float2(g.lvl[re] * g.gain, g.lvl[im] * g.gain);
   }
-  cf32* y0 = y + ((size_t)sf * g.nof_ports) * g.max_re;
-  if (g.Nl == 1) {
-    y0[u] = d[0];
-  } else { // srslte_precoding_diversity, 2 ports (precoding.c:1851-1861): y0 = x0, x1; y1 = -x1*, x0*
-    cf32* y1      = y0 + g.max_re;
-    y0[2 * u]     = d[0];
-    y0[2 * u + 1] = d[1];
-    y1[2 * u]     = make_float2(-d[1].x, d[1].y);
-    y1[2 * u + 1] = make_float2(d[0].x, -d[0].y);
+  cf32*      y0 = y + ((size_t)sf * g.nof_ports) * g.max_re;
+  const cf32 z  = make_float2(0.f, 0.f);
+  if (G == 1) {
+    y0[grp] = d[0];
+  } else if (G == 2) { // srslte_precoding_diversity, 2 ports (precoding.c:1851-1861): y0 = x0, x1; y1 = -x1*, x0*
+    cf32* y1        = y0 + g.max_re;
+    y0[2 * grp]     = d[0];
+    y0[2 * grp + 1] = d[1];
+    y1[2 * grp]     = make_float2(-d[1].x, d[1].y);
+    y1[2 * grp + 1] = make_float2(d[0].x, -d[0].y);
+  } else { // 4 ports (precoding.c:1862-1890): ports 0/2 on sub-carriers 4i, 4i+1, ports 1/3 on 4i+2, 4i+3, the others silent
+    cf32 *y1 = y0 + g.max_re, *y2 = y1 + g.max_re, *y3 = y2 + g.max_re;
+    const int k = 4 * grp;
+    y0[k] = d[0];     y1[k] = z;        y2[k] = make_float2(-d[1].x, d[1].y);     y3[k] = z;
+    y0[k + 1] = d[1]; y1[k + 1] = z;    y2[k + 1] = make_float2(d[0].x, -d[0].y); y3[k + 1] = z;
+    y0[k + 2] = z;    y1[k + 2] = d[2]; y2[k + 2] = z; y3[k + 2] = make_float2(-d[3].x, d[3].y);
+    y0[k + 3] = z;    y1[k + 3] = d[3]; y2[k + 3] = z; y3[k + 3] = make_float2(d[2].x, -d[2].y);
   }
 }
 
@@ -1422,7 +1505,9 @@ __global__ __launch_bounds__(256) void pdsch_tx_map_kernel(const cf32* __restric
   const int sf_idx = (g.tti0 + sf) % 10, v = g.src[sf_class(sf_idx)][port][k];
   cf32      o = make_float2(0.f, 0.f);
   if (v >= 0) o = y[(size_t)sp * g.max_re + v];
-  else if (v <= -2) o = pilots[(size_t)sf_idx * nref4 + (-(v + 2))];
+  else if (v <= -2) { // ports 0/1: [10][4][nref]; ports 2/3: [10][2][nref] behind them (chest.hip)
+    o = port < 2 ? pilots[(size_t)sf_idx * nref4 + (-(v + 2))] : pilots[(size_t)10 * nref4 + (size_t)sf_idx * (nref4 / 2) + (-(v + 2))];
+  }
   grid[(size_t)sp * g.grid_len + k] = o;
 }
 
@@ -1436,7 +1521,7 @@ struct srslte_hip_dl_tx {
   PuschTxGeom            cg; // CRC attachment / segmentation geometry (shared kernels)
   PdschTxGeom            g;
   uint32_t *             d_scr, *d_rm[4], *d_tbcrc, *d_idx[3];
-  int32_t*               d_src[3][2];
+  int32_t*               d_src[3][4];
   uint8_t *              d_cb, *d_parity, *d_sys_tail;
   cf32 *                 d_y, *d_grid;
 };
@@ -1447,10 +1532,14 @@ extern "C" void srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q)
   srslte_hip_ofdm_destroy(q->ofdm);
   srslte_hip_chest_dl_destroy(q->crs);
   void* bufs[] = {q->d_scr, q->d_rm[0], q->d_rm[1], q->d_rm[2], q->d_rm[3], q->d_tbcrc, q->d_idx[0], q->d_idx[1], q->d_idx[2],
-                  q->d_src[0][0], q->d_src[0][1], q->d_src[1][0], q->d_src[1][1], q->d_src[2][0], q->d_src[2][1],
                   q->d_cb, q->d_parity, q->d_sys_tail, q->d_y, q->d_grid};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
+  }
+  for (auto& cls : q->d_src) {
+    for (int32_t* b : cls) {
+      if (b) (void)hipFree(b);
+    }
   }
   delete q;
 }
@@ -1469,7 +1558,7 @@ static int dl_tx_rm_table(srslte_hip_dl_tx_t* q, uint32_t rv)
 
 extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->nof_ports > 2 || cfg->nof_prb < 6 || cfg->nof_prb > 110) {
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->nof_ports > 4 || cfg->nof_ports == 3 || cfg->nof_prb < 6 || cfg->nof_prb > 110) {
     fprintf(stderr, "[srslte_hip] dl_tx: invalid configuration\n");
     return nullptr;
   }
@@ -1499,8 +1588,8 @@ extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cf
     for (uint32_t port = 0; port < npt && ok; port++) {
       std::vector<int32_t> src(glen, -1);
       for (size_t i = 0; i < idx.size(); i++) src[idx[i]] = (int32_t)i;
-      for (int l = 0; l < 4; l++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272), ports 0/1: symbols 0, 4, 7, 11
-        const uint32_t sym = (l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7, fidx = ((((l + port) & 1) ? 3 : 0) + cfg->cell_id % 6) % 6;
+      for (int l = 0; l < (port < 2 ? 4 : 2); l++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272): ports 0/1 symbols 0, 4, 7, 11; ports 2/3 symbols 1, 8
+        const uint32_t sym = port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7), fidx = ((((l + port) & 1) ? 3 : 0) + cfg->cell_id % 6) % 6;
         for (uint32_t i = 0; i < 2 * P; i++) src[sym * nre + fidx + 6 * i] = -(int32_t)(l * 2 * P + i) - 2;
       }
       ok             = upload(&q->d_src[c][port], src) == SRSLTE_SUCCESS;
@@ -1521,7 +1610,7 @@ extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cf
   PuschTxGeom& cg = q->cg;
   cg.C = (int)C; cg.K = (int)K; cg.tbs = (int)cfg->tbs; cg.rlenB = (int)((C == 1 ? K : K - 24) / 8); cg.cb_stride = (int)((K / 8 + 15) & ~15u);
   cg.par_stride = (int)((K / 4 + 1 + 15) & ~15u);
-  g.grid_len = (int)glen; g.max_re = (int)max_re; g.Qm = (int)Qm; g.Nl = npt == 2 ? 2 : 1; g.nof_ports = (int)npt; g.scr_words = (int)scr_words;
+  g.grid_len = (int)glen; g.max_re = (int)max_re; g.Qm = (int)Qm; g.Nl = npt > 1 ? 2 : 1; g.nof_ports = (int)npt; g.scr_words = (int)scr_words;
   g.C = (int)C; g.K = (int)K; g.cb_stride = cg.cb_stride; g.par_stride = cg.par_stride; g.rm_len = (int)(3 * K + 12);
   for (uint32_t idx = 0; idx < (1u << cfg->mod); idx++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
     const int    nb = cfg->mod;
@@ -1578,7 +1667,7 @@ extern "C" int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb
   if (r) return r;
   PdschTxGeom g = q->g;
   g.tti0        = (int)tti0;
-  hipLaunchKernelGGL(pdsch_tx_mod_kernel, dim3(ceil_div(g.max_re / g.Nl, 256), nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
+  hipLaunchKernelGGL(pdsch_tx_mod_kernel, dim3(ceil_div(g.max_re / g.nof_ports, 256), nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
                      (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, (const uint32_t*)q->d_rm[rv], (const uint32_t*)q->d_scr, q->d_y, g);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(pdsch_tx_map_kernel, dim3(ceil_div(g.grid_len, 256), nof_sf * g.nof_ports), dim3(256), 0, st, (const cf32*)q->d_y,

@@ -715,24 +715,26 @@ def test_ul_tx_rx_loop(hp):
     rx.free()
 
 
-@pytest.mark.parametrize("prb,mod,tbs,nrx,snr,llr8,tti0,nsf", [(6, 1, 152, 1, 4.0, False, 0, 10), (25, 2, 4008, 1, 11.0, False, 8, 4), (25, 3, 9912, 2, 13.5, False, 3, 4),
-                                                              (100, 3, 75376, 1, 19.5, False, 4, 3), (50, 2, 11448, 2, 7.0, True, 9, 3),
-                                                              (100, 4, 97896, 2, 24.0, False, 5, 2)])
-def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf):
+@pytest.mark.parametrize("prb,mod,tbs,nrx,snr,llr8,tti0,nsf,npt", [(6, 1, 152, 1, 4.0, False, 0, 10, 2), (25, 2, 4008, 1, 11.0, False, 8, 4, 2), (25, 3, 9912, 2, 13.5, False, 3, 4, 2),
+                                                                  (100, 3, 75376, 1, 19.5, False, 4, 3, 2), (50, 2, 11448, 2, 7.0, True, 9, 3, 2),
+                                                                  (100, 4, 97896, 2, 24.0, False, 5, 2, 2), (6, 1, 152, 1, 5.0, False, 0, 10, 4),
+                                                                  (25, 2, 4008, 2, 9.0, False, 8, 4, 4), (100, 3, 61664, 1, 19.0, False, 4, 3, 4),
+                                                                  (50, 2, 11448, 2, 8.0, True, 9, 3, 4)])
+def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf, npt):
     """TM2 (2-port transmit diversity) receive chain on the device vs the oracle chain on identical IQ: estimates of
     both ports on every antenna, noise, SFBC-combined + layer-demapped symbols, LLRs, pass counts, CRC flags, TB bytes."""
     from lte_sim import DlConfig, make_subframe, oracle_rx
-    rng = np.random.default_rng(1500 + prb + mod + nrx)
-    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=2, llr8=llr8)
+    rng = np.random.default_rng(1500 + prb + mod + nrx + npt)
+    cfg = DlConfig(prb, 7, mod, tbs, nof_rx=nrx, nof_ports=npt, llr8=llr8)
     iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
     hc = hp.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
-    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=2)
+    rx = hp.DlRx(7, prb, 1, 0x1234, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=npt)
     rx.keep_symbols()
     tb, ok = rx.decode(np.stack(iq), tti0)
     C_ = cfg.seg.C
     it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
-    ce = rx.debug(1, np.complex64, nsf * 2 * nrx * cfg.grid_len).reshape(nsf, 2 * nrx, -1)
+    ce = rx.debug(1, np.complex64, nsf * npt * nrx * cfg.grid_len).reshape(nsf, npt * nrx, -1)
     res = rx.debug(2, np.float32, nsf * 10).reshape(nsf, 10)
     max_re = max(rx.nof_re(s) for s in (0, 1, 5))
     d_all = rx.debug(3, np.complex64, nsf * max_re).reshape(nsf, -1)
@@ -741,8 +743,8 @@ def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf):
     for b in range(nsf):
         r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
         nre = rx.nof_re((tti0 + b) % 10)
-        assert nre == len(r["d"]) and nre % 2 == 0
-        for i in range(2 * nrx):
+        assert nre == len(r["d"]) and nre % npt == 0
+        for i in range(npt * nrx):
             assert_close_c(ce[b, i], r["ce"][i], "ce[port %d][antenna %d] sf %d" % (i // nrx, i % nrx, b))
         assert abs(res[b, 0] - r["noise"]) <= 1e-4 * abs(r["noise"])
         assert_close_c(d_all[b, :nre], r["d"], "d sf %d" % b)
@@ -761,7 +763,8 @@ def test_dl_rx_chain_tx_diversity(hp, prb, mod, tbs, nrx, snr, llr8, tti0, nsf):
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8,tti0,nsf", [(6, 1, 152, 1, 1, 3.0, False, 0, 10), (15, 1, 1000, 1, 2, 1.5, False, 4, 4), (25, 2, 4008, 1, 1, 9.0, False, 8, 4),
                                                                   (25, 3, 9912, 2, 2, 12.5, False, 3, 4), (100, 3, 75376, 1, 1, 18.0, False, 4, 3),
                                                                   (25, 2, 4008, 1, 2, 8.5, True, 9, 3), (100, 4, 97896, 2, 1, 23.0, False, 5, 2),
-                                                                  (50, 3, 11448, 2, 1, 7.5, True, 0, 3), (25, 1, 1000, 1, 1, -1.0, False, 2, 3)])
+                                                                  (50, 3, 11448, 2, 1, 7.5, True, 0, 3), (25, 1, 1000, 1, 1, -1.0, False, 2, 3),
+                                                                  (25, 3, 7992, 2, 4, 12.5, False, 3, 4), (15, 2, 2216, 1, 4, 9.0, True, 0, 3)])
 def test_dl_rx_chain_csi_weighting(hp, prb, mod, tbs, nrx, npt, snr, llr8, tti0, nsf):
     """cfg.csi_enable (the srsUE default; csi_correction, pdsch.c:574-690): per-RE channel gains and their subframe maximum from the
     equaliser kernels, the weighting applied inside the rate de-matching kernels; pass counts, CRC flags and TB bytes vs the oracle
@@ -798,7 +801,8 @@ def test_dl_rx_chain_csi_weighting(hp, prb, mod, tbs, nrx, npt, snr, llr8, tti0,
 
 
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(25, 2, 4008, 1, 1, 3.0, False), (100, 3, 75376, 1, 1, 17.2, False), (50, 3, 11448, 1, 2, 8.2, True),
-                                                            (100, 3, 75376, 2, 2, 12.0, False), (6, 1, 152, 1, 1, -6.0, False), (100, 2, 43816, 1, 2, 7.5, False)])
+                                                            (100, 3, 75376, 2, 2, 12.0, False), (6, 1, 152, 1, 1, -6.0, False), (100, 2, 43816, 1, 2, 7.5, False),
+                                                            (50, 3, 30576, 1, 4, 12.5, False)])
 def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
     """HARQ on the device (srslte_hip_dl_rx_batch_harq): four slots, each its own transport block, sent with rv 0, 2, 3, 1 in different
     subframes with fresh noise; soft buffers, per-block CRC flags and bytes persist in the object. Per transmission and slot: CRC
@@ -840,7 +844,8 @@ def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
 
 
 @pytest.mark.parametrize("prb,mod,tbs,npt,tti0,nsf,rv,p_a", [(6, 1, 152, 1, 0, 10, 0, 0.0), (25, 2, 4008, 2, 8, 4, 0, 0.0), (100, 3, 75376, 1, 4, 3, 0, -3.0),
-                                                             (100, 3, 75376, 2, 9, 3, 2, 0.0), (50, 4, 48936, 1, 5, 2, 1, 0.0), (15, 1, 1000, 2, 0, 6, 3, 1.77)])
+                                                             (100, 3, 75376, 2, 9, 3, 2, 0.0), (50, 4, 48936, 1, 5, 2, 1, 0.0), (15, 1, 1000, 2, 0, 6, 3, 1.77),
+                                                             (25, 2, 4008, 4, 8, 4, 0, 0.0), (100, 3, 61664, 4, 4, 3, 2, 0.0), (6, 1, 152, 4, 0, 10, 1, -1.0)])
 def test_dl_tx_chain(hp, prb, mod, tbs, npt, tti0, nsf, rv, p_a):
     """eNB PDSCH transmit chain on the device vs the oracle's stimulus generator (pinned to the reference's
     srslte_pdsch_encode): per-port symbol streams exactly (bits exact, levels are table values), resource grids with CRS, time samples."""
@@ -873,18 +878,19 @@ def test_dl_tx_chain(hp, prb, mod, tbs, npt, tti0, nsf, rv, p_a):
     tx.free()
 
 
-@pytest.mark.parametrize("npt,nrx", [(1, 1), (2, 1), (2, 2)])
+@pytest.mark.parametrize("npt,nrx", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2)])
 def test_dl_tx_rx_loop(hp, npt, nrx):
     """Device transmit chain into the device receive chain (noise-free; the ports of a 2-port cell reach the antennas with different
     flat gains): every transport block comes back; then the same blocks as a HARQ retransmission (rv 2) into the kept soft buffers."""
-    prb, mod, tbs, nsf = 50, 3, 36696, 12
+    prb, mod, tbs, nsf = 50, 3, 30576, 12
     rng = np.random.default_rng(78)
     data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
     tx = hp.DlTx(5, prb, 1, 0x4321, mod, tbs, nsf, npt)
     hc = hp.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
     rx = hp.DlRx(5, prb, 1, 0x4321, mod, tbs, 6, nsf, True, hc, nof_rx=nrx, nof_ports=npt, power_scale=True, p_a=0.0)  # phy_dl_test.c:176-178,:219-221
-    gains = np.array([[1.0, 0.7 * np.exp(1.1j)], [0.8 * np.exp(-0.6j), 0.9 * np.exp(2.2j)]], np.complex64)  # [antenna][port]
+    gains = np.array([[1.0, 0.7 * np.exp(1.1j), 0.9 * np.exp(-2.0j), 0.6 * np.exp(0.4j)],
+                      [0.8 * np.exp(-0.6j), 0.9 * np.exp(2.2j), 0.7 * np.exp(1.5j), 1.1 * np.exp(-1.2j)]], np.complex64)  # [antenna][port]
     for rv, new in ((0, True), (2, False)):
         iq = tx.encode(data, 3, rv)  # [nsf][npt][sf_len]
         ant = np.stack([sum(gains[a, port] * iq[:, port] for port in range(npt)) for a in range(nrx)], axis=1)  # [nsf][nrx][sf_len]
