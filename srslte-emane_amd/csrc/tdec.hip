@@ -309,10 +309,10 @@ constexpr int ST_TOTAL = 2 * ST_BUF + ST_ARR;     // two buffers + zeros
 template <int W>
 constexpr int pairs_per_step() { return W == 32 ? 16 : 8; }
 struct Src {                 // global arrays of one SISO pass, offset to the first pair of the half being processed
-  const pk_t *x, *y, *xy;
+  const pk_t *x, *y;         // x + y is not an array: it is formed when the rows are staged (one saturating add per dword)
 };
 struct StRegs {
-  int4 a, b, c;
+  int4 a, b;
 };
 struct Stage {               // per-lane view of the staging area
   pk_t* lds;
@@ -342,7 +342,6 @@ __device__ __forceinline__ StRegs stage_load(const Src& S, const Stage& st, int 
   StRegs    r;
   r.a = *reinterpret_cast<const int4*>(S.x + off);
   r.b = *reinterpret_cast<const int4*>(S.y + off);
-  r.c = *reinterpret_cast<const int4*>(S.xy + off);
   return r;
 }
 __device__ __forceinline__ void stage_store(const Stage& st, int buf, int n, const StRegs& r)
@@ -351,7 +350,9 @@ __device__ __forceinline__ void stage_store(const Stage& st, int buf, int n, con
     pk_t* d = st.lds + buf * ST_BUF + st.sj * 8 + st.sp * 4;
     *reinterpret_cast<int4*>(d)              = r.a;
     *reinterpret_cast<int4*>(d + ST_ARR)     = r.b;
-    *reinterpret_cast<int4*>(d + 2 * ST_ARR) = r.c;
+    // x + y (turbodecoder_win.h:472-491), saturating; for the 8-bit back-ends a 0x7fff here is harmless (see M8)
+    *reinterpret_cast<int4*>(d + 2 * ST_ARR) =
+        make_int4(pk_add<true>(r.a.x, r.b.x), pk_add<true>(r.a.y, r.b.y), pk_add<true>(r.a.z, r.b.z), pk_add<true>(r.a.w, r.b.w));
   }
   // One wavefront per workgroup and the LDS executes a wave's instructions in order: the reads that follow see these writes.
   // Only the compiler has to be kept from reordering them; a __syncthreads() here would also drain vmcnt, i.e. wait for the
@@ -498,11 +499,12 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   const int     bstride = (top + 1) * 64;     // checkpoint columns of one half
 
   // ---- combine pass (turbodecoder_win.h:472-491): the four branch metrics of a step are 0, x = sat(app + syst), y = parity and
-  //      x + y. Only what is not already an array in the decoder's order is written: x + y always; x when there is a-priori
-  //      information to add; x and y too where the inputs are not packed pairs (8 windows) or need the 8-bit representation.
+  //      x + y. Only what is not already an array in the decoder's order is written: x when there is a-priori information to
+  //      add; x and y too where the inputs are not packed pairs (8 windows) or need the 8-bit representation. x + y is formed when
+  //      the rows are staged into LDS (stage_store): as an array it cost one write and two reads of K values per pass.
   constexpr bool DIRECT = W != 8 && !AR;
   const int      NE     = G * Lw;
-  pk_t *         XY = scratch, *Xb = scratch + NE, *Yb = scratch + 2 * NE;
+  pk_t *         Xb = scratch + NE, *Yb = scratch + 2 * NE;
   const pk_t*    Xs = DIRECT && !app ? reinterpret_cast<const pk_t*>(in) : Xb;
   const pk_t*    Ys = DIRECT ? reinterpret_cast<const pk_t*>(par) : Yb;
   if constexpr (W == 8) {
@@ -512,29 +514,27 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
           const pk_t x = app ? s_add<AR>(t.b, t.a) : t.a;
           Xb[i]        = x;
           Yb[i]        = t.c;
-          XY[i]        = pk_add<true>(x, t.c);
         });
-  } else { // four window pairs (16 bytes) per lane and memory instruction; NE is a multiple of 4
+  } else if (!DIRECT || app) { // four window pairs (16 bytes) per lane and memory instruction; NE is a multiple of 4
     struct Q3 { int4 a, b, c; };
     auto hi8 = [](int4 v) { // AR: int8 values in int16 containers -> high bytes (see ld_pair)
       return AR ? make_int4((v.x & 0x00FF00FF) << 8, (v.y & 0x00FF00FF) << 8, (v.z & 0x00FF00FF) << 8, (v.w & 0x00FF00FF) << 8) : v;
     };
     const int4 *in4 = reinterpret_cast<const int4*>(in), *app4 = reinterpret_cast<const int4*>(app), *par4 = reinterpret_cast<const int4*>(par);
-    int4 *      X4 = reinterpret_cast<int4*>(Xb), *Y4 = reinterpret_cast<int4*>(Yb), *XY4 = reinterpret_cast<int4*>(XY);
+    int4 *      X4 = reinterpret_cast<int4*>(Xb), *Y4 = reinterpret_cast<int4*>(Yb);
     batched<TDEC_EWU>(
-        L.lane, NE / 4, [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), hi8(par4[i])}; },
+        L.lane, NE / 4,
+        [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), DIRECT ? make_int4(0, 0, 0, 0) : hi8(par4[i])}; },
         [&](int i, Q3 t) {
           const int4 x = app ? make_int4(s_add<AR>(t.b.x, t.a.x), s_add<AR>(t.b.y, t.a.y), s_add<AR>(t.b.z, t.a.z), s_add<AR>(t.b.w, t.a.w)) : t.a;
-          if (!DIRECT || app) X4[i] = x;
+          X4[i] = x;
           if (!DIRECT) Y4[i] = t.c;
-          // AR: a 0x7fff in x + y is harmless (see M8)
-          XY4[i] = make_int4(pk_add<true>(x.x, t.c.x), pk_add<true>(x.y, t.c.y), pk_add<true>(x.z, t.c.z), pk_add<true>(x.w, t.c.w));
         });
   }
   __syncthreads();
   Src S[NH];
 #pragma unroll
-  for (int h = 0; h < NH; h++) S[h] = Src{Xs + h * 8, Ys + h * 8, XY + h * 8};
+  for (int h = 0; h < NH; h++) S[h] = Src{Xs + h * 8, Ys + h * 8};
   PROF(2)
 
   // ---- beta warm-up over the first 40 steps of every window (turbodecoder_win.h:456-464); positions are fixed: all static
