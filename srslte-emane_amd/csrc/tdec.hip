@@ -832,6 +832,8 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   bool           ok     = false;
   const int16_t* dec    = ext1;
   while (n_iter < a.nof_iter && !ok) {
+    uint32_t syn_fused = 0;
+    bool     have_syn  = false;
     if ((n_iter & 1) == 0) {
       if (n_iter) {
         batched<EWU>(
@@ -865,13 +867,31 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
             for (int j = 0; j < 8; j++) perm[t.c[j]] = t.a[j];
           });
       __syncthreads();
-      for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app1, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
+      if (a.t.crc_rem) { // the interleaved extrinsic values are this pass's decision metrics: their CRC syndrome (below) is taken on the way out
+        batched<EWU>(
+            L.lane, K8,
+            [&](int i8) {
+              const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
+              return V8W{*reinterpret_cast<const v8s*>(perm + 8 * i8), tp[0], tp[1]};
+            },
+            [&](int i8, V8W t) {
+              st8(app1, i8, t.a);
+#pragma unroll
+              for (int j = 0; j < 4; j++) syn_fused ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+            });
+        have_syn = true;
+      } else {
+        for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app1, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
+      }
       dec = app1;
     }
     __syncthreads();
     n_iter++;
     PROF(1)
-    if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
+    if (a.t.crc_rem && have_syn) {
+      for (int o = 32; o > 0; o >>= 1) syn_fused ^= __shfl_xor(syn_fused, o, 64);
+      ok = syn_fused == 0 && !(a.dbg & (1 | 16));
+    } else if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
       uint32_t syn = 0;
       batched<EWU>(
           L.lane, K8,
