@@ -269,16 +269,16 @@ def main():
                      "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,
                      "note": "serial-trellis integer kernel: not HBM-bound by construction (SURVEY §8d); streaming kernels are in 'kernels'",
-                     # what does bound it: VALU issue. Instructions per wave from the committed SQ counters (profiles/r01_pmc/final5_tdec_sq_*,
-                     # 64.4 k at 4.23 passes per block; scaled to this run's pass count), one wave per code block, 64 lanes; peak = 256 CUs x
+                     # what does bound it: VALU issue. Instructions per wave from the committed SQ counters (profiles/r01_pmc/final7_tdec_sq_*,
+                     # 65.9 k at 4.23 passes per block; scaled to this run's pass count), one wave per code block, 64 lanes; peak = 256 CUs x
                      # 4 SIMDs x 16 lanes per clock at the 2.4 GHz boost clock. Launches overlap on the three streams, so the per-launch
                      # duration understates the device-wide rate: 'valu_frac_step' uses the whole step time instead.
                      "valu": None if args.llr8 else {
-                         "instr_per_wave": int(64400 * (it_all / (n_all * 13)) / 4.23), "waves": B * 13,
-                         "lane_instr_per_s": round(64400 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (tdec_ms * 1e-3) / 1e12, 2),
+                         "instr_per_wave": int(65950 * (it_all / (n_all * 13)) / 4.23), "waves": B * 13,
+                         "lane_instr_per_s": round(65950 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (tdec_ms * 1e-3) / 1e12, 2),
                          "peak_lane_instr_per_s": round(256 * 4 * 16 * 2.4e9 / 1e12, 2), "unit": "T lane-instr/s",
-                         "valu_frac_launch": round(64400 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (tdec_ms * 1e-3) / (256 * 4 * 16 * 2.4e9), 3),
-                         "valu_frac_step": round(64400 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (ms_per_step * 1e-3) / (256 * 4 * 16 * 2.4e9), 3)}},
+                         "valu_frac_launch": round(65950 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (tdec_ms * 1e-3) / (256 * 4 * 16 * 2.4e9), 3),
+                         "valu_frac_step": round(65950 * (it_all / (n_all * 13)) / 4.23 * 64 * B * 13 / (ms_per_step * 1e-3) / (256 * 4 * 16 * 2.4e9), 3)}},
         "kernels": kernels,
         "kernels_large_batch": big,
         "cpu_baseline": cpu,
