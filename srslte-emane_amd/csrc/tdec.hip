@@ -308,6 +308,7 @@ constexpr int ST_BUF   = 3 * ST_ARR;              // x, y, x + y
 constexpr int ST_TOTAL = 2 * ST_BUF + ST_ARR;     // two buffers + zeros
 template <int W>
 constexpr int pairs_per_step() { return W == 32 ? 16 : 8; }
+typedef int v8i __attribute__((ext_vector_type(8)));
 struct Src {                 // global arrays of one SISO pass, offset to the first pair of the half being processed
   const pk_t *x, *y;         // x + y is not an array: it is formed when the rows are staged (one saturating add per dword)
 };
@@ -316,7 +317,9 @@ struct StRegs {
 };
 struct Stage {               // per-lane view of the staging area
   pk_t* lds;
-  int   rb[2][3];            // read base (dword index) per buffer and trellis phase: array of the slot's own metric + own pair
+  v8i   rb;                  // [buffer * 3 + trellis phase] read base (dword index): array of the slot's own metric + own pair. A vector
+                             // VALUE, not an int array: indexing an array with the run-time buffer number turns the struct into an
+                             // alloca that the compiler parks in LDS (2.5 KB per wavefront and a ds_read per use) or in scratch
   int   sj, sp;              // copy role: row (step) lane >> 1, half row lane & 1
 };
 __device__ __forceinline__ void stage_init(Stage& st, pk_t* lds, const LaneGeom& L)
@@ -330,7 +333,7 @@ __device__ __forceinline__ void stage_init(Stage& st, pk_t* lds, const LaneGeom&
 #pragma unroll
     for (int ph = 0; ph < 3; ph++) {
       const int ix = L.io[ph];
-      st.rb[b][ph] = (ix == 0 ? 2 * ST_BUF : b * ST_BUF + (ix - 1) * ST_ARR) + L.g;
+      st.rb[b * 3 + ph] = (ix == 0 ? 2 * ST_BUF : b * ST_BUF + (ix - 1) * ST_ARR) + L.g;
     }
   }
 }
@@ -362,7 +365,9 @@ __device__ __forceinline__ void stage_store(const Stage& st, int buf, int n, con
 // metric of the step staged at row jj, phase ph
 __device__ __forceinline__ pk_t stage_get(const Stage& st, int buf, int ph, int jj)
 {
-  return st.lds[(ph == 0 ? st.rb[buf][0] : (ph == 1 ? st.rb[buf][1] : st.rb[buf][2])) + jj * 8];
+  const v8i r = st.rb; // constant-index extracts and selects only: a run-time vector index goes through scratch
+  const int b0 = buf ? r[3] : r[0], b1 = buf ? r[4] : r[1], b2 = buf ? r[5] : r[2];
+  return st.lds[(ph == 0 ? b0 : (ph == 1 ? b1 : b2)) + jj * 8];
 }
 
 // nb blocks of BLK steps (BLK a multiple of 6 so that trellis phase and normalisation parity are compile-time), first
@@ -392,7 +397,7 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const Src& S
 #pragma unroll
     for (int j = 0; j < BLK; j++) {
       const int ph = DIR > 0 ? (PH0 + j) % 3 : (PH0 + 3 * BLK - j) % 3; // static after unrolling
-      c[j]         = st.lds[st.rb[buf][ph] + (DIR > 0 ? j : BLK - 1 - j) * 8];
+      c[j]         = st.lds[(buf ? st.rb[3 + ph] : st.rb[ph]) + (DIR > 0 ? j : BLK - 1 - j) * 8];
     }
 #pragma unroll
     for (int j6 = 0; j6 < BLK; j6 += 6) {
@@ -486,7 +491,7 @@ __device__ __forceinline__ void st8(int16_t* p, int i8, v8s v) { *reinterpret_ca
 // pairs. W = 32 (avx8): the wave handles the windows as NH = 2 halves of 16, one after the other in every phase - the windows
 // only meet in the two hand-overs, which see both halves' registers.
 template <int W, int AR>
-__device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
+__device__ __forceinline__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
                          pk_t* __restrict__ beta, pk_t* __restrict__ seg, pk_t* __restrict__ scratch, const Stage& st, int K PROF_ARGS)
 {
@@ -658,7 +663,7 @@ __device__ void win_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
       if (j + 2 < nf) sr2 = stage_load<G>(S[h], st, k0 + 2 * CKPT, CKPT); // two segments of rows in flight
       pk_t c[CKPT];
 #pragma unroll
-      for (int i = 0; i < CKPT; i++) c[i] = st.lds[st.rb[buf][i % 3] + i * 8]; // phase (k0 + i) % 3 = i % 3
+      for (int i = 0; i < CKPT; i++) c[i] = st.lds[(buf ? st.rb[3 + i % 3] : st.rb[i % 3]) + i * 8]; // phase (k0 + i) % 3 = i % 3
       const pk_t Btop = bh[(j + 1) * 64 + L.lane]; // beta[k0 + CKPT], as stored (before its normalisation)
       pk_t       vb   = Btop, dummy = 0;
       if (k0 + CKPT < Lw) win_normalize<AR>(vb); // the recursion continued from the normalised value (counter != 0); beta[Lw] is a start value
