@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline time budget (whole passes over the batch)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--llr8", action="store_true", help="8-bit LLR path (SURVEY §8f N2: demod_b, rm_turbo_rx_lut_8bit, avx8 decoder) instead of the 16-bit one")
-    ap.add_argument("--streams", type=int, default=3, help="pipeline instances / HIP streams that consecutive steps alternate over")
+    ap.add_argument("--streams", type=int, default=4, help="pipeline instances / HIP streams that consecutive steps alternate over")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --force-device 0 rehearses N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="use this GPU for every rank (rehearsal only)")
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
@@ -108,7 +108,7 @@ def main():
 
     hc = pkg.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0  # phy_dl_test.c:587-595
-    # Two pipeline instances on two HIP streams: consecutive steps (independent batches) alternate between them, so the
+    # Several pipeline instances (--streams, default 4) on as many HIP streams: consecutive steps (independent batches) alternate between them, so the
     # next batch's kernels fill the SIMDs that the previous batch's turbo-decoder tail (blocks needing all 6 passes) leaves idle.
     nstreams = max(1, args.streams)
     rxs = [pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc, llr_8bit=args.llr8) for _ in range(nstreams)]
