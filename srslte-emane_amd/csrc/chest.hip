@@ -1,13 +1,15 @@
 // Downlink channel estimator for gfx950: srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for FDD normal
-// subframes, tx ports 0/1 x up to 4 rx antennas, one (subframe, port, antenna) per workgroup, batched over subframes.
+// subframes, 1-, 2- and 4-port cells x up to 4 rx antennas, one (subframe, port, antenna) per workgroup, batched over
+// subframes. (The uplink estimator for the PUSCH DMRS is further down.)
 //
-// One workgroup per subframe fuses what the reference does in ~30 short vector calls: pilot gather + LS
+// A workgroup fuses what the reference does in ~30 short vector calls: pilot gather + LS
 // (refsignal_dl.c:275-295, chest_dl.c:689-690), RSRP/RSSI/CFO reductions (:558-596, :710-711), noise from
 // pilots (:304-379 — only the last symbol's residual survives upstream's '=' at :374, so only that one is
 // computed), Gauss/triangle smoothing with optional time averaging (:513-556, chest_common.c:62-88,
 // convolution.c:180-218 "extrapolates extremes" variant) and linear interpolation in frequency and time
-// (:415-511, interp.c:145-168,240-267). Pilot estimates stay in LDS; HBM traffic is the 4 pilot-bearing symbols
-// in and the 14-symbol estimate out (store-bound, coalesced one RE per thread).
+// (:415-511, interp.c:145-168,240-267), plus the optional sync-error and neighbour-cell measurements (:692-709). Pilot
+// estimates stay in LDS; HBM traffic is the pilot-bearing symbols in and the 14-symbol estimate out (store-bound,
+// coalesced one RE per thread). chest_fill_res_kernel combines the per-(port, antenna) scalars the way fill_res does.
 #include "common.hpp"
 #include "phy_hip_internal.hpp"
 #include <math.h>
