@@ -77,7 +77,9 @@ struct ChestState {
   DevStage               grid, ce, res;
 };
 
-DevStage g_demod_in, g_demod_out, g_tcod_in, g_tcod_out; // demod/tcod have no object to hang state on (one host thread at a time)
+// demod/tcod calls have no object to hang device staging on: one set per host thread, so that worker threads can call them
+// concurrently as they can upstream (SURVEY §8b "Threading")
+thread_local DevStage g_demod_in, g_demod_out, g_tcod_in, g_tcod_out;
 
 int cp_nsymb(srslte_cp_t cp) { return cp == SRSLTE_CP_NORM ? 7 : 6; }
 

@@ -455,3 +455,63 @@ def test_chest_dl_object_sync_error_and_neighbour_rsrp():
         assert abs(rres.sync_error - delay) < 0.05  # timing error in samples
     L.srslte_chest_dl_res_free(C.byref(res))
     L.srslte_chest_dl_free(est)
+
+
+def test_concurrent_host_threads():
+    """SURVEY §8b "Threading": the single-call API is used from several worker threads at once, each with its own objects; the
+    object-less demapper calls must be re-entrant too. Four threads run demapper + OFDM round trip + channel estimator concurrently
+    (ctypes releases the GIL inside the calls); every result is checked against the oracle."""
+    import threading
+    L = hip()
+    errors = []
+
+    def worker(tid):
+        try:
+            rng = np.random.default_rng(500 + tid)
+            prb = (6, 15, 25, 50)[tid]
+            n = 14 * 12 * prb
+            ifft, fft = opaque(1 << 12), opaque(1 << 12)
+            N = oracle().orc_symbol_sz(prb)
+            a, t, b = aligned(2 * n, np.float32), aligned(2 * 15 * N, np.float32), aligned(2 * n, np.float32)
+            assert L.srslte_ofdm_tx_init(ifft, 0, p(a), p(t), prb) == 0 and L.srslte_ofdm_rx_init(fft, 0, p(t), p(b), prb) == 0
+            L.srslte_ofdm_set_normalize(ifft, True)
+            L.srslte_ofdm_set_normalize(fft, True)
+            est, res = opaque(1 << 16), RefChestRes()
+            assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, 10 + tid, 0, 0, 0, 0)) == 0
+            assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+            cell = OrcCell(10 + tid, prb, 1, True)
+            for it in range(6):
+                mod = 1 + (tid + it) % 4
+                nsym = 1000 + 37 * tid + it
+                x = acopy((rng.standard_normal(2 * nsym) * 0.8).astype(np.float32))
+                l1, l2 = aligned(nsym * 2 * mod + 64, np.int16), aligned(nsym * 2 * mod + 64, np.int16)
+                assert L.srslte_demod_soft_demodulate_s(mod, p(x), p(l1), nsym) == 0
+                oracle().orc_demod_soft_s(mod, p(x), p(l2), nsym)
+                assert np.array_equal(l1, l2), ("demod", tid, it)
+                a[:] = rng.standard_normal(2 * n).astype(np.float32)
+                L.srslte_ofdm_tx_sf(ifft)
+                L.srslte_ofdm_rx_sf(fft)
+                assert close(b, a), ("ofdm", tid, it)
+                g = np.array(a).view(np.complex64).copy()
+                oracle().orc_crs_put_sf(C.byref(cell), it, 0, p(g))
+                grid = acopy((g * (2.0 + tid) + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+                sf = RefDlSfCfg()
+                sf.tti = it
+                assert L.srslte_chest_dl_estimate(est, C.byref(sf), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+                ref, rres, oc = np.zeros(n, np.complex64), OrcChestRes(), OrcChestCfg()
+                assert oracle().orc_chest_dl(C.byref(cell), it, C.byref(oc), p(grid), p(ref), C.byref(rres)) == 0
+                ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+                assert close(ce, ref), ("chest", tid, it)
+            L.srslte_chest_dl_res_free(C.byref(res))
+            L.srslte_chest_dl_free(est)
+            L.srslte_ofdm_tx_free(ifft)
+            L.srslte_ofdm_rx_free(fft)
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
