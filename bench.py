@@ -268,6 +268,9 @@ def main():
         "roofline": {"kernel": "tdec_win_kernel<32, 1>" if args.llr8 else "tdec_win_kernel<16, 0>", "bound": "hbm", "achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_ms": round(tdec_ms, 4), "algorithmic_bytes_per_launch": tdec_alg,
+                     # the events bracket the launch on its own stream: with several streams they include the time its workgroups queue
+                     # behind the other streams' kernels (rocprof's kernel duration starts at the first wave). Alone on the device:
+                     "avg_launch_ms_alone": kernels["tdec"]["ms"],
                      "note": "serial-trellis integer kernel: not HBM-bound by construction (SURVEY §8d); streaming kernels are in 'kernels'",
                      # what does bound it: VALU issue. Instructions per wave from the committed SQ counters (profiles/r01_pmc/final7_tdec_sq_*,
                      # 65.9 k at 4.23 passes per block; scaled to this run's pass count), one wave per code block, 64 lanes; peak = 256 CUs x
