@@ -913,22 +913,16 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
     }
   }
   PROF(7)
-  // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838)
-  uint8_t* o = a.out + (size_t)cb * a.out_stride;
-  batched<2>(
-      L.lane, K / 8,
-      [&](int b) {
-        uint32_t byte = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) byte |= (dec[win_pos<W>(8 * b + j, K)] > 0 ? 0x80u : 0u) >> j;
-        return byte;
-      },
-      [&](int b, uint32_t byte) { o[b] = (uint8_t)byte; });
-  // ---- this block's share of the transport-block CRC24A syndrome (sch.c:470-488): XOR over its set payload bits of
-  //      x^(position in the TB) mod g, from a table in the decoder's array order; the TB check then is an XOR of C words
-  uint32_t tsyn = 0;
-  if (a.tb_rem) {
-    const uint32_t* tab = a.tb_rem + (size_t)(cb % a.tb_C) * K;
+  // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838), and this block's share of the
+  //      transport-block CRC24A syndrome (sch.c:470-488): XOR over its set payload bits of x^(position in the TB) mod g, from a table in
+  //      the decoder's array order; the TB check then is an XOR of C words. One sweep over the decision metrics in array order feeds
+  //      both: the syndrome directly, the bytes through LDS (consecutive bits are W elements apart in the array: as 2-byte global
+  //      gathers they cost the L1 a cache line per lane).
+  uint8_t*        o    = a.out + (size_t)cb * a.out_stride;
+  uint32_t        tsyn = 0;
+  const uint32_t* tab  = a.tb_rem ? a.tb_rem + (size_t)(cb % a.tb_C) * K : nullptr;
+  __syncthreads(); // perm is free again
+  if (tab) {
     batched<TDEC_EWU>(
         L.lane, K / 8,
         [&](int i8) {
@@ -936,10 +930,31 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
           return V8W{ld8(dec, i8), tp[0], tp[1]};
         },
         [&](int i8, V8W t) {
+          *reinterpret_cast<v8s*>(perm + 8 * i8) = t.a;
 #pragma unroll
           for (int j = 0; j < 4; j++) tsyn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
         });
     for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
+  } else {
+    for (int i8 = L.lane; i8 < K8; i8 += 64) *reinterpret_cast<v8s*>(perm + 8 * i8) = ld8(dec, i8);
+  }
+  __syncthreads();
+  {
+    const int      Lw    = K / W;
+    const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw); // n / Lw = (n * magic) >> 32 for n < 2^32 / Lw
+    for (int b = L.lane; b < K8; b += 64) {
+      int      q = (int)__umulhi((uint32_t)(8 * b), magic), r = 8 * b - q * Lw; // natural index n -> array position (n % Lw) * W + n / Lw
+      uint32_t byte = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        byte |= (perm[r * W + q] > 0 ? 0x80u : 0u) >> j;
+        if (++r == Lw) {
+          r = 0;
+          q++;
+        }
+      }
+      o[b] = (uint8_t)byte;
+    }
   }
   PROF(8)
   if (L.lane == 0) {
