@@ -169,7 +169,7 @@ int orc_tcod_encode_bytes(uint8_t* sys, uint8_t* par, uint32_t K)
 { /* turbocoder.c:189-371 output format: sys[K/8] = tail nibble of stream 0 in the high 4 bits;
      par = [p0: K bits | 4 tail bits of stream 1 | p1: K bits | 4 tail bits of stream 2], MSB first.
      CRC fusion (turbocoder.c:205-283) is done by the caller in this restatement (orc_dlsch_encode). */
-  uint8_t* bits = malloc(K);
+  uint8_t* bits = calloc(K ? K : 1, 1);
   uint8_t* enc  = malloc(3 * K + 12);
   for (uint32_t i = 0; i < K; i++) {
     bits[i] = getbit(sys, i);

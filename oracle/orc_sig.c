@@ -208,7 +208,7 @@ int orc_fft(const orc_cf_t* in, orc_cf_t* out, int N, int forward)
     int R = p->radix[f], nb = N / R;
     for (int j = 0; j < nb; j++) {
       int      k = j % Ns;
-      orc_cf_t v[5];
+      orc_cf_t v[5] = {{0, 0}};
       for (int r = 0; r < R; r++) {
         orc_cf_t w = p->tw[((long long)r * k * (N / (Ns * R))) % N];
         if (!forward) w.im = -w.im;
