@@ -751,8 +751,8 @@ int srslte_tdec_new_cb(srslte_tdec_t* h, uint32_t long_cb)
 // One call = `passes` SISO passes from the unchanged input. The back-end follows turbodecoder.c:438-520: AUTO picks per K
 // and per LLR width; a manual type fixes width and window count, and the other API width is converted with a C cast
 // (convert_8_to_16 / convert_16_to_8, :451-463).
-static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t passes)
-{
+static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t passes, uint32_t start = 0)
+{ // start > 0: passes 0..start-1 were run by the previous call on this object for this code block; only the rest is run
   auto*          st = (TdecState*)h->dec16_hdlr[0];
   const uint32_t K  = h->current_long_cb;
   int            W  = -1;   // AUTO
@@ -784,16 +784,17 @@ static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* 
     for (uint32_t i = 0; i < len; i++) c[i] = ((const int8_t*)input)[i];
     if (!h2d(di, c.data(), len * 2)) return SRSLTE_ERROR;
   }
+  tdec_set_resume(st->h, start);
   if (tdec_run_batch_w(st->h, di, dec8 ? 1 : 0, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, nullptr))
     return SRSLTE_ERROR;
   return d2h(output, dout, K / 8) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 
 static void tdec_one_more(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output)
-{ // turbodecoder.c:539-545,:565-571. One more SISO pass: the device re-runs passes 1..n_iter+1 from the unchanged input, which is
-  // bit-identical to continuing the previous state (the schedule is deterministic) and keeps the object stateless on device.
+{ // turbodecoder.c:539-545,:565-571. One more SISO pass: the decoder's work arrays for this object's block slot stay on the device
+  // between calls, so pass n_iter continues from them (the input is uploaded again: upstream reads it on every pass too).
   if (h->current_cbidx >= 0) {
-    if (tdec_passes(h, input, api8, output, (uint32_t)h->n_iter + 1) == SRSLTE_SUCCESS) h->n_iter++;
+    if (tdec_passes(h, input, api8, output, (uint32_t)h->n_iter + 1, (uint32_t)h->n_iter) == SRSLTE_SUCCESS) h->n_iter++;
   } else {
     ERROR("Error CB index not set (call srslte_tdec_new_cb() first");
   }

@@ -35,6 +35,9 @@ int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmr
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);
 // tdec.hip: blocks with d_skip[cb] != 0 are left alone by the following runs: bytes, CRC flag, TB-CRC share stay (nullptr: off)
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip);
+// tdec.hip: the NEXT run continues blocks whose passes 0..start_iter-1 the previous run on this object did (same inputs, same block
+// slots): srslte_tdec_iteration's one-more-pass without redoing the earlier ones (turbodecoder.c:539-545)
+void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter);
 // tdec.hip: srslte_hip_tdec_run_batch with an optional forced back-end (force_w = -1 auto, 0 generic, 8, 16, 32 with llr8);
 // llr8: d_input is int8 and the 8-bit numerics / fall-backs of turbodecoder.c:438-487 apply
 int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,

@@ -224,6 +224,7 @@ struct TdecArgs {
   const uint32_t* tb_rem;      // optional [tb_C][K] remainders for the TB CRC share of each block (array order), else nullptr
   uint32_t        tb_C;
   uint32_t*       tb_syn;      // [nof_cb] out
+  uint32_t        start_iter;  // passes 0..start_iter-1 were run by the previous launch on these blocks (same input, work arrays untouched): resume
   const uint8_t*  skip;        // optional [nof_cb]: blocks whose CRC passed in an earlier transmission keep their bytes and flags (sch.c:317-318)
   unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   };
   const int K8 = K / 8;
   constexpr int EWU = TDEC_EWU; // 16-byte elements in flight per lane in the element-wise phases
-  uint32_t       n_iter = 0;
+  uint32_t       n_iter = a.start_iter; // > 0: the work arrays hold the state after that many passes (tdec_set_resume)
   bool           ok     = false;
   const int16_t* dec    = ext1;
   while (n_iter < a.nof_iter && !ok) {
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
   bool           use_app1 = false;
   const uint32_t nbytes   = K / 8;
   uint8_t*       o        = a.out + (size_t)cb * a.out_stride;
-  for (uint32_t n_iter = 0; n_iter < a.nof_iter; n_iter++) {
+  for (uint32_t n_iter = a.start_iter; n_iter < a.nof_iter; n_iter++) {
     const bool run = active && !ok;
     if ((n_iter & 1) == 0) {
       if (n_iter && run) {
@@ -1139,6 +1140,7 @@ struct srslte_hip_tdec {
   uint32_t                 tb_C   = 0;
   uint32_t*                tb_syn = nullptr;
   const uint8_t*           skip   = nullptr; // see tdec_set_skip
+  uint32_t                 start_iter = 0;   // see tdec_set_resume; consumed by the next run
   std::mutex               mtx;
 };
 
@@ -1244,6 +1246,7 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
 }
 
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip) { q->skip = d_skip; }
+void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter) { q->start_iter = start_iter; }
 
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn)
 { // windowed decoders only; the caller (pdsch.hip) builds d_rem in the decoder's array order
@@ -1296,6 +1299,8 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   a.tb_rem = W ? q->tb_rem : nullptr; a.tb_C = q->tb_C ? q->tb_C : 1; a.tb_syn = q->tb_syn;
   a.skip = q->skip;
+  a.start_iter = q->start_iter < nof_iterations ? q->start_iter : 0;
+  q->start_iter = 0;
   a.prof = nullptr;
 #ifdef TDEC_PROF
   static unsigned long long* d_prof = nullptr;
