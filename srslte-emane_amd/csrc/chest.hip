@@ -491,6 +491,73 @@ namespace {
 const uint32_t N_DMRS_1[8] = {0, 2, 3, 4, 6, 8, 9, 10}; // 36.211 Table 5.5.2.1.1-2 (refsignal_ul.c:42)
 const uint32_t N_DMRS_2[8] = {0, 6, 3, 4, 2, 8, 10, 9}; // 36.211 Table 5.5.2.1.1-1 (refsignal_ul.c:39)
 
+// 36.211 Tables 5.5.1.2-1 and 5.5.1.2-2: phi(n) of the QPSK base sequences for M_sc = 12 and 24 (one and two PRB), one string per
+// group u; digit d stands for phi = 2 d - 3, i.e. 0 1 2 3 = -3 -1 +1 +3 (the reference keeps them as int arrays, ul_rs_tables.h)
+const char* const PHI_12[30] = {
+    "123033223203",
+    "223331200203",
+    "220001002021",
+    "122221002031",
+    "132121012123",
+    "203112211302",
+    "130003213302",
+    "011120312032",
+    "203211122312",
+    "201331022222",
+    "131220010031",
+    "321133023233",
+    "202202220002",
+    "330302231033",
+    "021013233312",
+    "312011223210",
+    "232123331131",
+    "022303003231",
+    "032202001120",
+    "132321130101",
+    "102222321201",
+    "131200000210",
+    "220000130203",
+    "221010212312",
+    "223233121002",
+    "203323320113",
+    "230030211310",
+    "010103212300",
+    "130313303311",
+    "300110130321",
+};
+const char* const PHI_24[30] = {
+    "132031230323032212303010",
+    "030002003122232130023220",
+    "313322033332131221011233",
+    "102230220112323213220101",
+    "111001223313121021002011",
+    "022312320202211310300022",
+    "221130030211212210121310",
+    "033110132323221321230112",
+    "023021030311112000200020",
+    "220331013033312202122022",
+    "120031311000100212331213",
+    "233002321000330331031202",
+    "233222112031220331030101",
+    "311110133212333122023103",
+    "003232032322331102013223",
+    "112023021013232100110001",
+    "103111122032332120202201",
+    "231331021033312231013111",
+    "222221310223020122003220",
+    "233210313330212101231300",
+    "103000110103230131213021",
+    "002212121320121211330120",
+    "010321010030301232023310",
+    "111133323302313133032133",
+    "213310301131311222211013",
+    "212131322110220230220011",
+    "012322011030320302120222",
+    "103322310111320013010101",
+    "101120112102202003221311",
+    "221101313123213230021123",
+};
+
 uint32_t largest_prime_below(uint32_t x)
 {
   for (uint32_t p = x - 1; p >= 2; p--) {
@@ -629,12 +696,9 @@ extern "C" void srslte_hip_chest_ul_destroy(srslte_hip_chest_ul_t* q)
 extern "C" int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t sf_idx, uint32_t n_dmrs, void* r_host)
 {
   if (!q || !r_host || n_dmrs >= 8 || sf_idx >= 10 || L_prb > q->nof_prb) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (L_prb < 3) {
-    fprintf(stderr, "[srslte_hip] PUSCH DMRS for 1- and 2-PRB grants (tabulated base sequences) is not provided\n");
-    return SRSLTE_ERROR;
-  }
+  if (L_prb == 0) return SRSLTE_ERROR_INVALID_INPUTS;
   cf32*          r    = (cf32*)r_host;
-  const uint32_t M_sc = 12 * L_prb, N_sz = largest_prime_below(M_sc);
+  const uint32_t M_sc = 12 * L_prb, N_sz = L_prb >= 3 ? largest_prime_below(M_sc) : 1;
   for (uint32_t ns = 2 * sf_idx; ns < 2 * (sf_idx + 1); ns++) {
     const uint32_t u = ((q->cfg.group_hopping_en ? q->f_gh[ns] : 0) + (q->cell_id % 30) + q->cfg.delta_ss) % 30;
     const uint32_t v = (L_prb >= 6 && q->cfg.sequence_hopping_en) ? q->v[ns][q->cfg.delta_ss] : 0;
@@ -650,7 +714,8 @@ extern "C" int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* 
     const float    alpha = (float)(2 * M_PI * n_cs / 12);
     for (uint32_t i = 0; i < M_sc; i++) {
       const float m   = (float)(i % N_sz);
-      const float arg = (float)(-M_PI * qq * m * (m + 1) / n_sz); // arg_r_uv_mprb :271-283
+      float       arg = (float)(-M_PI * qq * m * (m + 1) / n_sz); // arg_r_uv_mprb :271-283
+      if (L_prb < 3) arg = (float)((2 * ((L_prb == 1 ? PHI_12 : PHI_24)[u][i] - '0') - 3) * M_PI / 4); // :143-147,:251-255
       const float x   = fmaf(alpha, (float)i, arg);
       r[(ns % 2) * M_sc + i] = make_float2(cosf(x), sinf(x));
     }

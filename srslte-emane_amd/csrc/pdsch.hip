@@ -986,7 +986,7 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 
 extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->max_iterations == 0 || cfg->L_prb < 3 ||
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->max_iterations == 0 || cfg->L_prb < 1 ||
       cfg->n_prb + cfg->L_prb > cfg->nof_prb || !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
     fprintf(stderr, "[srslte_hip] ul_rx: invalid configuration\n");
     return nullptr;
@@ -1317,7 +1317,7 @@ extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
 
 extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg)
 {
-  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->L_prb < 3 || cfg->n_prb + cfg->L_prb > cfg->nof_prb ||
+  if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->L_prb < 1 || cfg->n_prb + cfg->L_prb > cfg->nof_prb ||
       !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
     fprintf(stderr, "[srslte_hip] ul_tx: invalid configuration\n");
     return nullptr;

@@ -134,7 +134,7 @@ def test_chest_ul_golden(hp):
         assert np.all(ce[0][mask] == 0)
         for x, y in zip(res[0, :4], g["scal_%d" % n]):
             assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
-        assert q.dmrs(2, 0, 0)[0] == hp.SRSLTE_ERROR  # tabulated 1-/2-PRB sequences are not provided
+        assert q.dmrs(2, 0, 0)[0] == 0  # tabulated 1-/2-PRB sequences (36.211 Tables 5.5.1.2-1/-2)
         q.free()
 
 

@@ -641,7 +641,8 @@ def test_chest_ul_pusch_batch(hp, cell_id, prb, L, n_prb):
 
 
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf", [(6, 6, 0, 1, 1000, 3.5, 2, 4), (25, 10, 5, 2, 4008, 9.5, 8, 4), (100, 100, 0, 2, 43816, 12.5, 0, 3),
-                                                                (100, 48, 20, 3, 30576, 17.0, 7, 3), (100, 100, 0, 2, 43816, 9.0, 5, 2)])
+                                                                (100, 48, 20, 3, 30576, 17.0, 7, 3), (100, 100, 0, 2, 43816, 9.0, 5, 2),
+                                                                (25, 1, 7, 1, 104, 4.0, 3, 6), (50, 2, 31, 2, 328, 10.0, 0, 4)])
 def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
     """eNB PUSCH receive chain on the device (cfg3's receive side) vs the oracle chain on identical IQ: grid, ce, noise,
     equalised and de-precoded symbols, de-interleaved LLRs, per-block pass counts, CRC flags and TB bytes."""
@@ -678,7 +679,8 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
 
 
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf", [(6, 6, 0, 1, 1000, 2, 4), (25, 10, 5, 2, 4008, 8, 11), (100, 100, 0, 2, 43816, 0, 3),
-                                                            (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2)])
+                                                            (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2),
+                                                            (25, 1, 7, 1, 104, 3, 6), (50, 2, 31, 2, 328, 0, 4)])
 def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf):
     """UE PUSCH transmit chain on the device vs the oracle's: code blocks with both CRCs, modulated symbols (exact: the
     bits are exact and the levels are table values), transform-precoded symbols, resource grid with DMRS, time samples."""

@@ -193,8 +193,8 @@ def test_chest_ul_golden():
         assert np.all(ce[mask] == 0)  # nothing outside the grant is written
         for x, y in zip((res.noise_estimate, res.noise_estimate_dbm, res.snr, res.snr_db), g["scal_%d" % n]):
             assert abs(x - y) <= 1e-4 * abs(y) + 1e-6
-    bad = np.zeros(48, np.complex64)
-    assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), 2, 0, 0, p(bad)) == -2
+    small = np.zeros(48, np.complex64)  # 2-PRB grant: tabulated QPSK base sequence, unit modulus
+    assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(cfg), 2, 0, 0, p(small)) == 0 and np.allclose(np.abs(small), 1.0, atol=1e-6)
 
 
 UL_CASES = (("a", 6, 6, 0, 1, 1000, (2, 7)), ("b", 25, 10, 5, 2, 4008, (9,)), ("c", 100, 48, 20, 3, 30576, (4,)))

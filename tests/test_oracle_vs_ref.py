@@ -689,8 +689,8 @@ def test_harq_retransmissions_vs_reference_pdsch_decode(prb, mod, tbs, nrx, npt,
 @pytest.mark.parametrize("cell_id,prb", [(1, 6), (77, 25), (301, 100)])
 def test_ul_dmrs_pusch_vs_ref(cell_id, prb):
     """srslte_refsignal_dmrs_pusch_gen (refsignal_ul.c:459-487): every float of the sequence, incl. group / sequence hopping and all
-    cyclic shifts. At 100 PRB the exponent's argument reaches 4e6 rad: one different rounding is a 0.5 rad phase error, so this pins the
-    exact operation order of the reference build."""
+    cyclic shifts, from the tabulated QPSK sequences of 1- and 2-PRB grants to 100 PRB. At 100 PRB the exponent's argument reaches 4e6 rad:
+    one different rounding is a 0.5 rad phase error, so this pins the exact operation order of the reference build."""
     from _libs import OrcUlDmrs, OrcUlDmrsCfg
     R = ref()
     q = opaque(1 << 16)
@@ -699,7 +699,7 @@ def test_ul_dmrs_pusch_vs_ref(cell_id, prb):
     assert oracle().orc_ul_dmrs_init(C.byref(o), cell_id) == 0
     worst = 0.0
     for cfg in (OrcUlDmrsCfg(0, 0, False, False), OrcUlDmrsCfg(3, 7, True, False), OrcUlDmrsCfg(7, 29, False, True), OrcUlDmrsCfg(5, 13, True, True)):
-        for L in sorted({3, 4, 6, prb // 2 // 1 if oracle().orc_dft_precoding_valid_prb(prb // 2) else 3, prb if oracle().orc_dft_precoding_valid_prb(prb) else 6}):
+        for L in sorted({1, 2, 3, 4, 6, prb // 2 // 1 if oracle().orc_dft_precoding_valid_prb(prb // 2) else 3, prb if oracle().orc_dft_precoding_valid_prb(prb) else 6}):
             for sf_idx, n_dmrs in ((0, 0), (3, 5), (9, 7)):
                 a, b = aligned(2 * 2 * 12 * L, np.float32), np.zeros(2 * 12 * L, np.complex64)
                 assert R.srslte_refsignal_dmrs_pusch_gen(q, C.byref(cfg), L, sf_idx, n_dmrs, p(a)) == 0
