@@ -235,7 +235,7 @@ int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
 /* ------------------------------------------------------------------ PUSCH receive pipeline (eNB side): OFDM RX with the
  * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +
  * descramble + UL channel de-interleaver (pusch.c:423-520, sch.c:891-913,:991-1066) -> rate de-matching -> turbo decode -> TB CRC.
- * UL-SCH data only (no UCI multiplexing), same allocation in both slots, normal CP, subframe not shortened, rv 0, 16-bit LLRs. */
+ * UL-SCH data only (no UCI multiplexing), same allocation in both slots, normal CP, rv 0, 16-bit LLRs. */
 typedef struct srslte_hip_ul_rx srslte_hip_ul_rx_t;
 typedef struct {
   uint32_t cell_id, nof_prb;
@@ -246,6 +246,7 @@ typedef struct {
   uint32_t max_iterations, max_batch;
   int      mmse;           /* 1: noise_estimate from chest_ul (pusch.c:475) */
   srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;
+  int      shortened;      /* 1: the subframe's last symbol is left to the SRS (srslte_ul_sf_cfg_t.shortened, N_srs = 1): 11 data symbols */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -270,6 +271,7 @@ typedef struct {
   uint32_t L_prb, n_prb, n_dmrs;
   uint32_t max_batch;
   srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;
+  int      shortened;      /* as in srslte_hip_ul_rx_cfg_t */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);

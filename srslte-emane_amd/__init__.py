@@ -452,16 +452,16 @@ class DlRx:
 class UlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
-                ("dmrs_cfg", DmrsPuschCfg)]
+                ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int)]
 
 
 class UlRx:
     """Batched PUSCH receive chain (enb_ul.c + pusch.c:423-520 + the UL-SCH part of sch.c:991-1066)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
-                 group_hopping=False, sequence_hopping=False, mmse=True):
+                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
-                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0))
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0)
         L = lib()
         L.srslte_hip_ul_rx_create.restype = C.c_void_p
         L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
@@ -499,7 +499,7 @@ class UlRx:
 
 class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
-                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg)]
+                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int)]
 
 
 class UlTx:
@@ -507,9 +507,9 @@ class UlTx:
     srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
-                 sequence_hopping=False):
+                 sequence_hopping=False, shortened=False):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
-                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0))
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0)
         L = lib()
         L.srslte_hip_ul_tx_create.restype = C.c_void_p
         L.srslte_hip_ul_tx_create.argtypes = [C.POINTER(UlTxCfg)]

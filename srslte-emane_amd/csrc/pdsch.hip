@@ -906,6 +906,7 @@ namespace {
 
 struct PuschGeom {
   int cell_nre, M_sc, n_prb, mod, Qm, tti0, scr_words, mmse;
+  int nsymb; // data symbols per subframe: 12, or 11 when the last symbol is left to the SRS (shortened subframe, pusch.c:52-91)
 };
 
 __device__ __forceinline__ int pusch_data_symbol(int n) { return n < 3 ? n : (n < 9 ? n + 1 : n + 2); } // 12 data symbols skip l = 3, 10
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(256) void pusch_eq_kernel(const cf32* __restrict__ 
   const cf32   y = grid[o], h = ce[o];
   const float  n0 = g.mmse ? noise[sf * 5] : 0.f;
   const float  re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0; // precoding.c:277-288, scaling 1
-  z[((size_t)sf * 12 + n) * g.M_sc + k] = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+  z[((size_t)sf * g.nsymb + n) * g.M_sc + k] = make_float2(re * 1.0f / csi, im * 1.0f / csi);
 }
 
 // grid = (ceil(M_sc/64), nof_sf), 256 threads: demap the 12 symbols of 64 sub-carriers, descramble in the received (symbol-major)
@@ -931,10 +932,10 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
                                                           PuschGeom g)
 {
   __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
-  const int k0 = blockIdx.x * 64, sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = 12 * g.M_sc;
+  const int k0 = blockIdx.x * 64, sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = g.nsymb * g.M_sc;
   const int nk = min(64, g.M_sc - k0);
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
-  for (int t = threadIdx.x; t < 64 * 12; t += 256) {
+  for (int t = threadIdx.x; t < 64 * g.nsymb; t += 256) {
     const int n = t >> 6, kl = t & 63;
     if (kl >= nk) continue;
     const int i = n * g.M_sc + k0 + kl;
@@ -942,11 +943,11 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
     demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
     const int      bit0 = i * g.Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
-    for (int b = 0; b < g.Qm; b++) stage[(kl * 12 + n) * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
+    for (int b = 0; b < g.Qm; b++) stage[(kl * g.nsymb + n) * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
   }
   __syncthreads();
-  const int    nbytes = nk * 12 * g.Qm * 2; // a multiple of 48
-  char*        dst    = reinterpret_cast<char*>(gout + (size_t)sf * nsym * g.Qm + (size_t)k0 * 12 * g.Qm);
+  const int    nbytes = nk * g.nsymb * g.Qm * 2; // nk is a multiple of 4, Qm even: a multiple of 16
+  char*        dst    = reinterpret_cast<char*>(gout + (size_t)sf * nsym * g.Qm + (size_t)k0 * g.nsymb * g.Qm);
   const char*  src    = reinterpret_cast<const char*>(stage);
   for (int o16 = threadIdx.x * 16; o16 < nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
 }
@@ -1000,7 +1001,8 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
     return nullptr;
   }
   const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
-  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32 + 1; // spare word: the demapper reads two per symbol
+  const uint32_t nsymb = cfg->shortened ? 11 : 12; // 2 (7 - 1) - N_srs data symbols (pusch.c:335-343)
+  const uint32_t nof_re = nsymb * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32 + 1; // spare word: the demapper reads two per symbol
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
   q->chest = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
@@ -1064,7 +1066,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
     return nullptr;
   }
   q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
-  q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse;
+  q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse; q->pg.nsymb = (int)nsymb;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride; q->rg.Nl = 1;
   q->rg.out_len = (int)(3 * K + 12);
   q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re;
@@ -1105,10 +1107,10 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   if (r) return r;
   PuschGeom g = q->pg;
   g.tti0      = (int)tti0;
-  const dim3 grid(ceil_div(g.M_sc, 256), 12, nof_sf);
+  const dim3 grid(ceil_div(g.M_sc, 256), g.nsymb, nof_sf);
   hipLaunchKernelGGL(pusch_eq_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_grid, (const cf32*)q->d_ce, (const float*)q->d_res, q->d_z, g);
   LAUNCH_CHECK();
-  r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, 12 * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
+  r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, g.nsymb * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
   if (r) return r;
   hipLaunchKernelGGL(pusch_demod_kernel, dim3(ceil_div(g.M_sc, 64), nof_sf), dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
   LAUNCH_CHECK();
@@ -1201,6 +1203,7 @@ __device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_
 
 struct PuschTxGeom {
   int   cell_nre, M_sc, n_prb, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
+  int   nsymb; // 12 data symbols, 11 in a shortened subframe
   float lvl[16];
 };
 
@@ -1244,7 +1247,7 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
   if (k >= g.M_sc) return;
-  const int s = k * 12 + n; // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
+  const int s = k * g.nsymb + n; // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
   int       r, e0;
   if (s < g.C_lo * g.syms_lo) {
     r  = s / g.syms_lo;
@@ -1267,7 +1270,7 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
     if (b & 1) im = (im << 1) | bit;
     else re = (re << 1) | bit;
   }
-  d[((size_t)sf * 12 + n) * g.M_sc + k] = make_float2(g.lvl[re], g.lvl[im]);
+  d[((size_t)sf * g.nsymb + n) * g.M_sc + k] = make_float2(g.lvl[re], g.lvl[im]);
 }
 
 // grid = (ceil(cell_nre/256), 14, nof_sf): resource grid of the subframe: z on the granted PRBs of the 12 data symbols, DMRS on
@@ -1284,7 +1287,7 @@ __global__ __launch_bounds__(256) void pusch_tx_map_kernel(const cf32* __restric
       v = dmrs[((size_t)sf_idx * 2 + (l == 10)) * g.M_sc + kk];
     } else {
       const int n = l < 3 ? l : (l < 10 ? l - 1 : l - 2);
-      v           = z[((size_t)sf * 12 + n) * g.M_sc + kk];
+      if (n < g.nsymb) v = z[((size_t)sf * g.nsymb + n) * g.M_sc + kk]; // the last symbol of a shortened subframe stays empty
     }
   }
   grid[((size_t)sf * 14 + l) * g.cell_nre + k] = v;
@@ -1331,9 +1334,11 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
     return nullptr;
   }
   const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
-  const uint32_t nof_re = 12 * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
+  const uint32_t nsymb = cfg->shortened ? 11 : 12;
+  const uint32_t nof_re = nsymb * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
   PuschTxGeom&   g = q->g;
   g.cell_nre = 12 * (int)P; g.M_sc = (int)M_sc; g.n_prb = (int)cfg->n_prb; g.Qm = (int)Qm; g.scr_words = (int)scr_words; g.C = (int)C; g.K = (int)K;
+  g.nsymb = (int)nsymb;
   g.tbs = (int)cfg->tbs; g.rlenB = (int)((C == 1 ? K : K - 24) / 8); g.cb_stride = (int)((K / 8 + 15) & ~15u);
   g.par_stride = (int)((K / 4 + 1 + 15) & ~15u); g.rm_len = (int)(3 * K + 12);
   g.syms_lo = (int)(nof_re / C); g.C_lo = (int)(C - nof_re % C); // G' = nof_re, gamma = G' mod C (sch.c:205-207)
@@ -1414,10 +1419,10 @@ extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb
   int r = srslte_hip_tcod_encode_bytes_batch(q->d_cb, (uint32_t)g.cb_stride, q->d_parity, (uint32_t)g.par_stride, q->d_sys_tail, (uint32_t)g.K,
                                              nof_sf * (uint32_t)g.C, stream);
   if (r) return r;
-  hipLaunchKernelGGL(pusch_tx_mod_kernel, dim3(ceil_div(g.M_sc, 256), 12, nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
+  hipLaunchKernelGGL(pusch_tx_mod_kernel, dim3(ceil_div(g.M_sc, 256), g.nsymb, nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
                      (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, (const uint32_t*)q->d_rm, (const uint32_t*)q->d_scr, q->d_d, g);
   LAUNCH_CHECK();
-  r = srslte_hip_dft_precoding_batch(q->d_d, q->d_z, q->cfg.L_prb, 12 * nof_sf, 1, stream); // srslte_dft_precoding_init_tx: forward, 1/sqrt(N)
+  r = srslte_hip_dft_precoding_batch(q->d_d, q->d_z, q->cfg.L_prb, g.nsymb * nof_sf, 1, stream); // srslte_dft_precoding_init_tx: forward, 1/sqrt(N)
   if (r) return r;
   hipLaunchKernelGGL(pusch_tx_map_kernel, dim3(ceil_div(g.cell_nre, 256), 14, nof_sf), dim3(256), 0, st, (const cf32*)q->d_z, (const cf32*)d_r,
                      q->d_grid, g);

@@ -555,7 +555,7 @@ class UlConfig:
     """One PUSCH configuration: UL-SCH data only (no UCI), same allocation in both slots, rv 0, normal CP, not shortened."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0,
-                 group_hopping=False, sequence_hopping=False):
+                 group_hopping=False, sequence_hopping=False, shortened=False):
         from _libs import OrcUlDmrs, OrcUlDmrsCfg
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.L_prb, self.n_prb, self.n_dmrs = nof_prb, cell_id, mod, tbs, L_prb, n_prb, n_dmrs
         self.rnti, self.max_iter = rnti, max_iter
@@ -563,7 +563,8 @@ class UlConfig:
         self.nre = 12 * nof_prb
         self.grid_len = 14 * self.nre
         self.M_sc = 12 * L_prb
-        self.nof_re = 12 * self.M_sc          # 12 data symbols (pusch.c:52-91)
+        self.nsymb = 11 if shortened else 12  # data symbols: 2 (7 - 1) - N_srs (pusch.c:52-91,:335-343); the SRS takes the last one
+        self.nof_re = self.nsymb * self.M_sc
         self.nbits = self.nof_re * self.Qm
         self.N = oracle().orc_symbol_sz(nof_prb)
         self.sf_len = 15 * self.N
@@ -572,9 +573,9 @@ class UlConfig:
         assert oracle().orc_ul_dmrs_init(C.byref(self.dmrs), cell_id) == 0
         self.seg = OrcCbsegm()
         assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
-        self.data_syms = [l for l in range(14) if l not in (3, 10)]
+        self.data_syms = [l for l in range(14) if l not in (3, 10)][:self.nsymb]
         # UL channel interleaver without UCI (36.212 5.2.2.8, sch.c:580-598,:891-913): q[(i*R + j)*Qm + k] = g[(j*12 + i)*Qm + k]
-        j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(12), np.arange(self.Qm), indexing="ij")
+        j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(self.nsymb), np.arange(self.Qm), indexing="ij")
         self.q_of_g = ((i * self.M_sc + j) * self.Qm + k).reshape(-1)  # g index (j, i, k) row-major -> q index
 
     def r_dmrs(self, sf_idx):
@@ -603,7 +604,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     d = np.zeros(cfg.nof_re, np.complex64)
     orc.orc_modulate(cfg.mod, p(q), p(d), cfg.nbits)
     z = np.zeros_like(d)
-    orc.orc_dft_precoding(p(d), p(z), cfg.L_prb, 12, 1, True)
+    orc.orc_dft_precoding(p(d), p(z), cfg.L_prb, cfg.nsymb, 1, True)
     grid = np.zeros(cfg.grid_len, np.complex64)
     for n, l in enumerate(cfg.data_syms):
         grid[l * cfg.nre + 12 * cfg.n_prb: l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc] = z[n * cfg.M_sc:(n + 1) * cfg.M_sc]
@@ -641,7 +642,7 @@ def oracle_ul_rx(cfg, iq, tti, keep=False):
     y, h = np.ascontiguousarray(grid[sel]), np.ascontiguousarray(ce[sel])
     z, d = np.zeros(cfg.nof_re, np.complex64), np.zeros(cfg.nof_re, np.complex64)
     orc.orc_predecoding_single(p(y), p(h), p(z), cfg.nof_re, 1.0, res.noise_estimate)
-    orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, 12, 0, True)
+    orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, cfg.nsymb, 0, True)
     qllr = np.zeros(cfg.nbits, np.int16)
     orc.orc_demod_soft_s(cfg.mod, p(d), p(qllr), cfg.nof_re)
     orc.orc_scramble_s(p(qllr), p(cfg.scramble(sf_idx)), cfg.nbits)
@@ -699,7 +700,7 @@ class RefUlRx:
         h.view(np.complex64)[:] = self.ce.view(np.complex64)[self.sel]
         R.srslte_predecoding_single(p(y), p(h), p(z), None, n, 1.0, self.res.noise_estimate)
         d = self.aligned(2 * n, np.float32)
-        orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, 12, 0, True)
+        orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, cfg.nsymb, 0, True)
         q = self.aligned(cfg.nbits + 64, np.int16)
         R.srslte_demod_soft_demodulate_s(cfg.mod, p(d), p(q), n)
         qv = q[:cfg.nbits]
@@ -734,7 +735,7 @@ class RefUlsch:
             self.pc[off:off + 4].view(np.uint32)[0] = v
         u32(g0 + L["srslte_pusch_grant_t.L_prb"], cfg.L_prb)
         u32(g0 + L["srslte_pusch_grant_t.nof_re"], cfg.nof_re)
-        u32(g0 + L["srslte_pusch_grant_t.nof_symb"], 12)
+        u32(g0 + L["srslte_pusch_grant_t.nof_symb"], cfg.nsymb)
         u32(t0 + L["srslte_ra_tb_t.mod"], cfg.mod)
         u32(t0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
         u32(t0 + L["srslte_ra_tb_t.nof_bits"], cfg.nbits)

@@ -643,14 +643,17 @@ def test_chest_ul_pusch_batch(hp, cell_id, prb, L, n_prb):
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf", [(6, 6, 0, 1, 1000, 3.5, 2, 4), (25, 10, 5, 2, 4008, 9.5, 8, 4), (100, 100, 0, 2, 43816, 12.5, 0, 3),
                                                                 (100, 48, 20, 3, 30576, 17.0, 7, 3), (100, 100, 0, 2, 43816, 9.0, 5, 2),
                                                                 (25, 1, 7, 1, 104, 4.0, 3, 6), (50, 2, 31, 2, 328, 10.0, 0, 4)])
-def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
+@pytest.mark.parametrize("short", [False, True])
+def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, short):
     """eNB PUSCH receive chain on the device (cfg3's receive side) vs the oracle chain on identical IQ: grid, ce, noise,
     equalised and de-precoded symbols, de-interleaved LLRs, per-block pass counts, CRC flags and TB bytes."""
     from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
     rng = np.random.default_rng(1100 + prb + L + int(snr * 10))
-    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    low_snr_case = snr < 9.5
+    snr = snr + (0.8 if short else 0.0)  # one data symbol less for the same transport block
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6, shortened=short)
     iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j)) for b in range(nsf)])
-    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6)
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6, shortened=short)
     tb, ok = rx.decode(np.stack(iq), tti0)
     C_ = cfg.seg.C
     it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
@@ -674,22 +677,23 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf):
         if r["ok"]:
             n_ok += 1
             assert np.array_equal(tb[b][:tbs // 8], data[b])
-    assert n_ok > 0 or snr < 9.5
+    assert n_ok > 0 or low_snr_case
     rx.free()
 
 
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf", [(6, 6, 0, 1, 1000, 2, 4), (25, 10, 5, 2, 4008, 8, 11), (100, 100, 0, 2, 43816, 0, 3),
                                                             (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2),
                                                             (25, 1, 7, 1, 104, 3, 6), (50, 2, 31, 2, 328, 0, 4)])
-def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf):
+@pytest.mark.parametrize("short", [False, True])
+def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf, short):
     """UE PUSCH transmit chain on the device vs the oracle's: code blocks with both CRCs, modulated symbols (exact: the
     bits are exact and the levels are table values), transform-precoded symbols, resource grid with DMRS, time samples."""
     from lte_sim import UlConfig, make_ul_subframe
     rng = np.random.default_rng(1300 + prb + L + mod)
     hop = dict(n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
-    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, **hop)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, shortened=short, **hop)
     data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
-    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6)
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6, shortened=short)
     iq = tx.encode(data, tti0)
     d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
     z = tx.debug(3, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)

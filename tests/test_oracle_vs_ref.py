@@ -761,14 +761,16 @@ def test_pusch_chain_vs_reference_code(prb, L, n_prb, mod, tbs, snr):
     assert nok > 0
 
 
-@pytest.mark.parametrize("prb,L,mod,tbs,snr", [(6, 6, 1, 1000, 3.5), (25, 10, 2, 4008, 9.5), (100, 100, 2, 43816, 12.5), (100, 48, 3, 30576, 17.0), (50, 45, 3, 30576, 18.5)])
-def test_ulsch_functions_vs_oracle_chain(prb, L, mod, tbs, snr):
+@pytest.mark.parametrize("prb,L,mod,tbs,snr,short", [(6, 6, 1, 1000, 3.5, False), (25, 10, 2, 4008, 9.5, False), (100, 100, 2, 43816, 12.5, False),
+                                                       (100, 48, 3, 30576, 17.0, False), (50, 45, 3, 30576, 18.5, False), (25, 10, 2, 4008, 10.5, True),
+                                                       (100, 96, 3, 61664, 19.5, True), (15, 1, 1, 104, 5.0, True)])
+def test_ulsch_functions_vs_oracle_chain(prb, L, mod, tbs, snr, short):
     """The reference's own srslte_ulsch_encode and srslte_ulsch_decode (sch.c:991-1160, no UCI): coded bits g, interleaved bits q
     (36.212 5.2.2.8) and, on the receive side, the de-interleaved LLRs, CRC result and transport block, against the oracle chain's
     UL-SCH coder / UlConfig.q_of_g / decoder on identical inputs."""
     from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx
     rng = np.random.default_rng(700 + prb + L)
-    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3, shortened=short)  # short: 11 data symbols (grant.nof_symb), SRS in the last
     chain = RefUlsch(cfg)
     nok = 0
     for t in (2, 7, 9):
