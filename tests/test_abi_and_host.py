@@ -65,3 +65,30 @@ def test_argument_validation_without_gpu():
     assert lib.srslte_hip_tdec_input_len(5824, 1) == 3 * (5824 + 32) + 12 and lib.srslte_hip_tdec_input_len(40, 0) == 132
     assert lib.srslte_hip_ofdm_rx_sf_batch(None, None, None, 1, None) == -2
     assert lib.srslte_hip_demod_soft_demodulate_s_batch(9, None, None, 1, 1, None) == -1
+
+
+def test_pipeline_entry_points_reject_bad_arguments_without_gpu():
+    """The batched pipelines validate handles and pointers before touching the device: SRSLTE_ERROR_INVALID_INPUTS (-2), no crash,
+    and create() refuses configurations the kernels do not cover (NULL back, message on stderr)."""
+    import ctypes as C
+    pkg = importlib.import_module("srslte-emane_amd")
+    lib = pkg.lib()
+    vp = C.c_void_p
+    for name in ("srslte_hip_dl_rx_batch", "srslte_hip_dl_rx_grid_batch", "srslte_hip_ul_rx_batch"):
+        getattr(lib, name).argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
+        assert getattr(lib, name)(None, None, 0, 1, None, 0, None, None) == -2
+    lib.srslte_hip_dl_rx_batch_harq.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, vp, C.c_uint32, vp, vp]
+    assert lib.srslte_hip_dl_rx_batch_harq(None, None, 0, 1, 0, 1, None, 0, None, None) == -2
+    lib.srslte_hip_ul_tx_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    assert lib.srslte_hip_ul_tx_batch(None, None, 0, 0, 1, None, None) == -2
+    lib.srslte_hip_dl_tx_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    assert lib.srslte_hip_dl_tx_batch(None, None, 0, 0, 1, 0, None, None) == -2
+    lib.srslte_hip_dl_rx_keep_symbols.argtypes = [vp, C.c_int]
+    assert lib.srslte_hip_dl_rx_keep_symbols(None, 1) == -2
+    for fn, cfg in ((lib.srslte_hip_dl_rx_create, pkg.DlRxCfg(1, 100, 1, 1, 3, 75376, 6, 4, 1, pkg.ChestDlCfg(), 0, 1, 3, 0, 0, 0.0)),   # 3 ports
+                    (lib.srslte_hip_dl_rx_create, pkg.DlRxCfg(1, 100, 1, 1, 7, 75376, 6, 4, 1, pkg.ChestDlCfg(), 0, 1, 1, 0, 0, 0.0))):  # bad modulation
+        fn.restype = vp
+        assert fn(C.byref(cfg)) is None
+    for L in (lib.srslte_hip_dl_rx_debug_buffer, lib.srslte_hip_ul_rx_debug_buffer, lib.srslte_hip_ul_tx_debug_buffer, lib.srslte_hip_dl_tx_debug_buffer):
+        L.restype, L.argtypes = vp, [vp, C.c_int]
+        assert L(None, 0) is None
