@@ -589,8 +589,32 @@ class UlConfig:
         return c
 
 
-def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None):
-    """UE transmit side of pusch.c:314-421 (UL-SCH only): returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid."""
+def ack_type_map(cfg, ack, Qp):
+    """Bookkeeping for tests, per q position: -1 no ACK bit, 0 / 1 value bit, 2 repetition of the previous bit, 3 placeholder - the positions of
+    uci_ulsch_interleave_ack_gen (uci.c:497-520) and the pattern of encode_ri_ack (:573-602), derived from orc_uci_ack_insert itself by
+    inserting into constant streams (scrambling off: value bits show their value, placeholders 1, repetitions their predecessor)."""
+    orc = oracle()
+    zeros = np.zeros(cfg.nbits, np.uint8)
+    O = len(ack)
+    a = np.array(list(ack) + [0], np.uint8)[:2]
+
+    def run(fill, av):
+        q = np.full(cfg.nbits, fill, np.uint8)
+        assert orc.orc_uci_ack_insert(p(q), p(zeros), p(np.ascontiguousarray(av, np.uint8)), O, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
+        return q
+    r0, r1 = run(0, a), run(1, a)
+    touched = (r0 != 0) | (r1 != 1) | (run(0, a ^ 1) != 0) | (run(0, a ^ np.array([1, 0], np.uint8)) != 0)
+    flips = (r0 != run(0, a ^ np.array([1, 0], np.uint8))) | (r0 != run(0, a ^ np.array([0, 1], np.uint8)))  # follows an ACK value
+    types = np.full(cfg.nbits, -1, np.int8)
+    types[touched & ~flips] = 3                   # constant 1: placeholder
+    for q_i in np.nonzero(touched & flips)[0]:    # a repetition bit directly follows its value bit inside the symbol (1-bit ACK only)
+        types[q_i] = r0[q_i] if ((q_i % cfg.Qm) == 0 or O == 2) else 2
+    return types
+
+
+def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0):
+    """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits multiplexed): returns (iq[sf_len], payload bytes);
+    keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
     orc = oracle()
     sf_idx = tti % 10
     if data is None:
@@ -600,7 +624,14 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(g)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
     q = np.zeros(cfg.nbits, np.uint8)
     q[cfg.q_of_g] = g
-    q ^= cfg.scramble(sf_idx)
+    c = cfg.scramble(sf_idx)
+    q ^= c
+    if len(ack):  # HARQ-ACK symbols overwrite UL-SCH symbols next to the DMRS (36.212 5.2.2.6-5.2.2.8; orc_uci.c)
+        Qp = orc.orc_uci_ack_qprime(len(ack), I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+        a2 = np.array(list(ack) + [0], np.uint8)[:2]
+        assert Qp > 0 and orc.orc_uci_ack_insert(p(q), p(c), p(a2), len(ack), cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
+        if keep is not None:
+            keep.update(q_tx=q.copy(), ack_types=ack_type_map(cfg, ack, Qp))
     d = np.zeros(cfg.nof_re, np.complex64)
     orc.orc_modulate(cfg.mod, p(q), p(d), cfg.nbits)
     z = np.zeros_like(d)
@@ -625,7 +656,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     return iq.astype(np.complex64), data
 
 
-def oracle_ul_rx(cfg, iq, tti, keep=False):
+def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0):
     """eNB receive side: enb_ul.c:58-63 OFDM settings, srslte_chest_ul_estimate_pusch, srslte_pusch_decode (pusch.c:423-520) and the
     UL-SCH part of srslte_ulsch_decode (sch.c:991-1066) without UCI."""
     from _libs import OrcChestUlRes
@@ -645,14 +676,20 @@ def oracle_ul_rx(cfg, iq, tti, keep=False):
     orc.orc_dft_precoding(p(z), p(d), cfg.L_prb, cfg.nsymb, 0, True)
     qllr = np.zeros(cfg.nbits, np.int16)
     orc.orc_demod_soft_s(cfg.mod, p(d), p(qllr), cfg.nof_re)
-    orc.orc_scramble_s(p(qllr), p(cfg.scramble(sf_idx)), cfg.nbits)
+    c_seq = cfg.scramble(sf_idx)
+    orc.orc_scramble_s(p(qllr), p(c_seq), cfg.nbits)
+    q_before_ack = qllr.copy()
+    ack_out = np.zeros(2, np.uint8)
+    if O_ack:  # uci_decode_ri_ack (sch.c:929-966): ACK decisions from the interleaved LLRs, then those positions are zeroed
+        Qp = orc.orc_uci_ack_qprime(O_ack, I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+        assert Qp > 0 and orc.orc_uci_ack_extract(p(qllr), p(c_seq), p(ack_out), O_ack, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
     g = np.ascontiguousarray(qllr[cfg.q_of_g])  # ulsch_deinterleave: g[n] = q[lut^-1]
     sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
     tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
     rc = orc.orc_dlsch_decode(C.byref(sch), p(g), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
     if keep:
-        out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res)
+        out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res, q_before_ack=q_before_ack, ack=ack_out)
     return out
 
 
@@ -714,11 +751,13 @@ class RefUlsch:
     36.212 5.2.2.8 and its inverse, UCI absent) on its compiled code, with a hand-filled srslte_pusch_cfg_t (offsets from the reference
     headers at run time). Pins the UL side of the oracle chain: orc_dlsch_encode/decode used as UL-SCH coder and UlConfig.q_of_g."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, O_ack=0, I_offset_ack=0):
         from _libs import opaque, ref, ref_layout
         R = self.R = ref()
         self.cfg = cfg
-        L = self.L = ref_layout({"srslte_sch_t": [], "srslte_pusch_cfg_t": ["grant", "max_nof_iterations", "softbuffers"],
+        L = self.L = ref_layout({"srslte_sch_t": [], "srslte_pusch_cfg_t": ["grant", "max_nof_iterations", "softbuffers", "uci_cfg", "uci_offset"],
+                                 "srslte_uci_cfg_t": ["ack"], "srslte_uci_cfg_ack_t": ["nof_acks"], "srslte_uci_offset_cfg_t": ["I_offset_ack"],
+                                 "srslte_uci_value_t": ["ack"], "srslte_uci_value_ack_t": ["ack_value"],
                                  "srslte_pusch_grant_t": ["L_prb", "nof_re", "nof_symb", "tb"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_softbuffer_tx_t": []}, ["srslte/phy/ch_estimation/chest_ul.h", "srslte/phy/phch/pusch.h"])
@@ -741,18 +780,23 @@ class RefUlsch:
         u32(t0 + L["srslte_ra_tb_t.nof_bits"], cfg.nbits)
         self.pc[t0 + L["srslte_ra_tb_t.enabled"]] = 1
         u32(L["srslte_pusch_cfg_t.max_nof_iterations"], cfg.max_iter)
+        u32(L["srslte_pusch_cfg_t.uci_cfg"] + L["srslte_uci_cfg_t.ack"] + L["srslte_uci_cfg_ack_t.nof_acks"], O_ack)  # HARQ-ACK bits of carrier 0
+        u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_ack"], I_offset_ack)
+        self.ack_off = L["srslte_uci_value_t.ack"] + L["srslte_uci_value_ack_t.ack_value"]
         self.sb_off = L["srslte_pusch_cfg_t.softbuffers"]
 
-    def encode(self, data):
-        """payload bytes -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling (pusch.c:380-395)."""
+    def encode(self, data, ack=()):
+        """payload bytes (+ HARQ-ACK values) -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling
+        (pusch.c:380-395); the ACK positions of q hold the value bits, 0 for repetition / placeholder bits."""
         cfg, R = self.cfg, self.R
         self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_tx)
         R.srslte_softbuffer_tx_reset(self.sb_tx)
         d = np.zeros(cfg.tbs // 8 + 64, np.uint8)
         d[:cfg.tbs // 8] = data
         uci = np.zeros(4096, np.uint8)
+        uci[self.ack_off:self.ack_off + len(ack)] = ack
         g, q = np.zeros(cfg.nbits // 8 + 64, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8)
-        assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) == 0
+        assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) >= 0  # returns the number of RI/ACK q-bits
         return np.unpackbits(g)[:cfg.nbits], np.unpackbits(q)[:cfg.nbits]
 
     def decode(self, q_llr, c_seq):
@@ -766,4 +810,4 @@ class RefUlsch:
         cs = np.ascontiguousarray(c_seq, np.uint8)
         tb, uci = np.zeros(cfg.tbs // 8 + 64, np.uint8), np.zeros(4096, np.uint8)
         rc = R.srslte_ulsch_decode(self.q, p(self.pc), p(ql), p(gl), p(cs), p(tb), p(uci))
-        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy()}
+        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy(), "ack": uci[self.ack_off:self.ack_off + 2].copy()}

@@ -807,3 +807,43 @@ def test_pdsch_encode_function_vs_stimulus_generator(prb, mod, tbs, npt):
             exp = np.zeros(cfg.grid_len, np.complex64)
             exp[k["idx"]] = k["y"][port] * (np.sqrt(2.0) if npt > 1 else 1.0)
             assert np.abs(grids[port] - exp).max() <= 1e-6, (t, rv, port)
+
+
+@pytest.mark.parametrize("prb,L,mod,tbs,snr,short,O_ack,I_off", [(25, 10, 2, 4008, 9.5, False, 1, 8), (25, 10, 1, 2216, 4.0, False, 2, 5), (100, 100, 2, 43816, 12.5, False, 1, 10),
+                                                                  (100, 48, 3, 30576, 17.5, False, 2, 9), (50, 45, 3, 30576, 19.0, True, 1, 12), (6, 6, 1, 1000, 4.5, True, 2, 3),
+                                                                  (15, 1, 2, 104, 8.0, False, 1, 14)])
+def test_harq_ack_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, O_ack, I_off):
+    """HARQ-ACK (1 and 2 bits) multiplexed on the PUSCH: Q' and the ACK positions / value bits srslte_ulsch_encode writes into the
+    interleaved stream (sch.c:1170-1215 with srslte_uci_encode_ack_ri), and on the receive side the ACK decisions, the zeroed ACK
+    positions and the transport block of srslte_ulsch_decode (uci_decode_ri_ack, sch.c:929-966) - against orc_uci.c on identical inputs."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx
+    orc = oracle()
+    rng = np.random.default_rng(1000 + prb + L + O_ack)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3, shortened=short)
+    chain = RefUlsch(cfg, O_ack, I_off)
+    Qp = orc.orc_uci_ack_qprime(O_ack, I_off, L, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+    assert Qp > 0
+    n_ok = 0
+    for t, ack in ((2, (1, 0)), (7, (0, 1)), (9, (1, 1))):
+        ack = ack[:O_ack]
+        k = {}
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k, ack=ack, I_offset_ack=I_off)
+        # transmit side: the reference's pre-scrambling q stream against the data stream with the ACK value bits put in
+        g_r, q_r = chain.encode(data, ack)
+        c = cfg.scramble(t % 10)
+        q_tx = k["q_tx"]  # oracle: interleaved, scrambled, ACK inserted
+        val = np.array([q_tx[i] ^ c[i] for i in range(cfg.nbits)], np.uint8)  # unscrambled view
+        types = k["ack_types"]  # per q position: -1 none, 0/1 value, 2 repetition, 3 placeholder
+        sel = types < 0
+        assert np.array_equal(q_r[sel], val[sel]), t
+        vb = (types == 0) | (types == 1)
+        assert vb.sum() > 0 and np.array_equal(q_r[vb], types[vb].astype(np.uint8)) and not q_r[(types == 2) | (types == 3)].any()
+        # receive side
+        o = oracle_ul_rx(cfg, iq, t, keep=True, O_ack=O_ack, I_offset_ack=I_off)
+        r = chain.decode(o["q_before_ack"], c)
+        assert np.array_equal(r["ack"][:O_ack], o["ack"][:O_ack]) and np.array_equal(o["ack"][:O_ack], np.array(ack, np.uint8)), (t, r["ack"], o["ack"])
+        assert np.array_equal(r["g"], o["g"]) and r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        n_ok += r["ok"]
+    assert n_ok > 0
