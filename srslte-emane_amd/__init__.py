@@ -452,16 +452,17 @@ class DlRx:
 class UlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
-                ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int)]
+                ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32)]
 
 
 class UlRx:
     """Batched PUSCH receive chain (enb_ul.c + pusch.c:423-520 + the UL-SCH part of sch.c:991-1066)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
-                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False):
+                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
-                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0)
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
+                           ack_len, I_offset_ack)
         L = lib()
         L.srslte_hip_ul_rx_create.restype = C.c_void_p
         L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
@@ -469,6 +470,8 @@ class UlRx:
         L.srslte_hip_ul_rx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         L.srslte_hip_ul_rx_debug_buffer.restype = C.c_void_p
         L.srslte_hip_ul_rx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
+        L.srslte_hip_ul_rx_ack.restype = C.c_void_p
+        L.srslte_hip_ul_rx_ack.argtypes = [C.c_void_p]
         self.h = L.srslte_hip_ul_rx_create(C.byref(self.cfg))
         if not self.h:
             raise RuntimeError("srslte_hip_ul_rx_create failed")
@@ -483,7 +486,14 @@ class UlRx:
         _check(lib().srslte_hip_ul_rx_batch(self.h, din.ptr, tti0, x.shape[0], self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "ul_rx_batch")
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        self.last_nof_sf = x.shape[0]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def ack(self):
+        """HARQ-ACK decisions [nof_sf][2] of the last decode() (srslte_uci_value_t.ack.ack_value of srslte_pusch_decode)."""
+        out = np.empty(2 * self.max_batch, np.uint8)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, lib().srslte_hip_ul_rx_ack(self.h), out.nbytes), "memcpy_d2h")
+        return out.reshape(-1, 2)[:self.last_nof_sf, :max(self.cfg.ack_len, 1)]
 
     def debug(self, which, dtype, count):
         ptr = lib().srslte_hip_ul_rx_debug_buffer(self.h, which)
@@ -499,7 +509,8 @@ class UlRx:
 
 class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
-                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int)]
+                ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
+                ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32)]
 
 
 class UlTx:
@@ -507,14 +518,16 @@ class UlTx:
     srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
-                 sequence_hopping=False, shortened=False):
+                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
-                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0)
+                           DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
+                           ack_len, I_offset_ack)
         L = lib()
         L.srslte_hip_ul_tx_create.restype = C.c_void_p
         L.srslte_hip_ul_tx_create.argtypes = [C.POINTER(UlTxCfg)]
         L.srslte_hip_ul_tx_destroy.argtypes = [C.c_void_p]
         L.srslte_hip_ul_tx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.srslte_hip_ul_tx_batch_ack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.srslte_hip_ul_tx_debug_buffer.restype = C.c_void_p
         L.srslte_hip_ul_tx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
         self.h = L.srslte_hip_ul_tx_create(C.byref(self.cfg))
@@ -524,11 +537,17 @@ class UlTx:
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch)
 
-    def encode(self, tb, tti0=0):
-        """tb: [nof_sf][tbs/8] payload bytes -> iq [nof_sf][sf_len] (left on the device in self.d_iq as well)."""
+    def encode(self, tb, tti0=0, ack=None):
+        """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values) -> iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
         x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
         din = DevBuf.from_host(x)
-        _check(lib().srslte_hip_ul_tx_batch(self.h, din.ptr, self.tbs // 8, tti0, x.shape[0], self.d_iq.ptr, None), "ul_tx_batch")
+        if ack is not None:
+            a = np.zeros((x.shape[0], 2), np.uint8)
+            a[:, :self.cfg.ack_len] = np.asarray(ack, np.uint8).reshape(x.shape[0], -1)[:, :self.cfg.ack_len]
+            dack = DevBuf.from_host(a)
+            _check(lib().srslte_hip_ul_tx_batch_ack(self.h, din.ptr, self.tbs // 8, dack.ptr, tti0, x.shape[0], self.d_iq.ptr, None), "ul_tx_batch_ack")
+        else:
+            _check(lib().srslte_hip_ul_tx_batch(self.h, din.ptr, self.tbs // 8, tti0, x.shape[0], self.d_iq.ptr, None), "ul_tx_batch")
         sync()
         return self.d_iq.to_host(np.complex64).reshape(self.max_batch, self.sf_len)[:x.shape[0]]
 

@@ -904,8 +904,39 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // ====================================================================================================================
 namespace {
 
+// HARQ-ACK on the PUSCH (36.212 5.2.2.6-5.2.2.8; srslte_uci_encode_ack_ri / _decode_ack_ri, uci.c:497-520,:547-602,:627-656,:695-788; 1 or 2 bits,
+// no RI / CQI): ACK symbol i sits on data symbol {2,3,8,9}[(3i)%4] ({1,2,6,7} with at most 10 data symbols), sub-carrier M_sc-1-i/4.
+struct AckGeom {
+  int O, Qprime; // 0: no ACK
+};
+__device__ __forceinline__ int ack_symbol_index(const AckGeom& a, int n, int k, int M_sc, int nsymb)
+{ // index i of the ACK symbol at data symbol n, sub-carrier k, or -1
+  int colidx;
+  if (nsymb > 10) {
+    colidx = n == 2 ? 0 : (n == 3 ? 1 : (n == 8 ? 2 : (n == 9 ? 3 : -1)));
+  } else {
+    colidx = n == 1 ? 0 : (n == 2 ? 1 : (n == 6 ? 2 : (n == 7 ? 3 : -1)));
+  }
+  if (a.O == 0 || colidx < 0) return -1;
+  const int i = 4 * (M_sc - 1 - k) + (3 * colidx) % 4; // (3 i) % 4 == colidx <=> i % 4 == (3 colidx) % 4
+  return i < a.Qprime ? i : -1;
+}
+__device__ __forceinline__ int ack_bit_type(const uint8_t* ack, int O, int Qm, int e)
+{ // encode_ri_ack (uci.c:573-602) repeated: 0 / 1 value, 2 repetition of the previous bit, 3 placeholder
+  if (O == 1) {
+    const int r = e % Qm;
+    return r == 0 ? ack[0] : (r == 1 ? 2 : 3);
+  }
+  const int r = e % (3 * Qm), s3 = r / Qm, b = r % Qm;
+  if (b >= 2) return 3;
+  const int v = (2 * s3 + b) % 3; // o0 o1 | o2 o0 | o1 o2
+  return v == 0 ? ack[0] : (v == 1 ? ack[1] : (ack[0] ^ ack[1]));
+}
+
 struct PuschGeom {
   int cell_nre, M_sc, n_prb, mod, Qm, tti0, scr_words, mmse;
+  AckGeom ack;
+  int*    ack_sum; // [nof_sf][4] accumulators of the ACK decisions (zeroed per call), or null
   int nsymb; // data symbols per subframe: 12, or 11 when the last symbol is left to the SRS (shortened subframe, pusch.c:52-91)
 };
 
@@ -943,6 +974,19 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
     demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
     const int      bit0 = i * g.Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
+    const int      ai   = ack_symbol_index(g.ack, n, k0 + kl, g.M_sc, g.nsymb);
+    if (ai >= 0) { // uci_decode_ri_ack (sch.c:929-966): this symbol feeds the ACK decision and reaches the decoder as zeros
+      const int d0 = (c2 & 1) ? -o[0] : o[0], d1 = (c2 & 2) ? -o[1] : o[1]; // descrambled
+      if (g.ack.O == 1) { // value bit + its repetition, which carries the value bit's scrambling (uci.c:627-640)
+        atomicAdd(&g.ack_sum[sf * 4], d0 + ((c2 & 1) ? -o[1] : o[1]));
+      } else if (3 * (ai / 3) + 3 < g.ack.Qprime) { // a triplet is only used if another symbol follows it (uci.c:776-777)
+        const int s3 = ai % 3; // o0 o1 | o2 o0 | o1 o2
+        atomicAdd(&g.ack_sum[sf * 4 + (s3 == 0 ? 0 : (s3 == 1 ? 2 : 1))], d0);
+        atomicAdd(&g.ack_sum[sf * 4 + (s3 == 0 ? 1 : (s3 == 1 ? 0 : 2))], d1);
+      }
+      for (int b = 0; b < g.Qm; b++) stage[(kl * g.nsymb + n) * g.Qm + b] = 0;
+      continue;
+    }
     for (int b = 0; b < g.Qm; b++) stage[(kl * g.nsymb + n) * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
   }
   __syncthreads();
@@ -952,6 +996,27 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
   for (int o16 = threadIdx.x * 16; o16 < nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
 }
 
+} // namespace
+
+// Q' of the HARQ-ACK (Q_prime_ri_ack, uci.c:547-571, UL-SCH present): min(ceil(O M_sc N_symb beta / sum K_r), 4 M_sc) in float arithmetic
+static int pusch_ack_qprime(uint32_t O, uint32_t I_offset_ack, uint32_t L_prb, uint32_t nsymb, uint32_t K_segm)
+{
+  static const float beta_harq[16] = {2.0f, 2.5f, 3.125f, 4.0f, 5.0f, 6.250f, 8.0f, 10.0f, 12.625f, 15.875f, 20.0f, 31.0f, 50.0f, 80.0f, 126.0f, -1.0f}; // 36.213 Table 8.6.3-1
+  if (O == 0) return 0;
+  if (O > 2 || I_offset_ack > 15 || beta_harq[I_offset_ack] < 0 || K_segm == 0) return -1;
+  const uint32_t x = (uint32_t)ceilf((float)O * L_prb * 12 * nsymb * beta_harq[I_offset_ack] / K_segm), m = 4 * L_prb * 12;
+  const uint32_t Qp = x < m ? x : m;
+  return (Qp + 3) / 4 <= 12 * L_prb ? (int)Qp : -1; // the ACK rows must exist (uci.c:505)
+}
+
+namespace {
+__global__ void pusch_ack_decide_kernel(const int* __restrict__ sum, uint8_t* __restrict__ ack, int nof_sf)
+{
+  const int sf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sf >= nof_sf) return;
+  ack[2 * sf]     = sum[4 * sf] > 0;     // uci.c:782-785
+  ack[2 * sf + 1] = sum[4 * sf + 1] > 0;
+}
 } // namespace
 
 struct srslte_hip_ul_rx {
@@ -969,7 +1034,11 @@ struct srslte_hip_ul_rx {
   float*                 d_res; // [B] x srslte_hip_chest_ul_res_t
   int16_t *              d_g, *d_w;
   uint8_t *              d_cb_bytes, *d_cb_ok;
+  int*                   d_ack_sum; // [B][4]
+  uint8_t*               d_ack;     // [B][2] HARQ-ACK decisions of the last call
 };
+
+extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
 
 extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 {
@@ -978,7 +1047,7 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_chest_ul_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
-                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok};
+                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -1059,7 +1128,9 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
-       hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess;
+       hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 4 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)2 * B) == hipSuccess &&
+       hipMemset(q->d_ack, 0, (size_t)2 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0;
   if (!ok) {
     fprintf(stderr, "[srslte_hip] ul_rx: initialisation failed\n");
     srslte_hip_ul_rx_destroy(q);
@@ -1067,6 +1138,8 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   }
   q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse; q->pg.nsymb = (int)nsymb;
+  q->pg.ack.O = (int)cfg->ack_len; q->pg.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
+  q->pg.ack_sum = q->d_ack_sum;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride; q->rg.Nl = 1;
   q->rg.out_len = (int)(3 * K + 12);
   q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re;
@@ -1088,6 +1161,7 @@ extern "C" const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q
     case 7: return q->d_cb_ok;
     case 8: return q->d_cb_bytes;
     case 9: return q->d_z;
+    case 10: return q->d_ack;
   }
   return nullptr;
 }
@@ -1107,13 +1181,19 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   if (r) return r;
   PuschGeom g = q->pg;
   g.tti0      = (int)tti0;
+  g.ack_sum   = q->d_ack_sum;
   const dim3 grid(ceil_div(g.M_sc, 256), g.nsymb, nof_sf);
   hipLaunchKernelGGL(pusch_eq_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_grid, (const cf32*)q->d_ce, (const float*)q->d_res, q->d_z, g);
   LAUNCH_CHECK();
   r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, g.nsymb * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
   if (r) return r;
+  if (g.ack.O) HIP_TRY(hipMemsetAsync(q->d_ack_sum, 0, sizeof(int) * 4 * nof_sf, st));
   hipLaunchKernelGGL(pusch_demod_kernel, dim3(ceil_div(g.M_sc, 64), nof_sf), dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
   LAUNCH_CHECK();
+  if (g.ack.O) {
+    hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_sf, 64)), dim3(64), 0, st, (const int*)q->d_ack_sum, q->d_ack, (int)nof_sf);
+    LAUNCH_CHECK();
+  }
   RmGeom rg = q->rg;
   rg.tti0   = (int)tti0;
   if (rm_fits_lds(rg)) {
@@ -1204,6 +1284,8 @@ __device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_
 struct PuschTxGeom {
   int   cell_nre, M_sc, n_prb, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
   int   nsymb; // 12 data symbols, 11 in a shortened subframe
+  AckGeom        ack;
+  const uint8_t* ack_bits; // [nof_sf][2] HARQ-ACK values of this call, or null
   float lvl[16];
 };
 
@@ -1261,12 +1343,19 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
   const uint8_t * xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
   const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
   const int       q0  = (n * g.M_sc + k) * g.Qm;
-  int             re = 0, im = 0;
+  const int       ai  = g.ack_bits ? ack_symbol_index(g.ack, n, k, g.M_sc, g.nsymb) : -1;
+  int             re = 0, im = 0, prev = 0;
   for (int b = 0; b < g.Qm; b++) {
     const uint32_t src = rm[(e0 + b) % g.rm_len], pos = src & 0x3fffffffu;
     const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
     int            bit  = (byte >> (7 - (pos & 7))) & 1;
-    bit ^= (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
+    const int      cbit = (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
+    bit ^= cbit;
+    if (ai >= 0) { // HARQ-ACK symbol: value bits are scrambled, placeholders are 1, a repetition bit copies the transmitted bit before it
+      const int t = ack_bit_type(g.ack_bits + 2 * sf, g.ack.O, g.Qm, ai * g.Qm + b); // (sch.c:1203-1215, pusch.c:386-400)
+      bit         = t == 3 ? 1 : (t == 2 ? prev : (t ^ cbit));
+    }
+    prev = bit;
     if (b & 1) im = (im << 1) | bit;
     else re = (re << 1) | bit;
   }
@@ -1339,6 +1428,12 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
   PuschTxGeom&   g = q->g;
   g.cell_nre = 12 * (int)P; g.M_sc = (int)M_sc; g.n_prb = (int)cfg->n_prb; g.Qm = (int)Qm; g.scr_words = (int)scr_words; g.C = (int)C; g.K = (int)K;
   g.nsymb = (int)nsymb;
+  g.ack.O = (int)cfg->ack_len; g.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
+  if (g.ack.Qprime < 0) {
+    fprintf(stderr, "[srslte_hip] ul_tx: invalid HARQ-ACK configuration\n");
+    delete q;
+    return nullptr;
+  }
   g.tbs = (int)cfg->tbs; g.rlenB = (int)((C == 1 ? K : K - 24) / 8); g.cb_stride = (int)((K / 8 + 15) & ~15u);
   g.par_stride = (int)((K / 4 + 1 + 15) & ~15u); g.rm_len = (int)(3 * K + 12);
   g.syms_lo = (int)(nof_re / C); g.C_lo = (int)(C - nof_re % C); // G' = nof_re, gamma = G' mod C (sch.c:205-207)
@@ -1404,7 +1499,15 @@ extern "C" const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q
 extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, void* d_iq,
                                       void* stream)
 {
+  if (q && q->cfg.ack_len) return SRSLTE_ERROR_INVALID_INPUTS; // HARQ-ACK configured: the values come through _batch_ack
+  return srslte_hip_ul_tx_batch_ack(q, d_tb, tb_stride, nullptr, tti0, nof_sf, d_iq, stream);
+}
+
+extern "C" int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, uint32_t tti0,
+                                          uint32_t nof_sf, void* d_iq, void* stream)
+{
   if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if ((q->cfg.ack_len != 0) != (d_ack != nullptr)) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const void* d_r = nullptr;
@@ -1412,6 +1515,7 @@ extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb
   PuschTxGeom g = q->g;
   g.tti0        = (int)tti0;
   g.tb_stride   = (int)tb_stride;
+  g.ack_bits    = d_ack;
   hipLaunchKernelGGL(pusch_tx_tbcrc_kernel, dim3(nof_sf), dim3(256), 0, st, d_tb, q->d_tbcrc, g);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(pusch_tx_seg_kernel, dim3(g.C, nof_sf), dim3(256), 0, st, d_tb, (const uint32_t*)q->d_tbcrc, q->d_cb, g);

@@ -708,6 +708,88 @@ def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf, short):
     tx.free()
 
 
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf,O,Ioff,short", [(25, 10, 5, 2, 4008, 8, 6, 1, 9, False), (25, 10, 5, 2, 4008, 1, 6, 2, 9, False),
+                                                                        (6, 6, 0, 1, 1000, 2, 4, 2, 5, True), (100, 48, 20, 3, 30576, 7, 4, 1, 12, False),
+                                                                        (100, 100, 0, 3, 75376, 4, 4, 2, 14, True), (25, 1, 7, 1, 104, 3, 4, 2, 10, False),
+                                                                        (50, 2, 31, 2, 328, 0, 4, 1, 0, False)])
+def test_ul_tx_chain_harq_ack(hp, prb, L, n_prb, mod, tbs, tti0, nsf, O, Ioff, short):
+    """PUSCH transmit chain with 1-2 HARQ-ACK bits multiplexed next to the DMRS (sch.c:1168-1215, uci.c:497-602, the placeholder /
+    repetition handling of pusch.c:386-400) vs the oracle's (pinned on srslte_ulsch_encode): modulated symbols exact, samples 1e-4."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(1700 + prb + L + mod + O)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, shortened=short, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    acks = np.array([[(b >> j) & 1 for j in range(O)] for b in range(nsf)], np.uint8)  # every combination
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O, I_offset_ack=Ioff)
+    assert hp.lib().srslte_hip_ul_tx_batch(tx.h, tx.d_iq.ptr, tbs // 8, 0, 1, tx.d_iq.ptr, None) == hp.SRSLTE_ERROR_INVALID_INPUTS  # no ACK values
+    iq = tx.encode(data, tti0, ack=acks)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    n_diff = 0
+    for b in range(nsf):
+        k, k0 = {}, {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k, ack=tuple(acks[b]), I_offset_ack=Ioff)
+        make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k0)
+        n_diff += int((k["d"] != k0["d"]).sum())
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), "modulated symbols sf %d" % b
+        assert_close_c(iq[b], iq_o, "iq sf %d" % b)
+    assert n_diff > 0  # the ACK did change symbols
+    tx.free()
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O,Ioff,short", [(25, 10, 5, 2, 4008, 10.5, 8, 8, 1, 9, False), (25, 10, 5, 2, 4008, 10.5, 1, 8, 2, 9, False),
+                                                                            (6, 6, 0, 1, 1000, 5.0, 2, 4, 2, 5, True), (100, 48, 20, 3, 30576, 18.0, 7, 4, 1, 12, False),
+                                                                            (100, 100, 0, 2, 43816, 13.5, 4, 4, 2, 14, True), (25, 1, 7, 1, 104, 6.0, 3, 4, 2, 10, False),
+                                                                            (25, 10, 5, 1, 1000, -3.0, 0, 8, 2, 2, False)])
+def test_ul_rx_chain_harq_ack(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O, Ioff, short):
+    """PUSCH receive chain with HARQ-ACK on the PUSCH (uci_decode_ri_ack sch.c:929-966, uci.c:755-790) vs the oracle chain (pinned on
+    srslte_ulsch_decode) on identical IQ: ACK decisions, de-interleaved LLRs with the ACK positions zeroed, pass counts, CRC, TB."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(1800 + prb + L + mod + O)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6, shortened=short)
+    acks = np.array([[(b >> j) & 1 for j in range(O)] for b in range(nsf)], np.uint8)
+    iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), ack=tuple(acks[b]), I_offset_ack=Ioff)
+                     for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O, I_offset_ack=Ioff)
+    for rep in range(2):  # the second call checks that the accumulators are cleared per call
+        tb, ok = rx.decode(np.stack(iq), tti0)
+        ack = rx.ack()
+        C_ = cfg.seg.C
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+        n_ok = n_zero = 0
+        for b in range(nsf):
+            r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O, I_offset_ack=Ioff)
+            diff = np.abs(g[b].astype(np.int32) - r["g"].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size
+            zeroed = (r["q"] == 0) & (r["q_before_ack"] != 0)
+            n_zero += int(zeroed.sum())
+            assert np.array_equal(ack[b], r["ack"][:O]), "ack sf %d" % b
+            if snr > 0:
+                assert np.array_equal(ack[b], acks[b])
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+            if r["ok"] or diff.max() == 0:
+                assert np.array_equal(tb[b], r["tb"])
+            if r["ok"]:
+                n_ok += 1
+                assert np.array_equal(tb[b][:tbs // 8], data[b])
+        assert n_zero > 0 and (n_ok > 0 or snr < 0)
+    rx.free()
+
+
+def test_ul_tx_rx_loop_harq_ack(hp):
+    """Device transmit chain with HARQ-ACK into the device receive chain (noise-free): transport blocks and ACK values come back."""
+    prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
+    rng = np.random.default_rng(78)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    acks = rng.integers(0, 2, (nsf, 2), dtype=np.uint8)
+    tx = hp.UlTx(3, prb, 0x77, mod, tbs, L, n_prb, 1, nsf, ack_len=2, I_offset_ack=8)
+    rx = hp.UlRx(3, prb, 0x77, mod, tbs, L, n_prb, 1, 6, nsf, ack_len=2, I_offset_ack=8)
+    tb, ok = rx.decode(tx.encode(data, 5, ack=acks), 5)
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data) and np.array_equal(rx.ack(), acks)
+    tx.free()
+    rx.free()
+
+
 def test_ul_tx_rx_loop(hp):
     """Device transmit chain into the device receive chain (noise-free, flat gain): every transport block comes back, one pass per block."""
     prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
