@@ -99,7 +99,7 @@ const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
 
 /* ------------------------------------------------------------------ UL channel estimator (replaces
  * srslte_chest_ul_init/_set_cell/_pregen/_estimate_pusch, ch_estimation/chest_ul.h:47-104, chest_ul.c:51-327, and the PUSCH DMRS of
- * refsignal_ul.c:118-487). Normal CP, grants of >= 3 PRB (the 1- and 2-PRB base sequences are tabulated, not provided), same
+ * refsignal_ul.c:118-487). Normal CP, grants of >= 1 PRB (the 1- and 2-PRB base sequences from the tables of 36.211 5.5.1.2), same
  * allocation in both slots (the reference's estimator does not support intra-subframe hopping either, chest_ul.c:297-299). */
 typedef struct srslte_hip_chest_ul srslte_hip_chest_ul_t;
 typedef struct { /* srslte_refsignal_dmrs_pusch_cfg_t, refsignal_ul.h:46-51 */

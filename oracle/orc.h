@@ -125,6 +125,11 @@ int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t*
                  orc_chest_res_t* res);
 int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res); /* nof_rx receive antennas, one port */
+/* MBSFN subframes (chest_dl.c:718-745, refsignal_dl.c:297-487): pilots [3][6 nof_prb]; stimulus; one (antenna, port) estimate */
+int orc_mbsfn_pilots(uint32_t nof_prb, uint32_t area_id, uint32_t sf_idx, orc_cf_t* pilots);
+int orc_mbsfn_put_sf(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, uint32_t area_id, orc_cf_t* grid);
+int orc_chest_dl_mbsfn(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t area_id, uint32_t port,
+                       const orc_cf_t* grid, orc_cf_t* ce, float* noise_out);
 /* cell->nof_ports in {1, 2, 4} tx ports x nof_rx antennas (4 ports: not with interpolate_subframe, returns -3): ce[port * nof_rx + antenna]; raw_out [antenna][port]{noise, rsrp, rssi, cfo} */
 int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res, float* raw_out);

@@ -94,6 +94,44 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
   free(diff);
 }
 
+/* estimate_noise_pilots (chest_dl.c:304-379): rows[nsym][nref] pilot estimates; tmp holds 3 (nref + 2) values */
+static float noise_pilots(cf* est, uint32_t nref, uint32_t nsym, uint32_t fidx0, cf* tmp)
+{
+  cf* in2d[6];
+  for (uint32_t i = 0; i < nsym; i++) in2d[i + 1] = &est[i * nref];
+  in2d[0]        = &tmp[nref];
+  in2d[nsym + 1] = &tmp[2 * nref];
+  for (uint32_t k = 0; k < nref; k++) {
+    if (nsym > 3) { /* virtual rows before the first and after the last pilot symbol: linear extrapolation (:337-350) */
+      in2d[0][k]        = c_sub(c_scale(in2d[2][k], 2.0f), in2d[4][k]);
+      in2d[nsym + 1][k] = c_sub(c_scale(in2d[nsym - 1][k], 2.0f), in2d[nsym - 3][k]);
+    } else { /* two or three symbols: copies of the second / the last but one row */
+      in2d[0][k]        = in2d[2][k];
+      in2d[nsym + 1][k] = in2d[nsym - 1][k];
+    }
+  }
+  float sum_power = 0;
+  int   count     = 0;
+  for (uint32_t i = 1; i < nsym + 1; i++) {
+    uint32_t off = ((fidx0 < 3) ^ (i & 1)) ? 0 : 1;
+    for (uint32_t k = 0; k < nref; k++) tmp[k] = in2d[i][k];
+    for (int side = -1; side <= 1; side += 2) {
+      const cf* nb = in2d[(int)i + side];
+      for (uint32_t k = 0; k < nref - off; k++) tmp[off + k] = c_add(tmp[off + k], nb[k]);
+      for (uint32_t k = 0; k < nref + off - 1; k++) tmp[k] = c_add(tmp[k], nb[1 - off + k]);
+      if (off) {
+        tmp[0] = c_add(tmp[0], c_sub(c_scale(nb[0], 2.0f), nb[1]));
+      } else {
+        tmp[nref - 1] = c_add(tmp[nref - 1], c_sub(c_scale(nb[nref - 2], 2.0f), nb[nref - 1]));
+      }
+    }
+    for (uint32_t k = 0; k < nref; k++) tmp[k] = c_sub(in2d[i][k], c_scale(tmp[k], 1.0f / 5.0f));
+    sum_power = avg_power(tmp, nref); /* '=' not '+=': upstream quirk (chest_dl.c:374) */
+    count++;
+  }
+  return sum_power / (float)count * sqrtf(5.0f);
+}
+
 /* estimate_port for one port of one receive antenna (chest_dl.c:598-716); raw = {noise, rsrp, rssi, cfo, sync, corr} of that
    (antenna, port). Ports 0/1 have 4 pilot symbols per subframe, ports 2/3 two (symbols 1 and 8). est is the estimator's
    q->pilot_estimates, [4][2 nof_prb], SHARED by the ports of an antenna as upstream: chest_estimate_cfo (:573-596) always pairs its
@@ -159,43 +197,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   }
 
   /* noise from pilots (chest_dl.c:304-379) */
-  float noise = 0;
-  if (cfg->noise_alg == 0) {
-    uint32_t fidx0 = orc_crs_fidx(cell, 0, port);
-    cf*      in2d[6];
-    for (uint32_t i = 0; i < nsym; i++) in2d[i + 1] = &est[i * nref];
-    in2d[0]        = &tmp[nref];
-    in2d[nsym + 1] = &tmp[2 * nref];
-    for (uint32_t k = 0; k < nref; k++) {
-      if (nsym > 3) { /* virtual rows before the first and after the last pilot symbol: linear extrapolation (:337-350) */
-        in2d[0][k]        = c_sub(c_scale(in2d[2][k], 2.0f), in2d[4][k]);
-        in2d[nsym + 1][k] = c_sub(c_scale(in2d[nsym - 1][k], 2.0f), in2d[nsym - 3][k]);
-      } else { /* two symbols: copies of the other row */
-        in2d[0][k]        = in2d[2][k];
-        in2d[nsym + 1][k] = in2d[nsym - 1][k];
-      }
-    }
-    float sum_power = 0;
-    int   count     = 0;
-    for (uint32_t i = 1; i < nsym + 1; i++) {
-      uint32_t off = ((fidx0 < 3) ^ (i & 1)) ? 0 : 1;
-      for (uint32_t k = 0; k < nref; k++) tmp[k] = in2d[i][k];
-      for (int side = -1; side <= 1; side += 2) {
-        const cf* nb = in2d[(int)i + side];
-        for (uint32_t k = 0; k < nref - off; k++) tmp[off + k] = c_add(tmp[off + k], nb[k]);
-        for (uint32_t k = 0; k < nref + off - 1; k++) tmp[k] = c_add(tmp[k], nb[1 - off + k]);
-        if (off) {
-          tmp[0] = c_add(tmp[0], c_sub(c_scale(nb[0], 2.0f), nb[1]));
-        } else {
-          tmp[nref - 1] = c_add(tmp[nref - 1], c_sub(c_scale(nb[nref - 2], 2.0f), nb[nref - 1]));
-        }
-      }
-      for (uint32_t k = 0; k < nref; k++) tmp[k] = c_sub(in2d[i][k], c_scale(tmp[k], 1.0f / 5.0f));
-      sum_power = avg_power(tmp, nref); /* '=' not '+=': upstream quirk (chest_dl.c:374) */
-      count++;
-    }
-    noise = sum_power / (float)count * sqrtf(5.0f);
-  }
+  float noise = cfg->noise_alg == 0 ? noise_pilots(est, nref, nsym, orc_crs_fidx(cell, 0, port), tmp) : 0;
 
   if (ce) {
     float    filter[64];
@@ -333,6 +335,108 @@ int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_
   orc_cell_t c1 = *cell;
   c1.nof_ports  = 1;
   return orc_chest_dl_ports(&c1, sf_idx, cfg, nof_rx, grid, ce, res, NULL);
+}
+
+/* ------------------------------------------------------------------ MBSFN subframes: the reference signal of antenna
+ * port 4 (refsignal_dl.c:328-400) and estimate_port_mbsfn (chest_dl.c:718-745) with the MBSFN branches of average_pilots (:513-556),
+ * interpolate_pilots (:415-511) and estimate_noise_pilots (:304-379). The subframe has 12 symbols (extended CP); symbol 0 carries the
+ * cell's CRS, symbols 2, 6, 10 a pilot on every second sub-carrier (offsets 0, 1, 0). */
+static const uint32_t MBSFN_SYM[3] = {2, 6, 10}, MBSFN_FIDX[3] = {0, 1, 0};
+
+int orc_mbsfn_pilots(uint32_t nof_prb, uint32_t area_id, uint32_t sf_idx, orc_cf_t* pilots /* [3][6 nof_prb] */)
+{ /* refsignal_dl.c:361-400: c_init = 512 (7 (ns + 1) + l' + 1)(2 N_mbsfn + 1) + N_mbsfn, offset 3 (MAX_PRB - nof_prb) */
+  const uint32_t MAX_PRB = 110;
+  uint8_t*       c = malloc(20 * MAX_PRB);
+  if (nof_prb < 6 || nof_prb > MAX_PRB || area_id > 255 || sf_idx > 9) {
+    free(c);
+    return -1;
+  }
+  for (uint32_t l = 0; l < 3; l++) {
+    uint32_t lp = MBSFN_SYM[l] % 6, slot = l ? 2 * sf_idx + 1 : 2 * sf_idx;
+    orc_gold(512 * (7 * (slot + 1) + lp + 1) * (2 * area_id + 1) + area_id, 20 * MAX_PRB, c);
+    for (uint32_t i = 0; i < 6 * nof_prb; i++) {
+      uint32_t mp = i + 3 * (MAX_PRB - nof_prb);
+      pilots[6 * nof_prb * l + i].re = (float)((1 - 2 * (float)c[2 * mp]) / sqrt(2));
+      pilots[6 * nof_prb * l + i].im = (float)((1 - 2 * (float)c[2 * mp + 1]) / sqrt(2));
+    }
+  }
+  free(c);
+  return 0;
+}
+
+int orc_mbsfn_put_sf(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, uint32_t area_id, orc_cf_t* grid)
+{ /* srslte_refsignal_mbsfn_put_sf (refsignal_dl.c:297-326): the first CRS symbol of the port + the three MBSFN pilot symbols */
+  const uint32_t P = cell->nof_prb, nre = 12 * P;
+  cf*            crs = malloc(sizeof(cf) * 8 * P);
+  cf*            mb  = malloc(sizeof(cf) * 18 * P);
+  if (port_id > 3 || orc_mbsfn_pilots(P, area_id, sf_idx, mb)) {
+    free(crs); free(mb);
+    return -1;
+  }
+  orc_crs_pilots(cell, sf_idx, port_id, crs);
+  uint32_t fidx = orc_crs_fidx(cell, 0, port_id);
+  for (uint32_t i = 0; i < 2 * P; i++) grid[fidx + 6 * i] = crs[i]; /* always symbol 0 (:308) */
+  for (uint32_t l = 0; l < 3; l++) {
+    for (uint32_t i = 0; i < 6 * P; i++) grid[MBSFN_SYM[l] * nre + MBSFN_FIDX[l] + 2 * i] = mb[6 * P * l + i];
+  }
+  free(crs); free(mb);
+  return 0;
+}
+
+int orc_chest_dl_mbsfn(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t area_id, uint32_t port,
+                       const orc_cf_t* grid, orc_cf_t* ce /* 12 symbols written */, float* noise_out)
+{ /* estimate_port_mbsfn (chest_dl.c:718-745) + chest_interpolate_noise_est (:598-676) in MBSFN mode. The reference leaves rsrp, rssi,
+     cfo and the sync error of the (antenna, port) as the last normal subframe set them; with the PSS / EMPTY noise algorithms the noise
+     estimate stays too (MBSFN subframes are never 0 or 5): *noise_out is NaN then. Without interpolate_subframe the reference
+     estimates symbol 0 only and interpolates from never-written symbols (-3 here), as it does for ports 2/3 (symbol 0 unwritten). */
+  const uint32_t P = cell->nof_prb, nre = 12 * P, ncrs = 2 * P, nmb = 6 * P, npil = 20 * P;
+  if (port > 1 || !cfg->interpolate_subframe) return -3;
+  cf* known = malloc(sizeof(cf) * 8 * P);
+  cf* mb    = malloc(sizeof(cf) * 18 * P);
+  cf* est   = malloc(sizeof(cf) * npil);
+  cf* avg   = malloc(sizeof(cf) * npil);
+  cf* tmp   = malloc(sizeof(cf) * 3 * (npil / 3 + 2));
+  if (orc_mbsfn_pilots(P, area_id, sf_idx, mb)) {
+    free(known); free(mb); free(est); free(avg); free(tmp);
+    return -1;
+  }
+  orc_crs_pilots(cell, sf_idx, port, known);
+  uint32_t fidx = orc_crs_fidx(cell, 0, port); /* srslte_refsignal_mbsfn_get_sf (refsignal_dl.c:455-487) + LS (:734-741) */
+  for (uint32_t i = 0; i < ncrs; i++) est[i] = c_mulconj(grid[orc_crs_nsymbol(0, cell->cp_norm, port) * nre + fidx + 6 * i], known[i]);
+  for (uint32_t l = 0; l < 3; l++) {
+    for (uint32_t i = 0; i < nmb; i++) est[ncrs + nmb * l + i] = c_mulconj(grid[MBSFN_SYM[l] * nre + MBSFN_FIDX[l] + 2 * i], mb[nmb * l + i]);
+  }
+  /* REFS noise: estimate_noise_pilots walks the 20 nof_prb estimates as 3 rows of 20 nof_prb / 3 (integer), CRS row included (:310-315) */
+  float noise = cfg->noise_alg == 0 ? noise_pilots(est, npil / 3, 3, MBSFN_FIDX[1], tmp) : NAN;
+  if (noise_out) *noise_out = noise;
+  if (ce) {
+    float    filter[64];
+    uint32_t flen = 0;
+    if (cfg->filter_type == 0) { /* the reference warns that Gauss is "not supported" and applies it (:628-637) */
+      flen = cfg->filter_coef[0] <= 0 ? gauss_filter(filter, 4, noise * 200.0f) : gauss_filter(filter, (uint32_t)cfg->filter_coef[0], cfg->filter_coef[1]);
+    } else if (cfg->filter_type == 1) {
+      filter[0] = cfg->filter_coef[0]; filter[2] = cfg->filter_coef[0]; filter[1] = 1 - 2 * cfg->filter_coef[0];
+      flen = 3;
+    }
+    const cf* pil = est;
+    if (cfg->filter_type != 2) { /* average_pilots: the CRS row is copied, each MBSFN row smoothed (:546-555) */
+      memcpy(avg, est, sizeof(cf) * ncrs);
+      for (uint32_t l = 0; l < 3; l++) conv_same_cf(&est[ncrs + nmb * l], filter, &avg[ncrs + nmb * l], nmb, flen);
+      pil = avg;
+    }
+    interp_linear_offset(pil, &ce[orc_crs_nsymbol(0, cell->cp_norm, port) * nre], ncrs, 6, fidx, 6 - fidx); /* :436-440 */
+    for (uint32_t l = 0; l < 3; l++) {                                                                      /* :441-447 */
+      interp_linear_offset(&pil[ncrs + nmb * l], &ce[MBSFN_SYM[l] * nre], nmb, 2, MBSFN_FIDX[l], MBSFN_FIDX[l] ? 1 : 2);
+    }
+#define S(i) (&ce[(i) * nre])
+    interp_vector(S(0), S(2), NULL, S(1), 2, 1, nre); /* :474-478 */
+    interp_vector(S(2), S(6), NULL, S(3), 4, 3, nre);
+    interp_vector(S(6), S(10), NULL, S(7), 4, 3, nre);
+    interp_vector(S(6), S(10), S(10), S(11), 4, 1, nre);
+#undef S
+  }
+  free(known); free(mb); free(est); free(avg); free(tmp);
+  return 0;
 }
 
 /* ------------------------------------------------------------------ UL: PUSCH DMRS (refsignal_ul.c) and srslte_chest_ul_estimate_pusch

@@ -254,6 +254,78 @@ def test_chest_dl_vs_ref(prb, cid):
             R.srslte_chest_dl_free(q)
 
 
+MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
+              {"filter_coef": (4.0, 1.5)}, {}]
+
+
+@pytest.mark.parametrize("prb,cid,area,port", [(6, 1, 1, 0), (25, 2, 0, 0), (50, 3, 255, 0), (100, 4, 17, 0), (100, 5, 2, 1), (15, 150, 77, 1)])
+def test_chest_dl_mbsfn_vs_ref(prb, cid, area, port):
+    """MBSFN subframes: srslte_refsignal_mbsfn_put_sf and srslte_chest_dl_estimate_cfg with sf_type MBSFN
+    (chest_dl.c:718-745 and the MBSFN branches of :304-556) against orc_mbsfn_put_sf / orc_chest_dl_mbsfn, with the applications'
+    configuration (triangle 0.1, PSS noise: cc_worker.cc:90-93) and the other filters; the 12 written symbols of ce and the REFS noise.
+    The measurement fields the reference leaves stale in an MBSFN subframe keep the previous normal subframe's values."""
+    R, rng = ref(), np.random.default_rng(900 + prb + cid + area)
+    orc = oracle()
+    orc.orc_chest_dl_mbsfn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    nports = 2 if port else 1
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, nports, True)
+    q = opaque(1 << 20)
+    assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, nports, cid, 0, 0, 0, 0)) == 0
+    assert R.srslte_chest_dl_set_mbsfn_area_id(q, area) == 0
+    for sf_idx in (1, 2, 3, 6, 7, 8):
+        # the reference's generator for the stimulus pilots
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        g2 = g.copy()
+        assert orc.orc_mbsfn_put_sf(C.byref(cell), sf_idx, port, area, p(g)) == 0
+        crs, mb = np.zeros(8 * prb, np.complex64), np.zeros(18 * prb, np.complex64)
+        orc.orc_crs_pilots(C.byref(cell), sf_idx, port, p(crs))
+        orc.orc_mbsfn_pilots(prb, area, sf_idx, p(mb))
+        rs = opaque(4096)
+        assert R.srslte_refsignal_mbsfn_init(rs, prb) == 0 and R.srslte_refsignal_mbsfn_set_cell(rs, RefCell(prb, nports, cid, 0, 0, 0, 0), area) == 0
+        from _libs import ref_layout
+        off = ref_layout({"srslte_refsignal_t": ["pilots"]}, ["srslte/phy/ch_estimation/refsignal_dl.h"])["srslte_refsignal_t.pilots"]
+        pil_ptr = C.cast(C.byref(rs, off), C.POINTER(C.c_void_p))
+        ref_mb = np.frombuffer(C.string_at(pil_ptr[(port // 2) * 10 + sf_idx], 8 * 18 * prb), np.complex64)
+        assert np.array_equal(ref_mb.view(np.float32), mb.view(np.float32)), "MBSFN pilot sequence"
+        ga = acopy(g2.view(np.float32))
+        assert R.srslte_refsignal_mbsfn_put_sf(RefCell(prb, nports, cid, 0, 0, 0, 0), port, p(acopy(crs.view(np.float32))), C.c_void_p(ref_mb.ctypes.data), p(ga)) == 0
+        assert np.array_equal(ga, g.view(np.float32)), "mbsfn_put_sf"
+        R.srslte_refsignal_free(rs)
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+        grid = acopy((g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        for kw in MBSFN_CFGS:
+            rc, oc = RefChestCfg(), OrcChestCfg()
+            for kk, v in kw.items():
+                if kk == "filter_coef":
+                    rc.filter_coef[0], rc.filter_coef[1] = v
+                    oc.filter_coef[0], oc.filter_coef[1] = v
+                else:
+                    setattr(rc, kk, v)
+                    setattr(oc, kk, v)
+            rc.interpolate_subframe = oc.interpolate_subframe = True
+            rc.mbsfn_area_id = area
+            ces = [aligned(2 * n, np.float32) for _ in range(nports)]
+            res, sf = RefChestRes(), RefDlSfCfg()
+            for pp in range(nports):
+                res.ce[pp][0] = ces[pp].ctypes.data
+            sf.tti, sf.sf_type = sf_idx, 1
+            inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+            assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+            ce2, noise = np.zeros(n, np.complex64), C.c_float(0)
+            assert orc.orc_chest_dl_mbsfn(C.byref(cell), sf_idx, C.byref(oc), area, port, p(grid), p(ce2), C.byref(noise)) == 0
+            a = ces[port].view(np.complex64)[:12 * nre]
+            assert np.abs(a - ce2[:12 * nre]).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (prb, cid, kw, sf_idx)
+            if kw.get("noise_alg", 0) == 0 and nports == 1:
+                assert abs(res.noise_estimate - noise.value) <= 1e-4 * abs(noise.value), (res.noise_estimate, noise.value)
+            elif kw.get("noise_alg", 0):
+                assert np.isnan(noise.value)
+    R.srslte_chest_dl_free(q)
+    oc = OrcChestCfg()
+    assert orc.orc_chest_dl_mbsfn(C.byref(cell), 1, C.byref(oc), area, 0, p(grid), p(ce2), None) == -3  # needs interpolate_subframe
+
+
 @pytest.mark.parametrize("prb,cid", [(6, 0), (25, 7), (100, 301)])
 def test_chest_dl_two_rx_antennas_vs_ref(prb, cid):
     """srslte_chest_dl_estimate_cfg with nof_rx_antennas = 2 (chest_dl.c:884-908 + fill_res :845-871): per-antenna estimates and the
