@@ -93,9 +93,18 @@ int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hi
 int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                              void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream);
 /* device pointer to [nof_sf][nof_ports][nof_rx] x {noise_estimate, rsrp, rssi, cfo, sync_err, rsrp_corr} (6 floats) of the last call
- * with more than one (port, antenna) or cfg.rsrp_neighbour: the per-antenna / per-port terms of fill_res (chest_dl.c:860-870) and of
- * get_rsrp_neighbour (:821-843) */
+ * with d_res: the per-antenna / per-port terms of fill_res (chest_dl.c:860-870) and of get_rsrp_neighbour (:821-843) */
 const float* srslte_hip_chest_dl_last_raw(const srslte_hip_chest_dl_t* q);
+/* MBSFN subframes (srslte_chest_dl_set_mbsfn_area_id chest_dl.c:244-262 with the reference signal of refsignal_dl.c:361-400,
+ * estimate_port_mbsfn :718-745 and the MBSFN branches of :304-556). 1- and 2-port cells, cfg->interpolate_subframe set (the reference's
+ * result without it is undefined), area id from cfg->mbsfn_area_id. d_grid [nof_sf][nof_rx][14][12*nof_prb] holds the 12 symbols of
+ * the extended-CP subframe; d_ce [nof_sf][nof_ports][nof_rx][14][12*nof_prb] gets symbols 0-11. d_noise (or NULL):
+ * [nof_sf][nof_ports][nof_rx] REFS noise estimates, written only with cfg->noise_alg == REFS. As in the reference an MBSFN subframe
+ * measures nothing else: rsrp, rssi, cfo and the sync error keep the values of the last normal subframe (the compat layer keeps them). */
+int         srslte_hip_chest_dl_set_mbsfn_area_id(srslte_hip_chest_dl_t* q, uint16_t mbsfn_area_id);
+const void* srslte_hip_chest_dl_mbsfn_pilots(const srslte_hip_chest_dl_t* q, uint16_t mbsfn_area_id); /* device [10][3][6*nof_prb] or NULL */
+int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
+                                             void* d_ce, float* d_noise, int nof_sf, int nof_rx, void* stream);
 
 /* ------------------------------------------------------------------ UL channel estimator (replaces
  * srslte_chest_ul_init/_set_cell/_pregen/_estimate_pusch, ch_estimation/chest_ul.h:47-104, chest_ul.c:51-327, and the PUSCH DMRS of

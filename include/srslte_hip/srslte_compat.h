@@ -11,8 +11,8 @@
  * (srslte_dft_plan_t.p, srslte_tdec_t.dec16_hdlr[0], srslte_chest_dl_t.tmp_noise ...).
  * tests/test_abi_layout.py checks sizeof/offsetof of every struct below against the reference headers.
  *
- * Not provided (documented in DESIGN.md): MBSFN channel estimation, multi-port / multi-antenna estimation; those calls
- * return SRSLTE_ERROR with a message.
+ * Not provided (documented in DESIGN.md): the PSS / EMPTY noise algorithms in normal subframes, interpolate_subframe on a 4-port cell or
+ * switched off in an MBSFN subframe; those calls return SRSLTE_ERROR with a message.
  */
 #ifndef SRSLTE_HIP_SRSLTE_COMPAT_H
 #define SRSLTE_HIP_SRSLTE_COMPAT_H
@@ -215,7 +215,7 @@ void srslte_chest_dl_res_set_identity(srslte_chest_dl_res_t* q);
 void srslte_chest_dl_res_set_ones(srslte_chest_dl_res_t* q);
 void srslte_chest_dl_res_free(srslte_chest_dl_res_t* q);
 int  srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell);
-int  srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id); /* SRSLTE_ERROR: MBSFN estimation not provided */
+int  srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id); /* chest_dl.c:244-262 */
 int  srslte_chest_dl_estimate(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res);
 int  srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg, cf_t* input[SRSLTE_MAX_PORTS],
                                   srslte_chest_dl_res_t* res);

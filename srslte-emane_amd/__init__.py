@@ -81,6 +81,10 @@ def lib():
         L.srslte_hip_chest_dl_create.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
         L.srslte_hip_chest_dl_destroy.argtypes = [vp]
         L.srslte_hip_chest_dl_estimate_batch.argtypes = [vp, C.POINTER(ChestDlCfg), C.c_uint32, vp, vp, vp, C.c_int, vp]
+        L.srslte_hip_chest_dl_set_mbsfn_area_id.argtypes = [vp, C.c_uint16]
+        L.srslte_hip_chest_dl_mbsfn_pilots.restype = vp
+        L.srslte_hip_chest_dl_mbsfn_pilots.argtypes = [vp, C.c_uint16]
+        L.srslte_hip_chest_dl_estimate_mbsfn_batch.argtypes = [vp, C.POINTER(ChestDlCfg), C.c_uint32, vp, vp, vp, C.c_int, C.c_int, vp]
         for n in ("", "_s", "_b"):
             getattr(L, "srslte_hip_demod_soft_demodulate%s_batch" % n).argtypes = [C.c_int, vp, vp, C.c_int, C.c_int, vp]
         L.srslte_hip_tdec_create.restype = vp
@@ -234,6 +238,24 @@ class ChestDl:
         if not self.h:
             raise RuntimeError("srslte_hip_chest_dl_create failed")
         self.grid_len = 14 * 12 * nof_prb
+        self.nof_ports = nof_ports
+
+    def set_mbsfn_area_id(self, area_id):
+        """srslte_chest_dl_set_mbsfn_area_id (chest_dl.c:244-262)."""
+        return lib().srslte_hip_chest_dl_set_mbsfn_area_id(self.h, area_id)
+
+    def estimate_mbsfn(self, grid, tti0, cfg, nof_rx=1, want_ce=True):
+        """MBSFN subframes (cfg.mbsfn_area_id): grid [nof_sf][nof_rx][14*12*prb] -> (rc, ce [nof_sf][nof_ports][nof_rx][...], noise
+        [nof_sf][nof_ports][nof_rx]); symbols 12, 13 of ce are not written (returned as zeros)."""
+        g = np.ascontiguousarray(grid, np.complex64).reshape(-1, nof_rx, self.grid_len)
+        n = g.shape[0]
+        dg, dce, dn = DevBuf.from_host(g), DevBuf(g.nbytes * self.nof_ports), DevBuf(4 * n * nof_rx * self.nof_ports)
+        _check(lib().srslte_hip_memset(dce.ptr, 0, g.nbytes * self.nof_ports), "memset")
+        rc = lib().srslte_hip_chest_dl_estimate_mbsfn_batch(self.h, C.byref(cfg), tti0, dg.ptr, dce.ptr if want_ce else None, dn.ptr, n, nof_rx, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None
+        sync()
+        return rc, dce.to_host(np.complex64).reshape(n, self.nof_ports, nof_rx, self.grid_len), dn.to_host(np.float32).reshape(n, self.nof_ports, nof_rx)
 
     def estimate(self, grid, tti0=0, cfg=None, want_ce=True):
         cfg = cfg or ChestDlCfg()

@@ -304,6 +304,103 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   }
 }
 
+// MBSFN subframes (chest_dl.c:718-745 with the MBSFN branches of :304-556): one workgroup per (subframe, port, antenna). The 12-symbol
+// subframe carries the port's CRS in symbol 0 and the MBSFN reference signal on every second sub-carrier of symbols 2, 6, 10 (offsets
+// 0, 1, 0). LS estimates est = [2P CRS | 3 x 6P MBSFN]; the CRS row is used as it is, the MBSFN rows are smoothed; frequency interpolation
+// (step 6 / step 2) is evaluated per sub-carrier straight into the time interpolation 0-2, 2-6, 6-10 and the extrapolation to 11.
+// noise: estimate_noise_pilots reads the 20P estimates as 3 rows of 20P/3 (CRS included) and keeps the last row's residual (:310-378).
+__global__ __launch_bounds__(CH_THREADS) void chest_dl_mbsfn_kernel(const cf32* __restrict__ grid, cf32* __restrict__ ce, float* __restrict__ noise_out,
+                                                                   const cf32* __restrict__ pilots, const cf32* __restrict__ mbsfn_pilots,
+                                                                   ChestParams p)
+{
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int P = p.nof_prb, nre = 12 * P, ncrs = 2 * P, nmb = 6 * P, npil = 20 * P;
+  cf32*  est = reinterpret_cast<cf32*>(lds_raw); // [20 P]
+  cf32*  avg = est + npil;                       // [20 P]
+  __shared__ float red[CH_THREADS / 64];
+  __shared__ float filt[64];
+  const int   sf = blockIdx.x, tid = threadIdx.x;
+  const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
+  const cf32* g     = grid + ((size_t)sfn * p.nof_rx + ant) * 14 * nre;
+  const cf32* known = pilots + (size_t)sf_idx * 4 * ncrs;      // first CRS symbol of ports 0/1
+  const cf32* mb    = mbsfn_pilots + (size_t)sf_idx * 3 * nmb; // [3][6 P]
+  const int   fidx  = crs_fidx(p.cell_id, 0, port);
+
+  for (int i = tid; i < npil; i += CH_THREADS) { // srslte_refsignal_mbsfn_get_sf (refsignal_dl.c:455-487) + LS (chest_dl.c:734-741)
+    if (i < ncrs) {
+      est[i] = c_mulconj(g[fidx + 6 * i], known[i]);
+    } else {
+      const int l = (i - ncrs) / nmb, k = (i - ncrs) - l * nmb;
+      est[i]      = c_mulconj(g[(2 + 4 * l) * nre + (l == 1 ? 1 : 0) + 2 * k], mb[l * nmb + k]);
+    }
+  }
+  __syncthreads();
+
+  float noise = 0;
+  if (p.noise_alg == 0) { // last of the 3 rows: odd row index and fidx(1) = 1 < 3 give offset 1; both neighbour rows are the middle row
+    const int   nref = npil / 3;
+    const cf32 *r2 = est + nref, *r3 = est + 2 * nref;
+    float       acc = 0;
+    for (int k = tid; k < nref; k += CH_THREADS) {
+      const cf32 side = c_add(r2[k], k >= 1 ? r2[k - 1] : c_sub(c_scale(r2[0], 2.0f), r2[1]));
+      cf32       t    = c_add(c_add(r3[k], side), side);
+      t               = c_sub(r3[k], c_scale(t, 1.0f / 5.0f));
+      acc += t.x * t.x + t.y * t.y;
+    }
+    noise = block_sum(acc, red) / nref / 3.0f * sqrtf(5.0f);
+    if (tid == 0 && noise_out) noise_out[sf] = noise;
+  }
+  if (!ce) return;
+
+  if (tid == 0) { // chest_dl.c:626-646
+    if (p.filter_type == 0) {
+      const int   order = p.coef0 <= 0 ? 4 : (int)p.coef0;
+      const float sd    = p.coef0 <= 0 ? noise * 200.0f : p.coef1;
+      const int   len = order + 1, center = (len - 1) / 2;
+      float       norm = 0;
+      for (int i = 0; i < len; i++) {
+        filt[i] = expf(-powf((float)(i - center), 2) / (2.0f * powf(sd, 2)));
+        norm += filt[i];
+      }
+      for (int i = 0; i < len; i++) filt[i] *= 1.0f / norm;
+    } else if (p.filter_type == 1) {
+      filt[0] = p.coef0;
+      filt[2] = p.coef0;
+      filt[1] = 1 - 2 * p.coef0;
+    }
+  }
+  const int flen = p.filter_type == 0 ? (p.coef0 <= 0 ? 5 : (int)p.coef0 + 1) : (p.filter_type == 1 ? 3 : 0);
+  __syncthreads();
+  const cf32* pil = est;
+  if (p.filter_type != 2) { // average_pilots, MBSFN: CRS row copied, MBSFN rows smoothed (chest_dl.c:546-555)
+    for (int i = tid; i < npil; i += CH_THREADS) {
+      if (i < ncrs) {
+        avg[i] = est[i];
+      } else {
+        const int l = (i - ncrs) / nmb;
+        avg[i]      = conv_at(est + ncrs + l * nmb, filt, nmb, flen, (i - ncrs) - l * nmb);
+      }
+    }
+    __syncthreads();
+    pil = avg;
+  }
+  cf32* o = ce + (size_t)sf * 14 * nre;
+  for (int k = tid; k < nre; k += CH_THREADS) { // interpolate_pilots, MBSFN (chest_dl.c:436-447, :474-478)
+    const cf32 s0 = interp_offset_at(pil, ncrs, 6, fidx, k), s2 = interp_offset_at(pil + ncrs, nmb, 2, 0, k);
+    const cf32 s6 = interp_offset_at(pil + ncrs + nmb, nmb, 2, 1, k), s10 = interp_offset_at(pil + ncrs + 2 * nmb, nmb, 2, 0, k);
+    o[k]           = s0;
+    o[nre + k]     = c_add(s0, c_scale(c_sub(s2, s0), 1.0f / 2));
+    o[2 * nre + k] = s2;
+    cf32 d = c_scale(c_sub(s6, s2), 1.0f / 4), v = s2;
+    for (int l = 3; l <= 5; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+    o[6 * nre + k] = s6;
+    d = c_scale(c_sub(s10, s6), 1.0f / 4); v = s6;
+    for (int l = 7; l <= 9; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+    o[10 * nre + k] = s10;
+    o[11 * nre + k] = c_add(s10, d);
+  }
+}
+
 // fill_res (chest_dl.c:747-871) for more than one (antenna, port): noise averaged over ports and antennas; RSSI and RSRQ from port 0,
 // averaged over the antennas; get_rsrp (:809-819) indexes ports with the ANTENNA counter: max over i < nof_rx of the antenna-mean RSRP
 // of port i (0 for a port that was never estimated); q->cfo is overwritten by every estimate in turn: the last (antenna, port) survives
@@ -368,6 +465,7 @@ struct srslte_hip_chest_dl {
   cf32*     d_pilots; // [10][4][2*nof_prb] ports 0 and 1, then [10][2][2*nof_prb] ports 2 and 3 (4-port cells)
   ChestRaw* d_raw;    // per (subframe, port, antenna) scalars of multi-antenna / multi-port calls, grown on demand
   size_t    raw_cap;
+  cf32*     d_mbsfn[256]; // per MBSFN area id: [10][3][6*nof_prb] (set_mbsfn_area_id), or null
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
@@ -399,6 +497,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   q->d_pilots = nullptr;
   q->d_raw    = nullptr;
   q->raw_cap  = 0;
+  for (auto& m : q->d_mbsfn) m = nullptr;
   if (hipMalloc((void**)&q->d_pilots, sizeof(cf32) * pil.size()) != hipSuccess ||
       hipMemcpy(q->d_pilots, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] chest_dl: device allocation failed\n");
@@ -413,7 +512,75 @@ extern "C" void srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q)
   if (!q) return;
   if (q->d_pilots) (void)hipFree(q->d_pilots);
   if (q->d_raw) (void)hipFree(q->d_raw);
+  for (auto m : q->d_mbsfn) {
+    if (m) (void)hipFree(m);
+  }
   delete q;
+}
+
+extern "C" int srslte_hip_chest_dl_set_mbsfn_area_id(srslte_hip_chest_dl_t* q, uint16_t mbsfn_area_id)
+{ // srslte_chest_dl_set_mbsfn_area_id (chest_dl.c:244-262) with srslte_refsignal_mbsfn_gen_seq (refsignal_dl.c:361-400)
+  if (!q || mbsfn_area_id > 255) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->d_mbsfn[mbsfn_area_id]) return SRSLTE_SUCCESS;
+  const int            nmb = 6 * q->nof_prb, MAX_PRB = 110;
+  std::vector<cf32>    pil((size_t)10 * 3 * nmb);
+  std::vector<uint8_t> c;
+  for (uint32_t sf = 0; sf < 10; sf++) {
+    for (uint32_t l = 0; l < 3; l++) {
+      const uint32_t lp = (2 + 4 * l) % 6, slot = l ? 2 * sf + 1 : 2 * sf;
+      gold(512 * (7 * (slot + 1) + lp + 1) * (2 * (uint32_t)mbsfn_area_id + 1) + mbsfn_area_id, 20 * MAX_PRB, c);
+      for (int i = 0; i < nmb; i++) {
+        const int mp = i + 3 * (MAX_PRB - q->nof_prb);
+        pil[((size_t)sf * 3 + l) * nmb + i] =
+            make_float2((float)((1 - 2 * (float)c[2 * mp]) / sqrt(2.0)), (float)((1 - 2 * (float)c[2 * mp + 1]) / sqrt(2.0)));
+      }
+    }
+  }
+  cf32* d = nullptr;
+  HIP_TRY(hipMalloc((void**)&d, sizeof(cf32) * pil.size()));
+  if (hipMemcpy(d, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipFree(d);
+    return SRSLTE_ERROR;
+  }
+  q->d_mbsfn[mbsfn_area_id] = d;
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" const void* srslte_hip_chest_dl_mbsfn_pilots(const srslte_hip_chest_dl_t* q, uint16_t mbsfn_area_id)
+{
+  return q && mbsfn_area_id < 256 ? q->d_mbsfn[mbsfn_area_id] : nullptr;
+}
+
+extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
+                                                        const void* d_grid, void* d_ce, float* d_noise, int nof_sf, int nof_rx, void* stream)
+{
+  if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4 || cfg->mbsfn_area_id > 255) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!q->d_mbsfn[cfg->mbsfn_area_id]) {
+    fprintf(stderr, "[srslte_hip] chest_dl: MBSFN area id=%d not initialized\n", cfg->mbsfn_area_id); // chest_dl.c:729-731
+    return SRSLTE_ERROR;
+  }
+  if (q->nof_ports > 2 || (!cfg->interpolate_subframe && d_ce)) {
+    // upstream then interpolates in time from symbols nothing wrote (chest_dl.c:430-433,:474-478; ports 2/3 leave symbol 0 unwritten)
+    fprintf(stderr, "[srslte_hip] chest_dl: MBSFN subframes need interpolate_subframe and a 1- or 2-port cell\n");
+    return SRSLTE_ERROR;
+  }
+  if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && cfg->noise_alg != 0 && d_ce) {
+    fprintf(stderr, "[srslte_hip] chest_dl: the automatic Gauss filter needs the REFS noise estimate in an MBSFN subframe\n");
+    return SRSLTE_ERROR;
+  }
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  ChestParams p;
+  p = ChestParams{};
+  p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;
+  p.noise_alg = cfg->noise_alg; p.filter_type = cfg->filter_type; p.interpolate_subframe = 1;
+  p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
+  p.nof_rx = nof_rx; p.nof_ports = q->nof_ports;
+  hipLaunchKernelGGL(chest_dl_mbsfn_kernel, dim3(nof_sf * nof_rx * q->nof_ports), dim3(CH_THREADS), sizeof(cf32) * 40 * q->nof_prb,
+                     (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce, d_noise, (const cf32*)q->d_pilots,
+                     (const cf32*)q->d_mbsfn[cfg->mbsfn_area_id], p);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
 }
 
 extern "C" const void* srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q) { return q ? q->d_pilots : nullptr; }
@@ -449,7 +616,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.nof_ports = q->nof_ports;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
-  if ((nslice > 1 || cfg->rsrp_neighbour) && d_res) {
+  if (d_res) {
     const size_t need = (size_t)nof_sf * nslice;
     if (need > q->raw_cap) {
       if (q->d_raw) (void)hipFree(q->d_raw);

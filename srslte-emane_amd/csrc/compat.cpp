@@ -878,10 +878,11 @@ int srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell)
 }
 
 int srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id)
-{ // chest_dl.c:195-210 builds the MBSFN reference signal; the MBSFN estimator (:718-745) is SURVEY §8f N4
-  (void)q;
-  ERROR("MBSFN channel estimation (area id %u) is not provided by the HIP build", (unsigned)mbsfn_area_id);
-  return SRSLTE_ERROR;
+{ // chest_dl.c:244-262: builds the area's MBSFN reference signal (on the device)
+  auto* st = q ? (ChestState*)q->tmp_noise : nullptr;
+  if (!st || !st->h) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (mbsfn_area_id >= 256) return SRSLTE_ERROR; // SRSLTE_MAX_MBSFN_AREA_IDS; // upstream returns -1 without a message (:260)
+  return srslte_hip_chest_dl_set_mbsfn_area_id(st->h, mbsfn_area_id) ? SRSLTE_ERROR : SRSLTE_SUCCESS;
 }
 
 int srslte_chest_dl_res_init(srslte_chest_dl_res_t* q, uint32_t max_prb)
@@ -920,15 +921,87 @@ void srslte_chest_dl_res_free(srslte_chest_dl_res_t* q)
   memset(q, 0, sizeof(*q));
 }
 
+// MBSFN subframes (chest_dl.c:718-745,:892-896): estimates and, with the REFS algorithm, the noise come from the device; rsrp, rssi, cfo,
+// the sync error (and the noise with PSS / EMPTY) are what the last normal subframe left in q, and fill_res (:845-871) reads those
+static int chest_dl_estimate_mbsfn(srslte_chest_dl_t* q, ChestState* st, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg,
+                                   cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res)
+{
+  const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
+  const size_t   n   = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
+  char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx * npt);
+  float*         dnoise = (float*)st->res.get(sizeof(float) * 16);
+  if (!dg || !dce || !dnoise) return SRSLTE_ERROR;
+  bool want_ce = false;
+  for (uint32_t a = 0; a < nrx; a++) {
+    if (!input[a] || !h2d(dg + a * n, input[a], n)) return SRSLTE_ERROR_INVALID_INPUTS;
+    for (uint32_t pt = 0; pt < npt; pt++) want_ce = want_ce || res->ce[pt][a];
+  }
+  if (want_ce) { // the caller's symbols 12, 13 (not part of the 12-symbol subframe) stay as they are
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      for (uint32_t a = 0; a < nrx; a++) {
+        if (res->ce[pt][a] && !h2d(dce + (pt * nrx + a) * n, res->ce[pt][a], n)) return SRSLTE_ERROR;
+      }
+    }
+  }
+  srslte_hip_chest_dl_cfg_t hc;
+  memset(&hc, 0, sizeof(hc));
+  hc.noise_alg = cfg->noise_alg; hc.filter_type = cfg->filter_type; hc.filter_coef[0] = cfg->filter_coef[0]; hc.filter_coef[1] = cfg->filter_coef[1];
+  hc.interpolate_subframe = cfg->interpolate_subframe; hc.mbsfn_area_id = cfg->mbsfn_area_id;
+  if (srslte_hip_chest_dl_estimate_mbsfn_batch(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dnoise, 1, (int)nrx, nullptr)) return SRSLTE_ERROR;
+  if (cfg->noise_alg == SRSLTE_NOISE_ALG_REFS) {
+    float nz[16];
+    if (!d2h(nz, dnoise, sizeof(float) * nrx * npt)) return SRSLTE_ERROR;
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      for (uint32_t a = 0; a < nrx; a++) q->noise_estimate[a][pt] = nz[pt * nrx + a];
+    }
+  }
+  for (uint32_t pt = 0; pt < npt; pt++) {
+    for (uint32_t a = 0; a < nrx; a++) {
+      if (res->ce[pt][a] && !d2h(res->ce[pt][a], dce + (pt * nrx + a) * n, n)) return SRSLTE_ERROR;
+    }
+  }
+  // fill_res (chest_dl.c:747-871) on the estimator's kept state
+  auto  dbm = [](float a) { return (float)(10 * log10(a) + 30); };
+  auto  db  = [](float a) { return (float)(10 * log10(a)); };
+  float noise = 0.f, rssi = 0.f, rsrq = 0.f, rsrp = -1e9f, neigh = -1e9f;
+  for (uint32_t a = 0; a < nrx; a++) {
+    float s = 0.f, c = 0.f;
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      s += q->noise_estimate[a][pt];
+      c += q->rsrp_corr[a][pt];
+    }
+    noise += s / npt;
+    rssi += 4 * q->rssi[a][0] / q->cell.nof_prb / 12;
+    rsrq += q->cell.nof_prb * q->rsrp[a][0] / q->rssi[a][0];
+    float v = 0.f; // get_rsrp indexes the ports with the antenna counter (:809-819)
+    for (uint32_t j = 0; j < nrx; j++) v += q->rsrp[j][a];
+    v /= nrx;
+    rsrp  = v > rsrp ? v : rsrp;
+    neigh = c / npt > neigh ? c / npt : neigh;
+  }
+  noise /= nrx; rssi /= nrx; rsrq /= nrx;
+  res->noise_estimate = noise; res->noise_estimate_dbm = dbm(noise); res->cfo = q->cfo; res->rsrp = rsrp; res->rsrp_dbm = dbm(rsrp);
+  res->rsrp_neigh = neigh; res->rsrq = rsrq; res->rsrq_db = db(rsrq); res->snr_db = db(rsrp / noise); res->rssi_dbm = dbm(rssi);
+  res->sync_error = q->sync_err[0][0];
+  for (uint32_t pt = 0; pt < npt; pt++) {
+    float mean_rsrp = 0.f;
+    for (uint32_t a = 0; a < nrx; a++) {
+      mean_rsrp += q->rsrp[a][pt] / nrx;
+      res->snr_ant_port_db[a][pt]   = db(q->rsrp[a][pt] / q->noise_estimate[a][pt]);
+      res->rsrp_ant_port_dbm[a][pt] = dbm(q->rsrp[a][pt]);
+      res->rsrq_ant_port_db[a][pt]  = db(q->cell.nof_prb * q->rsrp[a][pt] / q->rssi[a][pt]);
+    }
+    res->rsrp_port_dbm[pt] = dbm(mean_rsrp);
+  }
+  return SRSLTE_SUCCESS;
+}
+
 int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg, cf_t* input[SRSLTE_MAX_PORTS],
                                  srslte_chest_dl_res_t* res)
 { // chest_dl.c:884-908
   auto* st = q ? (ChestState*)q->tmp_noise : nullptr;
   if (!st || !st->h || !sf || !cfg || !input || !res) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (sf->sf_type != SRSLTE_SF_NORM) {
-    ERROR("chest_dl: only normal subframes are implemented on device");
-    return SRSLTE_ERROR;
-  }
+  if (sf->sf_type == SRSLTE_SF_MBSFN) return chest_dl_estimate_mbsfn(q, st, sf, cfg, input, res);
   const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
   const size_t   n   = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
   char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx * npt);
@@ -960,7 +1033,7 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   res->rsrp = r.rsrp; res->rsrp_dbm = r.rsrp_dbm; res->rsrq = r.rsrq; res->rsrq_db = r.rsrq_db; res->rssi_dbm = r.rssi_dbm;
   res->cfo = q->cfo; res->sync_error = r.sync_error;
   float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}
-  if ((nrx * npt > 1 || hc.rsrp_neighbour) && !d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 6 * nrx * npt)) return SRSLTE_ERROR;
+  if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 6 * nrx * npt)) return SRSLTE_ERROR;
   if (hc.rsrp_neighbour) {
     for (uint32_t pt = 0; pt < npt; pt++) {
       for (uint32_t a = 0; a < nrx; a++) q->rsrp_corr[a][pt] = raw[pt * nrx + a][5];
@@ -979,6 +1052,7 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   if (nrx * npt == 1) {
     q->noise_estimate[0][0] = r.noise_estimate;
     q->rsrp[0][0]           = r.rsrp;
+    q->rssi[0][0]           = raw[0][2];
     res->rsrp_port_dbm[0] = r.rsrp_dbm; res->snr_ant_port_db[0][0] = r.snr_db; res->rsrp_ant_port_dbm[0][0] = r.rsrp_dbm;
     res->rsrq_ant_port_db[0][0] = r.rsrq_db;
   } else { // per-antenna / per-port fields (chest_dl.c:860-870) from the per-(port, antenna) scalars the device kept

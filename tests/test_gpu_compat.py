@@ -299,6 +299,65 @@ def test_chest_dl_object():
     L.srslte_chest_dl_free(est)
 
 
+def test_chest_dl_object_mbsfn():
+    """srslte_chest_dl_set_mbsfn_area_id + srslte_chest_dl_estimate_cfg on an MBSFN subframe (ue_dl.c:374-397 with cc_worker.cc:90-93's
+    configuration, and with the REFS noise): the 12 estimated symbols, and a result struct whose rsrp / rssi-derived fields are the last
+    normal subframe's while the noise (REFS) is the MBSFN subframe's, as the reference's fill_res reports them."""
+    L, rng = hip(), np.random.default_rng(14)
+    orc = oracle()
+    orc.orc_chest_dl_mbsfn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    prb, cid, area = 50, 7, 33
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    orc.orc_crs_put_sf(C.byref(cell), 0, 0, p(g))
+    grid0 = acopy((g * h + 0.05 * rng.standard_normal(n)).astype(np.complex64).view(np.float32))
+    sf, rc = RefDlSfCfg(), RefChestCfg()
+    sf.tti = 0
+    assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid0.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+    r0, oc0 = OrcChestRes(), OrcChestCfg()
+    assert orc.orc_chest_dl(C.byref(cell), 0, C.byref(oc0), p(grid0), None, C.byref(r0)) == 0
+    prev_noise = res.noise_estimate
+    sf.tti, sf.sf_type = 21, 1
+    rc.mbsfn_area_id, rc.interpolate_subframe = area, True
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    assert orc.orc_mbsfn_put_sf(C.byref(cell), 1, 0, area, p(g)) == 0
+    grid = acopy((g * h + 0.05 * rng.standard_normal(n)).astype(np.complex64).view(np.float32))
+    inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+    assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) != 0  # area id not set
+    assert L.srslte_chest_dl_set_mbsfn_area_id(est, 256) != 0 and L.srslte_chest_dl_set_mbsfn_area_id(est, area) == 0
+    ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+    for alg, ftype, coef in ((1, 1, 0.1), (0, 1, 0.1), (2, 2, 0.0), (0, 0, 0.0)):
+        rc.noise_alg, rc.filter_type = alg, ftype
+        rc.filter_coef[0] = coef
+        ce[12 * nre:] = 7 + 7j
+        rcode = L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res))
+        oc = OrcChestCfg()
+        oc.noise_alg, oc.filter_type, oc.interpolate_subframe = alg, ftype, True
+        oc.filter_coef[0] = coef
+        ref, nz = np.zeros(n, np.complex64), C.c_float(0)
+        assert rcode == 0 and orc.orc_chest_dl_mbsfn(C.byref(cell), 1, C.byref(oc), area, 0, p(grid), p(ref), C.byref(nz)) == 0
+        assert close(ce[:12 * nre], ref[:12 * nre]) and (ce[12 * nre:] == 7 + 7j).all()
+        if alg == 0:
+            assert abs(res.noise_estimate - nz.value) <= 1e-4 * nz.value
+            prev_noise = res.noise_estimate
+        else:
+            assert res.noise_estimate == prev_noise
+        assert abs(res.rsrp - r0.rsrp) <= 1e-4 * r0.rsrp and abs(res.rsrq_db - r0.rsrq_db) < 1e-3 and abs(res.rssi_dbm - r0.rssi_dbm) < 1e-3
+        assert abs(res.snr_db - 10 * np.log10(res.rsrp / res.noise_estimate)) < 1e-3
+        assert abs(res.snr_ant_port_db[0][0] - res.snr_db) < 1e-3 and abs(res.rsrp_port_dbm[0] - r0.rsrp_dbm) < 1e-3
+    rc.noise_alg, rc.filter_type = 1, 0
+    rc.filter_coef[0] = 0.0  # automatic Gauss from a noise estimate this subframe does not make: refused, not guessed
+    assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) != 0
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)
+
+
 @pytest.mark.parametrize("mod", [1, 2, 3, 4])
 def test_demod_calls(mod):
     """soft_demod_test.c:118-249: srslte_demod_soft_demodulate{,_s,_b} on host arrays."""

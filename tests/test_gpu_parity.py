@@ -171,6 +171,59 @@ def test_chest_dl(hp, prb, cid, ci):
     est.free()
 
 
+MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
+              {"filter_coef": (4.0, 1.5)}, {}]
+
+
+@pytest.mark.parametrize("prb,cid,area,nports,nrx", [(6, 1, 1, 1, 1), (25, 2, 0, 1, 2), (50, 3, 255, 1, 1), (100, 4, 17, 1, 1), (100, 5, 2, 2, 2),
+                                                     (15, 150, 77, 2, 1), (110, 9, 40, 1, 1)])
+@pytest.mark.parametrize("ci", range(len(MBSFN_CFGS)))
+def test_chest_dl_mbsfn(hp, prb, cid, area, nports, nrx, ci):
+    """MBSFN subframes (chest_dl.c:718-745 and the MBSFN branches of :304-556) on the device vs the oracle (pinned on the
+    reference's estimator): the 12 estimated symbols of every (port, antenna) and the REFS noise; with the applications' configuration
+    (triangle 0.1, PSS noise: cc_worker.cc:90-93), other filters, 1-2 ports, 1-2 antennas."""
+    orc = oracle()
+    orc.orc_chest_dl_mbsfn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(prb * 1000 + cid + area)
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, nports, True)
+    tti0, nsf = 1, 3  # MBSFN subframes 1, 2, 3
+    grids = np.zeros((nsf, nrx, n), np.complex64)
+    for b in range(nsf):
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        assert orc.orc_mbsfn_put_sf(C.byref(cell), tti0 + b, 0, area, p(g)) == 0
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        for a in range(nrx):
+            h = ((3 + np.sin(k / 40.0 + a)) * np.exp(1j * (k / 100.0 + 0.1 * l + a))).astype(np.complex64)
+            grids[b, a] = (g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    hc, oc = hp.ChestDlCfg(), OrcChestCfg()
+    for k_, v in MBSFN_CFGS[ci].items():
+        if k_ == "filter_coef":
+            hc.filter_coef[0], hc.filter_coef[1] = v
+            oc.filter_coef[0], oc.filter_coef[1] = v
+        else:
+            setattr(hc, k_, v)
+            setattr(oc, k_, v)
+    hc.mbsfn_area_id, hc.interpolate_subframe, oc.interpolate_subframe = area, 1, True
+    est = hp.ChestDl(cid, prb, nports)
+    assert est.estimate_mbsfn(grids, tti0, hc, nrx)[0] == hp.SRSLTE_ERROR  # area id not initialised (chest_dl.c:729-731)
+    assert est.set_mbsfn_area_id(area) == 0 and est.set_mbsfn_area_id(area) == 0
+    rc, ce, noise = est.estimate_mbsfn(grids, tti0, hc, nrx)
+    assert rc == 0
+    for b in range(nsf):
+        for pt in range(nports):
+            for a in range(nrx):
+                ref, nz = np.zeros(n, np.complex64), C.c_float(0)
+                assert orc.orc_chest_dl_mbsfn(C.byref(cell), tti0 + b, C.byref(oc), area, pt, p(np.ascontiguousarray(grids[b, a])), p(ref), C.byref(nz)) == 0
+                assert_close_c(ce[b, pt, a, :12 * nre], ref[:12 * nre], "ce sf %d port %d ant %d" % (b, pt, a))
+                assert not ce[b, pt, a, 12 * nre:].any()  # symbols 12, 13 are not part of the subframe
+                if hc.noise_alg == 0:
+                    assert abs(noise[b, pt, a] - nz.value) <= 1e-4 * nz.value, (noise[b, pt, a], nz.value)
+    hc.interpolate_subframe = 0
+    assert est.estimate_mbsfn(grids, tti0, hc, nrx)[0] == hp.SRSLTE_ERROR
+    est.free()
+
+
 # ---------------------------------------------------------------- turbo
 def _noisy_llr(rng, enc_bits, snr_db, scale=100):
     tx = 2.0 * enc_bits.astype(np.float64) - 1.0

@@ -273,6 +273,14 @@ def test_chest_dl_mbsfn_vs_ref(prb, cid, area, port):
     q = opaque(1 << 20)
     assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, nports, cid, 0, 0, 0, 0)) == 0
     assert R.srslte_chest_dl_set_mbsfn_area_id(q, area) == 0
+    # a normal subframe first: its rsrp / rssi / noise are what the MBSFN subframes report for the fields they do not measure
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    for pp in range(nports):
+        orc.orc_crs_put_sf(C.byref(cell), 0, pp, p(g))
+    grid0 = acopy((g * np.complex64(2 + 1j) + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+    rc0, res0, sf0 = RefChestCfg(), RefChestRes(), RefDlSfCfg()
+    assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf0), C.byref(rc0), (C.c_void_p * 4)(grid0.ctypes.data, 0, 0, 0), C.byref(res0)) == 0
+    prev_noise = res0.noise_estimate
     for sf_idx in (1, 2, 3, 6, 7, 8):
         # the reference's generator for the stimulus pilots
         g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
@@ -319,8 +327,14 @@ def test_chest_dl_mbsfn_vs_ref(prb, cid, area, port):
             assert np.abs(a - ce2[:12 * nre]).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (prb, cid, kw, sf_idx)
             if kw.get("noise_alg", 0) == 0 and nports == 1:
                 assert abs(res.noise_estimate - noise.value) <= 1e-4 * abs(noise.value), (res.noise_estimate, noise.value)
+                prev_noise = res.noise_estimate
             elif kw.get("noise_alg", 0):
                 assert np.isnan(noise.value)
+                if nports == 1:
+                    assert res.noise_estimate == prev_noise  # PSS / EMPTY leave the estimate alone outside subframes 0 and 5
+            assert res.rsrp == res0.rsrp and res.rsrq == res0.rsrq and res.rssi_dbm == res0.rssi_dbm and res.cfo == res0.cfo
+            if nports == 1:
+                assert abs(res.snr_db - 10 * np.log10(res0.rsrp / res.noise_estimate)) < 1e-3
     R.srslte_chest_dl_free(q)
     oc = OrcChestCfg()
     assert orc.orc_chest_dl_mbsfn(C.byref(cell), 1, C.byref(oc), area, 0, p(grid), p(ce2), None) == -3  # needs interpolate_subframe
