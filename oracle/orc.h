@@ -111,7 +111,7 @@ uint32_t orc_crs_fidx(const orc_cell_t* cell, uint32_t l, uint32_t port_id);
 uint32_t orc_crs_nsymbol(uint32_t l, bool cp_norm, uint32_t port_id);
 
 typedef struct {
-  int   noise_alg;            /* 0 REFS, 1 PSS, 2 EMPTY (chest_dl.h:85-89) — only REFS restated */
+  int   noise_alg;            /* 0 REFS, 1 PSS, 2 EMPTY (chest_dl.h:85-89) */
   int   filter_type;          /* 0 GAUSS, 1 TRIANGLE, 2 NONE */
   float filter_coef[2];
   bool  interpolate_subframe;
@@ -125,6 +125,11 @@ int orc_chest_dl(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t*
                  orc_chest_res_t* res);
 int orc_chest_dl_multi(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce, orc_chest_res_t* res); /* nof_rx receive antennas, one port */
+/* the same with the estimator's kept noise estimates [antenna][port] (in/out): what the PSS / EMPTY noise algorithms (chest_dl.c:381-411,
+   :657-672) report outside subframes 0 and 5 and feed the automatic Gauss filter with */
+int orc_chest_dl_ports_state(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                             orc_cf_t* const* ce, orc_chest_res_t* res, float* raw_out, float* noise_state);
+void orc_pss_generate(uint32_t N_id_2, orc_cf_t* signal /* [62] */); /* pss.c:348-376 */
 /* MBSFN subframes (chest_dl.c:718-745, refsignal_dl.c:297-487): pilots [3][6 nof_prb]; stimulus; one (antenna, port) estimate */
 int orc_mbsfn_pilots(uint32_t nof_prb, uint32_t area_id, uint32_t sf_idx, orc_cf_t* pilots);
 int orc_mbsfn_put_sf(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, uint32_t area_id, orc_cf_t* grid);

@@ -137,8 +137,19 @@ static float noise_pilots(cf* est, uint32_t nref, uint32_t nsym, uint32_t fidx0,
    q->pilot_estimates, [4][2 nof_prb], SHARED by the ports of an antenna as upstream: chest_estimate_cfo (:573-596) always pairs its
    first and second half, so for ports 2/3 it multiplies their two symbols with what port 1 left in the second half.
    interpolate_subframe with ports 2/3 is refused: upstream then copies the never-written symbol 0 of ce over the subframe (:467-471). */
+void orc_pss_generate(uint32_t N_id_2, orc_cf_t* signal /* [62] */)
+{ /* srslte_pss_generate (pss.c:348-376): Zadoff-Chu roots 25, 29, 34 with the DC element left out */
+  const float root_value[] = {25.0, 29.0, 34.0};
+  for (int i = 0; i < 62; i++) {
+    float arg = i < 31 ? (float)-1 * M_PI * root_value[N_id_2 % 3] * ((float)i * ((float)i + 1.0)) / 63.0
+                       : (float)-1 * M_PI * root_value[N_id_2 % 3] * (((float)i + 2.0) * ((float)i + 1.0)) / 63.0;
+    signal[i].re = cosf(arg);
+    signal[i].im = sinf(arg);
+  }
+}
+
 static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, uint32_t port,
-                      cf* est, float raw[6])
+                      cf* est, float raw[6], float noise_prev)
 {
   const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = port < 2 ? 4 : 2, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
@@ -197,7 +208,8 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   }
 
   /* noise from pilots (chest_dl.c:304-379) */
-  float noise = cfg->noise_alg == 0 ? noise_pilots(est, nref, nsym, orc_crs_fidx(cell, 0, port), tmp) : 0;
+  /* PSS / EMPTY: the estimate of the last subframe 0 or 5 stays (and sets the automatic Gauss filter) until ce is there (:657-672) */
+  float noise = cfg->noise_alg == 0 ? noise_pilots(est, nref, nsym, orc_crs_fidx(cell, 0, port), tmp) : noise_prev;
 
   if (ce) {
     float    filter[64];
@@ -245,6 +257,24 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
       interp_vector(S(7), S(11), NULL, S(8), 4, 3, nre);
       interp_vector(S(7), S(11), S(11), S(12), 4, 2, nre);
 #undef S
+    }
+    if (cfg->noise_alg != 0 && (sf_idx == 0 || sf_idx == 5)) {
+      const uint32_t k_pss = 6 * nre + nre / 2 - 31, k_sss = 5 * nre + nre / 2 - 31;
+      if (cfg->noise_alg == 1) { /* estimate_noise_pss (chest_dl.c:381-398): |ce pss - received|^2 over the 62 PSS carriers */
+        cf pss[62], d[62];
+        orc_pss_generate(cell->id % 3, pss);
+        for (int i = 0; i < 62; i++) {
+          cf h = ce[k_pss + i], x = pss[i];
+          d[i] = c_sub((cf){h.re * x.re - h.im * x.im, h.re * x.im + h.im * x.re}, grid[k_pss + i]);
+        }
+        noise = (float)(cell->nof_ports * avg_power(d, 62) / sqrt(2));
+      } else { /* estimate_noise_empty_sc (:401-411): the 5 empty carriers either side of SSS and PSS */
+        noise = 0;
+        noise += avg_power(&grid[k_sss - 5], 5);
+        noise += avg_power(&grid[k_sss + 62], 5);
+        noise += avg_power(&grid[k_pss - 5], 5);
+        noise += avg_power(&grid[k_pss + 62], 5);
+      }
     }
   }
 
@@ -298,18 +328,27 @@ static void fill_res(uint32_t P, uint32_t nof_rx, uint32_t nof_ports, float raw[
 
 int orc_chest_dl_ports(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
                        orc_cf_t* const* ce /* [port * nof_rx + antenna] */, orc_chest_res_t* res, float* raw_out /* [antenna][port][4] or NULL */)
-{ /* srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for cell->nof_ports in {1, 2} and nof_rx receive antennas */
+{
+  return orc_chest_dl_ports_state(cell, sf_idx, cfg, nof_rx, grid, ce, res, raw_out, NULL);
+}
+
+int orc_chest_dl_ports_state(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, uint32_t nof_rx, const orc_cf_t* const* grid,
+                             orc_cf_t* const* ce, orc_chest_res_t* res, float* raw_out, float* noise_state /* [antenna][port] in/out or NULL */)
+{ /* srslte_chest_dl_estimate_cfg (chest_dl.c:884-908) for cell->nof_ports in {1, 2, 4} and nof_rx receive antennas; noise_state is the
+     estimator's q->noise_estimate, which the PSS / EMPTY algorithms only renew in subframes 0 and 5 */
   float raw[4][4][6];
   memset(raw, 0, sizeof(raw));
   if (nof_rx < 1 || nof_rx > 4 || (cell->nof_ports != 1 && cell->nof_ports != 2 && cell->nof_ports != 4)) return -1;
   cf* est = calloc(8 * cell->nof_prb, sizeof(cf)); /* q->pilot_estimates */
   for (uint32_t a = 0; a < nof_rx; a++) {
     for (uint32_t p = 0; p < cell->nof_ports; p++) {
-      int r = chest_port(cell, sf_idx, cfg, grid[a], ce ? ce[p * nof_rx + a] : NULL, p, est, raw[a][p]);
+      int r = chest_port(cell, sf_idx, cfg, grid[a], ce ? ce[p * nof_rx + a] : NULL, p, est, raw[a][p],
+                         noise_state ? noise_state[a * cell->nof_ports + p] : 0.0f);
       if (r) {
         free(est);
         return r;
       }
+      if (noise_state) noise_state[a * cell->nof_ports + p] = raw[a][p][0];
     }
   }
   free(est);

@@ -254,6 +254,76 @@ def test_chest_dl_vs_ref(prb, cid):
             R.srslte_chest_dl_free(q)
 
 
+@pytest.mark.parametrize("prb,cid,npt", [(6, 1, 1), (25, 2, 1), (50, 3, 2), (100, 4, 1), (100, 5, 2)])
+@pytest.mark.parametrize("alg", [1, 2])
+def test_chest_dl_noise_pss_empty_vs_ref(prb, cid, npt, alg):
+    """cfg.noise_alg PSS / EMPTY (chest_dl.c:381-411,:657-672) over a run of subframes on ONE estimator object: the estimate is renewed in
+    subframes 0 and 5 only (from the PSS carriers against the channel estimates, or from the empty carriers around PSS / SSS), is reported
+    unchanged in between, and sets the automatic Gauss filter of the next subframes; srslte_pss_generate for the sequence."""
+    R, rng = ref(), np.random.default_rng(300 + prb + cid + alg)
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for n2 in range(3):
+        a, b = aligned(2 * 62, np.float32), np.zeros(62, np.complex64)
+        assert R.srslte_pss_generate(p(a), n2) == 0
+        orc.orc_pss_generate(n2, p(b))
+        assert np.array_equal(a, b.view(np.float32))
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, npt, True)
+    q = opaque(1 << 20)
+    assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, npt, cid, 0, 0, 0, 0)) == 0
+    state = np.zeros(16, np.float32)
+    pss = np.zeros(62, np.complex64)
+    orc.orc_pss_generate(cid % 3, p(pss))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+    # (a fresh object's estimate is 0, and the automatic Gauss filter then is NaN in the reference as well: start with explicit taps)
+    for step, (tti, kw) in enumerate([(0, {"filter_coef": (4.0, 1.5)}), (1, {}), (2, {"interpolate_subframe": True}), (5, {}), (6, {}),
+                                      (10, {"filter_type": 2}), (13, {})]):
+        sf_idx = tti % 10
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        for pp in range(npt):
+            orc.orc_crs_put_sf(C.byref(cell), sf_idx, pp, p(g))
+        if sf_idx in (0, 5):
+            kp, ks = 6 * nre + nre // 2 - 31, 5 * nre + nre // 2 - 31
+            g[kp:kp + 62] = pss
+            for k0 in (kp - 5, kp + 62, ks - 5, ks + 62):
+                g[k0:k0 + 5] = 0
+        sig = 0.05 * (1 + step)
+        grid = acopy((g * h + sig * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        rc, oc = RefChestCfg(), OrcChestCfg()
+        for kk, v in kw.items():
+            if kk == "filter_coef":
+                rc.filter_coef[0], rc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(rc, kk, v)
+                setattr(oc, kk, v)
+        rc.noise_alg = oc.noise_alg = alg
+        ces = [aligned(2 * n, np.float32) for _ in range(npt)]
+        res, sf = RefChestRes(), RefDlSfCfg()
+        for pp in range(npt):
+            res.ce[pp][0] = ces[pp].ctypes.data
+        sf.tti = tti
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        ce2 = [np.zeros(n, np.complex64) for _ in range(npt)]
+        ores = OrcChestRes()
+        gp, cp = (C.c_void_p * 1)(grid.ctypes.data), (C.c_void_p * npt)(*[c.ctypes.data for c in ce2])
+        prev = state.copy()
+        assert orc.orc_chest_dl_ports_state(C.byref(cell), sf_idx, C.byref(oc), 1, gp, cp, C.byref(ores), None, p(state)) == 0
+        for pp in range(npt):
+            a = ces[pp].view(np.complex64)
+            assert np.abs(a - ce2[pp]).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (tti, pp)
+        assert abs(res.noise_estimate - ores.noise_estimate) <= 1e-4 * abs(ores.noise_estimate) + 1e-12, (tti, res.noise_estimate, ores.noise_estimate)
+        if sf_idx in (0, 5):
+            assert not np.array_equal(state[:npt], prev[:npt])
+        else:
+            assert np.array_equal(state, prev)
+        if step:
+            assert abs(res.snr_db - ores.snr_db) < 1e-3 and abs(res.noise_estimate_dbm - ores.noise_estimate_dbm) < 1e-3
+    R.srslte_chest_dl_free(q)
+
+
 MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
               {"filter_coef": (4.0, 1.5)}, {}]
 
