@@ -69,7 +69,8 @@ int srslte_hip_dft_precoding_batch(const void* d_in, void* d_out, uint32_t nof_p
  * ch_estimation/chest_dl.h:49-156, chest_dl.c:598-908) */
 typedef struct srslte_hip_chest_dl srslte_hip_chest_dl_t;
 typedef struct {             /* same members, order and meaning as srslte_chest_dl_cfg_t (chest_dl.h:116-130) */
-  int      noise_alg;        /* 0 REFS (the only one on device), 1 PSS, 2 EMPTY */
+  int      noise_alg;        /* 0 REFS, 1 PSS, 2 EMPTY (chest_dl.h:85-89); PSS / EMPTY renew the estimate in subframes 0 and 5 and report the
+                              * kept one otherwise, carried through the batch in subframe order and between calls on the object */
   int      filter_type;      /* 0 GAUSS, 1 TRIANGLE, 2 NONE (chest_common.h:30-34) */
   float    filter_coef[2];
   uint16_t mbsfn_area_id;

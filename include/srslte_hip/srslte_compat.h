@@ -11,8 +11,8 @@
  * (srslte_dft_plan_t.p, srslte_tdec_t.dec16_hdlr[0], srslte_chest_dl_t.tmp_noise ...).
  * tests/test_abi_layout.py checks sizeof/offsetof of every struct below against the reference headers.
  *
- * Not provided (documented in DESIGN.md): the PSS / EMPTY noise algorithms in normal subframes, interpolate_subframe on a 4-port cell or
- * switched off in an MBSFN subframe; those calls return SRSLTE_ERROR with a message.
+ * Not provided (documented in DESIGN.md): interpolate_subframe on a 4-port cell or switched off in an MBSFN subframe; those calls
+ * return SRSLTE_ERROR with a message.
  */
 #ifndef SRSLTE_HIP_SRSLTE_COMPAT_H
 #define SRSLTE_HIP_SRSLTE_COMPAT_H

@@ -257,6 +257,26 @@ class ChestDl:
         sync()
         return rc, dce.to_host(np.complex64).reshape(n, self.nof_ports, nof_rx, self.grid_len), dn.to_host(np.float32).reshape(n, self.nof_ports, nof_rx)
 
+    def estimate_multi(self, grid, tti0, cfg, nof_rx=1):
+        """grid [nof_sf][nof_rx][14*12*prb] -> (rc, ce [nof_sf][nof_ports][nof_rx][...], res dict, raw [nof_sf][nof_ports][nof_rx][6])."""
+        L = lib()
+        L.srslte_hip_chest_dl_estimate_batch_multi.argtypes = [C.c_void_p, C.POINTER(ChestDlCfg), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                               C.c_int, C.c_int, C.c_void_p]
+        L.srslte_hip_chest_dl_last_raw.restype = C.c_void_p
+        L.srslte_hip_chest_dl_last_raw.argtypes = [C.c_void_p]
+        g = np.ascontiguousarray(grid, np.complex64).reshape(-1, nof_rx, self.grid_len)
+        n = g.shape[0]
+        dg, dce, dres = DevBuf.from_host(g), DevBuf(g.nbytes * self.nof_ports), DevBuf(n * 40)
+        rc = L.srslte_hip_chest_dl_estimate_batch_multi(self.h, C.byref(cfg), tti0, dg.ptr, dce.ptr, dres.ptr, n, nof_rx, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None, None
+        sync()
+        res = dres.to_host(np.float32).reshape(n, 10)
+        raw = np.empty(n * self.nof_ports * nof_rx * 6, np.float32)
+        _check(L.srslte_hip_memcpy_d2h(raw.ctypes.data, L.srslte_hip_chest_dl_last_raw(self.h), raw.nbytes), "memcpy_d2h")
+        return (rc, dce.to_host(np.complex64).reshape(n, self.nof_ports, nof_rx, self.grid_len), {k: res[:, i] for i, k in enumerate(CHEST_RES_FIELDS)},
+                raw.reshape(n, self.nof_ports, nof_rx, 6))
+
     def estimate(self, grid, tti0=0, cfg=None, want_ce=True):
         cfg = cfg or ChestDlCfg()
         g = np.ascontiguousarray(grid, np.complex64).reshape(-1, self.grid_len)

@@ -90,8 +90,8 @@ __device__ __forceinline__ cf32 interp_offset_at(const cf32* in, int L, int M, i
 
 __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __restrict__ grid, cf32* __restrict__ ce,
                                                              ChestResDev* __restrict__ res, ChestRaw* __restrict__ raw,
-                                                             const cf32* __restrict__ pilots,
-                                                             ChestParams p)
+                                                             const cf32* __restrict__ pilots, const cf32* __restrict__ pss,
+                                                             const float* __restrict__ noise_state, ChestParams p)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int P = p.nof_prb, nre = 12 * P, nref = 2 * P;
@@ -176,8 +176,9 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     cfo = (float)((double)(-atan2f(si, sr) * n / (7.0f * (n + ng))) / 2 / M_PI);
   }
 
-  // ---- noise from pilots (REFS): residual of the last pilot symbol only (chest_dl.c:352-378)
-  float noise = 0;
+  // ---- noise from pilots (REFS): residual of the last pilot symbol only (chest_dl.c:352-378); PSS / EMPTY: the estimator's kept
+  // estimate [port][antenna], renewed below in subframes 0 and 5 once ce is there (:657-672)
+  float noise = p.noise_alg == 0 ? 0.f : noise_state[sf % (p.nof_rx * p.nof_ports)];
   if (p.noise_alg == 0) {
     const int   off = crs_fidx(p.cell_id, 0, port) < 3 ? 0 : 1;
     // the last pilot row, its predecessor, and the row before that (4 symbols: rows 3, 2, 0; 2 symbols: rows 1, 0, -)
@@ -283,6 +284,26 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
         o[11 * nre + k] = s11;
         v = s11;
         for (int l = 12; l <= 13; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+      }
+    }
+    if (p.noise_alg != 0 && (sf_idx == 0 || sf_idx == 5)) {
+      const int k_pss = 6 * nre + nre / 2 - 31, k_sss = 5 * nre + nre / 2 - 31;
+      __syncthreads(); // the estimates of symbol 6 written above, read back by other lanes
+      acc = 0;
+      if (p.noise_alg == 1) { // estimate_noise_pss (chest_dl.c:381-398)
+        if (tid < 62) {
+          const cf32 h = o[k_pss + tid], x = pss[tid], y = g[k_pss + tid];
+          const cf32 d = make_float2(h.x * x.x - h.y * x.y - y.x, h.x * x.y + h.y * x.x - y.y);
+          acc          = d.x * d.x + d.y * d.y;
+        }
+        noise = (float)((double)((float)p.nof_ports * (block_sum(acc, red) / 62)) / sqrt(2.0));
+      } else { // estimate_noise_empty_sc (:401-411): 5 empty carriers either side of the SSS and the PSS
+        if (tid < 20) {
+          const int  r = tid / 5, base = (r < 2 ? k_sss : k_pss) + ((r & 1) ? 62 : -5);
+          const cf32 y = g[base + tid % 5];
+          acc          = y.x * y.x + y.y * y.y;
+        }
+        noise = block_sum(acc, red) / 5;
       }
     }
   }
@@ -401,6 +422,21 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_mbsfn_kernel(const cf32* 
   }
 }
 
+// PSS / EMPTY noise: one thread per (port, antenna) walks the batch in subframe order; the estimate of a subframe 0 or 5 stays for the
+// subframes after it, state carries it from and to the neighbouring calls on the object (q->noise_estimate of the reference)
+__global__ void chest_noise_carry_kernel(ChestRaw* __restrict__ raw, float* __restrict__ state, int nof_sf, int nslice, int tti0, int have_ce)
+{
+  const int s = threadIdx.x;
+  if (s >= nslice) return;
+  float cur = state[s];
+  for (int b = 0; b < nof_sf; b++) {
+    const int sf_idx = (tti0 + b) % 10;
+    if (have_ce && (sf_idx == 0 || sf_idx == 5)) cur = raw[(size_t)b * nslice + s].noise;
+    else raw[(size_t)b * nslice + s].noise = cur;
+  }
+  state[s] = cur;
+}
+
 // fill_res (chest_dl.c:747-871) for more than one (antenna, port): noise averaged over ports and antennas; RSSI and RSRQ from port 0,
 // averaged over the antennas; get_rsrp (:809-819) indexes ports with the ANTENNA counter: max over i < nof_rx of the antenna-mean RSRP
 // of port i (0 for a port that was never estimated); q->cfo is overwritten by every estimate in turn: the last (antenna, port) survives
@@ -466,6 +502,8 @@ struct srslte_hip_chest_dl {
   ChestRaw* d_raw;    // per (subframe, port, antenna) scalars of multi-antenna / multi-port calls, grown on demand
   size_t    raw_cap;
   cf32*     d_mbsfn[256]; // per MBSFN area id: [10][3][6*nof_prb] (set_mbsfn_area_id), or null
+  cf32*     d_pss;        // the cell's 62 PSS values (pss.c:348-376), for the PSS noise algorithm
+  float*    d_noise_state; // [port][antenna] noise estimates kept between calls by the PSS / EMPTY algorithms
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
@@ -498,7 +536,20 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   q->d_raw    = nullptr;
   q->raw_cap  = 0;
   for (auto& m : q->d_mbsfn) m = nullptr;
+  q->d_pss = nullptr;
+  q->d_noise_state = nullptr;
+  cf32 pss[62];
+  {
+    const float root_value[] = {25.0, 29.0, 34.0};
+    for (int i = 0; i < 62; i++) {
+      const float arg = i < 31 ? (float)-1 * M_PI * root_value[cell_id % 3] * ((float)i * ((float)i + 1.0)) / 63.0
+                               : (float)-1 * M_PI * root_value[cell_id % 3] * (((float)i + 2.0) * ((float)i + 1.0)) / 63.0;
+      pss[i] = make_float2(cosf(arg), sinf(arg));
+    }
+  }
   if (hipMalloc((void**)&q->d_pilots, sizeof(cf32) * pil.size()) != hipSuccess ||
+      hipMalloc((void**)&q->d_pss, sizeof(pss)) != hipSuccess || hipMemcpy(q->d_pss, pss, sizeof(pss), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMalloc((void**)&q->d_noise_state, sizeof(float) * 16) != hipSuccess || hipMemset(q->d_noise_state, 0, sizeof(float) * 16) != hipSuccess ||
       hipMemcpy(q->d_pilots, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] chest_dl: device allocation failed\n");
     delete q;
@@ -512,6 +563,8 @@ extern "C" void srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q)
   if (!q) return;
   if (q->d_pilots) (void)hipFree(q->d_pilots);
   if (q->d_raw) (void)hipFree(q->d_raw);
+  if (q->d_pss) (void)hipFree(q->d_pss);
+  if (q->d_noise_state) (void)hipFree(q->d_noise_state);
   for (auto m : q->d_mbsfn) {
     if (m) (void)hipFree(m);
   }
@@ -583,6 +636,12 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
   return SRSLTE_SUCCESS;
 }
 
+int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise /* [port][antenna], 16 */)
+{
+  if (!q || !noise) return SRSLTE_ERROR_INVALID_INPUTS;
+  return hipMemcpy(q->d_noise_state, noise, sizeof(float) * 16, hipMemcpyHostToDevice) == hipSuccess ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+
 extern "C" const void* srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q) { return q ? q->d_pilots : nullptr; }
 
 // d_grid: [nof_sf][nof_rx][14][12*prb]; d_ce: [nof_sf][nof_ports][nof_rx][14][12*prb] or NULL (measurements only); d_res: [nof_sf]
@@ -592,8 +651,10 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
                                                         const void* d_grid, void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream)
 {
   if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (cfg->noise_alg != 0) {
-    fprintf(stderr, "[srslte_hip] chest_dl: only SRSLTE_NOISE_ALG_REFS is implemented on device\n");
+  if (cfg->noise_alg < 0 || cfg->noise_alg > 2) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (cfg->noise_alg != 0 && cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && nof_sf > 1 && d_ce) {
+    // the automatic Gauss filter of a subframe then depends on the estimates of the subframes before it: a sequential chain
+    fprintf(stderr, "[srslte_hip] chest_dl: the automatic Gauss filter with the PSS / EMPTY noise algorithms needs one subframe per call\n");
     return SRSLTE_ERROR;
   }
   if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
@@ -616,7 +677,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.nof_ports = q->nof_ports;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
-  if (d_res) {
+  if (d_res || cfg->noise_alg) {
     const size_t need = (size_t)nof_sf * nslice;
     if (need > q->raw_cap) {
       if (q->d_raw) (void)hipFree(q->d_raw);
@@ -629,9 +690,15 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   const int nref = 2 * q->nof_prb, nre = 12 * q->nof_prb;
   size_t lds = sizeof(cf32) * (8 * nref + (cfg->interpolate_subframe ? 4 * nre : 0));
   hipLaunchKernelGGL(chest_dl_kernel, dim3(nof_sf * nslice), dim3(CH_THREADS), lds, (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce,
-                     (ChestResDev*)d_res, raw, (const cf32*)q->d_pilots, p);
+                     cfg->noise_alg ? nullptr : (ChestResDev*)d_res, raw, (const cf32*)q->d_pilots, (const cf32*)q->d_pss,
+                     (const float*)q->d_noise_state, p);
   LAUNCH_CHECK();
-  if (raw && nslice > 1) {
+  if (raw && cfg->noise_alg) {
+    hipLaunchKernelGGL(chest_noise_carry_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, raw, q->d_noise_state, nof_sf, nslice, (int)tti0,
+                       d_ce ? 1 : 0);
+    LAUNCH_CHECK();
+  }
+  if (raw && d_res && (nslice > 1 || cfg->noise_alg)) {
     hipLaunchKernelGGL(chest_fill_res_kernel, dim3((nof_sf + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const ChestRaw*)raw,
                        (ChestResDev*)d_res, nof_sf, nof_rx, q->nof_ports, q->nof_prb);
     LAUNCH_CHECK();

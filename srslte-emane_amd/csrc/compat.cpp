@@ -1018,6 +1018,13 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   hc.interpolate_subframe = cfg->interpolate_subframe; hc.rsrp_neighbour = cfg->rsrp_neighbour;
   hc.cfo_estimate_enable  = cfg->cfo_estimate_enable && ((1u << (sf->tti % 10)) & cfg->cfo_estimate_sf_mask);
   hc.cfo_estimate_sf_mask = cfg->cfo_estimate_sf_mask; hc.sync_error_enable = cfg->sync_error_enable;
+  if (hc.noise_alg != SRSLTE_NOISE_ALG_REFS) { // PSS / EMPTY renew q->noise_estimate in subframes 0 and 5 only (chest_dl.c:657-672)
+    float state[16] = {0};
+    for (uint32_t pt = 0; pt < npt; pt++) {
+      for (uint32_t a = 0; a < nrx; a++) state[pt * nrx + a] = q->noise_estimate[a][pt];
+    }
+    if (chest_dl_set_noise_state(st->h, state)) return SRSLTE_ERROR;
+  }
   if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, nullptr)) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
   if (!d2h(&r, dres, sizeof(r))) return SRSLTE_ERROR;

@@ -30,6 +30,8 @@ void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); /
 
 // chest.hip: device DMRS table of a PUSCH grant, [10][2][12 * L_prb] cf32 (owned by q)
 int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r);
+// chest.hip: the noise estimates [port][antenna] the PSS / EMPTY algorithms keep between calls (q->noise_estimate of the reference)
+int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise);
 // tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).
 // d_rem: [C][K] words, x^(tbs+24-1-position in the TB) mod g for the block's payload bits in the decoder's array order, 0 elsewhere
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);

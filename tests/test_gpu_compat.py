@@ -299,6 +299,51 @@ def test_chest_dl_object():
     L.srslte_chest_dl_free(est)
 
 
+@pytest.mark.parametrize("alg", [1, 2])
+def test_chest_dl_object_noise_pss_empty(alg):
+    """srslte_chest_dl_estimate_cfg with cfg.noise_alg PSS / EMPTY (phy_common.cc:111-118 selects them from snr_estim_alg) over a run of
+    subframes on one object, with the automatic Gauss filter fed by the kept estimate, against the oracle's run."""
+    L, rng = hip(), np.random.default_rng(40 + alg)
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    prb, cid = 25, 5
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    pss = np.zeros(62, np.complex64)
+    orc.orc_pss_generate(cid % 3, p(pss))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+    state = np.zeros(16, np.float32)
+    ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+    for step, (tti, coef) in enumerate([(0, (4.0, 1.5)), (1, (0.0, 0.0)), (5, (0.0, 0.0)), (6, (0.0, 0.0)), (7, (3.0, 1.0))]):
+        sf_idx = tti % 10
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        orc.orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        if sf_idx in (0, 5):
+            kp, ks = 6 * nre + nre // 2 - 31, 5 * nre + nre // 2 - 31
+            g[kp:kp + 62] = pss
+            for k0 in (kp - 5, kp + 62, ks - 5, ks + 62):
+                g[k0:k0 + 5] = 0
+        grid = acopy((g * h + 0.03 * (1 + step) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        sf, rc, oc = RefDlSfCfg(), RefChestCfg(), OrcChestCfg()
+        sf.tti = tti
+        rc.noise_alg = oc.noise_alg = alg
+        rc.filter_coef[0], rc.filter_coef[1] = coef
+        oc.filter_coef[0], oc.filter_coef[1] = coef
+        assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        ref, ores = np.zeros(n, np.complex64), OrcChestRes()
+        gp, cp = (C.c_void_p * 1)(grid.ctypes.data), (C.c_void_p * 1)(ref.ctypes.data)
+        assert orc.orc_chest_dl_ports_state(C.byref(cell), sf_idx, C.byref(oc), 1, gp, cp, C.byref(ores), None, p(state)) == 0
+        assert close(ce, ref), step
+        assert abs(res.noise_estimate - ores.noise_estimate) <= 1e-4 * ores.noise_estimate and abs(res.snr_db - ores.snr_db) < 1e-3
+        assert abs(res.rsrp_dbm - ores.rsrp_dbm) < 1e-3 and abs(res.snr_ant_port_db[0][0] - ores.snr_db) < 1e-3
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)
+
+
 def test_chest_dl_object_mbsfn():
     """srslte_chest_dl_set_mbsfn_area_id + srslte_chest_dl_estimate_cfg on an MBSFN subframe (ue_dl.c:374-397 with cc_worker.cc:90-93's
     configuration, and with the REFS noise): the 12 estimated symbols, and a result struct whose rsrp / rssi-derived fields are the last

@@ -171,6 +171,72 @@ def test_chest_dl(hp, prb, cid, ci):
     est.free()
 
 
+@pytest.mark.parametrize("prb,cid,npt,nrx", [(6, 1, 1, 1), (25, 2, 1, 2), (50, 3, 2, 1), (100, 4, 1, 1), (100, 5, 2, 2)])
+@pytest.mark.parametrize("alg", [1, 2])
+def test_chest_dl_noise_pss_empty(hp, prb, cid, npt, nrx, alg):
+    """cfg.noise_alg PSS / EMPTY (chest_dl.c:381-411,:657-672) on the device vs the oracle run subframe by subframe with its kept
+    estimate: renewed in subframes 0 and 5 from the PSS carriers / the empty carriers, carried over the other subframes of the batch
+    and into the next call on the object; estimates, per-(port, antenna) noise, combined result fields."""
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(2100 + prb + cid + alg)
+    nre, n = 12 * prb, 14 * 12 * prb
+    cell = OrcCell(cid, prb, npt, True)
+    pss = np.zeros(62, np.complex64)
+    orc.orc_pss_generate(cid % 3, p(pss))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    est = hp.ChestDl(cid, prb, npt)
+    state = np.zeros(16, np.float32)  # oracle's, [antenna][port]
+    for call, (tti0, nsf, kw) in enumerate([(8, 9, {"filter_coef": (4.0, 1.5)}), (17, 5, {"filter_type": 1, "filter_coef": (0.1, 0.0)}),
+                                            (22, 1, {}), (23, 4, {"filter_type": 2, "interpolate_subframe": npt < 4})]):
+        grids = np.zeros((nsf, nrx, n), np.complex64)
+        for b in range(nsf):
+            sf_idx = (tti0 + b) % 10
+            g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+            for pp in range(npt):
+                orc.orc_crs_put_sf(C.byref(cell), sf_idx, pp, p(g))
+            if sf_idx in (0, 5):
+                kp, ks = 6 * nre + nre // 2 - 31, 5 * nre + nre // 2 - 31
+                g[kp:kp + 62] = pss
+                for k0 in (kp - 5, kp + 62, ks - 5, ks + 62):
+                    g[k0:k0 + 5] = 0
+            for a in range(nrx):
+                h = ((3 + np.sin(k / 40.0 + a)) * np.exp(1j * (k / 100.0 + 0.1 * l + a))).astype(np.complex64)
+                grids[b, a] = (g * h + 0.05 * (1 + b + call) * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        hc, oc = hp.ChestDlCfg(), OrcChestCfg()
+        for k_, v in kw.items():
+            if k_ == "filter_coef":
+                hc.filter_coef[0], hc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(hc, k_, 1 if v is True else (0 if v is False else v))
+                setattr(oc, k_, v)
+        hc.noise_alg = oc.noise_alg = alg
+        rc, ce, res, raw = est.estimate_multi(grids, tti0, hc, nrx)
+        assert rc == 0
+        for b in range(nsf):
+            ce2 = [np.zeros(n, np.complex64) for _ in range(npt * nrx)]
+            ores = OrcChestRes()
+            gl = [np.ascontiguousarray(grids[b, a]) for a in range(nrx)]
+            gp, cp = (C.c_void_p * nrx)(*[x.ctypes.data for x in gl]), (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce2])
+            assert orc.orc_chest_dl_ports_state(C.byref(cell), (tti0 + b) % 10, C.byref(oc), nrx, gp, cp, C.byref(ores), None, p(state)) == 0
+            for pt in range(npt):
+                for a in range(nrx):
+                    assert_close_c(ce[b, pt, a], ce2[pt * nrx + a], "ce call %d sf %d port %d ant %d" % (call, b, pt, a))
+                    want = state[a * npt + pt]
+                    assert abs(raw[b, pt, a, 0] - want) <= 1e-4 * want + 1e-12, (call, b, pt, a, raw[b, pt, a, 0], want)
+            for name in ("noise_estimate", "rsrp", "rsrq"):
+                x, y = float(res[name][b]), float(getattr(ores, name))
+                assert abs(x - y) <= 1e-4 * abs(y) + 1e-9, (name, call, b, x, y)
+            if call or b >= 2:  # a noise estimate exists from the first subframe 0 on
+                for name in ("noise_estimate_dbm", "snr_db", "rsrp_dbm", "rsrq_db", "rssi_dbm"):
+                    assert abs(float(res[name][b]) - float(getattr(ores, name))) <= 1e-3, name
+    hc = hp.ChestDlCfg()
+    hc.noise_alg = alg
+    assert est.estimate_multi(grids, 0, hc, nrx)[0] == hp.SRSLTE_ERROR  # automatic Gauss over a batch: a sequential chain, one subframe per call
+    est.free()
+
+
 MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
               {"filter_coef": (4.0, 1.5)}, {}]
 
