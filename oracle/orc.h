@@ -218,5 +218,14 @@ int orc_uci_ack_insert(uint8_t* q_bits, const uint8_t* c_seq, const uint8_t ack[
                        uint32_t Qprime);
 int orc_uci_ack_extract(int16_t* q_llr, const uint8_t* c_seq, uint8_t ack[2], uint32_t O_ack, uint32_t Qm, uint32_t nof_re, uint32_t nof_symb,
                         uint32_t Qprime);
+/* rank indication (1-2 bits) on the PUSCH (sch.c:968-979,:1110-1129; uci.c:521-545): as the ACK on its own columns, but the channel
+   interleaver leaves its symbols out: lut[q index] = g index (0 at RI positions), returns the number of UL-SCH bits */
+int  orc_uci_ri_qprime(uint32_t O_ri, uint32_t I_offset_ri, uint32_t L_prb, uint32_t nof_symb, uint32_t K_segm);
+int  orc_uci_ri_insert(uint8_t* q_bits, const uint8_t* c_seq, const uint8_t ri[2], uint32_t O_ri, uint32_t Qm, uint32_t nof_re, uint32_t nof_symb,
+                       uint32_t Qprime);
+int  orc_uci_ri_extract(int16_t* q_llr, const uint8_t* c_seq, uint8_t ri[2], uint32_t O_ri, uint32_t Qm, uint32_t nof_re, uint32_t nof_symb,
+                        uint32_t Qprime);
+int  orc_ulsch_interleaver_lut(uint32_t Qm, uint32_t nof_re, uint32_t nof_symb, uint32_t Qprime_ri, uint32_t* lut);
+void orc_ulsch_deinterleave(const int16_t* q_llr, const uint32_t* lut, int16_t* g_llr, uint32_t n);
 
 #endif

@@ -612,20 +612,38 @@ def ack_type_map(cfg, ack, Qp):
     return types
 
 
-def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0):
-    """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits multiplexed): returns (iq[sf_len], payload bytes);
-    keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
+def ul_ri_layout(cfg, O_ri, I_offset_ri):
+    """(Q'_ri, lut, RI mask, G): the channel interleaver with the rank-indication symbols left out (ulsch_interleave_gen, sch.c:580-598)."""
+    orc = oracle()
+    Qp = orc.orc_uci_ri_qprime(O_ri, I_offset_ri, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1) if O_ri else 0
+    assert Qp >= 0
+    lut = np.zeros(cfg.nbits, np.uint32)
+    G = orc.orc_ulsch_interleaver_lut(cfg.Qm, cfg.nof_re, cfg.nsymb, Qp, p(lut))
+    mask = (lut == 0) & (np.arange(cfg.nbits) != 0)
+    assert G == cfg.nbits - Qp * cfg.Qm == cfg.nbits - int(mask.sum())
+    return Qp, lut, mask, G
+
+
+def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0, ri=(), I_offset_ri=0):
+    """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits and / or a 1-2 bit rank indication multiplexed):
+    returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
     orc = oracle()
     sf_idx = tti % 10
     if data is None:
         data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
-    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
-    g = np.zeros(cfg.nbits, np.uint8)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, len(ri), I_offset_ri)
+    sch = OrcSchCfg(cfg.tbs, G, cfg.Qm, 0, cfg.max_iter)
+    g = np.zeros(G, np.uint8)
     assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(g)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
     q = np.zeros(cfg.nbits, np.uint8)
-    q[cfg.q_of_g] = g
+    q[~ri_mask] = g[lut[~ri_mask]]
+    if not len(ri):
+        assert np.array_equal(np.flatnonzero(~ri_mask)[np.argsort(lut[~ri_mask])], cfg.q_of_g)
     c = cfg.scramble(sf_idx)
     q ^= c
+    if len(ri):  # RI symbols in the places the interleaver left free (sch.c:1110-1129)
+        r2 = np.array(list(ri) + [0], np.uint8)[:2]
+        assert Qp_ri > 0 and orc.orc_uci_ri_insert(p(q), p(c), p(r2), len(ri), cfg.Qm, cfg.nof_re, cfg.nsymb, Qp_ri) == 0
     if len(ack):  # HARQ-ACK symbols overwrite UL-SCH symbols next to the DMRS (36.212 5.2.2.6-5.2.2.8; orc_uci.c)
         Qp = orc.orc_uci_ack_qprime(len(ack), I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
         a2 = np.array(list(ack) + [0], np.uint8)[:2]
@@ -656,7 +674,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     return iq.astype(np.complex64), data
 
 
-def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0):
+def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0):
     """eNB receive side: enb_ul.c:58-63 OFDM settings, srslte_chest_ul_estimate_pusch, srslte_pusch_decode (pusch.c:423-520) and the
     UL-SCH part of srslte_ulsch_decode (sch.c:991-1066) without UCI."""
     from _libs import OrcChestUlRes
@@ -683,13 +701,21 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0):
     if O_ack:  # uci_decode_ri_ack (sch.c:929-966): ACK decisions from the interleaved LLRs, then those positions are zeroed
         Qp = orc.orc_uci_ack_qprime(O_ack, I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
         assert Qp > 0 and orc.orc_uci_ack_extract(p(qllr), p(c_seq), p(ack_out), O_ack, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
-    g = np.ascontiguousarray(qllr[cfg.q_of_g])  # ulsch_deinterleave: g[n] = q[lut^-1]
-    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+    ri_out = np.zeros(2, np.uint8)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_offset_ri)
+    if O_ri:  # after the ACK (sch.c:968-979); the RI LLRs stay in q, and the scatter below leaves the last of them in g[0] (sch.c:891-918)
+        assert orc.orc_uci_ri_extract(p(qllr), p(c_seq), p(ri_out), O_ri, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp_ri) == 0
+    g_full = np.zeros(cfg.nbits, np.int16)
+    orc.orc_ulsch_deinterleave(p(qllr), p(lut), p(g_full), cfg.nbits)  # ulsch_deinterleave: g[lut[i]] = q[i]
+    g = np.ascontiguousarray(g_full[:G])
+    if not O_ri:
+        assert np.array_equal(g, qllr[cfg.q_of_g])
+    sch = OrcSchCfg(cfg.tbs, G, cfg.Qm, 0, cfg.max_iter)
     tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
     rc = orc.orc_dlsch_decode(C.byref(sch), p(g), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
     if keep:
-        out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res, q_before_ack=q_before_ack, ack=ack_out)
+        out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res, q_before_ack=q_before_ack, ack=ack_out, ri=ri_out)
     return out
 
 
@@ -751,13 +777,14 @@ class RefUlsch:
     36.212 5.2.2.8 and its inverse, UCI absent) on its compiled code, with a hand-filled srslte_pusch_cfg_t (offsets from the reference
     headers at run time). Pins the UL side of the oracle chain: orc_dlsch_encode/decode used as UL-SCH coder and UlConfig.q_of_g."""
 
-    def __init__(self, cfg, O_ack=0, I_offset_ack=0):
+    def __init__(self, cfg, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0):
         from _libs import opaque, ref, ref_layout
         R = self.R = ref()
         self.cfg = cfg
         L = self.L = ref_layout({"srslte_sch_t": [], "srslte_pusch_cfg_t": ["grant", "max_nof_iterations", "softbuffers", "uci_cfg", "uci_offset"],
-                                 "srslte_uci_cfg_t": ["ack"], "srslte_uci_cfg_ack_t": ["nof_acks"], "srslte_uci_offset_cfg_t": ["I_offset_ack"],
-                                 "srslte_uci_value_t": ["ack"], "srslte_uci_value_ack_t": ["ack_value"],
+                                 "srslte_uci_cfg_t": ["ack", "cqi"], "srslte_uci_cfg_ack_t": ["nof_acks"], "srslte_cqi_cfg_t": ["ri_len"],
+                                 "srslte_uci_offset_cfg_t": ["I_offset_ack", "I_offset_ri"],
+                                 "srslte_uci_value_t": ["ack", "ri"], "srslte_uci_value_ack_t": ["ack_value"],
                                  "srslte_pusch_grant_t": ["L_prb", "nof_re", "nof_symb", "tb"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_softbuffer_tx_t": []}, ["srslte/phy/ch_estimation/chest_ul.h", "srslte/phy/phch/pusch.h"])
@@ -782,10 +809,13 @@ class RefUlsch:
         u32(L["srslte_pusch_cfg_t.max_nof_iterations"], cfg.max_iter)
         u32(L["srslte_pusch_cfg_t.uci_cfg"] + L["srslte_uci_cfg_t.ack"] + L["srslte_uci_cfg_ack_t.nof_acks"], O_ack)  # HARQ-ACK bits of carrier 0
         u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_ack"], I_offset_ack)
+        u32(L["srslte_pusch_cfg_t.uci_cfg"] + L["srslte_uci_cfg_t.cqi"] + L["srslte_cqi_cfg_t.ri_len"], O_ri)
+        u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_ri"], I_offset_ri)
+        self.ri_off = L["srslte_uci_value_t.ri"]
         self.ack_off = L["srslte_uci_value_t.ack"] + L["srslte_uci_value_ack_t.ack_value"]
         self.sb_off = L["srslte_pusch_cfg_t.softbuffers"]
 
-    def encode(self, data, ack=()):
+    def encode(self, data, ack=(), ri=None):
         """payload bytes (+ HARQ-ACK values) -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling
         (pusch.c:380-395); the ACK positions of q hold the value bits, 0 for repetition / placeholder bits."""
         cfg, R = self.cfg, self.R
@@ -795,6 +825,8 @@ class RefUlsch:
         d[:cfg.tbs // 8] = data
         uci = np.zeros(4096, np.uint8)
         uci[self.ack_off:self.ack_off + len(ack)] = ack
+        if ri is not None:
+            uci[self.ri_off] = ri
         g, q = np.zeros(cfg.nbits // 8 + 64, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8)
         assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) >= 0  # returns the number of RI/ACK q-bits
         return np.unpackbits(g)[:cfg.nbits], np.unpackbits(q)[:cfg.nbits]
@@ -810,4 +842,5 @@ class RefUlsch:
         cs = np.ascontiguousarray(c_seq, np.uint8)
         tb, uci = np.zeros(cfg.tbs // 8 + 64, np.uint8), np.zeros(4096, np.uint8)
         rc = R.srslte_ulsch_decode(self.q, p(self.pc), p(ql), p(gl), p(cs), p(tb), p(uci))
-        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy(), "ack": uci[self.ack_off:self.ack_off + 2].copy()}
+        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy(), "ack": uci[self.ack_off:self.ack_off + 2].copy(),
+                "ri": int(uci[self.ri_off])}

@@ -1003,3 +1003,43 @@ def test_harq_ack_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, s
             assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
         n_ok += r["ok"]
     assert n_ok > 0
+
+
+@pytest.mark.parametrize("prb,L,mod,tbs,snr,short,O_ri,I_ri,O_ack,I_ack", [(25, 10, 2, 4008, 12.0, False, 1, 9, 0, 0), (25, 10, 2, 4008, 12.0, False, 1, 9, 2, 9),
+                                                                          (6, 6, 1, 1000, 6.0, True, 1, 5, 1, 5), (100, 48, 3, 30576, 19.0, False, 1, 12, 0, 0),
+                                                                          (50, 20, 2, 7736, 12.0, False, 2, 8, 1, 8), (100, 100, 2, 43816, 15.0, True, 1, 11, 2, 12)])
+def test_ri_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, O_ri, I_ri, O_ack, I_ack):
+    """Rank indication (with and without HARQ-ACK) on the PUSCH against srslte_ulsch_encode / srslte_ulsch_decode: the RI symbols the
+    channel interleaver leaves out (sch.c:580-598), the UL-SCH rate-matched to the rest, the RI decision, and the de-interleaved LLRs
+    including the reference's g[0], which its scatter leaves holding the last RI position's LLR (sch.c:891-918)."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(1200 + prb + L + O_ri + O_ack)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3, shortened=short)
+    chain = RefUlsch(cfg, O_ack, I_ack, O_ri, I_ri)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_ri)
+    assert Qp_ri > 0 and ri_mask.sum() == Qp_ri * cfg.Qm
+    n_ok = 0
+    for t, ri, ack in ((2, 1, (1, 0)), (7, 0, (0, 1)), (9, 1, (1, 1))):
+        ack = ack[:O_ack]
+        k = {}
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k, ack=ack, I_offset_ack=I_ack, ri=(ri, 0)[:O_ri], I_offset_ri=I_ri)
+        g_r, q_r = chain.encode(data, ack, ri)
+        assert np.array_equal(g_r[:G], k["g"]), "UL-SCH bits rate-matched to G = %d" % G
+        c = cfg.scramble(t % 10)
+        ack_pos = k["ack_types"] >= 0 if O_ack else np.zeros(cfg.nbits, bool)
+        q_plain = np.zeros(cfg.nbits, np.uint8)
+        q_plain[~ri_mask] = k["g"][lut[~ri_mask]]
+        sel = ~ri_mask & ~ack_pos
+        assert np.array_equal(q_r[sel], q_plain[sel]), t
+        first = np.flatnonzero(ri_mask)[::cfg.Qm]  # first bit of every RI symbol carries a value bit
+        if O_ri == 1:
+            assert (q_r[first] == ri).all() and not q_r[np.setdiff1d(np.flatnonzero(ri_mask), first)].any()
+        o = oracle_ul_rx(cfg, iq, t, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri)
+        r = chain.decode(o["q_before_ack"], c)
+        assert r["ri"] == o["ri"][0] == ri, (t, r["ri"], o["ri"])
+        assert np.array_equal(r["ack"][:O_ack], o["ack"][:O_ack])
+        assert np.array_equal(r["g"][:G], o["g"]) and r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        n_ok += r["ok"]
+    assert n_ok > 0
