@@ -259,6 +259,9 @@ typedef struct {
   int      shortened;      /* 1: the subframe's last symbol is left to the SRS (srslte_ul_sf_cfg_t.shortened, N_srs = 1): 11 data symbols */
   uint32_t ack_len;        /* 0..2 HARQ-ACK bits multiplexed on the PUSCH (srslte_uci_cfg_t.ack[0].nof_acks, sch.c:1074-1090, uci.c:755-790) */
   uint32_t I_offset_ack;   /* beta_offset index of 36.213 Table 8.6.3-1 (srslte_uci_offset_cfg_t.I_offset_ack) */
+  uint32_t ri_len;         /* 0..2 rank-indication bits on the PUSCH (srslte_cqi_cfg_t.ri_len, sch.c:968-979,:1110-1129): their symbols are
+                            * left out by the channel interleaver and the UL-SCH is rate-matched to the rest */
+  uint32_t I_offset_ri;    /* index into 36.213 Table 8.6.3-2 (srslte_uci_offset_cfg_t.I_offset_ri) */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -268,6 +271,7 @@ int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti
 /* Device pointer to the HARQ-ACK decisions of the last batch on this object, [max_batch][2] bytes (srslte_uci_value_t.ack.ack_value of
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);
+const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q); /* the same for the rank indication (srslte_uci_value_t.ri in [b][0]) */
 /* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest_ul res, 3 d (after de-precoding), 4 g (LLRs after
  * the de-interleaver), 5 w, 6 cb iters, 7 cb ok, 8 cb bytes, 9 z (equalised) */
 const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q, int which);
@@ -288,6 +292,7 @@ typedef struct {
   srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;
   int      shortened;      /* as in srslte_hip_ul_rx_cfg_t */
   uint32_t ack_len, I_offset_ack; /* as in srslte_hip_ul_rx_cfg_t (srslte_ulsch_encode's uci_cfg, sch.c:1168-1215) */
+  uint32_t ri_len, I_offset_ri;   /* as in srslte_hip_ul_rx_cfg_t (sch.c:1110-1129) */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);
@@ -297,6 +302,9 @@ int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t 
 /* The same with the HARQ-ACK values d_ack [nof_sf][2] (0/1 bytes, device) multiplexed in; requires cfg.ack_len > 0 */
 int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, uint32_t tti0,
                                uint32_t nof_sf, void* d_iq, void* stream);
+/* HARQ-ACK values d_ack and rank-indication bits d_ri, each [nof_sf][2] device bytes, each required exactly when configured */
+int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                               uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
  * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
 const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);

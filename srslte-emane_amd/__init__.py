@@ -494,18 +494,21 @@ class DlRx:
 class UlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
-                ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32)]
+                ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
+                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
 
 
 class UlRx:
     """Batched PUSCH receive chain (enb_ul.c + pusch.c:423-520 + the UL-SCH part of sch.c:991-1066)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
-                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0):
+                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri)
         L = lib()
+        L.srslte_hip_ul_rx_ri.restype = C.c_void_p
+        L.srslte_hip_ul_rx_ri.argtypes = [C.c_void_p]
         L.srslte_hip_ul_rx_create.restype = C.c_void_p
         L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
         L.srslte_hip_ul_rx_destroy.argtypes = [C.c_void_p]
@@ -537,6 +540,12 @@ class UlRx:
         _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, lib().srslte_hip_ul_rx_ack(self.h), out.nbytes), "memcpy_d2h")
         return out.reshape(-1, 2)[:self.last_nof_sf, :max(self.cfg.ack_len, 1)]
 
+    def ri(self):
+        """Rank-indication decisions [nof_sf][ri_len] of the last decode() (srslte_uci_value_t.ri)."""
+        out = np.empty(2 * self.max_batch, np.uint8)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, lib().srslte_hip_ul_rx_ri(self.h), out.nbytes), "memcpy_d2h")
+        return out.reshape(-1, 2)[:self.last_nof_sf, :max(self.cfg.ri_len, 1)]
+
     def debug(self, which, dtype, count):
         ptr = lib().srslte_hip_ul_rx_debug_buffer(self.h, which)
         out = np.empty(count, dtype)
@@ -552,7 +561,7 @@ class UlRx:
 class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
-                ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32)]
+                ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
 
 
 class UlTx:
@@ -560,11 +569,12 @@ class UlTx:
     srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
-                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0):
+                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri)
         L = lib()
+        L.srslte_hip_ul_tx_batch_uci.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.srslte_hip_ul_tx_create.restype = C.c_void_p
         L.srslte_hip_ul_tx_create.argtypes = [C.POINTER(UlTxCfg)]
         L.srslte_hip_ul_tx_destroy.argtypes = [C.c_void_p]
@@ -579,11 +589,21 @@ class UlTx:
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch)
 
-    def encode(self, tb, tti0=0, ack=None):
-        """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values) -> iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
+    def encode(self, tb, tti0=0, ack=None, ri=None):
+        """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits) ->
+        iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
         x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
         din = DevBuf.from_host(x)
-        if ack is not None:
+        if ri is not None:
+            bufs = []
+            for v, n in ((ack, self.cfg.ack_len), (ri, self.cfg.ri_len)):
+                a = np.zeros((x.shape[0], 2), np.uint8)
+                if v is not None:
+                    a[:, :n] = np.asarray(v, np.uint8).reshape(x.shape[0], -1)[:, :n]
+                bufs.append(DevBuf.from_host(a) if v is not None else None)
+            _check(lib().srslte_hip_ul_tx_batch_uci(self.h, din.ptr, self.tbs // 8, bufs[0].ptr if bufs[0] else None, bufs[1].ptr, tti0, x.shape[0],
+                                                    self.d_iq.ptr, None), "ul_tx_batch_uci")
+        elif ack is not None:
             a = np.zeros((x.shape[0], 2), np.uint8)
             a[:, :self.cfg.ack_len] = np.asarray(ack, np.uint8).reshape(x.shape[0], -1)[:, :self.cfg.ack_len]
             dack = DevBuf.from_host(a)

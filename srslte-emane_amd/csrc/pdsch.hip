@@ -921,6 +921,34 @@ __device__ __forceinline__ int ack_symbol_index(const AckGeom& a, int n, int k, 
   const int i = 4 * (M_sc - 1 - k) + (3 * colidx) % 4; // (3 i) % 4 == colidx <=> i % 4 == (3 colidx) % 4
   return i < a.Qprime ? i : -1;
 }
+// rank indication: the same rule on the columns {1,4,7,10} ({0,3,5,8} with at most 10 symbols; uci.c:521-545)
+__device__ __forceinline__ int ri_symbol_index(const AckGeom& a, int n, int k, int M_sc, int nsymb)
+{
+  int colidx;
+  if (nsymb > 10) {
+    colidx = n == 1 ? 0 : (n == 4 ? 1 : (n == 7 ? 2 : (n == 10 ? 3 : -1)));
+  } else {
+    colidx = n == 0 ? 0 : (n == 3 ? 1 : (n == 5 ? 2 : (n == 8 ? 3 : -1)));
+  }
+  if (a.O == 0 || colidx < 0) return -1;
+  const int i = 4 * (M_sc - 1 - k) + (3 * colidx) % 4;
+  return i < a.Qprime ? i : -1;
+}
+// number of RI symbols before (k, n) in the row-by-row order the channel interleaver fills (ulsch_interleave_gen, sch.c:580-598):
+// the UL-SCH symbol at (k, n) is symbol k nsymb + n - ri_before of the rate-matched stream
+__device__ __forceinline__ int ri_before(const AckGeom& a, int n, int k, int M_sc, int nsymb)
+{
+  if (a.O == 0) return 0;
+  int cnt = max(0, a.Qprime - 4 * (M_sc - k)); // rows above k in the matrix are sub-carriers below it: RI symbols i >= 4 (M_sc - k)
+  const int i0 = 4 * (M_sc - 1 - k);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c   = (3 * j) % 4;
+    const int col = nsymb > 10 ? 1 + 3 * c : (c == 0 ? 0 : (c == 1 ? 3 : (c == 2 ? 5 : 8)));
+    cnt += (i0 + j < a.Qprime && col < n) ? 1 : 0;
+  }
+  return cnt;
+}
 __device__ __forceinline__ int ack_bit_type(const uint8_t* ack, int O, int Qm, int e)
 { // encode_ri_ack (uci.c:573-602) repeated: 0 / 1 value, 2 repetition of the previous bit, 3 placeholder
   if (O == 1) {
@@ -935,8 +963,9 @@ __device__ __forceinline__ int ack_bit_type(const uint8_t* ack, int O, int Qm, i
 
 struct PuschGeom {
   int cell_nre, M_sc, n_prb, mod, Qm, tti0, scr_words, mmse;
-  AckGeom ack;
+  AckGeom ack, ri;
   int*    ack_sum; // [nof_sf][4] accumulators of the ACK decisions (zeroed per call), or null
+  int*    ri_sum;  // the same for the rank indication
   int nsymb; // data symbols per subframe: 12, or 11 when the last symbol is left to the SRS (shortened subframe, pusch.c:52-91)
 };
 
@@ -965,6 +994,7 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
   __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
   const int k0 = blockIdx.x * 64, sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = g.nsymb * g.M_sc;
   const int nk = min(64, g.M_sc - k0);
+  const int rb0 = ri_before(g.ri, 0, k0, g.M_sc, g.nsymb); // RI symbols on the sub-carriers before this workgroup's
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
   for (int t = threadIdx.x; t < 64 * g.nsymb; t += 256) {
     const int n = t >> 6, kl = t & 63;
@@ -975,6 +1005,19 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
     const int      bit0 = i * g.Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
     const int      ai   = ack_symbol_index(g.ack, n, k0 + kl, g.M_sc, g.nsymb);
+    const int      ri   = ri_symbol_index(g.ri, n, k0 + kl, g.M_sc, g.nsymb);
+    if (ri >= 0) { // the interleaver left this symbol out of the UL-SCH stream (sch.c:968-979): it only feeds the RI decision
+      const int d0 = (c2 & 1) ? -o[0] : o[0], d1 = (c2 & 2) ? -o[1] : o[1];
+      if (g.ri.O == 1) {
+        atomicAdd(&g.ri_sum[sf * 4], d0 + ((c2 & 1) ? -o[1] : o[1]));
+      } else if (3 * (ri / 3) + 3 < g.ri.Qprime) {
+        const int s3 = ri % 3;
+        atomicAdd(&g.ri_sum[sf * 4 + (s3 == 0 ? 0 : (s3 == 1 ? 2 : 1))], d0);
+        atomicAdd(&g.ri_sum[sf * 4 + (s3 == 0 ? 1 : (s3 == 1 ? 0 : 2))], d1);
+      }
+      continue;
+    }
+    const int sl = kl * g.nsymb + n - (ri_before(g.ri, n, k0 + kl, g.M_sc, g.nsymb) - rb0); // symbol slot in this workgroup's stage
     if (ai >= 0) { // uci_decode_ri_ack (sch.c:929-966): this symbol feeds the ACK decision and reaches the decoder as zeros
       const int d0 = (c2 & 1) ? -o[0] : o[0], d1 = (c2 & 2) ? -o[1] : o[1]; // descrambled
       if (g.ack.O == 1) { // value bit + its repetition, which carries the value bit's scrambling (uci.c:627-640)
@@ -984,27 +1027,47 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
         atomicAdd(&g.ack_sum[sf * 4 + (s3 == 0 ? 0 : (s3 == 1 ? 2 : 1))], d0);
         atomicAdd(&g.ack_sum[sf * 4 + (s3 == 0 ? 1 : (s3 == 1 ? 0 : 2))], d1);
       }
-      for (int b = 0; b < g.Qm; b++) stage[(kl * g.nsymb + n) * g.Qm + b] = 0;
+      for (int b = 0; b < g.Qm; b++) stage[sl * g.Qm + b] = 0;
       continue;
     }
-    for (int b = 0; b < g.Qm; b++) stage[(kl * g.nsymb + n) * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
+    for (int b = 0; b < g.Qm; b++) stage[sl * g.Qm + b] = ((c2 >> b) & 1) ? (short)-o[b] : o[b];
   }
   __syncthreads();
-  const int    nbytes = nk * g.nsymb * g.Qm * 2; // nk is a multiple of 4, Qm even: a multiple of 16
-  char*        dst    = reinterpret_cast<char*>(gout + (size_t)sf * nsym * g.Qm + (size_t)k0 * g.nsymb * g.Qm);
-  const char*  src    = reinterpret_cast<const char*>(stage);
-  for (int o16 = threadIdx.x * 16; o16 < nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+  if (g.ri.O && k0 == 0 && threadIdx.x == 0) {
+    // ulsch_deinterleave scatters g[lut[i]] = q[i] in ascending i with lut = 0 at the RI positions (sch.c:589-591,:910): g[0] ends up
+    // with the LLR of the LAST RI bit position: last bit of RI symbol 1 (symbol 0 if it is the only one), on the bottom sub-carrier; the
+    // 1-bit decoder has re-scrambled its repetition bit by then (uci.c:632-633)
+    const int n = g.ri.Qprime >= 2 ? (g.nsymb > 10 ? 10 : 8) : (g.nsymb > 10 ? 1 : 0), i = n * g.M_sc + g.M_sc - 1, bit = i * g.Qm + g.Qm - 1;
+    short     o[8];
+    demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
+    const int cbit = (cs[bit >> 5] >> (bit & 31)) & 1;
+    stage[0]       = (g.ri.O == 1 && g.Qm == 2) ? o[1] : (cbit ? (short)-o[g.Qm - 1] : o[g.Qm - 1]);
+    __threadfence_block();
+  }
+  if (g.ri.O && k0 == 0) __syncthreads();
+  const int    nsl    = nk * g.nsymb - (ri_before(g.ri, 0, k0 + nk, g.M_sc, g.nsymb) - rb0); // UL-SCH symbols of this workgroup
+  const size_t first  = (size_t)sf * nsym * g.Qm + (size_t)(k0 * g.nsymb - rb0) * g.Qm;
+  if (g.ri.O == 0 || (rb0 == 0 && nsl == nk * g.nsymb)) {
+    const int    nbytes = nk * g.nsymb * g.Qm * 2; // nk is a multiple of 4, Qm even: a multiple of 16
+    char*        dst    = reinterpret_cast<char*>(gout + first);
+    const char*  src    = reinterpret_cast<const char*>(stage);
+    for (int o16 = threadIdx.x * 16; o16 < nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+  } else { // the few workgroups that hold RI symbols: neither the length nor the start is 16-byte granular any more
+    for (int e = threadIdx.x; e < nsl * g.Qm; e += 256) gout[first + e] = stage[e];
+  }
 }
 
 } // namespace
 
 // Q' of the HARQ-ACK (Q_prime_ri_ack, uci.c:547-571, UL-SCH present): min(ceil(O M_sc N_symb beta / sum K_r), 4 M_sc) in float arithmetic
-static int pusch_ack_qprime(uint32_t O, uint32_t I_offset_ack, uint32_t L_prb, uint32_t nsymb, uint32_t K_segm)
+static int pusch_ack_qprime(uint32_t O, uint32_t I_offset_ack, uint32_t L_prb, uint32_t nsymb, uint32_t K_segm, bool is_ri = false)
 {
   static const float beta_harq[16] = {2.0f, 2.5f, 3.125f, 4.0f, 5.0f, 6.250f, 8.0f, 10.0f, 12.625f, 15.875f, 20.0f, 31.0f, 50.0f, 80.0f, 126.0f, -1.0f}; // 36.213 Table 8.6.3-1
+  static const float beta_ri[16] = {1.25f, 1.625f, 2.0f, 2.5f, 3.125f, 4.0f, 5.0f, 6.25f, 8.0f, 10.0f, 12.625f, 15.875f, 20.0f, -1.0f, -1.0f, -1.0f}; // Table 8.6.3-2 (sch.c:47-48)
+  const float* beta = is_ri ? beta_ri : beta_harq;
   if (O == 0) return 0;
-  if (O > 2 || I_offset_ack > 15 || beta_harq[I_offset_ack] < 0 || K_segm == 0) return -1;
-  const uint32_t x = (uint32_t)ceilf((float)O * L_prb * 12 * nsymb * beta_harq[I_offset_ack] / K_segm), m = 4 * L_prb * 12;
+  if (O > 2 || I_offset_ack > 15 || beta[I_offset_ack] < 0 || K_segm == 0) return -1;
+  const uint32_t x = (uint32_t)ceilf((float)O * L_prb * 12 * nsymb * beta[I_offset_ack] / K_segm), m = 4 * L_prb * 12;
   const uint32_t Qp = x < m ? x : m;
   return (Qp + 3) / 4 <= 12 * L_prb ? (int)Qp : -1; // the ACK rows must exist (uci.c:505)
 }
@@ -1034,11 +1097,12 @@ struct srslte_hip_ul_rx {
   float*                 d_res; // [B] x srslte_hip_chest_ul_res_t
   int16_t *              d_g, *d_w;
   uint8_t *              d_cb_bytes, *d_cb_ok;
-  int*                   d_ack_sum; // [B][4]
-  uint8_t*               d_ack;     // [B][2] HARQ-ACK decisions of the last call
+  int*                   d_ack_sum; // [B][4] ACK, then [B][4] RI
+  uint8_t*               d_ack;     // [B][2] HARQ-ACK decisions of the last call, then [B][2] rank indications
 };
 
 extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
+extern "C" const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack + 2 * q->cfg.max_batch : nullptr; }
 
 extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 {
@@ -1072,6 +1136,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   const uint32_t P = cfg->nof_prb, B = cfg->max_batch, C = q->seg.C, K = q->seg.K1, Qm = 2 * (uint32_t)cfg->mod, M_sc = 12 * cfg->L_prb;
   const uint32_t nsymb = cfg->shortened ? 11 : 12; // 2 (7 - 1) - N_srs data symbols (pusch.c:335-343)
   const uint32_t nof_re = nsymb * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32 + 1; // spare word: the demapper reads two per symbol
+  const int      Qp_ri = pusch_ack_qprime(cfg->ri_len, cfg->I_offset_ri, cfg->L_prb, nsymb, C * K, true);
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
   q->chest = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
@@ -1129,8 +1194,9 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess &&
-       hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 4 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)2 * B) == hipSuccess &&
-       hipMemset(q->d_ack, 0, (size_t)2 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0;
+       hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 8 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)4 * B) == hipSuccess &&
+       hipMemset(q->d_ack, 0, (size_t)4 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0 &&
+       Qp_ri >= 0 && (uint32_t)Qp_ri < nof_re;
   if (!ok) {
     fprintf(stderr, "[srslte_hip] ul_rx: initialisation failed\n");
     srslte_hip_ul_rx_destroy(q);
@@ -1140,9 +1206,10 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse; q->pg.nsymb = (int)nsymb;
   q->pg.ack.O = (int)cfg->ack_len; q->pg.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
   q->pg.ack_sum = q->d_ack_sum;
+  q->pg.ri.O = (int)cfg->ri_len; q->pg.ri.Qprime = Qp_ri; q->pg.ri_sum = q->d_ack_sum + 4 * B;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride; q->rg.Nl = 1;
   q->rg.out_len = (int)(3 * K + 12);
-  q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re;
+  q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re - Qp_ri; // the UL-SCH is rate-matched to what the RI leaves (sch.c:1157-1160)
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
   return q;
 }
@@ -1182,16 +1249,23 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   PuschGeom g = q->pg;
   g.tti0      = (int)tti0;
   g.ack_sum   = q->d_ack_sum;
+  g.ri_sum    = q->d_ack_sum + 4 * q->cfg.max_batch;
   const dim3 grid(ceil_div(g.M_sc, 256), g.nsymb, nof_sf);
   hipLaunchKernelGGL(pusch_eq_kernel, grid, dim3(256), 0, st, (const cf32*)q->d_grid, (const cf32*)q->d_ce, (const float*)q->d_res, q->d_z, g);
   LAUNCH_CHECK();
   r = srslte_hip_dft_precoding_batch(q->d_z, q->d_d, q->cfg.L_prb, g.nsymb * nof_sf, 0, stream); // srslte_dft_precoding_init_rx: inverse, 1/sqrt(N)
   if (r) return r;
   if (g.ack.O) HIP_TRY(hipMemsetAsync(q->d_ack_sum, 0, sizeof(int) * 4 * nof_sf, st));
+  if (g.ri.O) HIP_TRY(hipMemsetAsync(q->d_ack_sum + 4 * q->cfg.max_batch, 0, sizeof(int) * 4 * nof_sf, st));
   hipLaunchKernelGGL(pusch_demod_kernel, dim3(ceil_div(g.M_sc, 64), nof_sf), dim3(256), 0, st, (const cf32*)q->d_d, (const uint32_t*)q->d_scr, q->d_g, g);
   LAUNCH_CHECK();
   if (g.ack.O) {
     hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_sf, 64)), dim3(64), 0, st, (const int*)q->d_ack_sum, q->d_ack, (int)nof_sf);
+    LAUNCH_CHECK();
+  }
+  if (g.ri.O) {
+    hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_sf, 64)), dim3(64), 0, st, (const int*)(q->d_ack_sum + 4 * q->cfg.max_batch),
+                       q->d_ack + 2 * q->cfg.max_batch, (int)nof_sf);
     LAUNCH_CHECK();
   }
   RmGeom rg = q->rg;
@@ -1284,8 +1358,9 @@ __device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_
 struct PuschTxGeom {
   int   cell_nre, M_sc, n_prb, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
   int   nsymb; // 12 data symbols, 11 in a shortened subframe
-  AckGeom        ack;
+  AckGeom        ack, ri;
   const uint8_t* ack_bits; // [nof_sf][2] HARQ-ACK values of this call, or null
+  const uint8_t* ri_bits;  // [nof_sf][2] rank indication bits of this call, or null
   float lvl[16];
 };
 
@@ -1329,7 +1404,9 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
   if (k >= g.M_sc) return;
-  const int s = k * g.nsymb + n; // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
+  const int ri = g.ri_bits ? ri_symbol_index(g.ri, n, k, g.M_sc, g.nsymb) : -1; // RI symbol: outside the UL-SCH stream (sch.c:580-598)
+  // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
+  const int s = ri >= 0 ? 0 : k * g.nsymb + n - (g.ri_bits ? ri_before(g.ri, n, k, g.M_sc, g.nsymb) : 0);
   int       r, e0;
   if (s < g.C_lo * g.syms_lo) {
     r  = s / g.syms_lo;
@@ -1353,6 +1430,10 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
     bit ^= cbit;
     if (ai >= 0) { // HARQ-ACK symbol: value bits are scrambled, placeholders are 1, a repetition bit copies the transmitted bit before it
       const int t = ack_bit_type(g.ack_bits + 2 * sf, g.ack.O, g.Qm, ai * g.Qm + b); // (sch.c:1203-1215, pusch.c:386-400)
+      bit         = t == 3 ? 1 : (t == 2 ? prev : (t ^ cbit));
+    }
+    if (ri >= 0) { // rank indication: the same encoder (sch.c:1110-1129)
+      const int t = ack_bit_type(g.ri_bits + 2 * sf, g.ri.O, g.Qm, ri * g.Qm + b);
       bit         = t == 3 ? 1 : (t == 2 ? prev : (t ^ cbit));
     }
     prev = bit;
@@ -1436,7 +1517,14 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
   }
   g.tbs = (int)cfg->tbs; g.rlenB = (int)((C == 1 ? K : K - 24) / 8); g.cb_stride = (int)((K / 8 + 15) & ~15u);
   g.par_stride = (int)((K / 4 + 1 + 15) & ~15u); g.rm_len = (int)(3 * K + 12);
-  g.syms_lo = (int)(nof_re / C); g.C_lo = (int)(C - nof_re % C); // G' = nof_re, gamma = G' mod C (sch.c:205-207)
+  g.ri.O = (int)cfg->ri_len; g.ri.Qprime = pusch_ack_qprime(cfg->ri_len, cfg->I_offset_ri, cfg->L_prb, nsymb, C * K, true);
+  if (g.ri.Qprime < 0 || (uint32_t)g.ri.Qprime >= nof_re) {
+    fprintf(stderr, "[srslte_hip] ul_tx: invalid rank-indication configuration\n");
+    delete q;
+    return nullptr;
+  }
+  const uint32_t g_re = nof_re - g.ri.Qprime; // UL-SCH symbols: what the RI leaves (sch.c:1157-1160)
+  g.syms_lo = (int)(g_re / C); g.C_lo = (int)(C - g_re % C); // G' = the UL-SCH symbols, gamma = G' mod C (sch.c:205-207)
   for (uint32_t idx = 0; idx < (1u << cfg->mod); idx++) { // 36.211 7.1.2-7.1.4, one axis: bits b0 b2 b4 of the symbol (lte_tables.c:57-182)
     const int    nb = cfg->mod;
     double       v  = 1.0;
@@ -1499,15 +1587,21 @@ extern "C" const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q
 extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, void* d_iq,
                                       void* stream)
 {
-  if (q && q->cfg.ack_len) return SRSLTE_ERROR_INVALID_INPUTS; // HARQ-ACK configured: the values come through _batch_ack
+  if (q && (q->cfg.ack_len || q->cfg.ri_len)) return SRSLTE_ERROR_INVALID_INPUTS; // UCI configured: the values come through _batch_ack / _batch_uci
   return srslte_hip_ul_tx_batch_ack(q, d_tb, tb_stride, nullptr, tti0, nof_sf, d_iq, stream);
 }
 
 extern "C" int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, uint32_t tti0,
                                           uint32_t nof_sf, void* d_iq, void* stream)
 {
+  return srslte_hip_ul_tx_batch_uci(q, d_tb, tb_stride, d_ack, nullptr, tti0, nof_sf, d_iq, stream);
+}
+
+extern "C" int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                          uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream)
+{
   if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
-  if ((q->cfg.ack_len != 0) != (d_ack != nullptr)) return SRSLTE_ERROR_INVALID_INPUTS;
+  if ((q->cfg.ack_len != 0) != (d_ack != nullptr) || (q->cfg.ri_len != 0) != (d_ri != nullptr)) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const void* d_r = nullptr;
@@ -1516,6 +1610,7 @@ extern "C" int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* 
   g.tti0        = (int)tti0;
   g.tb_stride   = (int)tb_stride;
   g.ack_bits    = d_ack;
+  g.ri_bits     = d_ri;
   hipLaunchKernelGGL(pusch_tx_tbcrc_kernel, dim3(nof_sf), dim3(256), 0, st, d_tb, q->d_tbcrc, g);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(pusch_tx_seg_kernel, dim3(g.C, nof_sf), dim3(256), 0, st, d_tb, (const uint32_t*)q->d_tbcrc, q->d_cb, g);

@@ -895,6 +895,88 @@ def test_ul_rx_chain_harq_ack(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O, Io
     rx.free()
 
 
+UL_RI_CASES = [(25, 10, 5, 2, 4008, 12.0, 8, 6, 1, 9, 0, 0, False), (25, 10, 5, 2, 4008, 12.0, 1, 6, 1, 9, 2, 9, False), (6, 6, 0, 1, 1000, 6.0, 2, 4, 1, 5, 1, 5, True),
+               (100, 48, 20, 3, 30576, 19.0, 7, 4, 1, 12, 0, 0, False), (50, 20, 3, 2, 7736, 12.0, 4, 4, 2, 8, 1, 8, False),
+               (100, 100, 0, 2, 43816, 15.0, 4, 4, 1, 11, 2, 12, True), (25, 1, 7, 1, 104, 8.0, 3, 4, 1, 10, 0, 0, False), (15, 3, 12, 3, 1800, 19.0, 9, 3, 2, 12, 2, 3, False)]
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O_ri,I_ri,O_ack,I_ack,short", UL_RI_CASES)
+def test_ul_tx_chain_rank_indication(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_ri, I_ri, O_ack, I_ack, short):
+    """PUSCH transmit chain with a rank indication (and HARQ-ACK): RI symbols on their own columns, left out by the channel interleaver,
+    UL-SCH rate-matched to the rest (sch.c:580-598,:1110-1160) vs the oracle's (pinned on srslte_ulsch_encode): symbols exact."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(1900 + prb + L + mod + O_ri)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, shortened=short, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    ris = np.array([[(b >> j) & 1 for j in range(O_ri)] for b in range(nsf)], np.uint8)
+    acks = np.array([[((b + 1) >> j) & 1 for j in range(O_ack)] for b in range(nsf)], np.uint8) if O_ack else None
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri,
+                 I_offset_ri=I_ri)
+    iq = tx.encode(data, tti0, ack=acks, ri=ris)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    for b in range(nsf):
+        k = {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k, ack=tuple(acks[b]) if O_ack else (), I_offset_ack=I_ack,
+                                   ri=tuple(ris[b]), I_offset_ri=I_ri)
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), "modulated symbols sf %d" % b
+        assert_close_c(iq[b], iq_o, "iq sf %d" % b)
+    tx.free()
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O_ri,I_ri,O_ack,I_ack,short", UL_RI_CASES)
+def test_ul_rx_chain_rank_indication(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_ri, I_ri, O_ack, I_ack, short):
+    """PUSCH receive chain with a rank indication (and HARQ-ACK) vs the oracle chain (pinned on srslte_ulsch_decode) on identical IQ:
+    RI and ACK decisions, the de-interleaved UL-SCH LLRs - first element included, which the reference's scatter leaves holding the last
+    RI position's LLR (sch.c:891-918) -, pass counts, CRC, TB."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(2000 + prb + L + mod + O_ri)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6, shortened=short)
+    G = ul_ri_layout(cfg, O_ri, I_ri)[3]
+    ris = np.array([[(b >> j) & 1 for j in range(O_ri)] for b in range(nsf)], np.uint8)
+    acks = np.array([[((b + 1) >> j) & 1 for j in range(O_ack)] for b in range(nsf)], np.uint8) if O_ack else None
+    iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), ack=tuple(acks[b]) if O_ack else (),
+                                      I_offset_ack=I_ack, ri=tuple(ris[b]), I_offset_ri=I_ri) for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri,
+                 I_offset_ri=I_ri)
+    for rep in range(2):
+        tb, ok = rx.decode(np.stack(iq), tti0)
+        ri, ack = rx.ri(), rx.ack()
+        C_ = cfg.seg.C
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+        n_ok = 0
+        for b in range(nsf):
+            r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri)
+            diff = np.abs(g[b, :G].astype(np.int32) - r["g"].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size + 1, (b, int(diff.max()), int((diff != 0).sum()))
+            assert np.array_equal(ri[b], r["ri"][:O_ri]) and np.array_equal(ri[b], ris[b]), "ri sf %d" % b
+            if O_ack:
+                assert np.array_equal(ack[b], r["ack"][:O_ack])  # (with Q' <= 3 the 2-bit decoder never combines a triplet: all-zero decisions, uci.c:776-777)
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+            if r["ok"] or diff.max() == 0:
+                assert np.array_equal(tb[b], r["tb"])
+            if r["ok"]:
+                n_ok += 1
+                assert np.array_equal(tb[b][:tbs // 8], data[b])
+        assert n_ok > 0
+    rx.free()
+
+
+def test_ul_tx_rx_loop_uci(hp):
+    """Device transmit chain with HARQ-ACK and rank indication into the device receive chain (noise-free): everything comes back."""
+    prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
+    rng = np.random.default_rng(79)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    acks, ris = rng.integers(0, 2, (nsf, 2), dtype=np.uint8), rng.integers(0, 2, (nsf, 1), dtype=np.uint8)
+    kw = dict(ack_len=2, I_offset_ack=8, ri_len=1, I_offset_ri=7)
+    tx = hp.UlTx(3, prb, 0x77, mod, tbs, L, n_prb, 1, nsf, **kw)
+    rx = hp.UlRx(3, prb, 0x77, mod, tbs, L, n_prb, 1, 6, nsf, **kw)
+    tb, ok = rx.decode(tx.encode(data, 5, ack=acks, ri=ris), 5)
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data) and np.array_equal(rx.ack(), acks) and np.array_equal(rx.ri(), ris)
+    tx.free()
+    rx.free()
+
+
 def test_ul_tx_rx_loop_harq_ack(hp):
     """Device transmit chain with HARQ-ACK into the device receive chain (noise-free): transport blocks and ACK values come back."""
     prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
