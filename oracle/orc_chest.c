@@ -153,7 +153,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
 {
   const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = port < 2 ? 4 : 2, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
-  if (!cell->cp_norm || port > 3) return -1; /* extended CP time interpolation not restated */
+  if (port > 3) return -1;
   if (port > 1 && ce && cfg->interpolate_subframe) return -3;
   cf* known = malloc(sizeof(cf) * 4 * nref);
   cf* recv  = malloc(sizeof(cf) * 4 * nref);
@@ -199,7 +199,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   }
   float cfo = 0;
   if (cfg->cfo_estimate_enable) { /* chest_dl.c:573-596 */
-    float n = (float)orc_symbol_sz((int)P), ns = 7.0f, ng = (float)orc_cp_len_norm(1, (int)n);
+    float n = (float)orc_symbol_sz((int)P), ns = cell->cp_norm ? 7.0f : 6.0f, ng = (float)orc_cp_len_norm(1, (int)n); /* the normal-CP length whatever the cell's (:577) */
     cf    sum = {0, 0};
     for (uint32_t i = 0; i < 2; i++) { /* npilots is port 0's whatever the port (:582) */
       for (uint32_t k = 0; k < nref; k++) sum = c_add(sum, c_mulconj(est[i * nref + k], est[(i + 2) * nref + k]));
@@ -249,17 +249,24 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
     } else {
       for (uint32_t l = 0; l < nsym; l++) {
         uint32_t off = orc_crs_fidx(cell, l, port);
-        interp_linear_offset(&pil[nref * l], &ce[orc_crs_nsymbol(l, true, port) * nre], nref, 6, off, 6 - off);
+        interp_linear_offset(&pil[nref * l], &ce[orc_crs_nsymbol(l, cell->cp_norm, port) * nre], nref, 6, off, 6 - off);
       }
 #define S(i) (&ce[(i) * nre])
-      interp_vector(S(0), S(4), NULL, S(1), 4, 3, nre);
-      interp_vector(S(4), S(7), NULL, S(5), 3, 2, nre);
-      interp_vector(S(7), S(11), NULL, S(8), 4, 3, nre);
-      interp_vector(S(7), S(11), S(11), S(12), 4, 2, nre);
+      if (cell->cp_norm) {
+        interp_vector(S(0), S(4), NULL, S(1), 4, 3, nre);
+        interp_vector(S(4), S(7), NULL, S(5), 3, 2, nre);
+        interp_vector(S(7), S(11), NULL, S(8), 4, 3, nre);
+        interp_vector(S(7), S(11), S(11), S(12), 4, 2, nre);
+      } else { /* extended CP: pilot symbols 0, 3, 6, 9 of 12 (chest_dl.c:497-502) */
+        interp_vector(S(0), S(3), NULL, S(1), 3, 2, nre);
+        interp_vector(S(3), S(6), NULL, S(4), 3, 2, nre);
+        interp_vector(S(6), S(9), NULL, S(7), 3, 2, nre);
+        interp_vector(S(6), S(9), S(9), S(10), 3, 2, nre);
+      }
 #undef S
     }
     if (cfg->noise_alg != 0 && (sf_idx == 0 || sf_idx == 5)) {
-      const uint32_t k_pss = 6 * nre + nre / 2 - 31, k_sss = 5 * nre + nre / 2 - 31;
+      const uint32_t nsl = cell->cp_norm ? 7 : 6, k_pss = (nsl - 1) * nre + nre / 2 - 31, k_sss = (nsl - 2) * nre + nre / 2 - 31;
       if (cfg->noise_alg == 1) { /* estimate_noise_pss (chest_dl.c:381-398): |ce pss - received|^2 over the 62 PSS carriers */
         cf pss[62], d[62];
         orc_pss_generate(cell->id % 3, pss);

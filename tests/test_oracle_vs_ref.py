@@ -324,6 +324,67 @@ def test_chest_dl_noise_pss_empty_vs_ref(prb, cid, npt, alg):
     R.srslte_chest_dl_free(q)
 
 
+@pytest.mark.parametrize("prb,cid,npt", [(6, 1, 1), (25, 2, 2), (50, 3, 1), (100, 4, 2), (15, 150, 1)])
+def test_chest_dl_extended_cp_vs_ref(prb, cid, npt):
+    """Cells with the extended cyclic prefix (12 symbols per subframe; CRS on symbols 0, 3, 6, 9 with N_cp = 0 in c_init, refsignal_dl.c:
+    66-116,:234-249): srslte_chest_dl_estimate_cfg with every configuration of CHEST_CFGS, the extended-CP time interpolation
+    (chest_dl.c:497-502), CFO with 6 symbols per slot, and the PSS / EMPTY noise positions - against the oracle."""
+    R, rng = ref(), np.random.default_rng(700 + prb + cid)
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    nre, n = 12 * prb, 12 * 12 * prb
+    cell = OrcCell(cid, prb, npt, False)
+    pss = np.zeros(62, np.complex64)
+    orc.orc_pss_generate(cid % 3, p(pss))
+    q = opaque(1 << 20)
+    assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, npt, cid, 1, 0, 0, 0)) == 0
+    state, last_cfo = np.zeros(16, np.float32), 0.0
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+    cfgs = [dict(kw) for kw in CHEST_CFGS] + [{"noise_alg": 1, "filter_coef": (4.0, 1.5)}, {"noise_alg": 2, "filter_type": 1, "filter_coef": (0.1, 0.0)},
+                                              {"noise_alg": 1}]
+    for step, kw in enumerate(cfgs):
+        sf_idx = (0, 3, 5)[step % 3]
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        for pp in range(npt):
+            orc.orc_crs_put_sf(C.byref(cell), sf_idx, pp, p(g))
+        if sf_idx in (0, 5):
+            kp, ks = 5 * nre + nre // 2 - 31, 4 * nre + nre // 2 - 31
+            g[kp:kp + 62] = pss
+            for k0 in (kp - 5, kp + 62, ks - 5, ks + 62):
+                g[k0:k0 + 5] = 0
+        grid = acopy((g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        rc, oc = RefChestCfg(), OrcChestCfg()
+        for kk, v in kw.items():
+            if kk == "filter_coef":
+                rc.filter_coef[0], rc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(rc, kk, v)
+                setattr(oc, kk, v)
+        rc.cfo_estimate_sf_mask = 0x3FF
+        ces = [aligned(2 * n, np.float32) for _ in range(npt)]
+        res, sf = RefChestRes(), RefDlSfCfg()
+        for pp in range(npt):
+            res.ce[pp][0] = ces[pp].ctypes.data
+        sf.tti = sf_idx
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        ce2, ores = [np.zeros(n, np.complex64) for _ in range(npt)], OrcChestRes()
+        gp, cp = (C.c_void_p * 1)(grid.ctypes.data), (C.c_void_p * npt)(*[c.ctypes.data for c in ce2])
+        assert orc.orc_chest_dl_ports_state(C.byref(cell), sf_idx, C.byref(oc), 1, gp, cp, C.byref(ores), None, p(state)) == 0
+        for pp in range(npt):
+            a = ces[pp].view(np.complex64)
+            assert np.abs(a - ce2[pp]).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (step, kw, pp)
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, step, x, y)
+        if kw.get("cfo_estimate_enable"):
+            last_cfo = ores.cfo
+            assert last_cfo != 0
+        assert abs(res.cfo - last_cfo) <= 1e-4 * abs(last_cfo) + 1e-9  # q->cfo keeps its last enabled value
+    R.srslte_chest_dl_free(q)
+
+
 MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
               {"filter_coef": (4.0, 1.5)}, {}]
 
