@@ -83,6 +83,7 @@ typedef struct {             /* same members, order and meaning as srslte_chest_
 typedef struct {             /* scalar members of srslte_chest_dl_res_t (chest_dl.h:49-67), one per subframe */
   float noise_estimate, noise_estimate_dbm, snr_db, rsrp, rsrp_dbm, rsrq, rsrq_db, rssi_dbm, cfo, sync_error;
 } srslte_hip_chest_dl_res_t;
+/* cp_is_norm = 0: extended-CP cell, 12 symbols per subframe: every "[14]" below reads "[12]" then (CRS on symbols 0, 3, 6, 9; chest_dl.c:497-502) */
 srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm); /* chest_dl.c:69-160,193-300 */
 void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
 const void*            srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q); /* device CRS table [10][4][2*prb] (refsignal_dl.c:66-116) */

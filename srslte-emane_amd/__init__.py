@@ -237,7 +237,7 @@ class ChestDl:
         self.h = lib().srslte_hip_chest_dl_create(cell_id, nof_prb, nof_ports, 1 if cp_norm else 0)
         if not self.h:
             raise RuntimeError("srslte_hip_chest_dl_create failed")
-        self.grid_len = 14 * 12 * nof_prb
+        self.grid_len = (14 if cp_norm else 12) * 12 * nof_prb
         self.nof_ports = nof_ports
 
     def set_mbsfn_area_id(self, area_id):

@@ -26,6 +26,7 @@ struct ChestParams {
   int   symbol_sz, cp1; // for CFO
   int   nof_rx;         // receive antennas, tx ports: block v = (sf * nof_ports + port) * nof_rx + antenna reads grid [sf][antenna]
   int   nof_ports;      // and writes ce [sf][port][antenna]
+  int   nsl;            // symbols per slot: 7, or 6 in an extended-CP cell (grids and estimates are then [12][12 nof_prb])
 };
 struct ChestRaw { float noise, rsrp, rssi, cfo, sync, corr; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ cf32 c_scale(cf32 a, float s) { return make_float2(a.
 __device__ __forceinline__ cf32 c_mulconj(cf32 a, cf32 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
 
 // refsignal_dl.c:234-249, normal CP: ports 0/1 use symbols 0, 4, 7, 11, ports 2/3 symbols 1 and 8
-__device__ __forceinline__ int crs_nsymbol(int l, int port = 0) { return port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7); }
+__device__ __forceinline__ int crs_nsymbol(int l, int port, int nsl) { return port >= 2 ? 1 + nsl * l : ((l & 1) ? (l / 2 + 1) * nsl - 3 : (l / 2) * nsl); } // nsl: symbols per slot
 // refsignal_dl.c:134-168: v = 0/3 alternating with the pilot symbol, the other way round for the odd port of each pair
 __device__ __forceinline__ int crs_fidx(int cell_id, int l, int port) { return ((((l + port) & 1) ? 3 : 0) + (cell_id % 6)) % 6; }
 
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
 
   const int   sf = blockIdx.x, tid = threadIdx.x; // sf: (subframe, port, antenna) index
   const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
-  const cf32* g      = grid + ((size_t)sfn * p.nof_rx + ant) * 14 * nre;
+  const cf32* g      = grid + ((size_t)sfn * p.nof_rx + ant) * 2 * p.nsl * nre;
   const int   nsym = port < 2 ? 4 : 2, npil = nsym * nref; // ports 2/3: two pilot symbols per subframe
   // ports 0 and 1 share their values (refsignal_dl.c pilots[port / 2]), [10][4][nref]; ports 2 and 3 theirs, [10][2][nref] behind
   const cf32* known = port < 2 ? pilots + (size_t)sf_idx * 4 * nref : pilots + (size_t)10 * 4 * nref + (size_t)sf_idx * 2 * nref;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   float acc = 0;
   for (int i = tid; i < npil; i += CH_THREADS) {
     const int l = i / nref, k = i - l * nref;
-    cf32      r = g[crs_nsymbol(l, port) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
+    cf32      r = g[crs_nsymbol(l, port, p.nsl) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
     est[i]      = c_mulconj(r, known[i]);
     acc += r.x * r.x + r.y * r.y;
   }
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   acc = 0;
   for (int i = tid; i < nsym * nre; i += CH_THREADS) {
     const int l = i / nre;
-    cf32      v = g[crs_nsymbol(l, port) * nre + (i - l * nre)];
+    cf32      v = g[crs_nsymbol(l, port, p.nsl) * nre + (i - l * nre)];
     acc += v.x * v.x + v.y * v.y;
   }
   const float rssi = block_sum(acc, red) / (float)nsym;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
         second = est[i + 2 * nref];
       } else {
         const int l = 2 + i / nref, k = i % nref;
-        second = c_mulconj(g[crs_nsymbol(l, 1) * nre + crs_fidx(p.cell_id, l, 1) + 6 * k], pilots[(size_t)sf_idx * 4 * nref + l * nref + k]);
+        second = c_mulconj(g[crs_nsymbol(l, 1, p.nsl) * nre + crs_fidx(p.cell_id, l, 1) + 6 * k], pilots[(size_t)sf_idx * 4 * nref + l * nref + k]);
       }
       cf32 v = c_mulconj(est[i], second);
       sr += v.x;
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     sr = block_sum(sr, red);
     si = block_sum(si, red);
     const float n = (float)p.symbol_sz, ng = (float)p.cp1;
-    cfo = (float)((double)(-atan2f(si, sr) * n / (7.0f * (n + ng))) / 2 / M_PI);
+    cfo = (float)((double)(-atan2f(si, sr) * n / ((float)p.nsl * (n + ng))) / 2 / M_PI);
   }
 
   // ---- noise from pilots (REFS): residual of the last pilot symbol only (chest_dl.c:352-378); PSS / EMPTY: the estimator's kept
@@ -256,13 +257,15 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       pil = avg;
     }
 
-    cf32* o = ce + (size_t)sf * 14 * nre;
+    cf32* o = ce + (size_t)sf * 2 * p.nsl * nre;
     if (!p.interpolate_subframe) { // chest_dl.c:448-471
       const int off = p.cell_id % 3;
       for (int k = tid; k < nre; k += CH_THREADS) {
         const cf32 v = interp_offset_at(pil, 4 * P, 3, off, k);
 #pragma unroll
-        for (int l = 0; l < 14; l++) o[l * nre + k] = v;
+        for (int l = 0; l < 14; l++) {
+          if (l < 2 * p.nsl) o[l * nre + k] = v;
+        }
       }
     } else { // chest_dl.c:456-495
       for (int i = tid; i < 4 * nre; i += CH_THREADS) {
@@ -272,6 +275,20 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       __syncthreads();
       for (int k = tid; k < nre; k += CH_THREADS) {
         const cf32 s0 = fr[k], s4 = fr[nre + k], s7 = fr[2 * nre + k], s11 = fr[3 * nre + k];
+        if (p.nsl == 6) { // extended CP: pilot symbols 0, 3, 6, 9 (chest_dl.c:497-502); the last step extrapolates with the 6-9 slope
+          const cf32 pil4[4] = {s0, s4, s7, s11};
+          cf32       dd = make_float2(0.f, 0.f);
+          for (int seg = 0; seg < 3; seg++) {
+            dd     = c_scale(c_sub(pil4[seg + 1], pil4[seg]), 1.0f / 3);
+            cf32 w = pil4[seg];
+            o[(3 * seg) * nre + k] = w;
+            for (int l = 1; l <= 2; l++) { w = c_add(w, dd); o[(3 * seg + l) * nre + k] = w; }
+          }
+          cf32 w = s11;
+          o[9 * nre + k] = w;
+          for (int l = 10; l <= 11; l++) { w = c_add(w, dd); o[l * nre + k] = w; }
+          continue;
+        }
         cf32       d = c_scale(c_sub(s4, s0), 1.0f / 4), v = s0;
         o[k] = s0;
         for (int l = 1; l <= 3; l++) { v = c_add(v, d); o[l * nre + k] = v; }
@@ -287,7 +304,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       }
     }
     if (p.noise_alg != 0 && (sf_idx == 0 || sf_idx == 5)) {
-      const int k_pss = 6 * nre + nre / 2 - 31, k_sss = 5 * nre + nre / 2 - 31;
+      const int k_pss = (p.nsl - 1) * nre + nre / 2 - 31, k_sss = (p.nsl - 2) * nre + nre / 2 - 31;
       __syncthreads(); // the estimates of symbol 6 written above, read back by other lanes
       acc = 0;
       if (p.noise_alg == 1) { // estimate_noise_pss (chest_dl.c:381-398)
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_mbsfn_kernel(const cf32* 
   __shared__ float filt[64];
   const int   sf = blockIdx.x, tid = threadIdx.x;
   const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
-  const cf32* g     = grid + ((size_t)sfn * p.nof_rx + ant) * 14 * nre;
+  const cf32* g     = grid + ((size_t)sfn * p.nof_rx + ant) * 2 * p.nsl * nre;
   const cf32* known = pilots + (size_t)sf_idx * 4 * ncrs;      // first CRS symbol of ports 0/1
   const cf32* mb    = mbsfn_pilots + (size_t)sf_idx * 3 * nmb; // [3][6 P]
   const int   fidx  = crs_fidx(p.cell_id, 0, port);
@@ -405,7 +422,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_mbsfn_kernel(const cf32* 
     __syncthreads();
     pil = avg;
   }
-  cf32* o = ce + (size_t)sf * 14 * nre;
+  cf32* o = ce + (size_t)sf * 2 * p.nsl * nre;
   for (int k = tid; k < nre; k += CH_THREADS) { // interpolate_pilots, MBSFN (chest_dl.c:436-447, :474-478)
     const cf32 s0 = interp_offset_at(pil, ncrs, 6, fidx, k), s2 = interp_offset_at(pil + ncrs, nmb, 2, 0, k);
     const cf32 s6 = interp_offset_at(pil + ncrs + nmb, nmb, 2, 1, k), s10 = interp_offset_at(pil + ncrs + 2 * nmb, nmb, 2, 0, k);
@@ -497,7 +514,7 @@ void gold(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c)
 void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) { gold(c_init, len, c); }
 
 struct srslte_hip_chest_dl {
-  int       cell_id, nof_prb, nof_ports;
+  int       cell_id, nof_prb, nof_ports, nsl; // nsl: symbols per slot (7, extended CP 6)
   cf32*     d_pilots; // [10][4][2*nof_prb] ports 0 and 1, then [10][2][2*nof_prb] ports 2 and 3 (4-port cells)
   ChestRaw* d_raw;    // per (subframe, port, antenna) scalars of multi-antenna / multi-port calls, grown on demand
   size_t    raw_cap;
@@ -508,8 +525,8 @@ struct srslte_hip_chest_dl {
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
 {
-  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || (nof_ports != 1 && nof_ports != 2 && nof_ports != 4) || !cp_is_norm) {
-    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1, 2 or 4 ports, normal CP only\n", cell_id,
+  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || (nof_ports != 1 && nof_ports != 2 && nof_ports != 4)) {
+    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1, 2 or 4 ports\n", cell_id,
             nof_prb, nof_ports, cp_is_norm);
     return nullptr;
   }
@@ -518,8 +535,8 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   std::vector<uint8_t> c;
   for (uint32_t ns = 0; ns < 20; ns++) {
     for (uint32_t l = 0; l < 3; l++) { // l = 0, 1: symbols 0 and 4 of the slot (ports 0/1); l = 2: symbol 1 (ports 2/3)
-      const uint32_t lp     = l == 0 ? 0 : (l == 1 ? 4 : 1);
-      const uint32_t c_init = 1024 * (7 * (ns + 1) + lp + 1) * (2 * cell_id + 1) + 2 * cell_id + 1;
+      const uint32_t lp     = l == 0 ? 0 : (l == 1 ? (cp_is_norm ? 4 : 3) : 1);
+      const uint32_t c_init = 1024 * (7 * (ns + 1) + lp + 1) * (2 * cell_id + 1) + 2 * cell_id + (cp_is_norm ? 1 : 0); // N_cp (refsignal_dl.c:92)
       gold(c_init, 4 * MAX_PRB, c);
       cf32* dst = l < 2 ? &pil[((size_t)(ns / 2) * 4 + (ns % 2) * 2 + l) * nref] : &pil[(size_t)10 * 4 * nref + ((size_t)(ns / 2) * 2 + ns % 2) * nref];
       for (int i = 0; i < nref; i++) {
@@ -532,6 +549,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   q->cell_id  = cell_id;
   q->nof_prb  = nof_prb;
   q->nof_ports = (int)nof_ports;
+  q->nsl      = cp_is_norm ? 7 : 6;
   q->d_pilots = nullptr;
   q->d_raw    = nullptr;
   q->raw_cap  = 0;
@@ -628,7 +646,7 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;
   p.noise_alg = cfg->noise_alg; p.filter_type = cfg->filter_type; p.interpolate_subframe = 1;
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
-  p.nof_rx = nof_rx; p.nof_ports = q->nof_ports;
+  p.nof_rx = nof_rx; p.nof_ports = q->nof_ports; p.nsl = q->nsl;
   hipLaunchKernelGGL(chest_dl_mbsfn_kernel, dim3(nof_sf * nof_rx * q->nof_ports), dim3(CH_THREADS), sizeof(cf32) * 40 * q->nof_prb,
                      (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce, d_noise, (const cf32*)q->d_pilots,
                      (const cf32*)q->d_mbsfn[cfg->mbsfn_area_id], p);
@@ -675,6 +693,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.cp1 = lte_cp_len_norm(1, p.symbol_sz);
   p.nof_rx = nof_rx;
   p.nof_ports = q->nof_ports;
+  p.nsl = q->nsl;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
   if (d_res || cfg->noise_alg) {

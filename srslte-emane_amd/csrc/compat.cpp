@@ -927,7 +927,7 @@ static int chest_dl_estimate_mbsfn(srslte_chest_dl_t* q, ChestState* st, srslte_
                                    cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res)
 {
   const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
-  const size_t   n   = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
+  const size_t   n   = sizeof(cf_t) * 2 * cp_nsymb(q->cell.cp) * 12 * q->cell.nof_prb; // SRSLTE_SF_LEN_RE
   char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx * npt);
   float*         dnoise = (float*)st->res.get(sizeof(float) * 16);
   if (!dg || !dce || !dnoise) return SRSLTE_ERROR;
@@ -1003,7 +1003,7 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
   if (!st || !st->h || !sf || !cfg || !input || !res) return SRSLTE_ERROR_INVALID_INPUTS;
   if (sf->sf_type == SRSLTE_SF_MBSFN) return chest_dl_estimate_mbsfn(q, st, sf, cfg, input, res);
   const uint32_t nrx = q->nof_rx_antennas, npt = q->cell.nof_ports;
-  const size_t   n   = sizeof(cf_t) * 14 * 12 * q->cell.nof_prb;
+  const size_t   n   = sizeof(cf_t) * 2 * cp_nsymb(q->cell.cp) * 12 * q->cell.nof_prb; // SRSLTE_SF_LEN_RE
   char *         dg = (char*)st->grid.get(n * nrx), *dce = (char*)st->ce.get(n * nrx * npt);
   void*          dres = st->res.get(sizeof(srslte_hip_chest_dl_res_t));
   if (!dg || !dce || !dres) return SRSLTE_ERROR;

@@ -299,6 +299,35 @@ def test_chest_dl_object():
     L.srslte_chest_dl_free(est)
 
 
+def test_chest_dl_object_extended_cp():
+    """srslte_chest_dl_* on an extended-CP cell (12-symbol grids, SRSLTE_SF_LEN_RE): default configuration and subframe interpolation."""
+    L, rng = hip(), np.random.default_rng(24)
+    prb, cid = 25, 3
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 1, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 12 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, False)
+    for sf_idx, interp in ((0, False), (4, True)):
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        grid = acopy((g * ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))) + 0.05 * rng.standard_normal(n)).astype(np.complex64).view(np.float32))
+        sf, rc, oc = RefDlSfCfg(), RefChestCfg(), OrcChestCfg()
+        sf.tti = 10 + sf_idx
+        rc.interpolate_subframe = oc.interpolate_subframe = interp
+        rc.filter_coef[0], rc.filter_coef[1] = 4.0, 1.0
+        oc.filter_coef[0], oc.filter_coef[1] = 4.0, 1.0
+        assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        ref, rres = np.zeros(n, np.complex64), OrcChestRes()
+        assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ref), C.byref(rres)) == 0
+        ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+        assert close(ce, ref)
+        assert abs(res.noise_estimate - rres.noise_estimate) <= 1e-4 * rres.noise_estimate and abs(res.rsrp_dbm - rres.rsrp_dbm) < 1e-3
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)
+
+
 @pytest.mark.parametrize("alg", [1, 2])
 def test_chest_dl_object_noise_pss_empty(alg):
     """srslte_chest_dl_estimate_cfg with cfg.noise_alg PSS / EMPTY (phy_common.cc:111-118 selects them from snr_estim_alg) over a run of

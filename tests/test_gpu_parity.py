@@ -237,6 +237,67 @@ def test_chest_dl_noise_pss_empty(hp, prb, cid, npt, nrx, alg):
     est.free()
 
 
+@pytest.mark.parametrize("prb,cid,npt,nrx", [(6, 1, 1, 1), (25, 2, 2, 2), (50, 3, 1, 1), (100, 4, 2, 1), (15, 150, 1, 2)])
+def test_chest_dl_extended_cp(hp, prb, cid, npt, nrx):
+    """Extended-CP cells (12 symbols per subframe, CRS on symbols 0, 3, 6, 9, N_cp = 0 in the pilot sequences; chest_dl.c:497-502) on the
+    device vs the oracle (pinned on the reference): every filter / interpolation configuration, CFO, and the PSS / EMPTY noise positions."""
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(2300 + prb + cid)
+    nre, n = 12 * prb, 12 * 12 * prb
+    cell = OrcCell(cid, prb, npt, False)
+    pss = np.zeros(62, np.complex64)
+    orc.orc_pss_generate(cid % 3, p(pss))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    est = hp.ChestDl(cid, prb, npt, cp_norm=False)
+    state = np.zeros(16, np.float32)
+    cfgs = [dict(kw) for kw in CHEST_CFGS] + [{"noise_alg": 1, "filter_coef": (4.0, 1.5)}, {"noise_alg": 2, "filter_type": 1, "filter_coef": (0.1, 0.0)}]
+    for call, kw in enumerate(cfgs):
+        tti0, nsf = 8 + call, 4
+        grids = np.zeros((nsf, nrx, n), np.complex64)
+        for b in range(nsf):
+            sf_idx = (tti0 + b) % 10
+            g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+            for pp in range(npt):
+                orc.orc_crs_put_sf(C.byref(cell), sf_idx, pp, p(g))
+            if sf_idx in (0, 5):
+                kp, ks = 5 * nre + nre // 2 - 31, 4 * nre + nre // 2 - 31
+                g[kp:kp + 62] = pss
+                for k0 in (kp - 5, kp + 62, ks - 5, ks + 62):
+                    g[k0:k0 + 5] = 0
+            for a in range(nrx):
+                h = ((3 + np.sin(k / 40.0 + a)) * np.exp(1j * (k / 100.0 + 0.1 * l + a))).astype(np.complex64)
+                grids[b, a] = (g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        hc, oc = hp.ChestDlCfg(), OrcChestCfg()
+        for k_, v in kw.items():
+            if k_ == "filter_coef":
+                hc.filter_coef[0], hc.filter_coef[1] = v
+                oc.filter_coef[0], oc.filter_coef[1] = v
+            else:
+                setattr(hc, k_, 1 if v is True else v)
+                setattr(oc, k_, v)
+        rc, ce, res, raw = est.estimate_multi(grids, tti0, hc, nrx)
+        assert rc == 0
+        if kw.get("noise_alg") and not cfgs[call - 1].get("noise_alg"):
+            state[:] = 0  # the batched object keeps its PSS / EMPTY estimate between PSS / EMPTY calls only (phy_hip.h)
+        for b in range(nsf):
+            ce2 = [np.zeros(n, np.complex64) for _ in range(npt * nrx)]
+            ores = OrcChestRes()
+            gl = [np.ascontiguousarray(grids[b, a]) for a in range(nrx)]
+            gp, cp = (C.c_void_p * nrx)(*[x.ctypes.data for x in gl]), (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce2])
+            assert orc.orc_chest_dl_ports_state(C.byref(cell), (tti0 + b) % 10, C.byref(oc), nrx, gp, cp, C.byref(ores), None, p(state)) == 0
+            for pt in range(npt):
+                for a in range(nrx):
+                    assert_close_c(ce[b, pt, a], ce2[pt * nrx + a], "ce cfg %d sf %d port %d ant %d" % (call, b, pt, a))
+            names = ("noise_estimate", "rsrp", "rsrq") + (("cfo",) if kw.get("cfo_estimate_enable") else ())
+            if kw.get("noise_alg") and not state[:npt * nrx].all():
+                names = ("rsrp", "rsrq")  # no PSS / EMPTY estimate yet
+            for name in names:
+                x, y = float(res[name][b]), float(getattr(ores, name))
+                assert abs(x - y) <= 1e-4 * abs(y) + 1e-9, (name, call, b, x, y)
+    est.free()
+
+
 MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
               {"filter_coef": (4.0, 1.5)}, {}]
 
