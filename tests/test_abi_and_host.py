@@ -92,3 +92,32 @@ def test_pipeline_entry_points_reject_bad_arguments_without_gpu():
     for L in (lib.srslte_hip_dl_rx_debug_buffer, lib.srslte_hip_ul_rx_debug_buffer, lib.srslte_hip_ul_tx_debug_buffer, lib.srslte_hip_dl_tx_debug_buffer):
         L.restype, L.argtypes = vp, [vp, C.c_int]
         assert L(None, 0) is None
+
+
+def test_round_additions_reject_bad_arguments_without_gpu():
+    """Entry points added for UCI on the PUSCH, MBSFN estimation and the noise algorithms: the same contract (-2 / NULL, no crash)."""
+    import ctypes as C
+    pkg = importlib.import_module("srslte-emane_amd")
+    lib = pkg.lib()
+    vp = C.c_void_p
+    lib.srslte_hip_ul_tx_batch_ack.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_uint32, vp, vp]
+    assert lib.srslte_hip_ul_tx_batch_ack(None, None, 0, None, 0, 1, None, None) == -2
+    lib.srslte_hip_ul_tx_batch_uci.argtypes = [vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, vp, vp]
+    assert lib.srslte_hip_ul_tx_batch_uci(None, None, 0, None, None, 0, 1, None, None) == -2
+    for fn in (lib.srslte_hip_ul_rx_ack, lib.srslte_hip_ul_rx_ri):
+        fn.restype, fn.argtypes = vp, [vp]
+        assert fn(None) is None
+    lib.srslte_hip_chest_dl_set_mbsfn_area_id.argtypes = [vp, C.c_uint16]
+    assert lib.srslte_hip_chest_dl_set_mbsfn_area_id(None, 3) == -2
+    lib.srslte_hip_chest_dl_mbsfn_pilots.restype, lib.srslte_hip_chest_dl_mbsfn_pilots.argtypes = vp, [vp, C.c_uint16]
+    assert lib.srslte_hip_chest_dl_mbsfn_pilots(None, 3) is None
+    cfg = pkg.ChestDlCfg()
+    lib.srslte_hip_chest_dl_estimate_mbsfn_batch.argtypes = [vp, C.POINTER(pkg.ChestDlCfg), C.c_uint32, vp, vp, vp, C.c_int, C.c_int, vp]
+    assert lib.srslte_hip_chest_dl_estimate_mbsfn_batch(None, C.byref(cfg), 0, None, None, None, 1, 1, None) == -2
+    lib.srslte_hip_chest_dl_estimate_batch_multi.argtypes = [vp, C.POINTER(pkg.ChestDlCfg), C.c_uint32, vp, vp, vp, C.c_int, C.c_int, vp]
+    assert lib.srslte_hip_chest_dl_estimate_batch_multi(None, C.byref(cfg), 0, None, None, None, 1, 1, None) == -2
+    # UCI configurations the tables reserve (36.213 Table 8.6.3-1 index 15, Table 8.6.3-2 index 13) or more than 2 bits: create() refuses
+    lib.srslte_hip_ul_tx_create.restype = vp
+    base = (1, 25, 0x1234, 2, 4008, 10, 5, 0, 4, pkg.DmrsPuschCfg(0, 0, 0, 0), 0)
+    for uci in ((1, 15, 0, 0), (3, 0, 0, 0), (0, 0, 1, 13), (0, 0, 3, 0)):
+        assert lib.srslte_hip_ul_tx_create(C.byref(pkg.UlTxCfg(*base, *uci))) is None
