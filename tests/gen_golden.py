@@ -296,7 +296,43 @@ def pdsch_function():
     print("pdsch_function.npz", os.path.getsize(os.path.join(OUT, "pdsch_function.npz")), "bytes")
 
 
+def chest_mbsfn():
+    """Outputs of the reference's srslte_chest_dl_estimate_cfg on MBSFN subframes (after srslte_chest_dl_set_mbsfn_area_id), with the
+    applications' configuration (triangle 0.1, PSS noise) and with the REFS noise / no filter: grids in, the 12 estimated symbols and
+    the noise estimate out. Stimulus: the oracle's orc_mbsfn_put_sf (itself pinned on srslte_refsignal_mbsfn_put_sf)."""
+    R, rng, out = ref(), np.random.default_rng(2026100402), {}
+    for tag, (prb, cid, area, sf_idx, ftype, coef, alg) in {"app": (25, 2, 9, 1, 1, 0.1, 1), "refs": (6, 1, 200, 7, 2, 0.0, 0), "tri": (50, 3, 31, 3, 1, 0.2, 0)}.items():
+        nre, n = 12 * prb, 14 * 12 * prb
+        cell = OrcCell(cid, prb, 1, True)
+        q = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+        assert R.srslte_chest_dl_set_mbsfn_area_id(q, area) == 0
+        g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+        assert oracle().orc_mbsfn_put_sf(C.byref(cell), sf_idx, 0, area, p(g)) == 0
+        k, l = np.arange(n) % nre, np.arange(n) // nre
+        h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+        grid = acopy((g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        rc, res, sf = RefChestCfg(), RefChestRes(), RefDlSfCfg()
+        rc.noise_alg, rc.filter_type, rc.interpolate_subframe, rc.mbsfn_area_id = alg, ftype, True, area
+        rc.filter_coef[0] = coef
+        ce = aligned(2 * n, np.float32)
+        res.ce[0][0] = ce.ctypes.data
+        sf.tti, sf.sf_type = sf_idx, 1
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        out[tag + "_meta"] = np.array([prb, cid, area, sf_idx, ftype, alg], np.int32)
+        out[tag + "_coef"] = np.array([coef], np.float32)
+        out[tag + "_grid"] = grid.view(np.complex64).copy()
+        out[tag + "_ce"] = ce.view(np.complex64)[:12 * nre].copy()
+        out[tag + "_noise"] = np.array([res.noise_estimate], np.float32)
+        R.srslte_chest_dl_free(q)
+    np.savez_compressed(os.path.join(OUT, "chest_mbsfn.npz"), **out)
+    print("chest_mbsfn.npz", os.path.getsize(os.path.join(OUT, "chest_mbsfn.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if "--mbsfn-only" in sys.argv:
+        chest_mbsfn()
+        sys.exit(0)
     if "--pdsch-only" in sys.argv:
         pdsch_function()
         sys.exit(0)
@@ -304,3 +340,4 @@ if __name__ == "__main__":
         main()
     extra()
     pdsch_function()
+    chest_mbsfn()

@@ -172,3 +172,22 @@ def test_pdsch_function_golden(hp, tag):
         if ok[0]:
             assert np.array_equal(tb[0], g["%s_tb_%d" % (tag, n)]) and np.array_equal(tb[0][:tbs // 8], g["%s_data_%d" % (tag, n)])
     rx.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["app", "refs", "tri"])
+def test_chest_mbsfn_golden(hp, tag):
+    """Device MBSFN estimator vs outputs of the reference's srslte_chest_dl_estimate_cfg (tests/gen_golden.py:chest_mbsfn)."""
+    g = load("chest_mbsfn.npz")
+    prb, cid, area, sf_idx, ftype, alg = [int(x) for x in g[tag + "_meta"]]
+    hc = hp.ChestDlCfg()
+    hc.noise_alg, hc.filter_type, hc.interpolate_subframe, hc.mbsfn_area_id = alg, ftype, 1, area
+    hc.filter_coef[0] = float(g[tag + "_coef"][0])
+    est = hp.ChestDl(cid, prb, 1)
+    assert est.set_mbsfn_area_id(area) == 0
+    rc, ce, noise = est.estimate_mbsfn(g[tag + "_grid"], sf_idx, hc, 1)
+    want = g[tag + "_ce"]
+    assert rc == 0 and np.abs(ce[0, 0, 0, :want.size] - want).max() <= 1e-4 * max(np.abs(want).max(), np.sqrt((np.abs(want) ** 2).mean()))
+    if alg == 0:
+        assert abs(noise[0, 0, 0] - float(g[tag + "_noise"][0])) <= 1e-4 * noise[0, 0, 0]
+    est.free()

@@ -231,3 +231,21 @@ def test_pdsch_function_golden(tag):
         assert bool(g["%s_ok_%d" % (tag, n)][0]) == r["ok"], n
         if r["ok"]:
             assert np.array_equal(r["tb"], g["%s_tb_%d" % (tag, n)]) and np.array_equal(r["tb"][:tbs // 8], g["%s_data_%d" % (tag, n)])
+
+
+@pytest.mark.parametrize("tag", ["app", "refs", "tri"])
+def test_chest_mbsfn_golden(tag):
+    """Oracle vs outputs of the reference's srslte_chest_dl_estimate_cfg on MBSFN subframes (tests/gen_golden.py:chest_mbsfn)."""
+    g = np.load(os.path.join(G, "chest_mbsfn.npz"))
+    prb, cid, area, sf_idx, ftype, alg = [int(x) for x in g[tag + "_meta"]]
+    orc = oracle()
+    orc.orc_chest_dl_mbsfn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    cell, oc = OrcCell(cid, prb, 1, True), OrcChestCfg()
+    oc.noise_alg, oc.filter_type, oc.interpolate_subframe = alg, ftype, True
+    oc.filter_coef[0] = float(g[tag + "_coef"][0])
+    grid, ce, nz = np.ascontiguousarray(g[tag + "_grid"]), np.zeros(14 * 12 * prb, np.complex64), C.c_float(0)
+    assert orc.orc_chest_dl_mbsfn(C.byref(cell), sf_idx, C.byref(oc), area, 0, p(grid), p(ce), C.byref(nz)) == 0
+    want = g[tag + "_ce"]
+    assert np.abs(ce[:want.size] - want).max() <= 1e-4 * max(np.abs(want).max(), np.sqrt((np.abs(want) ** 2).mean()))
+    if alg == 0:
+        assert abs(nz.value - float(g[tag + "_noise"][0])) <= 1e-4 * nz.value
