@@ -43,9 +43,11 @@ OBJS := $(patsubst $(RLIB)/src/phy/%.c,$(OBJ)/%.o,$(REF_C)) $(patsubst $(RLIB)/s
 .PHONY: ref all clean
 ref: $(OUT)/libsrslte_ref.so
 
+# the umbrella-header handling only for the translation units that include that header: force-including debug.h into the others
+# would define DEBUG, which the Viterbi sources test with #ifdef to enable their metric dumps
 $(OBJ)/%.o: $(RLIB)/src/phy/%.c
 	@mkdir -p $(dir $@)
-	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) -c $< -o $@
+	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) -c $< -o $@
 
 $(OBJ)/%.o: $(RLIB)/src/phy/%.cpp
 	@mkdir -p $(dir $@)
@@ -54,3 +56,9 @@ $(OBJ)/%.o: $(RLIB)/src/phy/%.cpp
 $(OUT)/libsrslte_ref.so: $(OBJS) ref_exports.map
 	g++ -shared -o $@ $(OBJS) -Wl,--gc-sections -Wl,--version-script=ref_exports.map -lm -lpthread
 	@if nm -D --undefined-only $@ | grep -q 'srslte_\|fftw'; then echo "ERROR: unresolved reference symbols:"; nm -D --undefined-only $@ | grep 'srslte_\|fftw'; rm -f $@; exit 1; fi
+
+# refdrv.c: this repo's own C driver over the reference library (the reference's callers' sequences from a frequency-domain grid on;
+# see its header). Compiled against the reference headers, linked to libsrslte_ref.so.
+ref: $(OUT)/librefdrv.so
+$(OUT)/librefdrv.so: refdrv.c $(OUT)/libsrslte_ref.so
+	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) -shared -o $@ refdrv.c -L$(OUT) -lsrslte_ref -Wl,-rpath,'$$ORIGIN' -lm
