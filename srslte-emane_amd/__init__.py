@@ -157,6 +157,16 @@ class DevBuf:
             pass
 
 
+class DevView(DevBuf):
+    """Device memory owned by somebody else (e.g. a torch tensor), seen through the same interface."""
+
+    def __init__(self, ptr, nbytes):
+        self.nbytes, self.ptr = int(nbytes), int(ptr)
+
+    def free(self):
+        self.ptr = None
+
+
 def sync():
     _check(lib().srslte_hip_sync(), "sync")
 
@@ -422,7 +432,7 @@ class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
     def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False, nof_rx=1,
-                 nof_ports=1, csi=False, power_scale=False, p_a=0.0):
+                 nof_ports=1, csi=False, power_scale=False, p_a=0.0, out_ptrs=None):
         self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
                            1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0, 1 if power_scale else 0, p_a)
         self.nof_rx = nof_rx
@@ -432,7 +442,10 @@ class DlRx:
         self.tbs, self.max_batch = tbs, max_batch
         self.tb_stride = (tbs // 8 + 6 + 15) & ~15
         self.sf_len = 15 * symbol_sz(nof_prb)
-        self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+        if out_ptrs is None:
+            self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+        else:  # caller-owned device memory (e.g. a torch tensor that a collective reads): (tb pointer, ok pointer)
+            self.d_tb, self.d_ok = DevView(out_ptrs[0], self.tb_stride * max_batch), DevView(out_ptrs[1], max_batch)
         # per-subframe stride of the LLR buffer e (debug buffer 4)
         self.e_stride = (max(self.nof_re(s) for s in (0, 1, 5)) * {1: 2, 2: 4, 3: 6, 4: 8}[mod] + 15) & ~15
 
