@@ -1,0 +1,55 @@
+# oracle/ref_hip.mk — TEST INFRASTRUCTURE ONLY: the link-time drop-in of INTEGRATION.md §1, performed.
+#
+# Compiles, from the sources WHERE THEY LIE under $(REF) (never copied), the reference's lib/src/phy MINUS the translation units
+# that libsrslte_phy_hip.so replaces into _ref/hip/libsrslte_upper.a, and the reference's own test programs
+# against it, linked with ../srslte-emane_amd/csrc/libsrslte_phy_hip.so in place of those translation units and of FFTW:
+#   lib/test/phy/phy_dl_test.c, phch/test/{pdsch_test,pusch_test,pdsch_pdcch_file_test,pcfich_file_test,pbch_file_test,pmch_file_test}.c,
+#   fec/test/{turbodecoder_test,turbocoder_test}.c, dft/test/ofdm_test.c, utils/test/dft_test.c, ch_estimation/test/chest_test_dl.c,
+#   modem/test/{soft_demod_test,modem_test}.c
+# tests/test_gpu_dropin.py runs them on the GPU box with the reference's CTest arguments and asserts exit code 0.
+# Nothing is stubbed: the same flags / force-include handling of the cmake-generated version.h as ref.mk.
+#
+# Output only into oracle/_ref/hip/ (git-ignored, travels with gpurun).
+include ref.mk
+
+HIPLIB   := ../srslte-emane_amd/csrc
+HOUT     := $(OUT)/hip
+HOBJ     := $(HOUT)/obj
+
+# translation units served by libsrslte_phy_hip.so
+REPLACED := dft/dft_fftw.c dft/ofdm.c dft/dft_precoding.c fec/turbodecoder.c fec/turbodecoder_gen.c fec/turbodecoder_sse.c fec/turbocoder.c \
+            fec/cbsegm.c fec/tc_interl_lte.c ch_estimation/chest_dl.c modem/demod_soft.c
+# channel/: only the AWGN generator the tests use (the fading / delay / HST / RLF emulators are stimulus tools outside the path)
+UP_DIRS  := agc ch_estimation common dft enb fec io mimo modem phch resampling scrambling sync ue utils
+UP_C     := $(filter-out %viterbi37_neon.c $(addprefix $(RLIB)/src/phy/,$(REPLACED)),$(foreach d,$(UP_DIRS),$(wildcard $(RLIB)/src/phy/$(d)/*.c)) \
+            $(RLIB)/src/phy/channel/ch_awgn.c $(RLIB)/src/phy/channel/gauss.c)
+UP_OBJS  := $(patsubst $(RLIB)/src/phy/%.c,$(HOBJ)/%.o,$(UP_C)) $(HOBJ)/utils/random.o
+
+TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/phy/phch/test/pusch_test lib/src/phy/phch/test/pdsch_pdcch_file_test \
+            lib/src/phy/phch/test/pcfich_file_test lib/src/phy/phch/test/pbch_file_test lib/src/phy/phch/test/pmch_file_test \
+            lib/src/phy/fec/test/turbodecoder_test lib/src/phy/fec/test/turbocoder_test lib/src/phy/dft/test/ofdm_test lib/src/phy/utils/test/dft_test \
+            lib/src/phy/ch_estimation/test/chest_test_dl lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test
+TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
+
+.PHONY: ref_hip
+ref_hip: $(TEST_BIN)
+
+$(HOBJ)/%.o: $(RLIB)/src/phy/%.c
+	@mkdir -p $(dir $@)
+	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) -c $< -o $@
+
+$(HOBJ)/utils/random.o: $(RLIB)/src/phy/utils/random.cpp
+	@mkdir -p $(dir $@)
+	g++ -std=c++11 $(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS)) -c $< -o $@
+
+$(HOUT)/libsrslte_upper.a: $(UP_OBJS)
+	@rm -f $@
+	ar rcs $@ $(UP_OBJS)
+
+# every test program includes the umbrella header
+define TEST_RULE
+$(HOUT)/$(notdir $(1)): $(REF)/$(1).c $(HOUT)/libsrslte_upper.a $(HIPLIB)/libsrslte_phy_hip.so
+	gcc -std=c99 $$(REF_FLAGS) $$(FORCEINC) -I$(REF)/$(dir $(1)) $$< -o $$@ $(HOUT)/libsrslte_upper.a -L$(HIPLIB) -lsrslte_phy_hip \
+	    -Wl,-rpath,'$$$$ORIGIN/../../../srslte-emane_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lstdc++ -lm -lpthread
+endef
+$(foreach t,$(TESTS),$(eval $(call TEST_RULE,$(t))))

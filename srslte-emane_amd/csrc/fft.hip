@@ -307,13 +307,45 @@ __global__ FFT_BOUNDS void dft_batch_kernel(const cf32* __restrict__ in, cf32* _
       [&](int n, cf32 v) { dst[n] = make_float2(v.x * scale, v.y * scale); });
 }
 
+// Any other length (a prime factor beyond 5, or N > 2048): the DFT sum itself, one thread per output bin, double accumulation.
+// FFTW plans every N (dft_fftw.c:93-117) and callers outside the hot path rely on it (PRACH: N_zc = 839 / 139, prach.c; the PSS / SSS
+// correlators' conv_fft_cc lengths; utils/test/dft_test.c -N 255): they keep working through the boundary, at O(N^2) cost.
+constexpr int DIRECT_CHUNK = 1024;
+__global__ __launch_bounds__(256) void dft_direct_kernel(const cf32* __restrict__ in, cf32* __restrict__ out, int N, int idist, int odist, float sgn,
+                                                         float scale, const cf32* __restrict__ tw)
+{
+  __shared__ cf32 xs[DIRECT_CHUNK];
+  const cf32*     src = in + (size_t)blockIdx.y * idist;
+  cf32*           dst = out + (size_t)blockIdx.y * odist;
+  const int       k   = blockIdx.x * blockDim.x + threadIdx.x;
+  double          ar = 0.0, ai = 0.0;
+  int             idx = 0; // (n * k) mod N, kept incrementally
+  const int       kk  = k < N ? k : 0;
+  for (int n0 = 0; n0 < N; n0 += DIRECT_CHUNK) {
+    const int len = min(DIRECT_CHUNK, N - n0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < len; i += blockDim.x) xs[i] = src[n0 + i];
+    __syncthreads();
+    for (int i = 0; i < len; i++) {
+      const cf32   w  = tw[idx];
+      const double wr = w.x, wi = -sgn * w.y; // tw = exp(-j 2 pi k / N); sgn = -1 forward, +1 backward
+      ar += (double)xs[i].x * wr - (double)xs[i].y * wi;
+      ai += (double)xs[i].x * wi + (double)xs[i].y * wr;
+      idx += kk;
+      if (idx >= N) idx -= N;
+    }
+  }
+  if (k < N) dst[k] = make_float2((float)(ar * scale), (float)(ai * scale));
+}
+
 // ---------------------------------------------------------------- host side: twiddle cache
 struct TwEntry {
   FftFactors f;
   cf32*      d_tw;
 };
 std::mutex             g_tw_mutex;
-std::map<long, TwEntry> g_tw_cache; // key: device*65536 + N
+std::map<long, TwEntry> g_tw_cache; // key: device * 2^20 + N
+constexpr int           FFT_MAX_N = 1 << 17; // prach.c plans up to 12 x 2048 x 4 points
 
 static int fft_threads(int N) { return N >= 1024 ? 128 : 64; }
 
@@ -330,7 +362,8 @@ int factorize(int N, FftFactors* f)
   while (n % 3 == 0 && f->nf < 8) { f->radix[f->nf++] = 3; n /= 3; }
   while (n % 5 == 0 && f->nf < 8) { f->radix[f->nf++] = 5; n /= 5; }
   f->inplace = fft_is_fixed(N) ? 1 : 0;
-  return n == 1 ? 0 : -1;
+  if (n != 1 || N > 2048) f->nf = 0; // no LDS plan: dft_direct_kernel
+  return 0;
 }
 
 static size_t fft_lds_bytes(const FftFactors& f) { return (f.inplace ? 1 : 2) * sizeof(cf32) * (size_t)(f.N + f.N / 16 + 2); }
@@ -353,25 +386,22 @@ static size_t fft_lds_bytes(const FftFactors& f) { return (f.inplace ? 1 : 2) * 
 
 int fft_get_plan(int N, FftFactors* f, const cf32** d_tw)
 {
-  if (N < 2 || N > 2048) {
-    fprintf(stderr, "[srslte_hip] unsupported DFT size %d (2..2048, factors 2/3/5)\n", N);
+  if (N < 1 || N > FFT_MAX_N) {
+    fprintf(stderr, "[srslte_hip] unsupported DFT size %d (1..%d)\n", N, FFT_MAX_N);
     return SRSLTE_ERROR_INVALID_INPUTS;
   }
   int dev = 0;
   HIP_TRY(hipGetDevice(&dev));
   std::lock_guard<std::mutex> lk(g_tw_mutex); // planning is serialised, like dft_fftw.c:42
-  auto it = g_tw_cache.find((long)dev * 65536 + N);
+  auto it = g_tw_cache.find(((long)dev << 20) + N);
   if (it == g_tw_cache.end()) {
     TwEntry e;
-    if (factorize(N, &e.f)) {
-      fprintf(stderr, "[srslte_hip] DFT size %d has a prime factor other than 2, 3, 5\n", N);
-      return SRSLTE_ERROR_INVALID_INPUTS;
-    }
+    factorize(N, &e.f);
     std::vector<cf32> tw(N);
     for (int k = 0; k < N; k++) tw[k] = make_float2((float)cos(2.0 * M_PI * k / N), (float)-sin(2.0 * M_PI * k / N));
     HIP_TRY(hipMalloc((void**)&e.d_tw, sizeof(cf32) * N));
     HIP_TRY(hipMemcpy(e.d_tw, tw.data(), sizeof(cf32) * N, hipMemcpyHostToDevice));
-    it = g_tw_cache.emplace((long)dev * 65536 + N, e).first;
+    it = g_tw_cache.emplace(((long)dev << 20) + N, e).first;
   }
   *f    = it->second.f;
   *d_tw = it->second.d_tw;
@@ -544,6 +574,12 @@ extern "C" int srslte_hip_dft_batch(const void* d_in, void* d_out, int N, int ho
   const cf32* d_tw;
   int         r = fft_get_plan(N, &f, &d_tw);
   if (r) return r;
+  if (f.nf == 0) {
+    hipLaunchKernelGGL(dft_direct_kernel, dim3((N + 255) / 256, howmany), dim3(256), 0, (hipStream_t)stream, (const cf32*)d_in, (cf32*)d_out, N, idist, odist,
+                       forward ? -1.0f : 1.0f, scale, d_tw);
+    LAUNCH_CHECK();
+    return SRSLTE_SUCCESS;
+  }
   FFT_DISPATCH(dft_batch_kernel, N, dim3(howmany), dim3(fft_threads(N)), fft_lds_bytes(f), (hipStream_t)stream, (const cf32*)d_in,
                (cf32*)d_out, f, idist, odist, forward ? -1.0f : 1.0f, scale, d_tw);
   LAUNCH_CHECK();

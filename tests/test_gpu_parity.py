@@ -81,6 +81,20 @@ def test_ofdm_rx_tx(hp, prb, norm, shift):
     rx.free()
 
 
+@pytest.mark.parametrize("N", [1, 7, 139, 255, 839, 2049, 4096])
+def test_dft_any_length(hp, N):
+    """FFTW plans every length (dft_fftw.c:93-117) and callers beyond the hot path use that (prach.c: 839 / 139 point sequences,
+    dft_test -N 255): lengths without a 2/3/5 plan or above 2048 are served by the direct-sum kernel."""
+    rng = np.random.default_rng(N)
+    x = (rng.standard_normal((2, N)) + 1j * rng.standard_normal((2, N))).astype(np.complex64)
+    for fwd in (True, False):
+        y = hp.dft(x, forward=fwd)
+        ref = np.zeros_like(x)
+        for i in range(2):
+            oracle().orc_dft_exact(p(x[i]), p(ref[i]), N, 1 if fwd else 0)
+        assert_close_c(y, ref, "dft N=%d fwd=%s" % (N, fwd))
+
+
 def test_dft_precoding_invalid(hp):
     rc, _ = hp.dft_precoding(np.zeros(12 * 7, np.complex64), 7, 1)
     assert rc == hp.SRSLTE_ERROR  # dft_precoding.c:104-107

@@ -1104,3 +1104,41 @@ def test_ri_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, 
             assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
         n_ok += r["ok"]
     assert n_ok > 0
+
+
+def test_reference_cdd_predecoder_on_a_noise_free_channel():
+    """Fact about the reference, recorded because tests/test_gpu_dropin.py leaves `phy_dl_test -t 3` out: the reference's own compiled
+    large-delay-CDD predecoder (mimo/precoding.c:1067-1102 -> srslte_predecoding_ccd_2x2_mmse[_csi], :915-1065), fed what that test
+    feeds it - 2 layers, the "perfect crossed channel" y0 = x0 + x1, y1 = x0 - x1 (phy_dl_test.c:543-555), exact channel estimates and
+    a vanishing noise estimate - returns NaN, while the spatial-multiplexing predecoder on the same inputs is exact. None of this code
+    is replaced by libsrslte_phy_hip.so."""
+    R = ref()
+    R.srslte_predecoding_type.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+    R.srslte_precoding_type.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    n, rng = 256, np.random.default_rng(0)
+
+    def cbuf(v=None):
+        b = aligned(2 * n, np.float32)
+        if v is not None:
+            b.view(np.complex64)[:] = v
+        return b
+
+    x = [cbuf((rng.choice([-1, 1], n) + 1j * rng.choice([-1, 1], n)) / np.sqrt(2)) for _ in range(2)]
+    res = {}
+    for scheme in (2, 3):  # SRSLTE_TXSCHEME_SPATIALMUX, SRSLTE_TXSCHEME_CDD (phy_common.h:233-236)
+        y = [cbuf(), cbuf()]
+        xp, yp = (C.c_void_p * 4)(x[0].ctypes.data, x[1].ctypes.data, 0, 0), (C.c_void_p * 4)(y[0].ctypes.data, y[1].ctypes.data, 0, 0)
+        R.srslte_precoding_type(xp, yp, 2, 2, 1, n, 1.0, scheme)
+        t0, t1 = y[0].view(np.complex64).copy(), y[1].view(np.complex64).copy()
+        r = [cbuf(t0 + t1), cbuf(t0 - t1)]
+        h = [[cbuf(np.ones(n)), cbuf(np.ones(n))], [cbuf(np.ones(n)), cbuf(-np.ones(n))]]  # h[port][rx antenna]
+        hp = ((C.c_void_p * 4) * 4)()
+        for i in range(2):
+            for j in range(2):
+                hp[i][j] = h[i][j].ctypes.data
+        out = [cbuf(), cbuf()]
+        op, rp = (C.c_void_p * 4)(out[0].ctypes.data, out[1].ctypes.data, 0, 0), (C.c_void_p * 4)(r[0].ctypes.data, r[1].ctypes.data, 0, 0)
+        assert R.srslte_predecoding_type(rp, hp, op, None, 2, 2, 2, 1, n, scheme, 1.0, 1e-12) == 0
+        res[scheme] = max(np.abs(out[k].view(np.complex64) - x[k].view(np.complex64)).max() for k in range(2))
+    assert res[2] < 1e-3
+    assert np.isnan(res[3])
