@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --force-device 0 rehearses N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="use this GPU for every rank (rehearsal only)")
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
+    ap.add_argument("--grants", action="store_true", help="run the same workload through srslte_hip_dl_rx_batch_grants: one grant per subframe "
+                    "(here 128 equal full-band MCS-28 grants), RE lists and scrambling sequences made on the device from the grants on every call")
     ap.add_argument("--cpu-worker", nargs=6, metavar=("NPY", "LO", "HI", "SECONDS", "CELL", "RNTI"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
@@ -228,9 +230,20 @@ def main():
     h_stage = [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)] if (world > 1 and not on_device) else None
     h_out = [torch.zeros((world, res_bytes), dtype=torch.uint8).pin_memory() for _ in range(nstreams)] if rank == 0 else None
 
+    grant_arr = None
+    if args.grants:
+        grant_arr = (pkg.DlGrant * B)(*[pkg.DlGrant.make(NOF_PRB, MOD, TBS, ue["rnti"], cfi=CFI) for _ in range(B)])
+
     def step(k, src, ev=None):
         s = k % nstreams
-        for stage in range(6):
+        if grant_arr is not None:
+            if ev is not None:
+                L.srslte_hip_event_record(ev[0], streams[s])
+                L.srslte_hip_event_record(ev[1], streams[s])
+            rc = L.srslte_hip_dl_rx_batch_grants(rxs[s].h, src.data_ptr(), 0, B, grant_arr, rxs[s].d_tb.ptr, rxs[s].tb_stride, rxs[s].d_ok.ptr, streams[s])
+            if rc:
+                raise RuntimeError("dl_rx_batch_grants failed: %d" % rc)
+        for stage in range(6 if grant_arr is None else 0):
             if ev is not None and stage == 4:
                 L.srslte_hip_event_record(ev[0], streams[s])
             rc = rxs[s].stage(stage, src.data_ptr(), 0, B, streams[s])
@@ -299,7 +312,7 @@ def main():
     checks = [check_instance(s) for s in range(nstreams)]
     good, wrong, rec0 = checks[0]
     instances_agree = all(np.array_equal(c[2], rec0) for c in checks)  # same input on every instance: same records
-    iters = rx.debug(6, np.uint32, B * 13)
+    iters = rx.debug(13 if args.grants else 6, np.uint32, B * 13)
     good_all, wrong_all, n_all, it_all, agree_all = sharding.reduce_counts([good, wrong, B, int(iters.sum()), int(instances_agree)], dist if world > 1 else None, cdev)
     # rank 0: the host copy of the gathered records holds every rank's record in rank order
     gather_ok = None
@@ -319,7 +332,7 @@ def main():
             step(k, d_iq_full)
         ftimes, _ = timed_repeats(d_iq_full, args.min_timed_s / 2, False)
         barrier()
-        it_full = sharding.reduce_counts([int(rx.debug(6, np.uint32, B * 13).sum())], dist if world > 1 else None, cdev)[0]
+        it_full = sharding.reduce_counts([int(rx.debug(13 if args.grants else 6, np.uint32, B * 13).sum())], dist if world > 1 else None, cdev)[0]
         full = {"snr_db": args.snr_full, "value": round(world * B * args.steps / float(np.median(ftimes)), 1),
                 "avg_siso_passes_per_cb": round(it_full / (world * B * 13), 3), "repeats": len(ftimes)}
         for k in range(nstreams):  # back to the headline input for what follows
@@ -465,6 +478,7 @@ def main():
                    "avg_siso_passes_per_cb": round(passes, 3),
                    "sharding": "one UE per GPU; one gather of TBs + CRC flags per batch to rank 0 (%s), inside the timed region" % ("RCCL" if on_device else args.backend)
                    if world > 1 else "one UE per GPU; single GPU: results copied to host inside the timed region",
+                   "entry_point": "srslte_hip_dl_rx_batch_grants (a grant per subframe)" if args.grants else "srslte_hip_dl_rx_stage x 6 (one fixed grant)",
                    "streams": nstreams, "pipeline_instances_verified": nstreams if agree_all == world else 0, "results_on_host_verified": gather_ok,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(world * B * args.steps / max(times), 1),
                    "repeat_max_value": round(world * B * args.steps / min(times), 1), "full_iter": full,

@@ -232,6 +232,22 @@ int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_
  * ue_dl.c:375-397; SURVEY §8d cfg5 feeds grids) */
 int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                                 uint8_t* d_tb_ok, void* stream);
+/* A new grant every subframe, as srslte_pdsch_decode takes it (pdsch.c:833-997 with a srslte_pdsch_grant_t per call, pdsch_cfg.h:38-50):
+ * subframe b of the batch is received with grants[b] (host array). prb_mask[s]: bit n = srslte_pdsch_grant_t.prb_idx[s][n], the PRBs of
+ * slot s (any subset; the two slots may differ, as with distributed virtual resource blocks), walked as srslte_pdsch_cp does
+ * (pdsch.c:81-206). tbs = 0: no transport block in that subframe (tb_ok = 0). rv / new_data as srslte_hip_dl_rx_batch_harq, per subframe.
+ * cfg.tbs of the object bounds every grant's tbs; cfg.mod / cfg.rnti / cfg.cfi are not used. Single-port cells, 16-bit LLRs. */
+typedef struct {
+  uint32_t prb_mask[2][4];
+  int      mod;      /* srslte_mod_t: 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM */
+  uint32_t tbs;      /* bits */
+  uint32_t rv;
+  uint32_t cfi;
+  uint16_t rnti;
+  int      new_data; /* != 0: new transport block in HARQ slot b (soft buffer overwritten); 0: retransmission (combined) */
+} srslte_hip_dl_grant_t;
+int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
+                                  uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,

@@ -12,19 +12,31 @@
 int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const uint8_t* prb_mask, uint32_t* idx)
 { /* pdsch.c:81-206 expressed per RE: symbol-major, PRB ascending, skipping CRS and (FDD) the central
      72 sub-carriers of PSS/SSS symbols (slot 0, last two symbols, sf 0/5) and PBCH symbols (slot 1, l<4, sf 0).
-     For odd nof_prb the half-PRB handling of pdsch.c:167-188 is the same per-RE rule. */
+     prb_mask: NULL = every PRB in both slots, else [2][nof_prb] bytes = srslte_pdsch_grant_t.prb_idx[s][n] (pdsch.c:119).
+     For odd nof_prb the sync region cuts PRBs nof_prb/2-3 and nof_prb/2+3 in half (pdsch.c:167-188): the same per-RE rule, with one
+     upstream quirk kept: in those half PRBs the CRS position comes from the variable `offset`, which is only assigned in the branch
+     of whole PRBs (pdsch.c:147-157) - so it holds what the last CRS-bearing whole PRB before it in the loop left there (0 if none). */
   uint32_t P = cell->nof_prb, nre = 12 * P, nsymb = cell->cp_norm ? 7 : 6, n = 0;
   uint32_t nof_refs = cell->nof_ports == 1 ? 2 : 4;
+  uint32_t offset_var = 0; /* the reference's `offset`, pdsch.c:91 */
   for (uint32_t s = 0; s < 2; s++) {
     for (uint32_t l = (s == 0 ? lstart : 0); l < nsymb; l++) {
       bool has_ref = (l == 1 && cell->nof_ports == 4) || l == 0 || l == nsymb - 3; /* phy_common.h:139-141 */
       uint32_t offset = nof_refs == 2 ? (l == 0 ? cell->id % 6 : (cell->id + 3) % 6) : cell->id % 3;
       bool sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= nsymb - 2) || (s == 1 && sf_idx == 0 && l < 4);
       for (uint32_t p = 0; p < P; p++) {
-        if (prb_mask && !prb_mask[p]) continue;
+        if (prb_mask && !prb_mask[s * P + p]) continue;
+        bool centre = p >= P / 2 - 3 && p < P / 2 + 3 + (P % 2);
+        bool skip   = centre && sync;
+        uint32_t off_used = offset;
+        if (!skip) {
+          if (has_ref) offset_var = offset;
+        } else {
+          off_used = offset_var;
+        }
         for (uint32_t k = 12 * p; k < 12 * p + 12; k++) {
           if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) continue;
-          if (has_ref && (k % (12 / nof_refs)) == offset % (12 / nof_refs)) continue;
+          if (has_ref && (k % (12 / nof_refs)) == off_used % (12 / nof_refs)) continue;
           idx[n++] = (s * nsymb + l) * nre + k;
         }
       }

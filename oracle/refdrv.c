@@ -258,6 +258,83 @@ int refdrv_dl_set_grant(refdrv_dl_t* q, uint32_t tti, uint32_t cfi, uint16_t rnt
   return 0;
 }
 
+/* Replace the PRB allocation of the current grant by arbitrary per-slot masks (srslte_pdsch_grant_t.prb_idx[s][n], what
+ * srslte_ra_dl_grant_to_grant_prb_allocation fills for type 0 / 1 / 2-localized / 2-distributed allocations, ra_dl.c) and recompute
+ * nof_re / nof_bits as srslte_ra_dl_dci_to_grant does (ra_dl.c:645). Transport block size and modulation stay those of the MCS and
+ * PRB count the grant was made with. Returns nof_re. */
+int refdrv_dl_set_prb_masks(refdrv_dl_t* q, const uint8_t* slot0, const uint8_t* slot1)
+{
+  for (uint32_t n = 0; n < q->cell.nof_prb; n++) {
+    q->pdsch_cfg.grant.prb_idx[0][n] = slot0[n] != 0;
+    q->pdsch_cfg.grant.prb_idx[1][n] = slot1[n] != 0;
+  }
+  srslte_ra_dl_compute_nof_re(&q->cell, &q->sf, &q->pdsch_cfg.grant);
+  return (int)q->pdsch_cfg.grant.nof_re;
+}
+
+/* what the current grant says: PRB masks of both slots, modulation (srslte_mod_t), TBS, nof_re, nof_bits, rv */
+void refdrv_dl_grant_info(refdrv_dl_t* q, uint8_t* slot0, uint8_t* slot1, int* mod, int* tbs, uint32_t* nof_re, uint32_t* nof_bits, int* rv)
+{
+  for (uint32_t n = 0; n < q->cell.nof_prb; n++) {
+    slot0[n] = q->pdsch_cfg.grant.prb_idx[0][n];
+    slot1[n] = q->pdsch_cfg.grant.prb_idx[1][n];
+  }
+  *mod      = (int)q->pdsch_cfg.grant.tb[0].mod;
+  *tbs      = q->pdsch_cfg.grant.tb[0].tbs;
+  *nof_re   = q->pdsch_cfg.grant.nof_re;
+  *nof_bits = q->pdsch_cfg.grant.tb[0].nof_bits;
+  *rv       = q->pdsch_cfg.grant.tb[0].rv;
+}
+
+/* type-2 allocation (format 1A): localized or distributed virtual resource blocks, L_crb blocks from RB_start (ra_dl.c:206-290) */
+int refdrv_dl_set_grant_type2(refdrv_dl_t* q, uint32_t tti, uint32_t cfi, uint16_t rnti, uint32_t L_crb, uint32_t RB_start, int distributed, int n_gap2,
+                              uint32_t mcs, int rv, int* tbs, uint32_t* nof_re)
+{
+  bzero(&q->sf, sizeof(q->sf));
+  q->sf.tti = tti;
+  q->sf.cfi = cfi;
+  bzero(&q->dci_dl, sizeof(q->dci_dl));
+  q->dci_dl.rnti              = rnti;
+  q->dci_dl.format            = SRSLTE_DCI_FORMAT1A;
+  q->dci_dl.alloc_type        = SRSLTE_RA_ALLOC_TYPE2;
+  q->dci_dl.type2_alloc.mode  = distributed ? SRSLTE_RA_TYPE2_DIST : SRSLTE_RA_TYPE2_LOC;
+  q->dci_dl.type2_alloc.n_gap = n_gap2 ? SRSLTE_RA_TYPE2_NG2 : SRSLTE_RA_TYPE2_NG1;
+  q->dci_dl.type2_alloc.riv   = srslte_ra_type2_to_riv(L_crb, RB_start, q->cell.nof_prb);
+  q->dci_dl.tb[0].mcs_idx     = mcs;
+  q->dci_dl.tb[0].rv          = rv;
+  SRSLTE_DCI_TB_DISABLE(q->dci_dl.tb[1]);
+  if (srslte_ra_dl_dci_to_grant(&q->cell, &q->sf, SRSLTE_TM1, false, &q->dci_dl, &q->pdsch_cfg.grant)) return -1;
+  q->pdsch_cfg.rnti = rnti;
+  if (tbs) *tbs = q->pdsch_cfg.grant.tb[0].tbs;
+  if (nof_re) *nof_re = q->pdsch_cfg.grant.nof_re;
+  return 0;
+}
+
+/* srslte_pdsch_encode on the current grant (eNB side of the same object family: needs its own srslte_pdsch_t in eNB mode): used to
+ * pin the oracle's transmitter for arbitrary allocations. grid_out: the port-0 resource grid, zero outside the PDSCH. */
+int refdrv_dl_encode_pdsch(refdrv_dl_t* q, const uint8_t* data, cf_t* grid_out)
+{
+  static srslte_pdsch_t          tx;
+  static srslte_softbuffer_tx_t  sb;
+  static bool                    init = false;
+  static uint32_t                tx_prb = 0, tx_id = 0xffffffff;
+  if (!init || tx_prb != q->cell.nof_prb || tx_id != q->cell.id) {
+    if (init) {
+      srslte_pdsch_free(&tx);
+      srslte_softbuffer_tx_free(&sb);
+    }
+    if (srslte_pdsch_init_enb(&tx, q->cell.nof_prb) || srslte_pdsch_set_cell(&tx, q->cell) || srslte_softbuffer_tx_init(&sb, q->cell.nof_prb)) return -1;
+    init = true; tx_prb = q->cell.nof_prb; tx_id = q->cell.id;
+  }
+  srslte_pdsch_cfg_t cfg = q->pdsch_cfg;
+  cfg.softbuffers.tx[0]  = &sb;
+  srslte_softbuffer_tx_reset_tbs(&sb, (uint32_t)cfg.grant.tb[0].tbs);
+  cf_t*    grids[SRSLTE_MAX_PORTS] = {grid_out, NULL, NULL, NULL};
+  uint8_t* d[SRSLTE_MAX_CODEWORDS] = {(uint8_t*)data, NULL};
+  bzero(grid_out, sizeof(cf_t) * SRSLTE_SF_LEN_RE(q->cell.nof_prb, q->cell.cp));
+  return srslte_pdsch_encode(&tx, &q->sf, &cfg, d, grids);
+}
+
 /* channel estimate only (srslte_chest_dl_estimate_cfg) for the subframe set by refdrv_dl_set_grant */
 int refdrv_dl_chest(refdrv_dl_t* q) { return srslte_chest_dl_estimate_cfg(&q->chest, &q->sf, &q->chest_cfg, q->sf_symbols, &q->chest_res); }
 

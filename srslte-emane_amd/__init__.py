@@ -44,6 +44,23 @@ class DlRxCfg(C.Structure):
                 ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int), ("power_scale", C.c_int), ("p_a", C.c_float)]
 
 
+class DlGrant(C.Structure):
+    """srslte_hip_dl_grant_t (phy_hip.h): the per-subframe part of srslte_pdsch_cfg_t / srslte_pdsch_grant_t."""
+    _fields_ = [("prb_mask", (C.c_uint32 * 4) * 2), ("mod", C.c_int), ("tbs", C.c_uint32), ("rv", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16),
+                ("new_data", C.c_int)]
+
+    @classmethod
+    def make(cls, nof_prb, mod, tbs, rnti, cfi=1, rv=0, new_data=True, prb_mask=None):
+        """prb_mask: None = every PRB in both slots, else [2][nof_prb] of 0/1 (srslte_pdsch_grant_t.prb_idx)."""
+        g = cls()
+        g.mod, g.tbs, g.rv, g.cfi, g.rnti, g.new_data = mod, tbs, rv, cfi, rnti, 1 if new_data else 0
+        for s in range(2):
+            for n in range(nof_prb):
+                if prb_mask is None or prb_mask[s][n]:
+                    g.prb_mask[s][n >> 5] |= 1 << (n & 31)
+        return g
+
+
 def lib():
     """The native library; raises if it was not built (no fallback path exists)."""
     global _lib
@@ -110,6 +127,7 @@ def lib():
         L.srslte_hip_dl_rx_batch.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
         L.srslte_hip_dl_rx_grid_batch.argtypes = L.srslte_hip_dl_rx_batch.argtypes
         L.srslte_hip_dl_rx_stage.argtypes = [vp, C.c_int, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, vp]
+        L.srslte_hip_dl_rx_batch_grants.argtypes = [vp, vp, C.c_uint32, C.c_uint32, C.POINTER(DlGrant), vp, C.c_uint32, vp, vp]
         L.srslte_hip_dl_rx_debug_buffer.restype = vp
         L.srslte_hip_dl_rx_debug_buffer.argtypes = [vp, C.c_int]
         L.srslte_hip_dl_rx_keep_symbols.argtypes = [vp, C.c_int]
@@ -469,6 +487,19 @@ class DlRx:
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def decode_grants(self, iq, tti0, grants):
+        """srslte_hip_dl_rx_batch_grants: subframe b with grants[b] (DlGrant). Returns (rc, tb [nsf][tbs_max/8+3], ok [nsf])."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * self.sf_len)
+        assert len(grants) == x.shape[0]
+        arr = (DlGrant * len(grants))(*grants)
+        din = DevBuf.from_host(x)
+        rc = lib().srslte_hip_dl_rx_batch_grants(self.h, din.ptr, tti0, x.shape[0], arr, self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        return rc, tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
 
     def decode_harq(self, iq, tti0, rv, new_data):
         """srslte_hip_dl_rx_batch_harq: slot b keeps its soft buffers / CRC flags / bytes between calls."""

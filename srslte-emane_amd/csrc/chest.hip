@@ -568,6 +568,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   if (hipMalloc((void**)&q->d_pilots, sizeof(cf32) * pil.size()) != hipSuccess ||
       hipMalloc((void**)&q->d_pss, sizeof(pss)) != hipSuccess || hipMemcpy(q->d_pss, pss, sizeof(pss), hipMemcpyHostToDevice) != hipSuccess ||
       hipMalloc((void**)&q->d_noise_state, sizeof(float) * 16) != hipSuccess || hipMemset(q->d_noise_state, 0, sizeof(float) * 16) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess /* null-stream memset vs the callers' non-blocking streams */ ||
       hipMemcpy(q->d_pilots, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
     fprintf(stderr, "[srslte_hip] chest_dl: device allocation failed\n");
     delete q;

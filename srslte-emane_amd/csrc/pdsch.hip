@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "demod_dev.hpp"
 #include "phy_hip_internal.hpp"
+#include <map>
 #include <math.h>
 #include <string.h>
 #include <vector>
@@ -36,7 +37,29 @@ struct SfClass { // RE list per subframe class: 0 = sf 0 (PSS/SSS+PBCH), 1 = sf 
   int             nof_re;
 };
 
+// Per-subframe / per-code-block descriptors of srslte_hip_dl_rx_batch_grants: every subframe of a batch carries its own grant
+// (srslte_pdsch_grant_t: PRB masks of both slots, modulation, transport block size, redundancy version; RNTI, CFI). Null descriptor
+// pointers in the geometry structs = the one fixed full-band configuration of srslte_hip_dl_rx_batch.
+struct SfDesc {
+  const uint32_t* idx; // RE list of the subframe (pdsch_relist_kernel)
+  const uint32_t* scr; // packed scrambling bits of the subframe (scr_gen_kernel)
+  int             nof_re, mod, Qm;
+  int             C, K, tbs, rlen; // segmentation of its transport block (36.212 5.1.2): C blocks of K bits, rlen payload bits per block
+};
+struct CbDesc {
+  int             sf, cb;  // subframe of the batch, code block of its transport block
+  int             C, K, Qm, nof_re;
+  int             combine; // 0: new data, the soft buffer is overwritten; 1: retransmission, added (and skipped if the block's CRC passed)
+  int             w_len;   // soft-buffer slots of this block length (multiple of 32) = stride of its slot table
+  const uint32_t* tbl;     // slot table of (K, rv)
+};
+struct GrantDev { // what the list / sequence kernels need of a grant
+  uint32_t mask[2][4]; // prb_idx[s][n] as bits
+  int      sf_idx, lstart, q_off, rnti;
+};
+
 struct PdschGeom {
+  const SfDesc* desc; // grants mode, else null
   SfClass cls[3];
   int     grid_len;   // 14 * 12 * nof_prb
   int     max_re, max_bits, mod, Qm, mmse, scr_words, tti0, nof_rx, nof_ports;
@@ -62,8 +85,14 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
                                                           cf32* __restrict__ d_out, LLR* __restrict__ e_out, PdschGeom g)
 {
   __shared__ __attribute__((aligned(16))) LLR stage[256 * 8]; // the workgroup's LLRs, written out with 16-byte stores
-  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
-  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  SfClass         c  = g.cls[sf_class(sf_idx)];
+  int             mod = g.mod, Qm = g.Qm;
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+  if (g.desc) {
+    const SfDesc d = g.desc[sf];
+    c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
+  }
   const int     base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
   if (base >= c.nof_re) return;
   const bool     live = i < c.nof_re;
@@ -98,22 +127,21 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x;
   LLR o[8];
   if constexpr (sizeof(LLR) == 1) {
-    demod_dev::demod_b(g.mod, x, i, c.nof_re, o);
+    demod_dev::demod_b(mod, x, i, c.nof_re, o);
   } else {
-    demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+    demod_dev::demod_s(mod, x, i, c.nof_re, o);
   }
-  const uint32_t* cs   = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
-  const int       bit0 = (live ? i : 0) * g.Qm;
+  const int       bit0 = (live ? i : 0) * Qm;
   const uint32_t  c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
-  for (int j = 0; j < g.Qm; j++) {
+  for (int j = 0; j < Qm; j++) {
     LLR v = o[j];
     if ((c2 >> j) & 1) v = (LLR)-v; // scrambling.c:45-51: sign instruction, -(-min) stays min
-    stage[threadIdx.x * g.Qm + j] = v;
+    stage[threadIdx.x * Qm + j] = v;
   }
   __syncthreads();
   // max_bits is a multiple of 16 and so is 256 * Qm: the workgroup's output starts on a 16-byte boundary
-  const int   nbytes = min(256, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
-  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const int   nbytes = min(256, c.nof_re - base) * Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * Qm);
   const char* src    = reinterpret_cast<const char*>(stage);
   for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
   const int rem = nbytes & 15;
@@ -245,6 +273,8 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
 }
 
 struct RmGeom {
+  const CbDesc* cbd;       // grants mode: one entry per launched block (then C = code-block slots per subframe), else null
+  uint8_t*      cb_ok_rst; // grants mode: CRC flags, cleared here for blocks that start new data
   int C, K, Qm, tti0, max_bits, w_stride, out_len; // out_len = 3K+12
   int nof_re[3];
   int             max_re, mod;
@@ -324,37 +354,45 @@ template <typename LLR>
 __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, LLR* __restrict__ w, const uint32_t* __restrict__ inv, RmGeom g)
 {
   constexpr int PER = 4 / (int)sizeof(LLR); // slots per dword
-  const int cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C;
+  // the block: memory slot cbg = sf * g.C + cb; in grants mode its own (C, K, Qm, nof_re, table) come from the descriptor
+  int             cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)];
+  const uint32_t* tbl = inv;
+  if (g.cbd) {
+    const CbDesc d = g.cbd[blockIdx.y];
+    sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
+  }
   const int j = PER * (blockIdx.x * blockDim.x + threadIdx.x);
-  if (j >= g.w_stride || (g.skip && g.skip[cbg])) return;
-  const int nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], QmL = g.Qm * g.Nl, Gp = nre / g.Nl; // Gp = nof_bits / (Qm N_L)
-  const int gamma = Gp % g.C, n_e = QmL * (Gp / g.C);
+  if (j >= w_len || (g.skip && combine && g.skip[cbg])) return;
+  if (g.cb_ok_rst && !combine && j == 0) g.cb_ok_rst[cbg] = 0;
+  const int QmL = Qm * g.Nl, Gp = nre / g.Nl; // Gp = nof_bits / (Qm N_L)
+  const int gamma = Gp % C, n_e = QmL * (Gp / C);
   int       rp = cb * n_e, n_e2 = n_e;
-  if (cb > g.C - gamma) { // sch.c:331-334 (the '>' quirk is upstream's)
+  if (cb > C - gamma) { // sch.c:331-334 (the '>' quirk is upstream's)
     n_e2 = n_e + QmL;
-    rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
+    rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
   const LLR* src = e + (size_t)sf * g.max_bits + rp;
   CsiW       cw;
   if (g.csi) cw = csi_setup(g, sf, nre);
   uint32_t   n[PER], word = 0;
   if constexpr (PER == 2) {
-    const uint2 t = *reinterpret_cast<const uint2*>(inv + j);
+    const uint2 t = *reinterpret_cast<const uint2*>(tbl + j);
     n[0] = t.x; n[1] = t.y;
   } else {
-    const uint4 t = *reinterpret_cast<const uint4*>(inv + j);
+    const uint4 t = *reinterpret_cast<const uint4*>(tbl + j);
     n[0] = t.x; n[1] = t.y; n[2] = t.z; n[3] = t.w;
   }
 #pragma unroll
   for (int s = 0; s < PER; s++) {
     int acc = 0;
     if (n[s] != 0xffffffffu) {
-      for (int i = (int)n[s]; i < n_e2; i += g.out_len) acc += g.csi ? csi_apply<LLR>(cw, src[i], rp + i) : src[i];
+      for (int i = (int)n[s]; i < n_e2; i += out_len) acc += g.csi ? csi_apply<LLR>(cw, src[i], rp + i) : src[i];
     }
     word |= ((uint32_t)acc & ((1u << (8 * sizeof(LLR))) - 1u)) << (8 * sizeof(LLR) * s);
   }
   uint32_t* dst = reinterpret_cast<uint32_t*>(w + (size_t)cbg * g.w_stride + j);
-  *dst          = g.combine ? add_wrap<LLR>(*dst, word) : word;
+  *dst          = combine ? add_wrap<LLR>(*dst, word) : word;
 }
 
 // Same result with the code block's LLR segment staged in LDS: one workgroup per code block copies its n_e LLRs with 16-byte
@@ -368,14 +406,21 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) char seg_raw[];
   constexpr int PER = 16 / (int)sizeof(LLR), NV = PER / 8; // slots per 16 bytes; uint4 loads of 16-bit table entries per step
   LLR*          seg = reinterpret_cast<LLR*>(seg_raw);
-  const int cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C;
-  if (g.skip && g.skip[cbg]) return;
-  const int nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], QmL = g.Qm * g.Nl, Gp = nre / g.Nl;
-  const int gamma = Gp % g.C, n_e = QmL * (Gp / g.C);
+  int             cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)];
+  const uint32_t* tbl = inv;
+  if (g.cbd) {
+    const CbDesc d = g.cbd[blockIdx.x];
+    sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
+  }
+  if (g.skip && combine && g.skip[cbg]) return;
+  if (g.cb_ok_rst && !combine && threadIdx.x == 0) g.cb_ok_rst[cbg] = 0;
+  const int QmL = Qm * g.Nl, Gp = nre / g.Nl;
+  const int gamma = Gp % C, n_e = QmL * (Gp / C);
   int       rp = cb * n_e, n_e2 = n_e;
-  if (cb > g.C - gamma) { // sch.c:331-334
+  if (cb > C - gamma) { // sch.c:331-334
     n_e2 = n_e + QmL;
-    rp   = (g.C - gamma) * n_e + (cb - (g.C - gamma)) * n_e2;
+    rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
   const LLR* src = e + (size_t)sf * g.max_bits + rp;
   // the segment starts at an arbitrary LLR index: copy from the 16-byte boundary below it
@@ -400,9 +445,9 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   }
   __syncthreads();
   const LLR*   ls    = seg + mis;
-  const uint4* inv16 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(inv + g.w_stride));
+  const uint4* inv16 = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(tbl + w_len));
   uint4*       dst   = reinterpret_cast<uint4*>(w + (size_t)cbg * g.w_stride);
-  const int    ngroups = g.w_stride / PER;
+  const int    ngroups = w_len / PER;
   for (int j0 = threadIdx.x; j0 < ngroups; j0 += 4 * 256) {
     uint4 tt[4][NV];
 #pragma unroll
@@ -421,12 +466,12 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
         const uint32_t pair = (&tt[u][s / 8].x)[(s / 2) & 3], n = (s & 1) ? pair >> 16 : pair & 0xffffu;
         int            acc  = 0;
         if (n != 0xffffu) {
-          for (int i = (int)n; i < n_e2; i += g.out_len) acc += ls[i];
+          for (int i = (int)n; i < n_e2; i += out_len) acc += ls[i];
         }
         constexpr int BITS = 8 * (int)sizeof(LLR);
         o[s * BITS / 32] |= ((uint32_t)acc & ((1u << BITS) - 1u)) << ((s * BITS) & 31);
       }
-      if (g.combine) {
+      if (combine) {
         const uint4 old = dst[j];
         dst[j] = make_uint4(add_wrap<LLR>(old.x, o[0]), add_wrap<LLR>(old.y, o[1]), add_wrap<LLR>(old.z, o[2]), add_wrap<LLR>(old.w, o[3]));
       } else {
@@ -437,6 +482,7 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
 }
 
 struct TbGeom {
+  const SfDesc* desc; // grants mode: per-subframe (C, K, tbs, rlen), C = code-block slots per subframe, crc_rem = x^i mod g for i >= 0; else null
   int C, K, tbs, rlen, cb_stride, tb_stride;
 };
 
@@ -447,18 +493,27 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
                                                      TbGeom g)
 {
   __shared__ uint32_t red[8];
-  const int sf = blockIdx.x, nbytes = g.tbs / 8 + 3, rb = g.rlen / 8;
+  int C = g.C, K = g.K, tbs = g.tbs, rlen = g.rlen;
+  if (g.desc) {
+    const SfDesc d = g.desc[blockIdx.x];
+    C = d.C; K = d.K; tbs = d.tbs; rlen = d.rlen;
+  }
+  const int sf = blockIdx.x, nbytes = tbs / 8 + 3, rb = rlen / 8;
   uint8_t*  dst = tb + (size_t)sf * g.tb_stride;
   uint32_t  syn = 0;
+  if (C == 0) { // grants mode: no transport block in this subframe
+    if (threadIdx.x == 0) tb_ok[sf] = 0;
+    return;
+  }
   for (int b0 = threadIdx.x * 4; b0 < nbytes + 3; b0 += blockDim.x * 4) {
     uint32_t word = 0;
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const int b = b0 + t;
       int       cb = b / rb;
-      if (cb > g.C - 1) cb = g.C - 1;
+      if (cb > C - 1) cb = C - 1;
       const int     off = b - cb * rb;
-      const uint8_t v   = (b < nbytes + 3 && off < g.K / 8) ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : 0;
+      const uint8_t v   = (b < nbytes + 3 && off < K / 8) ? cb_bytes[((size_t)sf * g.C + cb) * g.cb_stride + off] : 0;
       if (b < nbytes + 3) dst[b] = v;
       word |= (uint32_t)(b < nbytes ? v : 0) << (8 * t);
     }
@@ -466,7 +521,7 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
     for (int j = 0; j < 32; j++) { // bit j of byte t = message bit 8*(b0+t) + (7 - j%8)
       const int      t = j >> 3, bit = 8 * (b0 + t) + 7 - (j & 7);
       const uint32_t m = 0u - ((word >> j) & 1u);
-      syn ^= (bit < 8 * nbytes ? crc_rem[bit] : 0u) & m;
+      syn ^= (bit < 8 * nbytes ? crc_rem[g.desc ? 8 * nbytes - 1 - bit : bit] : 0u) & m;
     }
   }
   for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
@@ -476,12 +531,96 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
     syn = 0;
     for (int i = 0; i < (int)blockDim.x / 64; i++) syn ^= red[i];
     bool ok = syn == 0;
-    for (int c = 0; c < g.C; c++) ok = ok && cb_ok[sf * g.C + c];
+    for (int c = 0; c < C; c++) ok = ok && cb_ok[sf * g.C + c];
     // par_rx == par_tx && par_rx != 0 (sch.c:481): a zero parity with zero syndrome is rejected upstream
-    const uint8_t* p = dst + g.tbs / 8;
+    const uint8_t* p = dst + tbs / 8;
     ok               = ok && (p[0] | p[1] | p[2]);
     tb_ok[sf]        = ok ? 1 : 0;
   }
+}
+
+// ---- grants mode: RE lists and scrambling sequences made on the device from the grants of the batch
+// pdsch.c:81-206 as a per-RE rule for a single-port cell (see pdsch_re_indices below and oracle/orc_pdsch.c): symbol sym = 7 s + l,
+// sub-carrier k. q_off: what upstream's `offset` variable holds when it reaches the half PRBs of an odd-bandwidth cell (pdsch.c:172-190)
+__host__ __device__ __forceinline__ bool pdsch_re_used(int P, int cell_id, int sf_idx, int q_off, int s, int l, int k)
+{
+  const int  nre  = 12 * P;
+  const bool sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
+  if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) return false;
+  if (l == 0 || l == 4) {
+    const int  p      = k / 12;
+    const bool centre = p >= P / 2 - 3 && p < P / 2 + 3 + (P % 2);
+    const int  off    = (centre && sync) ? q_off : (l == 0 ? cell_id % 6 : (cell_id + 3) % 6);
+    if (k % 6 == off % 6) return false;
+  }
+  return true;
+}
+
+// One workgroup per subframe: idx_out[sf][...] = the grid positions of the subframe's PDSCH REs in the reference's order (symbol-major,
+// PRB ascending): counts per (symbol, PRB) unit, prefix sum in LDS, then every unit writes its REs.
+__global__ __launch_bounds__(256) void pdsch_relist_kernel(const GrantDev* __restrict__ gr, uint32_t* __restrict__ idx_out, int P, int cell_id,
+                                                           int max_re)
+{
+  __shared__ int cnt[14 * 110 + 1];
+  __shared__ int part[257];
+  const int      sf = blockIdx.x, units = 14 * P, nre = 12 * P;
+  const GrantDev g  = gr[sf];
+  auto           alloc = [&](int u) {
+    const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
+    return (s == 1 || l >= g.lstart) && ((g.mask[s][p >> 5] >> (p & 31)) & 1u);
+  };
+  for (int u = threadIdx.x; u < units; u += 256) {
+    int n = 0;
+    if (alloc(u)) {
+      const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
+      for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k) ? 1 : 0;
+    }
+    cnt[u] = n;
+  }
+  __syncthreads();
+  const int chunk = (units + 255) / 256, lo = threadIdx.x * chunk, hi = min(units, lo + chunk);
+  int       sum = 0;
+  for (int u = lo; u < hi; u++) sum += cnt[u];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int i = 0; i < 256; i++) {
+      const int t = part[i];
+      part[i]     = acc;
+      acc += t;
+    }
+  }
+  __syncthreads();
+  int off = part[threadIdx.x];
+  for (int u = lo; u < hi; u++) {
+    const int n = cnt[u];
+    if (n) {
+      const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
+      uint32_t* o = idx_out + (size_t)sf * max_re + off;
+      int       w = 0;
+      for (int k = 12 * p; k < 12 * p + 12; k++) {
+        if (pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k)) o[w++] = (uint32_t)(sym * nre + k);
+      }
+    }
+    off += n;
+  }
+}
+
+// Gold sequence c(n) = x1(n + 1600) ^ x2(n + 1600) (36.211 7.2, sequence.c:48-79) as a linear function of c_init: row 0 of `basis` is the x1
+// part (packed, 32 bits per word), row 1 + j the x2 sequence of c_init = 1 << j. One thread per output word:
+// scr[sf][w] = row0[w] ^ XOR over the set bits j of c_init of row(1 + j)[w], c_init = rnti * 2^14 + sf_idx * 2^9 + cell id (pdsch.c:469).
+__global__ __launch_bounds__(256) void scr_gen_kernel(const GrantDev* __restrict__ gr, const uint32_t* __restrict__ basis, uint32_t* __restrict__ out,
+                                                      int words, int cell_id)
+{
+  const int sf = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= words) return;
+  const GrantDev g = gr[sf];
+  uint32_t       c_init = ((uint32_t)g.rnti << 14) + ((uint32_t)g.sf_idx << 9) + (uint32_t)cell_id, v = basis[w];
+  for (int j = 0; j < 31; j++) {
+    if ((c_init >> j) & 1u) v ^= basis[(size_t)(1 + j) * words + w];
+  }
+  out[(size_t)sf * words + w] = v;
 }
 
 // Same result from the per-block syndrome shares the windowed turbo decoders emit (tdec_set_tb_syndrome): the CRC is linear,
@@ -563,6 +702,18 @@ int upload(T** d, const std::vector<T>& h)
 
 } // namespace
 
+// Device / host resources of the per-subframe-grant mode (srslte_hip_dl_rx_batch_grants)
+struct GrantsState {
+  srslte_hip_tdec_t* tdec;       // any block length up to 6144
+  uint32_t           Cmax, stride, max_re, max_bits, words;
+  uint32_t *         d_relist, *d_scr, *d_basis, *d_rev, *d_cb_iters;
+  int16_t *          d_e, *d_w;
+  uint8_t *          d_cb_bytes, *d_cb_ok, *d_desc;
+  size_t             desc_bytes;
+  std::vector<uint8_t>                                 h_desc;
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t*>   rm_tbl; // (K, rv) -> slot table in the layout of that K's decoder
+};
+
 struct srslte_hip_dl_rx {
   srslte_hip_dl_rx_cfg_t cfg;
   srslte_hip_ofdm_t*     ofdm;
@@ -589,6 +740,7 @@ struct srslte_hip_dl_rx {
   float*                 d_csi;     // [B][max_re], cfg.csi_enable
   uint32_t*              d_csi_max; // [B]
   const cf32*            grid_in; // resource grids supplied by the caller (srslte_hip_dl_rx_grid_batch) instead of d_grid
+  struct GrantsState*    gs;      // srslte_hip_dl_rx_batch_grants: created on first use
 };
 
 extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
@@ -602,6 +754,16 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
                   q->d_csi,    q->d_csi_max, q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3]};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
+  }
+  if (q->gs) {
+    GrantsState* g = q->gs;
+    srslte_hip_tdec_destroy(g->tdec);
+    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_rev, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc};
+    for (void* b : gb) {
+      if (b) (void)hipFree(b);
+    }
+    for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
+    delete g;
   }
   delete q;
 }
@@ -708,6 +870,10 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     ok = hipMalloc((void**)&q->d_csi, sizeof(float) * (size_t)max_re * B) == hipSuccess &&
          hipMalloc((void**)&q->d_csi_max, sizeof(uint32_t) * B) == hipSuccess;
   }
+  // HARQ state of slots that have not seen new data yet (a retransmission into such a slot combines with an empty soft buffer and
+  // decodes every block); the memsets run on the null stream, which the callers' non-blocking streams do not order against: wait here
+  ok = ok && hipMemset(q->d_cb_ok, 0, (size_t)B * C) == hipSuccess && hipMemset(q->d_w, 0, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
+       hipMemset(q->d_cb_bytes, 0, (size_t)(K / 8) * B * C) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   if (!ok) {
     fprintf(stderr, "[srslte_hip] dl_rx: initialisation failed\n");
     srslte_hip_dl_rx_destroy(q);
@@ -757,6 +923,14 @@ extern "C" const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q
     case 8: return q->d_cb_bytes;
     case 9: return q->d_csi;
     case 10: return q->d_csi_max;
+    // grants mode (srslte_hip_dl_rx_batch_grants): 11 e [nof_sf][max_bits], 12 w [nof_sf * Cmax][stride], 13 cb iters, 14 cb ok,
+    // 15 RE lists [nof_sf][max_re], 16 scrambling words [nof_sf][words]
+    case 11: return q->gs ? q->gs->d_e : nullptr;
+    case 12: return q->gs ? q->gs->d_w : nullptr;
+    case 13: return q->gs ? q->gs->d_cb_iters : nullptr;
+    case 14: return q->gs ? q->gs->d_cb_ok : nullptr;
+    case 15: return q->gs ? q->gs->d_relist : nullptr;
+    case 16: return q->gs ? q->gs->d_scr : nullptr;
   }
   return nullptr;
 }
@@ -894,6 +1068,254 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
   for (int s = 1; s < 6 && r == SRSLTE_SUCCESS; s++) r = srslte_hip_dl_rx_stage(q, s, nullptr, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
   q->grid_in = nullptr;
   return r;
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+// Per-subframe grants (what a TTI stream looks like: srslte_pdsch_decode takes a new srslte_pdsch_grant_t every subframe, pdsch.c:833-997):
+// subframe b of the batch is received with grants[b] - PRB masks of both slots (srslte_pdsch_grant_t.prb_idx, walked by srslte_pdsch_cp
+// pdsch.c:81-206), modulation, transport block size, redundancy version, RNTI, CFI, new-data flag. RE lists and scrambling sequences are made
+// on the device from the grants, rate de-matching runs over the ragged set of code blocks of the batch, the turbo decoder once per block
+// length present in it. cfg.tbs bounds the transport block size (buffer sizes), cfg.mod / cfg.rnti / cfg.cfi are not used here.
+// Single-port cells (TM1), 1..4 receive antennas, 16-bit LLRs.
+// --------------------------------------------------------------------------------------------------------------------
+static int grants_init(srslte_hip_dl_rx_t* q)
+{
+  auto*          g = new GrantsState();
+  const uint32_t P = q->cfg.nof_prb, B = q->cfg.max_batch;
+  g->Cmax     = q->seg.C;
+  g->stride   = (srslte_hip_tdec_input_len(6144, 1) + 31) & ~31u;
+  g->max_re   = 14 * 12 * P;                       // upper bound of any allocation
+  g->max_bits = (g->max_re * 8 + 15) & ~15u;       // 256QAM
+  g->words    = (g->max_re * 8 + 31) / 32 + 2;     // + the spare word the demapper reads
+  g->tdec     = srslte_hip_tdec_create(6144, B * g->Cmax);
+  g->d_relist = g->d_scr = g->d_basis = g->d_rev = g->d_cb_iters = nullptr;
+  g->d_e = g->d_w = nullptr;
+  g->d_cb_bytes = g->d_cb_ok = g->d_desc = nullptr;
+  q->gs = g;
+  if (!g->tdec) return SRSLTE_ERROR;
+  // Gold-sequence basis (sequence.c:48-79): all 31 x2 basis sequences advance together, bit j of the state word = basis j
+  {
+    const uint32_t         nbits = g->words * 32, Nc = 1600, tot = nbits + Nc + 31;
+    std::vector<uint8_t>   x1(tot);
+    std::vector<uint32_t>  x2(tot);
+    for (uint32_t n = 0; n < 31; n++) {
+      x1[n] = n == 0;
+      x2[n] = 1u << n;
+    }
+    for (uint32_t n = 0; n + 31 < tot; n++) {
+      x1[n + 31] = x1[n + 3] ^ x1[n];
+      x2[n + 31] = x2[n + 3] ^ x2[n + 2] ^ x2[n + 1] ^ x2[n];
+    }
+    std::vector<uint32_t> basis((size_t)32 * g->words, 0);
+    for (uint32_t n = 0; n < nbits; n++) {
+      const uint32_t w = n >> 5, b = n & 31, v2 = x2[n + Nc];
+      basis[w] |= (uint32_t)x1[n + Nc] << b;
+      for (uint32_t j = 0; j < 31; j++) basis[(size_t)(1 + j) * g->words + w] |= ((v2 >> j) & 1u) << b;
+    }
+    if (upload(&g->d_basis, basis)) return SRSLTE_ERROR;
+  }
+  { // x^i mod g_CRC24A, i = 0 .. cfg.tbs + 23: the TB check of any transport block size reads it backwards
+    std::vector<uint32_t> rev(q->cfg.tbs + 24);
+    uint32_t              v = 1;
+    for (uint32_t i = 0; i < rev.size(); i++) {
+      rev[i] = v;
+      v <<= 1;
+      if (v & 0x1000000) v ^= 0x1864CFB;
+    }
+    if (upload(&g->d_rev, rev)) return SRSLTE_ERROR;
+  }
+  const size_t nblk = (size_t)B * g->Cmax;
+  g->desc_bytes     = sizeof(GrantDev) * B + sizeof(SfDesc) * B + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk;
+  g->h_desc.resize(g->desc_bytes);
+  HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * B));
+  HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * B));
+  HIP_TRY(hipMalloc((void**)&g->d_e, sizeof(int16_t) * ((size_t)g->max_bits * B + 16)));
+  HIP_TRY(hipMalloc((void**)&g->d_w, sizeof(int16_t) * (size_t)g->stride * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_cb_bytes, (size_t)768 * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_cb_ok, nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_cb_iters, sizeof(uint32_t) * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+  // HARQ state of slots that have not seen new data yet: nothing decoded, empty soft buffers
+  HIP_TRY(hipMemset(g->d_cb_ok, 0, nblk));
+  HIP_TRY(hipMemset(g->d_w, 0, sizeof(int16_t) * (size_t)g->stride * nblk));
+  HIP_TRY(hipMemset(g->d_cb_bytes, 0, (size_t)768 * nblk));
+  HIP_TRY(hipDeviceSynchronize());
+  return SRSLTE_SUCCESS;
+}
+
+// slot table of (K, rv) in the input layout of the decoder AUTO selects for K, stride = that layout's length rounded up to 32
+static int grants_rm_table(GrantsState* g, uint32_t K, uint32_t rv, uint32_t W, uint32_t w_len, const uint32_t** d_tbl)
+{
+  auto it = g->rm_tbl.find({K, rv});
+  if (it == g->rm_tbl.end()) {
+    std::vector<uint32_t> t;
+    lte_rm_rx_table(K, rv, t);
+    if (W) {
+      for (auto& v : t) v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / W)) * W + (v / 3) / (K / W) : (v - 3 * K) + 3 * (K + 32);
+    }
+    uint32_t* d = nullptr;
+    if (upload(&d, rm_slot_table(t, w_len))) return SRSLTE_ERROR;
+    it = g->rm_tbl.emplace(std::make_pair(K, rv), d).first;
+  }
+  *d_tbl = it->second;
+  return SRSLTE_SUCCESS;
+}
+
+extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
+                                             uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.csi_enable) {
+    fprintf(stderr, "[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs, no CSI weighting\n");
+    return SRSLTE_ERROR;
+  }
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  if (!q->gs && grants_init(q)) return SRSLTE_ERROR;
+  GrantsState*   g  = q->gs;
+  hipStream_t    st = (hipStream_t)stream;
+  const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id, B = q->cfg.max_batch;
+  const size_t   nblk = (size_t)B * g->Cmax;
+  auto*          h_gr = reinterpret_cast<GrantDev*>(g->h_desc.data());
+  auto*          h_sf = reinterpret_cast<SfDesc*>(h_gr + B);
+  auto*          h_cb = reinterpret_cast<CbDesc*>(h_sf + B);
+  auto*          h_map = reinterpret_cast<uint32_t*>(h_cb + nblk);
+  auto*          d_gr = reinterpret_cast<GrantDev*>(g->d_desc);
+  auto*          d_sf = reinterpret_cast<SfDesc*>(d_gr + B);
+  auto*          d_cb = reinterpret_cast<CbDesc*>(d_sf + B);
+  auto*          d_map = reinterpret_cast<uint32_t*>(d_cb + nblk);
+  struct Group { uint32_t K, single; std::vector<uint32_t> slots; };
+  std::vector<Group> groups;
+  uint32_t           ncb = 0, max_seg = 0;
+  for (uint32_t b = 0; b < nof_sf; b++) {
+    const srslte_hip_dl_grant_t& gr = grants[b];
+    GrantDev&                    gd = h_gr[b];
+    SfDesc&                      sd = h_sf[b];
+    memset(&gd, 0, sizeof(gd));
+    memset(&sd, 0, sizeof(sd));
+    const uint32_t sf_idx = (tti0 + b) % 10, lstart = gr.cfi + (P < 10 ? 1 : 0);
+    gd.sf_idx = (int)sf_idx; gd.lstart = (int)lstart; gd.rnti = gr.rnti;
+    sd.idx = g->d_relist + (size_t)b * g->max_re;
+    sd.scr = g->d_scr + (size_t)b * g->words;
+    if (gr.tbs == 0) continue; // no transport block in this subframe: C = 0, tb_ok = 0
+    srslte_hip_cbsegm_t seg;
+    if (gr.mod < 1 || gr.mod > 4 || gr.cfi < 1 || gr.cfi > 3 || gr.rv > 3 || gr.tbs > q->cfg.tbs || (gr.tbs % 8) || srslte_hip_cbsegm(&seg, gr.tbs) || seg.F ||
+        seg.C2 || seg.C > g->Cmax) {
+      fprintf(stderr, "[srslte_hip] dl_rx grants: subframe %u: unsupported grant (mod %d, tbs %u, cfi %u, rv %u)\n", b, gr.mod, gr.tbs, gr.cfi, gr.rv);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    bool any0 = false, below1 = false;
+    for (uint32_t n = 0; n < P; n++) {
+      for (int s = 0; s < 2; s++) {
+        if ((gr.prb_mask[s][n >> 5] >> (n & 31)) & 1u) {
+          gd.mask[s][n >> 5] |= 1u << (n & 31);
+          if (s == 0) any0 = true;
+          if (s == 1 && n + 3 < P / 2) below1 = true;
+        }
+      }
+    }
+    // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them
+    gd.q_off = below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0);
+    // number of PDSCH REs (what pdsch_relist_kernel will list; srslte_ra_dl_grant_nof_re): per symbol, whole PRBs carry 12 REs (10 with
+    // CRS), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half there 6 (5 with CRS)
+    auto pop = [](const uint32_t* m, const uint32_t* f) {
+      return __builtin_popcount(m[0] & f[0]) + __builtin_popcount(m[1] & f[1]) + __builtin_popcount(m[2] & f[2]) + __builtin_popcount(m[3] & f[3]);
+    };
+    uint32_t centre[4] = {0, 0, 0, 0}, half[4] = {0, 0, 0, 0}, all[4] = {~0u, ~0u, ~0u, ~0u};
+    for (uint32_t n = P / 2 - 3; n < P / 2 + 3 + (P % 2); n++) centre[n >> 5] |= 1u << (n & 31);
+    if (P % 2) {
+      half[(P / 2 - 3) >> 5] |= 1u << ((P / 2 - 3) & 31);
+      half[(P / 2 + 3) >> 5] |= 1u << ((P / 2 + 3) & 31);
+    }
+    uint32_t nre = 0;
+    for (int sym = 0; sym < 14; sym++) {
+      const int s = sym / 7, l = sym % 7;
+      if (s == 0 && l < (int)lstart) continue;
+      const bool ref = l == 0 || l == 4, sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
+      const int  per = ref ? 10 : 12;
+      nre += per * pop(gd.mask[s], all);
+      if (sync) nre += (ref ? 5 : 6) * pop(gd.mask[s], half) - per * pop(gd.mask[s], centre);
+    }
+    const uint32_t Qm = 2 * (uint32_t)gr.mod, K = seg.K1, C = seg.C;
+    if (nre == 0 || nre * Qm < C * Qm) {
+      fprintf(stderr, "[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    sd.nof_re = (int)nre; sd.mod = gr.mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)gr.tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
+    const uint32_t W = srslte_hip_tdec_autoimp_get_subblocks(K), w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
+    const uint32_t* tbl = nullptr;
+    if (grants_rm_table(g, K, gr.rv, W, w_len, &tbl)) return SRSLTE_ERROR;
+    Group* grp = nullptr;
+    for (auto& x : groups) {
+      if (x.K == K && x.single == (C == 1 ? gr.tbs : 0)) grp = &x;
+    }
+    if (!grp) {
+      groups.push_back(Group{K, C == 1 ? gr.tbs : 0, {}});
+      grp = &groups.back();
+    }
+    for (uint32_t c = 0; c < C; c++) {
+      CbDesc& cd = h_cb[ncb++];
+      cd.sf = (int)b; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = gr.new_data ? 0 : 1;
+      cd.w_len = (int)w_len; cd.tbl = tbl;
+      grp->slots.push_back(b * g->Cmax + c);
+    }
+    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm) * 2 + 32;
+    max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
+  }
+  uint32_t nmap = 0;
+  for (auto& x : groups) {
+    for (uint32_t v : x.slots) h_map[nmap++] = v;
+  }
+  // stages 0, 1: OFDM demodulation and channel estimation do not depend on the grants
+  int r = srslte_hip_dl_rx_stage(q, 0, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+  if (!r) r = srslte_hip_dl_rx_stage(q, 1, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+  if (r) return r;
+  // the descriptors: pageable source, so the copy has left the host buffer when the call returns and the buffer may be refilled
+  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_desc.data(), g->desc_bytes, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re);
+  hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis, g->d_scr,
+                     (int)g->words, (int)cell_id);
+  LAUNCH_CHECK();
+  {
+    PdschGeom pg = q->pg;
+    pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = nullptr; pg.csi_max = nullptr;
+    const cf32* grid = q->d_grid;
+    hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                       (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
+    LAUNCH_CHECK();
+  }
+  if (ncb) {
+    RmGeom rg;
+    memset(&rg, 0, sizeof(rg));
+    rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
+    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re;
+    const int lds = (int)((max_seg + 15) & ~15u);
+    if (lds <= 64 * 1024) {
+      hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(ncb), dim3(256), lds, st, (const int16_t*)g->d_e, g->d_w, (const uint32_t*)nullptr, rg);
+    } else {
+      hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div((int)g->stride, 512), ncb), dim3(256), 0, st, (const int16_t*)g->d_e, g->d_w,
+                         (const uint32_t*)nullptr, rg);
+    }
+    LAUNCH_CHECK();
+    tdec_set_tb_syndrome(g->tdec, nullptr, 1, nullptr);
+    tdec_set_skip(g->tdec, g->d_cb_ok);
+    uint32_t off = 0;
+    for (auto& x : groups) {
+      const uint32_t n = (uint32_t)x.slots.size(), W = srslte_hip_tdec_autoimp_get_subblocks(x.K);
+      tdec_set_cb_map(g->tdec, d_map + off);
+      r = tdec_run_batch_w(g->tdec, g->d_w, 0, g->stride, W != 0, x.K, -1, n, q->cfg.max_iterations, x.single ? 0x1864CFBu : 0x1800063u,
+                           x.single ? x.single + 24 : x.K, g->d_cb_bytes, 768, g->d_cb_iters, g->d_cb_ok, st);
+      tdec_set_cb_map(g->tdec, nullptr);
+      if (r) return r;
+      off += n;
+    }
+  }
+  TbGeom tg;
+  memset(&tg, 0, sizeof(tg));
+  tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride;
+  hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, (const uint32_t*)g->d_rev, d_tb,
+                     d_tb_ok, tg);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
 }
 
 // ====================================================================================================================
@@ -1197,6 +1619,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 8 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)4 * B) == hipSuccess &&
        hipMemset(q->d_ack, 0, (size_t)4 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0 &&
        Qp_ri >= 0 && (uint32_t)Qp_ri < nof_re;
+  ok = ok && hipDeviceSynchronize() == hipSuccess; // the memsets above ran on the null stream
   if (!ok) {
     fprintf(stderr, "[srslte_hip] ul_rx: initialisation failed\n");
     srslte_hip_ul_rx_destroy(q);

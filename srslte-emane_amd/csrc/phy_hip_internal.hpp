@@ -37,6 +37,9 @@ int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise);
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);
 // tdec.hip: blocks with d_skip[cb] != 0 are left alone by the following runs: bytes, CRC flag, TB-CRC share stay (nullptr: off)
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip);
+// tdec.hip: the following runs work on the block slots d_map[0 .. nof_cb) instead of 0 .. nof_cb-1 (input, output, iteration count, CRC flag,
+// skip flag; nullptr: off). For ragged batches, where the code blocks of one length are scattered over the batch's slots
+void tdec_set_cb_map(srslte_hip_tdec_t* q, const uint32_t* d_map);
 // tdec.hip: the NEXT run continues blocks whose passes 0..start_iter-1 the previous run on this object did (same inputs, same block
 // slots): srslte_tdec_iteration's one-more-pass without redoing the earlier ones (turbodecoder.c:539-545)
 void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter);

@@ -226,6 +226,8 @@ struct TdecArgs {
   uint32_t*       tb_syn;      // [nof_cb] out
   uint32_t        start_iter;  // passes 0..start_iter-1 were run by the previous launch on these blocks (same input, work arrays untouched): resume
   const uint8_t*  skip;        // optional [nof_cb]: blocks whose CRC passed in an earlier transmission keep their bytes and flags (sch.c:317-318)
+  const uint32_t* cb_map;      // optional [nof_cb]: launched block i works on block slot cb_map[i] of in / out / iters / crc_ok / skip (ragged
+                               // batches: the blocks of one length are scattered over the batch); the work arrays stay per launched block
   unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
@@ -752,14 +754,14 @@ template <int W, int AR>
 __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a)
 {
   using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
-  const int      cb = blockIdx.x, K = (int)a.K;
+  const int      lcb = blockIdx.x, cb = a.cb_map ? (int)a.cb_map[lcb] : lcb, K = (int)a.K;
   if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
     if (threadIdx.x == 0 && a.iters) a.iters[cb] = 0;
     return;
   }
   const LaneGeom L  = lane_geom();
   const in_t*    in = reinterpret_cast<const in_t*>(a.in) + (size_t)cb * a.in_stride;
-  int16_t*       wk = a.work + (size_t)cb * 7 * a.Kp;
+  int16_t*       wk = a.work + (size_t)lcb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
   // beta checkpoints (lane-private columns): ceil(Lw / CKPT) + 1 rows per half; Lw <= MAX_K / W (two halves for W = 32)
@@ -776,7 +778,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   Stage st;
   stage_init(st, mt, L);
   PROF_DECL;
-  pk_t*           xy = reinterpret_cast<pk_t*>(a.xy + (size_t)cb * a.K); // 16 B per trellis step: room for the x, y and x + y arrays
+  pk_t*           xy = reinterpret_cast<pk_t*>(a.xy + (size_t)lcb * a.K); // 16 B per trellis step: room for the x, y and x + y arrays
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91). The 12 tail LLRs go to LDS. A 16-bit
   //      SB-layout buffer already is three window-ordered arrays: like upstream (turbodecoder_iter.h:84-91) the decoder then
@@ -1019,11 +1021,12 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
   const LaneGeom L      = lane_geom();
   const int      K      = (int)a.K;
   const uint32_t cb_raw = blockIdx.x * 8 + L.g;
-  const bool     skipped = cb_raw < a.nof_cb && a.skip && a.skip[cb_raw]; // sch.c:317-318
+  const uint32_t lcb    = cb_raw < a.nof_cb ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
+  const uint32_t cb     = a.cb_map ? a.cb_map[lcb] : lcb;
+  const bool     skipped = cb_raw < a.nof_cb && a.skip && a.skip[cb]; // sch.c:317-318
   const bool     active = cb_raw < a.nof_cb && !skipped;
-  const uint32_t cb     = cb_raw < a.nof_cb ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
   const int16_t* in     = a.in + (size_t)cb * a.in_stride;
-  int16_t*       wk     = a.work + (size_t)cb * 7 * a.Kp;
+  int16_t*       wk     = a.work + (size_t)lcb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
   pk_t* beta = a.beta + (size_t)blockIdx.x * a.beta_stride;
@@ -1140,6 +1143,7 @@ struct srslte_hip_tdec {
   uint32_t                 tb_C   = 0;
   uint32_t*                tb_syn = nullptr;
   const uint8_t*           skip   = nullptr; // see tdec_set_skip
+  const uint32_t*          cb_map = nullptr; // see tdec_set_cb_map
   uint32_t                 start_iter = 0;   // see tdec_set_resume; consumed by the next run
   std::mutex               mtx;
 };
@@ -1184,7 +1188,8 @@ extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint3
       hipMalloc((void**)&q->d_beta, sizeof(pk_t) * (beta_words > gen_words ? beta_words : gen_words)) != hipSuccess ||
       hipMalloc((void**)&q->d_xy, sizeof(int4) * (size_t)max_nof_cb * max_long_cb) != hipSuccess ||
       hipMalloc((void**)&q->d_zeros, sizeof(pk_t) * (size_t)max_long_cb) != hipSuccess ||
-      hipMemset(q->d_zeros, 0, sizeof(pk_t) * (size_t)max_long_cb) != hipSuccess) {
+      hipMemset(q->d_zeros, 0, sizeof(pk_t) * (size_t)max_long_cb) != hipSuccess ||
+      hipDeviceSynchronize() != hipSuccess /* the memset ran on the null stream; callers launch on non-blocking streams */) {
     fprintf(stderr, "[srslte_hip] tdec: device allocation failed\n");
     if (q->d_work) (void)hipFree(q->d_work);
     delete q;
@@ -1246,6 +1251,7 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
 }
 
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip) { q->skip = d_skip; }
+void tdec_set_cb_map(srslte_hip_tdec_t* q, const uint32_t* d_map) { q->cb_map = d_map; }
 void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter) { q->start_iter = start_iter; }
 
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn)
@@ -1295,10 +1301,14 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   TdecArgs a;
   a.in = d_input; a.in_stride = in_stride; a.sb_layout = sb_layout; a.K = K; a.nof_cb = nof_cb; a.nof_iter = nof_iterations;
   a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy; a.zeros = q->d_zeros;
+  a.dbg = 0;
+#ifdef TDEC_DEBUG // timing experiments only (scripts/): a stray environment variable must not be able to change what a product build decodes
   a.dbg = getenv("SRSLTE_HIP_TDEC_DBG") ? atoi(getenv("SRSLTE_HIP_TDEC_DBG")) : 0;
+#endif
   a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok;
   a.tb_rem = W ? q->tb_rem : nullptr; a.tb_C = q->tb_C ? q->tb_C : 1; a.tb_syn = q->tb_syn;
   a.skip = q->skip;
+  a.cb_map = q->cb_map;
   a.start_iter = q->start_iter < nof_iterations ? q->start_iter : 0;
   q->start_iter = 0;
   a.prof = nullptr;

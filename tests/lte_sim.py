@@ -18,8 +18,11 @@ class DlConfig:
     """One PDSCH configuration: full-band grant, rv 0; nof_ports = 1: single antenna port (TM1),
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None):
+    def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None,
+                 prb_mask=None):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
+        # srslte_pdsch_grant_t.prb_idx[s][n] (pdsch_cfg.h:41): None = every PRB in both slots, else [2][nof_prb] of 0/1
+        self.prb_mask = None if prb_mask is None else np.ascontiguousarray(prb_mask, np.uint8).reshape(2, nof_prb)
         self.Qm = MOD_BITS[mod]
         # bits per "symbol" in the code-block split of the rate matcher: Qm * N_L, N_L = 2 for transmit diversity (36.212 5.1.4.1.2;
         # srslte_dlsch_decode2 / _encode2, sch.c:507-531,:549-575)
@@ -44,7 +47,7 @@ class DlConfig:
 
     def indices(self, sf_idx):
         idx = np.zeros(self.grid_len, np.uint32)
-        n = oracle().orc_pdsch_indices(C.byref(self.cell), sf_idx, self.lstart, None, p(idx))
+        n = oracle().orc_pdsch_indices(C.byref(self.cell), sf_idx, self.lstart, None if self.prb_mask is None else p(self.prb_mask), p(idx))
         return idx[:n].copy()
 
     def orc_chest_cfg(self):

@@ -35,6 +35,11 @@ def lib():
         L.refdrv_dl_find_dci.argtypes = [C.c_void_p, C.c_uint16, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.refdrv_dl_set_grant.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.refdrv_dl_chest.argtypes = [C.c_void_p]
+        L.refdrv_dl_set_prb_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.refdrv_dl_grant_info.argtypes = [C.c_void_p] + [C.c_void_p] * 7
+        L.refdrv_dl_set_grant_type2.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_int,
+                                                C.c_void_p, C.c_void_p]
+        L.refdrv_dl_encode_pdsch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.refdrv_dl_decode_pdsch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.refdrv_dl_pmch_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_uint16, C.c_uint32, C.c_void_p]
         L.refdrv_dl_pbch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -111,6 +116,29 @@ class RefDl:
 
     def chest(self):
         return self.L.refdrv_dl_chest(self.h)
+
+    def set_grant_type2(self, tti, cfi, rnti, mcs, L_crb, RB_start, distributed=False, n_gap2=False, rv=0):
+        tbs, nre = C.c_int(0), C.c_uint32(0)
+        rc = self.L.refdrv_dl_set_grant_type2(self.h, tti, cfi, rnti, L_crb, RB_start, int(distributed), int(n_gap2), mcs, rv, C.byref(tbs), C.byref(nre))
+        assert rc == 0
+        return tbs.value, nre.value
+
+    def set_prb_masks(self, slot0, slot1):
+        a, b = np.ascontiguousarray(slot0, np.uint8), np.ascontiguousarray(slot1, np.uint8)
+        assert a.size == self.nof_prb and b.size == self.nof_prb
+        return self.L.refdrv_dl_set_prb_masks(self.h, a.ctypes.data, b.ctypes.data)
+
+    def grant_info(self):
+        m0, m1 = np.zeros(self.nof_prb, np.uint8), np.zeros(self.nof_prb, np.uint8)
+        mod, tbs, nre, nbits, rv = C.c_int(0), C.c_int(0), C.c_uint32(0), C.c_uint32(0), C.c_int(0)
+        self.L.refdrv_dl_grant_info(self.h, m0.ctypes.data, m1.ctypes.data, C.byref(mod), C.byref(tbs), C.byref(nre), C.byref(nbits), C.byref(rv))
+        return {"prb_mask": np.stack([m0, m1]), "mod": mod.value, "tbs": tbs.value, "nof_re": nre.value, "nof_bits": nbits.value, "rv": rv.value}
+
+    def encode_pdsch(self, data):
+        grid = np.zeros(self.grid_len, np.complex64)
+        d = np.ascontiguousarray(data, np.uint8)
+        assert self.L.refdrv_dl_encode_pdsch(self.h, d.ctypes.data, grid.ctypes.data) == 0
+        return grid
 
     def decode_pdsch(self, new_data=True):
         it = C.c_float(0)
