@@ -410,6 +410,52 @@ def test_tdec_run_all(hp, K):
     dec.free()
 
 
+@pytest.mark.parametrize("K,llr8", [(6144, False), (6144, True), (800, False), (400, False), (40, False), (5824, False)])
+def test_tdec_full_object_boundaries(hp, K, llr8):
+    """The decoder object filled to the last block it was created for, with caller strides that are odd / not multiples of anything:
+    every per-wave slab (work arrays, x/y scratch, beta) and every caller buffer is indexed up to its last element. An index that
+    runs past a block's share shows as a wrong block, a changed guard word, or a fault here rather than in a benchmark run (round 1
+    has one unexplained `Memory access fault` on record from an uncommitted decoder build). max_nof_cb = 61 is neither a
+    multiple of 8 (the generic kernel packs 8 blocks per wave) nor of the wave count of a CU."""
+    L = hp.lib()
+    rng = np.random.default_rng(K + 17)
+    ncb, nit = 61, 3
+    dec = hp.Tdec(K, ncb)  # exactly this length, exactly this many blocks: no slack in any slab
+    bits = rng.integers(0, 2, (ncb, K)).astype(np.uint8)
+    enc = np.zeros((ncb, 3 * K + 12), np.uint8)
+    for i in range(ncb):
+        oracle().orc_tcod_encode_bits(p(bits[i]), p(enc[i]), K)
+    llr = _noisy_llr(rng, enc, 1.5, 20 if llr8 else 300)
+    if llr8:
+        llr = np.clip(llr, -127, 127).astype(np.int8)
+    in_stride, out_stride, G = 3 * K + 12 + 5, K // 8 + 3, 64  # odd strides; G guard elements around every caller buffer
+    x = np.full(G + ncb * in_stride + G, 77, llr.dtype)
+    for i in range(ncb):
+        x[G + i * in_stride:G + i * in_stride + 3 * K + 12] = llr[i]
+    din = hp.DevBuf.from_host(x)
+    dout, dit, dok = hp.DevBuf.from_host(np.full(G + ncb * out_stride + G, 0xA5, np.uint8)), hp.DevBuf.from_host(np.full(ncb + 2 * G, 0xDEADBEEF, np.uint32)), \
+        hp.DevBuf.from_host(np.full(ncb + 2 * G, 0x5A, np.uint8))
+    isz = x.dtype.itemsize
+    fn = L.srslte_hip_tdec_run_batch_8bit if llr8 else L.srslte_hip_tdec_run_batch
+    rc = fn(dec.h, din.ptr + G * isz, in_stride, 0, K, ncb, nit, 0, 0, dout.ptr + G, out_stride, dit.ptr + 4 * G, dok.ptr + G, None)
+    assert rc == 0
+    hp.sync()
+    out, it, ok = dout.to_host(np.uint8), dit.to_host(np.uint32), dok.to_host(np.uint8)
+    assert np.all(out[:G] == 0xA5) and np.all(out[G + ncb * out_stride:] == 0xA5) and np.all(it[:G] == 0xDEADBEEF) and np.all(it[G + ncb:] == 0xDEADBEEF)
+    assert np.all(ok[:G] == 0x5A) and np.all(ok[G + ncb:] == 0x5A) and np.all(it[G:G + ncb] == nit)
+    assert np.array_equal(din.to_host(x.dtype), x)  # the input is read-only
+    for i in range(ncb):
+        row = out[G + i * out_stride:G + (i + 1) * out_stride]
+        ref = np.zeros(K // 8, np.uint8)
+        if llr8:
+            assert oracle().orc_tdec_run_8bit(p(np.ascontiguousarray(llr[i])), False, K, nit, p(ref), None) == 0
+        else:
+            assert oracle().orc_tdec_run(p(np.ascontiguousarray(llr[i])), False, K, nit, p(ref), None) == 0
+        assert np.array_equal(row[:K // 8], ref), (K, i)
+        assert np.all(row[K // 8:] == 0xA5)  # the bytes between two blocks' outputs stay untouched
+    dec.free()
+
+
 @pytest.mark.parametrize("K,W", [(504, 0), (504, 16), (1008, 8), (1008, 0), (6144, 8)])
 def test_tdec_manual_numerics(hp, K, W):
     """srslte_tdec_init_manual: force generic / sse16 / avx16 numerics on any K (turbodecoder.c:168-215)."""
