@@ -32,7 +32,12 @@ TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/ph
 TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
 
 .PHONY: ref_hip
-ref_hip: $(TEST_BIN)
+ref_hip: $(TEST_BIN) $(HOUT)/dropin_log_test
+
+# this repo's own caller: a registered log handler must receive the library's diagnostics (phy_logger.c:37-52)
+$(HOUT)/dropin_log_test: dropin_log_test.c $(HOUT)/libsrslte_upper.a $(HIPLIB)/libsrslte_phy_hip.so
+	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) $< -o $@ $(HOUT)/libsrslte_upper.a -L$(HIPLIB) -lsrslte_phy_hip \
+	    -Wl,-rpath,'$$ORIGIN/../../../srslte-emane_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lstdc++ -lm -lpthread
 
 $(HOBJ)/%.o: $(RLIB)/src/phy/%.c
 	@mkdir -p $(dir $@)

@@ -1,5 +1,29 @@
 // Device plumbing of the C ABI: lets a plain-C host (or ctypes) drive libsrslte_phy_hip.so without HIP headers.
 #include "phy_hip_internal.hpp"
+#include <stdarg.h>
+#include <string.h>
+
+extern "C" {
+// the reference's logging hook, present only when the program also links lib/src/phy/utils/phy_logger.c (phy_logger.h:41-47, debug.h:46)
+extern int handler_registered __attribute__((weak));
+void       srslte_phy_log_print(int log_level, const char* format, ...) __attribute__((weak));
+}
+
+void hip_log(const char* fmt, ...)
+{
+  char    buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (&handler_registered && handler_registered && srslte_phy_log_print) {
+    size_t n = strlen(buf);
+    if (n && buf[n - 1] == '\n') buf[n - 1] = 0; // the reference's messages carry no newline when they go to a handler
+    srslte_phy_log_print(2 /* LOG_LEVEL_ERROR_S */, "%s", buf);
+  } else {
+    fputs(buf, stderr);
+  }
+}
 
 extern "C" int srslte_hip_device_count(void)
 {
@@ -18,7 +42,7 @@ extern "C" void* srslte_hip_malloc(size_t nbytes)
 {
   void* p = nullptr;
   if (hipMalloc(&p, nbytes ? nbytes : 1) != hipSuccess) {
-    fprintf(stderr, "[srslte_hip] hipMalloc(%zu) failed\n", nbytes);
+    hip_log("[srslte_hip] hipMalloc(%zu) failed\n", nbytes);
     return nullptr;
   }
   return p;

@@ -526,7 +526,7 @@ struct srslte_hip_chest_dl {
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
 {
   if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || (nof_ports != 1 && nof_ports != 2 && nof_ports != 4)) {
-    fprintf(stderr, "[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1, 2 or 4 ports\n", cell_id,
+    hip_log("[srslte_hip] chest_dl: unsupported cell (id=%u prb=%u ports=%u cp_norm=%d); 1, 2 or 4 ports\n", cell_id,
             nof_prb, nof_ports, cp_is_norm);
     return nullptr;
   }
@@ -570,7 +570,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
       hipMalloc((void**)&q->d_noise_state, sizeof(float) * 16) != hipSuccess || hipMemset(q->d_noise_state, 0, sizeof(float) * 16) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess /* null-stream memset vs the callers' non-blocking streams */ ||
       hipMemcpy(q->d_pilots, pil.data(), sizeof(cf32) * pil.size(), hipMemcpyHostToDevice) != hipSuccess) {
-    fprintf(stderr, "[srslte_hip] chest_dl: device allocation failed\n");
+    hip_log("[srslte_hip] chest_dl: device allocation failed\n");
     delete q;
     return nullptr;
   }
@@ -628,17 +628,17 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
 {
   if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4 || cfg->mbsfn_area_id > 255) return SRSLTE_ERROR_INVALID_INPUTS;
   if (!q->d_mbsfn[cfg->mbsfn_area_id]) {
-    fprintf(stderr, "[srslte_hip] chest_dl: MBSFN area id=%d not initialized\n", cfg->mbsfn_area_id); // chest_dl.c:729-731
+    hip_log("[srslte_hip] chest_dl: MBSFN area id=%d not initialized\n", cfg->mbsfn_area_id); // chest_dl.c:729-731
     return SRSLTE_ERROR;
   }
   if (q->nof_ports > 2 || (!cfg->interpolate_subframe && d_ce)) {
     // upstream then interpolates in time from symbols nothing wrote (chest_dl.c:430-433,:474-478; ports 2/3 leave symbol 0 unwritten)
-    fprintf(stderr, "[srslte_hip] chest_dl: MBSFN subframes need interpolate_subframe and a 1- or 2-port cell\n");
+    hip_log("[srslte_hip] chest_dl: MBSFN subframes need interpolate_subframe and a 1- or 2-port cell\n");
     return SRSLTE_ERROR;
   }
   if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && cfg->noise_alg != 0 && d_ce) {
-    fprintf(stderr, "[srslte_hip] chest_dl: the automatic Gauss filter needs the REFS noise estimate in an MBSFN subframe\n");
+    hip_log("[srslte_hip] chest_dl: the automatic Gauss filter needs the REFS noise estimate in an MBSFN subframe\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -673,13 +673,13 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   if (cfg->noise_alg < 0 || cfg->noise_alg > 2) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->noise_alg != 0 && cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && nof_sf > 1 && d_ce) {
     // the automatic Gauss filter of a subframe then depends on the estimates of the subframes before it: a sequential chain
-    fprintf(stderr, "[srslte_hip] chest_dl: the automatic Gauss filter with the PSS / EMPTY noise algorithms needs one subframe per call\n");
+    hip_log("[srslte_hip] chest_dl: the automatic Gauss filter with the PSS / EMPTY noise algorithms needs one subframe per call\n");
     return SRSLTE_ERROR;
   }
   if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
   if (q->nof_ports == 4 && cfg->interpolate_subframe && d_ce) {
     // upstream then copies symbol 0 of the ports-2/3 estimates, which nothing wrote, over the subframe (chest_dl.c:467-471): no defined result
-    fprintf(stderr, "[srslte_hip] chest_dl: interpolate_subframe is not defined for the ports 2/3 of a 4-port cell\n");
+    hip_log("[srslte_hip] chest_dl: interpolate_subframe is not defined for the ports 2/3 of a 4-port cell\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -910,7 +910,7 @@ struct srslte_hip_chest_ul {
 extern "C" srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, uint32_t nof_prb, int cp_is_norm, const srslte_hip_dmrs_pusch_cfg_t* cfg)
 { // srslte_chest_ul_init + srslte_chest_ul_set_cell (chest_ul.c:51-194, refsignal_ul.c:206-238) + srslte_chest_ul_pregen
   if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || !cp_is_norm || !cfg || cfg->cyclic_shift >= 8 || cfg->delta_ss >= 30) {
-    fprintf(stderr, "[srslte_hip] chest_ul: unsupported cell / DMRS configuration (id=%u prb=%u cp_norm=%d)\n", cell_id, nof_prb, cp_is_norm);
+    hip_log("[srslte_hip] chest_ul: unsupported cell / DMRS configuration (id=%u prb=%u cp_norm=%d)\n", cell_id, nof_prb, cp_is_norm);
     return nullptr;
   }
   auto* q    = new srslte_hip_chest_ul();
@@ -1004,7 +1004,7 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q
 {
   if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
   if (!srslte_hip_dft_precoding_valid_prb(L_prb)) {
-    fprintf(stderr, "[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
+    hip_log("[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
     return SRSLTE_ERROR_INVALID_INPUTS;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;

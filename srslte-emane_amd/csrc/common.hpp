@@ -8,12 +8,19 @@
 #define SRSLTE_ERROR -1
 #define SRSLTE_ERROR_INVALID_INPUTS -2
 
-// Every HIP failure surfaces as SRSLTE_ERROR with a diagnostic on stderr (config.h:58-66 convention).
+// Diagnostics. The reference's ERROR() macro (lib/include/srslte/phy/utils/debug.h:75-89) prints to stderr unless the application has
+// registered a handler with srslte_phy_log_register_handler (utils/phy_logger.c:37-52), in which case the text goes to that callback.
+// hip_log does the same: when this library is linked into a program that also carries the reference's phy_logger.c (the link-time drop-in
+// of INTEGRATION.md §1), `handler_registered` and `srslte_phy_log_print` resolve to the reference's and a registered handler receives
+// every message; on its own the library has neither symbol (weak, null) and prints to stderr.
+void hip_log(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// Every HIP failure surfaces as SRSLTE_ERROR with a diagnostic through hip_log (config.h:58-66 convention).
 #define HIP_TRY(expr)                                                                                   \
   do {                                                                                                  \
     hipError_t e__ = (expr);                                                                            \
     if (e__ != hipSuccess) {                                                                            \
-      fprintf(stderr, "[srslte_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+      hip_log("[srslte_hip] %s failed: %s (%s:%d)\n", #expr, hipGetErrorString(e__), __FILE__, __LINE__);    \
       return SRSLTE_ERROR;                                                                              \
     }                                                                                                   \
   } while (0)

@@ -8,11 +8,7 @@
 #include <string.h>
 #include <strings.h>
 
-#define ERROR(...)                            \
-  do {                                        \
-    fprintf(stderr, "[srslte_hip] " __VA_ARGS__); \
-    fprintf(stderr, "\n");                    \
-  } while (0)
+#define ERROR(fmt, ...) hip_log("[srslte_hip] " fmt "\n", ##__VA_ARGS__)
 
 namespace {
 

@@ -103,7 +103,7 @@ int demod_launch(int type, int mod, const void* d_sym, void* d_llr, int nsym, in
                  hipStream_t st)
 {
   if (mod < 0 || mod > 4) {
-    fprintf(stderr, "[srslte_hip] Invalid modulation %d\n", mod);
+    hip_log("[srslte_hip] Invalid modulation %d\n", mod);
     return SRSLTE_ERROR;
   }
   if (!d_sym || !d_llr || nsym < 0 || ncalls < 0) return SRSLTE_ERROR_INVALID_INPUTS;

@@ -109,7 +109,7 @@ extern "C" int srslte_hip_tc_interl_LTE_gen_interl(uint16_t* forward, uint16_t* 
   const int idx = lte_cb_index(long_cb);
   if (!forward || !reverse) return SRSLTE_ERROR_INVALID_INPUTS;
   if (idx < 0 || lte_qpp_table[idx].K != long_cb || (interl_win > 1 && long_cb % interl_win)) {
-    fprintf(stderr, "[srslte_hip] Can't find long_cb=%u in valid TC CB table\n", long_cb);
+    hip_log("[srslte_hip] Can't find long_cb=%u in valid TC CB table\n", long_cb);
     return SRSLTE_ERROR;
   }
   std::vector<uint16_t> f, r;

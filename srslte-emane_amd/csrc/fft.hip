@@ -387,7 +387,7 @@ static size_t fft_lds_bytes(const FftFactors& f) { return (f.inplace ? 1 : 2) * 
 int fft_get_plan(int N, FftFactors* f, const cf32** d_tw)
 {
   if (N < 1 || N > FFT_MAX_N) {
-    fprintf(stderr, "[srslte_hip] unsupported DFT size %d (1..%d)\n", N, FFT_MAX_N);
+    hip_log("[srslte_hip] unsupported DFT size %d (1..%d)\n", N, FFT_MAX_N);
     return SRSLTE_ERROR_INVALID_INPUTS;
   }
   int dev = 0;
@@ -424,7 +424,7 @@ extern "C" srslte_hip_ofdm_t* srslte_hip_ofdm_create(int nof_prb, int cp_is_norm
 {
   const int N = lte_symbol_sz(nof_prb);
   if (N < 0) {
-    fprintf(stderr, "[srslte_hip] Error: Invalid nof_prb=%d\n", nof_prb);
+    hip_log("[srslte_hip] Error: Invalid nof_prb=%d\n", nof_prb);
     return nullptr;
   }
   auto* q = new srslte_hip_ofdm();
@@ -475,12 +475,12 @@ extern "C" int srslte_hip_ofdm_set_mbsfn(srslte_hip_ofdm_t* q, int enable, int n
     return SRSLTE_SUCCESS;
   }
   if (q->g.nsym != 12 || non_mbsfn_region < 1 || non_mbsfn_region > 2) {
-    fprintf(stderr, "[srslte_hip] MBSFN layout needs an extended-CP object and non_mbsfn_region 1 or 2 (got %d symbols, region %d)\n", q->g.nsym,
+    hip_log("[srslte_hip] MBSFN layout needs an extended-CP object and non_mbsfn_region 1 or 2 (got %d symbols, region %d)\n", q->g.nsym,
             non_mbsfn_region);
     return SRSLTE_ERROR;
   }
   if (q->d_shift) {
-    fprintf(stderr, "[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
+    hip_log("[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
     return SRSLTE_ERROR;
   }
   const int N = q->g.f.N, ext = lte_cp_len_ext(N);
@@ -502,7 +502,7 @@ extern "C" int srslte_hip_ofdm_set_freq_shift(srslte_hip_ofdm_t* q, float freq_s
 { // ofdm.c:360-378: builds the shift table and disables DC handling
   if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
   if (q->mbsfn) {
-    fprintf(stderr, "[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
+    hip_log("[srslte_hip] MBSFN layout with a frequency shift is not supported\n");
     return SRSLTE_ERROR;
   }
   const int         N = q->g.f.N, len = q->g.cp_max + N;
@@ -599,7 +599,7 @@ extern "C" int srslte_hip_dft_precoding_valid_prb(uint32_t nof_prb)
 extern "C" int srslte_hip_dft_precoding_batch(const void* d_in, void* d_out, uint32_t nof_prb, uint32_t nof_symbols, int forward, void* stream)
 { // dft_precoding.c:100-113: nof_symbols DFTs of 12*nof_prb points, 1/sqrt(N)
   if (!srslte_hip_dft_precoding_valid_prb(nof_prb)) {
-    fprintf(stderr, "[srslte_hip] Error invalid number of PRB (%u)\n", nof_prb);
+    hip_log("[srslte_hip] Error invalid number of PRB (%u)\n", nof_prb);
     return SRSLTE_ERROR;
   }
   const int N = 12 * (int)nof_prb;

@@ -786,14 +786,14 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4 || cfg->nof_ports > 4 ||
       cfg->nof_ports == 3 || (cfg->nof_ports == 4 && cfg->chest_cfg.interpolate_subframe)) {
-    fprintf(stderr, "[srslte_hip] dl_rx: invalid configuration\n");
+    hip_log("[srslte_hip] dl_rx: invalid configuration\n");
     return nullptr;
   }
   auto* q = new srslte_hip_dl_rx();
   memset(q, 0, sizeof(*q));
   q->cfg = *cfg;
   if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
-    fprintf(stderr, "[srslte_hip] dl_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    hip_log("[srslte_hip] dl_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
     delete q;
     return nullptr;
   }
@@ -875,7 +875,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   ok = ok && hipMemset(q->d_cb_ok, 0, (size_t)B * C) == hipSuccess && hipMemset(q->d_w, 0, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMemset(q->d_cb_bytes, 0, (size_t)(K / 8) * B * C) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   if (!ok) {
-    fprintf(stderr, "[srslte_hip] dl_rx: initialisation failed\n");
+    hip_log("[srslte_hip] dl_rx: initialisation failed\n");
     srslte_hip_dl_rx_destroy(q);
     return nullptr;
   }
@@ -1166,7 +1166,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
   if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.csi_enable) {
-    fprintf(stderr, "[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs, no CSI weighting\n");
+    hip_log("[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs, no CSI weighting\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -1200,7 +1200,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     srslte_hip_cbsegm_t seg;
     if (gr.mod < 1 || gr.mod > 4 || gr.cfi < 1 || gr.cfi > 3 || gr.rv > 3 || gr.tbs > q->cfg.tbs || (gr.tbs % 8) || srslte_hip_cbsegm(&seg, gr.tbs) || seg.F ||
         seg.C2 || seg.C > g->Cmax) {
-      fprintf(stderr, "[srslte_hip] dl_rx grants: subframe %u: unsupported grant (mod %d, tbs %u, cfi %u, rv %u)\n", b, gr.mod, gr.tbs, gr.cfi, gr.rv);
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported grant (mod %d, tbs %u, cfi %u, rv %u)\n", b, gr.mod, gr.tbs, gr.cfi, gr.rv);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     bool any0 = false, below1 = false;
@@ -1237,7 +1237,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     }
     const uint32_t Qm = 2 * (uint32_t)gr.mod, K = seg.K1, C = seg.C;
     if (nre == 0 || nre * Qm < C * Qm) {
-      fprintf(stderr, "[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     sd.nof_re = (int)nre; sd.mod = gr.mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)gr.tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
@@ -1544,14 +1544,14 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->max_iterations == 0 || cfg->L_prb < 1 ||
       cfg->n_prb + cfg->L_prb > cfg->nof_prb || !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
-    fprintf(stderr, "[srslte_hip] ul_rx: invalid configuration\n");
+    hip_log("[srslte_hip] ul_rx: invalid configuration\n");
     return nullptr;
   }
   auto* q = new srslte_hip_ul_rx();
   memset(q, 0, sizeof(*q));
   q->cfg = *cfg;
   if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
-    fprintf(stderr, "[srslte_hip] ul_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    hip_log("[srslte_hip] ul_rx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
     delete q;
     return nullptr;
   }
@@ -1621,7 +1621,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        Qp_ri >= 0 && (uint32_t)Qp_ri < nof_re;
   ok = ok && hipDeviceSynchronize() == hipSuccess; // the memsets above ran on the null stream
   if (!ok) {
-    fprintf(stderr, "[srslte_hip] ul_rx: initialisation failed\n");
+    hip_log("[srslte_hip] ul_rx: initialisation failed\n");
     srslte_hip_ul_rx_destroy(q);
     return nullptr;
   }
@@ -1915,14 +1915,14 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->L_prb < 1 || cfg->n_prb + cfg->L_prb > cfg->nof_prb ||
       !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
-    fprintf(stderr, "[srslte_hip] ul_tx: invalid configuration\n");
+    hip_log("[srslte_hip] ul_tx: invalid configuration\n");
     return nullptr;
   }
   auto* q = new srslte_hip_ul_tx();
   memset(q, 0, sizeof(*q));
   q->cfg = *cfg;
   if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
-    fprintf(stderr, "[srslte_hip] ul_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    hip_log("[srslte_hip] ul_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
     delete q;
     return nullptr;
   }
@@ -1934,7 +1934,7 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
   g.nsymb = (int)nsymb;
   g.ack.O = (int)cfg->ack_len; g.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
   if (g.ack.Qprime < 0) {
-    fprintf(stderr, "[srslte_hip] ul_tx: invalid HARQ-ACK configuration\n");
+    hip_log("[srslte_hip] ul_tx: invalid HARQ-ACK configuration\n");
     delete q;
     return nullptr;
   }
@@ -1942,7 +1942,7 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
   g.par_stride = (int)((K / 4 + 1 + 15) & ~15u); g.rm_len = (int)(3 * K + 12);
   g.ri.O = (int)cfg->ri_len; g.ri.Qprime = pusch_ack_qprime(cfg->ri_len, cfg->I_offset_ri, cfg->L_prb, nsymb, C * K, true);
   if (g.ri.Qprime < 0 || (uint32_t)g.ri.Qprime >= nof_re) {
-    fprintf(stderr, "[srslte_hip] ul_tx: invalid rank-indication configuration\n");
+    hip_log("[srslte_hip] ul_tx: invalid rank-indication configuration\n");
     delete q;
     return nullptr;
   }
@@ -1986,7 +1986,7 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
        hipMalloc((void**)&q->d_z, sizeof(cf32) * (size_t)nof_re * B) == hipSuccess &&
        hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B) == hipSuccess;
   if (!ok) {
-    fprintf(stderr, "[srslte_hip] ul_tx: initialisation failed\n");
+    hip_log("[srslte_hip] ul_tx: initialisation failed\n");
     srslte_hip_ul_tx_destroy(q);
     return nullptr;
   }
@@ -2189,14 +2189,14 @@ static int dl_tx_rm_table(srslte_hip_dl_tx_t* q, uint32_t rv)
 extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg)
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->nof_ports > 4 || cfg->nof_ports == 3 || cfg->nof_prb < 6 || cfg->nof_prb > 110) {
-    fprintf(stderr, "[srslte_hip] dl_tx: invalid configuration\n");
+    hip_log("[srslte_hip] dl_tx: invalid configuration\n");
     return nullptr;
   }
   auto* q = new srslte_hip_dl_tx();
   memset(q, 0, sizeof(*q));
   q->cfg = *cfg;
   if (srslte_hip_cbsegm(&q->seg, cfg->tbs) || q->seg.F || q->seg.C2 || (cfg->tbs % 8)) {
-    fprintf(stderr, "[srslte_hip] dl_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
+    hip_log("[srslte_hip] dl_tx: TBS %u needs filler bits or two code-block sizes; not supported on device yet\n", cfg->tbs);
     delete q;
     return nullptr;
   }
@@ -2258,7 +2258,7 @@ extern "C" srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cf
        hipMalloc((void**)&q->d_y, sizeof(cf32) * (size_t)max_re * B * npt) == hipSuccess &&
        hipMalloc((void**)&q->d_grid, sizeof(cf32) * (size_t)glen * B * npt) == hipSuccess;
   if (!ok) {
-    fprintf(stderr, "[srslte_hip] dl_tx: initialisation failed\n");
+    hip_log("[srslte_hip] dl_tx: initialisation failed\n");
     srslte_hip_dl_tx_destroy(q);
     return nullptr;
   }

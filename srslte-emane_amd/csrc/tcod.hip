@@ -161,7 +161,7 @@ static int tcod_perm(uint32_t long_cb, uint16_t** d_perm_out)
 {
   const int idx = lte_cb_index(long_cb);
   if (idx < 0 || lte_qpp_table[idx].K != long_cb) {
-    fprintf(stderr, "[srslte_hip] Invalid CB size %u\n", long_cb); // turbocoder.c:89-93
+    hip_log("[srslte_hip] Invalid CB size %u\n", long_cb); // turbocoder.c:89-93
     return SRSLTE_ERROR;
   }
   int dev = 0;

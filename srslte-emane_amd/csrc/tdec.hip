@@ -1168,7 +1168,7 @@ extern "C" uint32_t srslte_hip_tdec_input_len(uint32_t K, int sb_layout) { retur
 extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint32_t max_nof_cb)
 {
   if (max_long_cb < 40 || max_long_cb > 6144 || max_nof_cb == 0) {
-    fprintf(stderr, "[srslte_hip] tdec: invalid max_long_cb=%u / max_nof_cb=%u\n", max_long_cb, max_nof_cb);
+    hip_log("[srslte_hip] tdec: invalid max_long_cb=%u / max_nof_cb=%u\n", max_long_cb, max_nof_cb);
     return nullptr;
   }
   auto* q         = new srslte_hip_tdec();
@@ -1190,7 +1190,7 @@ extern "C" srslte_hip_tdec_t* srslte_hip_tdec_create(uint32_t max_long_cb, uint3
       hipMalloc((void**)&q->d_zeros, sizeof(pk_t) * (size_t)max_long_cb) != hipSuccess ||
       hipMemset(q->d_zeros, 0, sizeof(pk_t) * (size_t)max_long_cb) != hipSuccess ||
       hipDeviceSynchronize() != hipSuccess /* the memset ran on the null stream; callers launch on non-blocking streams */) {
-    fprintf(stderr, "[srslte_hip] tdec: device allocation failed\n");
+    hip_log("[srslte_hip] tdec: device allocation failed\n");
     if (q->d_work) (void)hipFree(q->d_work);
     delete q;
     return nullptr;
@@ -1268,12 +1268,12 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   const int16_t* d_input = (const int16_t*)d_input_any;
   if (!q || !d_input || !d_output) return SRSLTE_ERROR_INVALID_INPUTS;
   if (K > q->max_long_cb) {
-    fprintf(stderr, "[srslte_hip] TDEC was initialized for max_long_cb=%u\n", q->max_long_cb); // turbodecoder.c:524-527
+    hip_log("[srslte_hip] TDEC was initialized for max_long_cb=%u\n", q->max_long_cb); // turbodecoder.c:524-527
     return SRSLTE_ERROR;
   }
   const int idx = lte_cb_index(K);
   if (idx < 0 || lte_qpp_table[idx].K != K) {
-    fprintf(stderr, "[srslte_hip] Invalid CB length %u\n", K); // turbodecoder.c:531-534
+    hip_log("[srslte_hip] Invalid CB length %u\n", K); // turbodecoder.c:531-534
     return SRSLTE_ERROR;
   }
   if (nof_cb > q->max_nof_cb || nof_iterations == 0 || out_stride < K / 8 || in_stride < srslte_hip_tdec_input_len(K, sb_layout) ||

@@ -91,3 +91,11 @@ def test_phy_dl_test_headline_and_latency():
     os.makedirs(os.path.join(OUT, "r2"), exist_ok=True)
     with open(os.path.join(OUT, "r2", "dropin_phy_dl_test_100prb_mcs28.txt"), "w") as f:
         f.write(out[-1500:] + "\nUE receive path through the single-call API: %.0f us per subframe\n" % us)
+
+
+@need_bin
+def test_registered_log_handler_receives_diagnostics():
+    """srslte_phy_log_register_handler (utils/phy_logger.c:37-52): with the library linked next to the reference's phy_logger.c its
+    diagnostics go to the registered callback like the reference's ERROR() does (debug.h:75-89). oracle/dropin_log_test.c."""
+    rc, out = run("dropin_log_test", [])
+    assert rc == 0, out
