@@ -191,8 +191,16 @@ def test_dft_plan_options(N):
             assert np.abs(z / scale - x).max() < 1e-4 * np.abs(x).max() * 10
         L.srslte_dft_plan_free(C.byref(fwd))
         L.srslte_dft_plan_free(C.byref(bwd))
+    # FFTW plans any length (dft_fftw.c:167-191): so does this library - lengths without a 2/3/5 plan go to the direct-sum kernel
+    odd = DftPlan()
+    assert L.srslte_dft_plan_c(C.byref(odd), 7 * 12, 0) == 0
+    xo, yo, ro = x[:84].copy(), np.zeros(84, np.complex64), np.zeros(84, np.complex64)
+    L.srslte_dft_run_c(C.byref(odd), p(xo), p(yo))
+    oracle().orc_dft_exact(p(xo), p(ro), 84, 1)
+    assert close(yo, ro)
+    L.srslte_dft_plan_free(C.byref(odd))
     bad = DftPlan()
-    assert L.srslte_dft_plan_c(C.byref(bad), 7 * 12, 0) == -1
+    assert L.srslte_dft_plan_c(C.byref(bad), 0, 0) != 0 and L.srslte_dft_plan_c(C.byref(bad), 1 << 20, 0) != 0
 
 
 def test_dft_precoding_object():
