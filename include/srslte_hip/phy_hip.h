@@ -279,6 +279,8 @@ typedef struct {
   uint32_t ri_len;         /* 0..2 rank-indication bits on the PUSCH (srslte_cqi_cfg_t.ri_len, sch.c:968-979,:1110-1129): their symbols are
                             * left out by the channel interleaver and the UL-SCH is rate-matched to the rest */
   uint32_t I_offset_ri;    /* index into 36.213 Table 8.6.3-2 (srslte_uci_offset_cfg_t.I_offset_ri) */
+  uint32_t cqi_len, I_offset_cqi; /* CQI / PMI report of cqi_len bits (srslte_cqi_size of uci_cfg.cqi, up to 64) multiplexed in front of the UL-SCH
+                                     with srslte_uci_offset_cfg_t.I_offset_cqi (sch.c:1031-1060,:1133-1160, uci.c:264-494); 0 = none */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -289,6 +291,9 @@ int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);
 const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q); /* the same for the rank indication (srslte_uci_value_t.ri in [b][0]) */
+/* the CQI reports of the last batch: [max_batch][64] bits (one per byte, srslte_cqi_value_pack order), then [max_batch] flags
+ * (srslte_uci_value_t.cqi.data_crc: always 1 up to 11 bits, the CRC-8 result above; bits are only written when the flag is 1) */
+const uint8_t* srslte_hip_ul_rx_cqi(const srslte_hip_ul_rx_t* q);
 /* intermediate device buffers of the last call, for parity tests: 0 grid, 1 ce, 2 chest_ul res, 3 d (after de-precoding), 4 g (LLRs after
  * the de-interleaver), 5 w, 6 cb iters, 7 cb ok, 8 cb bytes, 9 z (equalised) */
 const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q, int which);
@@ -310,6 +315,7 @@ typedef struct {
   int      shortened;      /* as in srslte_hip_ul_rx_cfg_t */
   uint32_t ack_len, I_offset_ack; /* as in srslte_hip_ul_rx_cfg_t (srslte_ulsch_encode's uci_cfg, sch.c:1168-1215) */
   uint32_t ri_len, I_offset_ri;   /* as in srslte_hip_ul_rx_cfg_t (sch.c:1110-1129) */
+  uint32_t cqi_len, I_offset_cqi; /* as in srslte_hip_ul_rx_cfg_t (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);
@@ -322,6 +328,10 @@ int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint3
 /* HARQ-ACK values d_ack and rank-indication bits d_ri, each [nof_sf][2] device bytes, each required exactly when configured */
 int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
                                uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
+/* ... and the CQI / PMI report d_cqi [nof_sf][64] device bytes (one bit each, the first cfg.cqi_len used: srslte_cqi_value_pack's output),
+ * required exactly when cfg.cqi_len > 0 (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
+int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                   const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
  * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
 const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);

@@ -228,4 +228,10 @@ int  orc_uci_ri_extract(int16_t* q_llr, const uint8_t* c_seq, uint8_t ri[2], uin
 int  orc_ulsch_interleaver_lut(uint32_t Qm, uint32_t nof_re, uint32_t nof_symb, uint32_t Qprime_ri, uint32_t* lut);
 void orc_ulsch_deinterleave(const int16_t* q_llr, const uint32_t* lut, int16_t* g_llr, uint32_t n);
 
+/* ---------------------------------------------------------------- CQI / PMI report on the PUSCH (orc_cqi.c; uci.c:264-494) */
+int orc_uci_cqi_qprime(uint32_t O_cqi, uint32_t I_offset_cqi, uint32_t L_prb, uint32_t nof_symb, uint32_t K_segm, uint32_t Qprime_ri);
+int orc_uci_cqi_encode(const uint8_t* cqi, uint32_t O, uint8_t* q_bits, uint32_t Q);
+int orc_uci_cqi_decode(int16_t* q_llr, uint32_t Q, uint32_t O, uint8_t* cqi, uint8_t* crc_ok);
+void orc_viterbi37_tb_f(const float* sym, uint32_t F, uint8_t* out); /* srslte_viterbi_decode_f, tail-biting K = 7 rate 1/3 */
+
 #endif

@@ -539,20 +539,23 @@ class UlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
                 ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
-                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
+                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32)]
 
 
 class UlRx:
     """Batched PUSCH receive chain (enb_ul.c + pusch.c:423-520 + the UL-SCH part of sch.c:991-1066)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
-                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
+                 group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0,
+                 cqi_len=0, I_offset_cqi=0):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi)
         L = lib()
         L.srslte_hip_ul_rx_ri.restype = C.c_void_p
         L.srslte_hip_ul_rx_ri.argtypes = [C.c_void_p]
+        L.srslte_hip_ul_rx_cqi.restype = C.c_void_p
+        L.srslte_hip_ul_rx_cqi.argtypes = [C.c_void_p]
         L.srslte_hip_ul_rx_create.restype = C.c_void_p
         L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
         L.srslte_hip_ul_rx_destroy.argtypes = [C.c_void_p]
@@ -590,6 +593,13 @@ class UlRx:
         _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, lib().srslte_hip_ul_rx_ri(self.h), out.nbytes), "memcpy_d2h")
         return out.reshape(-1, 2)[:self.last_nof_sf, :max(self.cfg.ri_len, 1)]
 
+    def cqi(self):
+        """CQI reports of the last decode(): bits [nof_sf][cqi_len] and the CRC flags [nof_sf] (srslte_uci_value_t.cqi, .cqi.data_crc)."""
+        out = np.empty(65 * self.max_batch, np.uint8)
+        _check(lib().srslte_hip_memcpy_d2h(out.ctypes.data, lib().srslte_hip_ul_rx_cqi(self.h), out.nbytes), "memcpy_d2h")
+        n = self.last_nof_sf
+        return out[:64 * self.max_batch].reshape(-1, 64)[:n, :self.cfg.cqi_len], out[64 * self.max_batch:][:n]
+
     def debug(self, which, dtype, count):
         ptr = lib().srslte_hip_ul_rx_debug_buffer(self.h, which)
         out = np.empty(count, dtype)
@@ -605,7 +615,8 @@ class UlRx:
 class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
-                ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
+                ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32),
+                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32)]
 
 
 class UlTx:
@@ -613,11 +624,13 @@ class UlTx:
     srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
-                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
+                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0, cqi_len=0, I_offset_cqi=0):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi)
         L = lib()
+        L.srslte_hip_ul_tx_batch_uci_cqi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                     C.c_void_p, C.c_void_p]
         L.srslte_hip_ul_tx_batch_uci.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         L.srslte_hip_ul_tx_create.restype = C.c_void_p
         L.srslte_hip_ul_tx_create.argtypes = [C.POINTER(UlTxCfg)]
@@ -633,12 +646,22 @@ class UlTx:
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch)
 
-    def encode(self, tb, tti0=0, ack=None, ri=None):
-        """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits) ->
-        iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
+    def encode(self, tb, tti0=0, ack=None, ri=None, cqi=None):
+        """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits,
+        cqi: [nof_sf][cqi_len] report bits) -> iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
         x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
         din = DevBuf.from_host(x)
-        if ri is not None:
+        if cqi is not None:
+            bufs = []
+            for v, n, w in ((ack, self.cfg.ack_len, 2), (ri, self.cfg.ri_len, 2), (cqi, self.cfg.cqi_len, 64)):
+                a = np.zeros((x.shape[0], w), np.uint8)
+                if v is not None:
+                    a[:, :n] = np.asarray(v, np.uint8).reshape(x.shape[0], -1)[:, :n]
+                bufs.append(DevBuf.from_host(a) if v is not None else None)
+            _check(lib().srslte_hip_ul_tx_batch_uci_cqi(self.h, din.ptr, self.tbs // 8, bufs[0].ptr if bufs[0] else None,
+                                                        bufs[1].ptr if bufs[1] else None, bufs[2].ptr, tti0, x.shape[0], self.d_iq.ptr, None),
+                   "ul_tx_batch_uci_cqi")
+        elif ri is not None:
             bufs = []
             for v, n in ((ack, self.cfg.ack_len), (ri, self.cfg.ri_len)):
                 a = np.zeros((x.shape[0], 2), np.uint8)

@@ -283,6 +283,7 @@ struct RmGeom {
   const uint32_t* csi_max;
   int             combine; // HARQ: add to the soft buffer kept from earlier transmissions (rm_turbo.c:407-409 accumulates) instead of writing it
   const uint8_t*  skip;    // HARQ: [B*C] blocks whose CRC already passed are not touched (sch.c:317-318)
+  int             e_off;   // LLRs in front of the shared channel's in every subframe (PUSCH: the CQI report's, sch.c:1058-1064)
 };
 
 // wrapping lane-wise add of packed int16 / int8 (the soft buffer accumulates with plain C '+=' on int16_t / int8_t)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
     n_e2 = n_e + QmL;
     rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
-  const LLR* src = e + (size_t)sf * g.max_bits + rp;
+  const LLR* src = e + (size_t)sf * g.max_bits + g.e_off + rp;
   CsiW       cw;
   if (g.csi) cw = csi_setup(g, sf, nre);
   uint32_t   n[PER], word = 0;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
     n_e2 = n_e + QmL;
     rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
-  const LLR* src = e + (size_t)sf * g.max_bits + rp;
+  const LLR* src = e + (size_t)sf * g.max_bits + g.e_off + rp;
   // the segment starts at an arbitrary LLR index: copy from the 16-byte boundary below it
   const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / sizeof(LLR));
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
@@ -1481,6 +1482,158 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
 
 } // namespace
 
+namespace {
+// ---- CQI / PMI report on the PUSCH (36.212 5.2.2.6, 5.2.2.6.4; srslte_uci_decode_cqi_pusch, uci.c:423-467): the first Q = Q' Qm LLRs of the
+// de-interleaved stream. Up to 11 bits: (32, O) block code - the repetitions are added up with wrapping int16 (srslte_vec_sum_sss) and the
+// sum is correlated with all 2^O code words, the first word of the highest correlation wins (decode_cqi_short :305-341). Above 11 bits:
+// srslte_rm_conv_rx_s (rm_conv.c:160-219, sequential because of its 10000 = "no value yet" sentinel), then the tail-biting K = 7 rate-1/3
+// Viterbi decoder of viterbi37_avx2_16bit.c on three repetitions of the frame - one lane per state, predecessors by shuffle, decisions by
+// ballot - with the soft bits scaled as srslte_viterbi_decode_f scales them (the reference's int16 wrapper overflows, see oracle/orc_cqi.c),
+// and the CRC-8. One workgroup per subframe; the Viterbi runs on its first wavefront.
+__constant__ uint16_t CQI_M32[32] = {0x403, 0x607, 0x749, 0x50D, 0x48F, 0x5D3, 0x755, 0x599, 0x69B, 0x65D, 0x6E5, 0x567, 0x7A9, 0x6AB, 0x4B1, 0x6F3,
+                                     0x277, 0x139, 0x0FB, 0x061, 0x445, 0x60B, 0x591, 0x717, 0x3DF, 0x4E3, 0x32D, 0x3AF, 0x175, 0x1FD, 0x7FF, 0x001}; // Table 5.2.2.6.4-1
+__constant__ uint8_t  CQI_PERM[32]     = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31, 0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30};
+__constant__ uint8_t  CQI_PERM_INV[32] = {16, 0, 24, 8, 20, 4, 28, 12, 18, 2, 26, 10, 22, 6, 30, 14, 17, 1, 25, 9, 21, 5, 29, 13, 19, 3, 27, 11, 23, 7, 31, 15};
+__device__ __forceinline__ uint32_t cqi_crc8(const uint8_t* bits, int n)
+{
+  uint32_t r = 0;
+  for (int i = 0; i < n + 8; i++) {
+    r = (r << 1) | (i < n ? (bits[i] & 1u) : 0u);
+    if (r & 0x100u) r ^= 0x19Bu;
+  }
+  return r & 0xffu;
+}
+
+__global__ __launch_bounds__(256) void pusch_cqi_decode_kernel(const int16_t* __restrict__ gl, int g_stride, int Q, int O, uint8_t* __restrict__ cqi_out,
+                                                               uint8_t* __restrict__ ok_out)
+{
+  __shared__ int16_t            acc[32];
+  __shared__ long long          best[4];
+  __shared__ int16_t            tmp[3 * 96], dem[3 * 72];
+  __shared__ uint16_t           us[3 * 72];
+  __shared__ unsigned long long dec[3 * 72 + 6];
+  __shared__ uint8_t            bits[3 * 72];
+  const int      sf = blockIdx.x, tid = threadIdx.x;
+  const int16_t* q  = gl + (size_t)sf * g_stride;
+  uint8_t*       out = cqi_out + (size_t)sf * 64;
+  if (O <= 11) {
+    if (tid < 32) {
+      int a = 0;
+      for (int i = tid; i < Q; i += 32) a += q[i];
+      acc[tid] = (int16_t)a; // wrapping, like the int16 adds of srslte_vec_sum_sss
+    }
+    __syncthreads();
+    const int n = Q < 32 ? Q : 32;
+    long long key = INT64_MIN;
+    for (uint32_t w = tid; w < (1u << O); w += 256) {
+      int corr = 0;
+      for (int i = 0; i < n; i++) {
+        uint32_t m = 0; // code bit i of word w: bit k of the report is bit O-1-k of w
+        for (int k = 0; k < O; k++) m ^= ((w >> (O - 1 - k)) & 1u) & ((CQI_M32[i] >> k) & 1u);
+        corr += m ? acc[i] : -acc[i];
+      }
+      const long long kk = ((long long)corr << 32) | (long long)(0xffffffffu - w); // highest correlation, then lowest word
+      key = kk > key ? kk : key;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const long long other = __shfl_xor(key, o, 64);
+      key = other > key ? other : key;
+    }
+    if ((tid & 63) == 0) best[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+      for (int i = 1; i < 4; i++) key = best[i] > key ? best[i] : key;
+      const uint32_t w = 0xffffffffu - (uint32_t)(key & 0xffffffffll);
+      for (int k = 0; k < O; k++) out[k] = (w >> (O - 1 - k)) & 1u;
+      ok_out[sf] = 1;
+    }
+    return;
+  }
+  const int F = O + 8, nrows = (F - 1) / 32 + 1, K_p = nrows * 32, ndummy = K_p - F;
+  for (int i = tid; i < 3 * K_p; i += 256) tmp[i] = 10000; // SRSLTE_RX_NULL
+  for (int i = tid; i < 3 * F + 6; i += 256) dec[i] = 0ull;
+  __syncthreads();
+  if (tid == 0) {
+    int k = 0, j = 0;
+    while (k < Q) {
+      const int d_i = (j % K_p) / nrows, d_j = (j % K_p) % nrows;
+      if (d_j * 32 + CQI_PERM[d_i] >= ndummy) {
+        const int16_t v = q[k];
+        if (tmp[j] == 10000) {
+          tmp[j] = v;
+        } else if (v != 10000) {
+          tmp[j] = (int16_t)(tmp[j] + v);
+        }
+        k++;
+      }
+      if (++j == 3 * K_p) j = 0;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * F; e += 256) {
+    const int     i = e / 3, s = e - 3 * i, d_i = (i + ndummy) / 32, d_j = (i + ndummy) % 32;
+    const int16_t o = tmp[K_p * s + CQI_PERM_INV[d_j] * nrows + d_i];
+    dem[e]          = o != 10000 ? o : (int16_t)0;
+  }
+  __syncthreads();
+  if (tid >= 64) return;
+  // srslte_viterbi_decode_f's quantisation (viterbi.c:532-540, srslte_vec_quant_fus): gain 1000 / max |.|, offset 32767.5, clip to 16 bits
+  float mx = -9e9f;
+  for (int i = tid; i < 3 * F; i += 64) mx = fmaxf(mx, fabsf((float)dem[i]));
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  const float gain = 1000.0f / mx;
+  for (int i = tid; i < 3 * F; i += 64) {
+    const long t = (long)fmaf(gain, (float)dem[i], 32767.5f);
+    us[i]        = (uint16_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): one wavefront from here on, LDS in order
+  const int      n = tid, b = n >> 1;
+  const uint32_t bt0 = (__builtin_popcount((2 * b) & 0x6D) & 1) ? 65535u : 0u, bt1 = (__builtin_popcount((2 * b) & 0x4F) & 1) ? 65535u : 0u,
+                 bt2 = (__builtin_popcount((2 * b) & 0x57) & 1) ? 65535u : 0u;
+  uint32_t old = 63;
+  for (int t = 0; t < 3 * F; t++) {
+    const int      f  = t % F;
+    const uint32_t a = bt0 ^ us[3 * f], bb = bt1 ^ us[3 * f + 1], c = bt2 ^ us[3 * f + 2];
+    const uint32_t m01 = (a + bb + 1) >> 1, met = ((c + m01 + 1) >> 1) >> 3, mm = 8191u - met;
+    const uint32_t oi = (uint32_t)__shfl((int)old, b, 64), oj = (uint32_t)__shfl((int)old, b + 32, 64);
+    const uint16_t x  = (uint16_t)(oi + ((n & 1) ? mm : met)), y = (uint16_t)(oj + ((n & 1) ? met : mm)); // (m0, m1) or (m2, m3)
+    const bool     d  = (int16_t)(uint16_t)(x - y) > 0;
+    old               = d ? y : x;
+    const unsigned long long bal = __ballot(d);
+    if (tid == 0) dec[t] = bal;
+  }
+  uint32_t mn = old;
+  for (int o = 32; o > 0; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+  const unsigned long long at_min = __ballot(old == mn);
+  if (tid == 0) {
+    uint32_t endstate = (uint32_t)(63 - __builtin_clzll(at_min)) << 2; // the LAST state with the smallest metric
+    for (int i = 3 * F - 1; i >= F; i--) {
+      const uint32_t k = (uint32_t)(dec[6 + i] >> (endstate >> 2)) & 1u;
+      endstate         = (endstate >> 1) | (k << 7);
+      bits[i]          = (uint8_t)k;
+    }
+    const uint8_t* msg = bits + F; // the middle repetition
+    uint32_t       rx  = 0;
+    for (int i = 0; i < 8; i++) rx = (rx << 1) | msg[O + i];
+    const bool good = cqi_crc8(msg, O) == rx;
+    if (good) {
+      for (int k = 0; k < O; k++) out[k] = msg[k];
+    }
+    ok_out[sf] = good ? 1 : 0;
+  }
+}
+} // namespace
+
+static int pusch_cqi_qprime(uint32_t O, uint32_t I_offset_cqi, uint32_t L_prb, uint32_t nsymb, uint32_t K_segm, uint32_t Qp_ri)
+{ // Q_prime_cqi (uci.c:264-281), float arithmetic; 0 without a report
+  static const float beta_cqi[16] = {-1.0f, -1.0f, 1.125f, 1.25f, 1.375f, 1.625f, 1.750f, 2.0f, 2.25f, 2.5f, 2.875f, 3.125f, 3.5f, 4.0f, 5.0f, 6.25f}; // sch.c:51-52
+  if (O == 0) return 0;
+  if (O > 64 || I_offset_cqi > 15 || beta_cqi[I_offset_cqi] < 0 || K_segm == 0) return -1;
+  const uint32_t L = O < 11 ? 0 : 8;
+  const uint32_t x = (uint32_t)ceilf((float)(O + L) * L_prb * 12 * nsymb * beta_cqi[I_offset_cqi] / K_segm), m = L_prb * 12 * nsymb - Qp_ri;
+  return (int)(x < m ? x : m);
+}
+
 // Q' of the HARQ-ACK (Q_prime_ri_ack, uci.c:547-571, UL-SCH present): min(ceil(O M_sc N_symb beta / sum K_r), 4 M_sc) in float arithmetic
 static int pusch_ack_qprime(uint32_t O, uint32_t I_offset_ack, uint32_t L_prb, uint32_t nsymb, uint32_t K_segm, bool is_ri = false)
 {
@@ -1521,10 +1674,13 @@ struct srslte_hip_ul_rx {
   uint8_t *              d_cb_bytes, *d_cb_ok;
   int*                   d_ack_sum; // [B][4] ACK, then [B][4] RI
   uint8_t*               d_ack;     // [B][2] HARQ-ACK decisions of the last call, then [B][2] rank indications
+  uint8_t*               d_cqi;     // [B][64] CQI report bits of the last call, then [B] CRC flags
+  int                    Qp_cqi;
 };
 
 extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack + 2 * q->cfg.max_batch : nullptr; }
+extern "C" const uint8_t* srslte_hip_ul_rx_cqi(const srslte_hip_ul_rx_t* q) { return q ? q->d_cqi : nullptr; }
 
 extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 {
@@ -1533,7 +1689,7 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_chest_ul_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
-                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack};
+                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -1559,6 +1715,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   const uint32_t nsymb = cfg->shortened ? 11 : 12; // 2 (7 - 1) - N_srs data symbols (pusch.c:335-343)
   const uint32_t nof_re = nsymb * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32 + 1; // spare word: the demapper reads two per symbol
   const int      Qp_ri = pusch_ack_qprime(cfg->ri_len, cfg->I_offset_ri, cfg->L_prb, nsymb, C * K, true);
+  const int      Qp_cqi = Qp_ri >= 0 ? pusch_cqi_qprime(cfg->cqi_len, cfg->I_offset_cqi, cfg->L_prb, nsymb, C * K, (uint32_t)Qp_ri) : -1;
   q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
   q->chest = srslte_hip_chest_ul_create(cfg->cell_id, P, 1, &cfg->dmrs_cfg);
   q->tdec  = srslte_hip_tdec_create(K, B * C);
@@ -1618,7 +1775,8 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 8 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)4 * B) == hipSuccess &&
        hipMemset(q->d_ack, 0, (size_t)4 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0 &&
-       Qp_ri >= 0 && (uint32_t)Qp_ri < nof_re;
+       Qp_ri >= 0 && (uint32_t)Qp_ri < nof_re && Qp_cqi >= 0 && (uint32_t)(Qp_ri + Qp_cqi) + C < nof_re &&
+       hipMalloc((void**)&q->d_cqi, (size_t)65 * B) == hipSuccess && hipMemset(q->d_cqi, 0, (size_t)65 * B) == hipSuccess;
   ok = ok && hipDeviceSynchronize() == hipSuccess; // the memsets above ran on the null stream
   if (!ok) {
     hip_log("[srslte_hip] ul_rx: initialisation failed\n");
@@ -1632,7 +1790,10 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
   q->pg.ri.O = (int)cfg->ri_len; q->pg.ri.Qprime = Qp_ri; q->pg.ri_sum = q->d_ack_sum + 4 * B;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)nbits; q->rg.w_stride = (int)q->in_stride; q->rg.Nl = 1;
   q->rg.out_len = (int)(3 * K + 12);
-  q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re - Qp_ri; // the UL-SCH is rate-matched to what the RI leaves (sch.c:1157-1160)
+  // the UL-SCH is rate-matched to what the RI and the CQI report leave (sch.c:1157-1160) and follows the report in the stream
+  q->rg.nof_re[0] = q->rg.nof_re[1] = q->rg.nof_re[2] = (int)nof_re - Qp_ri - Qp_cqi;
+  q->rg.e_off = Qp_cqi * (int)Qm;
+  q->Qp_cqi   = Qp_cqi;
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
   return q;
 }
@@ -1689,6 +1850,11 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   if (g.ri.O) {
     hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_sf, 64)), dim3(64), 0, st, (const int*)(q->d_ack_sum + 4 * q->cfg.max_batch),
                        q->d_ack + 2 * q->cfg.max_batch, (int)nof_sf);
+    LAUNCH_CHECK();
+  }
+  if (q->cfg.cqi_len) { // the report in front of the UL-SCH (sch.c:1031-1056)
+    hipLaunchKernelGGL(pusch_cqi_decode_kernel, dim3(nof_sf), dim3(256), 0, st, (const int16_t*)q->d_g, q->rg.max_bits, q->Qp_cqi * q->rg.Qm,
+                       (int)q->cfg.cqi_len, q->d_cqi, q->d_cqi + 64 * q->cfg.max_batch);
     LAUNCH_CHECK();
   }
   RmGeom rg = q->rg;
@@ -1784,8 +1950,49 @@ struct PuschTxGeom {
   AckGeom        ack, ri;
   const uint8_t* ack_bits; // [nof_sf][2] HARQ-ACK values of this call, or null
   const uint8_t* ri_bits;  // [nof_sf][2] rank indication bits of this call, or null
+  const uint8_t* q_cqi;    // [nof_sf][cqi_stride] coded CQI report bits of this call, or null
+  int            Qp_cqi, cqi_stride;
   float lvl[16];
 };
+
+// grid = nof_sf, 256 threads: the coded CQI / PMI report, Q = Q' Qm bits per subframe (srslte_uci_encode_cqi_pusch, uci.c:470-494). Up to 11
+// bits: the (32, O) block code repeated (encode_cqi_short :283-302). Above: CRC-8, the tail-biting rate-1/3 convolutional code (a circular
+// convolution with 0x6D, 0x4F, 0x57; convcoder.c:43-72) and srslte_rm_conv_tx (rm_conv.c:44-89) as the table rm: output bit -> coded bit.
+__global__ __launch_bounds__(256) void pusch_cqi_encode_kernel(const uint8_t* __restrict__ cqi, uint8_t* __restrict__ qb, int q_stride, int Q, int O,
+                                                               const uint16_t* __restrict__ rm)
+{
+  __shared__ uint8_t msg[72], enc[3 * 72];
+  const int          sf = blockIdx.x, tid = threadIdx.x;
+  const uint8_t*     in = cqi + (size_t)sf * 64;
+  uint8_t*           out = qb + (size_t)sf * q_stride;
+  if (O <= 11) {
+    if (tid < 32) {
+      int b = 0;
+      for (int n = 0; n < O; n++) b ^= in[n] & (CQI_M32[tid] >> n) & 1;
+      enc[tid] = (uint8_t)b;
+    }
+    __syncthreads();
+    for (int i = tid; i < Q; i += 256) out[i] = enc[i & 31];
+    return;
+  }
+  const int F = O + 8;
+  if (tid < O) msg[tid] = in[tid] & 1;
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t c = cqi_crc8(msg, O);
+    for (int i = 0; i < 8; i++) msg[O + i] = (c >> (7 - i)) & 1;
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * F; e += 256) {
+    const int      i = e / 3, p = e - 3 * i;
+    const uint32_t poly = p == 0 ? 0x6Du : (p == 1 ? 0x4Fu : 0x57u);
+    int            b = 0;
+    for (int j = 0; j < 7; j++) b ^= ((poly >> j) & 1u) & msg[(i - j + F) % F];
+    enc[e] = (uint8_t)b;
+  }
+  __syncthreads();
+  for (int i = tid; i < Q; i += 256) out[i] = enc[rm[i]];
+}
 
 // grid = nof_sf, 256 threads: CRC24A of each transport block (sch.c:470-488 on the transmit side :1104-1110)
 __global__ __launch_bounds__(256) void pusch_tx_tbcrc_kernel(const uint8_t* __restrict__ tb, uint32_t* __restrict__ crc_out, PuschTxGeom g)
@@ -1829,8 +2036,11 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
   if (k >= g.M_sc) return;
   const int ri = g.ri_bits ? ri_symbol_index(g.ri, n, k, g.M_sc, g.nsymb) : -1; // RI symbol: outside the UL-SCH stream (sch.c:580-598)
   // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
-  const int s = ri >= 0 ? 0 : k * g.nsymb + n - (g.ri_bits ? ri_before(g.ri, n, k, g.M_sc, g.nsymb) : 0);
-  int       r, e0;
+  const int s0 = ri >= 0 ? 0 : k * g.nsymb + n - (g.ri_bits ? ri_before(g.ri, n, k, g.M_sc, g.nsymb) : 0);
+  // the first Q'_cqi symbols of the stream carry the CQI report, the UL-SCH follows (sch.c:1133-1160)
+  const bool is_cqi = ri < 0 && s0 < g.Qp_cqi;
+  const int  s      = is_cqi || ri >= 0 ? 0 : s0 - g.Qp_cqi;
+  int        r, e0;
   if (s < g.C_lo * g.syms_lo) {
     r  = s / g.syms_lo;
     e0 = (s - r * g.syms_lo) * g.Qm;
@@ -1850,6 +2060,7 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
     const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
     int            bit  = (byte >> (7 - (pos & 7))) & 1;
     const int      cbit = (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
+    if (is_cqi) bit = g.q_cqi[(size_t)sf * g.cqi_stride + s0 * g.Qm + b];
     bit ^= cbit;
     if (ai >= 0) { // HARQ-ACK symbol: value bits are scrambled, placeholders are 1, a repetition bit copies the transmitted bit before it
       const int t = ack_bit_type(g.ack_bits + 2 * sf, g.ack.O, g.Qm, ai * g.Qm + b); // (sch.c:1203-1215, pusch.c:386-400)
@@ -1895,7 +2106,8 @@ struct srslte_hip_ul_tx {
   srslte_hip_cbsegm_t    seg;
   PuschTxGeom            g;
   uint32_t *             d_scr, *d_rm, *d_tbcrc;
-  uint8_t *              d_cb, *d_parity, *d_sys_tail;
+  uint8_t *              d_cb, *d_parity, *d_sys_tail, *d_qcqi;
+  uint16_t*              d_cqi_rm;
   cf32 *                 d_d, *d_z, *d_grid;
 };
 
@@ -1904,7 +2116,7 @@ extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
   if (!q) return;
   srslte_hip_ofdm_destroy(q->ofdm);
   srslte_hip_chest_ul_destroy(q->dmrs);
-  void* bufs[] = {q->d_scr, q->d_rm, q->d_tbcrc, q->d_cb, q->d_parity, q->d_sys_tail, q->d_d, q->d_z, q->d_grid};
+  void* bufs[] = {q->d_scr, q->d_rm, q->d_tbcrc, q->d_cb, q->d_parity, q->d_sys_tail, q->d_d, q->d_z, q->d_grid, q->d_qcqi, q->d_cqi_rm};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -1946,7 +2158,14 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
     delete q;
     return nullptr;
   }
-  const uint32_t g_re = nof_re - g.ri.Qprime; // UL-SCH symbols: what the RI leaves (sch.c:1157-1160)
+  g.Qp_cqi = pusch_cqi_qprime(cfg->cqi_len, cfg->I_offset_cqi, cfg->L_prb, nsymb, C * K, (uint32_t)g.ri.Qprime);
+  if (g.Qp_cqi < 0 || (uint32_t)(g.ri.Qprime + g.Qp_cqi) + C >= nof_re) {
+    hip_log("[srslte_hip] ul_tx: invalid CQI configuration\n");
+    delete q;
+    return nullptr;
+  }
+  g.cqi_stride = (g.Qp_cqi * (int)Qm + 15) & ~15;
+  const uint32_t g_re = nof_re - g.ri.Qprime - g.Qp_cqi; // UL-SCH symbols: what the RI and the CQI report leave (sch.c:1157-1160)
   g.syms_lo = (int)(g_re / C); g.C_lo = (int)(C - g_re % C); // G' = the UL-SCH symbols, gamma = G' mod C (sch.c:205-207)
   for (uint32_t idx = 0; idx < (1u << cfg->mod); idx++) { // 36.211 7.1.2-7.1.4, one axis: bits b0 b2 b4 of the symbol (lte_tables.c:57-182)
     const int    nb = cfg->mod;
@@ -1977,6 +2196,23 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
     }
     ok = upload(&q->d_rm, t) == SRSLTE_SUCCESS;
   }
+  if (ok && cfg->cqi_len > 11) { // srslte_rm_conv_tx (rm_conv.c:44-89): the sub-block interleaved streams read circularly, dummies skipped
+    static const uint8_t perm[32] = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31, 0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30};
+    const int            F = (int)cfg->cqi_len + 8, nrows = (F - 1) / 32 + 1, K_p = nrows * 32, ndummy = K_p - F, Q = g.Qp_cqi * (int)Qm;
+    std::vector<int>      w;
+    for (int st = 0; st < 3; st++) {
+      for (int j = 0; j < 32; j++) {
+        for (int i = 0; i < nrows; i++) {
+          const int pos = i * 32 + perm[j];
+          if (pos >= ndummy) w.push_back((pos - ndummy) * 3 + st);
+        }
+      }
+    }
+    std::vector<uint16_t> t((size_t)(Q > 0 ? Q : 1));
+    for (int i = 0; i < Q; i++) t[i] = (uint16_t)w[(size_t)i % w.size()];
+    ok = upload(&q->d_cqi_rm, t) == SRSLTE_SUCCESS;
+  }
+  if (ok && cfg->cqi_len) ok = hipMalloc((void**)&q->d_qcqi, (size_t)g.cqi_stride * B + 16) == hipSuccess;
   const size_t glen = (size_t)14 * 12 * P;
   ok = ok && hipMalloc((void**)&q->d_tbcrc, sizeof(uint32_t) * B) == hipSuccess &&
        hipMalloc((void**)&q->d_cb, (size_t)g.cb_stride * B * C) == hipSuccess &&
@@ -2010,7 +2246,7 @@ extern "C" const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q
 extern "C" int srslte_hip_ul_tx_batch(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, void* d_iq,
                                       void* stream)
 {
-  if (q && (q->cfg.ack_len || q->cfg.ri_len)) return SRSLTE_ERROR_INVALID_INPUTS; // UCI configured: the values come through _batch_ack / _batch_uci
+  if (q && (q->cfg.ack_len || q->cfg.ri_len || q->cfg.cqi_len)) return SRSLTE_ERROR_INVALID_INPUTS; // UCI configured: the values come through _batch_ack / _batch_uci / _batch_uci_cqi
   return srslte_hip_ul_tx_batch_ack(q, d_tb, tb_stride, nullptr, tti0, nof_sf, d_iq, stream);
 }
 
@@ -2023,8 +2259,15 @@ extern "C" int srslte_hip_ul_tx_batch_ack(srslte_hip_ul_tx_t* q, const uint8_t* 
 extern "C" int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
                                           uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream)
 {
+  return srslte_hip_ul_tx_batch_uci_cqi(q, d_tb, tb_stride, d_ack, d_ri, nullptr, tti0, nof_sf, d_iq, stream);
+}
+
+extern "C" int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                              const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream)
+{
   if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
-  if ((q->cfg.ack_len != 0) != (d_ack != nullptr) || (q->cfg.ri_len != 0) != (d_ri != nullptr)) return SRSLTE_ERROR_INVALID_INPUTS;
+  if ((q->cfg.ack_len != 0) != (d_ack != nullptr) || (q->cfg.ri_len != 0) != (d_ri != nullptr) || (q->cfg.cqi_len != 0) != (d_cqi != nullptr))
+    return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const void* d_r = nullptr;
@@ -2034,6 +2277,12 @@ extern "C" int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* 
   g.tb_stride   = (int)tb_stride;
   g.ack_bits    = d_ack;
   g.ri_bits     = d_ri;
+  g.q_cqi       = d_cqi ? q->d_qcqi : nullptr;
+  if (d_cqi) {
+    hipLaunchKernelGGL(pusch_cqi_encode_kernel, dim3(nof_sf), dim3(256), 0, st, d_cqi, q->d_qcqi, g.cqi_stride, g.Qp_cqi * g.Qm, (int)q->cfg.cqi_len,
+                       (const uint16_t*)q->d_cqi_rm);
+    LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(pusch_tx_tbcrc_kernel, dim3(nof_sf), dim3(256), 0, st, d_tb, q->d_tbcrc, g);
   LAUNCH_CHECK();
   hipLaunchKernelGGL(pusch_tx_seg_kernel, dim3(g.C, nof_sf), dim3(256), 0, st, d_tb, (const uint32_t*)q->d_tbcrc, q->d_cb, g);

@@ -627,17 +627,33 @@ def ul_ri_layout(cfg, O_ri, I_offset_ri):
     return Qp, lut, mask, G
 
 
-def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0, ri=(), I_offset_ri=0):
-    """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits and / or a 1-2 bit rank indication multiplexed):
-    returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
+def ul_cqi_qprime(cfg, O_cqi, I_offset_cqi, Qp_ri):
+    Qp = oracle().orc_uci_cqi_qprime(O_cqi, I_offset_cqi, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1, Qp_ri) if O_cqi else 0
+    assert Qp >= 0
+    return Qp
+
+
+def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0, ri=(), I_offset_ri=0, cqi=(),
+                     I_offset_cqi=0):
+    """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits, a 1-2 bit rank indication and / or a CQI report of
+    `cqi` bits multiplexed): returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
     orc = oracle()
     sf_idx = tti % 10
     if data is None:
         data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
     Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, len(ri), I_offset_ri)
-    sch = OrcSchCfg(cfg.tbs, G, cfg.Qm, 0, cfg.max_iter)
+    # the CQI's coded bits come first in the stream the interleaver reads, the UL-SCH is rate-matched to the rest (sch.c:1133-1160)
+    Qp_cqi = ul_cqi_qprime(cfg, len(cqi), I_offset_cqi, Qp_ri)
+    n_cqi = Qp_cqi * cfg.Qm
+    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, 0, cfg.max_iter)
     g = np.zeros(G, np.uint8)
-    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(g)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
+    if n_cqi:
+        qc = np.zeros(n_cqi, np.uint8)
+        assert orc.orc_uci_cqi_encode(p(np.ascontiguousarray(cqi, np.uint8)), len(cqi), p(qc), n_cqi) == 0
+        g[:n_cqi] = qc
+    gs = np.zeros(G - n_cqi, np.uint8)
+    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(gs)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
+    g[n_cqi:] = gs
     q = np.zeros(cfg.nbits, np.uint8)
     q[~ri_mask] = g[lut[~ri_mask]]
     if not len(ri):
@@ -677,7 +693,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     return iq.astype(np.complex64), data
 
 
-def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0):
+def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0, O_cqi=0, I_offset_cqi=0):
     """eNB receive side: enb_ul.c:58-63 OFDM settings, srslte_chest_ul_estimate_pusch, srslte_pusch_decode (pusch.c:423-520) and the
     UL-SCH part of srslte_ulsch_decode (sch.c:991-1066) without UCI."""
     from _libs import OrcChestUlRes
@@ -713,10 +729,15 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
     g = np.ascontiguousarray(g_full[:G])
     if not O_ri:
         assert np.array_equal(g, qllr[cfg.q_of_g])
-    sch = OrcSchCfg(cfg.tbs, G, cfg.Qm, 0, cfg.max_iter)
+    # the CQI report sits in front of the UL-SCH (sch.c:1031-1060)
+    n_cqi = ul_cqi_qprime(cfg, O_cqi, I_offset_cqi, Qp_ri) * cfg.Qm
+    cqi_out, cqi_ok = np.zeros(64, np.uint8), C.c_uint8(0)
+    if O_cqi:
+        assert orc.orc_uci_cqi_decode(p(g[:n_cqi].copy()), n_cqi, O_cqi, p(cqi_out), C.byref(cqi_ok)) == 0
+    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, 0, cfg.max_iter)
     tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
-    rc = orc.orc_dlsch_decode(C.byref(sch), p(g), p(tb), p(iters), p(cbok))
-    out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
+    rc = orc.orc_dlsch_decode(C.byref(sch), p(np.ascontiguousarray(g[n_cqi:])), p(tb), p(iters), p(cbok))
+    out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok, "cqi": cqi_out[:O_cqi], "cqi_ok": bool(cqi_ok.value)}
     if keep:
         out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res, q_before_ack=q_before_ack, ack=ack_out, ri=ri_out)
     return out
@@ -780,14 +801,16 @@ class RefUlsch:
     36.212 5.2.2.8 and its inverse, UCI absent) on its compiled code, with a hand-filled srslte_pusch_cfg_t (offsets from the reference
     headers at run time). Pins the UL side of the oracle chain: orc_dlsch_encode/decode used as UL-SCH coder and UlConfig.q_of_g."""
 
-    def __init__(self, cfg, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0):
+    def __init__(self, cfg, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0, cqi_N=None, I_offset_cqi=0):
+        """cqi_N: None = no CQI report; 0 = wide-band report (4 bits); N > 0 = higher-layer configured sub-band report, 4 + 2 N bits."""
         from _libs import opaque, ref, ref_layout
         R = self.R = ref()
         self.cfg = cfg
         L = self.L = ref_layout({"srslte_sch_t": [], "srslte_pusch_cfg_t": ["grant", "max_nof_iterations", "softbuffers", "uci_cfg", "uci_offset"],
-                                 "srslte_uci_cfg_t": ["ack", "cqi"], "srslte_uci_cfg_ack_t": ["nof_acks"], "srslte_cqi_cfg_t": ["ri_len"],
-                                 "srslte_uci_offset_cfg_t": ["I_offset_ack", "I_offset_ri"],
-                                 "srslte_uci_value_t": ["ack", "ri"], "srslte_uci_value_ack_t": ["ack_value"],
+                                 "srslte_uci_cfg_t": ["ack", "cqi"], "srslte_uci_cfg_ack_t": ["nof_acks"], "srslte_cqi_cfg_t": ["ri_len", "data_enable", "N", "type"],
+                                 "srslte_uci_offset_cfg_t": ["I_offset_ack", "I_offset_ri", "I_offset_cqi"],
+                                 "srslte_uci_value_t": ["ack", "ri", "cqi"], "srslte_uci_value_ack_t": ["ack_value"],
+                                 "srslte_cqi_value_t": ["data_crc", "wideband.wideband_cqi", "subband_hl.wideband_cqi_cw0", "subband_hl.subband_diff_cqi_cw0"],
                                  "srslte_pusch_grant_t": ["L_prb", "nof_re", "nof_symb", "tb"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_softbuffer_tx_t": []}, ["srslte/phy/ch_estimation/chest_ul.h", "srslte/phy/phch/pusch.h"])
@@ -814,11 +837,33 @@ class RefUlsch:
         u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_ack"], I_offset_ack)
         u32(L["srslte_pusch_cfg_t.uci_cfg"] + L["srslte_uci_cfg_t.cqi"] + L["srslte_cqi_cfg_t.ri_len"], O_ri)
         u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_ri"], I_offset_ri)
+        self.cqi_N = cqi_N
+        if cqi_N is not None:
+            c0 = L["srslte_pusch_cfg_t.uci_cfg"] + L["srslte_uci_cfg_t.cqi"]
+            self.pc[c0 + L["srslte_cqi_cfg_t.data_enable"]] = 1
+            u32(c0 + L["srslte_cqi_cfg_t.N"], cqi_N)
+            u32(c0 + L["srslte_cqi_cfg_t.type"], 3 if cqi_N else 0)  # SRSLTE_CQI_TYPE_SUBBAND_HL / _WIDEBAND (cqi.h:113-118)
+            u32(L["srslte_pusch_cfg_t.uci_offset"] + L["srslte_uci_offset_cfg_t.I_offset_cqi"], I_offset_cqi)
+        self.cqi_val = L["srslte_uci_value_t.cqi"]
         self.ri_off = L["srslte_uci_value_t.ri"]
         self.ack_off = L["srslte_uci_value_t.ack"] + L["srslte_uci_value_ack_t.ack_value"]
         self.sb_off = L["srslte_pusch_cfg_t.softbuffers"]
 
-    def encode(self, data, ack=(), ri=None):
+    def cqi_bits(self, wb, diff=0):
+        """the report's bits as srslte_cqi_value_pack lays them out (cqi.c:41-76,:100-134): 4-bit wide-band CQI, then 2 N bits of sub-band
+        differentials, MSB first"""
+        N = self.cqi_N
+        return np.array([(wb >> (3 - i)) & 1 for i in range(4)] + [(diff >> (2 * N - 1 - i)) & 1 for i in range(2 * N)], np.uint8)
+
+    def _put_cqi(self, uci, wb, diff):
+        L = self.L
+        if self.cqi_N:
+            uci[self.cqi_val + L["srslte_cqi_value_t.subband_hl.wideband_cqi_cw0"]] = wb
+            uci[self.cqi_val + L["srslte_cqi_value_t.subband_hl.subband_diff_cqi_cw0"]:][:4].view(np.uint32)[0] = diff
+        else:
+            uci[self.cqi_val + L["srslte_cqi_value_t.wideband.wideband_cqi"]] = wb
+
+    def encode(self, data, ack=(), ri=None, cqi=None):
         """payload bytes (+ HARQ-ACK values) -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling
         (pusch.c:380-395); the ACK positions of q hold the value bits, 0 for repetition / placeholder bits."""
         cfg, R = self.cfg, self.R
@@ -830,6 +875,8 @@ class RefUlsch:
         uci[self.ack_off:self.ack_off + len(ack)] = ack
         if ri is not None:
             uci[self.ri_off] = ri
+        if cqi is not None:
+            self._put_cqi(uci, *cqi)
         g, q = np.zeros(cfg.nbits // 8 + 64, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8)
         assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) >= 0  # returns the number of RI/ACK q-bits
         return np.unpackbits(g)[:cfg.nbits], np.unpackbits(q)[:cfg.nbits]
@@ -845,5 +892,14 @@ class RefUlsch:
         cs = np.ascontiguousarray(c_seq, np.uint8)
         tb, uci = np.zeros(cfg.tbs // 8 + 64, np.uint8), np.zeros(4096, np.uint8)
         rc = R.srslte_ulsch_decode(self.q, p(self.pc), p(ql), p(gl), p(cs), p(tb), p(uci))
-        return {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy(), "ack": uci[self.ack_off:self.ack_off + 2].copy(),
-                "ri": int(uci[self.ri_off])}
+        out = {"tb": tb[:cfg.tbs // 8 + 3].copy(), "ok": rc == 0, "g": gl[:cfg.nbits].copy(), "ack": uci[self.ack_off:self.ack_off + 2].copy(),
+               "ri": int(uci[self.ri_off])}
+        if self.cqi_N is not None:
+            L = self.L
+            out["cqi_crc"] = bool(uci[self.cqi_val + L["srslte_cqi_value_t.data_crc"]])
+            if self.cqi_N:
+                out["cqi"] = (int(uci[self.cqi_val + L["srslte_cqi_value_t.subband_hl.wideband_cqi_cw0"]]),
+                              int(uci[self.cqi_val + L["srslte_cqi_value_t.subband_hl.subband_diff_cqi_cw0"]:][:4].view(np.uint32)[0]))
+            else:
+                out["cqi"] = (int(uci[self.cqi_val + L["srslte_cqi_value_t.wideband.wideband_cqi"]]), 0)
+        return out

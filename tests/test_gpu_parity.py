@@ -1083,6 +1083,129 @@ def test_ul_rx_chain_rank_indication(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf
     rx.free()
 
 
+# prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, shortened
+UL_CQI_CASES = [(25, 10, 5, 2, 4008, 12.0, 8, 6, 4, 7, 0, 0, 0, 0, False), (25, 10, 5, 2, 4008, 12.0, 1, 6, 11, 9, 1, 9, 2, 9, False),
+                (6, 6, 0, 1, 1000, 6.0, 2, 4, 20, 6, 1, 5, 1, 5, True), (100, 48, 20, 3, 30576, 19.0, 7, 4, 64, 12, 0, 0, 0, 0, False),
+                (50, 20, 3, 2, 7736, 12.0, 4, 4, 28, 8, 2, 8, 1, 8, False), (100, 100, 0, 2, 43816, 15.0, 4, 4, 1, 15, 1, 11, 2, 12, True),
+                (25, 2, 7, 1, 256, 8.0, 3, 4, 12, 2, 0, 0, 0, 0, False), (15, 3, 12, 3, 1800, 19.0, 9, 3, 36, 10, 2, 12, 2, 3, False),
+                (50, 25, 0, 2, 9912, 3.0, 0, 4, 48, 4, 1, 6, 2, 6, False)]
+
+
+def _cqi_bits(nsf, O):
+    r = np.random.default_rng(4242 + O)
+    return r.integers(0, 2, (nsf, O), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O_cqi,I_cqi,O_ri,I_ri,O_ack,I_ack,short", UL_CQI_CASES)
+def test_ul_tx_chain_cqi(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, short):
+    """PUSCH transmit chain with a CQI report (block code up to 11 bits, CRC-8 + tail-biting convolutional code + rate matching above),
+    alone and with RI / HARQ-ACK: the report's Q' symbols lead the interleaved stream, the UL-SCH is rate-matched to the rest
+    (sch.c:1133-1160, uci.c:264-302,:470-494) vs the oracle's (pinned on srslte_ulsch_encode): symbols exact."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(2100 + prb + L + mod + O_cqi)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, shortened=short, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    cqis = _cqi_bits(nsf, O_cqi)
+    ris = np.array([[(b >> j) & 1 for j in range(O_ri)] for b in range(nsf)], np.uint8) if O_ri else None
+    acks = np.array([[((b + 1) >> j) & 1 for j in range(O_ack)] for b in range(nsf)], np.uint8) if O_ack else None
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri,
+                 I_offset_ri=I_ri, cqi_len=O_cqi, I_offset_cqi=I_cqi)
+    iq = tx.encode(data, tti0, ack=acks, ri=ris, cqi=cqis)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    for b in range(nsf):
+        k = {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k, ack=tuple(acks[b]) if O_ack else (), I_offset_ack=I_ack,
+                                   ri=tuple(ris[b]) if O_ri else (), I_offset_ri=I_ri, cqi=tuple(cqis[b]), I_offset_cqi=I_cqi)
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), "modulated symbols sf %d" % b
+        assert_close_c(iq[b], iq_o, "iq sf %d" % b)
+    tx.free()
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O_cqi,I_cqi,O_ri,I_ri,O_ack,I_ack,short", UL_CQI_CASES)
+def test_ul_rx_chain_cqi(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, short):
+    """PUSCH receive chain with a CQI report vs the oracle chain (pinned on srslte_ulsch_decode / srslte_uci_decode_cqi_pusch, the long
+    report through srslte_viterbi_decode_f) on identical IQ: report bits and CRC flag, RI / ACK decisions, de-interleaved LLRs, pass
+    counts, CRC, TB. The last case is noisy enough for wrong reports: same wrong bits, same CRC verdicts."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(2200 + prb + L + mod + O_cqi)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6, shortened=short)
+    G = ul_ri_layout(cfg, O_ri, I_ri)[3]
+    cqis = _cqi_bits(nsf, O_cqi)
+    ris = np.array([[(b >> j) & 1 for j in range(O_ri)] for b in range(nsf)], np.uint8) if O_ri else None
+    acks = np.array([[((b + 1) >> j) & 1 for j in range(O_ack)] for b in range(nsf)], np.uint8) if O_ack else None
+    iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), ack=tuple(acks[b]) if O_ack else (),
+                                      I_offset_ack=I_ack, ri=tuple(ris[b]) if O_ri else (), I_offset_ri=I_ri, cqi=tuple(cqis[b]),
+                                      I_offset_cqi=I_cqi) for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6, shortened=short, ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri,
+                 I_offset_ri=I_ri, cqi_len=O_cqi, I_offset_cqi=I_cqi)
+    for rep in range(2):
+        tb, ok = rx.decode(np.stack(iq), tti0)
+        ri, ack = rx.ri(), rx.ack()
+        cqi, cqi_ok = rx.cqi()
+        C_ = cfg.seg.C
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+        n_ok = n_cqi_ok = 0
+        for b in range(nsf):
+            r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri, O_cqi=O_cqi,
+                             I_offset_cqi=I_cqi)
+            diff = np.abs(g[b, :G].astype(np.int32) - r["g"].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size + 1, (b, int(diff.max()), int((diff != 0).sum()))
+            exact = diff.max() == 0
+            if O_ri:
+                assert np.array_equal(ri[b], r["ri"][:O_ri]) and np.array_equal(ri[b], ris[b]), "ri sf %d" % b
+            if O_ack:
+                assert np.array_equal(ack[b], r["ack"][:O_ack])
+            if exact or snr > 5:
+                assert bool(cqi_ok[b]) == r["cqi_ok"], "cqi crc sf %d" % b
+                if r["cqi_ok"]:
+                    assert np.array_equal(cqi[b], r["cqi"]), "cqi sf %d" % b
+            if r["cqi_ok"] and np.array_equal(r["cqi"], cqis[b]):
+                n_cqi_ok += 1
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+            if r["ok"] or exact:
+                assert np.array_equal(tb[b], r["tb"])
+            if r["ok"]:
+                n_ok += 1
+                assert np.array_equal(tb[b][:tbs // 8], data[b])
+        assert (n_ok > 0 and n_cqi_ok > 0) or snr < 5
+    rx.free()
+
+
+def test_ul_tx_rx_loop_cqi(hp):
+    """Device transmit chain with CQI report, HARQ-ACK and rank indication into the device receive chain (noise-free): everything comes
+    back, for a block-coded and a convolutionally coded report."""
+    prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12
+    rng = np.random.default_rng(80)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    acks, ris = rng.integers(0, 2, (nsf, 2), dtype=np.uint8), rng.integers(0, 2, (nsf, 1), dtype=np.uint8)
+    for O in (4, 11, 12, 40, 64):
+        cqis = rng.integers(0, 2, (nsf, O), dtype=np.uint8)
+        kw = dict(ack_len=2, I_offset_ack=8, ri_len=1, I_offset_ri=7, cqi_len=O, I_offset_cqi=9)
+        tx = hp.UlTx(3, prb, 0x77, mod, tbs, L, n_prb, 1, nsf, **kw)
+        rx = hp.UlRx(3, prb, 0x77, mod, tbs, L, n_prb, 1, 6, nsf, **kw)
+        tb, ok = rx.decode(tx.encode(data, 5, ack=acks, ri=ris, cqi=cqis), 5)
+        cqi, cqi_ok = rx.cqi()
+        assert ok.all() and np.array_equal(tb[:, :tbs // 8], data) and np.array_equal(rx.ack(), acks) and np.array_equal(rx.ri(), ris)
+        assert cqi_ok.all() and np.array_equal(cqi, cqis), O
+        tx.free()
+        rx.free()
+
+
+def test_ul_cqi_config_errors(hp):
+    """Creation fails for a reserved CQI offset index (beta < 0, sch.c:51-52) or more than 64 report bits; the plain entry points refuse
+    a pipeline with a configured report."""
+    for kw in (dict(cqi_len=4, I_offset_cqi=0), dict(cqi_len=4, I_offset_cqi=16), dict(cqi_len=65, I_offset_cqi=5)):
+        with pytest.raises(RuntimeError):
+            hp.UlRx(3, 25, 0x77, 2, 4008, 10, 2, 1, 6, 2, **kw)
+        with pytest.raises(RuntimeError):
+            hp.UlTx(3, 25, 0x77, 2, 4008, 10, 2, 1, 2, **kw)
+    tx = hp.UlTx(3, 25, 0x77, 2, 4008, 10, 2, 1, 2, cqi_len=4, I_offset_cqi=5)
+    with pytest.raises(RuntimeError):
+        tx.encode(np.zeros((2, 501), np.uint8), 0)
+    tx.free()
+
+
 def test_ul_tx_rx_loop_uci(hp):
     """Device transmit chain with HARQ-ACK and rank indication into the device receive chain (noise-free): everything comes back."""
     prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12

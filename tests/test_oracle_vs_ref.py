@@ -1215,3 +1215,146 @@ def test_pdsch_arbitrary_allocation_vs_reference(case):
     if crc:
         assert np.array_equal(rx.payload(info["tbs"] // 8), r["tb"][:info["tbs"] // 8]) and np.array_equal(r["tb"][:info["tbs"] // 8], data)
     rx.free()
+
+
+# ---------------------------------------------------------------- CQI / PMI report on the PUSCH (uci.c:264-494)
+def _ref_pusch_cfg(L_prb, nof_symb, mod, K_segm):
+    from _libs import ref_layout
+    lay = ref_layout({"srslte_pusch_cfg_t": ["K_segm", "grant.L_prb", "grant.nof_symb", "grant.tb.mod"]}, ["srslte/phy/phch/pusch_cfg.h"])
+    buf = (C.c_uint8 * lay["srslte_pusch_cfg_t"])()
+    u32 = C.cast(buf, C.POINTER(C.c_uint32))
+    u32[lay["srslte_pusch_cfg_t.K_segm"] // 4], u32[lay["srslte_pusch_cfg_t.grant.L_prb"] // 4] = K_segm, L_prb
+    u32[lay["srslte_pusch_cfg_t.grant.nof_symb"] // 4], u32[lay["srslte_pusch_cfg_t.grant.tb.mod"] // 4] = nof_symb, mod
+    return buf
+
+
+BETA_CQI = [-1.0, -1.0, 1.125, 1.25, 1.375, 1.625, 1.750, 2.0, 2.25, 2.5, 2.875, 3.125, 3.5, 4.0, 5.0, 6.25]  # sch.c:51-52
+
+
+def _ref_viterbi(max_bits=512):
+    """srslte_viterbi_t for the LTE tail-biting K = 7 rate-1/3 code, as srslte_uci_cqi_init sets it up (uci.c:249-252)."""
+    R = ref()
+    v = opaque(4096)
+    poly = (C.c_int * 3)(0x6D, 0x4F, 0x57)
+    R.srslte_viterbi_init.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_uint32, C.c_bool]
+    assert R.srslte_viterbi_init(v, 2, poly, max_bits, True) == 0  # SRSLTE_VITERBI_37
+    return v
+
+
+def test_viterbi37_vs_reference_float_entry():
+    """srslte_viterbi_decode_f (viterbi.c:518-548) with the 16-bit AVX2 decoder an x86 build selects: hard decisions bit for bit, clean to
+    hopeless inputs, frame lengths of the CQI reports (O + 8)."""
+    R, orc = ref(), oracle()
+    v = _ref_viterbi()
+    rng = np.random.default_rng(37)
+    orc.orc_uci_cqi_encode.restype = C.c_int
+    for F in (20, 21, 28, 36, 48, 64, 72):
+        for sigma in (0.0, 0.4, 0.8, 1.2, 2.0, 5.0):
+            for trial in range(4):
+                bits = rng.integers(0, 2, F, dtype=np.uint8)
+                sr, enc = 0, np.zeros(3 * F, np.uint8)
+                for i in range(F - 6, F):
+                    sr = (sr << 1) | int(bits[i])
+                for i in range(F):
+                    sr = ((sr << 1) | int(bits[i])) & 0x7f
+                    for j, pl in enumerate((0x6D, 0x4F, 0x57)):
+                        enc[3 * i + j] = bin(sr & pl).count("1") & 1
+                sym = ((2.0 * enc - 1) * 7.3 + sigma * 7.3 * rng.standard_normal(3 * F)).astype(np.float32)
+                a, b = np.zeros(F, np.uint8), np.zeros(F, np.uint8)
+                assert R.srslte_viterbi_decode_f(v, p(acopy(sym)), p(a), F) >= 0
+                orc.orc_viterbi37_tb_f(p(sym), F, p(b))
+                assert np.array_equal(a, b), (F, sigma, trial)
+                if sigma <= 0.4:
+                    assert np.array_equal(a, bits)
+    R.srslte_viterbi_free(v)
+
+
+def test_reference_viterbi_decode_s_loses_positive_soft_bits():
+    """Fact about the reference: srslte_viterbi_decode_s - what decode_cqi_long (uci.c:393) calls - quantises with
+    (int16_t)(32767 + in) on an AVX2 build (viterbi.c:571, srslte_vec_quant_sus vector.c:443-453); every positive soft bit overflows and
+    comes out as 0 = certain zero. A clean code word of a non-zero message decodes to all zeros; the float entry point decodes it."""
+    R = ref()
+    v = _ref_viterbi()
+    F = 24
+    bits = np.array([1, 0, 1, 1, 0, 0, 1, 0] * 3, np.uint8)
+    sr, enc = 0, np.zeros(3 * F, np.uint8)
+    for i in range(F - 6, F):
+        sr = (sr << 1) | int(bits[i])
+    for i in range(F):
+        sr = ((sr << 1) | int(bits[i])) & 0x7f
+        for j, pl in enumerate((0x6D, 0x4F, 0x57)):
+            enc[3 * i + j] = bin(sr & pl).count("1") & 1
+    soft = (200 * (2 * enc.astype(np.int32) - 1)).astype(np.int16)
+    a, b = np.ones(F, np.uint8), np.zeros(F, np.uint8)
+    assert R.srslte_viterbi_decode_s(v, p(acopy(soft)), p(a), F) >= 0
+    assert R.srslte_viterbi_decode_f(v, p(acopy(soft.astype(np.float32))), p(b), F) >= 0
+    assert not a.any() and np.array_equal(b, bits)
+    R.srslte_viterbi_free(v)
+
+
+@pytest.mark.parametrize("O", [1, 2, 4, 5, 7, 10, 11, 12, 13, 20, 28, 40, 56, 64])
+def test_uci_cqi_pusch_vs_reference(O):
+    """srslte_uci_encode_cqi_pusch / srslte_uci_decode_cqi_pusch: Q' and coded bits for every report size; decoded report for the block
+    code (up to 11 bits) at three noise levels, bit for bit. Above 11 bits the reference's decoder is not usable (previous test): the
+    oracle's de-rate-matching + Viterbi (pinned above through the float entry point) + CRC must give back what was sent."""
+    R, orc = ref(), oracle()
+    rng = np.random.default_rng(900 + O)
+    q = opaque(1 << 16)
+    assert R.srslte_uci_cqi_init(q) == 0
+    R.srslte_uci_encode_cqi_pusch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_void_p]
+    R.srslte_uci_decode_cqi_pusch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    for L_prb, nsymb, mod, K_segm, I_off, Qp_ri in ((50, 12, 2, 2 * 5824, 7, 0), (100, 12, 3, 13 * 5824, 15, 8), (6, 11, 1, 1056, 9, 3), (25, 12, 2, 4032, 12, 0)):
+        cfg, Qm = _ref_pusch_cfg(L_prb, nsymb, mod, K_segm), 2 * mod
+        for trial in range(3):
+            cqi = rng.integers(0, 2, O, dtype=np.uint8)
+            qb_ref = np.zeros(8 * 14 * 12 * L_prb, np.uint8)
+            Qp = R.srslte_uci_encode_cqi_pusch(q, cfg, p(cqi), O, BETA_CQI[I_off], Qp_ri, p(qb_ref))
+            assert Qp == orc.orc_uci_cqi_qprime(O, I_off, L_prb, nsymb, K_segm, Qp_ri) and Qp > 0
+            Q = Qp * Qm
+            qb = np.zeros(Q, np.uint8)
+            assert orc.orc_uci_cqi_encode(p(cqi), O, p(qb), Q) == 0
+            assert np.array_equal(qb, qb_ref[:Q]), (O, L_prb)
+            for sigma in (0.3, 1.0, 2.5):
+                llr = np.clip(np.round(40 * ((2.0 * qb - 1) + sigma * rng.standard_normal(Q))), -30000, 30000).astype(np.int16)
+                out, ok = np.zeros(64, np.uint8), C.c_uint8(0)
+                assert orc.orc_uci_cqi_decode(p(acopy(llr)), Q, O, p(out), C.byref(ok)) == 0
+                if O <= 11:
+                    out_ref, ack_ref = np.zeros(64, np.uint8), C.c_bool(False)
+                    assert R.srslte_uci_decode_cqi_pusch(q, cfg, p(acopy(llr)), BETA_CQI[I_off], Qp_ri, O, p(out_ref), C.byref(ack_ref)) == Qp
+                    assert ok.value == 1 and ack_ref.value and np.array_equal(out[:O], out_ref[:O]), (O, L_prb, sigma)
+                elif sigma <= 1.0 and Q >= 6 * (O + 8):  # enough redundancy for the noise level: the report comes back and the CRC says so
+                    assert ok.value == 1 and np.array_equal(out[:O], cqi), (O, L_prb, sigma)
+    R.srslte_uci_cqi_free(q)
+
+
+@pytest.mark.parametrize("prb,L_prb,n_prb,mod,tbs,cqi_N,I_cqi,O_ack,O_ri,short", [(25, 25, 0, 2, 4008, 0, 7, 0, 0, False), (50, 40, 5, 1, 2792, 0, 12, 1, 0, False),
+                                                                                  (100, 100, 0, 3, 61664, 0, 9, 2, 2, False), (15, 12, 1, 2, 1800, 3, 8, 0, 0, True),
+                                                                                  (50, 50, 0, 2, 11448, 9, 10, 1, 1, False), (100, 96, 2, 3, 43816, 13, 6, 0, 2, False)])
+def test_ulsch_with_cqi_vs_reference(prb, L_prb, n_prb, mod, tbs, cqi_N, I_cqi, O_ack, O_ri, short):
+    """CQI on the PUSCH through the reference's own srslte_ulsch_encode / srslte_ulsch_decode (sch.c:991-1240): the oracle's transmit side
+    puts the same bits in the same places (coded report in front of the UL-SCH, Q' from the offset index, UL-SCH rate-matched to the rest,
+    next to HARQ-ACK and RI), and on the oracle's noisy subframe both receivers return the same transport block and - for the block-coded
+    reports (wide band, 4 bits) - the same report. Sub-band reports (22 / 30 bits here, convolutional code): transmit side and UL-SCH side
+    against the reference, the report itself against what was sent (the reference's decoder for them does not work, see above)."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(prb + tbs + cqi_N)
+    cfg = UlConfig(prb, 3, mod, tbs, L_prb, n_prb=n_prb, shortened=short)
+    I_ack, I_ri = 9, 7
+    chain = RefUlsch(cfg, O_ack, I_ack, O_ri, I_ri, cqi_N=cqi_N, I_offset_cqi=I_cqi)
+    wb, diff = int(rng.integers(0, 16)), int(rng.integers(0, 1 << (2 * cqi_N))) if cqi_N else 0
+    bits = chain.cqi_bits(wb, diff)
+    ack, ri = tuple(rng.integers(0, 2, O_ack)), tuple(rng.integers(0, 2, O_ri))
+    data = rng.integers(0, 256, tbs // 8, dtype=np.uint8)
+    keep = {}
+    iq, _ = make_ul_subframe(cfg, 4, rng, snr_db=None, data=data, keep=keep, ack=ack, I_offset_ack=I_ack, ri=ri, I_offset_ri=I_ri, cqi=bits, I_offset_cqi=I_cqi)
+    g_ref, q_ref = chain.encode(data, ack=ack, ri=(ri[0] if O_ri else None), cqi=(wb, diff))
+    assert np.array_equal(keep["g"], g_ref[:len(keep["g"])])  # CQI code word + UL-SCH bits, before the interleaver
+    snr = {1: 6.0, 2: 12.0, 3: 18.0}[mod]
+    iq, _ = make_ul_subframe(cfg, 4, rng, snr_db=snr, data=data, ack=ack, I_offset_ack=I_ack, ri=ri, I_offset_ri=I_ri, cqi=bits, I_offset_cqi=I_cqi)
+    r = oracle_ul_rx(cfg, iq, 4, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri, O_cqi=len(bits), I_offset_cqi=I_cqi)
+    d = chain.decode(r["q_before_ack"], cfg.scramble(4))
+    assert d["ok"] == r["ok"] and (not r["ok"] or np.array_equal(d["tb"], r["tb"]))
+    assert r["ok"] and np.array_equal(r["tb"][:tbs // 8], data)
+    assert np.array_equal(r["cqi"], bits) and r["cqi_ok"]
+    if cqi_N == 0:
+        assert d["cqi"] == (wb, 0) and d["cqi_crc"]
