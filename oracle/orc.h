@@ -161,6 +161,17 @@ void orc_predecoding_diversity2(const orc_cf_t* const* y, const orc_cf_t* const*
 void orc_precoding_diversity4(const orc_cf_t* d, orc_cf_t* const* y, int nof_symbols, float scaling);
 void orc_predecoding_diversity4(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* d, float* csi, int nof_rx, int nof_symbols,
                                 float scaling); /* precoding.c:138-262,:325-348 */
+/* orc_mimo.c: 2-layer modes on a 2-port cell with 2 receive antennas (TM3 large-delay CDD, TM4 closed-loop multiplexing; precoding.c:918-1014,
+ * :1326-1438,:1624-1707,:1946-2104); h[port * 2 + antenna], y[antenna]; layer l = codeword l */
+void orc_precoding_cdd2(const orc_cf_t* x0, const orc_cf_t* x1, orc_cf_t* y0, orc_cf_t* y1, int nof_symbols, float scaling);
+int  orc_precoding_mux2(const orc_cf_t* x0, const orc_cf_t* x1, orc_cf_t* y0, orc_cf_t* y1, int nof_layers, int codebook_idx, int nof_symbols,
+                        float scaling);
+void orc_predecoding_cdd_2x2(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x0, orc_cf_t* x1, float* csi0, float* csi1, int nof_symbols,
+                             float scaling, float noise_estimate);
+int  orc_predecoding_mux_2x2(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x0, orc_cf_t* x1, float* csi0, float* csi1, int codebook_idx,
+                             int nof_symbols, float scaling, float noise_estimate);
+int  orc_predecoding_mux_2x1(const orc_cf_t* const* y, const orc_cf_t* const* h, orc_cf_t* x, float* csi, int codebook_idx, int nof_symbols,
+                             float scaling);
 /* pdsch.c:81-206 RE (de)mapping for a full-band grant, 1 or 2/4 ports, FDD; returns nof RE */
 /* CSI weighting of the LLRs when srslte_pdsch_cfg_t.csi_enable is set (the srsUE default): the csi side output of
  * srslte_predecoding_single_csi (precoding.c:251-291; the diversity one is orc_predecoding_diversity2's) and csi_correction

@@ -62,3 +62,16 @@ $(OUT)/libsrslte_ref.so: $(OBJS) ref_exports.map
 ref: $(OUT)/librefdrv.so
 $(OUT)/librefdrv.so: refdrv.c $(OUT)/libsrslte_ref.so
 	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) -shared -o $@ refdrv.c -L$(OUT) -lsrslte_ref -Wl,-rpath,'$$ORIGIN' -lm
+
+# A second build that differs in ONE flag on ONE translation unit: mimo/precoding.c with -fsigned-zeros. The reference's flags contain
+# -Ofast, which implies -fno-signed-zeros; with this image's gcc 11.4 the two sign masks {+0,-0,...} / {-0,+0,...} of the SIMD large-delay
+# CDD pre-decoders (precoding.c:727-745,:929-947) then come out as ONE constant, the effective channel matrix gets two equal columns
+# and TM3 reception fails in the build above (the reference's own `phy_dl_test -t 3` fails the same way). The scalar
+# tail of the same functions is unaffected. This variant is what the source says; tests pin the two-layer modes on it and record the
+# difference between the two builds (tests/test_oracle_vs_ref.py).
+ref: $(OUT)/libsrslte_ref_sz.so
+$(OBJ)/mimo/precoding_sz.o: $(RLIB)/src/phy/mimo/precoding.c
+	@mkdir -p $(dir $@)
+	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) -fsigned-zeros -c $< -o $@
+$(OUT)/libsrslte_ref_sz.so: $(OBJS) $(OBJ)/mimo/precoding_sz.o ref_exports.map
+	g++ -shared -o $@ $(filter-out $(OBJ)/mimo/precoding.o,$(OBJS)) $(OBJ)/mimo/precoding_sz.o -Wl,--gc-sections -Wl,--version-script=ref_exports.map -lm -lpthread

@@ -69,6 +69,19 @@ def ref():
     return _cache["ref"]
 
 
+def ref_sz():
+    """oracle/_ref/libsrslte_ref_sz.so: the reference with mimo/precoding.c compiled with -fsigned-zeros (oracle/ref.mk says why): the
+    build whose large-delay-CDD receiver does what its source says. Only the two-layer tests use it."""
+    if "ref_sz" not in _cache:
+        path = REF_SO.replace("libsrslte_ref.so", "libsrslte_ref_sz.so")
+        lib = None
+        if os.path.exists(path):
+            lib = C.CDLL(path)
+            lib.srslte_rm_turbo_gentables()
+        _cache["ref_sz"] = lib
+    return _cache["ref_sz"]
+
+
 def hip():
     """The product library. Raises if it has not been built: tests must fail loudly, never fall back."""
     if "hip" not in _cache:

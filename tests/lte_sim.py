@@ -19,14 +19,22 @@ class DlConfig:
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None,
-                 prb_mask=None):
+                 prb_mask=None, tx_scheme=None, pmi=0, mod2=None, tbs2=0):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
+        # two-layer modes of a 2-port cell with 2 receive antennas (SURVEY §8f N4): tx_scheme "cdd" (TM3, two transport blocks) or "mux"
+        # (TM4: two transport blocks with pmi 0/1, or one - tbs2 = 0 - with pmi 0..3); srslte_pdsch_grant_t.tx_scheme / pmi / tb[1]
+        self.tx_scheme, self.pmi = tx_scheme, pmi
+        self.mods, self.tbss = [mod] + ([mod2 if mod2 is not None else mod] if tbs2 else []), [tbs] + ([tbs2] if tbs2 else [])
+        self.nof_tb = len(self.tbss)
+        if tx_scheme is not None:
+            assert nof_ports == 2 and nof_rx == 2 and tx_scheme in ("cdd", "mux") and (tx_scheme == "mux" or self.nof_tb == 2)
+            self.codebook_idx = pmi if self.nof_tb == 1 else pmi + 1  # pdsch.c:914
         # srslte_pdsch_grant_t.prb_idx[s][n] (pdsch_cfg.h:41): None = every PRB in both slots, else [2][nof_prb] of 0/1
         self.prb_mask = None if prb_mask is None else np.ascontiguousarray(prb_mask, np.uint8).reshape(2, nof_prb)
         self.Qm = MOD_BITS[mod]
         # bits per "symbol" in the code-block split of the rate matcher: Qm * N_L, N_L = 2 for transmit diversity (36.212 5.1.4.1.2;
         # srslte_dlsch_decode2 / _encode2, sch.c:507-531,:549-575)
-        self.Qm_sch = self.Qm * (2 if nof_ports > 1 else 1)
+        self.Qm_sch = self.Qm * (2 if nof_ports > 1 and tx_scheme is None else 1)
         self.nof_rx = nof_rx  # receive antennas (single tx port): MRC combining, SURVEY §8f N4
         self.llr8 = llr8  # 8-bit LLR path (pdsch.c q->llr_is_8bit, sch.c:336-338,:354-356), SURVEY §8f N2
         self.nof_ports = nof_ports
@@ -44,6 +52,10 @@ class DlConfig:
         self.chest = chest or {"filter_coef": (4.0, 1.0)}  # phy_dl_test.c:587-595
         self.seg = OrcCbsegm()
         assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
+        self.segs = [self.seg]
+        if tbs2:
+            self.segs.append(OrcCbsegm())
+            assert oracle().orc_cbsegm(C.byref(self.segs[1]), tbs2) == 0 and self.segs[1].F == 0
 
     def indices(self, sf_idx):
         idx = np.zeros(self.grid_len, np.uint32)
@@ -122,6 +134,14 @@ def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None
         orc.orc_precoding_diversity4(p(syms), (C.c_void_p * 4)(*[v.ctypes.data for v in y]), len(idx), cfg.scaling)
     if keep is not None:
         keep.update(y=[v.copy() for v in y], idx=idx)
+    return _ports_to_iq(cfg, sf_idx, idx, y, q, rng, snr_db, amp)
+
+
+def _ports_to_iq(cfg, sf_idx, idx, y, q, rng, snr_db, amp):
+    """Per-port PDSCH symbols -> RE mapping + CRS per port -> every (antenna, port) path through its own smooth frequency response (a gain
+    and a delay) -> OFDM TX per receive antenna, plus noise."""
+    orc = oracle()
+    npt = cfg.nof_ports
     tx = []
     for port in range(npt):
         g = np.zeros(cfg.grid_len, np.complex64)
@@ -145,6 +165,101 @@ def _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep=None
             iq = iq + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
         out.append(iq.astype(np.complex64))
     return out[0] if cfg.nof_rx == 1 else np.stack(out)
+
+
+def make_subframe_mimo(cfg, tti, rng, snr_db=None, amp=1.0, rv=(0, 0), data=None, keep=None):
+    """eNB side of pdsch.c:1059-1185 for the two-layer modes: every transport block coded, scrambled with its codeword's sequence and
+    modulated on its own (srslte_pdsch_codeword_encode, :1000-1056), no layer mapping (nof_layers == nof_tb), srslte_precoding_type with
+    CDD or the codebook, RE mapping + CRS per port, a 2x2 channel. Returns (iq [2][sf_len], [payload per TB])."""
+    orc = oracle()
+    sf_idx = tti % 10
+    idx = cfg.indices(sf_idx)
+    nre = len(idx)
+    if data is None:
+        data = [rng.integers(0, 256, t // 8, dtype=np.uint8) for t in cfg.tbss]
+    x = []
+    for cw in range(cfg.nof_tb):
+        Qm = MOD_BITS[cfg.mods[cw]]
+        sch = OrcSchCfg(cfg.tbss[cw], nre * Qm, Qm, rv[cw], cfg.max_iter)
+        e = np.zeros(nre * Qm, np.uint8)
+        assert orc.orc_dlsch_encode(C.byref(sch), p(np.ascontiguousarray(data[cw])), p(e)) == 0
+        c = np.zeros(nre * Qm, np.uint8)
+        orc.orc_gold(C.c_uint32(orc.orc_pdsch_cinit(cfg.rnti, cw, sf_idx, cfg.cell_id)), nre * Qm, p(c))
+        syms = np.zeros(nre, np.complex64)
+        orc.orc_modulate(cfg.mods[cw], p(e ^ c), p(syms), nre * Qm)
+        x.append(syms)
+    y = [np.zeros(nre, np.complex64) for _ in range(2)]
+    if cfg.tx_scheme == "cdd":
+        orc.orc_precoding_cdd2.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_float]
+        orc.orc_precoding_cdd2(p(x[0]), p(x[1]), p(y[0]), p(y[1]), nre, cfg.scaling)
+    else:
+        orc.orc_precoding_mux2.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float]
+        assert orc.orc_precoding_mux2(p(x[0]), p(x[1]) if cfg.nof_tb == 2 else None, p(y[0]), p(y[1]), cfg.nof_tb, cfg.codebook_idx, nre, cfg.scaling) == 0
+    if keep is not None:
+        keep.update(x=x, y=[v.copy() for v in y], idx=idx)
+    q = OrcOfdm()
+    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+    q.normalize = True
+    return _ports_to_iq(cfg, sf_idx, idx, y, q, rng, snr_db, amp), data
+
+
+def oracle_rx_mimo(cfg, iq, tti, keep=False, grid_in=None, rv=(0, 0)):
+    """Oracle UE chain for the two-layer modes (pdsch.c:833-997 with tx_scheme CDD / SPATIALMUX): per-port, per-antenna estimation, the
+    MMSE (or MRC) pre-decoder with its per-layer csi, then per codeword demapping, descrambling with that codeword's sequence, CSI
+    weighting and DL-SCH decoding. Lists per transport block in the result."""
+    orc = oracle()
+    sf_idx, nrx, npt = tti % 10, 2, 2
+    if grid_in is not None:
+        grid = np.ascontiguousarray(grid_in, np.complex64).reshape(nrx, cfg.grid_len)
+    else:
+        q = OrcOfdm()
+        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+        grid = np.zeros((nrx, cfg.grid_len), np.complex64)
+        iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+        for a in range(nrx):
+            orc.orc_ofdm_rx_sf(C.byref(q), p(iq2[a]), p(grid[a]))
+    res, ccfg = OrcChestRes(), cfg.orc_chest_cfg()
+    idx = cfg.indices(sf_idx)
+    nre = len(idx)
+    ce = np.zeros((npt * nrx, cfg.grid_len), np.complex64)  # [port * nrx + antenna]
+    gp, cp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grid]), (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce])
+    orc.orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert orc.orc_chest_dl_ports(C.byref(cfg.cell), sf_idx, C.byref(ccfg), nrx, gp, cp, C.byref(res), None) == 0
+    ys, hs = [np.ascontiguousarray(g[idx]) for g in grid], [np.ascontiguousarray(c[idx]) for c in ce]
+    yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * (npt * nrx))(*[v.ctypes.data for v in hs])
+    x, csi = [np.zeros(nre, np.complex64) for _ in range(2)], [np.zeros(nre, np.float32) for _ in range(2)]
+    noise = res.noise_estimate
+    if cfg.tx_scheme == "cdd":
+        orc.orc_predecoding_cdd_2x2.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_float]
+        orc.orc_predecoding_cdd_2x2(yp, hp, p(x[0]), p(x[1]), p(csi[0]), p(csi[1]), nre, cfg.scaling, noise)
+    elif cfg.nof_tb == 2:
+        orc.orc_predecoding_mux_2x2.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float]
+        assert orc.orc_predecoding_mux_2x2(yp, hp, p(x[0]), p(x[1]), p(csi[0]), p(csi[1]), cfg.codebook_idx, nre, cfg.scaling, noise) == 0
+    else:
+        orc.orc_predecoding_mux_2x1.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float]
+        assert orc.orc_predecoding_mux_2x1(yp, hp, p(x[0]), p(csi[0]), cfg.codebook_idx, nre, cfg.scaling) == 0
+    out = {"tb": [], "ok": [], "iters": [], "cb_ok": [], "e": [], "e_raw": []}
+    for cw in range(cfg.nof_tb):
+        mod, Qm, tbs, seg = cfg.mods[cw], MOD_BITS[cfg.mods[cw]], cfg.tbss[cw], cfg.segs[cw]
+        e = np.zeros(nre * Qm, np.int16)
+        orc.orc_demod_soft_s(mod, p(x[cw]), p(e), nre)
+        c = np.zeros(nre * Qm, np.uint8)
+        orc.orc_gold(C.c_uint32(orc.orc_pdsch_cinit(cfg.rnti, cw, sf_idx, cfg.cell_id)), nre * Qm, p(c))
+        orc.orc_scramble_s(p(e), p(c), nre * Qm)
+        out["e_raw"].append(e.copy())
+        if cfg.csi:
+            orc.orc_csi_correction_s(p(e), p(csi[cw]), nre, mod)
+        sch = OrcSchCfg(tbs, nre * Qm, Qm, rv[cw], cfg.max_iter)
+        tb, iters, cbok = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(seg.C, np.uint32), np.zeros(seg.C, np.uint8)
+        rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+        out["tb"].append(tb[:tbs // 8 + 3])
+        out["ok"].append(rc == 0)
+        out["iters"].append(iters)
+        out["cb_ok"].append(cbok)
+        out["e"].append(e)
+    if keep:
+        out.update(grid=grid, ce=ce, noise=noise, d=x[:cfg.nof_tb], csi=csi[:cfg.nof_tb], res=res)
+    return out
 
 
 def make_grid(cfg, tti, rng, snr_db):
@@ -358,13 +473,13 @@ class RefPdsch:
     srslte_chest_dl_estimate_cfg. Only the FFT in front of it is the oracle's. Struct offsets come from the reference headers at run
     time (_libs.ref_layout). Pins the stage-by-stage chains (RefRx, oracle_rx) and the CSI weighting of the LLRs."""
 
-    def __init__(self, cfg, csi_enable=False):
+    def __init__(self, cfg, csi_enable=False, lib=None):
         from _libs import RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, aligned, opaque, ref, ref_layout
-        R = self.R = ref()
+        R = self.R = lib if lib is not None else ref()
         self.cfg, self.aligned = cfg, aligned
         L = self.L = ref_layout({"srslte_pdsch_t": ["llr_is_8bit", "d", "e", "csi", "dl_sch"], "srslte_sch_t": ["llr_is_8bit"],
                                  "srslte_pdsch_cfg_t": ["rnti", "max_nof_iterations", "decoder_type", "csi_enable", "softbuffers", "p_a", "p_b", "power_scale"],
-                                 "srslte_pdsch_grant_t": ["tx_scheme", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
+                                 "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]}, ["srslte/phy/phch/pdsch.h"])
         cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
@@ -393,17 +508,22 @@ class RefPdsch:
 
         def u32(off, v):
             g[off:off + 4].view(np.uint32)[0] = v
-        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports > 1 else 0)
+        # srslte_tx_scheme_t (phy_common.h:232-237): PORT0, DIVERSITY, SPATIALMUX, CDD
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], {"cdd": 3, "mux": 2}[cfg.tx_scheme] if cfg.tx_scheme else (1 if cfg.nof_ports > 1 else 0))
+        u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
-        u32(L["srslte_pdsch_grant_t.nof_tb"], 1)
-        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_ports)
+        u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)
+        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_tb if cfg.tx_scheme else cfg.nof_ports)
         self.tb0 = L["srslte_pdsch_grant_t.tb"]
-        u32(self.tb0 + L["srslte_ra_tb_t.mod"], cfg.mod)
-        u32(self.tb0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
-        g[self.tb0 + L["srslte_ra_tb_t.enabled"]] = 1
+        for cw in range(cfg.nof_tb):
+            o = self.tb0 + cw * L["srslte_ra_tb_t"]
+            u32(o + L["srslte_ra_tb_t.mod"], cfg.mods[cw])
+            u32(o + L["srslte_ra_tb_t.tbs"], cfg.tbss[cw])
+            u32(o + L["srslte_ra_tb_t.cw_idx"], cw)
+            g[o + L["srslte_ra_tb_t.enabled"]] = 1
         g[L["srslte_pdsch_cfg_t.rnti"]:L["srslte_pdsch_cfg_t.rnti"] + 2].view(np.uint16)[0] = cfg.rnti
         u32(L["srslte_pdsch_cfg_t.max_nof_iterations"], cfg.max_iter)
         u32(L["srslte_pdsch_cfg_t.decoder_type"], 1)  # SRSLTE_MIMO_DECODER_MMSE
@@ -413,15 +533,56 @@ class RefPdsch:
             g[L["srslte_pdsch_cfg_t.p_a"]:L["srslte_pdsch_cfg_t.p_a"] + 4].view(np.float32)[0] = cfg.p_a
             u32(L["srslte_pdsch_cfg_t.p_b"], 1 if cfg.nof_ports > 1 else 0)  # rho_b = 1 (phy_dl_test.c:178)
         g[L["srslte_pdsch_cfg_t.softbuffers"]:L["srslte_pdsch_cfg_t.softbuffers"] + 8].view(np.uint64)[0] = C.addressof(self.sb)
+        if cfg.nof_tb == 2:  # softbuffers.rx[1]
+            self.sb1 = opaque(L["srslte_softbuffer_rx_t"] + 64)
+            assert R.srslte_softbuffer_rx_init(self.sb1, cfg.nof_prb) == 0
+            g[L["srslte_pdsch_cfg_t.softbuffers"] + 8:L["srslte_pdsch_cfg_t.softbuffers"] + 16].view(np.uint64)[0] = C.addressof(self.sb1)
         self.u32 = u32
         self.ofdm = OrcOfdm()
         oracle().orc_ofdm_init(C.byref(self.ofdm), cfg.nof_prb, True)
         self.nre = {s_: len(cfg.indices(s_)) for s_ in (0, 5, 1)}
 
-    def _ptr(self, name, dtype, count):
-        addr = np.frombuffer(self.q, np.uint64, 1, self.L["srslte_pdsch_t." + name])[0]
+    def _ptr(self, name, dtype, count, cw=0):
+        addr = np.frombuffer(self.q, np.uint64, 1, self.L["srslte_pdsch_t." + name] + 8 * cw)[0]
         nbytes = count * np.dtype(dtype).itemsize
         return np.frombuffer(C.string_at(int(addr), nbytes), dtype).copy()
+
+    def run_mimo(self, iq, tti, grid_in=None):
+        """Two-layer modes: per transport block lists of tb / ok / d / e / csi (rv 0, new data)."""
+        cfg, R, L = self.cfg, self.R, self.L
+        nrx = cfg.nof_rx
+        grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(nrx)]
+        if grid_in is not None:
+            for a_ in range(nrx):
+                grids[a_].view(np.complex64)[:] = np.asarray(grid_in, np.complex64).reshape(nrx, -1)[a_]
+        else:
+            iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+            for a_ in range(nrx):
+                oracle().orc_ofdm_rx_sf(C.byref(self.ofdm), p(iq2[a_]), p(grids[a_]))
+        self.sf.tti, self.sf.cfi = tti, cfg.cfi
+        inp = (C.c_void_p * 4)(*([g_.ctypes.data for g_ in grids] + [0] * (4 - nrx)))
+        assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
+        nre = self.nre[0 if tti % 10 == 0 else (5 if tti % 10 == 5 else 1)]
+        self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
+        R.srslte_softbuffer_rx_reset(self.sb)
+        payloads = [np.zeros(t // 8 + 64, np.uint8) for t in cfg.tbss]
+        data = np.zeros(2 * L["srslte_pdsch_res_t"], np.uint8)
+        for cw in range(cfg.nof_tb):
+            o = self.tb0 + cw * L["srslte_ra_tb_t"]
+            self.u32(o + L["srslte_ra_tb_t.nof_bits"], nre * MOD_BITS[cfg.mods[cw]])
+            self.u32(o + L["srslte_ra_tb_t.rv"], 0)
+            data[cw * L["srslte_pdsch_res_t"]:][:8].view(np.uint64)[0] = payloads[cw].ctypes.data
+            if cw:
+                R.srslte_softbuffer_rx_reset(self.sb1)
+        assert R.srslte_pdsch_decode(self.q, C.byref(self.sf), p(self.pc), C.byref(self.res), inp, p(data)) == 0
+        out = {"tb": [], "ok": [], "d": [], "e": [], "csi": [], "noise": self.res.noise_estimate}
+        for cw in range(cfg.nof_tb):
+            out["tb"].append(payloads[cw][:cfg.tbss[cw] // 8 + 3].copy())
+            out["ok"].append(bool(data[cw * L["srslte_pdsch_res_t"] + L["srslte_pdsch_res_t.crc"]]))
+            out["d"].append(self._ptr("d", np.complex64, nre, cw))
+            out["e"].append(self._ptr("e", np.int16, nre * MOD_BITS[cfg.mods[cw]], cw))
+            out["csi"].append(self._ptr("csi", np.float32, nre, cw))
+        return out
 
     def run(self, iq, tti, grid_in=None, rv=0, new_data=True):
         cfg, R, L = self.cfg, self.R, self.L
@@ -463,7 +624,7 @@ class RefPdschTx:
         R = self.R = ref()
         self.cfg, self.aligned = cfg, aligned
         L = self.L = ref_layout({"srslte_pdsch_t": [], "srslte_pdsch_cfg_t": ["rnti", "softbuffers"],
-                                 "srslte_pdsch_grant_t": ["tx_scheme", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
+                                 "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"], "srslte_softbuffer_tx_t": []},
                                 ["srslte/phy/phch/pdsch.h"])
         cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
@@ -477,20 +638,49 @@ class RefPdschTx:
 
         def u32(off, v):
             g[off:off + 4].view(np.uint32)[0] = v
-        u32(L["srslte_pdsch_grant_t.tx_scheme"], 1 if cfg.nof_ports > 1 else 0)
+        u32(L["srslte_pdsch_grant_t.tx_scheme"], {"cdd": 3, "mux": 2}[cfg.tx_scheme] if cfg.tx_scheme else (1 if cfg.nof_ports > 1 else 0))
+        u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
-        u32(L["srslte_pdsch_grant_t.nof_tb"], 1)
-        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_ports)
+        u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)
+        u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_tb if cfg.tx_scheme else cfg.nof_ports)
         self.tb0 = L["srslte_pdsch_grant_t.tb"]
-        u32(self.tb0 + L["srslte_ra_tb_t.mod"], cfg.mod)
-        u32(self.tb0 + L["srslte_ra_tb_t.tbs"], cfg.tbs)
-        g[self.tb0 + L["srslte_ra_tb_t.enabled"]] = 1
+        for cw in range(cfg.nof_tb):
+            o = self.tb0 + cw * L["srslte_ra_tb_t"]
+            u32(o + L["srslte_ra_tb_t.mod"], cfg.mods[cw])
+            u32(o + L["srslte_ra_tb_t.tbs"], cfg.tbss[cw])
+            u32(o + L["srslte_ra_tb_t.cw_idx"], cw)
+            g[o + L["srslte_ra_tb_t.enabled"]] = 1
         g[L["srslte_pdsch_cfg_t.rnti"]:L["srslte_pdsch_cfg_t.rnti"] + 2].view(np.uint16)[0] = cfg.rnti
         g[L["srslte_pdsch_cfg_t.softbuffers"]:L["srslte_pdsch_cfg_t.softbuffers"] + 8].view(np.uint64)[0] = C.addressof(self.sb)
+        if cfg.nof_tb == 2:  # softbuffers.tx[1]
+            self.sb1 = opaque(L["srslte_softbuffer_tx_t"] + 64)
+            assert R.srslte_softbuffer_tx_init(self.sb1, cfg.nof_prb) == 0
+            g[L["srslte_pdsch_cfg_t.softbuffers"] + 8:L["srslte_pdsch_cfg_t.softbuffers"] + 16].view(np.uint64)[0] = C.addressof(self.sb1)
         self.u32, self.sf = u32, RefDlSfCfg()
+
+    def run_mimo(self, data, tti):
+        """Two-layer modes: data = [payload per transport block] -> one resource grid per port (rv 0)."""
+        cfg, R, L = self.cfg, self.R, self.L
+        nre = len(cfg.indices(tti % 10))
+        self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
+        self.sf.tti, self.sf.cfi = tti, cfg.cfi
+        bufs = []
+        for cw in range(cfg.nof_tb):
+            o = self.tb0 + cw * L["srslte_ra_tb_t"]
+            self.u32(o + L["srslte_ra_tb_t.nof_bits"], nre * MOD_BITS[cfg.mods[cw]])
+            self.u32(o + L["srslte_ra_tb_t.rv"], 0)
+            R.srslte_softbuffer_tx_reset(self.sb1 if cw else self.sb)
+            d = np.zeros(cfg.tbss[cw] // 8 + 64, np.uint8)
+            d[:cfg.tbss[cw] // 8] = data[cw]
+            bufs.append(d)
+        dp = (C.c_void_p * 2)(*([b_.ctypes.data for b_ in bufs] + [0] * (2 - cfg.nof_tb)))
+        grids = [self.aligned(2 * cfg.grid_len, np.float32) for _ in range(2)]
+        gp = (C.c_void_p * 4)(grids[0].ctypes.data, grids[1].ctypes.data, 0, 0)
+        assert R.srslte_pdsch_encode(self.q, C.byref(self.sf), p(self.pc), dp, gp) == 0
+        return [g_.view(np.complex64).copy() for g_ in grids]
 
     def run(self, data, tti, rv=0):
         cfg, R, L = self.cfg, self.R, self.L
@@ -576,6 +766,10 @@ class UlConfig:
         assert oracle().orc_ul_dmrs_init(C.byref(self.dmrs), cell_id) == 0
         self.seg = OrcCbsegm()
         assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
+        self.segs = [self.seg]
+        if tbs2:
+            self.segs.append(OrcCbsegm())
+            assert oracle().orc_cbsegm(C.byref(self.segs[1]), tbs2) == 0 and self.segs[1].F == 0
         self.data_syms = [l for l in range(14) if l not in (3, 10)][:self.nsymb]
         # UL channel interleaver without UCI (36.212 5.2.2.8, sch.c:580-598,:891-913): q[(i*R + j)*Qm + k] = g[(j*12 + i)*Qm + k]
         j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(self.nsymb), np.arange(self.Qm), indexing="ij")

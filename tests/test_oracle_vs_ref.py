@@ -9,6 +9,7 @@ from _libs import (OrcCell, OrcChestCfg, OrcChestRes, RefCell, RefChestCfg, RefC
 from lte_sim import DlConfig, RefRx, RefUlRx, UlConfig, make_subframe, make_ul_subframe, oracle_rx, oracle_ul_rx
 
 pytestmark = pytest.mark.skipif(ref() is None, reason="oracle/_ref/libsrslte_ref.so not built")
+orc = oracle()
 ALL_K = list(range(40, 513, 8)) + list(range(528, 1025, 16)) + list(range(1056, 2049, 32)) + list(range(2112, 6145, 64))
 
 
@@ -1142,6 +1143,180 @@ def test_reference_cdd_predecoder_on_a_noise_free_channel():
         res[scheme] = max(np.abs(out[k].view(np.complex64) - x[k].view(np.complex64)).max() for k in range(2))
     assert res[2] < 1e-3
     assert np.isnan(res[3])
+
+
+# ---------------------------------------------------------------- two-layer modes: large-delay CDD (TM3), closed-loop multiplexing (TM4)
+def _mimo_bufs(n, seed):
+    rng = np.random.default_rng(seed)
+
+    def cbuf(v=None):
+        b = aligned(2 * n + 16, np.float32)[:2 * n]
+        if v is not None:
+            b.view(np.complex64)[:] = v
+        return b
+
+    def rc(scale=1.0):
+        return (scale * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    return cbuf, rc
+
+
+def _ref_predecode(R, scheme, y, h, n, nof_layers, codebook_idx, scaling, noise, cbuf):
+    """srslte_predecoding_type (precoding.c:1766-1830) with csi buffers, as srslte_pdsch_decode calls it; h[port][antenna]"""
+    R.srslte_predecoding_type.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float]
+    hp = ((C.c_void_p * 4) * 4)()
+    for i in range(2):
+        for j in range(2):
+            hp[i][j] = h[i][j].ctypes.data
+    out, csi = [cbuf(), cbuf()], [aligned(n + 16, np.float32)[:n], aligned(n + 16, np.float32)[:n]]
+    op, rp = (C.c_void_p * 4)(out[0].ctypes.data, out[1].ctypes.data, 0, 0), (C.c_void_p * 4)(y[0].ctypes.data, y[1].ctypes.data, 0, 0)
+    cp = (C.c_void_p * 2)(csi[0].ctypes.data, csi[1].ctypes.data)
+    assert R.srslte_predecoding_type(rp, hp, op, cp, 2, 2, nof_layers, codebook_idx, n, scheme, scaling, noise) == 0
+    return [o.view(np.complex64).copy() for o in out[:nof_layers]], [c.copy() for c in csi[:nof_layers]]
+
+
+def _orc_predecode(scheme, y, h, n, nof_layers, codebook_idx, scaling, noise):
+    ys = [np.ascontiguousarray(v.view(np.complex64)) for v in y]
+    hs = [np.ascontiguousarray(h[i][j].view(np.complex64)) for i in range(2) for j in range(2)]  # [port * 2 + antenna]
+    yp, hp = (C.c_void_p * 2)(*[v.ctypes.data for v in ys]), (C.c_void_p * 4)(*[v.ctypes.data for v in hs])
+    x, csi = [np.zeros(n, np.complex64) for _ in range(2)], [np.zeros(n, np.float32) for _ in range(2)]
+    if scheme == 3:
+        orc.orc_predecoding_cdd_2x2.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_float, C.c_float]
+        orc.orc_predecoding_cdd_2x2(yp, hp, p(x[0]), p(x[1]), p(csi[0]), p(csi[1]), n, scaling, noise)
+    elif nof_layers == 2:
+        orc.orc_predecoding_mux_2x2.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_float, C.c_float]
+        assert orc.orc_predecoding_mux_2x2(yp, hp, p(x[0]), p(x[1]), p(csi[0]), p(csi[1]), codebook_idx, n, scaling, noise) == 0
+    else:
+        orc.orc_predecoding_mux_2x1.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_float]
+        assert orc.orc_predecoding_mux_2x1(yp, hp, p(x[0]), p(csi[0]), codebook_idx, n, scaling) == 0
+    return x[:nof_layers], csi[:nof_layers]
+
+
+MIMO_MODES = [(3, 2, 0), (2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 1, 0), (2, 1, 1), (2, 1, 2), (2, 1, 3)]  # (tx scheme, layers, codebook index)
+
+
+@pytest.mark.parametrize("scheme,nl,cb", MIMO_MODES)
+def test_mimo_precoding_vs_reference(scheme, nl, cb):
+    """orc_precoding_cdd2 / orc_precoding_mux2 vs the reference's srslte_precoding_type (precoding.c:1897-2148), SIMD bodies and scalar tails
+    (length 206; the AVX large-delay-CDD precoder has no tail loop and leaves the last nof_symbols % 4 outputs unwritten, :1897-1916: 204
+    there): the transmit side of the two-layer stimulus."""
+    n = 204 if scheme == 3 else 206
+    cbuf, rc = _mimo_bufs(n, 10 * scheme + cb)
+    x = [cbuf(rc()), cbuf(rc())]
+    R = ref()
+    R.srslte_precoding_type.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]
+    y = [cbuf(), cbuf()]
+    xp, yp = (C.c_void_p * 4)(x[0].ctypes.data, x[1].ctypes.data, 0, 0), (C.c_void_p * 4)(y[0].ctypes.data, y[1].ctypes.data, 0, 0)
+    assert R.srslte_precoding_type(xp, yp, nl, 2, cb, n, 0.8, scheme) >= 0
+    xs = [np.ascontiguousarray(v.view(np.complex64)) for v in x]
+    o = [np.zeros(n, np.complex64), np.zeros(n, np.complex64)]
+    if scheme == 3:
+        orc.orc_precoding_cdd2.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_float]
+        orc.orc_precoding_cdd2(p(xs[0]), p(xs[1]), p(o[0]), p(o[1]), n, 0.8)
+    else:
+        orc.orc_precoding_mux2.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_float]
+        assert orc.orc_precoding_mux2(p(xs[0]), p(xs[1]), p(o[0]), p(o[1]), nl, cb, n, 0.8) == 0
+    for k in range(2):
+        assert np.abs(o[k] - y[k].view(np.complex64)).max() < 1e-6
+
+
+@pytest.mark.parametrize("scheme,nl,cb", MIMO_MODES)
+def test_mimo_predecoding_scalar_path_vs_reference(scheme, nl, cb):
+    """The pre-decoders' scalar code (what the reference runs on the last < 8 symbols of a subframe, and everywhere on a build without
+    SIMD): exact divisions on both sides, so the oracle must agree to float rounding. Six symbols per call keep the reference out of
+    its SIMD bodies; the CDD alternation restarts with every call, as in the reference."""
+    n = 6
+    for seed in range(6):
+        cbuf, rc = _mimo_bufs(n, 100 * scheme + 10 * cb + seed)
+        y, h = [cbuf(rc()), cbuf(rc())], [[cbuf(rc()), cbuf(rc())], [cbuf(rc()), cbuf(rc())]]
+        noise, scaling = (0.0, 0.03, 0.4)[seed % 3], (1.0, 1.4142135)[seed % 2]
+        xr, cr = _ref_predecode(ref(), scheme, y, h, n, nl, cb, scaling, noise, cbuf)
+        xo, co = _orc_predecode(scheme, y, h, n, nl, cb, scaling, noise)
+        for k in range(nl):
+            assert np.abs(xo[k] - xr[k]).max() <= 2e-5 * max(1.0, np.abs(xr[k]).max()), (seed, k)
+            assert np.abs(co[k] / cr[k] - 1).max() < 2e-5, (seed, k)
+
+
+@pytest.mark.parametrize("scheme,nl,cb", MIMO_MODES)
+def test_mimo_predecoding_simd_path_vs_reference(scheme, nl, cb):
+    """The SIMD bodies the x86 reference runs on whole subframes multiply by 12-bit reciprocal approximations (_mm256_rcp_ps in
+    srslte_simd_cf_rcp / srslte_simd_f_rcp, simd.h:284-300,:959-978; twice in a row for csi): symbols agree with the oracle's exact
+    arithmetic to 1e-3 relative, csi likewise. Large-delay CDD on the build that honours signed zeros (see the next test)."""
+    from _libs import ref_sz
+    n = 512
+    cbuf, rc = _mimo_bufs(n, 1000 + 10 * scheme + cb)
+    y, h = [cbuf(rc()), cbuf(rc())], [[cbuf(rc()), cbuf(rc())], [cbuf(rc()), cbuf(rc())]]
+    R = ref_sz() if scheme == 3 else ref()
+    xr, cr = _ref_predecode(R, scheme, y, h, n, nl, cb, 1.0, 0.05, cbuf)
+    xo, co = _orc_predecode(scheme, y, h, n, nl, cb, 1.0, 0.05)
+    for k in range(nl):
+        assert np.abs(xo[k] - xr[k]).max() <= 1e-3 * np.abs(xr[k]).max()
+        assert np.abs(co[k] / cr[k] - 1).max() < 1.5e-3
+
+
+def test_reference_cdd_sign_masks_collapse_with_no_signed_zeros():
+    """Fact about the reference build, recorded because it decides how TM3 is pinned. The SIMD large-delay-CDD pre-decoders build the
+    effective channel of even / odd symbols with two sign masks, {+0,-0,+0,...} and {-0,+0,-0,...} (precoding.c:727-745,:929-947). The
+    reference's flags include -Ofast (CMakeLists.txt:392), i.e. -fno-signed-zeros, and this image's gcc 11.4 then emits ONE constant for
+    both: column 2 of the effective channel equals column 1, the matrix is singular, csi comes out as the noise estimate and the
+    symbols are wrong (NaN without noise: the test above, and the reference's own `phy_dl_test -t 3`). Compiling that one file with
+    -fsigned-zeros (oracle/ref.mk, libsrslte_ref_sz.so) gives what the source - and its scalar tail in BOTH builds - says."""
+    from _libs import ref_sz
+    n, noise = 64, 0.05
+    cbuf, rc = _mimo_bufs(n, 5)
+    y, h = [cbuf(rc()), cbuf(rc())], [[cbuf(rc()), cbuf(rc())], [cbuf(rc()), cbuf(rc())]]
+    x_fast, csi_fast = _ref_predecode(ref(), 3, y, h, n, 2, 0, 1.0, noise, cbuf)
+    x_sz, csi_sz = _ref_predecode(ref_sz(), 3, y, h, n, 2, 0, 1.0, noise, cbuf)
+    xo, co = _orc_predecode(3, y, h, n, 2, 0, 1.0, noise)
+    assert np.abs(csi_fast[0] / noise - 1).max() < 0.05 and np.abs(csi_fast[1] / noise - 1).max() < 0.05  # rank-1 channel: csi = N0
+    assert np.abs(x_fast[0] - xo[0]).max() > 0.5
+    # model of the collapsed build: both columns built with the first mask
+    Y = np.stack([v.view(np.complex64) for v in y]).astype(np.complex128)
+    H = {(i, j): h[i][j].view(np.complex64).astype(np.complex128) for i in range(2) for j in range(2)}
+    sg = np.where(np.arange(n) % 2 == 0, 1.0, -1.0)
+    c0, c1 = H[0, 0] + sg * H[1, 0], H[0, 1] + sg * H[1, 1]
+    xm = np.zeros((2, n), complex)
+    for i in range(n):
+        Hm = np.array([[c0[i], c0[i]], [c1[i], c1[i]]])
+        xm[:, i] = 2.0 * np.linalg.inv(Hm.conj().T @ Hm + noise * np.eye(2)) @ Hm.conj().T @ Y[:, i]
+    assert np.abs(xm[0] - x_fast[0]).max() < 2e-3 * np.abs(xm).max() and np.abs(xm[1] - x_fast[1]).max() < 2e-3 * np.abs(xm).max()
+    for k in range(2):
+        assert np.abs(x_sz[k] - xo[k]).max() <= 1e-3 * np.abs(xo[k]).max() and np.abs(csi_sz[k] / co[k] - 1).max() < 1.5e-3
+
+
+TWO_LAYER_CASES = [  # nof_prb, cell_id, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti, snr
+    (25, 7, 2, 4008, 2, 4008, "cdd", 0, 1, 3, 22.0), (25, 7, 2, 4008, 1, 2216, "cdd", 0, 2, 0, 16.0), (6, 1, 1, 328, 1, 328, "cdd", 0, 3, 5, 14.0),
+    (50, 150, 3, 21384, 2, 9912, "cdd", 0, 1, 7, 30.0), (100, 2, 2, 22920, 2, 22920, "cdd", 0, 2, 1, 24.0),
+    (25, 7, 2, 4008, 3, 4008, "mux", 0, 1, 3, 24.0), (25, 7, 2, 4008, 2, 2216, "mux", 1, 2, 5, 22.0), (15, 33, 1, 1000, 2, 2216, "mux", 0, 1, 0, 20.0),
+    (100, 2, 3, 30576, 3, 30576, "mux", 1, 1, 4, 32.0),
+    (25, 7, 2, 4008, None, 0, "mux", 0, 1, 3, 14.0), (25, 7, 3, 6200, None, 0, "mux", 1, 2, 5, 18.0), (6, 1, 1, 328, None, 0, "mux", 2, 3, 0, 6.0),
+    (50, 150, 2, 9912, None, 0, "mux", 3, 1, 9, 14.0)]
+
+
+@pytest.mark.parametrize("prb,cid,mod,tbs,mod2,tbs2,scheme,pmi,cfi,tti,snr", TWO_LAYER_CASES)
+def test_pdsch_two_layer_modes_vs_reference(prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti, snr):
+    """The reference's own srslte_pdsch_encode / srslte_pdsch_decode (pdsch.c:833-1185) in TM3 (large-delay CDD, 2 transport blocks) and
+    TM4 (closed-loop multiplexing, 2 transport blocks with pmi 0/1 or 1 with pmi 0..3) on a 2-port cell with 2 receive antennas vs the
+    oracle: transmit grids exact; equalised symbols, csi and LLRs within what the reference's reciprocal approximations allow; transport
+    blocks and CRC verdicts identical. CDD on the build that honours signed zeros (previous test), multiplexing on the prescribed one."""
+    from _libs import ref_sz
+    from lte_sim import DlConfig, RefPdsch, RefPdschTx, make_subframe_mimo, oracle_rx_mimo
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=True, tx_scheme=scheme, pmi=pmi, mod2=mod2, tbs2=tbs2)
+    rng = np.random.default_rng(prb + cid + tti)
+    k = {}
+    iq, data = make_subframe_mimo(cfg, tti, rng, snr_db=snr, amp=0.4, keep=k)
+    grids = RefPdschTx(cfg).run_mimo(data, tti)
+    for port in range(2):  # the reference scales by rho_a = sqrt(2) on a 2-port cell (pdsch.c:525), the stimulus by 1
+        assert np.abs(grids[port][k["idx"]] - np.float32(np.sqrt(2.0)) * k["y"][port]).max() < 2e-6
+    r = oracle_rx_mimo(cfg, iq, tti, keep=True)
+    rr = RefPdsch(cfg, csi_enable=True, lib=ref_sz() if scheme == "cdd" else None).run_mimo(iq, tti)
+    assert abs(r["noise"] / rr["noise"] - 1) < 1e-4
+    for cw in range(cfg.nof_tb):
+        assert np.abs(r["d"][cw] - rr["d"][cw]).max() <= 1.5e-3 * max(1.0, np.abs(rr["d"][cw]).max()), cw
+        assert np.abs(r["csi"][cw] / rr["csi"][cw] - 1).max() < 2e-3, cw
+        de = np.abs(r["e"][cw].astype(np.int32) - rr["e"][cw].astype(np.int32))
+        assert de.max() <= 2 + np.abs(rr["e"][cw]).max() // 400, (cw, int(de.max()))
+        assert r["ok"][cw] == rr["ok"][cw] and r["ok"][cw], cw
+        assert np.array_equal(r["tb"][cw], rr["tb"][cw]) and np.array_equal(r["tb"][cw][:len(data[cw])], data[cw]), cw
 
 
 # ---------------------------------------------------------------- arbitrary PRB allocations (srslte_pdsch_grant_t.prb_idx[s][n], pdsch.c:81-206)
