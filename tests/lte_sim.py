@@ -766,10 +766,6 @@ class UlConfig:
         assert oracle().orc_ul_dmrs_init(C.byref(self.dmrs), cell_id) == 0
         self.seg = OrcCbsegm()
         assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
-        self.segs = [self.seg]
-        if tbs2:
-            self.segs.append(OrcCbsegm())
-            assert oracle().orc_cbsegm(C.byref(self.segs[1]), tbs2) == 0 and self.segs[1].F == 0
         self.data_syms = [l for l in range(14) if l not in (3, 10)][:self.nsymb]
         # UL channel interleaver without UCI (36.212 5.2.2.8, sch.c:580-598,:891-913): q[(i*R + j)*Qm + k] = g[(j*12 + i)*Qm + k]
         j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(self.nsymb), np.arange(self.Qm), indexing="ij")
