@@ -215,6 +215,16 @@ typedef struct {
                                rho_a = 10^(p_a/20) (x sqrt(2) for a 2-port cell). Only p_b values with rho_b = 1 (no rescaling of the
                                CRS-bearing symbols) are covered */
   float    p_a;             /* dB */
+  int      tx_scheme;       /* 0: by nof_ports as above. srslte_tx_scheme_t of the grant for the two-layer modes of a 2-port cell received with 2
+                               antennas: SRSLTE_TXSCHEME_CDD (3): large-delay CDD, TM3, two transport blocks
+                               (srslte_predecoding_ccd_2x2_mmse_csi, precoding.c:918-1014); SRSLTE_TXSCHEME_SPATIALMUX (2): closed-loop
+                               multiplexing, TM4, two transport blocks with pmi 0-1 (srslte_predecoding_multiplex_2x2_mmse_csi :1326-1438) or
+                               one with pmi 0-3 (srslte_predecoding_multiplex_2x1_mrc_csi :1624-1707). mmse = 0 zeroes the noise term
+                               (pdsch.c:866). 16-bit LLRs */
+  uint32_t pmi;             /* srslte_pdsch_grant_t.pmi */
+  int      mod2;            /* grant.tb[1].mod */
+  uint32_t tbs2;            /* grant.tb[1].tbs; 0: one transport block. With two, d_tb / d_tb_ok of the batch calls have 2 * nof_sf rows:
+                               row b = transport block 0 of subframe b, row nof_sf + b = transport block 1; tb_stride covers the larger */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -228,6 +238,10 @@ int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti
  * added to the kept soft buffers (rm_turbo.c:407-409), blocks whose CRC already passed are left alone (sch.c:317-318) */
 int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data,
                                 uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+/* the same with a redundancy version and a new-data flag per transport block (two-layer modes: grant.tb[0 / 1].rv and the state of
+ * softbuffers.rx[0 / 1]); srslte_hip_dl_rx_batch_harq applies one pair to both */
+int srslte_hip_dl_rx_batch_harq2(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const uint32_t rv[2], const int new_data[2],
+                                 uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* same from frequency-domain grids d_grid [nof_sf][14][12*nof_prb] (the part of srslte_ue_dl_decode after srslte_ofdm_rx_sf,
  * ue_dl.c:375-397; SURVEY §8d cfg5 feeds grids) */
 int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,

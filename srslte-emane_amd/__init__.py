@@ -41,7 +41,8 @@ class Cbsegm(C.Structure):
 class DlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int),
                 ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg),
-                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int), ("power_scale", C.c_int), ("p_a", C.c_float)]
+                ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int), ("power_scale", C.c_int), ("p_a", C.c_float),
+                ("tx_scheme", C.c_int), ("pmi", C.c_uint32), ("mod2", C.c_int), ("tbs2", C.c_uint32)]
 
 
 class DlGrant(C.Structure):
@@ -450,18 +451,20 @@ class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
     def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False, nof_rx=1,
-                 nof_ports=1, csi=False, power_scale=False, p_a=0.0, out_ptrs=None):
+                 nof_ports=1, csi=False, power_scale=False, p_a=0.0, out_ptrs=None, tx_scheme=0, pmi=0, mod2=0, tbs2=0):
+        """tx_scheme 3 (large-delay CDD) / 2 (closed-loop multiplexing) with pmi, and mod2 / tbs2 for a second transport block: the two-layer
+        modes; decode() then returns lists [transport block 0, transport block 1] of tb and ok arrays."""
         self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
-                           1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0, 1 if power_scale else 0, p_a)
+                           1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0, 1 if power_scale else 0, p_a, tx_scheme, pmi, mod2, tbs2)
         self.nof_rx = nof_rx
         self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
         if not self.h:
             raise RuntimeError("srslte_hip_dl_rx_create failed")
-        self.tbs, self.max_batch = tbs, max_batch
-        self.tb_stride = (tbs // 8 + 6 + 15) & ~15
+        self.tbs, self.max_batch, self.tbs2 = tbs, max_batch, tbs2
+        self.tb_stride = (max(tbs, tbs2) // 8 + 6 + 15) & ~15
         self.sf_len = 15 * symbol_sz(nof_prb)
         if out_ptrs is None:
-            self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+            self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch * (2 if tbs2 else 1)), DevBuf(max_batch * (2 if tbs2 else 1))
         else:  # caller-owned device memory (e.g. a torch tensor that a collective reads): (tb pointer, ok pointer)
             self.d_tb, self.d_ok = DevView(out_ptrs[0], self.tb_stride * max_batch), DevView(out_ptrs[1], max_batch)
         # per-subframe stride of the LLR buffer e (debug buffer 4)
@@ -485,8 +488,25 @@ class DlRx:
         din = DevBuf.from_host(x)
         _check(self.run_device(din.ptr, tti0, x.shape[0]), "dl_rx_batch")
         sync()
+        if self.tbs2:  # rows b and nof_sf + b: the two transport blocks of subframe b
+            n = x.shape[0]
+            tb, ok = self.d_tb.to_host(np.uint8).reshape(-1, self.tb_stride), self.d_ok.to_host(np.uint8)
+            return [tb[:n, :self.tbs // 8 + 3], tb[n:2 * n, :self.tbs2 // 8 + 3]], [ok[:n], ok[n:2 * n]]
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def decode_harq2(self, iq, tti0, rv, new_data):
+        """srslte_hip_dl_rx_batch_harq2: rv / new_data per transport block (two-layer modes)."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * self.sf_len)
+        din = DevBuf.from_host(x)
+        n = x.shape[0]
+        lib().srslte_hip_dl_rx_batch_harq2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                       C.c_void_p, C.c_void_p]
+        _check(lib().srslte_hip_dl_rx_batch_harq2(self.h, din.ptr, tti0, n, (C.c_uint32 * 2)(*rv), (C.c_int * 2)(*[1 if v else 0 for v in new_data]),
+                                                  self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "dl_rx_batch_harq2")
+        sync()
+        tb, ok = self.d_tb.to_host(np.uint8).reshape(-1, self.tb_stride), self.d_ok.to_host(np.uint8)
+        return [tb[:n, :self.tbs // 8 + 3], tb[n:2 * n, :self.tbs2 // 8 + 3]], [ok[:n], ok[n:2 * n]]
 
     def decode_grants(self, iq, tti0, grants):
         """srslte_hip_dl_rx_batch_grants: subframe b with grants[b] (DlGrant). Returns (rc, tb [nsf][tbs_max/8+3], ok [nsf])."""

@@ -66,6 +66,11 @@ struct PdschGeom {
   float     inv_scaling; // 1 / pdsch_scaling (pdsch.c:852-858): 1, or 1 / rho_a with cfg.power_scale
   float*    csi;     // [nof_sf][max_re] channel gain per RE, or null (cfg.csi_enable)
   uint32_t* csi_max; // [nof_sf] bit pattern of the largest gain of each subframe (non-negative floats order like their bits), zeroed per call
+  // two-layer modes (pdsch_demod_mimo_kernel): srslte_tx_scheme_t, codebook index, and the second codeword's modulation and buffers
+  int             tx_scheme, codebook_idx, nof_tb, mod1, Qm1, max_bits1, scr_words1;
+  const uint32_t* scr1;
+  float*          csi1;
+  uint32_t*       csi_max1;
 };
 
 // the subframe's largest csi: wavefront maximum, one atomic per wavefront
@@ -270,6 +275,123 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
   for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
   const int rem = nbytes & 15;
   if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
+}
+
+// Two-layer modes on a 2-port cell with 2 receive antennas: large-delay CDD (TM3; srslte_predecoding_ccd_2x2_mmse_csi,
+// precoding.c:918-1014) and closed-loop multiplexing (TM4; srslte_predecoding_multiplex_2x2_mmse_csi :1326-1438, one layer:
+// srslte_predecoding_multiplex_2x1_mrc_csi :1624-1707), each with srslte_mat_2x2_mmse_csi_gen's algebra (mat.c) in exact divisions, fused with
+// the demapper and descrambler of BOTH codewords (nof_layers == nof_tb in every case ra_dl.c:556-600 lets through: layer l is codeword l,
+// no layer de-mapping; srslte_pdsch_codeword_decode pdsch.c:729-790 with the codeword's own modulation and scrambling sequence).
+// One thread per PDSCH RE; ce is [sf][port][antenna][grid], grid [sf][antenna][grid]. grid = (ceil(max_re/256), nof_sf).
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cf32 cmulc(cf32 a, cf32 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); } // a conj(b)
+__device__ __forceinline__ cf32 cadd(cf32 a, cf32 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cf32 csub(cf32 a, cf32 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cf32 cmulj(cf32 a) { return make_float2(-a.y, a.x); }
+
+template <typename LLR>
+__global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                               const ChestResDev* __restrict__ res, const uint32_t* __restrict__ scr,
+                                                               cf32* __restrict__ d_out0, cf32* __restrict__ d_out1, LLR* __restrict__ e_out0,
+                                                               LLR* __restrict__ e_out1, PdschGeom g)
+{
+  __shared__ __attribute__((aligned(16))) LLR stage[2][256 * 8];
+  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int     base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
+  if (base >= c.nof_re) return;
+  const bool     live = i < c.nof_re;
+  const int      ii = live ? i : c.nof_re - 1;
+  const uint32_t k  = c.idx[ii];
+  const float    n0 = g.mmse ? res[sf].noise_estimate : 0.f;
+  const cf32*    yb = grid + (size_t)sf * 2 * g.grid_len;
+  const cf32*    hb = ce + (size_t)sf * 4 * g.grid_len;
+  const cf32     y0 = yb[k], y1 = yb[g.grid_len + k];
+  const cf32     p0a0 = hb[k], p0a1 = hb[(size_t)g.grid_len + k], p1a0 = hb[(size_t)2 * g.grid_len + k], p1a1 = hb[(size_t)3 * g.grid_len + k];
+  const float    scaling = 1.0f / g.inv_scaling;
+  cf32           x[2];
+  float          csi[2];
+  if (g.nof_tb == 1) { // one layer: the codebook column applied to the ports, maximum-ratio combining over the antennas
+    cf32 h0, h1;
+    switch (g.codebook_idx) {
+      case 0: h0 = cadd(p0a0, p1a0); h1 = cadd(p0a1, p1a1); break;
+      case 1: h0 = csub(p0a0, p1a0); h1 = csub(p0a1, p1a1); break;
+      case 2: h0 = cadd(p0a0, cmulj(p1a0)); h1 = cadd(p0a1, cmulj(p1a1)); break;
+      default: h0 = csub(p0a0, cmulj(p1a0)); h1 = csub(p0a1, cmulj(p1a1)); break;
+    }
+    const float norm = 1.41421356f / scaling;
+    const float cs = h0.x * h0.x + h0.y * h0.y + h1.x * h1.x + h1.y * h1.y, hh = norm / cs;
+    const cf32  t  = cadd(cmulc(y0, h0), cmulc(y1, h1)); // conj(h0) y0 + conj(h1) y1
+    x[0]   = make_float2(t.x * hh, t.y * hh);
+    x[1]   = x[0];
+    csi[0] = cs / norm * 0.70710678f;
+    csi[1] = 0.f;
+  } else {
+    cf32  h00, h01, h10, h11; // effective channel: h[antenna][layer]
+    float norm = 2.0f / scaling;
+    if (g.tx_scheme == 3) { // H W U D(i): the sign of the second port alternates with the symbol index
+      if (!(ii & 1)) {
+        h00 = cadd(p0a0, p1a0); h10 = cadd(p0a1, p1a1); h01 = csub(p0a0, p1a0); h11 = csub(p0a1, p1a1);
+      } else {
+        h00 = csub(p0a0, p1a0); h10 = csub(p0a1, p1a1); h01 = cadd(p0a0, p1a0); h11 = cadd(p0a1, p1a1);
+      }
+    } else if (g.codebook_idx == 0) {
+      h00 = p0a0; h01 = p1a0; h10 = p0a1; h11 = p1a1;
+      norm = 1.41421356f / scaling;
+    } else if (g.codebook_idx == 1) {
+      h00 = cadd(p0a0, p1a0); h01 = csub(p0a0, p1a0); h10 = cadd(p0a1, p1a1); h11 = csub(p0a1, p1a1);
+    } else {
+      h00 = cadd(p0a0, cmulj(p1a0)); h01 = csub(p0a0, cmulj(p1a0)); h10 = cadd(p0a1, cmulj(p1a1)); h11 = csub(p0a1, cmulj(p1a1));
+    }
+    // A = H'H + N0 I; B = norm A^-1; W = B H'; x = W y; csi_l = 1 / Re(B_ll)
+    cf32 a00 = cadd(cmulc(h00, h00), cmulc(h10, h10)), a11 = cadd(cmulc(h01, h01), cmulc(h11, h11));
+    a00.x += n0;
+    a11.x += n0;
+    const cf32  a01 = cadd(cmulc(h01, h00), cmulc(h11, h10)), a10 = cadd(cmulc(h00, h01), cmulc(h10, h11));
+    const cf32  det = csub(cmul(a00, a11), cmul(a01, a10));
+    const float dm  = det.x * det.x + det.y * det.y;
+    const cf32  nr  = make_float2(norm * (det.x / dm), norm * (-det.y / dm));
+    const cf32  b00 = cmul(a11, nr), b01 = cmul(make_float2(-a01.x, -a01.y), nr), b10 = cmul(make_float2(-a10.x, -a10.y), nr), b11 = cmul(a00, nr);
+    const cf32  w00 = cadd(cmulc(b00, h00), cmulc(b01, h01)), w01 = cadd(cmulc(b00, h10), cmulc(b01, h11));
+    const cf32  w10 = cadd(cmulc(b10, h00), cmulc(b11, h01)), w11 = cadd(cmulc(b10, h10), cmulc(b11, h11));
+    x[0]   = cadd(cmul(y0, w00), cmul(y1, w01));
+    x[1]   = cadd(cmul(y0, w10), cmul(y1, w11));
+    csi[0] = 1.0f / b00.x;
+    csi[1] = 1.0f / b11.x;
+  }
+#pragma unroll
+  for (int cw = 0; cw < 2; cw++) {
+    if (cw >= g.nof_tb) break;
+    const int       mod = cw ? g.mod1 : g.mod, Qm = cw ? g.Qm1 : g.Qm;
+    float*          csi_o = cw ? g.csi1 : g.csi;
+    cf32*           d_out = cw ? d_out1 : d_out0;
+    if (csi_o) {
+      if (live) csi_o[(size_t)sf * g.max_re + i] = csi[cw];
+      csi_note_max((cw ? g.csi_max1 : g.csi_max) + sf, live ? csi[cw] : 0.f);
+    }
+    if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x[cw];
+    LLR o[8];
+    if constexpr (sizeof(LLR) == 1) {
+      demod_dev::demod_b(mod, x[cw], i, c.nof_re, o);
+    } else {
+      demod_dev::demod_s(mod, x[cw], i, c.nof_re, o);
+    }
+    const uint32_t* cs   = cw ? g.scr1 + (size_t)sf_idx * g.scr_words1 : scr + (size_t)sf_idx * g.scr_words;
+    const int       bit0 = (live ? i : 0) * Qm;
+    const uint32_t  c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
+    for (int j = 0; j < Qm; j++) stage[cw][threadIdx.x * Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int cw = 0; cw < 2; cw++) {
+    if (cw >= g.nof_tb) break;
+    const int   Qm = cw ? g.Qm1 : g.Qm, nbytes = min(256, c.nof_re - base) * Qm * (int)sizeof(LLR);
+    char*       dst = reinterpret_cast<char*>((cw ? e_out1 : e_out0) + (size_t)sf * (cw ? g.max_bits1 : g.max_bits) + (size_t)base * Qm);
+    const char* src = reinterpret_cast<const char*>(stage[cw]);
+    for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
+    const int rem = nbytes & 15;
+    if ((int)threadIdx.x < rem) dst[nbytes - rem + threadIdx.x] = src[nbytes - rem + threadIdx.x];
+  }
 }
 
 struct RmGeom {
@@ -742,11 +864,13 @@ struct srslte_hip_dl_rx {
   uint32_t*              d_csi_max; // [B]
   const cf32*            grid_in; // resource grids supplied by the caller (srslte_hip_dl_rx_grid_batch) instead of d_grid
   struct GrantsState*    gs;      // srslte_hip_dl_rx_batch_grants: created on first use
+  struct srslte_hip_dl_rx* cw1;   // two-layer modes: the second codeword's back end (rate de-matching, decoder, TB assembly and their buffers)
 };
 
 extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
 {
   if (!q) return;
+  srslte_hip_dl_rx_destroy(q->cw1);
   srslte_hip_ofdm_destroy(q->ofdm);
   srslte_hip_chest_dl_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
@@ -783,12 +907,25 @@ static int dl_rx_rm_table(srslte_hip_dl_rx_t* q, uint32_t rv, uint32_t** d_tbl)
   return upload(d_tbl, rm_slot_table(t, q->in_stride)); // in_stride is a multiple of 32
 }
 
-extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg)
+// cw: 0 = a whole pipeline; 1 = the back end of the second codeword of a two-layer mode (cfg->mod / tbs already those of that codeword):
+// no OFDM / estimator objects, no grids, scrambling sequence q = 1 (36.211 6.3.1)
+static srslte_hip_dl_rx_t* dl_rx_create_impl(const srslte_hip_dl_rx_cfg_t* cfg, int cw)
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 4 || cfg->max_iterations == 0 || cfg->nof_rx_antennas > 4 || cfg->nof_ports > 4 ||
       cfg->nof_ports == 3 || (cfg->nof_ports == 4 && cfg->chest_cfg.interpolate_subframe)) {
     hip_log("[srslte_hip] dl_rx: invalid configuration\n");
     return nullptr;
+  }
+  const bool mimo = cfg->tx_scheme != 0;
+  if (mimo && cw == 0) { // what ra_dl.c:556-600 and precoding.c:1710-1759,:1087-1114 let through
+    const bool two = cfg->tbs2 != 0;
+    const bool ok  = (cfg->tx_scheme == 2 || cfg->tx_scheme == 3) && cfg->nof_ports == 2 && cfg->nof_rx_antennas == 2 && !cfg->llr_8bit &&
+                    (cfg->tx_scheme == 2 || two) && (two ? cfg->pmi < 2 : cfg->pmi < 4) && (!two || (cfg->mod2 >= 1 && cfg->mod2 <= 4));
+    if (!ok) {
+      hip_log("[srslte_hip] dl_rx: two-layer modes need a 2-port cell, 2 receive antennas, 16-bit LLRs; CDD with two transport blocks, "
+              "multiplexing with two (pmi 0-1) or one (pmi 0-3)\n");
+      return nullptr;
+    }
   }
   auto* q = new srslte_hip_dl_rx();
   memset(q, 0, sizeof(*q));
@@ -802,10 +939,12 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   const uint32_t lstart = cfg->cfi + (P < 10 ? 1 : 0); // SRSLTE_NOF_CTRL_SYMBOLS, phy_common.h:143
   const uint32_t nrx    = cfg->nof_rx_antennas ? cfg->nof_rx_antennas : 1;
   const uint32_t npt    = cfg->nof_ports ? cfg->nof_ports : 1;
-  q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
-  q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, npt, 1);
+  if (cw == 0) {
+    q->ofdm  = srslte_hip_ofdm_create((int)P, 1, 1);
+    q->chest = srslte_hip_chest_dl_create(cfg->cell_id, P, npt, 1);
+  }
   q->tdec  = srslte_hip_tdec_create(K, B * C);
-  bool ok  = q->ofdm && q->chest && q->tdec;
+  bool ok  = (cw || (q->ofdm && q->chest)) && q->tdec;
   // RE lists
   uint32_t max_re = 0;
   const uint32_t rep_sf[3] = {0, 5, 1};
@@ -815,6 +954,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     q->pg.cls[c].nof_re = (int)idx.size();
     q->rg.nof_re[c]     = (int)idx.size();
     max_re              = idx.size() > max_re ? (uint32_t)idx.size() : max_re;
+    if (cw) continue; // the lists are the first codeword's object's
     ok                  = upload(&q->d_idx[c], idx) == SRSLTE_SUCCESS;
     q->pg.cls[c].idx    = q->d_idx[c];
   }
@@ -824,7 +964,7 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     std::vector<uint32_t> scr((size_t)10 * scr_words, 0);
     std::vector<uint8_t>  c;
     for (uint32_t sf = 0; sf < 10; sf++) {
-      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + (sf << 9) + cfg->cell_id, max_re * Qm, c);
+      lte_gold_sequence(((uint32_t)cfg->rnti << 14) + ((uint32_t)cw << 13) + (sf << 9) + cfg->cell_id, max_re * Qm, c);
       for (uint32_t i = 0; i < max_re * Qm; i++) scr[(size_t)sf * scr_words + (i >> 5)] |= (uint32_t)c[i] << (i & 31);
     }
     ok = upload(&q->d_scr, scr) == SRSLTE_SUCCESS;
@@ -859,10 +999,12 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
     }
   }
   const size_t glen = (size_t)14 * nre;
-  ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
-       hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx * npt) == hipSuccess &&
-       hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess &&
-       hipMalloc((void**)&q->d_e, sizeof(int16_t) * ((size_t)max_bits * B + 16)) == hipSuccess /* +16: rm_rx_lds_kernel reads whole 16-byte words */ &&
+  if (cw == 0) {
+    ok = ok && hipMalloc((void**)&q->d_grid, sizeof(cf32) * glen * B * nrx) == hipSuccess &&
+         hipMalloc((void**)&q->d_ce, sizeof(cf32) * glen * B * nrx * npt) == hipSuccess &&
+         hipMalloc((void**)&q->d_res, sizeof(ChestResDev) * B) == hipSuccess;
+  }
+  ok = ok && hipMalloc((void**)&q->d_e, sizeof(int16_t) * ((size_t)max_bits * B + 16)) == hipSuccess /* +16: rm_rx_lds_kernel reads whole 16-byte words */ &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
@@ -885,16 +1027,37 @@ extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cf
   q->pg.csi = q->d_csi; q->pg.csi_max = q->d_csi_max;
   // apply_power_allocation (pdsch.c:518-554) with rho_b = 1: pdsch_scaling = rho_a = 10^(p_a/20), times sqrt(2) for a 2-port cell
   q->pg.inv_scaling = cfg->power_scale ? 1.0f / (powf(10.0f, cfg->p_a / 20.0f) * (npt == 1 ? 1.0f : sqrtf(2.0f))) : 1.0f;
-  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = npt > 1 ? 2 : 1;
+  // code-block split in units of Qm N_L bits: N_L = 2 for transmit diversity, 1 where nof_layers == nof_tb (srslte_dlsch_decode2, sch.c:507-531)
+  q->rg.csi = q->d_csi; q->rg.csi_max = q->d_csi_max; q->rg.max_re = (int)max_re; q->rg.mod = cfg->mod; q->rg.Nl = (npt > 1 && !mimo) ? 2 : 1;
   q->rg.C = (int)C; q->rg.K = (int)K; q->rg.Qm = (int)Qm; q->rg.max_bits = (int)max_bits; q->rg.w_stride = (int)q->in_stride;
   q->rg.out_len = (int)(3 * K + 12);
   q->tg.C = (int)C; q->tg.K = (int)K; q->tg.tbs = (int)cfg->tbs; q->tg.rlen = (int)(C == 1 ? K : K - 24); q->tg.cb_stride = (int)(K / 8);
+  if (mimo && cw == 0) {
+    q->pg.tx_scheme = cfg->tx_scheme; q->pg.nof_tb = cfg->tbs2 ? 2 : 1;
+    q->pg.codebook_idx = (int)(cfg->tbs2 ? cfg->pmi + 1 : cfg->pmi); // pdsch.c:914
+    if (cfg->tbs2) {
+      srslte_hip_dl_rx_cfg_t c1 = *cfg;
+      c1.mod = cfg->mod2; c1.tbs = cfg->tbs2; c1.mod2 = 0; c1.tbs2 = 0;
+      q->cw1 = dl_rx_create_impl(&c1, 1);
+      if (!q->cw1) {
+        srslte_hip_dl_rx_destroy(q);
+        return nullptr;
+      }
+      q->pg.mod1 = c1.mod; q->pg.Qm1 = q->cw1->pg.Qm; q->pg.max_bits1 = q->cw1->pg.max_bits; q->pg.scr_words1 = q->cw1->pg.scr_words;
+      q->pg.scr1 = q->cw1->d_scr; q->pg.csi1 = q->cw1->d_csi; q->pg.csi_max1 = q->cw1->d_csi_max;
+    }
+  }
   return q;
 }
+
+extern "C" srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg) { return dl_rx_create_impl(cfg, 0); }
 
 extern "C" int srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable)
 {
   if (!q) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->cw1) {
+    if (int r = srslte_hip_dl_rx_keep_symbols(q->cw1, enable)) return r;
+  }
   if (enable && !q->d_d) {
     HIP_TRY(hipMalloc((void**)&q->d_d, sizeof(cf32) * (size_t)q->pg.max_re * q->cfg.max_batch));
   } else if (!enable && q->d_d) {
@@ -912,6 +1075,7 @@ extern "C" uint32_t srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_
 extern "C" const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q, int which)
 {
   if (!q) return nullptr;
+  if (which >= 100) return srslte_hip_dl_rx_debug_buffer(q->cw1, which - 100); // the second codeword's buffers
   switch (which) {
     case 0: return q->d_grid;
     case 1: return q->d_ce;
@@ -953,7 +1117,12 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       PdschGeom g = q->pg;
       g.tti0      = (int)tti0;
       if (g.csi_max) HIP_TRY(hipMemsetAsync(g.csi_max, 0, sizeof(uint32_t) * nof_sf, st));
-      if (g.nof_ports == 4) {
+      if (g.tx_scheme) {
+        if (g.csi_max1) HIP_TRY(hipMemsetAsync(g.csi_max1, 0, sizeof(uint32_t) * nof_sf, st));
+        hipLaunchKernelGGL(pdsch_demod_mimo_kernel<int16_t>, dim3(ceil_div(g.max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                           (const ChestResDev*)q->d_res, (const uint32_t*)q->d_scr, q->d_d, q->cw1 ? q->cw1->d_d : (cf32*)nullptr, q->d_e,
+                           q->cw1 ? q->cw1->d_e : (int16_t*)nullptr, g);
+      } else if (g.nof_ports == 4) {
         if (q->cfg.llr_8bit) {
           hipLaunchKernelGGL(pdsch_demod_div4_kernel<int8_t>, dim3(ceil_div(g.max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                              (const uint32_t*)q->d_scr, q->d_d, (int8_t*)q->d_e, g);
@@ -980,6 +1149,9 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       return SRSLTE_SUCCESS;
     }
     case 3: {
+      if (q->cw1) {
+        if (int r = srslte_hip_dl_rx_stage(q->cw1, 3, nullptr, tti0, nof_sf, nullptr, 0, nullptr, stream)) return r;
+      }
       RmGeom g = q->rg;
       g.tti0   = (int)tti0;
       g.combine = q->harq_combine;
@@ -1005,12 +1177,18 @@ extern "C" int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const vo
       return SRSLTE_SUCCESS;
     }
     case 4:
+      if (q->cw1) {
+        if (int r = srslte_hip_dl_rx_stage(q->cw1, 4, nullptr, tti0, nof_sf, nullptr, 0, nullptr, stream)) return r;
+      }
       tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
       tdec_set_skip(q->tdec, q->harq_combine ? q->d_cb_ok : nullptr);
       return tdec_run_batch_w(q->tdec, q->d_w, q->cfg.llr_8bit ? 1 : 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations,
                               C > 1 ? 0x1800063u : 0x1864CFBu, C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
     case 5: {
       if (!d_tb || !d_tb_ok || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+      if (q->cw1) { // rows nof_sf .. 2 nof_sf - 1 of d_tb / d_tb_ok: the second transport block of every subframe
+        if (int r = srslte_hip_dl_rx_stage(q->cw1, 5, nullptr, tti0, nof_sf, d_tb + (size_t)nof_sf * tb_stride, tb_stride, d_tb_ok + nof_sf, stream)) return r;
+      }
       TbGeom g    = q->tg;
       g.tb_stride = (int)tb_stride;
       if (q->d_tb_rem) {
@@ -1047,15 +1225,35 @@ extern "C" int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_
                                            uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !d_tb || !d_tb_ok || rv > 3) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (!q->d_rm_tbl_rv[rv]) {
-    if (int r = dl_rx_rm_table(q, rv, &q->d_rm_tbl_rv[rv])) return r;
+  const uint32_t rv2[2] = {rv, rv};
+  const int      nd2[2] = {new_data, new_data};
+  return srslte_hip_dl_rx_batch_harq2(q, d_iq, tti0, nof_sf, rv2, nd2, d_tb, tb_stride, d_tb_ok, stream);
+}
+
+// the same with a redundancy version and a new-data flag per transport block (two-layer modes: each block has its own HARQ process state,
+// srslte_pdsch_cfg_t.softbuffers.rx[0 / 1] and grant.tb[0 / 1].rv)
+extern "C" int srslte_hip_dl_rx_batch_harq2(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const uint32_t rv[2],
+                                            const int new_data[2], uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !d_tb || !d_tb_ok || !rv || !new_data || rv[0] > 3 || rv[1] > 3) return SRSLTE_ERROR_INVALID_INPUTS;
+  srslte_hip_dl_rx_t* objs[2] = {q, q->cw1};
+  for (int c = 0; c < 2; c++) {
+    srslte_hip_dl_rx_t* o = objs[c];
+    if (!o) continue;
+    if (!o->d_rm_tbl_rv[rv[c]]) {
+      if (int r = dl_rx_rm_table(o, rv[c], &o->d_rm_tbl_rv[rv[c]])) return r;
+    }
+    o->harq_rv      = rv[c];
+    o->harq_combine = new_data[c] ? 0 : 1;
   }
-  q->harq_rv      = rv;
-  q->harq_combine = new_data ? 0 : 1;
   int r = SRSLTE_SUCCESS;
   for (int s = 0; s < 6 && !r; s++) r = srslte_hip_dl_rx_stage(q, s, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
-  q->harq_rv      = 0;
-  q->harq_combine = 0;
+  for (srslte_hip_dl_rx_t* o : objs) {
+    if (o) {
+      o->harq_rv      = 0;
+      o->harq_combine = 0;
+    }
+  }
   return r;
 }
 
@@ -1166,7 +1364,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.csi_enable) {
+  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.csi_enable || q->cfg.tx_scheme) {
     hip_log("[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs, no CSI weighting\n");
     return SRSLTE_ERROR;
   }

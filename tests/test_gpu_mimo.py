@@ -1,0 +1,155 @@
+"""Two-layer PDSCH modes on the device: large-delay CDD (TM3) and closed-loop spatial multiplexing (TM4) on a 2-port cell
+received with 2 antennas, through the C ABI (srslte_hip_dl_rx_create with cfg.tx_scheme / pmi / mod2 / tbs2), against the oracle chain
+(tests/lte_sim.py oracle_rx_mimo, pinned on the reference's srslte_pdsch_decode in tests/test_oracle_vs_ref.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCHEME = {"cdd": 3, "mux": 2}  # srslte_tx_scheme_t (phy_common.h:232-237)
+Q = {1: 2, 2: 4, 3: 6, 4: 8}
+
+CASES = [  # nof_prb, cell_id, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti0, nsf, snr
+    (25, 7, 2, 4008, 2, 4008, "cdd", 0, 1, 8, 4, 6.5), (25, 7, 2, 4008, 1, 2216, "cdd", 0, 2, 0, 6, 5.5), (6, 1, 1, 328, 1, 328, "cdd", 0, 3, 4, 7, 1.0),
+    (50, 150, 3, 21384, 2, 9912, "cdd", 0, 1, 7, 4, 14.0), (100, 2, 3, 75376, 3, 75376, "cdd", 0, 1, 3, 3, 22.0),
+    (25, 7, 2, 4008, 3, 4008, "mux", 0, 1, 3, 4, 8.0), (25, 7, 2, 4008, 2, 2216, "mux", 1, 2, 5, 4, 6.5), (15, 33, 1, 1000, 2, 2216, "mux", 0, 1, 9, 3, 5.0),
+    (100, 2, 3, 30576, 4, 48936, "mux", 1, 1, 4, 3, 17.5),
+    (25, 7, 2, 4008, 0, 0, "mux", 0, 1, 3, 4, 3.0), (25, 7, 3, 6200, 0, 0, "mux", 1, 2, 5, 4, 7.5), (6, 1, 1, 328, 0, 0, "mux", 2, 3, 0, 6, 1.0),
+    (50, 150, 2, 9912, 0, 0, "mux", 3, 1, 9, 3, 4.0)]
+
+
+def _chest(hp):
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    return hc
+
+
+@pytest.fixture(scope="module")
+def hp():
+    import importlib
+    return importlib.import_module("srslte-emane_amd")
+
+
+@pytest.mark.parametrize("prb,cid,mod,tbs,mod2,tbs2,scheme,pmi,cfi,tti0,nsf,snr", CASES)
+@pytest.mark.parametrize("csi", [False, True])
+def test_dl_rx_two_layer_modes(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti0, nsf, snr, csi):
+    """Equalised symbols, per-layer csi and its subframe maximum, LLRs of both codewords (each with its own modulation and scrambling
+    sequence), SISO pass counts, CRC verdicts and transport block bytes of every subframe vs the oracle chain on identical IQ. The SNRs
+    leave some blocks undecoded or needing several passes."""
+    from lte_sim import DlConfig, make_subframe_mimo, oracle_rx_mimo
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=csi, tx_scheme=scheme, pmi=pmi, mod2=mod2 or None, tbs2=tbs2)
+    rng = np.random.default_rng(3000 + prb + cid + tti0 + pmi)
+    iq, data = zip(*[make_subframe_mimo(cfg, tti0 + b, rng, snr_db=snr, amp=0.2) for b in range(nsf)])
+    rx = hp.DlRx(cid, prb, cfi, 0x1234, mod, tbs, 6, nsf, True, _chest(hp), nof_rx=2, nof_ports=2, csi=csi, tx_scheme=SCHEME[scheme], pmi=pmi, mod2=mod2,
+                 tbs2=tbs2)
+    rx.keep_symbols()
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    if not tbs2:
+        tb, ok = [tb], [ok]
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    n_ok = n_multi = 0
+    for cw in range(cfg.nof_tb):
+        off, C_, Qm = 100 * cw, cfg.segs[cw].C, Q[cfg.mods[cw]]
+        e_stride = (max_re * Qm + 15) & ~15
+        it = rx.debug(off + 6, np.uint32, nsf * C_).reshape(nsf, C_)
+        d = rx.debug(off + 3, np.complex64, nsf * max_re).reshape(nsf, -1)
+        e_all = rx.debug(off + 4, np.int16, nsf * e_stride).reshape(nsf, -1)
+        if csi:
+            cs, cmax = rx.debug(off + 9, np.float32, nsf * max_re).reshape(nsf, -1), rx.debug(off + 10, np.float32, nsf)
+        for b in range(nsf):
+            r = oracle_rx_mimo(cfg, iq[b], tti0 + b, keep=True)
+            nre = rx.nof_re((tti0 + b) % 10)
+            assert np.abs(d[b, :nre] - r["d"][cw]).max() <= 2e-4 * max(1.0, np.abs(r["d"][cw]).max()), (cw, b)
+            if csi:
+                assert np.abs(cs[b, :nre] / r["csi"][cw] - 1).max() <= 2e-4 and abs(cmax[b] / r["csi"][cw].max() - 1) <= 2e-4, (cw, b)
+            diff = np.abs(e_all[b, :nre * Qm].astype(np.int32) - r["e_raw"][cw].astype(np.int32))
+            assert diff.max() <= 1 + np.abs(r["e_raw"][cw]).max() // 2000 and (diff != 0).sum() <= 2e-3 * diff.size + 1, (cw, b, int(diff.max()), int((diff != 0).sum()))
+            exact = diff.max() == 0
+            if exact or r["ok"][cw]:
+                assert bool(ok[cw][b]) == r["ok"][cw], (cw, b)
+            if exact:
+                assert np.array_equal(it[b], r["iters"][cw]) and np.array_equal(tb[cw][b], r["tb"][cw]), (cw, b)
+            if r["ok"][cw]:
+                n_ok += 1
+                assert np.array_equal(tb[cw][b][:cfg.tbss[cw] // 8], data[b][cw]), (cw, b)
+            n_multi += int(r["iters"][cw].max() > 1)
+    assert n_ok > 0 and n_multi > 0, (n_ok, n_multi)
+    rx.free()
+
+
+def test_dl_rx_two_layer_noise_free_and_zf(hp):
+    """Noise-free subframes through the zero-forcing setting (cfg.mmse = 0: the noise term is dropped, pdsch.c:866): every transport block
+    of every mode comes back."""
+    from lte_sim import DlConfig, make_subframe_mimo
+    rng = np.random.default_rng(5)
+    for scheme, pmi, mod2, tbs2 in (("cdd", 0, 3, 9912), ("mux", 0, 2, 4008), ("mux", 1, 3, 9912), ("mux", 3, 0, 0)):
+        cfg = DlConfig(25, 11, 3, 9912, nof_rx=2, nof_ports=2, tx_scheme=scheme, pmi=pmi, mod2=mod2 or None, tbs2=tbs2)
+        iq, data = zip(*[make_subframe_mimo(cfg, b, rng) for b in range(10)])
+        rx = hp.DlRx(11, 25, 1, 0x1234, 3, 9912, 6, 10, False, _chest(hp), nof_rx=2, nof_ports=2, tx_scheme=SCHEME[scheme], pmi=pmi, mod2=mod2, tbs2=tbs2)
+        tb, ok = rx.decode(np.stack(iq), 0)
+        if not tbs2:
+            tb, ok = [tb], [ok]
+        for cw in range(cfg.nof_tb):
+            assert ok[cw].all(), (scheme, pmi, cw)
+            for b in range(10):
+                assert np.array_equal(tb[cw][b][:cfg.tbss[cw] // 8], data[b][cw])
+        rx.free()
+
+
+def test_dl_rx_two_layer_harq_per_transport_block(hp):
+    """srslte_hip_dl_rx_batch_harq2: each transport block has its own redundancy version and new-data flag. Block 0 is retransmitted with
+    rv 2 and combined, block 1 starts over: with the first transmission too noisy for either, block 0 decodes after combining, and
+    what the device returns equals the oracle's HARQ chain per block."""
+    from lte_sim import DlConfig, OrcHarq, make_subframe_mimo, oracle_rx_mimo
+    import ctypes as C
+    from _libs import OrcSchCfg, oracle, p
+    prb, nsf, SNR_HARQ = 25, 4, 6.0
+    cfg = DlConfig(prb, 9, 2, 6200, nof_rx=2, nof_ports=2, tx_scheme="cdd", mod2=2, tbs2=6200)
+    rng = np.random.default_rng(77)
+    rx = hp.DlRx(9, prb, 1, 0x1234, 2, 6200, 6, nsf, True, _chest(hp), nof_rx=2, nof_ports=2, tx_scheme=3, mod2=2, tbs2=6200)
+    first = [make_subframe_mimo(cfg, 1 + b, rng, snr_db=SNR_HARQ, amp=0.2) for b in range(nsf)]
+    tb, ok = rx.decode_harq2(np.stack([f[0] for f in first]), 1, (0, 0), (True, True))
+    orc = oracle()
+    harq = [[OrcHarq(cfg) for _ in range(2)] for _ in range(nsf)]
+
+    def oracle_step(b, iq, tti, rv, nd):
+        r = oracle_rx_mimo(cfg, iq, tti, keep=True, rv=rv)
+        out = []
+        for cw in range(2):
+            sch = OrcSchCfg(6200, len(r["e"][cw]), 4, rv[cw], 6)
+            t, it, cbok = np.zeros(6200 // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+            h = harq[b][cw]
+            rc = orc.orc_dlsch_decode_harq(C.byref(sch), p(r["e"][cw]), 0, 1 if nd[cw] else 0, p(h.w), p(h.crc), p(h.data), p(t), p(it), p(cbok))
+            out.append((rc == 0, t[:6200 // 8 + 3]))
+        return out
+    for b in range(nsf):
+        o = oracle_step(b, first[b][0], 1 + b, (0, 0), (True, True))
+        for cw in range(2):
+            assert bool(ok[cw][b]) == o[cw][0]
+    assert not ok[0].any()
+    second = [make_subframe_mimo(cfg, 9 + b, rng, snr_db=SNR_HARQ, amp=0.2, rv=(2, 0), data=[first[b][1][0], rng.integers(0, 256, 775, dtype=np.uint8)])
+              for b in range(nsf)]
+    tb, ok = rx.decode_harq2(np.stack([s_[0] for s_ in second]), 9, (2, 0), (False, True))
+    n0 = 0
+    for b in range(nsf):
+        o = oracle_step(b, second[b][0], 9 + b, (2, 0), (False, True))
+        for cw in range(2):
+            assert bool(ok[cw][b]) == o[cw][0], (b, cw)
+            if o[cw][0]:
+                assert np.array_equal(tb[cw][b], o[cw][1])
+        if ok[0][b]:
+            n0 += 1
+            assert np.array_equal(tb[0][b][:775], first[b][1][0])
+    assert n0 > 0
+    rx.free()
+
+
+def test_dl_rx_two_layer_config_errors(hp):
+    """Creation refuses what the reference's grant logic and pre-decoders refuse (ra_dl.c:556-600, precoding.c:1087-1114,:1710-1759)."""
+    ok = dict(nof_rx=2, nof_ports=2, tx_scheme=3, mod2=2, tbs2=4008)
+    for bad in (dict(ok, nof_rx=1), dict(ok, nof_ports=1), dict(ok, nof_ports=4), dict(ok, tbs2=0), dict(ok, tx_scheme=2, pmi=2), dict(ok, tx_scheme=2, tbs2=0, pmi=4),
+                dict(ok, tx_scheme=1), dict(ok, llr_8bit=True), dict(ok, mod2=0)):
+        with pytest.raises(RuntimeError):
+            hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **bad)
+    rx = hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **ok)
+    rx.free()
