@@ -516,6 +516,48 @@ def test_tdec_sb_layout_and_early_stop(hp, K):
     dec.free()
 
 
+@pytest.mark.parametrize("K,ncb,sb", [(816, 5, True), (832, 19, False), (1008, 8, True), (2048, 11, True), (3136, 16, False), (5824, 29, True), (6144, 9, True),
+                                       (5824, 13, False)])
+def test_tdec_eight_blocks_per_wavefront_mapping(hp, K, ncb, sb):
+    """tdec_lane_kernel (a lane = all eight states of a window pair, eight code blocks per wavefront; the batch pipelines' decoder) against
+    tdec_win_kernel<16, 0> (a lane = one state; forced with 16 sub-blocks) and the oracle's avx16 restatement: decoded bytes, pass counts and
+    CRC flags of every block, blocks of one wavefront stopping after different numbers of passes, block counts that leave slots empty;
+    with and without early stop; plain [s p0 p1] and rate-dematcher (SB) input layouts."""
+    rng = np.random.default_rng(31 * K + ncb)
+    dec = hp.Tdec(6144, 32)
+    stride = (3 * (K + 32) + 12) if sb else (3 * K + 12)
+    w = np.zeros((ncb, stride), np.int16)
+    n_e = (3 * K * 9 // 10) // 6 * 6
+    for i in range(ncb):
+        payload = rng.integers(0, 256, (K - 24) // 8, dtype=np.uint8)
+        crc = oracle().orc_crc_bytes(0x1800063, 24, p(payload), K - 24)
+        bits = np.unpackbits(np.concatenate([payload, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)]))
+        enc = np.zeros(3 * K + 12, np.uint8)
+        oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+        snr = (8.0, 3.0, 1.5, 1.0, 0.5, -2.0, 1.2, 0.8)[i % 8]
+        if sb:
+            e = np.zeros(n_e, np.uint8)
+            oracle().orc_rm_turbo_tx_bits(p(enc), p(e), n_e, K, 0)
+            oracle().orc_rm_turbo_rx(p(_noisy_llr(rng, e, snr, 100)), p(w[i]), n_e, K, 0, 16)
+        else:
+            w[i] = _noisy_llr(rng, enc, snr - 4.0, 60)
+    for poly, nbits, nit in ((hp.CRC24B, K, 6), (0, 0, 3), (0, 0, 4)):
+        rc, out, iters, ok = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=1016)
+        rc2, out2, iters2, ok2 = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=16)
+        assert rc == 0 and rc2 == 0
+        assert np.array_equal(iters, iters2) and np.array_equal(ok, ok2), (iters, iters2)
+        assert np.array_equal(out, out2)
+        if poly:
+            assert len(set(iters.tolist())) > 1 or ncb < 4
+    for i in range(0, ncb, 5):  # and against the oracle
+        per = np.zeros((6, K // 8), np.uint8)
+        ref = np.zeros(K // 8, np.uint8)
+        assert oracle().orc_tdec_run(p(w[i]), sb, K, 6, p(ref), p(per)) == 0
+        rc, out, iters, ok = dec.run_all(w[i:i + 1], K, 4, sb_layout=sb, force_subblocks=1016)
+        assert np.array_equal(out[0], per[3])
+    dec.free()
+
+
 @pytest.mark.parametrize("K", [40, 408, 800, 816, 1008, 2048, 2112, 3136, 5824, 6144])
 def test_tdec_run_all_8bit(hp, K):
     """srslte_tdec_run_all_8bit (turbodecoder.c:573-588): avx8 for K > 2048, sse8 for K > 800, widening fall-backs below."""
