@@ -1,0 +1,115 @@
+"""BASELINE.json's configurations at their FULL sizes (batch 128 / 512 of 20 MHz subframes), where the CPU oracle is too slow to check every
+subframe: size-independent properties instead - transmit -> receive round trips on the device, the gain of HARQ combining, no undetected
+errors, agreement between entry points and between the 16- and 8-bit LLR paths - plus the oracle on a sample of the batch."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return importlib.import_module("srslte-emane_amd")
+
+
+def _chest(hp):
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    return hc
+
+
+def test_cfg2_full_batch_round_trip_and_oracle_sample(hp):
+    """cfg2: 128 subframes of 100 PRB, 64QAM, TBS 75376 (13 blocks of 5824). Device PDSCH transmit pipeline -> device receive pipeline, noise
+    free: all 128 transport blocks come back; with noise added on the host, CRC verdicts, pass counts and bytes of a sample of the batch
+    equal the oracle's, the rest decode to what was sent wherever the CRC passes, and no wrong block passes its CRC."""
+    from lte_sim import DlConfig, oracle_rx
+    prb, mod, tbs, B = 100, 3, 75376, 128
+    rng = np.random.default_rng(2024)
+    data = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(1, prb, 1, 0x1234, mod, tbs, B)
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, B, True, _chest(hp))
+    iq = tx.encode(data, 0)[:, 0, :]
+    tb, ok = rx.decode(iq, 0)
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data)
+    sigma = np.sqrt(np.mean(np.abs(iq) ** 2) / 2) * 10 ** (-18.0 / 20)  # about the bench's working point: some blocks need all 6 passes
+    noisy = (iq + sigma * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+    tb, ok = rx.decode(noisy, 0)
+    it = rx.debug(6, np.uint32, B * 13).reshape(B, 13)
+    assert 0 < ok.sum() < B or ok.all()
+    for b in range(B):
+        if ok[b]:
+            assert np.array_equal(tb[b][:tbs // 8], data[b]), b  # a passed CRC24A with wrong bytes would be an undetected error
+    cfg = DlConfig(prb, 1, mod, tbs)
+    for b in (0, 5, 77, 127):
+        r = oracle_rx(cfg, noisy[b], b, keep=True)
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), b
+        if r["ok"]:
+            assert np.array_equal(tb[b], r["tb"])
+    # the grid entry point on the grids the pipeline made itself = the IQ entry point, byte for byte
+    grid = rx.debug(0, np.complex64, B * 14 * 12 * prb).reshape(B, -1)
+    tb2, ok2 = rx.decode_grid(grid, 0)
+    assert np.array_equal(ok, ok2) and np.array_equal(tb, tb2)
+    tx.free()
+    rx.free()
+
+
+def test_cfg2_full_batch_harq_gain(hp):
+    """HARQ at full batch (srslte_hip_dl_rx_batch_harq): at an SNR where a single transmission of MCS 28 almost never decodes, the rv 2
+    retransmission combined into the kept soft buffers decodes almost every block; blocks that passed in the first round keep their
+    bytes (they are neither combined nor decoded again, sch.c:317-318); no block that passes its CRC is wrong."""
+    prb, mod, tbs, B = 100, 3, 75376, 128
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(1, prb, 1, 0x1234, mod, tbs, B)
+    rx = hp.DlRx(1, prb, 1, 0x1234, mod, tbs, 6, B, True, _chest(hp))
+    oks = []
+    for rv, new_data in ((0, True), (2, False)):
+        iq = tx.encode(data, 0, rv=rv)[:, 0, :]
+        sigma = np.sqrt(np.mean(np.abs(iq) ** 2) / 2) * 10 ** (-15.5 / 20)
+        noisy = (iq + sigma * (rng.standard_normal(iq.shape) + 1j * rng.standard_normal(iq.shape))).astype(np.complex64)
+        tb, ok = rx.decode_harq(noisy, 0, rv, new_data)
+        for b in range(B):
+            if ok[b]:
+                assert np.array_equal(tb[b][:tbs // 8], data[b]), (rv, b)
+        oks.append(ok.copy())
+    assert oks[0].sum() < B // 4 and oks[1].sum() > 3 * B // 4, (int(oks[0].sum()), int(oks[1].sum()))
+    assert (oks[1] >= oks[0]).all()
+    tx.free()
+    rx.free()
+
+
+def test_cfg3_full_batch_uplink_round_trip(hp):
+    """cfg3: 128 subframes of 20 MHz uplink, the largest valid SC-FDMA grant (96 of 100 PRB), 16QAM: device PUSCH transmit pipeline (CRC,
+    segmentation, turbo encoder, rate matching, channel interleaver, DFT precoding, DMRS, OFDM) -> device receive pipeline: every transport
+    block comes back, with HARQ-ACK, rank indication and a CQI report multiplexed in."""
+    prb, L, mod, tbs, B = 100, 96, 2, 36696, 128
+    rng = np.random.default_rng(11)
+    data = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
+    acks, ris, cqis = rng.integers(0, 2, (B, 2), dtype=np.uint8), rng.integers(0, 2, (B, 1), dtype=np.uint8), rng.integers(0, 2, (B, 20), dtype=np.uint8)
+    kw = dict(ack_len=2, I_offset_ack=9, ri_len=1, I_offset_ri=8, cqi_len=20, I_offset_cqi=8)
+    tx = hp.UlTx(3, prb, 0x77, mod, tbs, L, 2, 1, B, **kw)
+    rx = hp.UlRx(3, prb, 0x77, mod, tbs, L, 2, 1, 6, B, **kw)
+    tb, ok = rx.decode(tx.encode(data, 3, ack=acks, ri=ris, cqi=cqis), 3)
+    cqi, cqi_ok = rx.cqi()
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data)
+    assert np.array_equal(rx.ack(), acks) and np.array_equal(rx.ri(), ris) and cqi_ok.all() and np.array_equal(cqi, cqis)
+    tx.free()
+    rx.free()
+
+
+def test_cfg5_full_batch_256qam(hp):
+    """cfg5: 512 subframes, 256QAM (TBS 97896), through transmit -> receive on the device, noise free; then the 8-bit LLR path of the same
+    batch agrees with the 16-bit one on every transport block."""
+    prb, mod, tbs, B = 100, 4, 97896, 512
+    rng = np.random.default_rng(13)
+    data = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(2, prb, 1, 0x4321, mod, tbs, B)
+    iq = tx.encode(data, 0)[:, 0, :].copy()
+    tx.free()
+    for llr8 in (False, True):
+        rx = hp.DlRx(2, prb, 1, 0x4321, mod, tbs, 6, B, True, _chest(hp), llr_8bit=llr8)
+        tb, ok = rx.decode(iq, 0)
+        assert ok.all() and np.array_equal(tb[:, :tbs // 8], data), llr8
+        rx.free()
