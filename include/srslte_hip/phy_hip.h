@@ -128,6 +128,9 @@ int srslte_hip_refsignal_dmrs_pusch_gen(const srslte_hip_chest_ul_t* q, uint32_t
  * subframe b is TTI tti0 + b; one grant (L_prb, n_prb, n_dmrs) for the batch */
 int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
                                              const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream);
+/* the same with a PRB offset per slot (srslte_pusch_grant_t.n_prb[0 / 1], intra-subframe hopping: chest_ul.c:244-266,:293-295) */
+int srslte_hip_chest_ul_estimate_pusch_batch_hop(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_prb_slot1,
+                                                 uint32_t n_dmrs, const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream);
 
 /* ------------------------------------------------------------------ soft demapper (replaces srslte_demod_soft_demodulate{,_s,_b},
  * modem/demod_soft.h:39-53, demod_soft.c:479-549). mod: 0 BPSK, 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM (srslte_mod_t).
@@ -295,6 +298,8 @@ typedef struct {
   uint32_t I_offset_ri;    /* index into 36.213 Table 8.6.3-2 (srslte_uci_offset_cfg_t.I_offset_ri) */
   uint32_t cqi_len, I_offset_cqi; /* CQI / PMI report of cqi_len bits (srslte_cqi_size of uci_cfg.cqi, up to 64) multiplexed in front of the UL-SCH
                                      with srslte_uci_offset_cfg_t.I_offset_cqi (sch.c:1031-1060,:1133-1160, uci.c:264-494); 0 = none */
+  uint32_t hopping, n_prb_slot1;  /* hopping != 0: intra-subframe hopping, slot 1 at PRB offset n_prb_slot1 (srslte_pusch_grant_t.n_prb[1] /
+                                     n_prb_tilde[1]; pusch.c:52-91, chest_ul.c:244-266, refsignal_ul.c:316-346); 0: both slots at n_prb */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -330,6 +335,7 @@ typedef struct {
   uint32_t ack_len, I_offset_ack; /* as in srslte_hip_ul_rx_cfg_t (srslte_ulsch_encode's uci_cfg, sch.c:1168-1215) */
   uint32_t ri_len, I_offset_ri;   /* as in srslte_hip_ul_rx_cfg_t (sch.c:1110-1129) */
   uint32_t cqi_len, I_offset_cqi; /* as in srslte_hip_ul_rx_cfg_t (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
+  uint32_t hopping, n_prb_slot1;  /* as in srslte_hip_ul_rx_cfg_t */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);

@@ -221,6 +221,9 @@ int orc_ul_dmrs_pusch_gen(const orc_ul_dmrs_t* q, const orc_ul_dmrs_cfg_t* cfg, 
 /* grid, ce: [14][12*cell_nof_prb]; only the granted PRBs of ce are written, as upstream */
 int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb, const orc_cf_t* grid, orc_cf_t* ce,
                        orc_chest_ul_res_t* res);
+/* the same with a PRB offset per slot (srslte_pusch_grant_t.n_prb[2]: intra-subframe hopping) */
+int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, const orc_cf_t* grid,
+                           orc_cf_t* ce, orc_chest_ul_res_t* res);
 
 
 /* ---------------------------------------------------------------- HARQ-ACK on the PUSCH (orc_uci.c): 1 or 2 bits, no RI / CQI */

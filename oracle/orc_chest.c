@@ -632,8 +632,16 @@ int orc_ul_dmrs_pusch_gen(const orc_ul_dmrs_t* q, const orc_ul_dmrs_cfg_t* cfg, 
 
 int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb, const orc_cf_t* grid, orc_cf_t* ce,
                        orc_chest_ul_res_t* res)
+{
+  return orc_chest_ul_pusch_hop(r_dmrs, cell_nof_prb, L_prb, n_prb, n_prb, grid, ce, res);
+}
+
+int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, const orc_cf_t* grid,
+                           orc_cf_t* ce, orc_chest_ul_res_t* res)
 { /* srslte_chest_ul_estimate_pusch (chest_ul.c:268-327) with the defaults of srslte_chest_ul_init (:101-102: 3-tap filter, w = 0.3333),
-     same allocation in both slots, no linear interpolation (DO_LINEAR_INTERPOLATION is not defined, :244-258) */
+     no linear interpolation (DO_LINEAR_INTERPOLATION is not defined, :244-258): every slot's estimate is copied over that slot at the
+     slot's own PRB offset grant.n_prb[s] - intra-subframe hopping works, upstream only prints a complaint (:293-295) */
+  const uint32_t n_prbs[2] = {n_prb0, n_prb1};
   const uint32_t nre = 12 * cell_nof_prb, nrefs = 12 * L_prb;
   cf *           recv = malloc(sizeof(cf) * 2 * nrefs), *est = malloc(sizeof(cf) * 2 * nrefs), *tmp = malloc(sizeof(cf) * nrefs);
   float          filter[3];
@@ -642,17 +650,17 @@ int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L
   for (uint32_t s = 0; s < 2; s++) {
     const uint32_t L = (s + 1) * 7 - 4; /* SRSLTE_REFSIGNAL_UL_L */
     for (uint32_t i = 0; i < nrefs; i++) {
-      recv[s * nrefs + i] = grid[L * nre + n_prb * 12 + i];
+      recv[s * nrefs + i] = grid[L * nre + n_prbs[s] * 12 + i];
       est[s * nrefs + i]  = c_mulconj(recv[s * nrefs + i], r_dmrs[s * nrefs + i]);
     }
   }
   float power = 0;
   for (uint32_t s = 0; s < 2; s++) {
     const uint32_t L = (s + 1) * 7 - 4;
-    cf*            dst = &ce[L * nre + n_prb * 12];
+    cf*            dst = &ce[L * nre + n_prbs[s] * 12];
     conv_same_cf(&est[s * nrefs], filter, dst, nrefs, 3);
     for (uint32_t l = 0; l < 7; l++) {
-      if (s * 7 + l != L) memcpy(&ce[(s * 7 + l) * nre + n_prb * 12], dst, sizeof(cf) * nrefs);
+      if (s * 7 + l != L) memcpy(&ce[(s * 7 + l) * nre + n_prbs[s] * 12], dst, sizeof(cf) * nrefs);
     }
     for (uint32_t i = 0; i < nrefs; i++) tmp[i] = c_sub(dst[i], est[s * nrefs + i]); /* srslte_chest_estimate_noise_pilots */
     power += avg_power(tmp, nrefs);

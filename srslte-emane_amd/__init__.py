@@ -559,7 +559,8 @@ class UlRxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
                 ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
-                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32)]
+                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32),
+                ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
 
 
 class UlRx:
@@ -567,10 +568,10 @@ class UlRx:
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
                  group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0,
-                 cqi_len=0, I_offset_cqi=0):
+                 cqi_len=0, I_offset_cqi=0, n_prb_slot1=None):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0)
         L = lib()
         L.srslte_hip_ul_rx_ri.restype = C.c_void_p
         L.srslte_hip_ul_rx_ri.argtypes = [C.c_void_p]
@@ -636,7 +637,7 @@ class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
                 ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32),
-                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32)]
+                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32), ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
 
 
 class UlTx:
@@ -644,10 +645,11 @@ class UlTx:
     srslte_ulsch_encode sch.c:1068-1160, DMRS, srslte_ofdm_tx_sf with ue_ul.c:59-64 settings)."""
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
-                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0, cqi_len=0, I_offset_cqi=0):
+                 sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0, cqi_len=0, I_offset_cqi=0,
+                 n_prb_slot1=None):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0)
         L = lib()
         L.srslte_hip_ul_tx_batch_uci_cqi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                      C.c_void_p, C.c_void_p]

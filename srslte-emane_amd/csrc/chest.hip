@@ -828,7 +828,7 @@ uint32_t largest_prime_below(uint32_t x)
 }
 
 struct ChestUlGeom {
-  int   cell_nre, L_prb, n_prb, tti0; // 12 * cell nof_prb; grant
+  int   cell_nre, L_prb, n_prb, n_prb1, tti0; // 12 * cell nof_prb; grant: PRB offset of slot 0 and of slot 1 (srslte_pusch_grant_t.n_prb[2])
   float w;                            // 3-tap smoothing filter {w, 1-2w, w} (chest_ul.c:101-102)
 };
 struct ChestUlResDev { float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo; };
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
   float       pw  = 0.f;
   for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
     const int  s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
-    const cf32 y = gs[L * g.cell_nre + g.n_prb * 12 + k];
+    const cf32 y = gs[L * g.cell_nre + (s ? g.n_prb1 : g.n_prb) * 12 + k];
     est[i]       = c_mulconj(y, r[i]);
     pw += y.x * y.x + y.y * y.y;
   }
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
       o = c_add(c_add(c_scale(e[k - 1], f0), c_scale(e[k], f1)), c_scale(e[k + 1], f0));
     }
     if (cs) {
-      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + g.n_prb * 12 + k] = o;
+      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + (s ? g.n_prb1 : g.n_prb) * 12 + k] = o;
     }
     const cf32 d = c_sub(o, e[k]);
     npw[s] += d.x * d.x + d.y * d.y;
@@ -1002,7 +1002,15 @@ int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmr
 extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
                                                         const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
 {
-  if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  return srslte_hip_chest_ul_estimate_pusch_batch_hop(q, tti0, L_prb, n_prb, n_prb, n_dmrs, d_grid, d_ce, d_res, nof_sf, stream);
+}
+
+// The same with a PRB offset per slot (srslte_pusch_grant_t.n_prb[0 / 1]): intra-subframe hopping. The reference estimates and fills each slot at
+// its own offset (chest_ul.c:244-266, no interpolation between the slots) and only prints a complaint (:293-295).
+extern "C" int srslte_hip_chest_ul_estimate_pusch_batch_hop(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_prb_slot1,
+                                                            uint32_t n_dmrs, const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
+{
+  if (!q || !d_grid || nof_sf < 0 || n_prb + L_prb > q->nof_prb || n_prb_slot1 + L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
   if (!srslte_hip_dft_precoding_valid_prb(L_prb)) {
     hip_log("[srslte_hip] Error invalid nof_prb=%u\n", L_prb); // chest_ul.c:278-281
     return SRSLTE_ERROR_INVALID_INPUTS;
@@ -1011,7 +1019,7 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q
   const void* d_r = nullptr;
   if (int rc = chest_ul_dmrs_table(q, L_prb, n_dmrs, &d_r)) return rc;
   ChestUlGeom g;
-  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.tti0 = (int)tti0; g.w = 0.3333f;
+  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.n_prb1 = (int)n_prb_slot1; g.tti0 = (int)tti0; g.w = 0.3333f;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(nof_sf), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, (hipStream_t)stream, (const cf32*)d_grid,
                      (cf32*)d_ce, (ChestUlResDev*)d_res, (const cf32*)q->d_r, g);
   LAUNCH_CHECK();

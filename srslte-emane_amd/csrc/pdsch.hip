@@ -1583,7 +1583,7 @@ __device__ __forceinline__ int ack_bit_type(const uint8_t* ack, int O, int Qm, i
 }
 
 struct PuschGeom {
-  int cell_nre, M_sc, n_prb, mod, Qm, tti0, scr_words, mmse;
+  int cell_nre, M_sc, n_prb, n_prb1, mod, Qm, tti0, scr_words, mmse; // n_prb / n_prb1: PRB offset of slot 0 / slot 1 (grant.n_prb_tilde[2])
   AckGeom ack, ri;
   int*    ack_sum; // [nof_sf][4] accumulators of the ACK decisions (zeroed per call), or null
   int*    ri_sum;  // the same for the rank indication
@@ -1598,7 +1598,8 @@ __global__ __launch_bounds__(256) void pusch_eq_kernel(const cf32* __restrict__ 
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z;
   if (k >= g.M_sc) return;
-  const size_t o  = ((size_t)sf * 14 + pusch_data_symbol(n)) * g.cell_nre + g.n_prb * 12 + k;
+  const int    l  = pusch_data_symbol(n);
+  const size_t o  = ((size_t)sf * 14 + l) * g.cell_nre + (l < 7 ? g.n_prb : g.n_prb1) * 12 + k;
   const cf32   y = grid[o], h = ce[o];
   const float  n0 = g.mmse ? noise[sf * 5] : 0.f;
   const float  re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0; // precoding.c:277-288, scaling 1
@@ -1897,7 +1898,8 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg)
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->max_iterations == 0 || cfg->L_prb < 1 ||
-      cfg->n_prb + cfg->L_prb > cfg->nof_prb || !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
+      cfg->n_prb + cfg->L_prb > cfg->nof_prb || (cfg->hopping && cfg->n_prb_slot1 + cfg->L_prb > cfg->nof_prb) ||
+      !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
     hip_log("[srslte_hip] ul_rx: invalid configuration\n");
     return nullptr;
   }
@@ -1981,7 +1983,7 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
     srslte_hip_ul_rx_destroy(q);
     return nullptr;
   }
-  q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
+  q->pg.cell_nre = 12 * (int)P; q->pg.M_sc = (int)M_sc; q->pg.n_prb = (int)cfg->n_prb; q->pg.n_prb1 = (int)(cfg->hopping ? cfg->n_prb_slot1 : cfg->n_prb); q->pg.mod = cfg->mod; q->pg.Qm = (int)Qm;
   q->pg.scr_words = (int)scr_words; q->pg.mmse = cfg->mmse; q->pg.nsymb = (int)nsymb;
   q->pg.ack.O = (int)cfg->ack_len; q->pg.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
   q->pg.ack_sum = q->d_ack_sum;
@@ -2025,7 +2027,7 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   const uint32_t C = q->seg.C, K = q->seg.K1;
   int            r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
   if (r) return r;
-  r = srslte_hip_chest_ul_estimate_pusch_batch(q->chest, tti0, q->cfg.L_prb, q->cfg.n_prb, q->cfg.n_dmrs, q->d_grid, q->d_ce, q->d_res, (int)nof_sf,
+  r = srslte_hip_chest_ul_estimate_pusch_batch_hop(q->chest, tti0, q->cfg.L_prb, q->cfg.n_prb, (uint32_t)q->pg.n_prb1, q->cfg.n_dmrs, q->d_grid, q->d_ce, q->d_res, (int)nof_sf,
                                                stream);
   if (r) return r;
   PuschGeom g = q->pg;
@@ -2143,7 +2145,7 @@ __device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_
 }
 
 struct PuschTxGeom {
-  int   cell_nre, M_sc, n_prb, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
+  int   cell_nre, M_sc, n_prb, n_prb1, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
   int   nsymb; // 12 data symbols, 11 in a shortened subframe
   AckGeom        ack, ri;
   const uint8_t* ack_bits; // [nof_sf][2] HARQ-ACK values of this call, or null
@@ -2282,7 +2284,7 @@ __global__ __launch_bounds__(256) void pusch_tx_map_kernel(const cf32* __restric
 {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
   if (k >= g.cell_nre) return;
-  const int kk = k - 12 * g.n_prb;
+  const int kk = k - 12 * (l < 7 ? g.n_prb : g.n_prb1); // each slot at its own offset (pusch_cp, pusch.c:52-91; refsignal_ul.c:316-330)
   cf32      v  = make_float2(0.f, 0.f);
   if (kk >= 0 && kk < g.M_sc) {
     if (l == 3 || l == 10) {
@@ -2324,6 +2326,7 @@ extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
 extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg)
 {
   if (!cfg || cfg->max_batch == 0 || cfg->mod < 1 || cfg->mod > 3 || cfg->L_prb < 1 || cfg->n_prb + cfg->L_prb > cfg->nof_prb ||
+      (cfg->hopping && cfg->n_prb_slot1 + cfg->L_prb > cfg->nof_prb) ||
       !srslte_hip_dft_precoding_valid_prb(cfg->L_prb)) {
     hip_log("[srslte_hip] ul_tx: invalid configuration\n");
     return nullptr;
@@ -2340,7 +2343,7 @@ extern "C" srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cf
   const uint32_t nsymb = cfg->shortened ? 11 : 12;
   const uint32_t nof_re = nsymb * M_sc, nbits = nof_re * Qm, scr_words = (nbits + 31) / 32;
   PuschTxGeom&   g = q->g;
-  g.cell_nre = 12 * (int)P; g.M_sc = (int)M_sc; g.n_prb = (int)cfg->n_prb; g.Qm = (int)Qm; g.scr_words = (int)scr_words; g.C = (int)C; g.K = (int)K;
+  g.cell_nre = 12 * (int)P; g.M_sc = (int)M_sc; g.n_prb = (int)cfg->n_prb; g.n_prb1 = (int)(cfg->hopping ? cfg->n_prb_slot1 : cfg->n_prb); g.Qm = (int)Qm; g.scr_words = (int)scr_words; g.C = (int)C; g.K = (int)K;
   g.nsymb = (int)nsymb;
   g.ack.O = (int)cfg->ack_len; g.ack.Qprime = pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K);
   if (g.ack.Qprime < 0) {

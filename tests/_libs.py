@@ -195,14 +195,15 @@ class RefChestUlRes(C.Structure):
                 ("snr_db", C.c_float), ("cfo", C.c_float)]
 
 
-def ref_pusch_cfg(L_prb, n_prb, n_dmrs):
+def ref_pusch_cfg(L_prb, n_prb, n_dmrs, n_prb_slot1=None):
     """A zeroed srslte_pusch_cfg_t (pusch_cfg.h:62-86) with the grant fields the UL estimator reads; offsets from the reference headers
     (checked by tests/test_abi_layout.py where those headers are available)."""
     buf = (C.c_uint8 * 520)()
     u32 = C.cast(buf, C.POINTER(C.c_uint32))
     u32[388 // 4] = L_prb
-    u32[392 // 4], u32[396 // 4] = n_prb, n_prb          # n_prb[2]
-    u32[400 // 4], u32[404 // 4] = n_prb, n_prb          # n_prb_tilde[2]
+    n1 = n_prb if n_prb_slot1 is None else n_prb_slot1
+    u32[392 // 4], u32[396 // 4] = n_prb, n1             # n_prb[2]
+    u32[400 // 4], u32[404 // 4] = n_prb, n1             # n_prb_tilde[2]
     u32[476 // 4] = n_dmrs
     return buf
 

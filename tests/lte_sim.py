@@ -747,10 +747,12 @@ def ref_sch_decode(self, e, nbits):
 class UlConfig:
     """One PUSCH configuration: UL-SCH data only (no UCI), same allocation in both slots, rv 0, normal CP, not shortened."""
 
-    def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0,
+    def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0, n_prb_slot1=None,
                  group_hopping=False, sequence_hopping=False, shortened=False):
         from _libs import OrcUlDmrs, OrcUlDmrsCfg
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.L_prb, self.n_prb, self.n_dmrs = nof_prb, cell_id, mod, tbs, L_prb, n_prb, n_dmrs
+        # srslte_pusch_grant_t.n_prb[2] / n_prb_tilde[2]: the PRB offset of each slot (intra-subframe hopping when they differ)
+        self.n_prbs = (n_prb, n_prb if n_prb_slot1 is None else n_prb_slot1)
         self.rnti, self.max_iter = rnti, max_iter
         self.Qm = MOD_BITS[mod]
         self.nre = 12 * nof_prb
@@ -864,11 +866,13 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     z = np.zeros_like(d)
     orc.orc_dft_precoding(p(d), p(z), cfg.L_prb, cfg.nsymb, 1, True)
     grid = np.zeros(cfg.grid_len, np.complex64)
-    for n, l in enumerate(cfg.data_syms):
-        grid[l * cfg.nre + 12 * cfg.n_prb: l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc] = z[n * cfg.M_sc:(n + 1) * cfg.M_sc]
+    for n, l in enumerate(cfg.data_syms):  # pusch_cp (pusch.c:52-91): slot l // 7 at its own offset n_prb_tilde[slot]
+        o = l * cfg.nre + 12 * cfg.n_prbs[l // 7]
+        grid[o:o + cfg.M_sc] = z[n * cfg.M_sc:(n + 1) * cfg.M_sc]
     r = cfg.r_dmrs(sf_idx)
-    for s_, l in enumerate((3, 10)):
-        grid[l * cfg.nre + 12 * cfg.n_prb: l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc] = r[s_ * cfg.M_sc:(s_ + 1) * cfg.M_sc]
+    for s_, l in enumerate((3, 10)):  # srslte_refsignal_dmrs_pusch_put (refsignal_ul.c:316-330)
+        o = l * cfg.nre + 12 * cfg.n_prbs[s_]
+        grid[o:o + cfg.M_sc] = r[s_ * cfg.M_sc:(s_ + 1) * cfg.M_sc]
     tx = OrcOfdm()
     orc.orc_ofdm_init(C.byref(tx), cfg.nof_prb, True)
     tx.normalize, tx.freq_shift, tx.freq_shift_f = True, True, 0.5  # ue_ul.c:63-64
@@ -895,8 +899,8 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
     grid = np.zeros(cfg.grid_len, np.complex64)
     orc.orc_ofdm_rx_sf(C.byref(rxo), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
     ce, res = np.zeros(cfg.grid_len, np.complex64), OrcChestUlRes()
-    assert orc.orc_chest_ul_pusch(p(cfg.r_dmrs(sf_idx)), cfg.nof_prb, cfg.L_prb, cfg.n_prb, p(grid), p(ce), C.byref(res)) == 0
-    sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prb, l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc) for l in cfg.data_syms])
+    assert orc.orc_chest_ul_pusch_hop(p(cfg.r_dmrs(sf_idx)), cfg.nof_prb, cfg.L_prb, cfg.n_prbs[0], cfg.n_prbs[1], p(grid), p(ce), C.byref(res)) == 0
+    sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // 7], l * cfg.nre + 12 * cfg.n_prbs[l // 7] + cfg.M_sc) for l in cfg.data_syms])
     y, h = np.ascontiguousarray(grid[sel]), np.ascontiguousarray(ce[sel])
     z, d = np.zeros(cfg.nof_re, np.complex64), np.zeros(cfg.nof_re, np.complex64)
     orc.orc_predecoding_single(p(y), p(h), p(z), cfg.nof_re, 1.0, res.noise_estimate)
@@ -948,7 +952,7 @@ class RefUlRx:
         assert R.srslte_chest_ul_init(self.chest, cfg.nof_prb) == 0
         assert R.srslte_chest_ul_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
         R.srslte_chest_ul_pregen(self.chest, C.byref(cfg.dmrs_cfg))
-        self.pcfg = ref_pusch_cfg(cfg.L_prb, cfg.n_prb, cfg.n_dmrs)
+        self.pcfg = ref_pusch_cfg(cfg.L_prb, cfg.n_prb, cfg.n_dmrs, cfg.n_prbs[1])
         self.res = RefChestUlRes()
         self.ce = aligned(2 * cfg.grid_len, np.float32)
         self.res.ce = self.ce.ctypes.data
@@ -962,7 +966,7 @@ class RefUlRx:
         self.q = OrcOfdm()
         oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, True)
         self.q.normalize, self.q.freq_shift, self.q.freq_shift_f = False, True, -0.5
-        self.sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prb, l * cfg.nre + 12 * cfg.n_prb + cfg.M_sc) for l in cfg.data_syms])
+        self.sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // 7], l * cfg.nre + 12 * cfg.n_prbs[l // 7] + cfg.M_sc) for l in cfg.data_syms])
 
     def run(self, iq, tti):
         from _libs import ref_ul_sf_cfg

@@ -1248,6 +1248,50 @@ def test_ul_cqi_config_errors(hp):
     tx.free()
 
 
+UL_HOP_CASES = [(25, 10, 5, 14, 2, 4008, 9.5, 8, 4, False), (100, 48, 50, 1, 3, 30576, 17.0, 3, 3, False), (6, 2, 0, 4, 1, 256, 5.0, 0, 6, True),
+                (50, 25, 0, 25, 2, 9912, 9.0, 5, 3, False)]
+
+
+@pytest.mark.parametrize("prb,L,n0,n1,mod,tbs,snr,tti0,nsf,short", UL_HOP_CASES)
+def test_ul_chains_intra_subframe_hopping(hp, prb, L, n0, n1, mod, tbs, snr, tti0, nsf, short):
+    """srslte_pusch_grant_t.n_prb[0] != n_prb[1] (cfg.hopping / n_prb_slot1): the transmit pipeline maps each slot's data and DMRS at
+    its own PRB offset (symbols exact vs the oracle's), and the receive pipeline estimates, equalises and decodes them there - channel
+    estimates, LLRs, pass counts, CRC and bytes vs the oracle chain (pinned on the reference's estimator with hopping)."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(2300 + prb + L + n1)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n0, shortened=short, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6, n_prb_slot1=n1)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.UlTx(11, prb, 0x1234, mod, tbs, L, n0, 3, nsf, 2, 5, True, L >= 6, shortened=short, n_prb_slot1=n1)
+    iq_dev = tx.encode(data, tti0)
+    for b in range(nsf):
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b])
+        assert_close_c(iq_dev[b], iq_o, "iq sf %d" % b)
+    tx.free()
+    iq, _ = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), data=data[b]) for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n0, 3, 6, nsf, 2, 5, True, L >= 6, shortened=short, n_prb_slot1=n1)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    C_ = cfg.seg.C
+    it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+    g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+    ce = rx.debug(1, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    n_ok = 0
+    for b in range(nsf):
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True)
+        for sym in range(14):  # estimates only where the slot's grant is
+            o = sym * cfg.nre + 12 * (n0 if sym < 7 else n1)
+            assert_close_c(ce[b][o:o + cfg.M_sc], r["ce"][o:o + cfg.M_sc], "ce sf %d symbol %d" % (b, sym))
+        diff = np.abs(g[b].astype(np.int32) - r["g"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size + 1, (b, int(diff.max()))
+        assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), "sf %d" % b
+        if r["ok"] or diff.max() == 0:
+            assert np.array_equal(tb[b], r["tb"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b][:tbs // 8], data[b])
+    assert n_ok > 0
+    rx.free()
+
+
 def test_ul_tx_rx_loop_uci(hp):
     """Device transmit chain with HARQ-ACK and rank indication into the device receive chain (noise-free): everything comes back."""
     prb, L, n_prb, mod, tbs, nsf = 50, 40, 4, 2, 17568, 12

@@ -962,6 +962,71 @@ def test_chest_ul_pusch_vs_ref(cell_id, prb, L, n_prb):
     R.srslte_chest_ul_free(q)
 
 
+@pytest.mark.parametrize("cell_id,prb,L,n0,n1", [(1, 6, 2, 0, 4), (77, 25, 10, 12, 1), (301, 100, 48, 2, 50), (12, 50, 20, 30, 0)])
+def test_chest_ul_pusch_intra_subframe_hopping_vs_ref(cell_id, prb, L, n0, n1, capfd):
+    """srslte_pusch_grant_t.n_prb[0] != n_prb[1]: the reference's estimator prints "intra-subframe frequency hopping not supported" and
+    goes on (chest_ul.c:293-295); with the per-slot copy it is compiled with (DO_LINEAR_INTERPOLATION undefined, :244-258) every slot
+    is estimated and filled at its own PRB offset, which is what the oracle's orc_chest_ul_pusch_hop restates."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg, RefChestUlRes, ref_pusch_cfg, ref_ul_sf_cfg
+    R, rng = ref(), np.random.default_rng(cell_id + prb)
+    q = opaque(1 << 16)
+    assert R.srslte_chest_ul_init(q, prb) == 0 and R.srslte_chest_ul_set_cell(q, RefCell(prb, 1, cell_id, 0, 0, 0, 0)) == 0
+    dcfg = OrcUlDmrsCfg(1, 7, False, True)
+    R.srslte_chest_ul_pregen(q, C.byref(dcfg))
+    o = OrcUlDmrs()
+    oracle().orc_ul_dmrs_init(C.byref(o), cell_id)
+    nre, n = 12 * prb, 14 * 12 * prb
+    for tti, n_dmrs, nz in ((7, 5, 0.05), (12, 1, 0.25)):
+        r = np.zeros(2 * 12 * L, np.complex64)
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        grid = (0.5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        k = np.arange(12 * L)
+        for s_, (sym, npb) in enumerate(((3, n0), (10, n1))):
+            h = ((1.5 - 0.5 * s_ + 0.4 * np.sin(k / 30.0)) * np.exp(1j * (0.4 + s_ + k / 150.0))).astype(np.complex64)
+            grid[sym * nre + 12 * npb: sym * nre + 12 * (npb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grid = acopy((grid + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        ce_r, res = aligned(2 * n, np.float32), RefChestUlRes()
+        ce_r[:] = 0
+        res.ce = ce_r.ctypes.data
+        assert R.srslte_chest_ul_estimate_pusch(q, ref_ul_sf_cfg(tti), ref_pusch_cfg(L, n0, n_dmrs, n1), p(grid), C.byref(res)) == 0
+        ce_o, ores = np.zeros(n, np.complex64), OrcChestUlRes()
+        oracle().orc_chest_ul_pusch_hop.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert oracle().orc_chest_ul_pusch_hop(p(r), prb, L, n0, n1, p(grid), p(ce_o), C.byref(ores)) == 0
+        a = ce_r.view(np.complex64)
+        assert np.abs(a - ce_o).max() <= 1e-4 * np.abs(a).max()
+        filled = np.zeros(n, bool)
+        for sym in range(14):
+            npb = n0 if sym < 7 else n1
+            filled[sym * nre + 12 * npb: sym * nre + 12 * (npb + L)] = True
+        assert not a[~filled].any() and np.abs(a[filled]).min() > 0
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr", "snr_db"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+    R.srslte_chest_ul_free(q)
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()  # the reference's complaint, once per call
+
+
+@pytest.mark.parametrize("prb,L,n0,n1,mod,tbs,snr", [(25, 10, 5, 14, 2, 4008, 9.5), (100, 48, 50, 1, 3, 30576, 17.0), (6, 2, 0, 4, 1, 256, 5.0)])
+def test_pusch_chain_with_hopping_vs_reference_code(prb, L, n0, n1, mod, tbs, snr, capfd):
+    """The receive chain on the reference's compiled stages with a different PRB offset in each slot (what pusch_cp / pusch_get does with
+    grant.n_prb_tilde[slot], pusch.c:52-91): same transport blocks, CRC flags and pass counts as the oracle chain."""
+    rng = np.random.default_rng(950 + prb + L)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, n_prb_slot1=n1)
+    chain = RefUlRx(cfg)
+    nok = 0
+    for t in (0, 4, 9):
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j))
+        r, o = chain.run(iq, t), oracle_ul_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"])
+        if r["ok"]:
+            nok += 1
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+    assert nok > 0
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()
+
+
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr", [(6, 6, 0, 1, 1000, 3.5), (25, 10, 5, 2, 4008, 9.5), (100, 100, 0, 2, 43816, 12.5), (100, 48, 20, 3, 30576, 17.0)])
 def test_pusch_chain_vs_reference_code(prb, L, n_prb, mod, tbs, snr):
     """eNB PUSCH receive chain: reference-code chain vs oracle chain on identical IQ - same TBs, CRC flags, pass counts."""
