@@ -429,16 +429,16 @@ struct CsiW {
   float        scale, inv;
   int          Qm, mod, body_bits, nsym;
 };
-__device__ __forceinline__ CsiW csi_setup(const RmGeom& g, int sf, int nsym)
-{
+__device__ __forceinline__ CsiW csi_setup(const RmGeom& g, int sf, int nsym, int Qm)
+{ // Qm: of this block's transport block (grants mode: from its descriptor); srslte_mod_t = Qm / 2
   CsiW c;
   c.csi = g.csi + (size_t)sf * g.max_re;
   const float mx = nsym > 0 ? __uint_as_float(g.csi_max[sf]) : 1.0f;
   c.scale = 32767.0f / mx;
   c.inv   = 1.0f / mx;
-  c.Qm = g.Qm; c.mod = g.mod; c.nsym = nsym;
-  const int G = g.mod == 3 ? 12 : (g.mod == 4 ? 8 : 4);
-  c.body_bits = (nsym * g.Qm / G) * G;
+  c.Qm = Qm; c.mod = Qm / 2; c.nsym = nsym;
+  const int G = c.mod == 3 ? 12 : (c.mod == 4 ? 8 : 4);
+  c.body_bits = (nsym * Qm / G) * G;
   return c;
 }
 template <typename LLR>
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   }
   const LLR* src = e + (size_t)sf * g.max_bits + g.e_off + rp;
   CsiW       cw;
-  if (g.csi) cw = csi_setup(g, sf, nre);
+  if (g.csi) cw = csi_setup(g, sf, nre, Qm);
   uint32_t   n[PER], word = 0;
   if constexpr (PER == 2) {
     const uint2 t = *reinterpret_cast<const uint2*>(tbl + j);
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
   const int   n16 = (n_e2 + mis + PER - 1) / PER;
   if (g.csi) { // weigh while staging: element j of 16-byte word i is LLR rp - mis + PER * i + j of the subframe
-    const CsiW cw = csi_setup(g, sf, nre);
+    const CsiW cw = csi_setup(g, sf, nre, Qm);
     for (int i = threadIdx.x; i < n16; i += 256) {
       union {
         int4 v;
@@ -832,6 +832,8 @@ struct GrantsState {
   uint32_t *         d_relist, *d_scr, *d_basis, *d_rev, *d_cb_iters;
   int16_t *          d_e, *d_w;
   uint8_t *          d_cb_bytes, *d_cb_ok, *d_desc;
+  float*             d_csi;     // [B][max_re], cfg.csi_enable
+  uint32_t*          d_csi_max; // [B]
   size_t             desc_bytes;
   std::vector<uint8_t>                                 h_desc;
   std::map<std::pair<uint32_t, uint32_t>, uint32_t*>   rm_tbl; // (K, rv) -> slot table in the layout of that K's decoder
@@ -883,7 +885,7 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   if (q->gs) {
     GrantsState* g = q->gs;
     srslte_hip_tdec_destroy(g->tdec);
-    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_rev, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc};
+    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_rev, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc, g->d_csi, g->d_csi_max};
     for (void* b : gb) {
       if (b) (void)hipFree(b);
     }
@@ -1096,6 +1098,7 @@ extern "C" const void* srslte_hip_dl_rx_debug_buffer(const srslte_hip_dl_rx_t* q
     case 14: return q->gs ? q->gs->d_cb_ok : nullptr;
     case 15: return q->gs ? q->gs->d_relist : nullptr;
     case 16: return q->gs ? q->gs->d_scr : nullptr;
+    case 17: return q->gs ? q->gs->d_csi : nullptr;
   }
   return nullptr;
 }
@@ -1275,7 +1278,7 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // pdsch.c:81-206), modulation, transport block size, redundancy version, RNTI, CFI, new-data flag. RE lists and scrambling sequences are made
 // on the device from the grants, rate de-matching runs over the ragged set of code blocks of the batch, the turbo decoder once per block
 // length present in it. cfg.tbs bounds the transport block size (buffer sizes), cfg.mod / cfg.rnti / cfg.cfi are not used here.
-// Single-port cells (TM1), 1..4 receive antennas, 16-bit LLRs.
+// Single-port cells (TM1), 1..4 receive antennas, 16-bit LLRs, with or without the CSI weighting of cfg.csi_enable.
 // --------------------------------------------------------------------------------------------------------------------
 static int grants_init(srslte_hip_dl_rx_t* q)
 {
@@ -1290,6 +1293,7 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   g->d_relist = g->d_scr = g->d_basis = g->d_rev = g->d_cb_iters = nullptr;
   g->d_e = g->d_w = nullptr;
   g->d_cb_bytes = g->d_cb_ok = g->d_desc = nullptr;
+  g->d_csi = nullptr; g->d_csi_max = nullptr;
   q->gs = g;
   if (!g->tdec) return SRSLTE_ERROR;
   // Gold-sequence basis (sequence.c:48-79): all 31 x2 basis sequences advance together, bit j of the state word = basis j
@@ -1334,6 +1338,10 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   HIP_TRY(hipMalloc((void**)&g->d_cb_ok, nblk));
   HIP_TRY(hipMalloc((void**)&g->d_cb_iters, sizeof(uint32_t) * nblk));
   HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+  if (q->cfg.csi_enable) {
+    HIP_TRY(hipMalloc((void**)&g->d_csi, sizeof(float) * (size_t)g->max_re * B));
+    HIP_TRY(hipMalloc((void**)&g->d_csi_max, sizeof(uint32_t) * B));
+  }
   // HARQ state of slots that have not seen new data yet: nothing decoded, empty soft buffers
   HIP_TRY(hipMemset(g->d_cb_ok, 0, nblk));
   HIP_TRY(hipMemset(g->d_w, 0, sizeof(int16_t) * (size_t)g->stride * nblk));
@@ -1364,8 +1372,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.csi_enable || q->cfg.tx_scheme) {
-    hip_log("[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs, no CSI weighting\n");
+  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.tx_scheme) {
+    hip_log("[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -1476,7 +1484,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   LAUNCH_CHECK();
   {
     PdschGeom pg = q->pg;
-    pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = nullptr; pg.csi_max = nullptr;
+    pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = g->d_csi; pg.csi_max = g->d_csi_max;
+    if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * nof_sf, st));
     const cf32* grid = q->d_grid;
     hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                        (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
@@ -1486,7 +1495,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     RmGeom rg;
     memset(&rg, 0, sizeof(rg));
     rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
-    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re;
+    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
     const int lds = (int)((max_seg + 15) & ~15u);
     if (lds <= 64 * 1024) {
       hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(ncb), dim3(256), lds, st, (const int16_t*)g->d_e, g->d_w, (const uint32_t*)nullptr, rg);

@@ -51,14 +51,14 @@ MIX = {
 }
 
 
-def build_stream(P, cell_id, tti0, rng):
+def build_stream(P, cell_id, tti0, rng, csi=False):
     """Grants from the reference where it is there (it is on the GPU box: oracle/_ref travels), subframes from the oracle's transmitter."""
     rx = refdrv.RefDl(P, 1, cell_id)
     out = []
     for b, (how, mcs, cfi, snr) in enumerate(MIX[P]):
         sf, rnti = (tti0 + b) % 10, 0x100 + 7 * b
         info = ref_grant(rx, P, sf, how, mcs, rnti, cfi, rng)
-        cfg = DlConfig(P, cell_id, info["mod"], info["tbs"], cfi=cfi, rnti=rnti, prb_mask=info["prb_mask"])
+        cfg = DlConfig(P, cell_id, info["mod"], info["tbs"], cfi=cfi, rnti=rnti, prb_mask=info["prb_mask"], csi=csi)
         iq, data = make_subframe(cfg, tti0 + b, rng, snr_db=snr)
         out.append({"cfg": cfg, "iq": iq, "data": data, "info": info})
     rx.free()
@@ -69,15 +69,17 @@ need_ref = pytest.mark.skipif(refdrv.lib() is None, reason="oracle/_ref did not 
 
 
 @need_ref
-@pytest.mark.parametrize("P,cell_id,tti0", [(100, 1, 0), (25, 150, 5), (15, 2, 0), (25, 3, 8)])
-def test_mixed_grants_vs_oracle_and_reference(hp, P, cell_id, tti0):
+@pytest.mark.parametrize("P,cell_id,tti0,csi", [(100, 1, 0, False), (25, 150, 5, False), (15, 2, 0, False), (25, 3, 8, False), (100, 1, 0, True), (15, 2, 5, True),
+                                               (25, 150, 0, True)])
+def test_mixed_grants_vs_oracle_and_reference(hp, P, cell_id, tti0, csi):
+    """csi: cfg.csi_enable (the srsUE default) - the per-RE gains of every subframe's own allocation weigh its LLRs (pdsch.c:574-690)."""
     rng = np.random.default_rng(P + tti0)
-    stream = build_stream(P, cell_id, tti0, rng)
+    stream = build_stream(P, cell_id, tti0, rng, csi)
     assert len({(s["info"]["mod"], s["info"]["tbs"], s["info"]["nof_re"]) for s in stream}) >= 4  # >= 4 different (allocation, MCS) pairs
     tbs_max = max(s["cfg"].tbs for s in stream)
     hc = hp.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
-    rxg = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, len(stream), True, hc)
+    rxg = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, len(stream), True, hc, csi=csi)
     grants = [hp.DlGrant.make(P, s["cfg"].mod, s["cfg"].tbs, s["cfg"].rnti, cfi=s["cfg"].cfi, prb_mask=s["cfg"].prb_mask) for s in stream]
     rc, tb, ok = rxg.decode_grants(np.stack([s["iq"] for s in stream]), tti0, grants)
     assert rc == 0
@@ -86,14 +88,14 @@ def test_mixed_grants_vs_oracle_and_reference(hp, P, cell_id, tti0):
     relist = rxg.debug(15, np.uint32, n * 14 * 12 * P).reshape(n, -1)
     ref = refdrv.RefDl(P, 1, cell_id)
     ref.set_chest_cfg(filter_type=0, coef=(4.0, 1.0))
-    ref.set_pdsch_cfg(max_iterations=6, mmse=True)
+    ref.set_pdsch_cfg(max_iterations=6, mmse=True, csi=csi)
     nok = 0
     for b, s in enumerate(stream):
         cfg = s["cfg"]
         r = oracle_rx(cfg, s["iq"], tti0 + b, keep=True)
         idx = cfg.indices((tti0 + b) % 10)
         assert np.array_equal(relist[b, :len(idx)], idx), b                     # RE list made on the device = srslte_pdsch_cp's order
-        diff = np.abs(e[b, :len(r["e"])].astype(int) - r["e"].astype(int))    # LLRs: own float stages upstream -> 1 LSB on a few
+        diff = np.abs(e[b, :len(r["e_raw"])].astype(int) - r["e_raw"].astype(int))  # LLRs (before the CSI weighting): own float stages upstream -> 1 LSB on a few
         assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (b, diff.max(), (diff > 0).mean())
         assert bool(ok[b]) == bool(r["ok"]), b
         if ok[b]:
