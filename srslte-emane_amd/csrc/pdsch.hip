@@ -1278,7 +1278,7 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // pdsch.c:81-206), modulation, transport block size, redundancy version, RNTI, CFI, new-data flag. RE lists and scrambling sequences are made
 // on the device from the grants, rate de-matching runs over the ragged set of code blocks of the batch, the turbo decoder once per block
 // length present in it. cfg.tbs bounds the transport block size (buffer sizes), cfg.mod / cfg.rnti / cfg.cfi are not used here.
-// Single-port cells (TM1), 1..4 receive antennas, 16-bit LLRs, with or without the CSI weighting of cfg.csi_enable.
+// Single-port cells (TM1), 1..4 receive antennas, 16- or 8-bit LLRs (cfg.llr_8bit), with or without the CSI weighting of cfg.csi_enable.
 // --------------------------------------------------------------------------------------------------------------------
 static int grants_init(srslte_hip_dl_rx_t* q)
 {
@@ -1372,8 +1372,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->pg.nof_ports != 1 || q->cfg.llr_8bit || q->cfg.tx_scheme) {
-    hip_log("[srslte_hip] dl_rx grants mode: single-port cells, 16-bit LLRs\n");
+  if (q->pg.nof_ports != 1 || q->cfg.tx_scheme) {
+    hip_log("[srslte_hip] dl_rx grants mode: single-port cells\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -1392,6 +1392,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   auto*          d_map = reinterpret_cast<uint32_t*>(d_cb + nblk);
   struct Group { uint32_t K, single; std::vector<uint32_t> slots; };
   std::vector<Group> groups;
+  const bool         l8 = q->cfg.llr_8bit != 0; // the 8-bit LLR path the applications select (pdsch.c:760-779, sch.c:336-356): same buffers, as bytes
   uint32_t           ncb = 0, max_seg = 0;
   for (uint32_t b = 0; b < nof_sf; b++) {
     const srslte_hip_dl_grant_t& gr = grants[b];
@@ -1448,7 +1449,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     sd.nof_re = (int)nre; sd.mod = gr.mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)gr.tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
-    const uint32_t W = srslte_hip_tdec_autoimp_get_subblocks(K), w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
+    const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
+    const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
     const uint32_t* tbl = nullptr;
     if (grants_rm_table(g, K, gr.rv, W, w_len, &tbl)) return SRSLTE_ERROR;
     Group* grp = nullptr;
@@ -1465,7 +1467,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
       cd.w_len = (int)w_len; cd.tbl = tbl;
       grp->slots.push_back(b * g->Cmax + c);
     }
-    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm) * 2 + 32;
+    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm) * (l8 ? 1 : 2) + 32;
     max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
   }
   uint32_t nmap = 0;
@@ -1487,8 +1489,13 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = g->d_csi; pg.csi_max = g->d_csi_max;
     if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * nof_sf, st));
     const cf32* grid = q->d_grid;
-    hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
-                       (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
+    if (l8) {
+      hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                         (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, (int8_t*)g->d_e, pg);
+    } else {
+      hipLaunchKernelGGL(pdsch_demod_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                         (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
+    }
     LAUNCH_CHECK();
   }
   if (ncb) {
@@ -1497,7 +1504,12 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
     rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
     const int lds = (int)((max_seg + 15) & ~15u);
-    if (lds <= 64 * 1024) {
+    if (l8 && lds <= 64 * 1024) {
+      hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(ncb), dim3(256), lds, st, (const int8_t*)g->d_e, (int8_t*)g->d_w, (const uint32_t*)nullptr, rg);
+    } else if (l8) {
+      hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div((int)g->stride, 1024), ncb), dim3(256), 0, st, (const int8_t*)g->d_e, (int8_t*)g->d_w,
+                         (const uint32_t*)nullptr, rg);
+    } else if (lds <= 64 * 1024) {
       hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(ncb), dim3(256), lds, st, (const int16_t*)g->d_e, g->d_w, (const uint32_t*)nullptr, rg);
     } else {
       hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div((int)g->stride, 512), ncb), dim3(256), 0, st, (const int16_t*)g->d_e, g->d_w,
@@ -1508,9 +1520,10 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     tdec_set_skip(g->tdec, g->d_cb_ok);
     uint32_t off = 0;
     for (auto& x : groups) {
-      const uint32_t n = (uint32_t)x.slots.size(), W = srslte_hip_tdec_autoimp_get_subblocks(x.K);
+      const uint32_t n = (uint32_t)x.slots.size();
+      const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(x.K) : srslte_hip_tdec_autoimp_get_subblocks(x.K);
       tdec_set_cb_map(g->tdec, d_map + off);
-      r = tdec_run_batch_w(g->tdec, g->d_w, 0, g->stride, W != 0, x.K, -1, n, q->cfg.max_iterations, x.single ? 0x1864CFBu : 0x1800063u,
+      r = tdec_run_batch_w(g->tdec, g->d_w, l8 ? 1 : 0, g->stride, W != 0, x.K, -1, n, q->cfg.max_iterations, x.single ? 0x1864CFBu : 0x1800063u,
                            x.single ? x.single + 24 : x.K, g->d_cb_bytes, 768, g->d_cb_iters, g->d_cb_ok, st);
       tdec_set_cb_map(g->tdec, nullptr);
       if (r) return r;

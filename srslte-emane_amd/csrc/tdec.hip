@@ -1753,12 +1753,11 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   if (llr8 && !ar8) {
     // upstream widens 3K+12 elements whatever the layout (turbodecoder.c:466), which leaves part of an SB-layout buffer stale;
     // the whole buffer is widened here
-    const size_t per = in_stride, n = (size_t)nof_cb * per;
-    if (!q->d_conv) {
-      const size_t cap = (size_t)q->max_nof_cb * (3 * (q->max_long_cb + 32) + 12);
-      HIP_TRY(hipMalloc((void**)&q->d_conv, cap * sizeof(int16_t)));
-    }
-    if (per > 3 * (q->max_long_cb + 32) + 12) return SRSLTE_ERROR_INVALID_INPUTS;
+    // with a block map (ragged batches) the launched blocks sit in arbitrary slots of the buffer: every slot is widened
+    const size_t per_max = ((size_t)3 * (q->max_long_cb + 32) + 12 + 31) & ~(size_t)31; // the pipelines round their strides up to 32
+    const size_t per = in_stride, n = (size_t)(q->cb_map ? q->max_nof_cb : nof_cb) * per;
+    if (!q->d_conv) HIP_TRY(hipMalloc((void**)&q->d_conv, (size_t)q->max_nof_cb * per_max * sizeof(int16_t)));
+    if (per > per_max) return SRSLTE_ERROR_INVALID_INPUTS;
     hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, st, (const int8_t*)d_input_any,
                        q->d_conv, n);
     LAUNCH_CHECK();
