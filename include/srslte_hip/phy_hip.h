@@ -253,7 +253,7 @@ int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint3
  * subframe b of the batch is received with grants[b] (host array). prb_mask[s]: bit n = srslte_pdsch_grant_t.prb_idx[s][n], the PRBs of
  * slot s (any subset; the two slots may differ, as with distributed virtual resource blocks), walked as srslte_pdsch_cp does
  * (pdsch.c:81-206). tbs = 0: no transport block in that subframe (tb_ok = 0). rv / new_data as srslte_hip_dl_rx_batch_harq, per subframe.
- * cfg.tbs of the object bounds every grant's tbs; cfg.mod / cfg.rnti / cfg.cfi are not used. Single-port cells; cfg.llr_8bit, cfg.csi_enable
+ * cfg.tbs of the object bounds every grant's tbs; cfg.mod / cfg.rnti / cfg.cfi are not used. Single antenna port or transmit diversity (cfg.nof_ports); cfg.llr_8bit, cfg.csi_enable
  * (csi_correction with every subframe's own allocation and modulation) and cfg.nof_rx_antennas apply. */
 typedef struct {
   uint32_t prb_mask[2][4];

@@ -303,7 +303,8 @@ int refdrv_dl_set_grant_type2(refdrv_dl_t* q, uint32_t tti, uint32_t cfi, uint16
   q->dci_dl.tb[0].mcs_idx     = mcs;
   q->dci_dl.tb[0].rv          = rv;
   SRSLTE_DCI_TB_DISABLE(q->dci_dl.tb[1]);
-  if (srslte_ra_dl_dci_to_grant(&q->cell, &q->sf, SRSLTE_TM1, false, &q->dci_dl, &q->pdsch_cfg.grant)) return -1;
+  /* transmit diversity on a cell with more than one port, as a format-1A grant gets it (ra_dl.c:530-552) */
+  if (srslte_ra_dl_dci_to_grant(&q->cell, &q->sf, q->cell.nof_ports > 1 ? SRSLTE_TM2 : SRSLTE_TM1, false, &q->dci_dl, &q->pdsch_cfg.grant)) return -1;
   q->pdsch_cfg.rnti = rnti;
   if (tbs) *tbs = q->pdsch_cfg.grant.tb[0].tbs;
   if (nof_re) *nof_re = q->pdsch_cfg.grant.nof_re;

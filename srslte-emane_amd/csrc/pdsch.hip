@@ -163,8 +163,13 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
                                                               PdschGeom g)
 {
   __shared__ __attribute__((aligned(16))) LLR stage[512 * 8];
-  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
-  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  SfClass         c  = g.cls[sf_class(sf_idx)];
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+  if (g.desc) { // per-subframe grants
+    const SfDesc d = g.desc[sf];
+    c.idx = d.idx; c.nof_re = d.nof_re; g.mod = d.mod; g.Qm = d.Qm; cs = d.scr;
+  }
   const int     base = blockIdx.x * 512, i0 = base + 2 * threadIdx.x; // nof_re is even for a 2-port cell
   if (base >= c.nof_re) return;
   const bool     live = i0 < c.nof_re;
@@ -189,7 +194,6 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
   hh *= 1.0f / g.inv_scaling; // hh *= scaling (precoding.c:593)
   const cf32 x[2] = {make_float2((float)((double)(x0r / hh) * 1.4142135623730951), (float)((double)(x0i / hh) * 1.4142135623730951)),
                      make_float2((float)((double)(x1r / hh) * 1.4142135623730951), (float)((double)(x1i / hh) * 1.4142135623730951))};
-  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
 #pragma unroll
   for (int t = 0; t < 2; t++) {
     const int i = (live ? i0 : 0) + t;
@@ -222,8 +226,13 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
                                                                PdschGeom g)
 {
   __shared__ __attribute__((aligned(16))) LLR stage[1024 * 8];
-  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
-  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  SfClass         c  = g.cls[sf_class(sf_idx)];
+  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
+  if (g.desc) { // per-subframe grants
+    const SfDesc d = g.desc[sf];
+    c.idx = d.idx; c.nof_re = d.nof_re; g.mod = d.mod; g.Qm = d.Qm; cs = d.scr;
+  }
   const int     base = blockIdx.x * 1024, i0 = base + 4 * threadIdx.x; // nof_re is a multiple of 4 for a 4-port cell
   if (base >= c.nof_re) return;
   const bool live = i0 < c.nof_re;
@@ -247,7 +256,6 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
       xi[2 * half + 1] += -(h01.y * r0.x - h01.x * r0.y) + h10.x * r1.y - h10.y * r1.x;
     }
   }
-  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
   float           gmax = 0.f;
 #pragma unroll
   for (int t = 0; t < 4; t++) {
@@ -665,16 +673,21 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
 // ---- grants mode: RE lists and scrambling sequences made on the device from the grants of the batch
 // pdsch.c:81-206 as a per-RE rule for a single-port cell (see pdsch_re_indices below and oracle/orc_pdsch.c): symbol sym = 7 s + l,
 // sub-carrier k. q_off: what upstream's `offset` variable holds when it reaches the half PRBs of an odd-bandwidth cell (pdsch.c:172-190)
-__host__ __device__ __forceinline__ bool pdsch_re_used(int P, int cell_id, int sf_idx, int q_off, int s, int l, int k)
+__host__ __device__ __forceinline__ bool pdsch_re_used(int P, int cell_id, int sf_idx, int q_off, int s, int l, int k, int nof_ports = 1)
 {
   const int  nre  = 12 * P;
   const bool sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
   if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) return false;
-  if (l == 0 || l == 4) {
+  if (l == 0 || l == 4 || (l == 1 && nof_ports == 4)) { // phy_common.h:139-141
     const int  p      = k / 12;
     const bool centre = p >= P / 2 - 3 && p < P / 2 + 3 + (P % 2);
-    const int  off    = (centre && sync) ? q_off : (l == 0 ? cell_id % 6 : (cell_id + 3) % 6);
-    if (k % 6 == off % 6) return false;
+    if (nof_ports == 1) {
+      const int off = (centre && sync) ? q_off : (l == 0 ? cell_id % 6 : (cell_id + 3) % 6);
+      if (k % 6 == off % 6) return false;
+    } else { // every port's CRS positions stay empty: one RE in three, the same offset in every CRS symbol (pdsch.c:103-107)
+      const int off = (centre && sync) ? (l == 1 ? (q_off >> 8) : (q_off & 255)) : cell_id % 3; // bits 8..: the value by symbol 1 of slot 1 (4 ports)
+      if (k % 3 == off % 3) return false;
+    }
   }
   return true;
 }
@@ -682,7 +695,7 @@ __host__ __device__ __forceinline__ bool pdsch_re_used(int P, int cell_id, int s
 // One workgroup per subframe: idx_out[sf][...] = the grid positions of the subframe's PDSCH REs in the reference's order (symbol-major,
 // PRB ascending): counts per (symbol, PRB) unit, prefix sum in LDS, then every unit writes its REs.
 __global__ __launch_bounds__(256) void pdsch_relist_kernel(const GrantDev* __restrict__ gr, uint32_t* __restrict__ idx_out, int P, int cell_id,
-                                                           int max_re)
+                                                           int max_re, int nof_ports)
 {
   __shared__ int cnt[14 * 110 + 1];
   __shared__ int part[257];
@@ -696,7 +709,7 @@ __global__ __launch_bounds__(256) void pdsch_relist_kernel(const GrantDev* __res
     int n = 0;
     if (alloc(u)) {
       const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
-      for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k) ? 1 : 0;
+      for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports) ? 1 : 0;
     }
     cnt[u] = n;
   }
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(256) void pdsch_relist_kernel(const GrantDev* __res
       uint32_t* o = idx_out + (size_t)sf * max_re + off;
       int       w = 0;
       for (int k = 12 * p; k < 12 * p + 12; k++) {
-        if (pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k)) o[w++] = (uint32_t)(sym * nre + k);
+        if (pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports)) o[w++] = (uint32_t)(sym * nre + k);
       }
     }
     off += n;
@@ -1278,7 +1291,8 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // pdsch.c:81-206), modulation, transport block size, redundancy version, RNTI, CFI, new-data flag. RE lists and scrambling sequences are made
 // on the device from the grants, rate de-matching runs over the ragged set of code blocks of the batch, the turbo decoder once per block
 // length present in it. cfg.tbs bounds the transport block size (buffer sizes), cfg.mod / cfg.rnti / cfg.cfi are not used here.
-// Single-port cells (TM1), 1..4 receive antennas, 16- or 8-bit LLRs (cfg.llr_8bit), with or without the CSI weighting of cfg.csi_enable.
+// Single-port cells (TM1) and 2- / 4-port cells with transmit diversity (TM2), 1..4 receive antennas, 16- or 8-bit LLRs (cfg.llr_8bit), with or
+// without the CSI weighting of cfg.csi_enable.
 // --------------------------------------------------------------------------------------------------------------------
 static int grants_init(srslte_hip_dl_rx_t* q)
 {
@@ -1372,8 +1386,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->pg.nof_ports != 1 || q->cfg.tx_scheme) {
-    hip_log("[srslte_hip] dl_rx grants mode: single-port cells\n");
+  if (q->cfg.tx_scheme) {
+    hip_log("[srslte_hip] dl_rx grants mode: single antenna port or transmit diversity\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
@@ -1421,8 +1435,15 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
         }
       }
     }
-    // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them
-    gd.q_off = below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0);
+    // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them;
+    // with 2 / 4 ports every CRS symbol sets the same value
+    const int npt = q->pg.nof_ports;
+    bool any1_whole = false; // any whole (non-centre) PRB of slot 1: by symbol 1 its symbol-0 row has set `offset` too
+    for (uint32_t n = 0; n < P; n++) {
+      if (((gr.prb_mask[1][n >> 5] >> (n & 31)) & 1u) && !(n >= P / 2 - 3 && n < P / 2 + 3 + (P % 2))) any1_whole = true;
+    }
+    gd.q_off = npt == 1 ? (below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0))
+                        : (((below1 || any0) ? (int)(cell_id % 3) : 0) | (((below1 || any0 || any1_whole) ? (int)(cell_id % 3) : 0) << 8));
     // number of PDSCH REs (what pdsch_relist_kernel will list; srslte_ra_dl_grant_nof_re): per symbol, whole PRBs carry 12 REs (10 with
     // CRS), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half there 6 (5 with CRS)
     auto pop = [](const uint32_t* m, const uint32_t* f) {
@@ -1438,12 +1459,16 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     for (int sym = 0; sym < 14; sym++) {
       const int s = sym / 7, l = sym % 7;
       if (s == 0 && l < (int)lstart) continue;
-      const bool ref = l == 0 || l == 4, sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
-      const int  per = ref ? 10 : 12;
+      const bool ref = l == 0 || l == 4 || (l == 1 && npt == 4), sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
+      const int  per = ref ? (npt == 1 ? 10 : 8) : 12;
       nre += per * pop(gd.mask[s], all);
-      if (sync) nre += (ref ? 5 : 6) * pop(gd.mask[s], half) - per * pop(gd.mask[s], centre);
+      if (sync) nre += (per / 2) * pop(gd.mask[s], half) - per * pop(gd.mask[s], centre);
     }
     const uint32_t Qm = 2 * (uint32_t)gr.mod, K = seg.K1, C = seg.C;
+    if (nre % (uint32_t)npt) { // the transmit-diversity pre-decoders take the REs in groups of nof_ports (precoding.c:564-650)
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: %u REs are not a multiple of the %d ports\n", b, nre, npt);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
     if (nre == 0 || nre * Qm < C * Qm) {
       hip_log("[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
       return SRSLTE_ERROR_INVALID_INPUTS;
@@ -1467,7 +1492,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
       cd.w_len = (int)w_len; cd.tbl = tbl;
       grp->slots.push_back(b * g->Cmax + c);
     }
-    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm) * (l8 ? 1 : 2) + 32;
+    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
     max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
   }
   uint32_t nmap = 0;
@@ -1480,7 +1505,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   if (r) return r;
   // the descriptors: pageable source, so the copy has left the host buffer when the call returns and the buffer may be refilled
   HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_desc.data(), g->desc_bytes, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re);
+  hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re,
+                     q->pg.nof_ports);
   hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis, g->d_scr,
                      (int)g->words, (int)cell_id);
   LAUNCH_CHECK();
@@ -1489,7 +1515,23 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = g->d_csi; pg.csi_max = g->d_csi_max;
     if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * nof_sf, st));
     const cf32* grid = q->d_grid;
-    if (l8) {
+    if (pg.nof_ports == 4) {
+      if (l8) {
+        hipLaunchKernelGGL(pdsch_demod_div4_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                           (const uint32_t*)g->d_scr, (cf32*)nullptr, (int8_t*)g->d_e, pg);
+      } else {
+        hipLaunchKernelGGL(pdsch_demod_div4_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                           (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
+      }
+    } else if (pg.nof_ports == 2) {
+      if (l8) {
+        hipLaunchKernelGGL(pdsch_demod_div_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                           (const uint32_t*)g->d_scr, (cf32*)nullptr, (int8_t*)g->d_e, pg);
+      } else {
+        hipLaunchKernelGGL(pdsch_demod_div_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                           (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
+      }
+    } else if (l8) {
       hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                          (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, (int8_t*)g->d_e, pg);
     } else {
@@ -1502,7 +1544,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     RmGeom rg;
     memset(&rg, 0, sizeof(rg));
     rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
-    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
+    rg.Nl = q->pg.nof_ports > 1 ? 2 : 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
     const int lds = (int)((max_seg + 15) & ~15u);
     if (l8 && lds <= 64 * 1024) {
       hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(ncb), dim3(256), lds, st, (const int8_t*)g->d_e, (int8_t*)g->d_w, (const uint32_t*)nullptr, rg);
