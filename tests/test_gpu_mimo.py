@@ -96,6 +96,34 @@ def test_dl_rx_two_layer_noise_free_and_zf(hp):
         rx.free()
 
 
+@pytest.mark.parametrize("scheme,pmi,tbs2,p_a", [("cdd", 0, 4008, -3.0), ("mux", 1, 4008, 1.0), ("mux", 2, 0, -4.77)])
+def test_dl_rx_two_layer_power_allocation(hp, scheme, pmi, tbs2, p_a):
+    """srslte_pdsch_cfg_t.power_scale / p_a with the two-layer modes: the pre-decoders divide by rho_a = sqrt(2) 10^(p_a/20) through their
+    `scaling` argument (pdsch.c:852-858, precoding.c:925,:1336-1346,:1631); symbols and transport blocks vs the oracle chain."""
+    from lte_sim import DlConfig, make_subframe_mimo, oracle_rx_mimo
+    prb, nsf = 25, 4
+    cfg = DlConfig(prb, 21, 2, 4008, nof_rx=2, nof_ports=2, tx_scheme=scheme, pmi=pmi, mod2=2 if tbs2 else None, tbs2=tbs2, p_a=p_a)
+    rng = np.random.default_rng(91)
+    iq, data = zip(*[make_subframe_mimo(cfg, b, rng, snr_db=14.0, amp=0.2) for b in range(nsf)])
+    rx = hp.DlRx(21, prb, 1, 0x1234, 2, 4008, 6, nsf, True, _chest(hp), nof_rx=2, nof_ports=2, tx_scheme=SCHEME[scheme], pmi=pmi, mod2=2 if tbs2 else 0, tbs2=tbs2,
+                 power_scale=True, p_a=p_a)
+    rx.keep_symbols()
+    tb, ok = rx.decode(np.stack(iq), 0)
+    if not tbs2:
+        tb, ok = [tb], [ok]
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    for cw in range(cfg.nof_tb):
+        d = rx.debug(100 * cw + 3, np.complex64, nsf * max_re).reshape(nsf, -1)
+        for b in range(nsf):
+            r = oracle_rx_mimo(cfg, iq[b], b, keep=True)
+            nre = rx.nof_re(b % 10)
+            assert np.abs(d[b, :nre] - r["d"][cw]).max() <= 2e-4 * max(1.0, np.abs(r["d"][cw]).max()), (cw, b)
+            assert np.abs(np.abs(r["d"][cw]).mean() - 0.95) < 0.25  # unit-power constellation after the division by rho_a
+            assert bool(ok[cw][b]) == r["ok"][cw] and r["ok"][cw]
+            assert np.array_equal(tb[cw][b][:cfg.tbss[cw] // 8], data[b][cw])
+    rx.free()
+
+
 def test_dl_rx_two_layer_harq_per_transport_block(hp):
     """srslte_hip_dl_rx_batch_harq2: each transport block has its own redundancy version and new-data flag. Block 0 is retransmitted with
     rv 2 and combined, block 1 starts over: with the first transmission too noisy for either, block 0 decodes after combining, and
