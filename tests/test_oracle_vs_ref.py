@@ -1355,6 +1355,7 @@ TWO_LAYER_CASES = [  # nof_prb, cell_id, mod, tbs, mod2, tbs2, scheme, pmi, cfi,
     (100, 2, 3, 30576, 3, 30576, "mux", 1, 1, 4, 32.0),
     (25, 7, 2, 4008, None, 0, "mux", 0, 1, 3, 14.0), (25, 7, 3, 6200, None, 0, "mux", 1, 2, 5, 18.0), (6, 1, 1, 328, None, 0, "mux", 2, 3, 0, 6.0),
     (50, 150, 2, 9912, None, 0, "mux", 3, 1, 9, 14.0)]
+TWO_LAYER_PA = {(25, 7, 2, 4008, 2, 4008, "cdd", 0, 1, 3, 22.0): -3.0, (25, 7, 2, 4008, 2, 2216, "mux", 1, 2, 5, 22.0): 1.0, (25, 7, 3, 6200, None, 0, "mux", 1, 2, 5, 18.0): -4.77}
 
 
 @pytest.mark.parametrize("prb,cid,mod,tbs,mod2,tbs2,scheme,pmi,cfi,tti,snr", TWO_LAYER_CASES)
@@ -1365,13 +1366,15 @@ def test_pdsch_two_layer_modes_vs_reference(prb, cid, mod, tbs, mod2, tbs2, sche
     blocks and CRC verdicts identical. CDD on the build that honours signed zeros (previous test), multiplexing on the prescribed one."""
     from _libs import ref_sz
     from lte_sim import DlConfig, RefPdsch, RefPdschTx, make_subframe_mimo, oracle_rx_mimo
-    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=True, tx_scheme=scheme, pmi=pmi, mod2=mod2, tbs2=tbs2)
+    # three of the cases also with srslte_pdsch_cfg_t.power_scale / p_a (pdsch.c:518-554,:852-858): the receiver divides by rho_a
+    p_a = TWO_LAYER_PA.get((prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti, snr))
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=True, tx_scheme=scheme, pmi=pmi, mod2=mod2, tbs2=tbs2, p_a=p_a)
     rng = np.random.default_rng(prb + cid + tti)
     k = {}
     iq, data = make_subframe_mimo(cfg, tti, rng, snr_db=snr, amp=0.4, keep=k)
     grids = RefPdschTx(cfg).run_mimo(data, tti)
-    for port in range(2):  # the reference scales by rho_a = sqrt(2) on a 2-port cell (pdsch.c:525), the stimulus by 1
-        assert np.abs(grids[port][k["idx"]] - np.float32(np.sqrt(2.0)) * k["y"][port]).max() < 2e-6
+    for port in range(2):  # the reference scales by rho_a = sqrt(2) on a 2-port cell (pdsch.c:525), the stimulus by cfg.scaling
+        assert np.abs(grids[port][k["idx"]] - np.float32(np.sqrt(2.0) / cfg.scaling) * k["y"][port]).max() < 4e-6
     r = oracle_rx_mimo(cfg, iq, tti, keep=True)
     rr = RefPdsch(cfg, csi_enable=True, lib=ref_sz() if scheme == "cdd" else None).run_mimo(iq, tti)
     assert abs(r["noise"] / rr["noise"] - 1) < 1e-4
