@@ -166,9 +166,10 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
   const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
   SfClass         c  = g.cls[sf_class(sf_idx)];
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
+  int             mod = g.mod, Qm = g.Qm; // locals: writing to the by-value argument would move it to scratch
   if (g.desc) { // per-subframe grants
     const SfDesc d = g.desc[sf];
-    c.idx = d.idx; c.nof_re = d.nof_re; g.mod = d.mod; g.Qm = d.Qm; cs = d.scr;
+    c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
   }
   const int     base = blockIdx.x * 512, i0 = base + 2 * threadIdx.x; // nof_re is even for a 2-port cell
   if (base >= c.nof_re) return;
@@ -200,17 +201,17 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
     if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x[t];
     LLR o[8];
     if constexpr (sizeof(LLR) == 1) {
-      demod_dev::demod_b(g.mod, x[t], i, c.nof_re, o);
+      demod_dev::demod_b(mod, x[t], i, c.nof_re, o);
     } else {
-      demod_dev::demod_s(g.mod, x[t], i, c.nof_re, o);
+      demod_dev::demod_s(mod, x[t], i, c.nof_re, o);
     }
-    const int      bit0 = i * g.Qm;
+    const int      bit0 = i * Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
-    for (int j = 0; j < g.Qm; j++) stage[(2 * threadIdx.x + t) * g.Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
+    for (int j = 0; j < Qm; j++) stage[(2 * threadIdx.x + t) * Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
   }
   __syncthreads();
-  const int   nbytes = min(512, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
-  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const int   nbytes = min(512, c.nof_re - base) * Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * Qm);
   const char* src    = reinterpret_cast<const char*>(stage);
   for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
   const int rem = nbytes & 15;
@@ -229,9 +230,10 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
   const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
   SfClass         c  = g.cls[sf_class(sf_idx)];
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
+  int             mod = g.mod, Qm = g.Qm; // locals: writing to the by-value argument would move it to scratch
   if (g.desc) { // per-subframe grants
     const SfDesc d = g.desc[sf];
-    c.idx = d.idx; c.nof_re = d.nof_re; g.mod = d.mod; g.Qm = d.Qm; cs = d.scr;
+    c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
   }
   const int     base = blockIdx.x * 1024, i0 = base + 4 * threadIdx.x; // nof_re is a multiple of 4 for a 4-port cell
   if (base >= c.nof_re) return;
@@ -267,18 +269,18 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
     if (d_out && live) d_out[(size_t)sf * g.max_re + i] = x;
     LLR o[8];
     if constexpr (sizeof(LLR) == 1) {
-      demod_dev::demod_b(g.mod, x, i, c.nof_re, o);
+      demod_dev::demod_b(mod, x, i, c.nof_re, o);
     } else {
-      demod_dev::demod_s(g.mod, x, i, c.nof_re, o);
+      demod_dev::demod_s(mod, x, i, c.nof_re, o);
     }
-    const int      bit0 = i * g.Qm;
+    const int      bit0 = i * Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
-    for (int j = 0; j < g.Qm; j++) stage[(4 * threadIdx.x + t) * g.Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
+    for (int j = 0; j < Qm; j++) stage[(4 * threadIdx.x + t) * Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
   }
   if (g.csi) csi_note_max(g.csi_max + sf, gmax);
   __syncthreads();
-  const int   nbytes = min(1024, c.nof_re - base) * g.Qm * (int)sizeof(LLR);
-  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * g.Qm);
+  const int   nbytes = min(1024, c.nof_re - base) * Qm * (int)sizeof(LLR);
+  char*       dst    = reinterpret_cast<char*>(e_out + (size_t)sf * g.max_bits + (size_t)base * Qm);
   const char* src    = reinterpret_cast<const char*>(stage);
   for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
   const int rem = nbytes & 15;
