@@ -1,0 +1,47 @@
+"""Compile-time resource check of every device kernel (hipcc cross-compiles gfx950 without a GPU): none may use scratch memory - a kernel
+that spills registers or indexes a private array dynamically silently runs several times slower (it happened: writing to a by-value
+argument struct moved it to scratch). Also pins the occupancy the pipelines count on for the turbo decoder."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "srslte-emane_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FILES = ["fft.hip", "chest.hip", "demod.hip", "tdec.hip", "tcod.hip", "pdsch.hip"]
+
+
+def _remarks(name):
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           "--cuda-device-only", "-c", os.path.join(CSRC, name), "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage"]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+        for key in ("ScratchSize [bytes/lane]", "VGPRs", "AGPRs", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", "VGPRs Spill"):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return kernels
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_no_kernel_uses_scratch_and_decoder_occupancy():
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        res = dict(zip(FILES, ex.map(_remarks, FILES)))
+    total = 0
+    for f, kernels in res.items():
+        assert kernels, f
+        for k, r in kernels.items():
+            total += 1
+            assert r.get("ScratchSize [bytes/lane]", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (f, k, r)
+    assert total >= 40
+    dec = [r for k, r in res["tdec.hip"].items() if "tdec_win_kernelILi16ELi0" in k]
+    assert len(dec) == 1 and dec[0]["Occupancy [waves/SIMD]"] == 2 and dec[0]["AGPRs"] == 0 and dec[0]["LDS Size [bytes/block]"] <= 16 * 1024 + 64, dec
