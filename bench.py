@@ -195,15 +195,18 @@ def main():
 
     import torch
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend=args.backend)  # "nccl" is RCCL on ROCm
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     dev_index = args.force_device if args.force_device >= 0 else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":  # RCCL on ROCm; the group is bound to this rank's GPU, so barrier() needs no guess
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
     on_device = args.backend == "nccl"
     cdev = dev if on_device else torch.device("cpu")  # where collective operands live
 
