@@ -14,9 +14,9 @@ import importlib
 sharding = importlib.import_module("srslte-emane_amd.sharding")
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29533")
-dist.init_process_group("nccl", rank=0, world_size=1)
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)  # as bench.py does
 res = torch.arange(1000, dtype=torch.int64, device=dev).to(torch.uint8)
 gath = torch.zeros((1, 1000), dtype=torch.uint8, device=dev)
 side = torch.cuda.Stream()
