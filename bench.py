@@ -181,7 +181,7 @@ def main():
     # ---- CPU baseline, all-cores leg: one process per core of this box's CPU share over disjoint subframes of the batch. Run BEFORE this
     #      process touches the GPU (child processes are started from a GPU-free parent, and 16 busy cores do not disturb the GPU timing)
     cpu_multi = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:  # the CPU baseline is a rank-0, N = 1 figure
         ncores = max(1, min(16, len(os.sched_getaffinity(0))))  # a one-GPU box shares its host: 16 cores per GPU
         with tempfile.TemporaryDirectory() as tmp:
             path = os.path.join(tmp, "iq.npy")
@@ -412,7 +412,7 @@ def main():
 
     # ---- CPU baseline on a bounded sample of the same subframes: one core, then one process per core of this box's CPU share
     cpu = None
-    if not args.no_cpu:
+    if world == 1 and not args.no_cpu:
         run, kind = cpu_chain(ue["cell_id"], ue["rnti"], args.llr8)
         nsf, dt, t_ofdm = 0, 0.0, 0.0
         while dt < args.cpu_seconds:  # bounded sample: whole passes over the batch
