@@ -45,6 +45,7 @@ struct SfDesc {
   const uint32_t* scr; // packed scrambling bits of the subframe (scr_gen_kernel)
   int             nof_re, mod, Qm;
   int             C, K, tbs, rlen; // segmentation of its transport block (36.212 5.1.2): C blocks of K bits, rlen payload bits per block
+  const uint32_t* crc_fac;         // [256] x^(8 cB (255 - t)) mod g_CRC24A, cB = ceil((tbs / 8 + 3) / 256): tb_crc_bytes_kernel's chunk weights
 };
 struct CbDesc {
   int             sf, cb;  // subframe of the batch, code block of its transport block
@@ -614,8 +615,59 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   }
 }
 
+__device__ __forceinline__ uint32_t gf24_mul(uint32_t a, uint32_t b, uint32_t poly)
+{ // a(x) b(x) mod g(x), deg g = 24 (poly carries the x^24 term)
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r <<= 1;
+    if (r & 0x1000000u) r ^= poly;
+    if ((b >> i) & 1) r ^= a;
+  }
+  return r;
+}
+
+// CRC24 (init 0, MSB first) of nbytes bytes by a 256-thread block: the message is zero-extended at the FRONT to 256 equal chunks
+// (leading zeros do not change the remainder), every thread runs the byte-table recursion over its chunk, and the chunk
+// remainders are folded pairwise with x^(8*chunk*2^level) mod g. tab/red: 256 words of LDS each. Result valid in every thread.
+template <typename Byte>
+__device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_t* tab, uint32_t* red)
+{
+  const int t = threadIdx.x;
+  {
+    uint32_t v = (uint32_t)t << 16;
+    for (int i = 0; i < 8; i++) {
+      v <<= 1;
+      if (v & 0x1000000u) v ^= poly;
+    }
+    tab[t] = v;
+  }
+  __syncthreads();
+  const int cB = (nbytes + 255) / 256, pad = 256 * cB - nbytes;
+  uint32_t  crc = 0;
+  for (int i = 0; i < cB; i++) {
+    const int v = t * cB + i - pad;
+    if (v >= 0) crc = ((crc << 8) & 0xffffffu) ^ tab[((crc >> 16) & 0xff) ^ byte_at(v)];
+  }
+  uint32_t m = 1; // x^(8 cB) mod g
+  for (int i = 0; i < 8 * cB; i++) {
+    m <<= 1;
+    if (m & 0x1000000u) m ^= poly;
+  }
+  red[t] = crc;
+  __syncthreads();
+  for (int s = 1; s < 256; s <<= 1) {
+    uint32_t v = 0;
+    if ((t & (2 * s - 1)) == 0) v = gf24_mul(red[t], m, poly) ^ red[t + s];
+    __syncthreads();
+    if ((t & (2 * s - 1)) == 0) red[t] = v;
+    m = gf24_mul(m, m, poly);
+    __syncthreads();
+  }
+  return red[0];
+}
+
 struct TbGeom {
-  const SfDesc* desc; // grants mode: per-subframe (C, K, tbs, rlen), C = code-block slots per subframe, crc_rem = x^i mod g for i >= 0; else null
+  const SfDesc* desc; // grants mode (tb_crc_bytes_kernel): per-subframe (C, K, tbs, rlen), C = code-block slots per subframe; else null
   int C, K, tbs, rlen, cb_stride, tb_stride;
 };
 
@@ -626,18 +678,10 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
                                                      TbGeom g)
 {
   __shared__ uint32_t red[8];
-  int C = g.C, K = g.K, tbs = g.tbs, rlen = g.rlen;
-  if (g.desc) {
-    const SfDesc d = g.desc[blockIdx.x];
-    C = d.C; K = d.K; tbs = d.tbs; rlen = d.rlen;
-  }
+  const int C = g.C, K = g.K, tbs = g.tbs, rlen = g.rlen;
   const int sf = blockIdx.x, nbytes = tbs / 8 + 3, rb = rlen / 8;
   uint8_t*  dst = tb + (size_t)sf * g.tb_stride;
   uint32_t  syn = 0;
-  if (C == 0) { // grants mode: no transport block in this subframe
-    if (threadIdx.x == 0) tb_ok[sf] = 0;
-    return;
-  }
   for (int b0 = threadIdx.x * 4; b0 < nbytes + 3; b0 += blockDim.x * 4) {
     uint32_t word = 0;
 #pragma unroll
@@ -654,7 +698,7 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
     for (int j = 0; j < 32; j++) { // bit j of byte t = message bit 8*(b0+t) + (7 - j%8)
       const int      t = j >> 3, bit = 8 * (b0 + t) + 7 - (j & 7);
       const uint32_t m = 0u - ((word >> j) & 1u);
-      syn ^= (bit < 8 * nbytes ? crc_rem[g.desc ? 8 * nbytes - 1 - bit : bit] : 0u) & m;
+      syn ^= (bit < 8 * nbytes ? crc_rem[bit] : 0u) & m;
     }
   }
   for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
@@ -669,6 +713,57 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
     const uint8_t* p = dst + tbs / 8;
     ok               = ok && (p[0] | p[1] | p[2]);
     tb_ok[sf]        = ok ? 1 : 0;
+  }
+}
+
+// The same for transport blocks of any size (grants mode): the bytes go through LDS, 256 threads take the CRC24A of contiguous chunks with a
+// byte table, and the chunk CRCs are combined with 256 weights x^(8 n) mod g that the host makes once per transport block size.
+__global__ __launch_bounds__(256) void tb_crc_bytes_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok, uint8_t* __restrict__ tb,
+                                                           uint8_t* __restrict__ tb_ok, TbGeom g)
+{
+  __shared__ uint32_t tab[256], red[4];
+  __shared__ uint8_t  bytes[97896 / 8 + 8]; // the largest transport block (256QAM, 100 PRB) + CRC
+  const SfDesc d  = g.desc[blockIdx.x];
+  const int    sf = blockIdx.x, C = d.C, K = d.K, nbytes = d.tbs / 8 + 3, rb = d.rlen / 8, t = threadIdx.x;
+  uint8_t*     dst = tb + (size_t)sf * g.tb_stride;
+  if (C == 0) { // no transport block in this subframe
+    if (t == 0) tb_ok[sf] = 0;
+    return;
+  }
+  {
+    uint32_t v = (uint32_t)t << 16; // byte table of CRC24A
+    for (int i = 0; i < 8; i++) {
+      v <<= 1;
+      if (v & 0x1000000u) v ^= 0x1864CFBu;
+    }
+    tab[t] = v;
+  }
+  for (int cb = 0; cb < C; cb++) { // block cb carries bytes [cb rb, (cb + 1) rb) of the transport block (the last one also the 3 bytes behind)
+    const uint8_t* src = cb_bytes + ((size_t)sf * g.C + cb) * g.cb_stride;
+    const int      n   = cb == C - 1 ? nbytes + 3 - cb * rb : rb;
+    for (int i = t; i < n; i += 256) {
+      const uint8_t v = i < K / 8 ? src[i] : 0;
+      dst[cb * rb + i] = v;
+      if (cb * rb + i < nbytes) bytes[cb * rb + i] = v;
+    }
+  }
+  __syncthreads();
+  // CRC of 256 contiguous chunks of cB bytes (zeros in front do not change a CRC), each weighted by x^(8 cB (chunks behind it)) mod g
+  const int cB = (nbytes + 255) / 256, pad = 256 * cB - nbytes;
+  uint32_t  crc = 0;
+  for (int i = 0; i < cB; i++) {
+    const int v = t * cB + i - pad;
+    if (v >= 0) crc = ((crc << 8) & 0xffffffu) ^ tab[((crc >> 16) & 0xff) ^ bytes[v]];
+  }
+  uint32_t syn = gf24_mul(crc, d.crc_fac[t], 0x1864CFBu);
+  for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
+  if ((t & 63) == 0) red[t >> 6] = syn;
+  __syncthreads();
+  if (t == 0) {
+    bool ok = (red[0] ^ red[1] ^ red[2] ^ red[3]) == 0;
+    for (int c = 0; c < C; c++) ok = ok && cb_ok[sf * g.C + c];
+    ok        = ok && (bytes[nbytes - 3] | bytes[nbytes - 2] | bytes[nbytes - 1]); // par_rx != 0 (sch.c:481)
+    tb_ok[sf] = ok ? 1 : 0;
   }
 }
 
@@ -695,59 +790,61 @@ __host__ __device__ __forceinline__ bool pdsch_re_used(int P, int cell_id, int s
 }
 
 // One workgroup per subframe: idx_out[sf][...] = the grid positions of the subframe's PDSCH REs in the reference's order (symbol-major,
-// PRB ascending): counts per (symbol, PRB) unit, prefix sum in LDS, then every unit writes its REs.
-__global__ __launch_bounds__(256) void pdsch_relist_kernel(const GrantDev* __restrict__ gr, uint32_t* __restrict__ idx_out, int P, int cell_id,
-                                                           int max_re, int nof_ports)
+// sub-carrier ascending). Two sweeps over the 14 x 12 P grid positions in chunks of 64: per-chunk counts by ballot, a prefix sum, then
+// every wavefront writes its chunks' positions compacted (coalesced).
+constexpr int RELIST_THREADS = 512;
+__global__ __launch_bounds__(RELIST_THREADS) void pdsch_relist_kernel(const GrantDev* __restrict__ gr, uint32_t* __restrict__ idx_out, int P, int cell_id,
+                                                                      int max_re, int nof_ports)
 {
-  __shared__ int cnt[14 * 110 + 1];
-  __shared__ int part[257];
-  const int      sf = blockIdx.x, units = 14 * P, nre = 12 * P;
+  __shared__ int cnt[14 * 21 + 1]; // chunks: 14 symbols x ceil(12 * 110 / 64)
+  const int      sf = blockIdx.x, nre = 12 * P, cps = (nre + 63) / 64, nchunks = 14 * cps;
+  const int      wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = RELIST_THREADS / 64;
   const GrantDev g  = gr[sf];
-  auto           alloc = [&](int u) {
-    const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
-    return (s == 1 || l >= g.lstart) && ((g.mask[s][p >> 5] >> (p & 31)) & 1u);
+  auto           used = [&](int sym, int kc) { // position (sym, kc * 64 + lane)
+    const int k = kc * 64 + lane, s = sym >= 7 ? 1 : 0, l = sym - 7 * s, p = k / 12;
+    if (k >= nre || !((g.mask[s][p >> 5] >> (p & 31)) & 1u)) return false;
+    return pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports);
   };
-  for (int u = threadIdx.x; u < units; u += 256) {
-    int n = 0;
-    if (alloc(u)) {
-      const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
-      for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports) ? 1 : 0;
-    }
-    cnt[u] = n;
-  }
-  __syncthreads();
-  const int chunk = (units + 255) / 256, lo = threadIdx.x * chunk, hi = min(units, lo + chunk);
-  int       sum = 0;
-  for (int u = lo; u < hi; u++) sum += cnt[u];
-  part[threadIdx.x] = sum;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int i = 0; i < 256; i++) {
-      const int t = part[i];
-      part[i]     = acc;
-      acc += t;
+  for (int sym = 0; sym < 14; sym++) {
+    const bool on = sym >= 7 || sym >= g.lstart; // control region
+    for (int kc = wave; kc < cps; kc += nwaves) {
+      const unsigned long long b = on ? __ballot(used(sym, kc)) : 0ull;
+      if (lane == 0) cnt[sym * cps + kc] = __popcll(b);
     }
   }
   __syncthreads();
-  int off = part[threadIdx.x];
-  for (int u = lo; u < hi; u++) {
-    const int n = cnt[u];
-    if (n) {
-      const int sym = u / P, p = u - sym * P, s = sym / 7, l = sym - 7 * s;
-      uint32_t* o = idx_out + (size_t)sf * max_re + off;
-      int       w = 0;
-      for (int k = 12 * p; k < 12 * p + 12; k++) {
-        if (pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports)) o[w++] = (uint32_t)(sym * nre + k);
-      }
+  if (wave == 0) { // exclusive prefix over <= 294 entries: five consecutive entries per lane, then a wavefront scan
+    constexpr int PL = (14 * 21 + 63) / 64;
+    int           v[PL], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+      const int c = lane * PL + j;
+      v[j]        = c < nchunks ? cnt[c] : 0;
+      sum += v[j];
     }
-    off += n;
+    int incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int acc = incl - sum;
+#pragma unroll
+    for (int j = 0; j < PL; j++) {
+      const int c = lane * PL + j;
+      if (c < nchunks) cnt[c] = acc;
+      acc += v[j];
+    }
+  }
+  __syncthreads();
+  uint32_t* o = idx_out + (size_t)sf * max_re;
+  for (int sym = (g.lstart < 7 ? g.lstart : 7); sym < 14; sym++) {
+    for (int kc = wave; kc < cps; kc += nwaves) {
+      const bool               u = used(sym, kc);
+      const unsigned long long b = __ballot(u);
+      if (u) o[cnt[sym * cps + kc] + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)(sym * nre + kc * 64 + lane);
+    }
   }
 }
-
-// Gold sequence c(n) = x1(n + 1600) ^ x2(n + 1600) (36.211 7.2, sequence.c:48-79) as a linear function of c_init: row 0 of `basis` is the x1
-// part (packed, 32 bits per word), row 1 + j the x2 sequence of c_init = 1 << j. One thread per output word:
-// scr[sf][w] = row0[w] ^ XOR over the set bits j of c_init of row(1 + j)[w], c_init = rnti * 2^14 + sf_idx * 2^9 + cell id (pdsch.c:469).
 __global__ __launch_bounds__(256) void scr_gen_kernel(const GrantDev* __restrict__ gr, const uint32_t* __restrict__ basis, uint32_t* __restrict__ out,
                                                       int words, int cell_id)
 {
@@ -844,14 +941,19 @@ int upload(T** d, const std::vector<T>& h)
 struct GrantsState {
   srslte_hip_tdec_t* tdec;       // any block length up to 6144
   uint32_t           Cmax, stride, max_re, max_bits, words;
-  uint32_t *         d_relist, *d_scr, *d_basis, *d_rev, *d_cb_iters;
+  uint32_t *         d_relist, *d_scr, *d_basis, *d_cb_iters;
   int16_t *          d_e, *d_w;
   uint8_t *          d_cb_bytes, *d_cb_ok, *d_desc;
   float*             d_csi;     // [B][max_re], cfg.csi_enable
   uint32_t*          d_csi_max; // [B]
   size_t             desc_bytes;
-  std::vector<uint8_t>                                 h_desc;
+  // descriptors of a call are built in one of four pinned host buffers and copied asynchronously: the host does not wait for the stream
+  uint8_t*   h_pin[4];
+  hipEvent_t h_ev[4];
+  bool       h_used[4];
+  uint32_t   h_slot;
   std::map<std::pair<uint32_t, uint32_t>, uint32_t*>   rm_tbl; // (K, rv) -> slot table in the layout of that K's decoder
+  std::map<uint32_t, uint32_t*>                        crc_fac; // tbs -> tb_crc_bytes_kernel's 256 chunk weights
 };
 
 struct srslte_hip_dl_rx {
@@ -900,11 +1002,18 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   if (q->gs) {
     GrantsState* g = q->gs;
     srslte_hip_tdec_destroy(g->tdec);
-    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_rev, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc, g->d_csi, g->d_csi_max};
+    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc, g->d_csi, g->d_csi_max};
     for (void* b : gb) {
       if (b) (void)hipFree(b);
     }
     for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
+    for (auto& kv : g->crc_fac) (void)hipFree(kv.second);
+    for (int i = 0; i < 4; i++) {
+      if (g->h_pin[i]) { // its event was created just before it
+        (void)hipHostFree(g->h_pin[i]);
+        (void)hipEventDestroy(g->h_ev[i]);
+      }
+    }
     delete g;
   }
   delete q;
@@ -1306,10 +1415,15 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   g->max_bits = (g->max_re * 8 + 15) & ~15u;       // 256QAM
   g->words    = (g->max_re * 8 + 31) / 32 + 2;     // + the spare word the demapper reads
   g->tdec     = srslte_hip_tdec_create(6144, B * g->Cmax);
-  g->d_relist = g->d_scr = g->d_basis = g->d_rev = g->d_cb_iters = nullptr;
+  g->d_relist = g->d_scr = g->d_basis = g->d_cb_iters = nullptr;
   g->d_e = g->d_w = nullptr;
   g->d_cb_bytes = g->d_cb_ok = g->d_desc = nullptr;
   g->d_csi = nullptr; g->d_csi_max = nullptr;
+  g->h_slot = 0;
+  for (int i = 0; i < 4; i++) {
+    g->h_pin[i]  = nullptr;
+    g->h_used[i] = false;
+  }
   q->gs = g;
   if (!g->tdec) return SRSLTE_ERROR;
   // Gold-sequence basis (sequence.c:48-79): all 31 x2 basis sequences advance together, bit j of the state word = basis j
@@ -1333,19 +1447,12 @@ static int grants_init(srslte_hip_dl_rx_t* q)
     }
     if (upload(&g->d_basis, basis)) return SRSLTE_ERROR;
   }
-  { // x^i mod g_CRC24A, i = 0 .. cfg.tbs + 23: the TB check of any transport block size reads it backwards
-    std::vector<uint32_t> rev(q->cfg.tbs + 24);
-    uint32_t              v = 1;
-    for (uint32_t i = 0; i < rev.size(); i++) {
-      rev[i] = v;
-      v <<= 1;
-      if (v & 0x1000000) v ^= 0x1864CFB;
-    }
-    if (upload(&g->d_rev, rev)) return SRSLTE_ERROR;
-  }
   const size_t nblk = (size_t)B * g->Cmax;
   g->desc_bytes     = sizeof(GrantDev) * B + sizeof(SfDesc) * B + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk;
-  g->h_desc.resize(g->desc_bytes);
+  for (int i = 0; i < 4; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
+  }
   HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * B));
   HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * B));
   HIP_TRY(hipMalloc((void**)&g->d_e, sizeof(int16_t) * ((size_t)g->max_bits * B + 16)));
@@ -1384,6 +1491,37 @@ static int grants_rm_table(GrantsState* g, uint32_t K, uint32_t rv, uint32_t W, 
   return SRSLTE_SUCCESS;
 }
 
+// weights of tb_crc_bytes_kernel for a transport block of tbs bits: w[t] = x^(8 cB (255 - t)) mod g_CRC24A
+static int grants_crc_factors(GrantsState* g, uint32_t tbs, const uint32_t** d_fac)
+{
+  auto it = g->crc_fac.find(tbs);
+  if (it == g->crc_fac.end()) {
+    const uint32_t poly = 0x1864CFBu, nbytes = tbs / 8 + 3, cB = (nbytes + 255) / 256;
+    auto           mul  = [&](uint32_t a, uint32_t b) {
+      uint32_t r = 0;
+      for (int i = 23; i >= 0; i--) {
+        r <<= 1;
+        if (r & 0x1000000u) r ^= poly;
+        if ((b >> i) & 1) r ^= a;
+      }
+      return r;
+    };
+    uint32_t m = 1; // x^(8 cB) mod g
+    for (uint32_t i = 0; i < 8 * cB; i++) {
+      m <<= 1;
+      if (m & 0x1000000u) m ^= poly;
+    }
+    std::vector<uint32_t> w(256);
+    w[255] = 1;
+    for (int t = 254; t >= 0; t--) w[t] = mul(w[t + 1], m);
+    uint32_t* d = nullptr;
+    if (upload(&d, w)) return SRSLTE_ERROR;
+    it = g->crc_fac.emplace(tbs, d).first;
+  }
+  *d_fac = it->second;
+  return SRSLTE_SUCCESS;
+}
+
 extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
@@ -1398,7 +1536,9 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   hipStream_t    st = (hipStream_t)stream;
   const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id, B = q->cfg.max_batch;
   const size_t   nblk = (size_t)B * g->Cmax;
-  auto*          h_gr = reinterpret_cast<GrantDev*>(g->h_desc.data());
+  const uint32_t hs = g->h_slot++ & 3u;
+  if (g->h_used[hs]) HIP_TRY(hipEventSynchronize(g->h_ev[hs])); // the copy that last read this buffer (four calls ago) has completed
+  auto*          h_gr = reinterpret_cast<GrantDev*>(g->h_pin[hs]);
   auto*          h_sf = reinterpret_cast<SfDesc*>(h_gr + B);
   auto*          h_cb = reinterpret_cast<CbDesc*>(h_sf + B);
   auto*          h_map = reinterpret_cast<uint32_t*>(h_cb + nblk);
@@ -1476,6 +1616,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     sd.nof_re = (int)nre; sd.mod = gr.mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)gr.tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
+    if (grants_crc_factors(g, gr.tbs, &sd.crc_fac)) return SRSLTE_ERROR;
     const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
     const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
     const uint32_t* tbl = nullptr;
@@ -1505,9 +1646,11 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   int r = srslte_hip_dl_rx_stage(q, 0, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
   if (!r) r = srslte_hip_dl_rx_stage(q, 1, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
   if (r) return r;
-  // the descriptors: pageable source, so the copy has left the host buffer when the call returns and the buffer may be refilled
-  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_desc.data(), g->desc_bytes, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re,
+  // the descriptors
+  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_pin[hs], g->desc_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(g->h_ev[hs], st));
+  g->h_used[hs] = true;
+  hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(RELIST_THREADS), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re,
                      q->pg.nof_ports);
   hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis, g->d_scr,
                      (int)g->words, (int)cell_id);
@@ -1577,8 +1720,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   TbGeom tg;
   memset(&tg, 0, sizeof(tg));
   tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride;
-  hipLaunchKernelGGL(tb_crc_kernel, dim3(nof_sf), dim3(512), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, (const uint32_t*)g->d_rev, d_tb,
-                     d_tb_ok, tg);
+  hipLaunchKernelGGL(tb_crc_bytes_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, d_tb, d_tb_ok, tg);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
@@ -2159,56 +2301,6 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
 // ====================================================================================================================
 namespace {
 
-__device__ __forceinline__ uint32_t gf24_mul(uint32_t a, uint32_t b, uint32_t poly)
-{ // a(x) b(x) mod g(x), deg g = 24 (poly carries the x^24 term)
-  uint32_t r = 0;
-  for (int i = 23; i >= 0; i--) {
-    r <<= 1;
-    if (r & 0x1000000u) r ^= poly;
-    if ((b >> i) & 1) r ^= a;
-  }
-  return r;
-}
-
-// CRC24 (init 0, MSB first) of nbytes bytes by a 256-thread block: the message is zero-extended at the FRONT to 256 equal chunks
-// (leading zeros do not change the remainder), every thread runs the byte-table recursion over its chunk, and the chunk
-// remainders are folded pairwise with x^(8*chunk*2^level) mod g. tab/red: 256 words of LDS each. Result valid in every thread.
-template <typename Byte>
-__device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_t* tab, uint32_t* red)
-{
-  const int t = threadIdx.x;
-  {
-    uint32_t v = (uint32_t)t << 16;
-    for (int i = 0; i < 8; i++) {
-      v <<= 1;
-      if (v & 0x1000000u) v ^= poly;
-    }
-    tab[t] = v;
-  }
-  __syncthreads();
-  const int cB = (nbytes + 255) / 256, pad = 256 * cB - nbytes;
-  uint32_t  crc = 0;
-  for (int i = 0; i < cB; i++) {
-    const int v = t * cB + i - pad;
-    if (v >= 0) crc = ((crc << 8) & 0xffffffu) ^ tab[((crc >> 16) & 0xff) ^ byte_at(v)];
-  }
-  uint32_t m = 1; // x^(8 cB) mod g
-  for (int i = 0; i < 8 * cB; i++) {
-    m <<= 1;
-    if (m & 0x1000000u) m ^= poly;
-  }
-  red[t] = crc;
-  __syncthreads();
-  for (int s = 1; s < 256; s <<= 1) {
-    uint32_t v = 0;
-    if ((t & (2 * s - 1)) == 0) v = gf24_mul(red[t], m, poly) ^ red[t + s];
-    __syncthreads();
-    if ((t & (2 * s - 1)) == 0) red[t] = v;
-    m = gf24_mul(m, m, poly);
-    __syncthreads();
-  }
-  return red[0];
-}
 
 struct PuschTxGeom {
   int   cell_nre, M_sc, n_prb, n_prb1, Qm, tti0, scr_words, C, K, tbs, rlenB, cb_stride, par_stride, tb_stride, rm_len, syms_lo, C_lo;
