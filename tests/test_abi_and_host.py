@@ -121,3 +121,35 @@ def test_round_additions_reject_bad_arguments_without_gpu():
     base = (1, 25, 0x1234, 2, 4008, 10, 5, 0, 4, pkg.DmrsPuschCfg(0, 0, 0, 0), 0)
     for uci in ((1, 15, 0, 0), (3, 0, 0, 0), (0, 0, 1, 13), (0, 0, 3, 0)):
         assert lib.srslte_hip_ul_tx_create(C.byref(pkg.UlTxCfg(*base, *uci))) is None
+
+
+def test_round2_additions_reject_bad_arguments_without_gpu():
+    """Entry points added in round 2 (per-subframe grants, two-layer modes, CQI reports, hopping): -2 / NULL on missing handles and pointers,
+    and configurations the reference refuses are refused at creation, all before anything touches a device."""
+    import ctypes as C
+    pkg = importlib.import_module("srslte-emane_amd")
+    lib = pkg.lib()
+    vp, u32 = C.c_void_p, C.c_uint32
+    lib.srslte_hip_dl_rx_batch_grants.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp]
+    assert lib.srslte_hip_dl_rx_batch_grants(None, None, 0, 1, None, None, 0, None, None) == -2
+    lib.srslte_hip_dl_rx_batch_harq2.argtypes = [vp, vp, u32, u32, vp, vp, vp, u32, vp, vp]
+    assert lib.srslte_hip_dl_rx_batch_harq2(None, None, 0, 1, None, None, None, 0, None, None) == -2
+    lib.srslte_hip_ul_tx_batch_uci_cqi.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, vp, vp]
+    assert lib.srslte_hip_ul_tx_batch_uci_cqi(None, None, 0, None, None, None, 0, 1, None, None) == -2
+    lib.srslte_hip_ul_rx_cqi.restype, lib.srslte_hip_ul_rx_cqi.argtypes = vp, [vp]
+    assert lib.srslte_hip_ul_rx_cqi(None) is None
+    lib.srslte_hip_chest_ul_estimate_pusch_batch_hop.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, vp, C.c_int, vp]
+    assert lib.srslte_hip_chest_ul_estimate_pusch_batch_hop(None, 0, 1, 0, 0, 0, None, None, None, 1, None) == -2
+    lib.srslte_hip_dl_rx_create.restype = vp
+    ok2 = dict(nof_rx=2, nof_ports=2)
+    for kw in (dict(tx_scheme=3, mod2=2, tbs2=4008, nof_rx=1, nof_ports=2), dict(tx_scheme=3, tbs2=0, **ok2), dict(tx_scheme=2, pmi=2, mod2=2, tbs2=4008, **ok2),
+               dict(tx_scheme=2, pmi=4, **ok2), dict(tx_scheme=5, mod2=2, tbs2=4008, **ok2), dict(tx_scheme=3, mod2=7, tbs2=4008, **ok2)):
+        cfg = pkg.DlRxCfg(7, 25, 1, 0x1234, 2, 4008, 6, 2, 1, pkg.ChestDlCfg(), 0, kw.get("nof_rx", 1), kw.get("nof_ports", 1), 0, 0, 0.0, kw.get("tx_scheme", 0),
+                          kw.get("pmi", 0), kw.get("mod2", 0), kw.get("tbs2", 0))
+        assert lib.srslte_hip_dl_rx_create(C.byref(cfg)) is None, kw
+    lib.srslte_hip_ul_rx_create.restype = vp
+    lib.srslte_hip_ul_tx_create.restype = vp
+    dm = pkg.DmrsPuschCfg(0, 0, 0, 0)
+    for tail in ((4, 0, 0, 0), (4, 16, 0, 0), (65, 5, 0, 0), (0, 0, 1, 20)):  # cqi_len, I_offset_cqi, hopping, n_prb_slot1 (20 + 10 PRB > 25)
+        assert lib.srslte_hip_ul_tx_create(C.byref(pkg.UlTxCfg(1, 25, 0x1234, 2, 4008, 10, 5, 0, 4, dm, 0, 0, 0, 0, 0, *tail))) is None, tail
+        assert lib.srslte_hip_ul_rx_create(C.byref(pkg.UlRxCfg(1, 25, 0x1234, 2, 4008, 10, 5, 0, 6, 4, 1, dm, 0, 0, 0, 0, 0, *tail))) is None, tail
