@@ -84,7 +84,7 @@ def main():
             else:  # a failed block's bytes follow the LLRs bit for bit; ours differ from the CPU's by 1 LSB on <= 0.1 % (float stages upstream)
                 failed_same += int(eq)
         cpu_dt = time.perf_counter() - tc
-        print(json.dumps({"workload": "cfg5: 100 PRB %s TBS %d (%d x K=%d), batch %d" % ({2: "16QAM", 3: "64QAM", 4: "256QAM"}[args.mod], args.tbs, C_, cfg.seg.K1, B),
+        print(json.dumps({"workload": "100 PRB %s TBS %d (%d x K=%d), batch %d" % ({2: "16QAM", 3: "64QAM", 4: "256QAM"}[args.mod], args.tbs, C_, cfg.seg.K1, B),
                           "llr": "i8" if args.llr8 else "i16", "snr_db": snr, "gpu_bler": round(1 - float(np.mean(ok)), 4),
                           "gpu_undetected_errors": undetected, "avg_siso_passes_per_cb": round(float(iters.mean()), 3),
                           "gpu_subframes_per_s": round(gpu_sfps, 1), "cpu_kind": "reference" if have_ref else "port", "cpu_subframes": n_cpu,
