@@ -718,11 +718,12 @@ __global__ __launch_bounds__(512) void tb_crc_kernel(const uint8_t* __restrict__
 
 // The same for transport blocks of any size (grants mode): the bytes go through LDS, 256 threads take the CRC24A of contiguous chunks with a
 // byte table, and the chunk CRCs are combined with 256 weights x^(8 n) mod g that the host makes once per transport block size.
+constexpr int TB_MAX_BITS = 105528;
 __global__ __launch_bounds__(256) void tb_crc_bytes_kernel(const uint8_t* __restrict__ cb_bytes, const uint8_t* __restrict__ cb_ok, uint8_t* __restrict__ tb,
                                                            uint8_t* __restrict__ tb_ok, TbGeom g)
 {
   __shared__ uint32_t tab[256], red[4];
-  __shared__ uint8_t  bytes[97896 / 8 + 8]; // the largest transport block (256QAM, 100 PRB) + CRC
+  __shared__ uint8_t  bytes[TB_MAX_BITS / 8 + 8]; // the largest one-layer transport block (36.213 Table 7.1.7.2.1-1: 105528 bits at 110 PRB) + CRC
   const SfDesc d  = g.desc[blockIdx.x];
   const int    sf = blockIdx.x, C = d.C, K = d.K, nbytes = d.tbs / 8 + 3, rb = d.rlen / 8, t = threadIdx.x;
   uint8_t*     dst = tb + (size_t)sf * g.tb_stride;
@@ -1562,7 +1563,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     sd.scr = g->d_scr + (size_t)b * g->words;
     if (gr.tbs == 0) continue; // no transport block in this subframe: C = 0, tb_ok = 0
     srslte_hip_cbsegm_t seg;
-    if (gr.mod < 1 || gr.mod > 4 || gr.cfi < 1 || gr.cfi > 3 || gr.rv > 3 || gr.tbs > q->cfg.tbs || (gr.tbs % 8) || srslte_hip_cbsegm(&seg, gr.tbs) || seg.F ||
+    if (gr.mod < 1 || gr.mod > 4 || gr.cfi < 1 || gr.cfi > 3 || gr.rv > 3 || gr.tbs > q->cfg.tbs || gr.tbs > (uint32_t)TB_MAX_BITS || (gr.tbs % 8) || srslte_hip_cbsegm(&seg, gr.tbs) || seg.F ||
         seg.C2 || seg.C > g->Cmax) {
       hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported grant (mod %d, tbs %u, cfi %u, rv %u)\n", b, gr.mod, gr.tbs, gr.cfi, gr.rv);
       return SRSLTE_ERROR_INVALID_INPUTS;
