@@ -266,6 +266,22 @@ typedef struct {
 } srslte_hip_dl_grant_t;
 int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
                                   uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+/* The same with the transmission scheme of each subframe's grant and a second transport block (srslte_pdsch_grant_t.tx_scheme / pmi / tb[1],
+ * as srslte_ra_dl_dci_to_grant fills them from DCI formats 1 / 1A / 2 / 2A, ra_dl.c:530-600): on a 2-port cell received with 2 antennas
+ * (cfg.nof_ports = cfg.nof_rx_antennas = 2, cfg.tx_scheme = 0) a batch may mix transmit diversity (tx_scheme 0 or 1), large-delay CDD
+ * (SRSLTE_TXSCHEME_CDD 3: two transport blocks) and closed-loop multiplexing (SRSLTE_TXSCHEME_SPATIALMUX 2: two blocks with pmi 0-1, or one
+ * with pmi 0-3). Then d_tb / d_tb_ok have 2 * nof_sf rows: row b = transport block 0 of subframe b, row nof_sf + b = transport block 1
+ * (tb_ok 0 where there is none); HARQ slot of block 1: its own. On other cells tx_scheme must be 0 / 1 and the rows are nof_sf. */
+typedef struct {
+  srslte_hip_dl_grant_t tb0; /* allocation, CFI, RNTI and transport block 0 */
+  int      tx_scheme;         /* srslte_tx_scheme_t */
+  uint32_t pmi;               /* srslte_pdsch_grant_t.pmi */
+  int      mod2;              /* transport block 1: modulation, size (0: none), redundancy version, new-data flag */
+  uint32_t tbs2, rv2;
+  int      new_data2;
+} srslte_hip_dl_grant2_t;
+int srslte_hip_dl_rx_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
+                                   uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,

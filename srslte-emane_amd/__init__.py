@@ -447,6 +447,11 @@ class ChestUl:
             self.h = None
 
 
+class DlGrant2(C.Structure):
+    """srslte_hip_dl_grant2_t: a grant with its transmission scheme, pmi and second transport block."""
+    _fields_ = [("tb0", DlGrant), ("tx_scheme", C.c_int), ("pmi", C.c_uint32), ("mod2", C.c_int), ("tbs2", C.c_uint32), ("rv2", C.c_uint32), ("new_data2", C.c_int)]
+
+
 class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
@@ -520,6 +525,24 @@ class DlRx:
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return rc, tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def decode_grants2(self, iq, tti0, grants):
+        """srslte_hip_dl_rx_batch_grants2: subframe b with grants[b] (DlGrant2: scheme, pmi and a second transport block per subframe).
+        Returns (rc, [tb0 rows, tb1 rows], [ok0, ok1]); on a cell without two-layer grants the second entries are None."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * self.sf_len)
+        n = x.shape[0]
+        assert len(grants) == n
+        two = self.cfg.nof_ports == 2 and self.cfg.nof_rx_antennas == 2
+        arr = (DlGrant2 * n)(*grants)
+        din, dtb, dok = DevBuf.from_host(x), DevBuf(self.tb_stride * n * 2), DevBuf(2 * n)
+        L = lib()
+        L.srslte_hip_dl_rx_batch_grants2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        rc = L.srslte_hip_dl_rx_batch_grants2(self.h, din.ptr, tti0, n, arr, dtb.ptr, self.tb_stride, dok.ptr, None)
+        if rc != SRSLTE_SUCCESS:
+            return rc, None, None
+        sync()
+        tb, ok = dtb.to_host(np.uint8).reshape(2 * n, self.tb_stride), dok.to_host(np.uint8)
+        return rc, [tb[:n], tb[n:] if two else None], [ok[:n], ok[n:2 * n] if two else None]
 
     def decode_harq(self, iq, tti0, rv, new_data):
         """srslte_hip_dl_rx_batch_harq: slot b keeps its soft buffers / CRC flags / bytes between calls."""

@@ -46,6 +46,8 @@ struct SfDesc {
   int             nof_re, mod, Qm;
   int             C, K, tbs, rlen; // segmentation of its transport block (36.212 5.1.2): C blocks of K bits, rlen payload bits per block
   const uint32_t* crc_fac;         // [256] x^(8 cB (255 - t)) mod g_CRC24A, cB = ceil((tbs / 8 + 3) / 256): tb_crc_bytes_kernel's chunk weights
+  int             scheme, codebook, nof_tb; // srslte_tx_scheme_t of the subframe's grant (0 / 1: the cell's single-port or diversity mode; 2, 3: two-layer
+                                            // modes), pre-decoder codebook index, transport blocks; codeword 1 has its own entry max_batch further on
 };
 struct CbDesc {
   int             sf, cb;  // subframe of the batch, code block of its transport block
@@ -53,10 +55,12 @@ struct CbDesc {
   int             combine; // 0: new data, the soft buffer is overwritten; 1: retransmission, added (and skipped if the block's CRC passed)
   int             w_len;   // soft-buffer slots of this block length (multiple of 32) = stride of its slot table
   const uint32_t* tbl;     // slot table of (K, rv)
+  int             Nl;      // the block split counts in units of Qm * Nl bits: 2 for transmit diversity, else 1 (sch.c:507-531)
 };
 struct GrantDev { // what the list / sequence kernels need of a grant
   uint32_t mask[2][4]; // prb_idx[s][n] as bits
   int      sf_idx, lstart, q_off, rnti;
+  int      cw;         // codeword of the scrambling sequence (36.211 6.3.1: q << 13 in c_init)
 };
 
 struct PdschGeom {
@@ -72,6 +76,7 @@ struct PdschGeom {
   const uint32_t* scr1;
   float*          csi1;
   uint32_t*       csi_max1;
+  int             cw1_off; // grants mode: codeword 1 of subframe sf is described by desc[cw1_off + sf]
 };
 
 // the subframe's largest csi: wavefront maximum, one atomic per wavefront
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_kernel(const cf32* __restrict
   const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
   if (g.desc) {
     const SfDesc d = g.desc[sf];
+    if (d.scheme >= 2) return; // a two-layer grant: pdsch_demod_mimo_kernel's
     c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
   }
   const int     base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_div_kernel(const cf32* __rest
   int             mod = g.mod, Qm = g.Qm; // locals: writing to the by-value argument would move it to scratch
   if (g.desc) { // per-subframe grants
     const SfDesc d = g.desc[sf];
+    if (d.scheme >= 2) return; // a two-layer grant: pdsch_demod_mimo_kernel's
     c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
   }
   const int     base = blockIdx.x * 512, i0 = base + 2 * threadIdx.x; // nof_re is even for a 2-port cell
@@ -234,6 +241,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_div4_kernel(const cf32* __res
   int             mod = g.mod, Qm = g.Qm; // locals: writing to the by-value argument would move it to scratch
   if (g.desc) { // per-subframe grants
     const SfDesc d = g.desc[sf];
+    if (d.scheme >= 2) return;
     c.idx = d.idx; c.nof_re = d.nof_re; mod = d.mod; Qm = d.Qm; cs = d.scr;
   }
   const int     base = blockIdx.x * 1024, i0 = base + 4 * threadIdx.x; // nof_re is a multiple of 4 for a 4-port cell
@@ -307,8 +315,18 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
                                                                LLR* __restrict__ e_out1, PdschGeom g)
 {
   __shared__ __attribute__((aligned(16))) LLR stage[2][256 * 8];
-  const int     sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
-  const SfClass c  = g.cls[sf_class(sf_idx)];
+  const int       sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10;
+  SfClass         c  = g.cls[sf_class(sf_idx)];
+  int             tx_scheme = g.tx_scheme, codebook_idx = g.codebook_idx, nof_tb = g.nof_tb, mods[2] = {g.mod, g.mod1}, Qms[2] = {g.Qm, g.Qm1};
+  const uint32_t* css[2] = {scr + (size_t)sf_idx * g.scr_words, g.scr1 ? g.scr1 + (size_t)sf_idx * g.scr_words1 : nullptr};
+  if (g.desc) { // per-subframe grants: this subframe's own scheme, allocation, modulations and sequences
+    const SfDesc d0 = g.desc[sf];
+    if (d0.scheme < 2) return; // single antenna port or transmit diversity: the other kernels'
+    const SfDesc d1 = g.desc[g.cw1_off + sf];
+    c.idx = d0.idx; c.nof_re = d0.nof_re; tx_scheme = d0.scheme; codebook_idx = d0.codebook; nof_tb = d0.nof_tb;
+    mods[0] = d0.mod; Qms[0] = d0.Qm; css[0] = d0.scr;
+    mods[1] = d1.mod; Qms[1] = d1.Qm; css[1] = d1.scr;
+  }
   const int     base = blockIdx.x * blockDim.x, i = base + threadIdx.x;
   if (base >= c.nof_re) return;
   const bool     live = i < c.nof_re;
@@ -322,9 +340,9 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
   const float    scaling = 1.0f / g.inv_scaling;
   cf32           x[2];
   float          csi[2];
-  if (g.nof_tb == 1) { // one layer: the codebook column applied to the ports, maximum-ratio combining over the antennas
+  if (nof_tb == 1) { // one layer: the codebook column applied to the ports, maximum-ratio combining over the antennas
     cf32 h0, h1;
-    switch (g.codebook_idx) {
+    switch (codebook_idx) {
       case 0: h0 = cadd(p0a0, p1a0); h1 = cadd(p0a1, p1a1); break;
       case 1: h0 = csub(p0a0, p1a0); h1 = csub(p0a1, p1a1); break;
       case 2: h0 = cadd(p0a0, cmulj(p1a0)); h1 = cadd(p0a1, cmulj(p1a1)); break;
@@ -340,16 +358,16 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
   } else {
     cf32  h00, h01, h10, h11; // effective channel: h[antenna][layer]
     float norm = 2.0f / scaling;
-    if (g.tx_scheme == 3) { // H W U D(i): the sign of the second port alternates with the symbol index
+    if (tx_scheme == 3) { // H W U D(i): the sign of the second port alternates with the symbol index
       if (!(ii & 1)) {
         h00 = cadd(p0a0, p1a0); h10 = cadd(p0a1, p1a1); h01 = csub(p0a0, p1a0); h11 = csub(p0a1, p1a1);
       } else {
         h00 = csub(p0a0, p1a0); h10 = csub(p0a1, p1a1); h01 = cadd(p0a0, p1a0); h11 = cadd(p0a1, p1a1);
       }
-    } else if (g.codebook_idx == 0) {
+    } else if (codebook_idx == 0) {
       h00 = p0a0; h01 = p1a0; h10 = p0a1; h11 = p1a1;
       norm = 1.41421356f / scaling;
-    } else if (g.codebook_idx == 1) {
+    } else if (codebook_idx == 1) {
       h00 = cadd(p0a0, p1a0); h01 = csub(p0a0, p1a0); h10 = cadd(p0a1, p1a1); h11 = csub(p0a1, p1a1);
     } else {
       h00 = cadd(p0a0, cmulj(p1a0)); h01 = csub(p0a0, cmulj(p1a0)); h10 = cadd(p0a1, cmulj(p1a1)); h11 = csub(p0a1, cmulj(p1a1));
@@ -372,8 +390,8 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
   }
 #pragma unroll
   for (int cw = 0; cw < 2; cw++) {
-    if (cw >= g.nof_tb) break;
-    const int       mod = cw ? g.mod1 : g.mod, Qm = cw ? g.Qm1 : g.Qm;
+    if (cw >= nof_tb) break;
+    const int       mod = mods[cw], Qm = Qms[cw];
     float*          csi_o = cw ? g.csi1 : g.csi;
     cf32*           d_out = cw ? d_out1 : d_out0;
     if (csi_o) {
@@ -387,7 +405,7 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
     } else {
       demod_dev::demod_s(mod, x[cw], i, c.nof_re, o);
     }
-    const uint32_t* cs   = cw ? g.scr1 + (size_t)sf_idx * g.scr_words1 : scr + (size_t)sf_idx * g.scr_words;
+    const uint32_t* cs   = css[cw];
     const int       bit0 = (live ? i : 0) * Qm;
     const uint32_t  c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
     for (int j = 0; j < Qm; j++) stage[cw][threadIdx.x * Qm + j] = ((c2 >> j) & 1) ? (LLR)-o[j] : o[j];
@@ -395,8 +413,8 @@ __global__ __launch_bounds__(256) void pdsch_demod_mimo_kernel(const cf32* __res
   __syncthreads();
 #pragma unroll
   for (int cw = 0; cw < 2; cw++) {
-    if (cw >= g.nof_tb) break;
-    const int   Qm = cw ? g.Qm1 : g.Qm, nbytes = min(256, c.nof_re - base) * Qm * (int)sizeof(LLR);
+    if (cw >= nof_tb) break;
+    const int   Qm = Qms[cw], nbytes = min(256, c.nof_re - base) * Qm * (int)sizeof(LLR);
     char*       dst = reinterpret_cast<char*>((cw ? e_out1 : e_out0) + (size_t)sf * (cw ? g.max_bits1 : g.max_bits) + (size_t)base * Qm);
     const char* src = reinterpret_cast<const char*>(stage[cw]);
     for (int o16 = threadIdx.x * 16; o16 + 16 <= nbytes; o16 += 256 * 16) *reinterpret_cast<uint4*>(dst + o16) = *reinterpret_cast<const uint4*>(src + o16);
@@ -490,16 +508,17 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   constexpr int PER = 4 / (int)sizeof(LLR); // slots per dword
   // the block: memory slot cbg = sf * g.C + cb; in grants mode its own (C, K, Qm, nof_re, table) come from the descriptor
   int             cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
-  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)];
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl;
   const uint32_t* tbl = inv;
   if (g.cbd) {
     const CbDesc d = g.cbd[blockIdx.y];
     sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
+    Nl = d.Nl;
   }
   const int j = PER * (blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= w_len || (g.skip && combine && g.skip[cbg])) return;
   if (g.cb_ok_rst && !combine && j == 0) g.cb_ok_rst[cbg] = 0;
-  const int QmL = Qm * g.Nl, Gp = nre / g.Nl; // Gp = nof_bits / (Qm N_L)
+  const int QmL = Qm * Nl, Gp = nre / Nl; // Gp = nof_bits / (Qm N_L)
   const int gamma = Gp % C, n_e = QmL * (Gp / C);
   int       rp = cb * n_e, n_e2 = n_e;
   if (cb > C - gamma) { // sch.c:331-334 (the '>' quirk is upstream's)
@@ -541,15 +560,16 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   constexpr int PER = 16 / (int)sizeof(LLR), NV = PER / 8; // slots per 16 bytes; uint4 loads of 16-bit table entries per step
   LLR*          seg = reinterpret_cast<LLR*>(seg_raw);
   int             cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
-  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)];
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl;
   const uint32_t* tbl = inv;
   if (g.cbd) {
     const CbDesc d = g.cbd[blockIdx.x];
     sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
+    Nl = d.Nl;
   }
   if (g.skip && combine && g.skip[cbg]) return;
   if (g.cb_ok_rst && !combine && threadIdx.x == 0) g.cb_ok_rst[cbg] = 0;
-  const int QmL = Qm * g.Nl, Gp = nre / g.Nl;
+  const int QmL = Qm * Nl, Gp = nre / Nl;
   const int gamma = Gp % C, n_e = QmL * (Gp / C);
   int       rp = cb * n_e, n_e2 = n_e;
   if (cb > C - gamma) { // sch.c:331-334
@@ -669,6 +689,7 @@ __device__ uint32_t block_crc24(Byte byte_at, int nbytes, uint32_t poly, uint32_
 struct TbGeom {
   const SfDesc* desc; // grants mode (tb_crc_bytes_kernel): per-subframe (C, K, tbs, rlen), C = code-block slots per subframe; else null
   int C, K, tbs, rlen, cb_stride, tb_stride;
+  int nof_sf, cw1_off; // grants mode: subframes of the call, descriptor offset of their second transport blocks
 };
 
 // one workgroup per subframe: assemble the payload (sch.c:360,:401-410) and check CRC24A (sch.c:470-488).
@@ -724,11 +745,13 @@ __global__ __launch_bounds__(256) void tb_crc_bytes_kernel(const uint8_t* __rest
 {
   __shared__ uint32_t tab[256], red[4];
   __shared__ uint8_t  bytes[TB_MAX_BITS / 8 + 8]; // the largest one-layer transport block (36.213 Table 7.1.7.2.1-1: 105528 bits at 110 PRB) + CRC
-  const SfDesc d  = g.desc[blockIdx.x];
-  const int    sf = blockIdx.x, C = d.C, K = d.K, nbytes = d.tbs / 8 + 3, rb = d.rlen / 8, t = threadIdx.x;
-  uint8_t*     dst = tb + (size_t)sf * g.tb_stride;
-  if (C == 0) { // no transport block in this subframe
-    if (t == 0) tb_ok[sf] = 0;
+  // row r < nof_sf: transport block 0 of subframe r (descriptor / HARQ slot r); row nof_sf + b: transport block 1 of subframe b (slot cw1_off + b)
+  const int    row = blockIdx.x, sf = row < g.nof_sf ? row : g.cw1_off + row - g.nof_sf;
+  const SfDesc d   = g.desc[sf];
+  const int    C = d.C, K = d.K, nbytes = d.tbs / 8 + 3, rb = d.rlen / 8, t = threadIdx.x;
+  uint8_t*     dst = tb + (size_t)row * g.tb_stride;
+  if (C == 0) { // no transport block here
+    if (t == 0) tb_ok[row] = 0;
     return;
   }
   {
@@ -764,7 +787,7 @@ __global__ __launch_bounds__(256) void tb_crc_bytes_kernel(const uint8_t* __rest
     bool ok = (red[0] ^ red[1] ^ red[2] ^ red[3]) == 0;
     for (int c = 0; c < C; c++) ok = ok && cb_ok[sf * g.C + c];
     ok        = ok && (bytes[nbytes - 3] | bytes[nbytes - 2] | bytes[nbytes - 1]); // par_rx != 0 (sch.c:481)
-    tb_ok[sf] = ok ? 1 : 0;
+    tb_ok[row] = ok ? 1 : 0;
   }
 }
 
@@ -852,7 +875,7 @@ __global__ __launch_bounds__(256) void scr_gen_kernel(const GrantDev* __restrict
   const int sf = blockIdx.y, w = blockIdx.x * 256 + threadIdx.x;
   if (w >= words) return;
   const GrantDev g = gr[sf];
-  uint32_t       c_init = ((uint32_t)g.rnti << 14) + ((uint32_t)g.sf_idx << 9) + (uint32_t)cell_id, v = basis[w];
+  uint32_t       c_init = ((uint32_t)g.rnti << 14) + ((uint32_t)g.cw << 13) + ((uint32_t)g.sf_idx << 9) + (uint32_t)cell_id, v = basis[w];
   for (int j = 0; j < 31; j++) {
     if ((c_init >> j) & 1u) v ^= basis[(size_t)(1 + j) * words + w];
   }
@@ -942,6 +965,7 @@ int upload(T** d, const std::vector<T>& h)
 struct GrantsState {
   srslte_hip_tdec_t* tdec;       // any block length up to 6144
   uint32_t           Cmax, stride, max_re, max_bits, words;
+  uint32_t           V; // per-subframe slots: max_batch, twice that on a cell where two-layer grants can occur (codeword 1 of subframe b: slot max_batch + b)
   uint32_t *         d_relist, *d_scr, *d_basis, *d_cb_iters;
   int16_t *          d_e, *d_w;
   uint8_t *          d_cb_bytes, *d_cb_ok, *d_desc;
@@ -1415,7 +1439,8 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   g->max_re   = 14 * 12 * P;                       // upper bound of any allocation
   g->max_bits = (g->max_re * 8 + 15) & ~15u;       // 256QAM
   g->words    = (g->max_re * 8 + 31) / 32 + 2;     // + the spare word the demapper reads
-  g->tdec     = srslte_hip_tdec_create(6144, B * g->Cmax);
+  g->V        = (q->pg.nof_ports == 2 && q->pg.nof_rx == 2) ? 2 * B : B;
+  g->tdec     = srslte_hip_tdec_create(6144, g->V * g->Cmax);
   g->d_relist = g->d_scr = g->d_basis = g->d_cb_iters = nullptr;
   g->d_e = g->d_w = nullptr;
   g->d_cb_bytes = g->d_cb_ok = g->d_desc = nullptr;
@@ -1448,23 +1473,23 @@ static int grants_init(srslte_hip_dl_rx_t* q)
     }
     if (upload(&g->d_basis, basis)) return SRSLTE_ERROR;
   }
-  const size_t nblk = (size_t)B * g->Cmax;
-  g->desc_bytes     = sizeof(GrantDev) * B + sizeof(SfDesc) * B + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk;
+  const size_t nblk = (size_t)g->V * g->Cmax;
+  g->desc_bytes     = sizeof(GrantDev) * g->V + sizeof(SfDesc) * g->V + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk;
   for (int i = 0; i < 4; i++) {
     HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
   }
   HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * B));
-  HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * B));
-  HIP_TRY(hipMalloc((void**)&g->d_e, sizeof(int16_t) * ((size_t)g->max_bits * B + 16)));
+  HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * g->V));
+  HIP_TRY(hipMalloc((void**)&g->d_e, sizeof(int16_t) * ((size_t)g->max_bits * g->V + 16)));
   HIP_TRY(hipMalloc((void**)&g->d_w, sizeof(int16_t) * (size_t)g->stride * nblk));
   HIP_TRY(hipMalloc((void**)&g->d_cb_bytes, (size_t)768 * nblk));
   HIP_TRY(hipMalloc((void**)&g->d_cb_ok, nblk));
   HIP_TRY(hipMalloc((void**)&g->d_cb_iters, sizeof(uint32_t) * nblk));
   HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
   if (q->cfg.csi_enable) {
-    HIP_TRY(hipMalloc((void**)&g->d_csi, sizeof(float) * (size_t)g->max_re * B));
-    HIP_TRY(hipMalloc((void**)&g->d_csi_max, sizeof(uint32_t) * B));
+    HIP_TRY(hipMalloc((void**)&g->d_csi, sizeof(float) * (size_t)g->max_re * g->V));
+    HIP_TRY(hipMalloc((void**)&g->d_csi_max, sizeof(uint32_t) * g->V));
   }
   // HARQ state of slots that have not seen new data yet: nothing decoded, empty soft buffers
   HIP_TRY(hipMemset(g->d_cb_ok, 0, nblk));
@@ -1523,64 +1548,135 @@ static int grants_crc_factors(GrantsState* g, uint32_t tbs, const uint32_t** d_f
   return SRSLTE_SUCCESS;
 }
 
+static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants, uint8_t* d_tb,
+                      uint32_t tb_stride, uint8_t* d_tb_ok, void* stream, bool second_rows);
+
 extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
+  if (!q || !grants || nof_sf > q->cfg.max_batch) return SRSLTE_ERROR_INVALID_INPUTS;
+  std::vector<srslte_hip_dl_grant2_t> g2(nof_sf);
+  for (uint32_t b = 0; b < nof_sf; b++) {
+    memset(&g2[b], 0, sizeof(g2[b]));
+    g2[b].tb0 = grants[b];
+  }
+  return grants_run(q, d_iq, tti0, nof_sf, g2.data(), d_tb, tb_stride, d_tb_ok, stream, false);
+}
+
+// The same with the transmission scheme per subframe and a second transport block: on a 2-port cell received with 2 antennas a grant can be
+// transmit diversity (tx_scheme 0 / 1: DCI 1 / 1A), large-delay CDD (3, two transport blocks) or closed-loop multiplexing (2, two blocks
+// with pmi 0-1 or one with pmi 0-3), as srslte_ra_dl_dci_to_grant makes them (ra_dl.c:530-600). Codeword 1 of subframe b is a second
+// per-subframe slot (descriptor, LLR row, CSI row, HARQ soft buffers) max_batch further on; its transport block is row nof_sf + b of d_tb.
+extern "C" int srslte_hip_dl_rx_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
+                                              uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  return grants_run(q, d_iq, tti0, nof_sf, grants, d_tb, tb_stride, d_tb_ok, stream, true);
+}
+
+// second_rows: rows nof_sf .. 2 nof_sf - 1 of d_tb / d_tb_ok exist (srslte_hip_dl_rx_batch_grants2 on a cell where two-layer grants can occur)
+static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants, uint8_t* d_tb,
+                      uint32_t tb_stride, uint8_t* d_tb_ok, void* stream, bool second_rows)
+{
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
   if (q->cfg.tx_scheme) {
-    hip_log("[srslte_hip] dl_rx grants mode: single antenna port or transmit diversity\n");
+    hip_log("[srslte_hip] dl_rx grants mode: create the object without a fixed two-layer scheme; the grants carry it\n");
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   if (!q->gs && grants_init(q)) return SRSLTE_ERROR;
   GrantsState*   g  = q->gs;
   hipStream_t    st = (hipStream_t)stream;
-  const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id, B = q->cfg.max_batch;
-  const size_t   nblk = (size_t)B * g->Cmax;
+  const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id, B = q->cfg.max_batch, V = g->V;
+  const int      npt = q->pg.nof_ports;
+  const size_t   nblk = (size_t)V * g->Cmax;
   const uint32_t hs = g->h_slot++ & 3u;
   if (g->h_used[hs]) HIP_TRY(hipEventSynchronize(g->h_ev[hs])); // the copy that last read this buffer (four calls ago) has completed
   auto*          h_gr = reinterpret_cast<GrantDev*>(g->h_pin[hs]);
-  auto*          h_sf = reinterpret_cast<SfDesc*>(h_gr + B);
-  auto*          h_cb = reinterpret_cast<CbDesc*>(h_sf + B);
+  auto*          h_sf = reinterpret_cast<SfDesc*>(h_gr + V);
+  auto*          h_cb = reinterpret_cast<CbDesc*>(h_sf + V);
   auto*          h_map = reinterpret_cast<uint32_t*>(h_cb + nblk);
   auto*          d_gr = reinterpret_cast<GrantDev*>(g->d_desc);
-  auto*          d_sf = reinterpret_cast<SfDesc*>(d_gr + B);
-  auto*          d_cb = reinterpret_cast<CbDesc*>(d_sf + B);
+  auto*          d_sf = reinterpret_cast<SfDesc*>(d_gr + V);
+  auto*          d_cb = reinterpret_cast<CbDesc*>(d_sf + V);
   auto*          d_map = reinterpret_cast<uint32_t*>(d_cb + nblk);
   struct Group { uint32_t K, single; std::vector<uint32_t> slots; };
   std::vector<Group> groups;
   const bool         l8 = q->cfg.llr_8bit != 0; // the 8-bit LLR path the applications select (pdsch.c:760-779, sch.c:336-356): same buffers, as bytes
   uint32_t           ncb = 0, max_seg = 0;
+  bool               any_mimo = false;
+  // one transport block into per-subframe slot v: descriptor, code-block descriptors, decoder group
+  auto add_tb = [&](uint32_t b, uint32_t v, int mod, uint32_t tbs, uint32_t rv, int new_data, uint32_t nre, uint32_t Nl) -> int {
+    SfDesc& sd = h_sf[v];
+    srslte_hip_cbsegm_t seg;
+    if (mod < 1 || mod > 4 || rv > 3 || tbs > q->cfg.tbs || tbs > (uint32_t)TB_MAX_BITS || (tbs % 8) || srslte_hip_cbsegm(&seg, tbs) || seg.F || seg.C2 ||
+        seg.C > g->Cmax) {
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported transport block (mod %d, tbs %u, rv %u)\n", b, mod, tbs, rv);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    const uint32_t Qm = 2 * (uint32_t)mod, K = seg.K1, C = seg.C;
+    if (nre == 0 || nre < C * Nl) {
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    sd.nof_re = (int)nre; sd.mod = mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
+    if (grants_crc_factors(g, tbs, &sd.crc_fac)) return SRSLTE_ERROR;
+    const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
+    const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
+    const uint32_t* tbl = nullptr;
+    if (grants_rm_table(g, K, rv, W, w_len, &tbl)) return SRSLTE_ERROR;
+    Group* grp = nullptr;
+    for (auto& x : groups) {
+      if (x.K == K && x.single == (C == 1 ? tbs : 0)) grp = &x;
+    }
+    if (!grp) {
+      groups.push_back(Group{K, C == 1 ? tbs : 0, {}});
+      grp = &groups.back();
+    }
+    for (uint32_t c = 0; c < C; c++) {
+      CbDesc& cd = h_cb[ncb++];
+      cd.sf = (int)v; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = new_data ? 0 : 1;
+      cd.w_len = (int)w_len; cd.tbl = tbl; cd.Nl = (int)Nl;
+      grp->slots.push_back(v * g->Cmax + c);
+    }
+    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
+    max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
+    return SRSLTE_SUCCESS;
+  };
   for (uint32_t b = 0; b < nof_sf; b++) {
-    const srslte_hip_dl_grant_t& gr = grants[b];
-    GrantDev&                    gd = h_gr[b];
-    SfDesc&                      sd = h_sf[b];
+    const srslte_hip_dl_grant2_t& g2 = grants[b];
+    const srslte_hip_dl_grant_t&  gr = g2.tb0;
+    GrantDev&                     gd = h_gr[b];
+    SfDesc&                       sd = h_sf[b];
     memset(&gd, 0, sizeof(gd));
     memset(&sd, 0, sizeof(sd));
+    if (V > B) {
+      memset(&h_gr[B + b], 0, sizeof(gd));
+      memset(&h_sf[B + b], 0, sizeof(sd));
+    }
     const uint32_t sf_idx = (tti0 + b) % 10, lstart = gr.cfi + (P < 10 ? 1 : 0);
     gd.sf_idx = (int)sf_idx; gd.lstart = (int)lstart; gd.rnti = gr.rnti;
     sd.idx = g->d_relist + (size_t)b * g->max_re;
     sd.scr = g->d_scr + (size_t)b * g->words;
     if (gr.tbs == 0) continue; // no transport block in this subframe: C = 0, tb_ok = 0
-    srslte_hip_cbsegm_t seg;
-    if (gr.mod < 1 || gr.mod > 4 || gr.cfi < 1 || gr.cfi > 3 || gr.rv > 3 || gr.tbs > q->cfg.tbs || gr.tbs > (uint32_t)TB_MAX_BITS || (gr.tbs % 8) || srslte_hip_cbsegm(&seg, gr.tbs) || seg.F ||
-        seg.C2 || seg.C > g->Cmax) {
-      hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported grant (mod %d, tbs %u, cfi %u, rv %u)\n", b, gr.mod, gr.tbs, gr.cfi, gr.rv);
+    const bool two_layer = g2.tx_scheme >= 2;
+    if (gr.cfi < 1 || gr.cfi > 3 || g2.tx_scheme < 0 || g2.tx_scheme > 3 ||
+        (two_layer && (V == B || (g2.tx_scheme == 3 && g2.tbs2 == 0) || (g2.tbs2 ? g2.pmi > 1 : g2.pmi > 3))) || (!two_layer && g2.tbs2)) {
+      hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported grant (cfi %u, tx_scheme %d, pmi %u, second transport block %u bits)\n", b, gr.cfi, g2.tx_scheme,
+              g2.pmi, g2.tbs2);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     bool any0 = false, below1 = false;
     for (uint32_t n = 0; n < P; n++) {
-      for (int s = 0; s < 2; s++) {
-        if ((gr.prb_mask[s][n >> 5] >> (n & 31)) & 1u) {
-          gd.mask[s][n >> 5] |= 1u << (n & 31);
-          if (s == 0) any0 = true;
-          if (s == 1 && n + 3 < P / 2) below1 = true;
+      for (int s_ = 0; s_ < 2; s_++) {
+        if ((gr.prb_mask[s_][n >> 5] >> (n & 31)) & 1u) {
+          gd.mask[s_][n >> 5] |= 1u << (n & 31);
+          if (s_ == 0) any0 = true;
+          if (s_ == 1 && n + 3 < P / 2) below1 = true;
         }
       }
     }
     // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them;
     // with 2 / 4 ports every CRS symbol sets the same value
-    const int npt = q->pg.nof_ports;
     bool any1_whole = false; // any whole (non-centre) PRB of slot 1: by symbol 1 its symbol-0 row has set `offset` too
     for (uint32_t n = 0; n < P; n++) {
       if (((gr.prb_mask[1][n >> 5] >> (n & 31)) & 1u) && !(n >= P / 2 - 3 && n < P / 2 + 3 + (P % 2))) any1_whole = true;
@@ -1588,7 +1684,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     gd.q_off = npt == 1 ? (below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0))
                         : (((below1 || any0) ? (int)(cell_id % 3) : 0) | (((below1 || any0 || any1_whole) ? (int)(cell_id % 3) : 0) << 8));
     // number of PDSCH REs (what pdsch_relist_kernel will list; srslte_ra_dl_grant_nof_re): per symbol, whole PRBs carry 12 REs (10 with
-    // CRS), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half there 6 (5 with CRS)
+    // CRS, 8 on a multi-port cell), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half
+    // there half of that
     auto pop = [](const uint32_t* m, const uint32_t* f) {
       return __builtin_popcount(m[0] & f[0]) + __builtin_popcount(m[1] & f[1]) + __builtin_popcount(m[2] & f[2]) + __builtin_popcount(m[3] & f[3]);
     };
@@ -1600,44 +1697,30 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     }
     uint32_t nre = 0;
     for (int sym = 0; sym < 14; sym++) {
-      const int s = sym / 7, l = sym % 7;
-      if (s == 0 && l < (int)lstart) continue;
-      const bool ref = l == 0 || l == 4 || (l == 1 && npt == 4), sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s == 1 && sf_idx == 0 && l < 4);
+      const int s_ = sym / 7, l = sym % 7;
+      if (s_ == 0 && l < (int)lstart) continue;
+      const bool ref = l == 0 || l == 4 || (l == 1 && npt == 4), sync = (s_ == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s_ == 1 && sf_idx == 0 && l < 4);
       const int  per = ref ? (npt == 1 ? 10 : 8) : 12;
-      nre += per * pop(gd.mask[s], all);
-      if (sync) nre += (per / 2) * pop(gd.mask[s], half) - per * pop(gd.mask[s], centre);
+      nre += per * pop(gd.mask[s_], all);
+      if (sync) nre += (per / 2) * pop(gd.mask[s_], half) - per * pop(gd.mask[s_], centre);
     }
-    const uint32_t Qm = 2 * (uint32_t)gr.mod, K = seg.K1, C = seg.C;
-    if (nre % (uint32_t)npt) { // the transmit-diversity pre-decoders take the REs in groups of nof_ports (precoding.c:564-650)
+    if (!two_layer && (nre % (uint32_t)npt)) { // the transmit-diversity pre-decoders take the REs in groups of nof_ports (precoding.c:564-650)
       hip_log("[srslte_hip] dl_rx grants: subframe %u: %u REs are not a multiple of the %d ports\n", b, nre, npt);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
-    if (nre == 0 || nre * Qm < C * Qm) {
-      hip_log("[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
-      return SRSLTE_ERROR_INVALID_INPUTS;
+    // nof_layers == nof_tb for the two-layer modes: N_L = 1; transmit diversity: 2 (srslte_dlsch_decode2, sch.c:507-531)
+    if (int r = add_tb(b, b, gr.mod, gr.tbs, gr.rv, gr.new_data, nre, (!two_layer && npt > 1) ? 2 : 1)) return r;
+    sd.scheme = g2.tx_scheme; sd.nof_tb = g2.tbs2 ? 2 : 1; sd.codebook = (int)(g2.tbs2 ? g2.pmi + 1 : g2.pmi); // pdsch.c:914
+    if (two_layer) any_mimo = true;
+    if (g2.tbs2) { // codeword 1: slot max_batch + b, the same REs, its own sequence (q = 1), modulation, transport block
+      GrantDev& gd1 = h_gr[B + b];
+      SfDesc&   sd1 = h_sf[B + b];
+      gd1 = gd; gd1.cw = 1;
+      sd1.idx = sd.idx;
+      sd1.scr = g->d_scr + (size_t)(B + b) * g->words;
+      if (int r = add_tb(b, B + b, g2.mod2, g2.tbs2, g2.rv2, g2.new_data2, nre, 1)) return r;
+      sd1.scheme = g2.tx_scheme; sd1.nof_tb = 2; sd1.codebook = sd.codebook;
     }
-    sd.nof_re = (int)nre; sd.mod = gr.mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)gr.tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
-    if (grants_crc_factors(g, gr.tbs, &sd.crc_fac)) return SRSLTE_ERROR;
-    const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
-    const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
-    const uint32_t* tbl = nullptr;
-    if (grants_rm_table(g, K, gr.rv, W, w_len, &tbl)) return SRSLTE_ERROR;
-    Group* grp = nullptr;
-    for (auto& x : groups) {
-      if (x.K == K && x.single == (C == 1 ? gr.tbs : 0)) grp = &x;
-    }
-    if (!grp) {
-      groups.push_back(Group{K, C == 1 ? gr.tbs : 0, {}});
-      grp = &groups.back();
-    }
-    for (uint32_t c = 0; c < C; c++) {
-      CbDesc& cd = h_cb[ncb++];
-      cd.sf = (int)b; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = gr.new_data ? 0 : 1;
-      cd.w_len = (int)w_len; cd.tbl = tbl;
-      grp->slots.push_back(b * g->Cmax + c);
-    }
-    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
-    max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
   }
   uint32_t nmap = 0;
   for (auto& x : groups) {
@@ -1651,15 +1734,20 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_pin[hs], g->desc_bytes, hipMemcpyHostToDevice, st));
   HIP_TRY(hipEventRecord(g->h_ev[hs], st));
   g->h_used[hs] = true;
+  const uint32_t nrows = (second_rows && V > B) ? 2 * nof_sf : nof_sf; // transport-block rows of the call
   hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_sf), dim3(RELIST_THREADS), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id, (int)g->max_re,
                      q->pg.nof_ports);
   hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_sf), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis, g->d_scr,
                      (int)g->words, (int)cell_id);
+  if (any_mimo) { // the sequences of the second codewords
+    hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_sf), dim3(256), 0, st, (const GrantDev*)(d_gr + B), (const uint32_t*)g->d_basis,
+                       g->d_scr + (size_t)B * g->words, (int)g->words, (int)cell_id);
+  }
   LAUNCH_CHECK();
   {
     PdschGeom pg = q->pg;
     pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = g->d_csi; pg.csi_max = g->d_csi_max;
-    if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * nof_sf, st));
+    if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * V, st));
     const cf32* grid = q->d_grid;
     if (pg.nof_ports == 4) {
       if (l8) {
@@ -1677,6 +1765,20 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
         hipLaunchKernelGGL(pdsch_demod_div_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 512), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                            (const uint32_t*)g->d_scr, (cf32*)nullptr, g->d_e, pg);
       }
+      if (any_mimo) { // the two-layer subframes (the kernels above skipped them); codeword 1's rows sit max_batch further on in every buffer
+        pg.cw1_off  = (int)B;
+        pg.max_bits1 = pg.max_bits;
+        pg.csi1     = g->d_csi ? g->d_csi + (size_t)B * g->max_re : nullptr;
+        pg.csi_max1 = g->d_csi_max ? g->d_csi_max + B : nullptr;
+        if (l8) {
+          hipLaunchKernelGGL(pdsch_demod_mimo_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, (cf32*)nullptr, (int8_t*)g->d_e,
+                             (int8_t*)g->d_e + (size_t)B * g->max_bits, pg);
+        } else {
+          hipLaunchKernelGGL(pdsch_demod_mimo_kernel<int16_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
+                             (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, (cf32*)nullptr, g->d_e, g->d_e + (size_t)B * g->max_bits, pg);
+        }
+      }
     } else if (l8) {
       hipLaunchKernelGGL(pdsch_demod_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 256), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
                          (const ChestResDev*)q->d_res, (const uint32_t*)g->d_scr, (cf32*)nullptr, (int8_t*)g->d_e, pg);
@@ -1690,7 +1792,7 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
     RmGeom rg;
     memset(&rg, 0, sizeof(rg));
     rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
-    rg.Nl = q->pg.nof_ports > 1 ? 2 : 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
+    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
     const int lds = (int)((max_seg + 15) & ~15u);
     if (l8 && lds <= 64 * 1024) {
       hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(ncb), dim3(256), lds, st, (const int8_t*)g->d_e, (int8_t*)g->d_w, (const uint32_t*)nullptr, rg);
@@ -1720,8 +1822,8 @@ extern "C" int srslte_hip_dl_rx_batch_grants(srslte_hip_dl_rx_t* q, const void* 
   }
   TbGeom tg;
   memset(&tg, 0, sizeof(tg));
-  tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride;
-  hipLaunchKernelGGL(tb_crc_bytes_kernel, dim3(nof_sf), dim3(256), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, d_tb, d_tb_ok, tg);
+  tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride; tg.nof_sf = (int)nof_sf; tg.cw1_off = (int)B;
+  hipLaunchKernelGGL(tb_crc_bytes_kernel, dim3(nrows), dim3(256), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, d_tb, d_tb_ok, tg);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }

@@ -511,8 +511,8 @@ class RefPdsch:
         # srslte_tx_scheme_t (phy_common.h:232-237): PORT0, DIVERSITY, SPATIALMUX, CDD
         u32(L["srslte_pdsch_grant_t.tx_scheme"], {"cdd": 3, "mux": 2}[cfg.tx_scheme] if cfg.tx_scheme else (1 if cfg.nof_ports > 1 else 0))
         u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
-        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
-        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
+        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1 if cfg.prb_mask is None else cfg.prb_mask
+        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb if cfg.prb_mask is None else int(cfg.prb_mask[0].sum()))
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
         u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)
@@ -640,8 +640,8 @@ class RefPdschTx:
             g[off:off + 4].view(np.uint32)[0] = v
         u32(L["srslte_pdsch_grant_t.tx_scheme"], {"cdd": 3, "mux": 2}[cfg.tx_scheme] if cfg.tx_scheme else (1 if cfg.nof_ports > 1 else 0))
         u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
-        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
-        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
+        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1 if cfg.prb_mask is None else cfg.prb_mask
+        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb if cfg.prb_mask is None else int(cfg.prb_mask[0].sum()))
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
         u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
         u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)

@@ -181,3 +181,83 @@ def test_dl_rx_two_layer_config_errors(hp):
             hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **bad)
     rx = hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **ok)
     rx.free()
+
+
+# ------------------------------------------------------------------ a TTI stream that mixes the schemes (srslte_hip_dl_rx_batch_grants2)
+def _mask(P, rng, how, n):
+    m = np.zeros((2, P), np.uint8)
+    if how == "all":
+        m[:] = 1
+    elif how == "centre":
+        m[:, P // 2 - 3:P // 2 - 3 + n] = 1
+    elif how == "slots":
+        m[0, rng.choice(P, n, replace=False)] = 1
+        m[1, rng.choice(P, n, replace=False)] = 1
+    else:
+        m[:, rng.choice(P, n, replace=False)] = 1
+    return m
+
+
+# (kind, allocation, n PRB, mod, tbs, mod2, tbs2, pmi, cfi, snr); kind: div = transmit diversity, cdd, mux (two blocks) or mux1 (one block)
+MIXED = {
+    25: [("cdd", "all", 25, 2, 4008, 2, 4008, 0, 1, 14.0), ("div", "random", 10, 1, 1000, 0, 0, 0, 1, 6.0), ("mux", "centre", 7, 1, 328, 1, 504, 1, 2, 9.0),
+         ("mux1", "slots", 12, 2, 2216, 0, 0, 2, 1, 12.0), ("cdd", "random", 9, 1, 1000, 2, 2216, 0, 3, 16.0), ("div", "all", 25, 2, 6200, 0, 0, 0, 1, 10.0),
+         ("mux", "all", 25, 3, 6200, 2, 4008, 0, 2, 22.0), ("mux1", "centre", 3, 1, 328, 0, 0, 3, 1, 7.0)],
+    50: [("mux", "random", 20, 2, 4008, 3, 6200, 1, 1, 20.0), ("cdd", "all", 50, 3, 21384, 2, 9912, 0, 1, 24.0), ("div", "slots", 16, 2, 2216, 0, 0, 0, 2, 9.0),
+         ("mux1", "all", 50, 2, 9912, 0, 0, 0, 1, 10.0), ("cdd", "centre", 6, 1, 504, 1, 328, 0, 1, 9.0)],
+}
+
+
+@pytest.mark.parametrize("P,cid,tti0,csi", [(25, 150, 0, False), (25, 7, 4, True), (50, 3, 5, True)])
+def test_mixed_two_layer_grants(hp, P, cid, tti0, csi):
+    """srslte_hip_dl_rx_batch_grants2 on a 2-port cell with 2 receive antennas: consecutive subframes carry transmit diversity, large-delay
+    CDD and closed-loop multiplexing grants (one or two transport blocks, different allocations - sync-region-only ones on the odd
+    bandwidth included -, modulations, pmi, CFI, RNTI). Every transport block against the oracle chain of its own mode; LLRs of both
+    codewords; the second blocks' rows; subframes without a second block report tb_ok = 0 there."""
+    from lte_sim import DlConfig, make_subframe, make_subframe_mimo, oracle_rx, oracle_rx_mimo
+    rng = np.random.default_rng(40 * P + tti0)
+    items = []
+    for b, (kind, how, n, mod, tbs, mod2, tbs2, pmi, cfi, snr) in enumerate(MIXED[P]):
+        mask, rnti = _mask(P, rng, how, n), 0x200 + 3 * b
+        kw = dict(cfi=cfi, rnti=rnti, nof_rx=2, nof_ports=2, csi=csi, prb_mask=mask)
+        if kind == "div":
+            cfg = DlConfig(P, cid, mod, tbs, **kw)
+            iq, data = make_subframe(cfg, tti0 + b, rng, snr_db=snr - 2.0, amp=0.2)
+            data = [data]
+        else:
+            cfg = DlConfig(P, cid, mod, tbs, tx_scheme="cdd" if kind == "cdd" else "mux", pmi=pmi, mod2=mod2 or None, tbs2=tbs2, **kw)
+            iq, data = make_subframe_mimo(cfg, tti0 + b, rng, snr_db=snr - 2.0, amp=0.2)
+        g = hp.DlGrant2(hp.DlGrant.make(P, mod, tbs, rnti, cfi=cfi, prb_mask=mask), {"div": 1, "cdd": 3, "mux": 2, "mux1": 2}[kind], pmi, mod2, tbs2, 0, 1)
+        items.append((kind, cfg, iq, data, g))
+    n = len(items)
+    tbs_max = max(max(c.tbss) if c.tx_scheme else c.tbs for _, c, _, _, _ in items)
+    rx = hp.DlRx(cid, P, 1, 0, 1, tbs_max, 6, n, True, _chest(hp), nof_rx=2, nof_ports=2, csi=csi)
+    rc, tb, ok = rx.decode_grants2(np.stack([it[2] for it in items]), tti0, [it[4] for it in items])
+    assert rc == 0
+    max_bits = 16 * ((14 * 12 * P * 8 + 15) // 16)
+    e = rx.debug(11, np.int16, 2 * n * max_bits).reshape(2 * n, -1)  # rows b: codeword 0; rows max_batch + b: codeword 1
+    nok = 0
+    for b, (kind, cfg, iq, data, g) in enumerate(items):
+        if kind == "div":
+            r = oracle_rx(cfg, iq, tti0 + b, keep=True)
+            res = [(r["e_raw"], r["ok"], r["tb"], cfg.tbs)]
+        else:
+            r = oracle_rx_mimo(cfg, iq, tti0 + b, keep=True)
+            res = [(r["e_raw"][cw], r["ok"][cw], r["tb"][cw], cfg.tbss[cw]) for cw in range(cfg.nof_tb)]
+        for cw, (e_o, ok_o, tb_o, tbs_) in enumerate(res):
+            row = b if cw == 0 else n + b
+            diff = np.abs(e[row, :len(e_o)].astype(int) - e_o.astype(int))
+            assert diff.max() <= 1 + np.abs(e_o).max() // 2000 and (diff > 0).mean() < 3e-3, (b, kind, cw, int(diff.max()))
+            if diff.max() == 0 or ok_o:
+                assert bool(ok[cw][b]) == bool(ok_o), (b, kind, cw)
+            if ok_o:
+                nok += 1
+                assert np.array_equal(tb[cw][b, :tbs_ // 8 + 3], tb_o) and np.array_equal(tb[cw][b, :tbs_ // 8], data[cw]), (b, kind, cw)
+        if len(res) == 1:
+            assert ok[1][b] == 0, (b, kind)
+    assert nok >= sum(len(it[3]) for it in items) - 3
+    # the plain entry point on the same object writes nof_sf rows only (guard values behind them stay)
+    div = [it for it in items if it[0] == "div"]
+    rc, tb1, ok1 = rx.decode_grants(np.stack([it[2] for it in div]), tti0, [it[4].tb0 for it in div])
+    assert rc == 0
+    rx.free()

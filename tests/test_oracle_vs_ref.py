@@ -1387,6 +1387,42 @@ def test_pdsch_two_layer_modes_vs_reference(prb, cid, mod, tbs, mod2, tbs2, sche
         assert np.array_equal(r["tb"][cw], rr["tb"][cw]) and np.array_equal(r["tb"][cw][:len(data[cw])], data[cw]), cw
 
 
+@pytest.mark.parametrize("prb,cid,scheme,pmi,mod,tbs,mod2,tbs2,how,n,cfi,tti,snr", [
+    (25, 150, "cdd", 0, 1, 1000, 2, 2216, "random", 9, 3, 4, 18.0), (25, 7, "mux", 1, 1, 328, 1, 504, "centre", 7, 2, 0, 12.0),
+    (25, 7, "mux", 2, 2, 2216, None, 0, "slots", 12, 1, 5, 12.0), (50, 3, "cdd", 0, 1, 504, 1, 328, "centre", 6, 1, 0, 10.0),
+    (15, 33, "mux", 0, 2, 1000, 1, 504, "centre", 5, 1, 5, 16.0)])
+def test_pdsch_two_layer_modes_partial_allocations_vs_reference(prb, cid, scheme, pmi, mod, tbs, mod2, tbs2, how, n, cfi, tti, snr):
+    """The two-layer modes on partial allocations - distributed PRBs, different PRBs per slot, the sync region of subframes 0 / 5 with
+    the half PRBs of an odd bandwidth - through the reference's srslte_pdsch_encode / srslte_pdsch_decode with grant.prb_idx set: same RE
+    order on both sides of the link (srslte_pdsch_cp for a 2-port cell), same transport blocks."""
+    from _libs import ref_sz
+    from lte_sim import DlConfig, RefPdsch, RefPdschTx, make_subframe_mimo, oracle_rx_mimo
+    rng = np.random.default_rng(7 * prb + tti)
+    m = np.zeros((2, prb), np.uint8)
+    if how == "centre":
+        m[:, prb // 2 - 3:prb // 2 - 3 + n] = 1
+    elif how == "slots":
+        m[0, rng.choice(prb, n, replace=False)] = 1
+        m[1, rng.choice(prb, n, replace=False)] = 1
+    else:
+        m[:, rng.choice(prb, n, replace=False)] = 1
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=True, tx_scheme=scheme, pmi=pmi, mod2=mod2, tbs2=tbs2, prb_mask=m)
+    k = {}
+    iq, data = make_subframe_mimo(cfg, tti, rng, snr_db=snr, amp=0.4, keep=k)
+    grids = RefPdschTx(cfg).run_mimo(data, tti)
+    for port in range(2):
+        assert np.abs(grids[port][k["idx"]] - np.float32(np.sqrt(2.0)) * k["y"][port]).max() < 4e-6
+        rest = np.ones(len(grids[port]), bool)
+        rest[k["idx"]] = False
+        assert not grids[port][rest].any()  # nothing outside the oracle's RE list
+    r = oracle_rx_mimo(cfg, iq, tti, keep=True)
+    rr = RefPdsch(cfg, csi_enable=True, lib=ref_sz() if scheme == "cdd" else None).run_mimo(iq, tti)
+    for cw in range(cfg.nof_tb):
+        assert np.abs(r["d"][cw] - rr["d"][cw]).max() <= 1.5e-3 * max(1.0, np.abs(rr["d"][cw]).max()), cw
+        assert r["ok"][cw] == rr["ok"][cw] and r["ok"][cw], cw
+        assert np.array_equal(r["tb"][cw], rr["tb"][cw]) and np.array_equal(r["tb"][cw][:len(data[cw])], data[cw]), cw
+
+
 # ---------------------------------------------------------------- arbitrary PRB allocations (srslte_pdsch_grant_t.prb_idx[s][n], pdsch.c:81-206)
 def _grant_cases():
     """(nof_prb, cell_id, sf_idx, cfi, mcs, how): `how` builds the allocation on the reference's grant."""
