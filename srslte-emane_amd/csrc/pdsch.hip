@@ -829,11 +829,15 @@ __global__ __launch_bounds__(RELIST_THREADS) void pdsch_relist_kernel(const Gran
     if (k >= nre || !((g.mask[s][p >> 5] >> (p & 31)) & 1u)) return false;
     return pdsch_re_used(P, cell_id, g.sf_idx, g.q_off, s, l, k, nof_ports);
   };
+  __shared__ unsigned long long msk[14 * 21]; // the chunks' masks: the second sweep does not evaluate the rule again
   for (int sym = 0; sym < 14; sym++) {
     const bool on = sym >= 7 || sym >= g.lstart; // control region
     for (int kc = wave; kc < cps; kc += nwaves) {
       const unsigned long long b = on ? __ballot(used(sym, kc)) : 0ull;
-      if (lane == 0) cnt[sym * cps + kc] = __popcll(b);
+      if (lane == 0) {
+        cnt[sym * cps + kc] = __popcll(b);
+        msk[sym * cps + kc] = b;
+      }
     }
   }
   __syncthreads();
@@ -863,9 +867,8 @@ __global__ __launch_bounds__(RELIST_THREADS) void pdsch_relist_kernel(const Gran
   uint32_t* o = idx_out + (size_t)sf * max_re;
   for (int sym = (g.lstart < 7 ? g.lstart : 7); sym < 14; sym++) {
     for (int kc = wave; kc < cps; kc += nwaves) {
-      const bool               u = used(sym, kc);
-      const unsigned long long b = __ballot(u);
-      if (u) o[cnt[sym * cps + kc] + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)(sym * nre + kc * 64 + lane);
+      const unsigned long long b = msk[sym * cps + kc];
+      if ((b >> lane) & 1ull) o[cnt[sym * cps + kc] + __popcll(b & ((1ull << lane) - 1ull))] = (uint32_t)(sym * nre + kc * 64 + lane);
     }
   }
 }
