@@ -138,6 +138,7 @@ int  srslte_tc_interl_init(srslte_tc_interl_t* h, uint32_t max_long_cb);
 void srslte_tc_interl_free(srslte_tc_interl_t* h);
 int  srslte_tc_interl_LTE_gen(srslte_tc_interl_t* h, uint32_t long_cb);
 int  srslte_tc_interl_LTE_gen_interl(srslte_tc_interl_t* h, uint32_t long_cb, uint32_t interl_win);
+int  srslte_tc_interl_UMTS_gen(srslte_tc_interl_t* h, uint32_t long_cb); /* tc_interl_umts.c:80-262 (25.212; no caller on the LTE path) */
 
 /* ------------------------------------------------------------------ turbo encoder (turbocoder.h:44-76) */
 typedef struct { uint32_t max_long_cb; uint8_t* temp; } srslte_tcod_t;
@@ -219,6 +220,33 @@ int  srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area
 int  srslte_chest_dl_estimate(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, cf_t* input[SRSLTE_MAX_PORTS], srslte_chest_dl_res_t* res);
 int  srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, srslte_chest_dl_cfg_t* cfg, cf_t* input[SRSLTE_MAX_PORTS],
                                   srslte_chest_dl_res_t* res);
+
+/* ------------------------------------------------------------------ reference-signal and filter helpers (refsignal_dl.h:56-107, chest_common.h:37-48)
+ * Index rules, init-time tables and put / get on HOST grids run on the host; the two array helpers (average_pilots, estimate_noise_pilots)
+ * run on the device like the other single-call wrappers (csrc/compat_refsignal.cpp). */
+int      srslte_refsignal_cs_init(srslte_refsignal_t* q, uint32_t max_prb);
+int      srslte_refsignal_cs_set_cell(srslte_refsignal_t* q, srslte_cell_t cell);
+void     srslte_refsignal_free(srslte_refsignal_t* q);
+int      srslte_refsignal_cs_put_sf(srslte_refsignal_t* q, srslte_dl_sf_cfg_t* sf, uint32_t port_id, cf_t* sf_symbols);
+int      srslte_refsignal_cs_get_sf(srslte_refsignal_t* q, srslte_dl_sf_cfg_t* sf, uint32_t port_id, cf_t* sf_symbols, cf_t* pilots);
+uint32_t srslte_refsignal_cs_fidx(srslte_cell_t cell, uint32_t l, uint32_t port_id, uint32_t m);
+uint32_t srslte_refsignal_cs_nsymbol(uint32_t l, srslte_cp_t cp, uint32_t port_id);
+uint32_t srslte_refsignal_cs_v(uint32_t port_id, uint32_t ref_symbol_idx);
+uint32_t srslte_refsignal_cs_nof_symbols(srslte_refsignal_t* q, srslte_dl_sf_cfg_t* sf, uint32_t port_id);
+uint32_t srslte_refsignal_cs_nof_re(srslte_refsignal_t* q, srslte_dl_sf_cfg_t* sf, uint32_t port_id);
+int      srslte_refsignal_mbsfn_init(srslte_refsignal_t* q, uint32_t max_prb);
+int      srslte_refsignal_mbsfn_set_cell(srslte_refsignal_t* q, srslte_cell_t cell, uint16_t mbsfn_area_id);
+int      srslte_refsignal_mbsfn_get_sf(srslte_cell_t cell, uint32_t port_id, cf_t* sf_symbols, cf_t* pilots);
+uint32_t srslte_refsignal_mbsfn_nsymbol(uint32_t l);
+uint32_t srslte_refsignal_mbsfn_fidx(uint32_t l);
+uint32_t srslte_refsignal_mbsfn_nof_symbols();
+int      srslte_refsignal_mbsfn_put_sf(srslte_cell_t cell, uint32_t port_id, cf_t* cs_pilots, cf_t* mbsfn_pilots, cf_t* sf_symbols);
+int      srslte_refsignal_mbsfn_gen_seq(srslte_refsignal_t* q, srslte_cell_t cell, uint32_t N_mbsfn_id);
+void     srslte_chest_average_pilots(cf_t* input, cf_t* output, float* filter, uint32_t nof_ref, uint32_t nof_symbols, uint32_t filter_len);
+uint32_t srslte_chest_set_smooth_filter3_coeff(float* smooth_filter, float w);
+float    srslte_chest_estimate_noise_pilots(cf_t* noisy, cf_t* noiseless, cf_t* noise_vec, uint32_t nof_pilots);
+uint32_t srslte_chest_set_triangle_filter(float* fil, int filter_len);
+uint32_t srslte_chest_set_smooth_filter_gauss(float* filter, uint32_t order, float std_dev);
 
 /* ------------------------------------------------------------------ soft demapper (demod_soft.h:39-53) */
 int srslte_demod_soft_demodulate(srslte_mod_t modulation, const cf_t* symbols, float* llr, int nsymbols);

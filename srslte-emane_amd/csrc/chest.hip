@@ -1025,3 +1025,53 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch_hop(srslte_hip_chest_ul_
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// chest_common.c's two array helpers as stand-alone launches (the estimator kernels above do the same work inline): the single-call
+// srslte_chest_average_pilots / srslte_chest_estimate_noise_pilots of the compatibility API (compat_refsignal.cpp) run these.
+namespace {
+
+__global__ void __launch_bounds__(CH_THREADS) chest_average_pilots_kernel(const cf32* __restrict__ in, cf32* __restrict__ out,
+                                                                           const float* __restrict__ filt, int nof_ref, int filter_len)
+{ // chest_common.c:95-101: one "same" convolution per symbol row (blockIdx.y)
+  const int   l = blockIdx.y, i = blockIdx.x * CH_THREADS + threadIdx.x;
+  if (i < nof_ref) out[(size_t)l * nof_ref + i] = conv_at(in + (size_t)l * nof_ref, filt, nof_ref, filter_len, i);
+}
+
+__global__ void __launch_bounds__(CH_THREADS) chest_noise_pilots_kernel(const cf32* __restrict__ noisy, const cf32* __restrict__ noiseless,
+                                                                         cf32* __restrict__ noise_vec, int n, float* __restrict__ power)
+{ // chest_common.c:51-60: noise_vec = noiseless - noisy, mean |noise_vec|^2
+  __shared__ float red[CH_THREADS];
+  float            acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += CH_THREADS) {
+    const cf32 d = c_sub(noiseless[i], noisy[i]);
+    noise_vec[i] = d;
+    acc += d.x * d.x + d.y * d.y;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = CH_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *power = red[0] / (float)n;
+}
+
+} // namespace
+
+int chest_average_pilots_launch(const void* d_in, void* d_out, const float* d_filt, int nof_ref, int nof_symbols, int filter_len, hipStream_t st)
+{
+  if (nof_ref <= 0 || nof_symbols <= 0) return SRSLTE_SUCCESS;
+  hipLaunchKernelGGL(chest_average_pilots_kernel, dim3((nof_ref + CH_THREADS - 1) / CH_THREADS, nof_symbols), dim3(CH_THREADS), 0, st,
+                     (const cf32*)d_in, (cf32*)d_out, d_filt, nof_ref, filter_len);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
+int chest_noise_pilots_launch(const void* d_noisy, const void* d_noiseless, void* d_noise_vec, int n, float* d_power, hipStream_t st)
+{
+  hipLaunchKernelGGL(chest_noise_pilots_kernel, dim3(1), dim3(CH_THREADS), 0, st, (const cf32*)d_noisy, (const cf32*)d_noiseless,
+                     (cf32*)d_noise_vec, n, d_power);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}

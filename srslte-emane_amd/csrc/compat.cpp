@@ -821,7 +821,8 @@ int srslte_chest_dl_init(srslte_chest_dl_t* q, uint32_t max_prb, uint32_t nof_rx
   if (!q || nof_rx_antennas == 0 || nof_rx_antennas > SRSLTE_MAX_PORTS || max_prb > SRSLTE_MAX_PRB) return SRSLTE_ERROR_INVALID_INPUTS;
   memset(q, 0, sizeof(*q));
   q->nof_rx_antennas = nof_rx_antennas;
-  q->tmp_noise       = (cf_t*)new ChestState(); // opaque slot for the device state
+  if (srslte_refsignal_cs_init(&q->csr_refs, max_prb)) return SRSLTE_ERROR; // the host copy callers read (chest_dl.c:88, chest_test_dl.c:154)
+  q->tmp_noise = (cf_t*)new ChestState(); // opaque slot for the device state
   return SRSLTE_SUCCESS;
 }
 
@@ -832,16 +833,13 @@ static void chest_drop_cell(srslte_chest_dl_t* q)
     srslte_hip_chest_dl_destroy(st->h);
     st->h = nullptr;
   }
-  for (int sf = 0; sf < SRSLTE_NOF_SF_X_FRAME; sf++) {
-    free(q->csr_refs.pilots[0][sf]);
-    q->csr_refs.pilots[0][sf] = nullptr;
-  }
 }
 
 void srslte_chest_dl_free(srslte_chest_dl_t* q)
 { // chest_dl.c:162-191
   if (!q) return;
   chest_drop_cell(q);
+  srslte_refsignal_free(&q->csr_refs);
   auto* st = (ChestState*)q->tmp_noise;
   if (st) {
     st->grid.release();
@@ -860,17 +858,12 @@ int srslte_chest_dl_set_cell(srslte_chest_dl_t* q, srslte_cell_t cell)
   auto* st = (ChestState*)q->tmp_noise;
   st->h    = srslte_hip_chest_dl_create(cell.id, cell.nof_prb, cell.nof_ports, cell.cp == SRSLTE_CP_NORM);
   if (!st->h) return SRSLTE_ERROR;
-  q->cell          = cell;
-  q->csr_refs.cell = cell;
-  // host copy of the CRS values for callers that use srslte_refsignal_cs_put_sf(&q->csr_refs, ...) (chest_test_dl.c:154)
-  const size_t npil = (size_t)4 * 2 * cell.nof_prb;
-  for (int sf = 0; sf < SRSLTE_NOF_SF_X_FRAME; sf++) {
-    q->csr_refs.pilots[0][sf] = (cf_t*)host_alloc(sizeof(cf_t) * npil);
-    if (!q->csr_refs.pilots[0][sf] ||
-        !d2h(q->csr_refs.pilots[0][sf], (const char*)srslte_hip_chest_dl_pilots(st->h) + sizeof(cf_t) * npil * sf, sizeof(cf_t) * npil))
-      return SRSLTE_ERROR;
-  }
-  return SRSLTE_SUCCESS;
+  q->cell = cell;
+  // host copy of the CRS values for callers that use srslte_refsignal_cs_put_sf(&q->csr_refs, ...) (chest_test_dl.c:154); the device
+  // object was rebuilt, so is this (upstream's table would survive a change of width alone, refsignal_dl.c:77)
+  srslte_refsignal_free(&q->csr_refs);
+  if (srslte_refsignal_cs_init(&q->csr_refs, cell.nof_prb)) return SRSLTE_ERROR;
+  return srslte_refsignal_cs_set_cell(&q->csr_refs, cell) ? SRSLTE_ERROR : SRSLTE_SUCCESS;
 }
 
 int srslte_chest_dl_set_mbsfn_area_id(srslte_chest_dl_t* q, uint16_t mbsfn_area_id)

@@ -30,6 +30,9 @@ void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); /
 
 // chest.hip: device DMRS table of a PUSCH grant, [10][2][12 * L_prb] cf32 (owned by q)
 int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r);
+// chest.hip: chest_common.c's stand-alone array helpers on device buffers (filter_len <= nof_ref, nof_ref >= 2 as the extrapolation reads in[0..1])
+int chest_average_pilots_launch(const void* d_in, void* d_out, const float* d_filt, int nof_ref, int nof_symbols, int filter_len, hipStream_t st);
+int chest_noise_pilots_launch(const void* d_noisy, const void* d_noiseless, void* d_noise_vec, int n, float* d_power, hipStream_t st);
 // chest.hip: the noise estimates [port][antenna] the PSS / EMPTY algorithms keep between calls (q->noise_estimate of the reference)
 int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise);
 // tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).

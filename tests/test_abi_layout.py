@@ -56,3 +56,21 @@ def test_struct_layouts_match_reference():
     ours = layout(["srslte_hip/srslte_compat.h"], [os.path.join(ROOT, "include")])
     diff = {k: (ref[k], ours.get(k)) for k in ref if ref[k] != ours.get(k)}
     assert not diff, "layout differences (reference, ours): %s" % diff
+
+
+def test_every_prototype_of_the_boundary_headers_is_exported():
+    """'every SRSLTE_API prototype' of the eleven headers the boundary names - all of them, by name, in the product library
+    (plus srslte_tc_interl_UMTS_gen, which row a6 cites and no header declares)."""
+    import ctypes
+    import re
+    from _libs import HIP_SO
+    heads = ["dft/dft", "dft/ofdm", "dft/dft_precoding", "fec/turbocoder", "fec/turbodecoder", "fec/tc_interl", "fec/cbsegm",
+             "ch_estimation/chest_dl", "ch_estimation/chest_common", "ch_estimation/refsignal_dl", "modem/demod_soft"]
+    names = set()
+    for h in heads:
+        src = re.sub(r"/\*.*?\*/|//[^\n]*", "", open(os.path.join(REF_INC, "srslte/phy", h + ".h")).read(), flags=re.S)
+        names.update(re.findall(r"SRSLTE_API\s+[^;{(]*?\b(srslte_[A-Za-z0-9_]+)\s*\(", src))
+    assert len(names) >= 100, len(names)
+    lib = ctypes.CDLL(HIP_SO)
+    missing = sorted(n for n in names | {"srslte_tc_interl_UMTS_gen"} if not hasattr(lib, n))
+    assert not missing, missing
