@@ -4,7 +4,8 @@
 # that libsrslte_phy_hip.so replaces into _ref/hip/libsrslte_upper.a, and the reference's own test programs
 # against it, linked with ../srslte-emane_amd/csrc/libsrslte_phy_hip.so in place of those translation units and of FFTW:
 #   lib/test/phy/phy_dl_test.c, phch/test/{pdsch_test,pusch_test,pdsch_pdcch_file_test,pcfich_file_test,pbch_file_test,pmch_file_test}.c,
-#   fec/test/{turbodecoder_test,turbocoder_test}.c, dft/test/ofdm_test.c, utils/test/dft_test.c, ch_estimation/test/chest_test_dl.c,
+#   phch/test/pmch_test.c, fec/test/{turbodecoder_test,turbocoder_test}.c, dft/test/ofdm_test.c, utils/test/dft_test.c,
+#   ch_estimation/test/{chest_test_dl,chest_test_ul}.c,
 #   modem/test/{soft_demod_test,modem_test}.c
 # tests/test_gpu_dropin.py runs them on the GPU box with the reference's CTest arguments and asserts exit code 0.
 # Nothing is stubbed: the same flags / force-include handling of the cmake-generated version.h as ref.mk.
@@ -18,7 +19,8 @@ HOBJ     := $(HOUT)/obj
 
 # translation units served by libsrslte_phy_hip.so
 REPLACED := dft/dft_fftw.c dft/ofdm.c dft/dft_precoding.c fec/turbodecoder.c fec/turbodecoder_gen.c fec/turbodecoder_sse.c fec/turbocoder.c \
-            fec/cbsegm.c fec/tc_interl_lte.c ch_estimation/chest_dl.c modem/demod_soft.c
+            fec/cbsegm.c fec/tc_interl_lte.c fec/tc_interl_umts.c ch_estimation/chest_dl.c ch_estimation/refsignal_dl.c ch_estimation/chest_common.c \
+            modem/demod_soft.c
 # channel/: only the AWGN generator the tests use (the fading / delay / HST / RLF emulators are stimulus tools outside the path)
 UP_DIRS  := agc ch_estimation common dft enb fec io mimo modem phch resampling scrambling sync ue utils
 UP_C     := $(filter-out %viterbi37_neon.c $(addprefix $(RLIB)/src/phy/,$(REPLACED)),$(foreach d,$(UP_DIRS),$(wildcard $(RLIB)/src/phy/$(d)/*.c)) \
@@ -28,7 +30,8 @@ UP_OBJS  := $(patsubst $(RLIB)/src/phy/%.c,$(HOBJ)/%.o,$(UP_C)) $(HOBJ)/utils/ra
 TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/phy/phch/test/pusch_test lib/src/phy/phch/test/pdsch_pdcch_file_test \
             lib/src/phy/phch/test/pcfich_file_test lib/src/phy/phch/test/pbch_file_test lib/src/phy/phch/test/pmch_file_test \
             lib/src/phy/fec/test/turbodecoder_test lib/src/phy/fec/test/turbocoder_test lib/src/phy/dft/test/ofdm_test lib/src/phy/utils/test/dft_test \
-            lib/src/phy/ch_estimation/test/chest_test_dl lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test
+            lib/src/phy/ch_estimation/test/chest_test_dl lib/src/phy/ch_estimation/test/chest_test_ul lib/src/phy/phch/test/pmch_test \
+            lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test
 TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
 
 .PHONY: ref_hip

@@ -36,6 +36,8 @@ CASES = [
     # lib/src/phy/ch_estimation/test/CMakeLists.txt:28-34
     ("chest_test_dl", ["-c", "0"]), ("chest_test_dl", ["-c", "1"]), ("chest_test_dl", ["-c", "2"]), ("chest_test_dl", ["-c", "0", "-r", "50"]),
     ("chest_test_dl", ["-c", "1", "-r", "50"]), ("chest_test_dl", ["-c", "2", "-r", "50"]),
+    # :47-49 - the reference's chest_ul.c over this library's srslte_chest_average_pilots / _estimate_noise_pilots / filter taps
+    ("chest_test_ul", ["-c", "0", "-r", "50"]), ("chest_test_ul", ["-c", "1", "-r", "50"]), ("chest_test_ul", ["-c", "2", "-r", "50"]),
     # lib/src/phy/modem/test/CMakeLists.txt:28-38
     ("modem_test", ["-n", "1024", "-m", "1"]), ("modem_test", ["-n", "1024", "-m", "2"]), ("modem_test", ["-n", "1024", "-m", "4"]),
     ("modem_test", ["-n", "1008", "-m", "6"]), ("modem_test", ["-n", "1024", "-m", "8"]),
@@ -44,6 +46,8 @@ CASES = [
     ("pdsch_test", ["-m", "10", "-n", "50", "-r", "1"]), ("pdsch_test", ["-m", "20", "-n", "100"]), ("pdsch_test", ["-n", "100"]),
     ("pdsch_test", ["-x", "1", "-a", "2", "-n", "25"]), ("pdsch_test", ["-x", "2", "-a", "2", "-n", "50"]), ("pdsch_test", ["-x", "3", "-a", "2", "-t", "0", "-n", "25"]),
     ("pusch_test", ["-n", "50", "-L", "50", "-m", "20"]),
+    # :206-208 - PMCH over the MBSFN (extended-CP) OFDM modulator / demodulator and the decoder
+    ("pmch_test", ["-m", "6", "-n", "50"]), ("pmch_test", ["-m", "15", "-n", "100"]), ("pmch_test", ["-m", "25", "-n", "100"]),
     # lib/test/phy/CMakeLists.txt: the whole chain eNB -> UE, all four transmission modes go through our OFDM / estimator / decoder
     ("phy_dl_test", ["-p", "6", "-t", "1", "-m", "7"]), ("phy_dl_test", ["-p", "25", "-t", "2", "-m", "21"]), ("phy_dl_test", ["-p", "50", "-t", "4", "-m", "14"]),
     ("phy_dl_test", ["-p", "25", "-t", "4", "-m", "28"]), ("phy_dl_test", ["-p", "100", "-t", "1", "-q", "-m", "27"]),
