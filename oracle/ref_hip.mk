@@ -50,7 +50,8 @@ $(HOBJ)/utils/random.o: $(RLIB)/src/phy/utils/random.cpp
 	@mkdir -p $(dir $@)
 	g++ -std=c++11 $(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS)) -c $< -o $@
 
-$(HOUT)/libsrslte_upper.a: $(UP_OBJS)
+# also on this file: a change of REPLACED alters the member list without touching any object
+$(HOUT)/libsrslte_upper.a: $(UP_OBJS) ref_hip.mk
 	@rm -f $@
 	ar rcs $@ $(UP_OBJS)
 
