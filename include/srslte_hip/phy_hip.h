@@ -296,7 +296,8 @@ int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
 /* ------------------------------------------------------------------ PUSCH receive pipeline (eNB side): OFDM RX with the
  * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +
  * descramble + UL channel de-interleaver (pusch.c:423-520, sch.c:891-913,:991-1066) -> rate de-matching -> turbo decode -> TB CRC.
- * UL-SCH data only (no UCI multiplexing), same allocation in both slots, normal CP, rv 0, 16-bit LLRs. */
+ * UL-SCH with optional HARQ-ACK / RI / CQI multiplexing (cfg fields below), one grant per object (optionally hopping between the slots), normal CP,
+ * 16-bit LLRs; redundancy versions and soft combining through srslte_hip_ul_rx_batch_harq. */
 typedef struct srslte_hip_ul_rx srslte_hip_ul_rx_t;
 typedef struct {
   uint32_t cell_id, nof_prb;
@@ -323,6 +324,12 @@ void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
 /* d_iq: [nof_sf][15*N]; d_tb [nof_sf][tb_stride] (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf]; subframe b is TTI tti0 + b */
 int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                            uint8_t* d_tb_ok, void* stream);
+/* HARQ (srslte_ulsch_decode -> decode_tb with grant.tb.rv and cfg->softbuffers.rx, sch.c:1063, :299-414): slot b of the object keeps its code
+ * blocks' soft buffers, CRC flags and bytes between calls. new_data != 0: new transport blocks (srslte_hip_ul_rx_batch is rv 0 / new data);
+ * new_data == 0: a retransmission with redundancy version rv (0..3) is added to the kept buffers, blocks whose CRC already passed are neither
+ * combined nor decoded again. UCI is decoded afresh on every call. */
+int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data, uint8_t* d_tb,
+                                uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* Device pointer to the HARQ-ACK decisions of the last batch on this object, [max_batch][2] bytes (srslte_uci_value_t.ack.ack_value of
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);
@@ -369,6 +376,10 @@ int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint3
  * required exactly when cfg.cqi_len > 0 (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
 int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
                                    const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
+/* ... with a redundancy version rv (0..3; srslte_pusch_grant_t.tb.rv -> srslte_ulsch_encode -> srslte_rm_turbo_tx_lut, sch.c:1157-1160): what a
+ * HARQ retransmission sends. d_ack / d_ri / d_cqi as above (NULL when not configured). */
+int srslte_hip_ul_tx_batch_rv(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                              const uint8_t* d_cqi, uint32_t rv, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
  * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
 const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);

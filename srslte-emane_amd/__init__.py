@@ -604,6 +604,8 @@ class UlRx:
         L.srslte_hip_ul_rx_create.argtypes = [C.POINTER(UlRxCfg)]
         L.srslte_hip_ul_rx_destroy.argtypes = [C.c_void_p]
         L.srslte_hip_ul_rx_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.srslte_hip_ul_rx_batch_harq.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                  C.c_void_p]
         L.srslte_hip_ul_rx_debug_buffer.restype = C.c_void_p
         L.srslte_hip_ul_rx_debug_buffer.argtypes = [C.c_void_p, C.c_int]
         L.srslte_hip_ul_rx_ack.restype = C.c_void_p
@@ -620,6 +622,17 @@ class UlRx:
         x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
         din = DevBuf.from_host(x)
         _check(lib().srslte_hip_ul_rx_batch(self.h, din.ptr, tti0, x.shape[0], self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "ul_rx_batch")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        self.last_nof_sf = x.shape[0]
+        return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
+
+    def decode_harq(self, iq, tti0, rv, new_data):
+        """srslte_hip_ul_rx_batch_harq: slot b keeps its soft buffers between calls; new_data starts new transport blocks."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
+        din = DevBuf.from_host(x)
+        _check(lib().srslte_hip_ul_rx_batch_harq(self.h, din.ptr, tti0, x.shape[0], rv, 1 if new_data else 0, self.d_tb.ptr, self.tb_stride,
+                                                 self.d_ok.ptr, None), "ul_rx_batch_harq")
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         self.last_nof_sf = x.shape[0]
@@ -691,12 +704,25 @@ class UlTx:
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch)
 
-    def encode(self, tb, tti0=0, ack=None, ri=None, cqi=None):
+    def encode(self, tb, tti0=0, ack=None, ri=None, cqi=None, rv=None):
         """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits,
-        cqi: [nof_sf][cqi_len] report bits) -> iq [nof_sf][sf_len] (left on the device in self.d_iq)."""
+        cqi: [nof_sf][cqi_len] report bits; rv: redundancy version through srslte_hip_ul_tx_batch_rv) -> iq [nof_sf][sf_len] (left on the
+        device in self.d_iq)."""
         x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
         din = DevBuf.from_host(x)
-        if cqi is not None:
+        if rv is not None:
+            bufs = []
+            for v, n, w in ((ack, self.cfg.ack_len, 2), (ri, self.cfg.ri_len, 2), (cqi, self.cfg.cqi_len, 64)):
+                a = np.zeros((x.shape[0], w), np.uint8)
+                if v is not None:
+                    a[:, :n] = np.asarray(v, np.uint8).reshape(x.shape[0], -1)[:, :n]
+                bufs.append(DevBuf.from_host(a) if v is not None else None)
+            L = lib()
+            L.srslte_hip_ul_tx_batch_rv.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                    C.c_uint32, C.c_void_p, C.c_void_p]
+            _check(L.srslte_hip_ul_tx_batch_rv(self.h, din.ptr, self.tbs // 8, *[b.ptr if b else None for b in bufs], rv, tti0, x.shape[0],
+                                               self.d_iq.ptr, None), "ul_tx_batch_rv")
+        elif cqi is not None:
             bufs = []
             for v, n, w in ((ack, self.cfg.ack_len, 2), (ri, self.cfg.ri_len, 2), (cqi, self.cfg.cqi_len, 64)):
                 a = np.zeros((x.shape[0], w), np.uint8)

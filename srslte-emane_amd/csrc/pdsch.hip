@@ -2181,6 +2181,7 @@ struct srslte_hip_ul_rx {
   TbGeom                 tg;
   uint32_t               W, in_stride;
   uint32_t *             d_scr, *d_rm_tbl, *d_tbcrc, *d_tb_rem, *d_cb_syn, *d_cb_iters;
+  uint32_t*              d_rm_tbl_rv[4]; // rate de-matching tables of redundancy versions 1-3, made on first use ([0] unused: d_rm_tbl)
   cf32 *                 d_grid, *d_ce, *d_z, *d_d;
   float*                 d_res; // [B] x srslte_hip_chest_ul_res_t
   int16_t *              d_g, *d_w;
@@ -2202,7 +2203,8 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_chest_ul_destroy(q->chest);
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
-                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi};
+                  q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi,
+                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3]};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -2285,7 +2287,8 @@ extern "C" srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cf
        hipMalloc((void**)&q->d_g, sizeof(int16_t) * ((size_t)nbits * B + 16)) == hipSuccess &&
        hipMalloc((void**)&q->d_w, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_bytes, (size_t)(K / 8) * B * C) == hipSuccess &&
-       hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess &&
+       hipMalloc((void**)&q->d_cb_ok, (size_t)B * C) == hipSuccess && hipMemset(q->d_cb_ok, 0, (size_t)B * C) == hipSuccess &&
+       hipMemset(q->d_w, 0, sizeof(int16_t) * (size_t)q->in_stride * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_cb_iters, sizeof(uint32_t) * B * C) == hipSuccess &&
        hipMalloc((void**)&q->d_ack_sum, sizeof(int) * 8 * B) == hipSuccess && hipMalloc((void**)&q->d_ack, (size_t)4 * B) == hipSuccess &&
        hipMemset(q->d_ack, 0, (size_t)4 * B) == hipSuccess && pusch_ack_qprime(cfg->ack_len, cfg->I_offset_ack, cfg->L_prb, nsymb, C * K) >= 0 &&
@@ -2335,10 +2338,35 @@ extern "C" const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q
 extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                                       uint8_t* d_tb_ok, void* stream)
 {
-  if (!q || !d_iq || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+  return srslte_hip_ul_rx_batch_harq(q, d_iq, tti0, nof_sf, 0, 1, d_tb, tb_stride, d_tb_ok, stream);
+}
+
+// HARQ on the uplink (srslte_ulsch_decode hands grant.tb.rv and cfg->softbuffers.rx to the same decode_tb as the downlink, sch.c:1063):
+// slot b keeps its code blocks' soft buffers, CRC flags and bytes between calls, exactly as srslte_hip_dl_rx_batch_harq. new_data != 0
+// starts new transport blocks; new_data == 0 adds the de-matched LLRs of redundancy version rv to the kept buffers and leaves blocks whose
+// CRC already passed alone. UCI (ACK / RI / CQI) is per transmission and decoded afresh on every call.
+extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data,
+                                           uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !d_tb || !d_tb_ok || rv > 3 || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t    st = (hipStream_t)stream;
   const uint32_t C = q->seg.C, K = q->seg.K1;
+  const uint32_t* d_rm_tbl = q->d_rm_tbl;
+  if (rv) {
+    if (!q->d_rm_tbl_rv[rv]) {
+      std::vector<uint32_t> t;
+      lte_rm_rx_table(K, rv, t);
+      if (q->W) {
+        for (auto& v : t) {
+          v = v < 3 * K ? (v % 3) * (K + 32) + ((v / 3) % (K / q->W)) * q->W + (v / 3) / (K / q->W) : (v - 3 * K) + 3 * (K + 32);
+        }
+      }
+      if (int rc = upload(&q->d_rm_tbl_rv[rv], rm_slot_table(t, q->in_stride))) return rc;
+    }
+    d_rm_tbl = q->d_rm_tbl_rv[rv];
+  }
+  const int combine = new_data ? 0 : 1;
   int            r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
   if (r) return r;
   r = srslte_hip_chest_ul_estimate_pusch_batch_hop(q->chest, tti0, q->cfg.L_prb, q->cfg.n_prb, (uint32_t)q->pg.n_prb1, q->cfg.n_dmrs, q->d_grid, q->d_ce, q->d_res, (int)nof_sf,
@@ -2373,15 +2401,17 @@ extern "C" int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, u
   }
   RmGeom rg = q->rg;
   rg.tti0   = (int)tti0;
+  rg.combine = combine;
+  rg.skip    = combine ? q->d_cb_ok : nullptr;
   if (rm_fits_lds(rg)) {
-    hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(rg, 2), st, (const int16_t*)q->d_g, q->d_w,
-                       (const uint32_t*)q->d_rm_tbl, rg);
+    hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(nof_sf * C), dim3(256), rm_lds_bytes(rg, 2), st, (const int16_t*)q->d_g, q->d_w, d_rm_tbl, rg);
   } else {
     hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div(rg.w_stride, 512), nof_sf * C), dim3(256), 0, st, (const int16_t*)q->d_g, q->d_w,
-                       (const uint32_t*)q->d_rm_tbl, rg);
+                       d_rm_tbl, rg);
   }
   LAUNCH_CHECK();
   tdec_set_tb_syndrome(q->tdec, q->d_tb_rem, C, q->d_cb_syn);
+  tdec_set_skip(q->tdec, combine ? q->d_cb_ok : nullptr);
   r = tdec_run_batch_w(q->tdec, q->d_w, 0, q->in_stride, q->W != 0, K, -1, nof_sf * C, q->cfg.max_iterations, C > 1 ? 0x1800063u : 0x1864CFBu,
                        C > 1 ? K : q->cfg.tbs + 24, q->d_cb_bytes, K / 8, q->d_cb_iters, q->d_cb_ok, st);
   if (r) return r;
@@ -2570,6 +2600,7 @@ struct srslte_hip_ul_tx {
   srslte_hip_cbsegm_t    seg;
   PuschTxGeom            g;
   uint32_t *             d_scr, *d_rm, *d_tbcrc;
+  uint32_t*              d_rm_rv[4]; // rate-matching tables of redundancy versions 1-3, made on first use ([0] unused: d_rm)
   uint8_t *              d_cb, *d_parity, *d_sys_tail, *d_qcqi;
   uint16_t*              d_cqi_rm;
   cf32 *                 d_d, *d_z, *d_grid;
@@ -2580,7 +2611,8 @@ extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
   if (!q) return;
   srslte_hip_ofdm_destroy(q->ofdm);
   srslte_hip_chest_ul_destroy(q->dmrs);
-  void* bufs[] = {q->d_scr, q->d_rm, q->d_tbcrc, q->d_cb, q->d_parity, q->d_sys_tail, q->d_d, q->d_z, q->d_grid, q->d_qcqi, q->d_cqi_rm};
+  void* bufs[] = {q->d_scr, q->d_rm, q->d_tbcrc, q->d_cb, q->d_parity, q->d_sys_tail, q->d_d, q->d_z, q->d_grid, q->d_qcqi, q->d_cqi_rm,
+                  q->d_rm_rv[1], q->d_rm_rv[2], q->d_rm_rv[3]};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -2730,13 +2762,35 @@ extern "C" int srslte_hip_ul_tx_batch_uci(srslte_hip_ul_tx_t* q, const uint8_t* 
 extern "C" int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
                                               const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream)
 {
-  if (!q || !d_tb || !d_iq || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  return srslte_hip_ul_tx_batch_rv(q, d_tb, tb_stride, d_ack, d_ri, d_cqi, 0, tti0, nof_sf, d_iq, stream);
+}
+
+// The same with a redundancy version (srslte_pusch_grant_t.tb.rv -> srslte_ulsch_encode -> srslte_rm_turbo_tx_lut's k0, rm_turbo.c:100-158):
+// what a retransmission sends. Everything else - UCI multiplexing, interleaver, scrambling - does not depend on it.
+extern "C" int srslte_hip_ul_tx_batch_rv(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                         const uint8_t* d_cqi, uint32_t rv, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream)
+{
+  if (!q || !d_tb || !d_iq || rv > 3 || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8) return SRSLTE_ERROR_INVALID_INPUTS;
   if ((q->cfg.ack_len != 0) != (d_ack != nullptr) || (q->cfg.ri_len != 0) != (d_ri != nullptr) || (q->cfg.cqi_len != 0) != (d_cqi != nullptr))
     return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
   const void* d_r = nullptr;
   if (int r = chest_ul_dmrs_table(q->dmrs, q->cfg.L_prb, q->cfg.n_dmrs, &d_r)) return r;
+  const uint32_t* d_rm = q->d_rm;
+  if (rv) {
+    if (!q->d_rm_rv[rv]) {
+      const uint32_t        K = q->seg.K1;
+      std::vector<uint32_t> t;
+      lte_rm_rx_table(K, rv, t);
+      for (auto& v : t) {
+        const uint32_t p = v / 3, s = v % 3;
+        v = s == 0 ? (p < K ? p : (1u << 30) | (p - K)) : (2u << 30) | (s == 1 ? p : K + 4 + p);
+      }
+      if (int r = upload(&q->d_rm_rv[rv], t)) return r;
+    }
+    d_rm = q->d_rm_rv[rv];
+  }
   PuschTxGeom g = q->g;
   g.tti0        = (int)tti0;
   g.tb_stride   = (int)tb_stride;
@@ -2756,7 +2810,7 @@ extern "C" int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8
                                              nof_sf * (uint32_t)g.C, stream);
   if (r) return r;
   hipLaunchKernelGGL(pusch_tx_mod_kernel, dim3(ceil_div(g.M_sc, 256), g.nsymb, nof_sf), dim3(256), 0, st, (const uint8_t*)q->d_cb,
-                     (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, (const uint32_t*)q->d_rm, (const uint32_t*)q->d_scr, q->d_d, g);
+                     (const uint8_t*)q->d_parity, (const uint8_t*)q->d_sys_tail, d_rm, (const uint32_t*)q->d_scr, q->d_d, g);
   LAUNCH_CHECK();
   r = srslte_hip_dft_precoding_batch(q->d_d, q->d_z, q->cfg.L_prb, g.nsymb * nof_sf, 1, stream); // srslte_dft_precoding_init_tx: forward, 1/sqrt(N)
   if (r) return r;

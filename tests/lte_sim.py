@@ -826,7 +826,7 @@ def ul_cqi_qprime(cfg, O_cqi, I_offset_cqi, Qp_ri):
 
 
 def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=None, keep=None, ack=(), I_offset_ack=0, ri=(), I_offset_ri=0, cqi=(),
-                     I_offset_cqi=0):
+                     I_offset_cqi=0, rv=0):
     """UE transmit side of pusch.c:314-421 (UL-SCH, optionally with 1-2 HARQ-ACK bits, a 1-2 bit rank indication and / or a CQI report of
     `cqi` bits multiplexed): returns (iq[sf_len], payload bytes); keep: dict that receives g, d, z, grid (and q_tx, ack_types with an ACK)."""
     orc = oracle()
@@ -837,7 +837,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     # the CQI's coded bits come first in the stream the interleaver reads, the UL-SCH is rate-matched to the rest (sch.c:1133-1160)
     Qp_cqi = ul_cqi_qprime(cfg, len(cqi), I_offset_cqi, Qp_ri)
     n_cqi = Qp_cqi * cfg.Qm
-    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, 0, cfg.max_iter)
+    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, rv, cfg.max_iter)  # rv: srslte_pusch_grant_t.tb.rv of a HARQ retransmission
     g = np.zeros(G, np.uint8)
     if n_cqi:
         qc = np.zeros(n_cqi, np.uint8)
@@ -887,7 +887,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     return iq.astype(np.complex64), data
 
 
-def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0, O_cqi=0, I_offset_cqi=0):
+def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_offset_ri=0, O_cqi=0, I_offset_cqi=0, harq=None, rv=0, new_data=True):
     """eNB receive side: enb_ul.c:58-63 OFDM settings, srslte_chest_ul_estimate_pusch, srslte_pusch_decode (pusch.c:423-520) and the
     UL-SCH part of srslte_ulsch_decode (sch.c:991-1066) without UCI."""
     from _libs import OrcChestUlRes
@@ -928,9 +928,13 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
     cqi_out, cqi_ok = np.zeros(64, np.uint8), C.c_uint8(0)
     if O_cqi:
         assert orc.orc_uci_cqi_decode(p(g[:n_cqi].copy()), n_cqi, O_cqi, p(cqi_out), C.byref(cqi_ok)) == 0
-    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, 0, cfg.max_iter)
+    sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, rv, cfg.max_iter)
     tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
-    rc = orc.orc_dlsch_decode(C.byref(sch), p(np.ascontiguousarray(g[n_cqi:])), p(tb), p(iters), p(cbok))
+    if harq is not None:  # an OrcHarq kept between the transmissions of one transport block (cfg->softbuffers.rx, sch.c:1063)
+        rc = orc.orc_dlsch_decode_harq(C.byref(sch), p(np.ascontiguousarray(g[n_cqi:])), 0, 1 if new_data else 0, p(harq.w), p(harq.crc), p(harq.data),
+                                       p(tb), p(iters), p(cbok))
+    else:
+        rc = orc.orc_dlsch_decode(C.byref(sch), p(np.ascontiguousarray(g[n_cqi:])), p(tb), p(iters), p(cbok))
     out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok, "cqi": cqi_out[:O_cqi], "cqi_ok": bool(cqi_ok.value)}
     if keep:
         out.update(grid=grid, ce=ce, noise=res.noise_estimate, z=z, d=d, q=qllr, g=g, res=res, q_before_ack=q_before_ack, ack=ack_out, ri=ri_out)
@@ -1042,6 +1046,7 @@ class RefUlsch:
         self.ri_off = L["srslte_uci_value_t.ri"]
         self.ack_off = L["srslte_uci_value_t.ack"] + L["srslte_uci_value_ack_t.ack_value"]
         self.sb_off = L["srslte_pusch_cfg_t.softbuffers"]
+        self.rv_off = t0 + L["srslte_ra_tb_t.rv"]
 
     def cqi_bits(self, wb, diff=0):
         """the report's bits as srslte_cqi_value_pack lays them out (cqi.c:41-76,:100-134): 4-bit wide-band CQI, then 2 N bits of sub-band
@@ -1057,12 +1062,14 @@ class RefUlsch:
         else:
             uci[self.cqi_val + L["srslte_cqi_value_t.wideband.wideband_cqi"]] = wb
 
-    def encode(self, data, ack=(), ri=None, cqi=None):
+    def encode(self, data, ack=(), ri=None, cqi=None, rv=0):
         """payload bytes (+ HARQ-ACK values) -> (g bits, q bits) one per element, as srslte_pusch_encode gets them before scrambling
-        (pusch.c:380-395); the ACK positions of q hold the value bits, 0 for repetition / placeholder bits."""
+        (pusch.c:380-395); the ACK positions of q hold the value bits, 0 for repetition / placeholder bits. rv: grant.tb.rv."""
         cfg, R = self.cfg, self.R
+        self.pc[self.rv_off:self.rv_off + 4].view(np.uint32)[0] = rv
         self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_tx)
-        R.srslte_softbuffer_tx_reset(self.sb_tx)
+        if rv == 0:  # a retransmission re-reads the coded bits the rv 0 call left in the soft buffer (encode_tb_off, sch.c:228-262)
+            R.srslte_softbuffer_tx_reset(self.sb_tx)
         d = np.zeros(cfg.tbs // 8 + 64, np.uint8)
         d[:cfg.tbs // 8] = data
         uci = np.zeros(4096, np.uint8)
@@ -1075,11 +1082,14 @@ class RefUlsch:
         assert R.srslte_ulsch_encode(self.q, p(self.pc), p(d), p(uci), p(g), p(q)) >= 0  # returns the number of RI/ACK q-bits
         return np.unpackbits(g)[:cfg.nbits], np.unpackbits(q)[:cfg.nbits]
 
-    def decode(self, q_llr, c_seq):
-        """descrambled int16 LLRs in received (q) order -> {tb, ok}, as srslte_pusch_decode calls it (pusch.c:497-503)."""
+    def decode(self, q_llr, c_seq, rv=0, new_data=True):
+        """descrambled int16 LLRs in received (q) order -> {tb, ok}, as srslte_pusch_decode calls it (pusch.c:497-503). new_data False: a
+        retransmission with redundancy version rv into the soft buffer the previous calls left (no srslte_softbuffer_rx_reset)."""
         cfg, R = self.cfg, self.R
+        self.pc[self.rv_off:self.rv_off + 4].view(np.uint32)[0] = rv
         self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_rx)
-        R.srslte_softbuffer_rx_reset(self.sb_rx)
+        if new_data:
+            R.srslte_softbuffer_rx_reset(self.sb_rx)
         ql = np.zeros(cfg.nbits + 64, np.int16)
         ql[:cfg.nbits] = q_llr
         gl = np.zeros(cfg.nbits + 64, np.int16)

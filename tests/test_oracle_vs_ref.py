@@ -1637,3 +1637,37 @@ def test_ulsch_with_cqi_vs_reference(prb, L_prb, n_prb, mod, tbs, cqi_N, I_cqi, 
     assert np.array_equal(r["cqi"], bits) and r["cqi_ok"]
     if cqi_N == 0:
         assert d["cqi"] == (wb, 0) and d["cqi_crc"]
+
+
+@pytest.mark.parametrize("prb,L,mod,tbs,snr,short,O_ack,O_ri", [(25, 10, 2, 4008, 4.5, False, 0, 0), (100, 48, 3, 30576, 11.5, False, 2, 1), (6, 6, 1, 1000, 0.5, True, 1, 0),
+                                                                (100, 100, 2, 43816, 7.5, False, 0, 1), (50, 45, 3, 30576, 12.5, True, 0, 0)])
+def test_ulsch_harq_vs_reference(prb, L, mod, tbs, snr, short, O_ack, O_ri):
+    """HARQ on the uplink: the reference's srslte_ulsch_encode with grant.tb.rv = 0, 2, 3, 1 and its srslte_ulsch_decode into ONE
+    srslte_softbuffer_rx_t across the four transmissions (sch.c:1063 -> decode_tb -> decode_tb_cb :299-414), against the oracle's UL chain
+    with an OrcHarq: coded bits of every redundancy version, and per transmission the de-interleaved LLRs, the CRC verdict and the bytes.
+    SNRs are set so that the first transmission fails and a later one succeeds for at least one of the transport blocks."""
+    from lte_sim import OrcHarq, RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(2600 + prb + L + O_ack + O_ri)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3, shortened=short)
+    I_ack, I_ri = 9, 8
+    chain = RefUlsch(cfg, O_ack, I_ack, O_ri, I_ri)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_ri)
+    first_fail_later_ok = 0
+    for trial in range(3):
+        harq, data, oks = OrcHarq(cfg), None, []
+        for n, (rv, t) in enumerate(((0, 2), (2, 10), (3, 18), (1, 26))):
+            ack, ri = (1, 0)[:O_ack], (1, 0)[:O_ri]
+            k = {}
+            iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k, data=data, ack=ack, I_offset_ack=I_ack, ri=ri, I_offset_ri=I_ri, rv=rv)
+            g_r, _ = chain.encode(data, ack, ri[0] if O_ri else None, rv=rv)
+            assert np.array_equal(g_r[:G], k["g"]), (trial, rv)
+            o = oracle_ul_rx(cfg, iq, t, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri, harq=harq, rv=rv, new_data=n == 0)
+            r = chain.decode(o["q_before_ack"], cfg.scramble(t % 10), rv=rv, new_data=n == 0)
+            assert np.array_equal(r["g"][:G], o["g"]) and r["ok"] == o["ok"], (trial, n, r["ok"], o["ok"])
+            if r["ok"]:
+                assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+            oks.append(r["ok"])
+            if r["ok"]:
+                break
+        first_fail_later_ok += (not oks[0]) and oks[-1]
+    assert first_fail_later_ok > 0
