@@ -1014,6 +1014,8 @@ struct srslte_hip_dl_rx {
   struct srslte_hip_dl_rx* cw1;   // two-layer modes: the second codeword's back end (rate de-matching, decoder, TB assembly and their buffers)
 };
 
+static void grants_free(GrantsState* g);
+
 extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
 {
   if (!q) return;
@@ -1027,23 +1029,7 @@ extern "C" void srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q)
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
-  if (q->gs) {
-    GrantsState* g = q->gs;
-    srslte_hip_tdec_destroy(g->tdec);
-    void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc, g->d_csi, g->d_csi_max};
-    for (void* b : gb) {
-      if (b) (void)hipFree(b);
-    }
-    for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
-    for (auto& kv : g->crc_fac) (void)hipFree(kv.second);
-    for (int i = 0; i < 4; i++) {
-      if (g->h_pin[i]) { // its event was created just before it
-        (void)hipHostFree(g->h_pin[i]);
-        (void)hipEventDestroy(g->h_ev[i]);
-      }
-    }
-    delete g;
-  }
+  grants_free(q->gs);
   delete q;
 }
 
@@ -1433,16 +1419,16 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // Single-port cells (TM1) and 2- / 4-port cells with transmit diversity (TM2), 1..4 receive antennas, 16- or 8-bit LLRs (cfg.llr_8bit), with or
 // without the CSI weighting of cfg.csi_enable.
 // --------------------------------------------------------------------------------------------------------------------
-static int grants_init(srslte_hip_dl_rx_t* q)
+// Buffers of a grants mode: V per-transport-block slots of up to Cmax code blocks and max_re resource elements each; relist_rows > 0 adds the
+// PDSCH RE lists, csi the CSI rows. Shared by the downlink (slot = subframe, or max_batch + subframe for codeword 1) and the uplink (slot = PUSCH).
+static int grants_alloc(GrantsState* g, uint32_t max_re, uint32_t V, uint32_t Cmax, uint32_t relist_rows, bool csi, size_t extra_desc_bytes)
 {
-  auto*          g = new GrantsState();
-  const uint32_t P = q->cfg.nof_prb, B = q->cfg.max_batch;
-  g->Cmax     = q->seg.C;
+  g->Cmax     = Cmax;
   g->stride   = (srslte_hip_tdec_input_len(6144, 1) + 31) & ~31u;
-  g->max_re   = 14 * 12 * P;                       // upper bound of any allocation
+  g->max_re   = max_re;                            // upper bound of any allocation
   g->max_bits = (g->max_re * 8 + 15) & ~15u;       // 256QAM
   g->words    = (g->max_re * 8 + 31) / 32 + 2;     // + the spare word the demapper reads
-  g->V        = (q->pg.nof_ports == 2 && q->pg.nof_rx == 2) ? 2 * B : B;
+  g->V        = V;
   g->tdec     = srslte_hip_tdec_create(6144, g->V * g->Cmax);
   g->d_relist = g->d_scr = g->d_basis = g->d_cb_iters = nullptr;
   g->d_e = g->d_w = nullptr;
@@ -1453,7 +1439,6 @@ static int grants_init(srslte_hip_dl_rx_t* q)
     g->h_pin[i]  = nullptr;
     g->h_used[i] = false;
   }
-  q->gs = g;
   if (!g->tdec) return SRSLTE_ERROR;
   // Gold-sequence basis (sequence.c:48-79): all 31 x2 basis sequences advance together, bit j of the state word = basis j
   {
@@ -1477,12 +1462,12 @@ static int grants_init(srslte_hip_dl_rx_t* q)
     if (upload(&g->d_basis, basis)) return SRSLTE_ERROR;
   }
   const size_t nblk = (size_t)g->V * g->Cmax;
-  g->desc_bytes     = sizeof(GrantDev) * g->V + sizeof(SfDesc) * g->V + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk;
+  g->desc_bytes     = sizeof(GrantDev) * g->V + sizeof(SfDesc) * g->V + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk + extra_desc_bytes;
   for (int i = 0; i < 4; i++) {
     HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
     HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
   }
-  HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * B));
+  if (relist_rows) HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * relist_rows));
   HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * g->V));
   HIP_TRY(hipMalloc((void**)&g->d_e, sizeof(int16_t) * ((size_t)g->max_bits * g->V + 16)));
   HIP_TRY(hipMalloc((void**)&g->d_w, sizeof(int16_t) * (size_t)g->stride * nblk));
@@ -1490,7 +1475,7 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   HIP_TRY(hipMalloc((void**)&g->d_cb_ok, nblk));
   HIP_TRY(hipMalloc((void**)&g->d_cb_iters, sizeof(uint32_t) * nblk));
   HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
-  if (q->cfg.csi_enable) {
+  if (csi) {
     HIP_TRY(hipMalloc((void**)&g->d_csi, sizeof(float) * (size_t)g->max_re * g->V));
     HIP_TRY(hipMalloc((void**)&g->d_csi_max, sizeof(uint32_t) * g->V));
   }
@@ -1500,6 +1485,33 @@ static int grants_init(srslte_hip_dl_rx_t* q)
   HIP_TRY(hipMemset(g->d_cb_bytes, 0, (size_t)768 * nblk));
   HIP_TRY(hipDeviceSynchronize());
   return SRSLTE_SUCCESS;
+}
+
+static void grants_free(GrantsState* g)
+{
+  if (!g) return;
+  srslte_hip_tdec_destroy(g->tdec);
+  void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_cb_iters, g->d_e, g->d_w, g->d_cb_bytes, g->d_cb_ok, g->d_desc, g->d_csi, g->d_csi_max};
+  for (void* b : gb) {
+    if (b) (void)hipFree(b);
+  }
+  for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
+  for (auto& kv : g->crc_fac) (void)hipFree(kv.second);
+  for (int i = 0; i < 4; i++) {
+    if (g->h_pin[i]) { // its event was created just before it
+      (void)hipHostFree(g->h_pin[i]);
+      (void)hipEventDestroy(g->h_ev[i]);
+    }
+  }
+  delete g;
+}
+
+static int grants_init(srslte_hip_dl_rx_t* q)
+{
+  auto*          g = new GrantsState();
+  const uint32_t P = q->cfg.nof_prb, B = q->cfg.max_batch;
+  q->gs = g;
+  return grants_alloc(g, 14 * 12 * P, (q->pg.nof_ports == 2 && q->pg.nof_rx == 2) ? 2 * B : B, q->seg.C, B, q->cfg.csi_enable != 0, 0);
 }
 
 // slot table of (K, rv) in the input layout of the decoder AUTO selects for K, stride = that layout's length rounded up to 32
@@ -1548,6 +1560,116 @@ static int grants_crc_factors(GrantsState* g, uint32_t tbs, const uint32_t** d_f
     it = g->crc_fac.emplace(tbs, d).first;
   }
   *d_fac = it->second;
+  return SRSLTE_SUCCESS;
+}
+
+// Host side of one grants-mode call: transport blocks are added one by one (descriptor of their slot, one descriptor per code block, decoder
+// group by block length), then grants_back_end runs rate de-matching, the decoders and the transport-block check over what was added.
+struct GrantsBuild {
+  struct Group { uint32_t K, single; std::vector<uint32_t> slots; };
+  GrantsState*       g;
+  SfDesc*            h_sf;
+  CbDesc*            h_cb;
+  bool               l8;      // 8-bit LLRs (pdsch.c:760-779, sch.c:336-356): same buffers, as bytes
+  uint32_t           max_tbs; // the object's largest transport block (its buffers are sized for it)
+  int                npt, max_mod;
+  const char*        who;
+  std::vector<Group> groups;
+  uint32_t           ncb = 0, max_seg = 0;
+  // one transport block into slot v: descriptor, code-block descriptors, decoder group. b: the caller's index, for the message
+  int add_tb(uint32_t b, uint32_t v, int mod, uint32_t tbs, uint32_t rv, int new_data, uint32_t nre, uint32_t Nl)
+  {
+    SfDesc& sd = h_sf[v];
+    srslte_hip_cbsegm_t seg;
+    if (mod < 1 || mod > max_mod || rv > 3 || tbs > max_tbs || tbs > (uint32_t)TB_MAX_BITS || (tbs % 8) || srslte_hip_cbsegm(&seg, tbs) || seg.F || seg.C2 ||
+        seg.C > g->Cmax) {
+      hip_log("[srslte_hip] %s grants: entry %u: unsupported transport block (mod %d, tbs %u, rv %u)\n", who, b, mod, tbs, rv);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    const uint32_t Qm = 2 * (uint32_t)mod, K = seg.K1, C = seg.C;
+    if (nre == 0 || nre < C * Nl) {
+      hip_log("[srslte_hip] %s grants: entry %u: empty allocation\n", who, b);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    sd.nof_re = (int)nre; sd.mod = mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
+    if (grants_crc_factors(g, tbs, &sd.crc_fac)) return SRSLTE_ERROR;
+    const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
+    const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
+    const uint32_t* tbl = nullptr;
+    if (grants_rm_table(g, K, rv, W, w_len, &tbl)) return SRSLTE_ERROR;
+    Group* grp = nullptr;
+    for (auto& x : groups) {
+      if (x.K == K && x.single == (C == 1 ? tbs : 0)) grp = &x;
+    }
+    if (!grp) {
+      groups.push_back(Group{K, C == 1 ? tbs : 0, {}});
+      grp = &groups.back();
+    }
+    for (uint32_t c = 0; c < C; c++) {
+      CbDesc& cd = h_cb[ncb++];
+      cd.sf = (int)v; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = new_data ? 0 : 1;
+      cd.w_len = (int)w_len; cd.tbl = tbl; cd.Nl = (int)Nl;
+      grp->slots.push_back(v * g->Cmax + c);
+    }
+    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
+    max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
+    return SRSLTE_SUCCESS;
+  }
+  uint32_t fill_map(uint32_t* h_map) const
+  {
+    uint32_t n = 0;
+    for (auto& x : groups) {
+      for (uint32_t v : x.slots) h_map[n++] = v;
+    }
+    return n;
+  }
+};
+
+// rate de-matching of every added block, the decoders group by group, and the transport-block check of rows 0 .. nrows-1 (row -> slot: the row
+// itself, or cw1_off + row - nof_rows0 for rows behind the first nof_rows0: the second codewords)
+static int grants_back_end(GrantsState* g, const GrantsBuild& bd, const SfDesc* d_sf, const CbDesc* d_cb, const uint32_t* d_map, uint32_t tti0,
+                           uint32_t max_iterations, uint32_t nrows, uint32_t nof_rows0, uint32_t cw1_off, uint8_t* d_tb, uint32_t tb_stride,
+                           uint8_t* d_tb_ok, hipStream_t st)
+{
+  const bool l8 = bd.l8;
+  if (bd.ncb) {
+    RmGeom rg;
+    memset(&rg, 0, sizeof(rg));
+    rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
+    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
+    const int lds = (int)((bd.max_seg + 15) & ~15u);
+    const uint32_t ncb = bd.ncb;
+    if (l8 && lds <= 64 * 1024) {
+      hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(ncb), dim3(256), lds, st, (const int8_t*)g->d_e, (int8_t*)g->d_w, (const uint32_t*)nullptr, rg);
+    } else if (l8) {
+      hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div((int)g->stride, 1024), ncb), dim3(256), 0, st, (const int8_t*)g->d_e, (int8_t*)g->d_w,
+                         (const uint32_t*)nullptr, rg);
+    } else if (lds <= 64 * 1024) {
+      hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(ncb), dim3(256), lds, st, (const int16_t*)g->d_e, g->d_w, (const uint32_t*)nullptr, rg);
+    } else {
+      hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div((int)g->stride, 512), ncb), dim3(256), 0, st, (const int16_t*)g->d_e, g->d_w,
+                         (const uint32_t*)nullptr, rg);
+    }
+    LAUNCH_CHECK();
+    tdec_set_tb_syndrome(g->tdec, nullptr, 1, nullptr);
+    tdec_set_skip(g->tdec, g->d_cb_ok);
+    uint32_t off = 0;
+    for (auto& x : bd.groups) {
+      const uint32_t n = (uint32_t)x.slots.size();
+      const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(x.K) : srslte_hip_tdec_autoimp_get_subblocks(x.K);
+      tdec_set_cb_map(g->tdec, d_map + off);
+      const int r = tdec_run_batch_w(g->tdec, g->d_w, l8 ? 1 : 0, g->stride, W != 0, x.K, -1, n, max_iterations, x.single ? 0x1864CFBu : 0x1800063u,
+                                     x.single ? x.single + 24 : x.K, g->d_cb_bytes, 768, g->d_cb_iters, g->d_cb_ok, st);
+      tdec_set_cb_map(g->tdec, nullptr);
+      if (r) return r;
+      off += n;
+    }
+  }
+  TbGeom tg;
+  memset(&tg, 0, sizeof(tg));
+  tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride; tg.nof_sf = (int)nof_rows0; tg.cw1_off = (int)cw1_off;
+  hipLaunchKernelGGL(tb_crc_bytes_kernel, dim3(nrows), dim3(256), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, d_tb, d_tb_ok, tg);
+  LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
 
@@ -1602,48 +1724,12 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
   auto*          d_sf = reinterpret_cast<SfDesc*>(d_gr + V);
   auto*          d_cb = reinterpret_cast<CbDesc*>(d_sf + V);
   auto*          d_map = reinterpret_cast<uint32_t*>(d_cb + nblk);
-  struct Group { uint32_t K, single; std::vector<uint32_t> slots; };
-  std::vector<Group> groups;
   const bool         l8 = q->cfg.llr_8bit != 0; // the 8-bit LLR path the applications select (pdsch.c:760-779, sch.c:336-356): same buffers, as bytes
-  uint32_t           ncb = 0, max_seg = 0;
   bool               any_mimo = false;
-  // one transport block into per-subframe slot v: descriptor, code-block descriptors, decoder group
+  GrantsBuild        bd;
+  bd.g = g; bd.h_sf = h_sf; bd.h_cb = h_cb; bd.l8 = l8; bd.max_tbs = q->cfg.tbs; bd.npt = npt; bd.max_mod = 4; bd.who = "dl_rx";
   auto add_tb = [&](uint32_t b, uint32_t v, int mod, uint32_t tbs, uint32_t rv, int new_data, uint32_t nre, uint32_t Nl) -> int {
-    SfDesc& sd = h_sf[v];
-    srslte_hip_cbsegm_t seg;
-    if (mod < 1 || mod > 4 || rv > 3 || tbs > q->cfg.tbs || tbs > (uint32_t)TB_MAX_BITS || (tbs % 8) || srslte_hip_cbsegm(&seg, tbs) || seg.F || seg.C2 ||
-        seg.C > g->Cmax) {
-      hip_log("[srslte_hip] dl_rx grants: subframe %u: unsupported transport block (mod %d, tbs %u, rv %u)\n", b, mod, tbs, rv);
-      return SRSLTE_ERROR_INVALID_INPUTS;
-    }
-    const uint32_t Qm = 2 * (uint32_t)mod, K = seg.K1, C = seg.C;
-    if (nre == 0 || nre < C * Nl) {
-      hip_log("[srslte_hip] dl_rx grants: subframe %u: empty allocation\n", b);
-      return SRSLTE_ERROR_INVALID_INPUTS;
-    }
-    sd.nof_re = (int)nre; sd.mod = mod; sd.Qm = (int)Qm; sd.C = (int)C; sd.K = (int)K; sd.tbs = (int)tbs; sd.rlen = (int)(C == 1 ? K : K - 24);
-    if (grants_crc_factors(g, tbs, &sd.crc_fac)) return SRSLTE_ERROR;
-    const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K);
-    const uint32_t w_len = (srslte_hip_tdec_input_len(K, W != 0) + 31) & ~31u;
-    const uint32_t* tbl = nullptr;
-    if (grants_rm_table(g, K, rv, W, w_len, &tbl)) return SRSLTE_ERROR;
-    Group* grp = nullptr;
-    for (auto& x : groups) {
-      if (x.K == K && x.single == (C == 1 ? tbs : 0)) grp = &x;
-    }
-    if (!grp) {
-      groups.push_back(Group{K, C == 1 ? tbs : 0, {}});
-      grp = &groups.back();
-    }
-    for (uint32_t c = 0; c < C; c++) {
-      CbDesc& cd = h_cb[ncb++];
-      cd.sf = (int)v; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = new_data ? 0 : 1;
-      cd.w_len = (int)w_len; cd.tbl = tbl; cd.Nl = (int)Nl;
-      grp->slots.push_back(v * g->Cmax + c);
-    }
-    const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
-    max_seg = seg_bytes > max_seg ? seg_bytes : max_seg;
-    return SRSLTE_SUCCESS;
+    return bd.add_tb(b, v, mod, tbs, rv, new_data, nre, Nl);
   };
   for (uint32_t b = 0; b < nof_sf; b++) {
     const srslte_hip_dl_grant2_t& g2 = grants[b];
@@ -1725,10 +1811,7 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
       sd1.scheme = g2.tx_scheme; sd1.nof_tb = 2; sd1.codebook = sd.codebook;
     }
   }
-  uint32_t nmap = 0;
-  for (auto& x : groups) {
-    for (uint32_t v : x.slots) h_map[nmap++] = v;
-  }
+  bd.fill_map(h_map);
   // stages 0, 1: OFDM demodulation and channel estimation do not depend on the grants
   int r = srslte_hip_dl_rx_stage(q, 0, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
   if (!r) r = srslte_hip_dl_rx_stage(q, 1, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
@@ -1791,44 +1874,7 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
     }
     LAUNCH_CHECK();
   }
-  if (ncb) {
-    RmGeom rg;
-    memset(&rg, 0, sizeof(rg));
-    rg.cbd = d_cb; rg.cb_ok_rst = g->d_cb_ok; rg.C = (int)g->Cmax; rg.tti0 = (int)tti0; rg.max_bits = (int)g->max_bits; rg.w_stride = (int)g->stride;
-    rg.Nl = 1; rg.skip = g->d_cb_ok; rg.max_re = (int)g->max_re; rg.csi = g->d_csi; rg.csi_max = g->d_csi_max;
-    const int lds = (int)((max_seg + 15) & ~15u);
-    if (l8 && lds <= 64 * 1024) {
-      hipLaunchKernelGGL(rm_rx_lds_kernel<int8_t>, dim3(ncb), dim3(256), lds, st, (const int8_t*)g->d_e, (int8_t*)g->d_w, (const uint32_t*)nullptr, rg);
-    } else if (l8) {
-      hipLaunchKernelGGL(rm_rx_kernel<int8_t>, dim3(ceil_div((int)g->stride, 1024), ncb), dim3(256), 0, st, (const int8_t*)g->d_e, (int8_t*)g->d_w,
-                         (const uint32_t*)nullptr, rg);
-    } else if (lds <= 64 * 1024) {
-      hipLaunchKernelGGL(rm_rx_lds_kernel<int16_t>, dim3(ncb), dim3(256), lds, st, (const int16_t*)g->d_e, g->d_w, (const uint32_t*)nullptr, rg);
-    } else {
-      hipLaunchKernelGGL(rm_rx_kernel<int16_t>, dim3(ceil_div((int)g->stride, 512), ncb), dim3(256), 0, st, (const int16_t*)g->d_e, g->d_w,
-                         (const uint32_t*)nullptr, rg);
-    }
-    LAUNCH_CHECK();
-    tdec_set_tb_syndrome(g->tdec, nullptr, 1, nullptr);
-    tdec_set_skip(g->tdec, g->d_cb_ok);
-    uint32_t off = 0;
-    for (auto& x : groups) {
-      const uint32_t n = (uint32_t)x.slots.size();
-      const uint32_t W = l8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(x.K) : srslte_hip_tdec_autoimp_get_subblocks(x.K);
-      tdec_set_cb_map(g->tdec, d_map + off);
-      r = tdec_run_batch_w(g->tdec, g->d_w, l8 ? 1 : 0, g->stride, W != 0, x.K, -1, n, q->cfg.max_iterations, x.single ? 0x1864CFBu : 0x1800063u,
-                           x.single ? x.single + 24 : x.K, g->d_cb_bytes, 768, g->d_cb_iters, g->d_cb_ok, st);
-      tdec_set_cb_map(g->tdec, nullptr);
-      if (r) return r;
-      off += n;
-    }
-  }
-  TbGeom tg;
-  memset(&tg, 0, sizeof(tg));
-  tg.desc = d_sf; tg.C = (int)g->Cmax; tg.cb_stride = 768; tg.tb_stride = (int)tb_stride; tg.nof_sf = (int)nof_sf; tg.cw1_off = (int)B;
-  hipLaunchKernelGGL(tb_crc_bytes_kernel, dim3(nrows), dim3(256), 0, st, (const uint8_t*)g->d_cb_bytes, (const uint8_t*)g->d_cb_ok, d_tb, d_tb_ok, tg);
-  LAUNCH_CHECK();
-  return SRSLTE_SUCCESS;
+  return grants_back_end(g, bd, d_sf, d_cb, d_map, tti0, q->cfg.max_iterations, nrows, nof_sf, B, d_tb, tb_stride, d_tb_ok, st);
 }
 
 // ====================================================================================================================
