@@ -318,6 +318,7 @@ typedef struct {
                                      with srslte_uci_offset_cfg_t.I_offset_cqi (sch.c:1031-1060,:1133-1160, uci.c:264-494); 0 = none */
   uint32_t hopping, n_prb_slot1;  /* hopping != 0: intra-subframe hopping, slot 1 at PRB offset n_prb_slot1 (srslte_pusch_grant_t.n_prb[1] /
                                      n_prb_tilde[1]; pusch.c:52-91, chest_ul.c:244-266, refsignal_ul.c:316-346); 0: both slots at n_prb */
+  uint32_t max_grants;            /* srslte_hip_ul_rx_batch_grants: PUSCHs (= HARQ slots) per call; 0 = max_batch */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -330,6 +331,22 @@ int srslte_hip_ul_rx_batch(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti
  * combined nor decoded again. UCI is decoded afresh on every call. */
 int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data, uint8_t* d_tb,
                                 uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+/* Per-PUSCH grants (srslte_enb_ul_get_pusch once per scheduled UE after one srslte_enb_ul_fft per TTI, enb_ul.c:170-235): grants[p] names the
+ * subframe of the batch it was received in (several PUSCHs may share one, on disjoint PRBs), its allocation (srslte_pusch_grant_t.L_prb,
+ * n_prb_tilde[0 / 1]), n_dmrs, RNTI, modulation (1..3), transport block (<= cfg.tbs, no filler bits, one block size), redundancy version and
+ * new-data flag. Slot p of the object is that PUSCH's srslte_softbuffer_rx_t between calls (HARQ as srslte_hip_ul_rx_batch_harq). Rows p of
+ * d_tb / d_tb_ok. The object's cell, DMRS configuration, shortened flag, equaliser and pass limit apply; create it without UCI (this mode
+ * decodes UL-SCH data only) and with cfg.tbs = the largest transport block, cfg.max_grants >= nof_grants. */
+typedef struct {
+  uint32_t sf;                       /* 0 .. nof_sf-1 */
+  uint16_t rnti;
+  uint32_t L_prb, n_prb, n_prb_slot1, n_dmrs;
+  int      mod;
+  uint32_t tbs, rv;
+  int      new_data;
+} srslte_hip_ul_grant_t;
+int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
+                                  uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* Device pointer to the HARQ-ACK decisions of the last batch on this object, [max_batch][2] bytes (srslte_uci_value_t.ack.ack_value of
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);

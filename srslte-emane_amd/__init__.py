@@ -583,7 +583,17 @@ class UlRxCfg(C.Structure):
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
                 ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
                 ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32),
-                ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
+                ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32)]
+
+
+class UlGrant(C.Structure):
+    """srslte_hip_ul_grant_t: one PUSCH of a srslte_hip_ul_rx_batch_grants call."""
+    _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("n_dmrs", C.c_uint32),
+                ("mod", C.c_int), ("tbs", C.c_uint32), ("rv", C.c_uint32), ("new_data", C.c_int)]
+
+    @classmethod
+    def make(cls, sf, rnti, L_prb, n_prb, mod, tbs, n_dmrs=0, n_prb_slot1=None, rv=0, new_data=True):
+        return cls(sf, rnti, L_prb, n_prb, n_prb if n_prb_slot1 is None else n_prb_slot1, n_dmrs, mod, tbs, rv, 1 if new_data else 0)
 
 
 class UlRx:
@@ -591,10 +601,11 @@ class UlRx:
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
                  group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0,
-                 cqi_len=0, I_offset_cqi=0, n_prb_slot1=None):
+                 cqi_len=0, I_offset_cqi=0, n_prb_slot1=None, max_grants=0):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0,
+                           max_grants)
         L = lib()
         L.srslte_hip_ul_rx_ri.restype = C.c_void_p
         L.srslte_hip_ul_rx_ri.argtypes = [C.c_void_p]
@@ -616,14 +627,29 @@ class UlRx:
         self.tbs, self.max_batch = tbs, max_batch
         self.tb_stride = (tbs // 8 + 6 + 15) & ~15
         self.sf_len = 15 * symbol_sz(nof_prb)
-        self.d_tb, self.d_ok = DevBuf(self.tb_stride * max_batch), DevBuf(max_batch)
+        self.rows = max(max_batch, max_grants)
+        self.d_tb, self.d_ok = DevBuf(self.tb_stride * self.rows), DevBuf(self.rows)
+
+    def decode_grants(self, iq, tti0, grants):
+        """srslte_hip_ul_rx_batch_grants: grants = list of UlGrant; row p of the result belongs to grants[p]."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
+        din = DevBuf.from_host(x)
+        arr = (UlGrant * len(grants))(*grants)
+        L = lib()
+        L.srslte_hip_ul_rx_batch_grants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                                    C.c_void_p]
+        _check(L.srslte_hip_ul_rx_batch_grants(self.h, din.ptr, tti0, x.shape[0], arr, len(grants), self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None),
+               "ul_rx_batch_grants")
+        sync()
+        tb = self.d_tb.to_host(np.uint8).reshape(self.rows, self.tb_stride)[:len(grants)]
+        return tb, self.d_ok.to_host(np.uint8)[:len(grants)]
 
     def decode(self, iq, tti0=0):
         x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)
         din = DevBuf.from_host(x)
         _check(lib().srslte_hip_ul_rx_batch(self.h, din.ptr, tti0, x.shape[0], self.d_tb.ptr, self.tb_stride, self.d_ok.ptr, None), "ul_rx_batch")
         sync()
-        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        tb = self.d_tb.to_host(np.uint8).reshape(self.rows, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         self.last_nof_sf = x.shape[0]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
 
@@ -634,7 +660,7 @@ class UlRx:
         _check(lib().srslte_hip_ul_rx_batch_harq(self.h, din.ptr, tti0, x.shape[0], rv, 1 if new_data else 0, self.d_tb.ptr, self.tb_stride,
                                                  self.d_ok.ptr, None), "ul_rx_batch_harq")
         sync()
-        tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
+        tb = self.d_tb.to_host(np.uint8).reshape(self.rows, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         self.last_nof_sf = x.shape[0]
         return tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
 

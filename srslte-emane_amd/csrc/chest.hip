@@ -12,6 +12,7 @@
 // coalesced one RE per thread). chest_fill_res_kernel combines the per-(port, antenna) scalars the way fill_res does.
 #include "common.hpp"
 #include "phy_hip_internal.hpp"
+#include <map>
 #include <math.h>
 #include <vector>
 
@@ -837,12 +838,17 @@ struct ChestUlResDev { float noise_estimate, noise_estimate_dbm, snr, snr_db, cf
 // edge extrapolation of srslte_conv_same_cf (convolution.c:180-218), the result copied to the 7 symbols of its slot
 // (DO_LINEAR_INTERPOLATION is not defined upstream), noise from the difference smoothed - raw, SNR from the pilot power.
 // d_r: [10][2][12 * L_prb] DMRS of the grant per subframe index.
+// items != null (per-PUSCH grants): workgroup i estimates items[i] - its subframe of the batch, its PRB offsets, its result row - and all
+// items of one launch share L_prb and the DMRS table.
 __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __restrict__ grid, cf32* __restrict__ ce,
-                                                             ChestUlResDev* __restrict__ res, const cf32* __restrict__ d_r, ChestUlGeom g)
+                                                             ChestUlResDev* __restrict__ res, const cf32* __restrict__ d_r, ChestUlGeom g,
+                                                             const ChestUlItem* __restrict__ items)
 {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   __shared__ float red[CH_THREADS / 64];
-  const int   sf = blockIdx.x, sf_idx = (g.tti0 + sf) % 10, tid = threadIdx.x, nrefs = 12 * g.L_prb;
+  const int   sf = items ? items[blockIdx.x].sf : (int)blockIdx.x, row = items ? items[blockIdx.x].row : sf;
+  const int   n_prb0 = items ? items[blockIdx.x].n_prb : g.n_prb, n_prb1 = items ? items[blockIdx.x].n_prb1 : g.n_prb1;
+  const int   sf_idx = (g.tti0 + sf) % 10, tid = threadIdx.x, nrefs = 12 * g.L_prb;
   cf32*       est = reinterpret_cast<cf32*>(lds_raw); // [2][nrefs]
   const cf32* gs  = grid + (size_t)sf * 14 * g.cell_nre;
   cf32*       cs  = ce ? ce + (size_t)sf * 14 * g.cell_nre : nullptr;
@@ -850,7 +856,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
   float       pw  = 0.f;
   for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
     const int  s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
-    const cf32 y = gs[L * g.cell_nre + (s ? g.n_prb1 : g.n_prb) * 12 + k];
+    const cf32 y = gs[L * g.cell_nre + (s ? n_prb1 : n_prb0) * 12 + k];
     est[i]       = c_mulconj(y, r[i]);
     pw += y.x * y.x + y.y * y.y;
   }
@@ -876,7 +882,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
       o = c_add(c_add(c_scale(e[k - 1], f0), c_scale(e[k], f1)), c_scale(e[k + 1], f0));
     }
     if (cs) {
-      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + (s ? g.n_prb1 : g.n_prb) * 12 + k] = o;
+      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + (s ? n_prb1 : n_prb0) * 12 + k] = o;
     }
     const cf32 d = c_sub(o, e[k]);
     npw[s] += d.x * d.x + d.y * d.y;
@@ -892,7 +898,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
     o.snr_db             = (float)(10 * log10((double)o.snr));
     o.noise_estimate_dbm = (float)(10 * log10((double)o.noise_estimate) + 30);
     o.cfo                = 0.f;
-    res[sf]              = o;
+    res[row]             = o;
   }
 }
 
@@ -905,6 +911,8 @@ struct srslte_hip_chest_ul {
   // device DMRS of the grant last used: [10][2][12 * L_prb]
   cf32*    d_r;
   uint32_t r_L, r_n_dmrs;
+  // per-PUSCH grants: every (L_prb, n_dmrs) seen so far keeps its table (srslte_chest_ul_pregen holds all of them at once, refsignal_ul.c:420-457)
+  std::map<std::pair<uint32_t, uint32_t>, cf32*>* tables;
 };
 
 extern "C" srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, uint32_t nof_prb, int cp_is_norm, const srslte_hip_dmrs_pusch_cfg_t* cfg)
@@ -919,6 +927,7 @@ extern "C" srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, u
   q->cfg     = *cfg;
   q->d_r     = nullptr;
   q->r_L = q->r_n_dmrs = 0xffffffffu;
+  q->tables = new std::map<std::pair<uint32_t, uint32_t>, cf32*>();
   std::vector<uint8_t> c;
   for (uint32_t ds = 0; ds < 30; ds++) { // generate_n_prs :118-141 and generate_srslte_sequence_hopping_v :149-163 share the seed
     gold(((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30), 8 * 7 * 20, c);
@@ -941,6 +950,8 @@ extern "C" void srslte_hip_chest_ul_destroy(srslte_hip_chest_ul_t* q)
 {
   if (!q) return;
   if (q->d_r) (void)hipFree(q->d_r);
+  for (auto& kv : *q->tables) (void)hipFree(kv.second);
+  delete q->tables;
   delete q;
 }
 
@@ -997,6 +1008,32 @@ int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmr
   return SRSLTE_SUCCESS;
 }
 
+// Per-PUSCH grants: n_items PUSCHs of one (L_prb, n_dmrs) - d_items[i] names the subframe of the batch, the PRB offset of each slot and the row
+// of d_res of PUSCH i - in one launch. The table of (L_prb, n_dmrs) is made on first use and kept.
+int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_dmrs, const ChestUlItem* d_items, int n_items,
+                            const void* d_grid, void* d_ce, void* d_res, hipStream_t st)
+{
+  if (!q || !d_grid || !d_items || n_items < 0 || L_prb == 0 || L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (n_items == 0) return SRSLTE_SUCCESS;
+  auto it = q->tables->find({L_prb, n_dmrs});
+  if (it == q->tables->end()) {
+    std::vector<cf32> r((size_t)10 * 2 * 12 * L_prb);
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      if (int rc = srslte_hip_refsignal_dmrs_pusch_gen(q, L_prb, sf, n_dmrs, r.data() + (size_t)sf * 2 * 12 * L_prb)) return rc;
+    }
+    cf32* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(cf32) * r.size()));
+    HIP_TRY(hipMemcpy(d, r.data(), sizeof(cf32) * r.size(), hipMemcpyHostToDevice));
+    it = q->tables->emplace(std::make_pair(L_prb, n_dmrs), d).first;
+  }
+  ChestUlGeom g;
+  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = 0; g.n_prb1 = 0; g.tti0 = (int)tti0; g.w = 0.3333f;
+  hipLaunchKernelGGL(chest_ul_kernel, dim3(n_items), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, st, (const cf32*)d_grid, (cf32*)d_ce,
+                     (ChestUlResDev*)d_res, (const cf32*)it->second, g, d_items);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
 // d_grid: [nof_sf][14][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
 // d_res: [nof_sf] srslte_hip_chest_ul_res_t or NULL. Same grant (L_prb, n_prb in both slots, n_dmrs) for every subframe of the batch.
 extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
@@ -1021,7 +1058,7 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch_hop(srslte_hip_chest_ul_
   ChestUlGeom g;
   g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.n_prb1 = (int)n_prb_slot1; g.tti0 = (int)tti0; g.w = 0.3333f;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(nof_sf), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, (hipStream_t)stream, (const cf32*)d_grid,
-                     (cf32*)d_ce, (ChestUlResDev*)d_res, (const cf32*)q->d_r, g);
+                     (cf32*)d_ce, (ChestUlResDev*)d_res, (const cf32*)q->d_r, g, (const ChestUlItem*)nullptr);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }

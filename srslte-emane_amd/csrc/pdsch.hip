@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "demod_dev.hpp"
 #include "phy_hip_internal.hpp"
+#include <algorithm>
 #include <map>
 #include <math.h>
 #include <string.h>
@@ -1970,20 +1971,19 @@ __global__ __launch_bounds__(256) void pusch_eq_kernel(const cf32* __restrict__ 
 // bit order and store at the de-interleaved position g[(k * 12 + n) * Qm + b] = q[(n * M_sc + k) * Qm + b] (36.212 5.2.2.8 without
 // UCI). The 64 x 12 x Qm LLRs of a workgroup are contiguous in g: they are collected in LDS and leave with 16-byte stores
 // (a 2-byte store per lane at a 24 Qm byte stride costs the L1 one cache line per lane).
-__global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict__ d, const uint32_t* __restrict__ scr, int16_t* __restrict__ gout,
-                                                          PuschGeom g)
+// d: the PUSCH's de-precoded symbols [nsymb][M_sc]; cs: its scrambling bits; gout: its LLR row; sf: its row of the UCI accumulators
+__device__ __forceinline__ void pusch_demod_body(const cf32* __restrict__ d, const uint32_t* __restrict__ cs, int16_t* __restrict__ gout, const PuschGeom& g,
+                                                 int sf, int k0, int16_t* stage)
 {
-  __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
-  const int k0 = blockIdx.x * 64, sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = g.nsymb * g.M_sc;
+  const int nsym = g.nsymb * g.M_sc;
   const int nk = min(64, g.M_sc - k0);
   const int rb0 = ri_before(g.ri, 0, k0, g.M_sc, g.nsymb); // RI symbols on the sub-carriers before this workgroup's
-  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words; // one spare word behind every sequence
   for (int t = threadIdx.x; t < 64 * g.nsymb; t += 256) {
     const int n = t >> 6, kl = t & 63;
     if (kl >= nk) continue;
     const int i = n * g.M_sc + k0 + kl;
     short     o[8];
-    demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
+    demod_dev::demod_s(g.mod, d[i], i, nsym, o);
     const int      bit0 = i * g.Qm;
     const uint32_t c2   = (uint32_t)((((uint64_t)cs[(bit0 >> 5) + 1] << 32) | cs[bit0 >> 5]) >> (bit0 & 31));
     const int      ai   = ack_symbol_index(g.ack, n, k0 + kl, g.M_sc, g.nsymb);
@@ -2021,14 +2021,14 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
     // 1-bit decoder has re-scrambled its repetition bit by then (uci.c:632-633)
     const int n = g.ri.Qprime >= 2 ? (g.nsymb > 10 ? 10 : 8) : (g.nsymb > 10 ? 1 : 0), i = n * g.M_sc + g.M_sc - 1, bit = i * g.Qm + g.Qm - 1;
     short     o[8];
-    demod_dev::demod_s(g.mod, d[(size_t)sf * nsym + i], i, nsym, o);
+    demod_dev::demod_s(g.mod, d[i], i, nsym, o);
     const int cbit = (cs[bit >> 5] >> (bit & 31)) & 1;
     stage[0]       = (g.ri.O == 1 && g.Qm == 2) ? o[1] : (cbit ? (short)-o[g.Qm - 1] : o[g.Qm - 1]);
     __threadfence_block();
   }
   if (g.ri.O && k0 == 0) __syncthreads();
   const int    nsl    = nk * g.nsymb - (ri_before(g.ri, 0, k0 + nk, g.M_sc, g.nsymb) - rb0); // UL-SCH symbols of this workgroup
-  const size_t first  = (size_t)sf * nsym * g.Qm + (size_t)(k0 * g.nsymb - rb0) * g.Qm;
+  const size_t first  = (size_t)(k0 * g.nsymb - rb0) * g.Qm;
   if (g.ri.O == 0 || (rb0 == 0 && nsl == nk * g.nsymb)) {
     const int    nbytes = nk * g.nsymb * g.Qm * 2; // nk is a multiple of 4, Qm even: a multiple of 16
     char*        dst    = reinterpret_cast<char*>(gout + first);
@@ -2037,6 +2037,55 @@ __global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict
   } else { // the few workgroups that hold RI symbols: neither the length nor the start is 16-byte granular any more
     for (int e = threadIdx.x; e < nsl * g.Qm; e += 256) gout[first + e] = stage[e];
   }
+}
+
+
+__global__ __launch_bounds__(256) void pusch_demod_kernel(const cf32* __restrict__ d, const uint32_t* __restrict__ scr, int16_t* __restrict__ gout,
+                                                          PuschGeom g)
+{
+  __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
+  const int sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nsym = g.nsymb * g.M_sc;
+  pusch_demod_body(d + (size_t)sf * nsym, scr + (size_t)sf_idx * g.scr_words /* one spare word behind every sequence */, gout + (size_t)sf * nsym * g.Qm, g, sf,
+                   blockIdx.x * 64, stage);
+}
+
+// Per-PUSCH grants (srslte_hip_ul_rx_batch_grants): PUSCH p of a call has its own allocation, modulation and sequence; its symbols sit at zoff in
+// the z / d buffers (PUSCHs of one L_prb next to each other, for the batched transform de-precoding), its LLRs in row p.
+struct PuschDesc {
+  int sf;                        // subframe of the batch whose grid it is in
+  int M_sc, n_prb, n_prb1, mod, Qm;
+  int zoff;                      // in cf32
+  AckGeom ack, ri;
+};
+
+// grid = (ceil(max M_sc / 256), nsymb, nof_pusch)
+__global__ __launch_bounds__(256) void pusch_eq_grants_kernel(const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                              const float* __restrict__ noise /* stride 5 floats */, cf32* __restrict__ z,
+                                                              const PuschDesc* __restrict__ desc, int cell_nre, int nsymb, int mmse)
+{
+  const PuschDesc& pd = desc[blockIdx.z];
+  const int        k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, M_sc = pd.M_sc;
+  if (k >= M_sc) return;
+  const int    l  = pusch_data_symbol(n);
+  const size_t o  = ((size_t)pd.sf * 14 + l) * cell_nre + (l < 7 ? pd.n_prb : pd.n_prb1) * 12 + k;
+  const cf32   y = grid[o], h = ce[o];
+  const float  n0 = mmse ? noise[blockIdx.z * 5] : 0.f;
+  const float  re = y.x * h.x + y.y * h.y, im = y.y * h.x - y.x * h.y, csi = h.x * h.x + h.y * h.y + n0; // precoding.c:277-288, scaling 1
+  z[(size_t)pd.zoff + (size_t)n * M_sc + k] = make_float2(re * 1.0f / csi, im * 1.0f / csi);
+}
+
+// grid = (ceil(max M_sc / 64), nof_pusch)
+__global__ __launch_bounds__(256) void pusch_demod_grants_kernel(const cf32* __restrict__ d, const uint32_t* __restrict__ scr, int scr_words,
+                                                                 int16_t* __restrict__ gout, int max_bits, const PuschDesc* __restrict__ desc, int nsymb,
+                                                                 int* __restrict__ ack_sum, int* __restrict__ ri_sum)
+{
+  __shared__ __attribute__((aligned(16))) int16_t stage[64 * 12 * 8];
+  const int p = blockIdx.y, k0 = blockIdx.x * 64;
+  if (k0 >= desc[p].M_sc) return;
+  PuschGeom g; // a local, not the kernel argument: filled from the descriptor
+  g.cell_nre = 0; g.M_sc = desc[p].M_sc; g.n_prb = desc[p].n_prb; g.n_prb1 = desc[p].n_prb1; g.mod = desc[p].mod; g.Qm = desc[p].Qm; g.tti0 = 0;
+  g.scr_words = scr_words; g.mmse = 0; g.ack = desc[p].ack; g.ri = desc[p].ri; g.ack_sum = ack_sum; g.ri_sum = ri_sum; g.nsymb = nsymb;
+  pusch_demod_body(d + desc[p].zoff, scr + (size_t)p * scr_words, gout + (size_t)p * max_bits, g, p, k0, stage);
 }
 
 } // namespace
@@ -2236,6 +2285,10 @@ struct srslte_hip_ul_rx {
   uint8_t*               d_ack;     // [B][2] HARQ-ACK decisions of the last call, then [B][2] rank indications
   uint8_t*               d_cqi;     // [B][64] CQI report bits of the last call, then [B] CRC flags
   int                    Qp_cqi;
+  // srslte_hip_ul_rx_batch_grants (created on first use): the shared grants machinery with one slot per PUSCH, plus the PUSCH front end's buffers
+  struct GrantsState*    gs;
+  cf32 *                 g_z, *g_d; // [max_grants][nsymb * 12 * nof_prb]
+  float*                 g_res;     // [max_grants] x srslte_hip_chest_ul_res_t
 };
 
 extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
@@ -2250,10 +2303,11 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
                   q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi,
-                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3]};
+                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3], q->g_z, q->g_d, q->g_res};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
+  grants_free(q->gs);
   delete q;
 }
 
@@ -2376,6 +2430,11 @@ extern "C" const void* srslte_hip_ul_rx_debug_buffer(const srslte_hip_ul_rx_t* q
     case 8: return q->d_cb_bytes;
     case 9: return q->d_z;
     case 10: return q->d_ack;
+    // per-PUSCH grants mode: estimator results, de-precoded symbols (at each PUSCH's offset), LLR rows, pass counts per block slot
+    case 20: return q->g_res;
+    case 21: return q->g_d;
+    case 22: return q->gs ? q->gs->d_e : nullptr;
+    case 23: return q->gs ? q->gs->d_cb_iters : nullptr;
   }
   return nullptr;
 }
@@ -2472,6 +2531,116 @@ extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_
   }
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
+}
+
+// Per-PUSCH grants: what an eNB receives in a run of TTIs - any number of PUSCHs per subframe, each with its own allocation (L_prb, PRB offset per
+// slot), DMRS cyclic shift, RNTI, modulation, transport block and redundancy version (srslte_enb_ul_get_pusch called once per scheduled UE,
+// enb_ul.c:200-235, after one srslte_enb_ul_fft per TTI). The OFDM demodulation runs once per subframe; estimator, equaliser and demapper take
+// their geometry from per-PUSCH descriptors, the transform de-precoding runs once per distinct L_prb (PUSCHs of one size sit next to each other
+// in the symbol buffers), and from the LLRs on it is the downlink's grants machinery with one slot per PUSCH: slot p = grants[p] keeps soft
+// buffers, CRC flags and bytes between calls (HARQ as srslte_hip_ul_rx_batch_harq). UL-SCH data only: no UCI in this mode yet.
+extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
+                                             uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
+  const uint32_t V = q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch, P = q->cfg.nof_prb;
+  if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->cfg.ack_len || q->cfg.ri_len || q->cfg.cqi_len) {
+    hip_log("[srslte_hip] ul_rx grants mode: create the object without UCI; this mode decodes UL-SCH data only\n");
+    return SRSLTE_ERROR;
+  }
+  if (nof_sf == 0 || nof_grants == 0) return SRSLTE_SUCCESS;
+  hipStream_t    st    = (hipStream_t)stream;
+  const uint32_t nsymb = (uint32_t)q->pg.nsymb, max_re = nsymb * 12 * P;
+  if (!q->gs) {
+    q->gs = new GrantsState();
+    if (grants_alloc(q->gs, 12 * 12 * P, V, q->seg.C, 0, false, (sizeof(PuschDesc) + sizeof(ChestUlItem)) * V)) return SRSLTE_ERROR;
+    HIP_TRY(hipMalloc((void**)&q->g_z, sizeof(cf32) * (size_t)max_re * V));
+    HIP_TRY(hipMalloc((void**)&q->g_d, sizeof(cf32) * (size_t)max_re * V));
+    HIP_TRY(hipMalloc((void**)&q->g_res, sizeof(float) * 5 * V));
+  }
+  GrantsState*   g    = q->gs;
+  const size_t   nblk = (size_t)V * g->Cmax;
+  const uint32_t hs   = g->h_slot++ & 3u;
+  if (g->h_used[hs]) HIP_TRY(hipEventSynchronize(g->h_ev[hs])); // the copy that last read this buffer (four calls ago) has completed
+  auto* h_gr = reinterpret_cast<GrantDev*>(g->h_pin[hs]);
+  auto* h_sf = reinterpret_cast<SfDesc*>(h_gr + V);
+  auto* h_cb = reinterpret_cast<CbDesc*>(h_sf + V);
+  auto* h_map = reinterpret_cast<uint32_t*>(h_cb + nblk);
+  auto* h_pd = reinterpret_cast<PuschDesc*>(h_map + nblk);
+  auto* h_it = reinterpret_cast<ChestUlItem*>(h_pd + V);
+  auto* d_gr = reinterpret_cast<GrantDev*>(g->d_desc);
+  auto* d_sf = reinterpret_cast<SfDesc*>(d_gr + V);
+  auto* d_cb = reinterpret_cast<CbDesc*>(d_sf + V);
+  auto* d_map = reinterpret_cast<uint32_t*>(d_cb + nblk);
+  auto* d_pd = reinterpret_cast<PuschDesc*>(d_map + nblk);
+  auto* d_it = reinterpret_cast<ChestUlItem*>(d_pd + V);
+  GrantsBuild bd;
+  bd.g = g; bd.h_sf = h_sf; bd.h_cb = h_cb; bd.l8 = false; bd.max_tbs = q->cfg.tbs; bd.npt = 1; bd.max_mod = 3; bd.who = "ul_rx";
+  // PUSCHs in the order (L_prb, n_dmrs): one estimator launch per (L_prb, n_dmrs), one de-precoding launch per L_prb
+  std::vector<uint32_t> order(nof_grants);
+  for (uint32_t p = 0; p < nof_grants; p++) order[p] = p;
+  uint32_t max_M = 0;
+  for (uint32_t p = 0; p < nof_grants; p++) {
+    const srslte_hip_ul_grant_t& gr = grants[p];
+    if (gr.sf >= nof_sf || gr.L_prb == 0 || !srslte_hip_dft_precoding_valid_prb(gr.L_prb) || gr.n_prb + gr.L_prb > P || gr.n_prb_slot1 + gr.L_prb > P ||
+        gr.n_dmrs >= 8) {
+      hip_log("[srslte_hip] ul_rx grants: entry %u: invalid allocation (subframe %u of %u, L_prb %u at %u / %u of %u PRB, n_dmrs %u)\n", p, gr.sf, nof_sf, gr.L_prb,
+              gr.n_prb, gr.n_prb_slot1, P, gr.n_dmrs);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    max_M = 12 * gr.L_prb > max_M ? 12 * gr.L_prb : max_M;
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    return grants[a].L_prb != grants[b].L_prb ? grants[a].L_prb < grants[b].L_prb : grants[a].n_dmrs < grants[b].n_dmrs;
+  });
+  uint32_t zoff = 0;
+  for (uint32_t i = 0; i < nof_grants; i++) {
+    const uint32_t               p  = order[i];
+    const srslte_hip_ul_grant_t& gr = grants[p];
+    GrantDev&                    gd = h_gr[p];
+    memset(&gd, 0, sizeof(gd));
+    memset(&h_sf[p], 0, sizeof(SfDesc));
+    gd.sf_idx = (int)((tti0 + gr.sf) % 10); gd.rnti = gr.rnti; // srslte_sequence_pusch (sequences.c:65-67): the PDSCH's c_init with q = 0
+    h_sf[p].scr = g->d_scr + (size_t)p * g->words;
+    PuschDesc& pd = h_pd[p];
+    memset(&pd, 0, sizeof(pd));
+    pd.sf = (int)gr.sf; pd.M_sc = 12 * (int)gr.L_prb; pd.n_prb = (int)gr.n_prb; pd.n_prb1 = (int)gr.n_prb_slot1; pd.mod = gr.mod; pd.Qm = 2 * gr.mod;
+    pd.zoff = (int)zoff;
+    zoff += nsymb * 12 * gr.L_prb;
+    h_it[i].sf = (int)gr.sf; h_it[i].n_prb = (int)gr.n_prb; h_it[i].n_prb1 = (int)gr.n_prb_slot1; h_it[i].row = (int)p;
+    if (int r = bd.add_tb(p, p, gr.mod, gr.tbs, gr.rv, gr.new_data, nsymb * 12 * gr.L_prb, 1)) return r;
+  }
+  bd.fill_map(h_map);
+  int r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
+  if (r) return r;
+  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_pin[hs], g->desc_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(g->h_ev[hs], st));
+  g->h_used[hs] = true;
+  for (uint32_t i = 0; i < nof_grants;) { // estimator: runs of equal (L_prb, n_dmrs)
+    uint32_t j = i + 1;
+    while (j < nof_grants && grants[order[j]].L_prb == grants[order[i]].L_prb && grants[order[j]].n_dmrs == grants[order[i]].n_dmrs) j++;
+    r = chest_ul_estimate_items(q->chest, tti0, grants[order[i]].L_prb, grants[order[i]].n_dmrs, d_it + i, (int)(j - i), q->d_grid, q->d_ce, q->g_res, st);
+    if (r) return r;
+    i = j;
+  }
+  hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_grants), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis, g->d_scr,
+                     (int)g->words, (int)q->cfg.cell_id);
+  hipLaunchKernelGGL(pusch_eq_grants_kernel, dim3(ceil_div((int)max_M, 256), nsymb, nof_grants), dim3(256), 0, st, (const cf32*)q->d_grid, (const cf32*)q->d_ce,
+                     (const float*)q->g_res, q->g_z, (const PuschDesc*)d_pd, 12 * (int)P, (int)nsymb, q->cfg.mmse);
+  LAUNCH_CHECK();
+  for (uint32_t i = 0; i < nof_grants;) { // inverse transform precoding: runs of equal L_prb (srslte_dft_precoding_init_rx: inverse, 1/sqrt(N))
+    uint32_t j = i + 1;
+    while (j < nof_grants && grants[order[j]].L_prb == grants[order[i]].L_prb) j++;
+    const size_t off = (size_t)h_pd[order[i]].zoff;
+    r = srslte_hip_dft_precoding_batch(q->g_z + off, q->g_d + off, grants[order[i]].L_prb, nsymb * (j - i), 0, stream);
+    if (r) return r;
+    i = j;
+  }
+  hipLaunchKernelGGL(pusch_demod_grants_kernel, dim3(ceil_div((int)max_M, 64), nof_grants), dim3(256), 0, st, (const cf32*)q->g_d, (const uint32_t*)g->d_scr,
+                     (int)g->words, g->d_e, (int)g->max_bits, (const PuschDesc*)d_pd, (int)nsymb, (int*)nullptr, (int*)nullptr);
+  LAUNCH_CHECK();
+  return grants_back_end(g, bd, d_sf, d_cb, d_map, tti0, q->cfg.max_iterations, nof_grants, nof_grants, 0, d_tb, tb_stride, d_tb_ok, st);
 }
 
 // ====================================================================================================================

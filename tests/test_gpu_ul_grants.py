@@ -1,0 +1,183 @@
+"""Per-PUSCH grants on the uplink (srslte_hip_ul_rx_batch_grants): a run of TTIs in which every subframe carries several PUSCHs of different
+UEs - own allocation, DMRS cyclic shift, RNTI, modulation, transport block, redundancy version - against the oracle's eNB chain run once per
+PUSCH on the same time samples (the chain tests/test_oracle_vs_ref.py pins to the reference's srslte_chest_ul_estimate_pusch and
+srslte_pusch_decode stages)."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hp():
+    return importlib.import_module("srslte-emane_amd")
+
+
+def close_c(a, b, what, tol=1e-4):
+    a, b = np.asarray(a).ravel(), np.asarray(b).ravel()
+    ref = max(np.abs(b).max(), np.sqrt((np.abs(b) ** 2).mean()))
+    assert np.abs(a - b).max() <= tol * ref, what
+
+
+# (L_prb, n_prb, n_prb_slot1, mod, tbs, n_dmrs, snr_db) per PUSCH; lists per subframe. TBS values: no filler bits, one code-block size.
+UE_SETS_25 = [
+    [(10, 0, 0, 2, 4008, 0, 9.5), (6, 12, 12, 1, 1000, 3, 5.0), (3, 20, 20, 1, 328, 5, 4.0)],
+    [(25, 0, 0, 2, 4008, 1, 3.0)],
+    [(1, 7, 7, 1, 104, 2, 8.0), (12, 8, 8, 3, 7992, 7, 17.0), (1, 24, 24, 1, 104, 4, 8.0), (4, 20, 20, 2, 1544, 6, 9.5)],
+    [(10, 2, 13, 2, 4008, 0, 9.5), (2, 12, 0, 1, 328, 1, 5.0)],  # intra-subframe hopping: the two swap ends between the slots
+]
+UE_SETS_100 = [
+    [(48, 0, 0, 3, 30576, 0, 16.5), (48, 50, 50, 2, 22152, 3, 11.0)],
+    [(96, 2, 2, 3, 61664, 5, 18.5)],
+    [(25, 0, 0, 2, 4008, 1, 3.0), (50, 25, 25, 3, 30576, 2, 16.0), (20, 80, 80, 1, 2216, 4, 2.5)],
+]
+
+
+@pytest.mark.parametrize("prb,sets,tti0", [(25, UE_SETS_25, 7), (100, UE_SETS_100, 18)])
+def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
+    """Every PUSCH: estimator noise figure, de-precoded symbols, de-interleaved LLRs (<= 1 LSB on <= 0.1 %), per-block pass counts, CRC flag
+    and bytes equal the oracle's for that UE on the summed time signal of its subframe."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(4100 + prb)
+    nsf = len(sets)
+    dm = dict(cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=False)
+    iq, ues, grants = [], [], []
+    for b, ue_list in enumerate(sets):
+        x, sig = None, []
+        for u, (L, n0, n1, mod, tbs, n_dmrs, snr) in enumerate(ue_list):
+            rnti = 0x100 + 16 * b + u
+            cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=rnti, n_prb_slot1=n1 if n1 != n0 else None, **dm)
+            gain = (0.7 + 0.1 * u) * np.exp(0.3j * (u + 1))
+            y, data = make_ul_subframe(cfg, tti0 + b, rng, amp=0.1, gain=gain)
+            sig.append(np.sqrt(0.01 * abs(gain) ** 2 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr / 20))  # the noise level that gives this UE `snr` per RE
+            x = y if x is None else x + y
+            ues.append((b, cfg, data))
+            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1))
+        x = x + min(sig) * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))  # one receiver noise: every UE at its SNR or better
+        iq.append(x.astype(np.complex64))
+    max_tbs = max(g.tbs for g in grants)
+    rx = hp.UlRx(11, prb, 0x1234, 1, max_tbs, 6, 0, 0, 6, nsf, 2, 5, True, False, max_grants=len(grants))
+    tb, ok = rx.decode_grants(np.stack(iq), tti0, grants)
+    n = len(grants)
+    res = rx.debug(20, np.float32, n * 5).reshape(n, 5)
+    Cmax = -(-max_tbs // 6120) if max_tbs > 6120 else 1
+    n_ok = 0
+    zoff_of = {}
+    order = sorted(range(n), key=lambda p: (grants[p].L_prb, grants[p].n_dmrs))
+    off = 0
+    for p in order:
+        zoff_of[p] = off
+        off += 12 * 12 * grants[p].L_prb
+    d_all = rx.debug(21, np.complex64, off)
+    e_rows = rx.debug(22, np.int16, n * ((12 * 12 * prb * 8 + 15) & ~15)).reshape(n, -1)
+    for p, (b, cfg, data) in enumerate(ues):
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True)
+        assert abs(res[p, 0] - r["noise"]) <= 1e-4 * abs(r["noise"]), p
+        close_c(d_all[zoff_of[p]:zoff_of[p] + cfg.nof_re], r["d"], "d of PUSCH %d" % p)
+        diff = np.abs(e_rows[p][:cfg.nbits].astype(np.int32) - r["g"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size, p
+        if diff.max() == 0 or r["ok"]:
+            assert bool(ok[p]) == r["ok"], p
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[p][:cfg.tbs // 8 + 3], r["tb"]) and np.array_equal(tb[p][:cfg.tbs // 8], data), p
+    assert n_ok >= n - 2, (n_ok, n)
+    rx.free()
+
+
+def test_ul_grants_harq_and_changing_grants(hp):
+    """Slot p of the object is PUSCH p's soft buffer across calls: a first call whose transmissions fail, a second with rv 2 in other subframes
+    and - for one UE - other PRBs (adaptive retransmission: same transport block, new allocation size is not allowed, new position is);
+    verdicts, pass counts and bytes per transmission equal the oracle's OrcHarq chain; then the slots are re-used for new transport blocks
+    of other sizes (new_data)."""
+    from lte_sim import OrcHarq, UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(4300)
+    prb, dm = 50, dict(cyclic_shift=1, delta_ss=3, group_hopping=False, sequence_hopping=False)
+    # L, n_prb, mod, tbs, n_dmrs, snr (of the time signal: per RE it is 10 log10(N / M_sc) higher), ~2 dB under what a single transmission needs
+    ue = [(20, 0, 2, 7736, 0, 2.7), (24, 20, 3, 15264, 3, 8.7), (5, 45, 1, 776, 6, -11.0)]
+    rx = hp.UlRx(5, prb, 0x1234, 1, 15264, 6, 0, 0, 6, 4, 1, 3, False, False, max_grants=3)
+    harq, data = [None] * 3, [None] * 3
+    n_first_fail, n_retx_ok, inexact, done = 0, 0, [False] * 3, [False] * 3
+    for n, (rv, tti0, sfs, shift) in enumerate(((0, 3, (0, 1, 2), 0), (2, 11, (2, 1, 1), 1))):
+        iq, sig = [np.zeros(rx.sf_len, np.complex128) for _ in range(3)], [[] for _ in range(3)]
+        grants, cfgs = [], []
+        for u, (L, n0, mod, tbs, n_dmrs, snr) in enumerate(ue):
+            n0 = n0 + (shift if u == 0 else 0) * 3
+            cfg = UlConfig(prb, 5, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=0x200 + u, **dm)
+            if harq[u] is None:
+                harq[u] = OrcHarq(cfg)
+            y, data[u] = make_ul_subframe(cfg, tti0 + sfs[u], rng, amp=0.1, rv=rv, data=data[u])
+            iq[sfs[u]] = iq[sfs[u]] + y
+            sig[sfs[u]].append(np.sqrt(0.01 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr / 20))
+            cfgs.append(cfg)
+            grants.append(hp.UlGrant.make(sfs[u], 0x200 + u, L, n0, mod, tbs, n_dmrs=n_dmrs, rv=rv, new_data=n == 0))
+        for b in range(3):
+            if sig[b]:
+                iq[b] = iq[b] + min(sig[b]) * (rng.standard_normal(rx.sf_len) + 1j * rng.standard_normal(rx.sf_len))
+        x = np.stack(iq).astype(np.complex64)
+        tb, ok = rx.decode_grants(x, tti0, grants)
+        e_rows = rx.debug(22, np.int16, 3 * ((12 * 12 * prb * 8 + 15) & ~15)).reshape(3, -1)
+        for u, cfg in enumerate(cfgs):
+            if done[u]:
+                continue  # an acknowledged block is not scheduled again (and the reference keeps no bytes of it, sch.c:393-403)
+            r = oracle_ul_rx(cfg, x[sfs[u]], tti0 + sfs[u], keep=True, harq=harq[u], rv=rv, new_data=n == 0)
+            diff = np.abs(e_rows[u][:cfg.nbits].astype(np.int32) - r["g"].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size, (n, u)
+            inexact[u] = inexact[u] or diff.max() != 0  # an LLR one LSB off may turn a marginal block's verdict
+            if inexact[u] and bool(ok[u]) != r["ok"]:
+                continue
+            assert bool(ok[u]) == r["ok"], (n, u, int(diff.max()))
+            n_first_fail += n == 0 and not r["ok"]
+            if r["ok"]:
+                assert np.array_equal(tb[u][:cfg.tbs // 8 + 3], r["tb"]) and np.array_equal(tb[u][:cfg.tbs // 8], data[u])
+                n_retx_ok += n > 0
+                done[u] = True
+    assert n_first_fail >= 1 and n_retx_ok >= 1, (n_first_fail, n_retx_ok)
+    # new transport blocks of other sizes in the same slots
+    ue2 = [(8, 10, 1, 1256, 2, 6.0), (30, 20, 2, 12216, 5, 12.0)]
+    iq, grants, exp = np.zeros((1, rx.sf_len), np.complex64), [], []
+    for u, (L, n0, mod, tbs, n_dmrs, snr) in enumerate(ue2):
+        cfg = UlConfig(prb, 5, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=0x300 + u, **dm)
+        y, d = make_ul_subframe(cfg, 29, rng, snr_db=snr, amp=0.1)
+        iq[0] += y
+        grants.append(hp.UlGrant.make(0, 0x300 + u, L, n0, mod, tbs, n_dmrs=n_dmrs))
+        exp.append((cfg, d))
+    tb, ok = rx.decode_grants(iq, 29, grants)
+    for u, (cfg, d) in enumerate(exp):
+        r = oracle_ul_rx(cfg, iq[0], 29)
+        assert r["ok"] and ok[u] and np.array_equal(tb[u][:cfg.tbs // 8], d), u
+    rx.free()
+
+
+def test_ul_grants_equal_fixed_pipeline(hp):
+    """The same grant in every subframe through both entry points: identical bytes and flags."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(4500)
+    prb, L, n0, mod, tbs, nsf = 25, 10, 5, 2, 4008, 6
+    cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=True)
+    iq = np.stack([make_ul_subframe(cfg, 4 + b, rng, snr_db=9.0, amp=0.1)[0] for b in range(nsf)])
+    rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n0, 3, 6, nsf, 2, 5, True, True)
+    tb0, ok0 = rx.decode(iq, 4)
+    tb1, ok1 = rx.decode_grants(iq, 4, [hp.UlGrant.make(b, 0x1234, L, n0, mod, tbs, n_dmrs=3) for b in range(nsf)])
+    assert np.array_equal(ok0, ok1) and np.array_equal(tb0, tb1[:, :tbs // 8 + 3]) and 0 < ok0.sum()
+    rx.free()
+
+
+def test_ul_grants_argument_errors(hp):
+    import ctypes as C
+    rx = hp.UlRx(1, 25, 0x1234, 2, 4008, 10, 5, 0, 6, 2, max_grants=2)
+    iq = np.zeros((2, rx.sf_len), np.complex64)
+    G = hp.UlGrant.make
+    for bad in ([G(2, 1, 10, 0, 2, 4008)], [G(0, 1, 7, 0, 2, 4008)], [G(0, 1, 10, 16, 2, 4008)], [G(0, 1, 10, 0, 4, 4008)], [G(0, 1, 10, 0, 2, 4016)],
+                [G(0, 1, 10, 0, 2, 6200)], [G(0, 1, 10, 0, 2, 4008, n_dmrs=8)], [G(0, 1, 10, 0, 2, 4008, rv=4)], [G(0, 1, 10, 0, 2, 4008)] * 3):
+        with pytest.raises(RuntimeError):
+            rx.decode_grants(iq, 0, bad)
+    tb, ok = rx.decode_grants(iq, 0, [])
+    assert len(ok) == 0
+    rx.free()
+    rx = hp.UlRx(1, 25, 0x1234, 2, 4008, 10, 5, 0, 6, 2, ack_len=1, I_offset_ack=5)
+    with pytest.raises(RuntimeError):
+        rx.decode_grants(iq, 0, [G(0, 1, 10, 0, 2, 4008)])
+    rx.free()
