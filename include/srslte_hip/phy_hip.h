@@ -335,8 +335,9 @@ int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_
  * subframe of the batch it was received in (several PUSCHs may share one, on disjoint PRBs), its allocation (srslte_pusch_grant_t.L_prb,
  * n_prb_tilde[0 / 1]), n_dmrs, RNTI, modulation (1..3), transport block (<= cfg.tbs, no filler bits, one block size), redundancy version and
  * new-data flag. Slot p of the object is that PUSCH's srslte_softbuffer_rx_t between calls (HARQ as srslte_hip_ul_rx_batch_harq). Rows p of
- * d_tb / d_tb_ok. The object's cell, DMRS configuration, shortened flag, equaliser and pass limit apply; create it without UCI (this mode
- * decodes UL-SCH data only) and with cfg.tbs = the largest transport block, cfg.max_grants >= nof_grants. */
+ * d_tb / d_tb_ok. The object's cell, DMRS configuration, shortened flag, equaliser and pass limit apply (its own grant and UCI fields are those of
+ * the fixed pipeline and play no part here); cfg.tbs = the largest transport block, cfg.max_grants >= nof_grants. HARQ-ACK and rank indication
+ * per PUSCH (decisions: srslte_hip_ul_rx_grants_ack / _ri, [max_grants][2] device bytes each, row p); CQI reports are not decoded in this mode. */
 typedef struct {
   uint32_t sf;                       /* 0 .. nof_sf-1 */
   uint16_t rnti;
@@ -344,9 +345,13 @@ typedef struct {
   int      mod;
   uint32_t tbs, rv;
   int      new_data;
+  uint32_t ack_len, I_offset_ack; /* 0..2 HARQ-ACK bits on this PUSCH and their offset index (as the cfg fields of the fixed pipeline) */
+  uint32_t ri_len, I_offset_ri;   /* 0..2 rank-indication bits */
 } srslte_hip_ul_grant_t;
 int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
                                   uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+const uint8_t* srslte_hip_ul_rx_grants_ack(const srslte_hip_ul_rx_t* q);
+const uint8_t* srslte_hip_ul_rx_grants_ri(const srslte_hip_ul_rx_t* q);
 /* Device pointer to the HARQ-ACK decisions of the last batch on this object, [max_batch][2] bytes (srslte_uci_value_t.ack.ack_value of
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);

@@ -589,11 +589,13 @@ class UlRxCfg(C.Structure):
 class UlGrant(C.Structure):
     """srslte_hip_ul_grant_t: one PUSCH of a srslte_hip_ul_rx_batch_grants call."""
     _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("n_dmrs", C.c_uint32),
-                ("mod", C.c_int), ("tbs", C.c_uint32), ("rv", C.c_uint32), ("new_data", C.c_int)]
+                ("mod", C.c_int), ("tbs", C.c_uint32), ("rv", C.c_uint32), ("new_data", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
+                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
 
     @classmethod
-    def make(cls, sf, rnti, L_prb, n_prb, mod, tbs, n_dmrs=0, n_prb_slot1=None, rv=0, new_data=True):
-        return cls(sf, rnti, L_prb, n_prb, n_prb if n_prb_slot1 is None else n_prb_slot1, n_dmrs, mod, tbs, rv, 1 if new_data else 0)
+    def make(cls, sf, rnti, L_prb, n_prb, mod, tbs, n_dmrs=0, n_prb_slot1=None, rv=0, new_data=True, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
+        return cls(sf, rnti, L_prb, n_prb, n_prb if n_prb_slot1 is None else n_prb_slot1, n_dmrs, mod, tbs, rv, 1 if new_data else 0, ack_len, I_offset_ack,
+                   ri_len, I_offset_ri)
 
 
 class UlRx:
@@ -642,7 +644,19 @@ class UlRx:
                "ul_rx_batch_grants")
         sync()
         tb = self.d_tb.to_host(np.uint8).reshape(self.rows, self.tb_stride)[:len(grants)]
+        self.last_nof_grants = len(grants)
         return tb, self.d_ok.to_host(np.uint8)[:len(grants)]
+
+    def grants_uci(self):
+        """(HARQ-ACK decisions [nof_grants][2], rank indications [nof_grants][2]) of the last decode_grants()."""
+        L = lib()
+        out = []
+        for fn in (L.srslte_hip_ul_rx_grants_ack, L.srslte_hip_ul_rx_grants_ri):
+            fn.restype, fn.argtypes = C.c_void_p, [C.c_void_p]
+            a = np.empty(2 * self.last_nof_grants, np.uint8)
+            _check(L.srslte_hip_memcpy_d2h(a.ctypes.data, fn(self.h), a.nbytes), "memcpy_d2h")
+            out.append(a.reshape(-1, 2))
+        return out
 
     def decode(self, iq, tti0=0):
         x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)

@@ -2289,11 +2289,18 @@ struct srslte_hip_ul_rx {
   struct GrantsState*    gs;
   cf32 *                 g_z, *g_d; // [max_grants][nsymb * 12 * nof_prb]
   float*                 g_res;     // [max_grants] x srslte_hip_chest_ul_res_t
+  int*                   g_uci_sum; // [max_grants][4] HARQ-ACK accumulators, then the same for the rank indication
+  uint8_t*               g_uci;     // [max_grants][2] HARQ-ACK decisions of the last grants call, then [max_grants][2] rank indications
 };
 
 extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack + 2 * q->cfg.max_batch : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_cqi(const srslte_hip_ul_rx_t* q) { return q ? q->d_cqi : nullptr; }
+extern "C" const uint8_t* srslte_hip_ul_rx_grants_ack(const srslte_hip_ul_rx_t* q) { return q ? q->g_uci : nullptr; }
+extern "C" const uint8_t* srslte_hip_ul_rx_grants_ri(const srslte_hip_ul_rx_t* q)
+{
+  return q && q->g_uci ? q->g_uci + 2 * (q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch) : nullptr;
+}
 
 extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
 {
@@ -2303,7 +2310,7 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
                   q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi,
-                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3], q->g_z, q->g_d, q->g_res};
+                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3], q->g_z, q->g_d, q->g_res, q->g_uci_sum, q->g_uci};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -2538,17 +2545,13 @@ extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_
 // enb_ul.c:200-235, after one srslte_enb_ul_fft per TTI). The OFDM demodulation runs once per subframe; estimator, equaliser and demapper take
 // their geometry from per-PUSCH descriptors, the transform de-precoding runs once per distinct L_prb (PUSCHs of one size sit next to each other
 // in the symbol buffers), and from the LLRs on it is the downlink's grants machinery with one slot per PUSCH: slot p = grants[p] keeps soft
-// buffers, CRC flags and bytes between calls (HARQ as srslte_hip_ul_rx_batch_harq). UL-SCH data only: no UCI in this mode yet.
+// buffers, CRC flags and bytes between calls (HARQ as srslte_hip_ul_rx_batch_harq). HARQ-ACK and rank indication per PUSCH; no CQI reports in this mode yet.
 extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
                                              uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
   if (!q || !d_iq || !grants || !d_tb || !d_tb_ok || nof_sf > q->cfg.max_batch || tb_stride < q->cfg.tbs / 8 + 6) return SRSLTE_ERROR_INVALID_INPUTS;
   const uint32_t V = q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch, P = q->cfg.nof_prb;
   if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->cfg.ack_len || q->cfg.ri_len || q->cfg.cqi_len) {
-    hip_log("[srslte_hip] ul_rx grants mode: create the object without UCI; this mode decodes UL-SCH data only\n");
-    return SRSLTE_ERROR;
-  }
   if (nof_sf == 0 || nof_grants == 0) return SRSLTE_SUCCESS;
   hipStream_t    st    = (hipStream_t)stream;
   const uint32_t nsymb = (uint32_t)q->pg.nsymb, max_re = nsymb * 12 * P;
@@ -2558,6 +2561,8 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     HIP_TRY(hipMalloc((void**)&q->g_z, sizeof(cf32) * (size_t)max_re * V));
     HIP_TRY(hipMalloc((void**)&q->g_d, sizeof(cf32) * (size_t)max_re * V));
     HIP_TRY(hipMalloc((void**)&q->g_res, sizeof(float) * 5 * V));
+    HIP_TRY(hipMalloc((void**)&q->g_uci_sum, sizeof(int) * 8 * V));
+    HIP_TRY(hipMalloc((void**)&q->g_uci, (size_t)4 * V));
   }
   GrantsState*   g    = q->gs;
   const size_t   nblk = (size_t)V * g->Cmax;
@@ -2595,6 +2600,7 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     return grants[a].L_prb != grants[b].L_prb ? grants[a].L_prb < grants[b].L_prb : grants[a].n_dmrs < grants[b].n_dmrs;
   });
   uint32_t zoff = 0;
+  bool     any_uci = false;
   for (uint32_t i = 0; i < nof_grants; i++) {
     const uint32_t               p  = order[i];
     const srslte_hip_ul_grant_t& gr = grants[p];
@@ -2609,7 +2615,20 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     pd.zoff = (int)zoff;
     zoff += nsymb * 12 * gr.L_prb;
     h_it[i].sf = (int)gr.sf; h_it[i].n_prb = (int)gr.n_prb; h_it[i].n_prb1 = (int)gr.n_prb_slot1; h_it[i].row = (int)p;
-    if (int r = bd.add_tb(p, p, gr.mod, gr.tbs, gr.rv, gr.new_data, nsymb * 12 * gr.L_prb, 1)) return r;
+    // HARQ-ACK and rank indication of this PUSCH (srslte_uci_cfg_t of its srslte_pusch_cfg_t): Q' from the grant's own size and code blocks; the
+    // UL-SCH is rate-matched to what the RI symbols leave (sch.c:1157-1160), the ACK symbols overwrite it
+    srslte_hip_cbsegm_t seg;
+    const uint32_t      nof_re = nsymb * 12 * gr.L_prb;
+    if (srslte_hip_cbsegm(&seg, gr.tbs)) return SRSLTE_ERROR_INVALID_INPUTS;
+    const int Qp_ack = pusch_ack_qprime(gr.ack_len, gr.I_offset_ack, gr.L_prb, nsymb, seg.C * seg.K1);
+    const int Qp_ri  = pusch_ack_qprime(gr.ri_len, gr.I_offset_ri, gr.L_prb, nsymb, seg.C * seg.K1, true);
+    if (Qp_ack < 0 || Qp_ri < 0 || (uint32_t)Qp_ri + seg.C >= nof_re) {
+      hip_log("[srslte_hip] ul_rx grants: entry %u: invalid UCI configuration (ack %u / %u, ri %u / %u)\n", p, gr.ack_len, gr.I_offset_ack, gr.ri_len, gr.I_offset_ri);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    pd.ack.O = (int)gr.ack_len; pd.ack.Qprime = Qp_ack; pd.ri.O = (int)gr.ri_len; pd.ri.Qprime = Qp_ri;
+    any_uci = any_uci || gr.ack_len || gr.ri_len;
+    if (int r = bd.add_tb(p, p, gr.mod, gr.tbs, gr.rv, gr.new_data, nof_re - (uint32_t)Qp_ri, 1)) return r;
   }
   bd.fill_map(h_map);
   int r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
@@ -2637,8 +2656,14 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     if (r) return r;
     i = j;
   }
+  if (any_uci) HIP_TRY(hipMemsetAsync(q->g_uci_sum, 0, sizeof(int) * 8 * V, st));
   hipLaunchKernelGGL(pusch_demod_grants_kernel, dim3(ceil_div((int)max_M, 64), nof_grants), dim3(256), 0, st, (const cf32*)q->g_d, (const uint32_t*)g->d_scr,
-                     (int)g->words, g->d_e, (int)g->max_bits, (const PuschDesc*)d_pd, (int)nsymb, (int*)nullptr, (int*)nullptr);
+                     (int)g->words, g->d_e, (int)g->max_bits, (const PuschDesc*)d_pd, (int)nsymb, q->g_uci_sum, q->g_uci_sum + 4 * V);
+  LAUNCH_CHECK();
+  // decisions of every row (zero sums -> 0 where a PUSCH carries none)
+  hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)q->g_uci_sum, q->g_uci, (int)nof_grants);
+  hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)(q->g_uci_sum + 4 * V), q->g_uci + 2 * V,
+                     (int)nof_grants);
   LAUNCH_CHECK();
   return grants_back_end(g, bd, d_sf, d_cb, d_map, tti0, q->cfg.max_iterations, nof_grants, nof_grants, 0, d_tb, tb_stride, d_tb_ok, st);
 }

@@ -43,18 +43,24 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
     rng = np.random.default_rng(4100 + prb)
     nsf = len(sets)
     dm = dict(cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=False)
-    iq, ues, grants = [], [], []
+    iq, ues, grants, uci = [], [], [], []
     for b, ue_list in enumerate(sets):
         x, sig = None, []
         for u, (L, n0, n1, mod, tbs, n_dmrs, snr) in enumerate(ue_list):
             rnti = 0x100 + 16 * b + u
             cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=rnti, n_prb_slot1=n1 if n1 != n0 else None, **dm)
             gain = (0.7 + 0.1 * u) * np.exp(0.3j * (u + 1))
-            y, data = make_ul_subframe(cfg, tti0 + b, rng, amp=0.1, gain=gain)
+            # every other PUSCH also carries HARQ-ACK (1 or 2 bits) and, every third, a rank indication
+            O_ack, O_ri = ((u + b) % 2) * (1 + (u % 2)), 1 if (u + b) % 3 == 0 else 0
+            if L == 1:
+                O_ack = O_ri = 0
+            ack, ri = tuple(int(v) for v in rng.integers(0, 2, O_ack)), tuple(int(v) for v in rng.integers(0, 2, O_ri))
+            uci.append((O_ack, ack, O_ri, ri))
+            y, data = make_ul_subframe(cfg, tti0 + b, rng, amp=0.1, gain=gain, ack=ack, I_offset_ack=9, ri=ri, I_offset_ri=8)
             sig.append(np.sqrt(0.01 * abs(gain) ** 2 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr / 20))  # the noise level that gives this UE `snr` per RE
             x = y if x is None else x + y
             ues.append((b, cfg, data))
-            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1))
+            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1, ack_len=O_ack, I_offset_ack=9, ri_len=O_ri, I_offset_ri=8))
         x = x + min(sig) * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))  # one receiver noise: every UE at its SNR or better
         iq.append(x.astype(np.complex64))
     max_tbs = max(g.tbs for g in grants)
@@ -72,11 +78,14 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
         off += 12 * 12 * grants[p].L_prb
     d_all = rx.debug(21, np.complex64, off)
     e_rows = rx.debug(22, np.int16, n * ((12 * 12 * prb * 8 + 15) & ~15)).reshape(n, -1)
+    acks, ris = rx.grants_uci()
     for p, (b, cfg, data) in enumerate(ues):
-        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True)
+        O_ack, ack, O_ri, ri = uci[p]
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=9, O_ri=O_ri, I_offset_ri=8)
+        assert tuple(acks[p][:O_ack]) == ack == tuple(r["ack"][:O_ack]) and tuple(ris[p][:O_ri]) == ri == tuple(r["ri"][:O_ri]), (p, acks[p], ack, ris[p], ri)
         assert abs(res[p, 0] - r["noise"]) <= 1e-4 * abs(r["noise"]), p
         close_c(d_all[zoff_of[p]:zoff_of[p] + cfg.nof_re], r["d"], "d of PUSCH %d" % p)
-        diff = np.abs(e_rows[p][:cfg.nbits].astype(np.int32) - r["g"].astype(np.int32))
+        diff = np.abs(e_rows[p][:len(r["g"])].astype(np.int32) - r["g"].astype(np.int32))
         assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size, p
         if diff.max() == 0 or r["ok"]:
             assert bool(ok[p]) == r["ok"], p
@@ -176,8 +185,7 @@ def test_ul_grants_argument_errors(hp):
             rx.decode_grants(iq, 0, bad)
     tb, ok = rx.decode_grants(iq, 0, [])
     assert len(ok) == 0
-    rx.free()
-    rx = hp.UlRx(1, 25, 0x1234, 2, 4008, 10, 5, 0, 6, 2, ack_len=1, I_offset_ack=5)
-    with pytest.raises(RuntimeError):
-        rx.decode_grants(iq, 0, [G(0, 1, 10, 0, 2, 4008)])
+    for bad in ([G(0, 1, 10, 0, 2, 4008, ack_len=3)], [G(0, 1, 10, 0, 2, 4008, ack_len=1, I_offset_ack=15)], [G(0, 1, 10, 0, 2, 4008, ri_len=1, I_offset_ri=13)]):
+        with pytest.raises(RuntimeError):
+            rx.decode_grants(iq, 0, bad)
     rx.free()
