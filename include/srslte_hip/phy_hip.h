@@ -337,7 +337,8 @@ int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_
  * new-data flag. Slot p of the object is that PUSCH's srslte_softbuffer_rx_t between calls (HARQ as srslte_hip_ul_rx_batch_harq). Rows p of
  * d_tb / d_tb_ok. The object's cell, DMRS configuration, shortened flag, equaliser and pass limit apply (its own grant and UCI fields are those of
  * the fixed pipeline and play no part here); cfg.tbs = the largest transport block, cfg.max_grants >= nof_grants. HARQ-ACK and rank indication
- * per PUSCH (decisions: srslte_hip_ul_rx_grants_ack / _ri, [max_grants][2] device bytes each, row p); CQI reports are not decoded in this mode. */
+ * per PUSCH (decisions: srslte_hip_ul_rx_grants_ack / _ri, [max_grants][2] device bytes each, row p) and CQI reports (srslte_hip_ul_rx_grants_cqi:
+ * [max_grants][64] bits, then [max_grants] CRC flags, as srslte_hip_ul_rx_cqi; rows whose grant carries no report keep their content). */
 typedef struct {
   uint32_t sf;                       /* 0 .. nof_sf-1 */
   uint16_t rnti;
@@ -347,11 +348,13 @@ typedef struct {
   int      new_data;
   uint32_t ack_len, I_offset_ack; /* 0..2 HARQ-ACK bits on this PUSCH and their offset index (as the cfg fields of the fixed pipeline) */
   uint32_t ri_len, I_offset_ri;   /* 0..2 rank-indication bits */
+  uint32_t cqi_len, I_offset_cqi; /* 0..64 bits of CQI / PMI report (srslte_cqi_size) */
 } srslte_hip_ul_grant_t;
 int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
                                   uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 const uint8_t* srslte_hip_ul_rx_grants_ack(const srslte_hip_ul_rx_t* q);
 const uint8_t* srslte_hip_ul_rx_grants_ri(const srslte_hip_ul_rx_t* q);
+const uint8_t* srslte_hip_ul_rx_grants_cqi(const srslte_hip_ul_rx_t* q);
 /* Device pointer to the HARQ-ACK decisions of the last batch on this object, [max_batch][2] bytes (srslte_uci_value_t.ack.ack_value of
  * srslte_pusch_decode); valid once the batch's stream work is done, all zero when cfg.ack_len == 0 */
 const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q);

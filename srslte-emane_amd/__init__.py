@@ -590,12 +590,13 @@ class UlGrant(C.Structure):
     """srslte_hip_ul_grant_t: one PUSCH of a srslte_hip_ul_rx_batch_grants call."""
     _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("n_dmrs", C.c_uint32),
                 ("mod", C.c_int), ("tbs", C.c_uint32), ("rv", C.c_uint32), ("new_data", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
-                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32)]
+                ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32)]
 
     @classmethod
-    def make(cls, sf, rnti, L_prb, n_prb, mod, tbs, n_dmrs=0, n_prb_slot1=None, rv=0, new_data=True, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0):
+    def make(cls, sf, rnti, L_prb, n_prb, mod, tbs, n_dmrs=0, n_prb_slot1=None, rv=0, new_data=True, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0,
+             cqi_len=0, I_offset_cqi=0):
         return cls(sf, rnti, L_prb, n_prb, n_prb if n_prb_slot1 is None else n_prb_slot1, n_dmrs, mod, tbs, rv, 1 if new_data else 0, ack_len, I_offset_ack,
-                   ri_len, I_offset_ri)
+                   ri_len, I_offset_ri, cqi_len, I_offset_cqi)
 
 
 class UlRx:
@@ -630,6 +631,7 @@ class UlRx:
         self.tb_stride = (tbs // 8 + 6 + 15) & ~15
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.rows = max(max_batch, max_grants)
+        self.rows_grants = max_grants or max_batch
         self.d_tb, self.d_ok = DevBuf(self.tb_stride * self.rows), DevBuf(self.rows)
 
     def decode_grants(self, iq, tti0, grants):
@@ -657,6 +659,15 @@ class UlRx:
             _check(L.srslte_hip_memcpy_d2h(a.ctypes.data, fn(self.h), a.nbytes), "memcpy_d2h")
             out.append(a.reshape(-1, 2))
         return out
+
+    def grants_cqi(self):
+        """(report bits [nof_grants][64], CRC flags [nof_grants]) of the last decode_grants()."""
+        L = lib()
+        L.srslte_hip_ul_rx_grants_cqi.restype, L.srslte_hip_ul_rx_grants_cqi.argtypes = C.c_void_p, [C.c_void_p]
+        out = np.empty(65 * self.rows_grants, np.uint8)
+        _check(L.srslte_hip_memcpy_d2h(out.ctypes.data, L.srslte_hip_ul_rx_grants_cqi(self.h), out.nbytes), "memcpy_d2h")
+        n = self.last_nof_grants
+        return out[:64 * self.rows_grants].reshape(-1, 64)[:n], out[64 * self.rows_grants:][:n]
 
     def decode(self, iq, tti0=0):
         x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.sf_len)

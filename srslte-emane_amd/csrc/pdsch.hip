@@ -57,6 +57,7 @@ struct CbDesc {
   int             w_len;   // soft-buffer slots of this block length (multiple of 32) = stride of its slot table
   const uint32_t* tbl;     // slot table of (K, rv)
   int             Nl;      // the block split counts in units of Qm * Nl bits: 2 for transmit diversity, else 1 (sch.c:507-531)
+  int             e_off;   // LLRs in front of the shared channel's in this block's row (PUSCH: the CQI report's)
 };
 struct GrantDev { // what the list / sequence kernels need of a grant
   uint32_t mask[2][4]; // prb_idx[s][n] as bits
@@ -509,12 +510,12 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
   constexpr int PER = 4 / (int)sizeof(LLR); // slots per dword
   // the block: memory slot cbg = sf * g.C + cb; in grants mode its own (C, K, Qm, nof_re, table) come from the descriptor
   int             cbg = blockIdx.y, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
-  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl;
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl, e_off = g.e_off;
   const uint32_t* tbl = inv;
   if (g.cbd) {
     const CbDesc d = g.cbd[blockIdx.y];
     sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
-    Nl = d.Nl;
+    Nl = d.Nl; e_off = d.e_off;
   }
   const int j = PER * (blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= w_len || (g.skip && combine && g.skip[cbg])) return;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(256) void rm_rx_kernel(const LLR* __restrict__ e, L
     n_e2 = n_e + QmL;
     rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
-  const LLR* src = e + (size_t)sf * g.max_bits + g.e_off + rp;
+  const LLR* src = e + (size_t)sf * g.max_bits + e_off + rp;
   CsiW       cw;
   if (g.csi) cw = csi_setup(g, sf, nre, Qm);
   uint32_t   n[PER], word = 0;
@@ -561,12 +562,12 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
   constexpr int PER = 16 / (int)sizeof(LLR), NV = PER / 8; // slots per 16 bytes; uint4 loads of 16-bit table entries per step
   LLR*          seg = reinterpret_cast<LLR*>(seg_raw);
   int             cbg = blockIdx.x, sf = cbg / g.C, cb = cbg - sf * g.C, C = g.C, Qm = g.Qm, out_len = g.out_len, w_len = g.w_stride, combine = g.combine;
-  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl;
+  int             nre = g.nof_re[sf_class((g.tti0 + sf) % 10)], Nl = g.Nl, e_off = g.e_off;
   const uint32_t* tbl = inv;
   if (g.cbd) {
     const CbDesc d = g.cbd[blockIdx.x];
     sf = d.sf; cb = d.cb; cbg = sf * g.C + cb; C = d.C; Qm = d.Qm; out_len = 3 * d.K + 12; w_len = d.w_len; combine = d.combine; nre = d.nof_re; tbl = d.tbl;
-    Nl = d.Nl;
+    Nl = d.Nl; e_off = d.e_off;
   }
   if (g.skip && combine && g.skip[cbg]) return;
   if (g.cb_ok_rst && !combine && threadIdx.x == 0) g.cb_ok_rst[cbg] = 0;
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(256) void rm_rx_lds_kernel(const LLR* __restrict__ 
     n_e2 = n_e + QmL;
     rp   = (C - gamma) * n_e + (cb - (C - gamma)) * n_e2;
   }
-  const LLR* src = e + (size_t)sf * g.max_bits + g.e_off + rp;
+  const LLR* src = e + (size_t)sf * g.max_bits + e_off + rp;
   // the segment starts at an arbitrary LLR index: copy from the 16-byte boundary below it
   const int mis = (int)((reinterpret_cast<uintptr_t>(src) & 15) / sizeof(LLR));
   const int4* s4 = reinterpret_cast<const int4*>(src - mis);
@@ -1578,7 +1579,7 @@ struct GrantsBuild {
   std::vector<Group> groups;
   uint32_t           ncb = 0, max_seg = 0;
   // one transport block into slot v: descriptor, code-block descriptors, decoder group. b: the caller's index, for the message
-  int add_tb(uint32_t b, uint32_t v, int mod, uint32_t tbs, uint32_t rv, int new_data, uint32_t nre, uint32_t Nl)
+  int add_tb(uint32_t b, uint32_t v, int mod, uint32_t tbs, uint32_t rv, int new_data, uint32_t nre, uint32_t Nl, uint32_t e_off = 0)
   {
     SfDesc& sd = h_sf[v];
     srslte_hip_cbsegm_t seg;
@@ -1609,7 +1610,7 @@ struct GrantsBuild {
     for (uint32_t c = 0; c < C; c++) {
       CbDesc& cd = h_cb[ncb++];
       cd.sf = (int)v; cd.cb = (int)c; cd.C = (int)C; cd.K = (int)K; cd.Qm = (int)Qm; cd.nof_re = (int)nre; cd.combine = new_data ? 0 : 1;
-      cd.w_len = (int)w_len; cd.tbl = tbl; cd.Nl = (int)Nl;
+      cd.w_len = (int)w_len; cd.tbl = tbl; cd.Nl = (int)Nl; cd.e_off = (int)e_off;
       grp->slots.push_back(v * g->Cmax + c);
     }
     const uint32_t seg_bytes = (Qm * (nre / C) + 2 * Qm * (uint32_t)npt) * (l8 ? 1 : 2) + 32;
@@ -2056,6 +2057,7 @@ struct PuschDesc {
   int M_sc, n_prb, n_prb1, mod, Qm;
   int zoff;                      // in cf32
   AckGeom ack, ri;
+  int cqi_Q, cqi_O;              // LLRs and bits of its CQI report (0: none)
 };
 
 // grid = (ceil(max M_sc / 256), nsymb, nof_pusch)
@@ -2112,9 +2114,12 @@ __device__ __forceinline__ uint32_t cqi_crc8(const uint8_t* bits, int n)
   return r & 0xffu;
 }
 
-__global__ __launch_bounds__(256) void pusch_cqi_decode_kernel(const int16_t* __restrict__ gl, int g_stride, int Q, int O, uint8_t* __restrict__ cqi_out,
-                                                               uint8_t* __restrict__ ok_out)
+__global__ __launch_bounds__(256) void pusch_cqi_decode_kernel(const int16_t* __restrict__ gl, int g_stride, int Q_all, int O_all, uint8_t* __restrict__ cqi_out,
+                                                               uint8_t* __restrict__ ok_out, const PuschDesc* __restrict__ desc)
 {
+  // per-PUSCH grants: the report's size comes from the row's descriptor (rows without a report are left alone)
+  const int Q = desc ? desc[blockIdx.x].cqi_Q : Q_all, O = desc ? desc[blockIdx.x].cqi_O : O_all;
+  if (O == 0) return;
   __shared__ int16_t            acc[32];
   __shared__ long long          best[4];
   __shared__ int16_t            tmp[3 * 96], dem[3 * 72];
@@ -2291,12 +2296,14 @@ struct srslte_hip_ul_rx {
   float*                 g_res;     // [max_grants] x srslte_hip_chest_ul_res_t
   int*                   g_uci_sum; // [max_grants][4] HARQ-ACK accumulators, then the same for the rank indication
   uint8_t*               g_uci;     // [max_grants][2] HARQ-ACK decisions of the last grants call, then [max_grants][2] rank indications
+  uint8_t*               g_cqi;     // [max_grants][64] CQI report bits of the last grants call, then [max_grants] CRC flags
 };
 
 extern "C" const uint8_t* srslte_hip_ul_rx_ack(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_ri(const srslte_hip_ul_rx_t* q) { return q ? q->d_ack + 2 * q->cfg.max_batch : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_cqi(const srslte_hip_ul_rx_t* q) { return q ? q->d_cqi : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_grants_ack(const srslte_hip_ul_rx_t* q) { return q ? q->g_uci : nullptr; }
+extern "C" const uint8_t* srslte_hip_ul_rx_grants_cqi(const srslte_hip_ul_rx_t* q) { return q ? q->g_cqi : nullptr; }
 extern "C" const uint8_t* srslte_hip_ul_rx_grants_ri(const srslte_hip_ul_rx_t* q)
 {
   return q && q->g_uci ? q->g_uci + 2 * (q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch) : nullptr;
@@ -2310,7 +2317,7 @@ extern "C" void srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q)
   srslte_hip_tdec_destroy(q->tdec);
   void* bufs[] = {q->d_scr, q->d_rm_tbl, q->d_tbcrc, q->d_tb_rem, q->d_cb_syn, q->d_cb_iters, q->d_grid, q->d_ce, q->d_z,
                   q->d_d,   q->d_res,    q->d_g,     q->d_w,      q->d_cb_bytes, q->d_cb_ok, q->d_ack_sum, q->d_ack, q->d_cqi,
-                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3], q->g_z, q->g_d, q->g_res, q->g_uci_sum, q->g_uci};
+                  q->d_rm_tbl_rv[1], q->d_rm_tbl_rv[2], q->d_rm_tbl_rv[3], q->g_z, q->g_d, q->g_res, q->g_uci_sum, q->g_uci, q->g_cqi};
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
@@ -2508,7 +2515,7 @@ extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_
   }
   if (q->cfg.cqi_len) { // the report in front of the UL-SCH (sch.c:1031-1056)
     hipLaunchKernelGGL(pusch_cqi_decode_kernel, dim3(nof_sf), dim3(256), 0, st, (const int16_t*)q->d_g, q->rg.max_bits, q->Qp_cqi * q->rg.Qm,
-                       (int)q->cfg.cqi_len, q->d_cqi, q->d_cqi + 64 * q->cfg.max_batch);
+                       (int)q->cfg.cqi_len, q->d_cqi, q->d_cqi + 64 * q->cfg.max_batch, (const PuschDesc*)nullptr);
     LAUNCH_CHECK();
   }
   RmGeom rg = q->rg;
@@ -2545,7 +2552,7 @@ extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_
 // enb_ul.c:200-235, after one srslte_enb_ul_fft per TTI). The OFDM demodulation runs once per subframe; estimator, equaliser and demapper take
 // their geometry from per-PUSCH descriptors, the transform de-precoding runs once per distinct L_prb (PUSCHs of one size sit next to each other
 // in the symbol buffers), and from the LLRs on it is the downlink's grants machinery with one slot per PUSCH: slot p = grants[p] keeps soft
-// buffers, CRC flags and bytes between calls (HARQ as srslte_hip_ul_rx_batch_harq). HARQ-ACK and rank indication per PUSCH; no CQI reports in this mode yet.
+// buffers, CRC flags and bytes between calls (HARQ as srslte_hip_ul_rx_batch_harq). HARQ-ACK, rank indication and CQI report per PUSCH.
 extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants,
                                              uint32_t nof_grants, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
 {
@@ -2563,6 +2570,9 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     HIP_TRY(hipMalloc((void**)&q->g_res, sizeof(float) * 5 * V));
     HIP_TRY(hipMalloc((void**)&q->g_uci_sum, sizeof(int) * 8 * V));
     HIP_TRY(hipMalloc((void**)&q->g_uci, (size_t)4 * V));
+    HIP_TRY(hipMalloc((void**)&q->g_cqi, (size_t)65 * V));
+    HIP_TRY(hipMemset(q->g_cqi, 0, (size_t)65 * V));
+    HIP_TRY(hipDeviceSynchronize());
   }
   GrantsState*   g    = q->gs;
   const size_t   nblk = (size_t)V * g->Cmax;
@@ -2600,7 +2610,7 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     return grants[a].L_prb != grants[b].L_prb ? grants[a].L_prb < grants[b].L_prb : grants[a].n_dmrs < grants[b].n_dmrs;
   });
   uint32_t zoff = 0;
-  bool     any_uci = false;
+  bool     any_uci = false, any_cqi = false;
   for (uint32_t i = 0; i < nof_grants; i++) {
     const uint32_t               p  = order[i];
     const srslte_hip_ul_grant_t& gr = grants[p];
@@ -2622,13 +2632,18 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
     if (srslte_hip_cbsegm(&seg, gr.tbs)) return SRSLTE_ERROR_INVALID_INPUTS;
     const int Qp_ack = pusch_ack_qprime(gr.ack_len, gr.I_offset_ack, gr.L_prb, nsymb, seg.C * seg.K1);
     const int Qp_ri  = pusch_ack_qprime(gr.ri_len, gr.I_offset_ri, gr.L_prb, nsymb, seg.C * seg.K1, true);
-    if (Qp_ack < 0 || Qp_ri < 0 || (uint32_t)Qp_ri + seg.C >= nof_re) {
-      hip_log("[srslte_hip] ul_rx grants: entry %u: invalid UCI configuration (ack %u / %u, ri %u / %u)\n", p, gr.ack_len, gr.I_offset_ack, gr.ri_len, gr.I_offset_ri);
+    const int Qp_cqi = Qp_ri >= 0 && gr.cqi_len <= 64 ? pusch_cqi_qprime(gr.cqi_len, gr.I_offset_cqi, gr.L_prb, nsymb, seg.C * seg.K1, (uint32_t)Qp_ri) : -1;
+    if (Qp_ack < 0 || Qp_ri < 0 || Qp_cqi < 0 || (uint32_t)(Qp_ri + Qp_cqi) + seg.C >= nof_re || gr.mod < 1 || gr.mod > 3) {
+      hip_log("[srslte_hip] ul_rx grants: entry %u: invalid UCI configuration (ack %u / %u, ri %u / %u, cqi %u / %u)\n", p, gr.ack_len, gr.I_offset_ack, gr.ri_len,
+              gr.I_offset_ri, gr.cqi_len, gr.I_offset_cqi);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
     pd.ack.O = (int)gr.ack_len; pd.ack.Qprime = Qp_ack; pd.ri.O = (int)gr.ri_len; pd.ri.Qprime = Qp_ri;
+    pd.cqi_O = (int)gr.cqi_len; pd.cqi_Q = Qp_cqi * 2 * gr.mod;
     any_uci = any_uci || gr.ack_len || gr.ri_len;
-    if (int r = bd.add_tb(p, p, gr.mod, gr.tbs, gr.rv, gr.new_data, nof_re - (uint32_t)Qp_ri, 1)) return r;
+    any_cqi = any_cqi || gr.cqi_len;
+    // the report's LLRs come first in the row; the UL-SCH is rate-matched to the rest (sch.c:1058-1064)
+    if (int r = bd.add_tb(p, p, gr.mod, gr.tbs, gr.rv, gr.new_data, nof_re - (uint32_t)Qp_ri - (uint32_t)Qp_cqi, 1, (uint32_t)pd.cqi_Q)) return r;
   }
   bd.fill_map(h_map);
   int r = srslte_hip_ofdm_rx_sf_batch(q->ofdm, d_iq, q->d_grid, (int)nof_sf, stream);
@@ -2664,6 +2679,10 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
   hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)q->g_uci_sum, q->g_uci, (int)nof_grants);
   hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)(q->g_uci_sum + 4 * V), q->g_uci + 2 * V,
                      (int)nof_grants);
+  if (any_cqi) { // the reports in front of the UL-SCH (sch.c:1031-1056); rows without one keep what they held
+    hipLaunchKernelGGL(pusch_cqi_decode_kernel, dim3(nof_grants), dim3(256), 0, st, (const int16_t*)g->d_e, (int)g->max_bits, 0, 0, q->g_cqi, q->g_cqi + 64 * V,
+                       (const PuschDesc*)d_pd);
+  }
   LAUNCH_CHECK();
   return grants_back_end(g, bd, d_sf, d_cb, d_map, tti0, q->cfg.max_iterations, nof_grants, nof_grants, 0, d_tb, tb_stride, d_tb_ok, st);
 }

@@ -54,13 +54,16 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
             O_ack, O_ri = ((u + b) % 2) * (1 + (u % 2)), 1 if (u + b) % 3 == 0 else 0
             if L == 1:
                 O_ack = O_ri = 0
+            O_cqi = (8 if b % 2 == 0 else 20) if (u == 0 and L >= 6) else 0  # block-coded and convolutionally coded reports
             ack, ri = tuple(int(v) for v in rng.integers(0, 2, O_ack)), tuple(int(v) for v in rng.integers(0, 2, O_ri))
-            uci.append((O_ack, ack, O_ri, ri))
-            y, data = make_ul_subframe(cfg, tti0 + b, rng, amp=0.1, gain=gain, ack=ack, I_offset_ack=9, ri=ri, I_offset_ri=8)
+            cqi = tuple(int(v) for v in rng.integers(0, 2, O_cqi))
+            uci.append((O_ack, ack, O_ri, ri, O_cqi, cqi))
+            y, data = make_ul_subframe(cfg, tti0 + b, rng, amp=0.1, gain=gain, ack=ack, I_offset_ack=9, ri=ri, I_offset_ri=8, cqi=cqi, I_offset_cqi=7)
             sig.append(np.sqrt(0.01 * abs(gain) ** 2 * cfg.M_sc / cfg.N / 2) * 10 ** (-snr / 20))  # the noise level that gives this UE `snr` per RE
             x = y if x is None else x + y
             ues.append((b, cfg, data))
-            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1, ack_len=O_ack, I_offset_ack=9, ri_len=O_ri, I_offset_ri=8))
+            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1, ack_len=O_ack, I_offset_ack=9, ri_len=O_ri, I_offset_ri=8,
+                                          cqi_len=O_cqi, I_offset_cqi=7))
         x = x + min(sig) * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))  # one receiver noise: every UE at its SNR or better
         iq.append(x.astype(np.complex64))
     max_tbs = max(g.tbs for g in grants)
@@ -79,20 +82,25 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
     d_all = rx.debug(21, np.complex64, off)
     e_rows = rx.debug(22, np.int16, n * ((12 * 12 * prb * 8 + 15) & ~15)).reshape(n, -1)
     acks, ris = rx.grants_uci()
+    cqis, cqi_ok = rx.grants_cqi()
+    n_cqi = 0
     for p, (b, cfg, data) in enumerate(ues):
-        O_ack, ack, O_ri, ri = uci[p]
-        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=9, O_ri=O_ri, I_offset_ri=8)
+        O_ack, ack, O_ri, ri, O_cqi, cqi = uci[p]
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=9, O_ri=O_ri, I_offset_ri=8, O_cqi=O_cqi, I_offset_cqi=7)
+        if O_cqi:
+            n_cqi += 1
+            assert tuple(cqis[p][:O_cqi]) == cqi == tuple(r["cqi"]) and bool(cqi_ok[p]) == r["cqi_ok"] and (r["cqi_ok"] or O_cqi <= 11), p
         assert tuple(acks[p][:O_ack]) == ack == tuple(r["ack"][:O_ack]) and tuple(ris[p][:O_ri]) == ri == tuple(r["ri"][:O_ri]), (p, acks[p], ack, ris[p], ri)
         assert abs(res[p, 0] - r["noise"]) <= 1e-4 * abs(r["noise"]), p
         close_c(d_all[zoff_of[p]:zoff_of[p] + cfg.nof_re], r["d"], "d of PUSCH %d" % p)
-        diff = np.abs(e_rows[p][:len(r["g"])].astype(np.int32) - r["g"].astype(np.int32))
+        diff = np.abs(e_rows[p][:len(r["g"])].astype(np.int32) - r["g"].astype(np.int32))  # the whole row: the CQI report's LLRs, then the UL-SCH's
         assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size, p
         if diff.max() == 0 or r["ok"]:
             assert bool(ok[p]) == r["ok"], p
         if r["ok"]:
             n_ok += 1
             assert np.array_equal(tb[p][:cfg.tbs // 8 + 3], r["tb"]) and np.array_equal(tb[p][:cfg.tbs // 8], data), p
-    assert n_ok >= n - 2, (n_ok, n)
+    assert n_ok >= n - 2 and n_cqi >= 2, (n_ok, n, n_cqi)
     rx.free()
 
 
@@ -185,7 +193,8 @@ def test_ul_grants_argument_errors(hp):
             rx.decode_grants(iq, 0, bad)
     tb, ok = rx.decode_grants(iq, 0, [])
     assert len(ok) == 0
-    for bad in ([G(0, 1, 10, 0, 2, 4008, ack_len=3)], [G(0, 1, 10, 0, 2, 4008, ack_len=1, I_offset_ack=15)], [G(0, 1, 10, 0, 2, 4008, ri_len=1, I_offset_ri=13)]):
+    for bad in ([G(0, 1, 10, 0, 2, 4008, ack_len=3)], [G(0, 1, 10, 0, 2, 4008, ack_len=1, I_offset_ack=15)], [G(0, 1, 10, 0, 2, 4008, ri_len=1, I_offset_ri=13)],
+                [G(0, 1, 10, 0, 2, 4008, cqi_len=65)], [G(0, 1, 10, 0, 2, 4008, cqi_len=4, I_offset_cqi=0)]):
         with pytest.raises(RuntimeError):
             rx.decode_grants(iq, 0, bad)
     rx.free()
