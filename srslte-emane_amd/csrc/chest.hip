@@ -495,24 +495,11 @@ __global__ void chest_fill_res_kernel(const ChestRaw* __restrict__ raw, ChestRes
   res[sf]              = o;
 }
 
-// Gold sequence (sequence.c:48-79) and CRS values (refsignal_dl.c:66-116) — init-time host tables.
-void gold(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c)
-{
-  const uint32_t Nc = 1600;
-  std::vector<uint8_t> x1(Nc + len + 31, 0), x2(Nc + len + 31, 0);
-  for (int n = 0; n < 31; n++) x2[n] = (c_init >> n) & 1;
-  x1[0] = 1;
-  for (uint32_t n = 0; n < Nc + len; n++) {
-    x1[n + 31] = (x1[n + 3] + x1[n]) & 1;
-    x2[n + 31] = (x2[n + 3] + x2[n + 2] + x2[n + 1] + x2[n]) & 1;
-  }
-  c.resize(len);
-  for (uint32_t n = 0; n < len; n++) c[n] = (x1[n + Nc] + x2[n + Nc]) & 1;
-}
+// Gold sequence (sequence.c:48-79; fec_tables.cpp) and CRS values (refsignal_dl.c:66-116) — init-time host tables.
+inline void gold(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) { lte_gold_sequence(c_init, len, c); }
 
 } // namespace
 
-void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c) { gold(c_init, len, c); }
 
 struct srslte_hip_chest_dl {
   int       cell_id, nof_prb, nof_ports, nsl; // nsl: symbols per slot (7, extended CP 6)

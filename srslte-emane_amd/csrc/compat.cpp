@@ -579,24 +579,7 @@ bool srslte_cbsegm_cbsize_isvalid(uint32_t size)
   return i >= 0 && lte_qpp_table[i].K == size;
 }
 
-int srslte_tc_interl_init(srslte_tc_interl_t* h, uint32_t max_long_cb)
-{ // tc_interl_umts.c-style allocation used by both interleavers
-  h->forward = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
-  h->reverse = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
-  if (!h->forward || !h->reverse) {
-    free(h->forward);
-    free(h->reverse);
-    return SRSLTE_ERROR;
-  }
-  h->max_long_cb = max_long_cb;
-  return SRSLTE_SUCCESS;
-}
-void srslte_tc_interl_free(srslte_tc_interl_t* h)
-{
-  free(h->forward);
-  free(h->reverse);
-  memset(h, 0, sizeof(*h));
-}
+// srslte_tc_interl_init / _free: compat_refsignal.cpp, next to the 25.212 generator they were written for (tc_interl_umts.c:58-78)
 int srslte_tc_interl_LTE_gen_interl(srslte_tc_interl_t* h, uint32_t long_cb, uint32_t interl_win)
 { // tc_interl_lte.c:75-114
   if (long_cb > h->max_long_cb) {

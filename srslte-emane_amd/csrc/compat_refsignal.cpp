@@ -333,6 +333,24 @@ float srslte_chest_estimate_noise_pilots(cf_t* noisy, cf_t* noiseless, cf_t* noi
 }
 
 // ====================================================================================================== 25.212 turbo interleaver
+int srslte_tc_interl_init(srslte_tc_interl_t* h, uint32_t max_long_cb)
+{ // tc_interl_umts.c-style allocation used by both interleavers
+  h->forward = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
+  h->reverse = (uint16_t*)calloc(max_long_cb, sizeof(uint16_t));
+  if (!h->forward || !h->reverse) {
+    free(h->forward);
+    free(h->reverse);
+    return SRSLTE_ERROR;
+  }
+  h->max_long_cb = max_long_cb;
+  return SRSLTE_SUCCESS;
+}
+void srslte_tc_interl_free(srslte_tc_interl_t* h)
+{
+  free(h->forward);
+  free(h->reverse);
+  memset(h, 0, sizeof(*h));
+}
 // srslte_tc_interl_UMTS_gen (tc_interl_umts.c:80-262): the 3GPP TS 25.212 4.2.3.2.3 prime interleaver as the reference builds it. Two
 // things differ from the specification's text and are kept, since the reference is what a caller of this symbol gets today: the row
 // multipliers q_i are the least INTEGERS > 6 coprime with p - 1 in increasing order (the text asks for primes; they differ from q = 25

@@ -141,3 +141,18 @@ void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index)
     if (d >= 0) d_index.push_back((uint32_t)d);
   }
 }
+
+// Gold sequence c(n) of 36.211 7.2 (sequence.c:48-79): x1 from 1 0 0 ..., x2 from c_init, both advanced Nc = 1600 steps
+void lte_gold_sequence(uint32_t c_init, uint32_t len, std::vector<uint8_t>& c)
+{
+  const uint32_t Nc = 1600;
+  std::vector<uint8_t> x1(Nc + len + 31, 0), x2(Nc + len + 31, 0);
+  for (int n = 0; n < 31; n++) x2[n] = (c_init >> n) & 1;
+  x1[0] = 1;
+  for (uint32_t n = 0; n < Nc + len; n++) {
+    x1[n + 31] = (x1[n + 3] + x1[n]) & 1;
+    x2[n + 31] = (x2[n + 3] + x2[n + 2] + x2[n + 1] + x2[n]) & 1;
+  }
+  c.resize(len);
+  for (uint32_t n = 0; n < len; n++) c[n] = (x1[n + Nc] + x2[n + Nc]) & 1;
+}
