@@ -2675,10 +2675,11 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
   hipLaunchKernelGGL(pusch_demod_grants_kernel, dim3(ceil_div((int)max_M, 64), nof_grants), dim3(256), 0, st, (const cf32*)q->g_d, (const uint32_t*)g->d_scr,
                      (int)g->words, g->d_e, (int)g->max_bits, (const PuschDesc*)d_pd, (int)nsymb, q->g_uci_sum, q->g_uci_sum + 4 * V);
   LAUNCH_CHECK();
-  // decisions of every row (zero sums -> 0 where a PUSCH carries none)
-  hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)q->g_uci_sum, q->g_uci, (int)nof_grants);
-  hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)(q->g_uci_sum + 4 * V), q->g_uci + 2 * V,
-                     (int)nof_grants);
+  if (any_uci) { // decisions of every row of the call (zero sums -> 0 where a PUSCH carries none); a call without any leaves the rows alone
+    hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)q->g_uci_sum, q->g_uci, (int)nof_grants);
+    hipLaunchKernelGGL(pusch_ack_decide_kernel, dim3(ceil_div((int)nof_grants, 64)), dim3(64), 0, st, (const int*)(q->g_uci_sum + 4 * V), q->g_uci + 2 * V,
+                       (int)nof_grants);
+  }
   if (any_cqi) { // the reports in front of the UL-SCH (sch.c:1031-1056); rows without one keep what they held
     hipLaunchKernelGGL(pusch_cqi_decode_kernel, dim3(nof_grants), dim3(256), 0, st, (const int16_t*)g->d_e, (int)g->max_bits, 0, 0, q->g_cqi, q->g_cqi + 64 * V,
                        (const PuschDesc*)d_pd);
