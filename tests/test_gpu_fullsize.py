@@ -128,6 +128,37 @@ def test_cfg3_full_batch_uplink_harq_gain(hp):
     rx.free()
 
 
+def test_full_batch_uplink_grants_four_ues_per_subframe(hp):
+    """Per-PUSCH grants at full batch: 128 subframes of a 100-PRB cell, four UEs per subframe (24 PRB each, own RNTI, cyclic shift, modulation
+    and transport block), their signals made by four device transmit pipelines and summed: all 512 transport blocks come back through
+    one srslte_hip_ul_rx_batch_grants call, each in the row of its grant; then the same batch with the grants listed in another order
+    gives the same blocks in the permuted rows."""
+    prb, B = 100, 128
+    rng = np.random.default_rng(23)
+    ues = [(24, 0, 1, 4584, 0), (24, 24, 2, 9144, 3), (24, 48, 3, 15264, 5), (24, 72, 2, 11064, 6)]  # L, n_prb, mod, tbs, n_dmrs
+    iq, datas = None, []
+    for u, (L, n0, mod, tbs, nd) in enumerate(ues):
+        tx = hp.UlTx(3, prb, 0x100 + u, mod, tbs, L, n0, nd, B)
+        d = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
+        y = tx.encode(d, 5)
+        iq = y.copy() if iq is None else iq + y
+        datas.append(d)
+        tx.free()
+    grants = [hp.UlGrant.make(b, 0x100 + u, L, n0, mod, tbs, n_dmrs=nd) for b in range(B) for u, (L, n0, mod, tbs, nd) in enumerate(ues)]
+    rx = hp.UlRx(3, prb, 0x77, 2, max(u[3] for u in ues), 6, 0, 0, 6, B, max_grants=len(grants))
+    tb, ok = rx.decode_grants(iq, 5, grants)
+    assert ok.all()
+    for u, (L, n0, mod, tbs, nd) in enumerate(ues):
+        assert np.array_equal(tb[u::4, :tbs // 8], datas[u]), u
+    perm = rng.permutation(len(grants))
+    tb2, ok2 = rx.decode_grants(iq, 5, [grants[i] for i in perm])
+    assert ok2.all()
+    for r, i in enumerate(perm):  # the bytes of each row's own transport block (behind them a row keeps what an earlier, longer block left)
+        nb = grants[i].tbs // 8 + 3
+        assert np.array_equal(tb2[r, :nb], tb[i, :nb]), (r, i)
+    rx.free()
+
+
 def test_cfg5_full_batch_256qam(hp):
     """cfg5: 512 subframes, 256QAM (TBS 97896), through transmit -> receive on the device, noise free; then the 8-bit LLR path of the same
     batch agrees with the 16-bit one on every transport block."""
