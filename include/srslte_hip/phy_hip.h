@@ -422,6 +422,7 @@ typedef struct {
   uint32_t max_batch;
   uint32_t nof_ports;      /* 0 or 1: TM1; 2 or 4: transmit diversity */
   float    p_a;            /* dB; rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports), pdsch.c:518-554 with p_b giving rho_b = 1 */
+  uint32_t max_grants;     /* srslte_hip_dl_tx_batch_grants: PDSCHs per call; 0 = max_batch */
 } srslte_hip_dl_tx_cfg_t;
 srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);
 void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);
@@ -429,6 +430,16 @@ void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);
  * redundancy version of the whole batch (the circular buffer is re-encoded, not kept) */
 int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf, uint32_t rv, void* d_iq,
                            void* stream);
+/* Per-PDSCH grants (srslte_enb_dl_put_base once per TTI, srslte_enb_dl_put_pdsch once per scheduled UE, srslte_enb_dl_gen_signal; enb_dl.c:330-419):
+ * grants[p] = the subframe of the batch and a grant as the receive side takes it (PRB masks of both slots, modulation, transport block <= cfg.tbs,
+ * redundancy version, RNTI, CFI; new_data unused); row p of d_tb is its transport block. Several PDSCHs may share a subframe; its grids carry the
+ * CRS of every port and nothing else besides the PDSCHs (no control region, PSS / SSS / PBCH). d_iq as srslte_hip_dl_tx_batch. */
+typedef struct {
+  uint32_t              sf; /* 0 .. nof_sf-1 */
+  srslte_hip_dl_grant_t grant;
+} srslte_hip_dl_tx_grant_t;
+int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf,
+                                  const srslte_hip_dl_tx_grant_t* grants, uint32_t nof_grants, void* d_iq, void* stream);
 /* intermediate device buffers of the last call: 0 code blocks, 1 parity streams, 2 per-port symbol streams [nof_sf][nof_ports][max nof_re],
  * 3 grids [nof_sf][nof_ports][14][12*nof_prb] */
 const void* srslte_hip_dl_tx_debug_buffer(const srslte_hip_dl_tx_t* q, int which);

@@ -816,14 +816,14 @@ class UlTx:
 
 class DlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32),
-                ("max_batch", C.c_uint32), ("nof_ports", C.c_uint32), ("p_a", C.c_float)]
+                ("max_batch", C.c_uint32), ("nof_ports", C.c_uint32), ("p_a", C.c_float), ("max_grants", C.c_uint32)]
 
 
 class DlTx:
     """Batched PDSCH transmit chain (srslte_pdsch_encode pdsch.c:1059-1185 + CRS + srslte_ofdm_tx_sf, enb_dl.c)."""
 
-    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports=1, p_a=0.0):
-        self.cfg = DlTxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports, p_a)
+    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports=1, p_a=0.0, max_grants=0):
+        self.cfg = DlTxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports, p_a, max_grants)
         L = lib()
         L.srslte_hip_dl_tx_create.restype = C.c_void_p
         L.srslte_hip_dl_tx_create.argtypes = [C.POINTER(DlTxCfg)]
@@ -837,6 +837,22 @@ class DlTx:
         self.tbs, self.max_batch, self.nof_ports = tbs, max_batch, max(1, nof_ports)
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch * self.nof_ports)
+
+    def encode_grants(self, tbs_bytes, tti0, nof_sf, grants):
+        """srslte_hip_dl_tx_batch_grants: grants = list of (sf, DlGrant); tbs_bytes[p] = the payload of grants[p] -> iq [nof_sf][nof_ports][sf_len]."""
+        class TxGrant(C.Structure):
+            _fields_ = [("sf", C.c_uint32), ("grant", DlGrant)]
+        stride = (self.tbs // 8 + 15) & ~15
+        x = np.zeros((len(grants), stride), np.uint8)
+        for p_, b in enumerate(tbs_bytes):
+            x[p_, :len(b)] = b
+        din = DevBuf.from_host(x)
+        arr = (TxGrant * max(1, len(grants)))(*[TxGrant(sf, g) for sf, g in grants])
+        L = lib()
+        L.srslte_hip_dl_tx_batch_grants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _check(L.srslte_hip_dl_tx_batch_grants(self.h, din.ptr, stride, tti0, nof_sf, arr, len(grants), self.d_iq.ptr, None), "dl_tx_batch_grants")
+        sync()
+        return self.d_iq.to_host(np.complex64).reshape(self.max_batch, self.nof_ports, self.sf_len)[:nof_sf]
 
     def encode(self, tb, tti0=0, rv=0):
         """tb: [nof_sf][tbs/8] payload bytes -> iq [nof_sf][nof_ports][sf_len]."""

@@ -1421,6 +1421,30 @@ extern "C" int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_
 // Single-port cells (TM1) and 2- / 4-port cells with transmit diversity (TM2), 1..4 receive antennas, 16- or 8-bit LLRs (cfg.llr_8bit), with or
 // without the CSI weighting of cfg.csi_enable.
 // --------------------------------------------------------------------------------------------------------------------
+// Gold-sequence basis (sequence.c:48-79) for scr_gen_kernel: row 0 = the x1 sequence, row 1 + j = the x2 sequence of c_init = 1 << j, `words`
+// packed words each; all 31 x2 basis sequences advance together, bit j of the state word = basis j
+static int gold_basis_upload(uint32_t words, uint32_t** d_basis)
+{
+  const uint32_t         nbits = words * 32, Nc = 1600, tot = nbits + Nc + 31;
+  std::vector<uint8_t>   x1(tot);
+  std::vector<uint32_t>  x2(tot);
+  for (uint32_t n = 0; n < 31; n++) {
+    x1[n] = n == 0;
+    x2[n] = 1u << n;
+  }
+  for (uint32_t n = 0; n + 31 < tot; n++) {
+    x1[n + 31] = x1[n + 3] ^ x1[n];
+    x2[n + 31] = x2[n + 3] ^ x2[n + 2] ^ x2[n + 1] ^ x2[n];
+  }
+  std::vector<uint32_t> basis((size_t)32 * words, 0);
+  for (uint32_t n = 0; n < nbits; n++) {
+    const uint32_t w = n >> 5, b = n & 31, v2 = x2[n + Nc];
+    basis[w] |= (uint32_t)x1[n + Nc] << b;
+    for (uint32_t j = 0; j < 31; j++) basis[(size_t)(1 + j) * words + w] |= ((v2 >> j) & 1u) << b;
+  }
+  return upload(d_basis, basis);
+}
+
 // Buffers of a grants mode: V per-transport-block slots of up to Cmax code blocks and max_re resource elements each; relist_rows > 0 adds the
 // PDSCH RE lists, csi the CSI rows. Shared by the downlink (slot = subframe, or max_batch + subframe for codeword 1) and the uplink (slot = PUSCH).
 static int grants_alloc(GrantsState* g, uint32_t max_re, uint32_t V, uint32_t Cmax, uint32_t relist_rows, bool csi, size_t extra_desc_bytes)
@@ -1442,27 +1466,7 @@ static int grants_alloc(GrantsState* g, uint32_t max_re, uint32_t V, uint32_t Cm
     g->h_used[i] = false;
   }
   if (!g->tdec) return SRSLTE_ERROR;
-  // Gold-sequence basis (sequence.c:48-79): all 31 x2 basis sequences advance together, bit j of the state word = basis j
-  {
-    const uint32_t         nbits = g->words * 32, Nc = 1600, tot = nbits + Nc + 31;
-    std::vector<uint8_t>   x1(tot);
-    std::vector<uint32_t>  x2(tot);
-    for (uint32_t n = 0; n < 31; n++) {
-      x1[n] = n == 0;
-      x2[n] = 1u << n;
-    }
-    for (uint32_t n = 0; n + 31 < tot; n++) {
-      x1[n + 31] = x1[n + 3] ^ x1[n];
-      x2[n + 31] = x2[n + 3] ^ x2[n + 2] ^ x2[n + 1] ^ x2[n];
-    }
-    std::vector<uint32_t> basis((size_t)32 * g->words, 0);
-    for (uint32_t n = 0; n < nbits; n++) {
-      const uint32_t w = n >> 5, b = n & 31, v2 = x2[n + Nc];
-      basis[w] |= (uint32_t)x1[n + Nc] << b;
-      for (uint32_t j = 0; j < 31; j++) basis[(size_t)(1 + j) * g->words + w] |= ((v2 >> j) & 1u) << b;
-    }
-    if (upload(&g->d_basis, basis)) return SRSLTE_ERROR;
-  }
+  if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
   const size_t nblk = (size_t)g->V * g->Cmax;
   g->desc_bytes     = sizeof(GrantDev) * g->V + sizeof(SfDesc) * g->V + sizeof(CbDesc) * nblk + sizeof(uint32_t) * nblk + extra_desc_bytes;
   for (int i = 0; i < 4; i++) {
@@ -1563,6 +1567,53 @@ static int grants_crc_factors(GrantsState* g, uint32_t tbs, const uint32_t** d_f
   }
   *d_fac = it->second;
   return SRSLTE_SUCCESS;
+}
+
+// The PRB masks of a grant as the RE-list kernel wants them, upstream's stale `offset` values, and the number of PDSCH REs of the allocation
+// (what pdsch_relist_kernel will list). gd.sf_idx / gd.lstart must be set; shared by the receive and the transmit grants modes.
+static uint32_t pdsch_grant_dev(const srslte_hip_dl_grant_t& gr, uint32_t P, uint32_t cell_id, int npt, GrantDev& gd)
+{
+  const uint32_t sf_idx = (uint32_t)gd.sf_idx, lstart = (uint32_t)gd.lstart;
+  bool any0 = false, below1 = false;
+  for (uint32_t n = 0; n < P; n++) {
+    for (int s_ = 0; s_ < 2; s_++) {
+      if ((gr.prb_mask[s_][n >> 5] >> (n & 31)) & 1u) {
+        gd.mask[s_][n >> 5] |= 1u << (n & 31);
+        if (s_ == 0) any0 = true;
+        if (s_ == 1 && n + 3 < P / 2) below1 = true;
+      }
+    }
+  }
+  // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them;
+  // with 2 / 4 ports every CRS symbol sets the same value
+  bool any1_whole = false; // any whole (non-centre) PRB of slot 1: by symbol 1 its symbol-0 row has set `offset` too
+  for (uint32_t n = 0; n < P; n++) {
+    if (((gr.prb_mask[1][n >> 5] >> (n & 31)) & 1u) && !(n >= P / 2 - 3 && n < P / 2 + 3 + (P % 2))) any1_whole = true;
+  }
+  gd.q_off = npt == 1 ? (below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0))
+                      : (((below1 || any0) ? (int)(cell_id % 3) : 0) | (((below1 || any0 || any1_whole) ? (int)(cell_id % 3) : 0) << 8));
+  // number of PDSCH REs (what pdsch_relist_kernel will list; srslte_ra_dl_grant_nof_re): per symbol, whole PRBs carry 12 REs (10 with
+  // CRS, 8 on a multi-port cell), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half
+  // there half of that
+  auto pop = [](const uint32_t* m, const uint32_t* f) {
+    return __builtin_popcount(m[0] & f[0]) + __builtin_popcount(m[1] & f[1]) + __builtin_popcount(m[2] & f[2]) + __builtin_popcount(m[3] & f[3]);
+  };
+  uint32_t centre[4] = {0, 0, 0, 0}, half[4] = {0, 0, 0, 0}, all[4] = {~0u, ~0u, ~0u, ~0u};
+  for (uint32_t n = P / 2 - 3; n < P / 2 + 3 + (P % 2); n++) centre[n >> 5] |= 1u << (n & 31);
+  if (P % 2) {
+    half[(P / 2 - 3) >> 5] |= 1u << ((P / 2 - 3) & 31);
+    half[(P / 2 + 3) >> 5] |= 1u << ((P / 2 + 3) & 31);
+  }
+  uint32_t nre = 0;
+  for (int sym = 0; sym < 14; sym++) {
+    const int s_ = sym / 7, l = sym % 7;
+    if (s_ == 0 && l < (int)lstart) continue;
+    const bool ref = l == 0 || l == 4 || (l == 1 && npt == 4), sync = (s_ == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s_ == 1 && sf_idx == 0 && l < 4);
+    const int  per = ref ? (npt == 1 ? 10 : 8) : 12;
+    nre += per * pop(gd.mask[s_], all);
+    if (sync) nre += (per / 2) * pop(gd.mask[s_], half) - per * pop(gd.mask[s_], centre);
+  }
+  return nre;
 }
 
 // Host side of one grants-mode call: transport blocks are added one by one (descriptor of their slot, one descriptor per code block, decoder
@@ -1756,45 +1807,7 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
               g2.pmi, g2.tbs2);
       return SRSLTE_ERROR_INVALID_INPUTS;
     }
-    bool any0 = false, below1 = false;
-    for (uint32_t n = 0; n < P; n++) {
-      for (int s_ = 0; s_ < 2; s_++) {
-        if ((gr.prb_mask[s_][n >> 5] >> (n & 31)) & 1u) {
-          gd.mask[s_][n >> 5] |= 1u << (n & 31);
-          if (s_ == 0) any0 = true;
-          if (s_ == 1 && n + 3 < P / 2) below1 = true;
-        }
-      }
-    }
-    // upstream's `offset` when it reaches the half PRBs of slot 1, symbol 0 (pdsch.c:147-157,:172-190): set by the whole PRBs before them;
-    // with 2 / 4 ports every CRS symbol sets the same value
-    bool any1_whole = false; // any whole (non-centre) PRB of slot 1: by symbol 1 its symbol-0 row has set `offset` too
-    for (uint32_t n = 0; n < P; n++) {
-      if (((gr.prb_mask[1][n >> 5] >> (n & 31)) & 1u) && !(n >= P / 2 - 3 && n < P / 2 + 3 + (P % 2))) any1_whole = true;
-    }
-    gd.q_off = npt == 1 ? (below1 ? (int)(cell_id % 6) : (any0 ? (int)((cell_id + 3) % 6) : 0))
-                        : (((below1 || any0) ? (int)(cell_id % 3) : 0) | (((below1 || any0 || any1_whole) ? (int)(cell_id % 3) : 0) << 8));
-    // number of PDSCH REs (what pdsch_relist_kernel will list; srslte_ra_dl_grant_nof_re): per symbol, whole PRBs carry 12 REs (10 with
-    // CRS, 8 on a multi-port cell), PRBs inside the PSS / SSS / PBCH region of a sync symbol none, the two PRBs an odd bandwidth cuts in half
-    // there half of that
-    auto pop = [](const uint32_t* m, const uint32_t* f) {
-      return __builtin_popcount(m[0] & f[0]) + __builtin_popcount(m[1] & f[1]) + __builtin_popcount(m[2] & f[2]) + __builtin_popcount(m[3] & f[3]);
-    };
-    uint32_t centre[4] = {0, 0, 0, 0}, half[4] = {0, 0, 0, 0}, all[4] = {~0u, ~0u, ~0u, ~0u};
-    for (uint32_t n = P / 2 - 3; n < P / 2 + 3 + (P % 2); n++) centre[n >> 5] |= 1u << (n & 31);
-    if (P % 2) {
-      half[(P / 2 - 3) >> 5] |= 1u << ((P / 2 - 3) & 31);
-      half[(P / 2 + 3) >> 5] |= 1u << ((P / 2 + 3) & 31);
-    }
-    uint32_t nre = 0;
-    for (int sym = 0; sym < 14; sym++) {
-      const int s_ = sym / 7, l = sym % 7;
-      if (s_ == 0 && l < (int)lstart) continue;
-      const bool ref = l == 0 || l == 4 || (l == 1 && npt == 4), sync = (s_ == 0 && (sf_idx == 0 || sf_idx == 5) && l >= 5) || (s_ == 1 && sf_idx == 0 && l < 4);
-      const int  per = ref ? (npt == 1 ? 10 : 8) : 12;
-      nre += per * pop(gd.mask[s_], all);
-      if (sync) nre += (per / 2) * pop(gd.mask[s_], half) - per * pop(gd.mask[s_], centre);
-    }
+    const uint32_t nre = pdsch_grant_dev(gr, P, cell_id, npt, gd);
     if (!two_layer && (nre % (uint32_t)npt)) { // the transmit-diversity pre-decoders take the REs in groups of nof_ports (precoding.c:564-650)
       hip_log("[srslte_hip] dl_rx grants: subframe %u: %u REs are not a multiple of the %d ports\n", b, nre, npt);
       return SRSLTE_ERROR_INVALID_INPUTS;
@@ -3098,15 +3111,15 @@ struct PdschTxGeom {
 // grid = (ceil(max_re / (256 * G)), nof_sf), G = nof_ports: one thread per precoding group (one symbol for TM1, the SFBC pair 2i, 2i+1 for
 // 2 ports, four symbols for 4 ports). Bit e of a code block = coded bit rm[e mod (3K+12)] in the encoder's byte streams, as in
 // pusch_tx_mod_kernel; the block split counts in units of Qm * N_L bits (N_L = 2 with transmit diversity). y: [nof_sf][nof_ports][max_re].
-__global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
-                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
-                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ y, PdschTxGeom g)
+// One transport block: nre symbols in precoding groups of G = nof_ports; cs: its scrambling bits; cb0: its first code-block slot; C / Qm / rm_len /
+// lvl: of ITS segmentation and modulation; y0: its [nof_ports][max_re] symbol streams.
+__device__ __forceinline__ void pdsch_tx_mod_body(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity, const uint8_t* __restrict__ sys_tail,
+                                                  const uint32_t* __restrict__ rm, const uint32_t* __restrict__ cs, cf32* __restrict__ y0, const PdschTxGeom& g,
+                                                  int grp, int nre, int cb0, int C, int Qm, int rm_len, const float* __restrict__ lvl)
 {
-  const int sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nre = g.cls[sf_class(sf_idx)].nof_re;
-  const int grp = blockIdx.x * blockDim.x + threadIdx.x, G = g.nof_ports, Gp = nre / g.Nl; // Gp = G' of 36.212 5.1.4.1.2
+  const int G = g.nof_ports, Gp = nre / g.Nl; // Gp = G' of 36.212 5.1.4.1.2
   if (grp * G >= nre) return;
-  const int QmL = g.Qm * g.Nl, gamma = Gp % g.C, lo = Gp / g.C, C_lo = g.C - gamma; // blocks 0..C_lo-1 carry lo units, the rest lo + 1 (sch.c:232-236)
-  const uint32_t* cs = scr + (size_t)sf_idx * g.scr_words;
+  const int QmL = Qm * g.Nl, gamma = Gp % C, lo = Gp / C, C_lo = C - gamma; // blocks 0..C_lo-1 carry lo units, the rest lo + 1 (sch.c:232-236)
   cf32            d[4];
   for (int t = 0; t < G; t++) {
     const int i = grp * G + t, u = i / g.Nl; // symbol, split unit
@@ -3119,22 +3132,21 @@ __global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __rest
       r           = C_lo + v / (lo + 1);
       e0          = (v % (lo + 1)) * QmL;
     }
-    e0 += (i % g.Nl) * g.Qm;
-    const size_t   cbi = (size_t)sf * g.C + r;
+    e0 += (i % g.Nl) * Qm;
+    const size_t   cbi = (size_t)cb0 + r;
     const uint8_t *xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
-    const int      q0 = i * g.Qm;
+    const int      q0 = i * Qm;
     int            re = 0, im = 0;
-    for (int b = 0; b < g.Qm; b++) {
-      const uint32_t src = rm[(e0 + b) % g.rm_len], pos = src & 0x3fffffffu;
+    for (int b = 0; b < Qm; b++) {
+      const uint32_t src = rm[(e0 + b) % rm_len], pos = src & 0x3fffffffu;
       const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
       int            bit  = (byte >> (7 - (pos & 7))) & 1;
       bit ^= (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
       if (b & 1) im = (im << 1) | bit;
       else re = (re << 1) | bit;
     }
-    d[t] = make_float2(g.lvl[re] * g.gain, g.lvl[im] * g.gain);
+    d[t] = make_float2(lvl[re] * g.gain, lvl[im] * g.gain);
   }
-  cf32*      y0 = y + ((size_t)sf * g.nof_ports) * g.max_re;
   const cf32 z  = make_float2(0.f, 0.f);
   if (G == 1) {
     y0[grp] = d[0];
@@ -3152,6 +3164,83 @@ __global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __rest
     y0[k + 2] = z;    y1[k + 2] = d[2]; y2[k + 2] = z; y3[k + 2] = make_float2(-d[3].x, d[3].y);
     y0[k + 3] = z;    y1[k + 3] = d[3]; y2[k + 3] = z; y3[k + 3] = make_float2(d[2].x, -d[2].y);
   }
+}
+
+
+__global__ __launch_bounds__(256) void pdsch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
+                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ y, PdschTxGeom g)
+{
+  const int sf = blockIdx.y, sf_idx = (g.tti0 + sf) % 10, nre = g.cls[sf_class(sf_idx)].nof_re, grp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (grp * g.nof_ports >= nre) return;
+  pdsch_tx_mod_body(cb, parity, sys_tail, rm, scr + (size_t)sf_idx * g.scr_words, y + ((size_t)sf * g.nof_ports) * g.max_re, g, grp, nre, sf * g.C, g.C, g.Qm,
+                    g.rm_len, g.lvl);
+}
+
+// ---- per-PDSCH grants on the transmit side (srslte_hip_dl_tx_batch_grants): PDSCH p of a call has its own allocation, RNTI, modulation, transport
+// block and redundancy version; several may share a subframe's grid
+struct TxDesc {
+  int             row, sf;             // row of the caller's d_tb; subframe of the batch
+  int             tbs, C, K, rlenB;    // segmentation of its transport block
+  int             cb0;                 // its first code-block slot (slots have the strides of the largest block size)
+  int             nre, mod, Qm;
+  const uint32_t* rm;                  // rate-matching table of (K, rv)
+};
+struct TxLevels { float v[5][16]; };   // constellation levels of one axis per srslte_mod_t
+
+// grid = nof_pdsch: CRC24A of each transport block
+__global__ __launch_bounds__(256) void tx_tbcrc_grants_kernel(const uint8_t* __restrict__ tb, int tb_stride, const TxDesc* __restrict__ desc,
+                                                              uint32_t* __restrict__ crc_out)
+{
+  __shared__ uint32_t tab[256], red[256];
+  const uint8_t*      x = tb + (size_t)desc[blockIdx.x].row * tb_stride;
+  const uint32_t      c = block_crc24([&](int i) { return (uint32_t)x[i]; }, desc[blockIdx.x].tbs / 8, 0x1864CFBu, tab, red);
+  if (threadIdx.x == 0) crc_out[blockIdx.x] = c;
+}
+
+// grid = (Cmax, nof_pdsch): segmentation + CRC24B as pusch_tx_seg_kernel, per descriptor
+__global__ __launch_bounds__(256) void tx_seg_grants_kernel(const uint8_t* __restrict__ tb, int tb_stride, const uint32_t* __restrict__ tbcrc,
+                                                            const TxDesc* __restrict__ desc, uint8_t* __restrict__ cb, int cb_stride)
+{
+  __shared__ uint32_t tab[256], red[256];
+  __shared__ uint8_t  xs[768];
+  const TxDesc&       d = desc[blockIdx.y];
+  const int           r = blockIdx.x, t = threadIdx.x, tbB = d.tbs / 8, rlenB = d.rlenB;
+  if (r >= d.C) return;
+  const uint8_t* x   = tb + (size_t)d.row * tb_stride;
+  const uint32_t crc = tbcrc[blockIdx.y];
+  uint8_t*       out = cb + ((size_t)d.cb0 + r) * cb_stride;
+  for (int i = t; i < rlenB; i += 256) {
+    const int j = r * rlenB + i;
+    xs[i]       = j < tbB ? x[j] : (uint8_t)(crc >> (8 * (2 - (j - tbB))));
+  }
+  __syncthreads();
+  for (int i = t; i < rlenB; i += 256) out[i] = xs[i];
+  if (d.C > 1) {
+    const uint32_t c = block_crc24([&](int i) { return (uint32_t)xs[i]; }, rlenB, 0x1800063u, tab, red);
+    if (t < 3) out[rlenB + t] = (uint8_t)(c >> (8 * (2 - t)));
+  }
+}
+
+// grid = (ceil(max_re / (256 * G)), nof_pdsch)
+__global__ __launch_bounds__(256) void pdsch_tx_mod_grants_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                                  const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ scr, int scr_words,
+                                                                  cf32* __restrict__ y, const TxDesc* __restrict__ desc, TxLevels lv, PdschTxGeom g)
+{
+  const TxDesc& d   = desc[blockIdx.y];
+  const int     grp = blockIdx.x * blockDim.x + threadIdx.x;
+  if (grp * g.nof_ports >= d.nre) return;
+  pdsch_tx_mod_body(cb, parity, sys_tail, d.rm, scr + (size_t)blockIdx.y * scr_words, y + ((size_t)blockIdx.y * g.nof_ports) * g.max_re, g, grp, d.nre, d.cb0,
+                    d.C, d.Qm, 3 * d.K + 12, lv.v[d.mod]);
+}
+
+// grid = (ceil(max_re / 256), nof_pdsch * nof_ports): the symbols of PDSCH p, port by port, onto the REs of its list in its subframe's grids
+__global__ __launch_bounds__(256) void pdsch_tx_scatter_kernel(const cf32* __restrict__ y, const uint32_t* __restrict__ relist, cf32* __restrict__ grid,
+                                                               const TxDesc* __restrict__ desc, int max_re, int grid_len, int nof_ports)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y / nof_ports, port = blockIdx.y - p * nof_ports;
+  if (i >= desc[p].nre) return;
+  grid[((size_t)desc[p].sf * nof_ports + port) * grid_len + relist[(size_t)p * max_re + i]] = y[((size_t)p * nof_ports + port) * max_re + i];
 }
 
 // grid = (ceil(grid_len/256), nof_sf * nof_ports): the resource grid of one port: PDSCH symbols, this port's CRS, zero elsewhere
@@ -3182,7 +3271,42 @@ struct srslte_hip_dl_tx {
   int32_t*               d_src[3][4];
   uint8_t *              d_cb, *d_parity, *d_sys_tail;
   cf32 *                 d_y, *d_grid;
+  struct TxGrantsState*  gs; // srslte_hip_dl_tx_batch_grants: created on first use
 };
+
+// Device / host resources of the per-PDSCH grants mode of the transmit pipeline
+struct TxGrantsState {
+  uint32_t  V, Cmax, max_re, words, cb_stride, par_stride;
+  uint32_t *d_relist, *d_scr, *d_basis, *d_tbcrc;
+  uint8_t * d_cb, *d_parity, *d_sys_tail, *d_desc;
+  cf32*     d_y;
+  int32_t*  d_crs_src[4]; // per port: grid RE -> -1 (zero) or the CRS pilot -(v + 2), for pdsch_tx_map_kernel as the grid initialiser
+  size_t    desc_bytes;
+  uint8_t*   h_pin[4];
+  hipEvent_t h_ev[4];
+  bool       h_used[4];
+  uint32_t   h_slot;
+  TxLevels   lv;
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t*> rm_tbl; // (K, rv) -> rate-matching table over the encoder's byte streams
+};
+
+static void tx_grants_free(TxGrantsState* g)
+{
+  if (!g) return;
+  void* gb[] = {g->d_relist, g->d_scr, g->d_basis, g->d_tbcrc, g->d_cb, g->d_parity, g->d_sys_tail, g->d_desc, g->d_y,
+                g->d_crs_src[0], g->d_crs_src[1], g->d_crs_src[2], g->d_crs_src[3]};
+  for (void* b : gb) {
+    if (b) (void)hipFree(b);
+  }
+  for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
+  for (int i = 0; i < 4; i++) {
+    if (g->h_pin[i]) {
+      (void)hipHostFree(g->h_pin[i]);
+      (void)hipEventDestroy(g->h_ev[i]);
+    }
+  }
+  delete g;
+}
 
 extern "C" void srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q)
 {
@@ -3199,6 +3323,7 @@ extern "C" void srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q)
       if (b) (void)hipFree(b);
     }
   }
+  tx_grants_free(q->gs);
   delete q;
 }
 
@@ -3332,4 +3457,154 @@ extern "C" int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb
                      (const cf32*)srslte_hip_chest_dl_pilots(q->crs), q->d_grid, 8 * (int)q->cfg.nof_prb, g);
   LAUNCH_CHECK();
   return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf * g.nof_ports, stream);
+}
+
+// Per-PDSCH grants on the transmit side: what an eNB sends in a run of TTIs - srslte_enb_dl_put_base once per TTI, then srslte_enb_dl_put_pdsch
+// once per scheduled UE (enb_dl.c:330-398 -> srslte_pdsch_encode, pdsch.c:1059-1185), each with its own srslte_pdsch_grant_t, then
+// srslte_enb_dl_gen_signal. grants[p]: the subframe of the batch, and a srslte_hip_dl_grant_t as the receive side takes it (PRB masks of both
+// slots, modulation, transport block, redundancy version, RNTI, CFI; new_data is not used). Row p of d_tb is its transport block. The grids are
+// initialised with the CRS of every port, each PDSCH's symbols go onto the REs pdsch_relist_kernel lists for its masks (srslte_pdsch_cp, put =
+// true, including upstream's stale-offset rule), overlapping allocations overwrite each other in grant order as they would upstream. The object's
+// cell, antenna ports (TM1 / transmit diversity), p_a apply; cfg.tbs bounds every grant's tbs, cfg.max_grants the number of PDSCHs per call.
+extern "C" int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf,
+                                             const srslte_hip_dl_tx_grant_t* grants, uint32_t nof_grants, void* d_iq, void* stream)
+{
+  if (!q || !d_tb || !d_iq || !grants || nof_sf > q->cfg.max_batch) return SRSLTE_ERROR_INVALID_INPUTS;
+  const uint32_t V = q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch, P = q->cfg.nof_prb, cell_id = q->cfg.cell_id;
+  const int      npt = q->g.nof_ports;
+  if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  if (!q->gs) {
+    auto* g = new TxGrantsState(); // value-initialised: every pointer and flag starts null / false
+    q->gs         = g;
+    g->V          = V;
+    g->Cmax       = q->seg.C;
+    g->max_re     = 14 * 12 * P;
+    g->words      = (g->max_re * 8 + 31) / 32 + 2;
+    g->cb_stride  = (6144 / 8 + 15) & ~15u;
+    g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
+    const size_t nblk = (size_t)V * g->Cmax;
+    g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc)) * V;
+    for (int i = 0; i < 4; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
+      HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
+    }
+    if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
+    HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * V));
+    HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
+    HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
+    HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+    HIP_TRY(hipMalloc((void**)&g->d_y, sizeof(cf32) * (size_t)g->max_re * V * npt));
+    for (int port = 0; port < npt; port++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272), as srslte_hip_dl_tx_create maps it
+      std::vector<int32_t> src((size_t)14 * 12 * P, -1);
+      for (int l = 0; l < (port < 2 ? 4 : 2); l++) {
+        const uint32_t sym = port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7), fidx = ((((l + port) & 1) ? 3 : 0) + cell_id % 6) % 6;
+        for (uint32_t i = 0; i < 2 * P; i++) src[sym * 12 * P + fidx + 6 * i] = -(int32_t)(l * 2 * P + i) - 2;
+      }
+      if (upload(&g->d_crs_src[port], src)) return SRSLTE_ERROR;
+    }
+    for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
+      for (uint32_t idx = 0; idx < (1u << mod); idx++) {
+        double v = 1.0;
+        for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
+        const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
+        g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
+      }
+    }
+  }
+  TxGrantsState* g  = q->gs;
+  const uint32_t hs = g->h_slot++ & 3u;
+  if (g->h_used[hs]) HIP_TRY(hipEventSynchronize(g->h_ev[hs]));
+  auto* h_gr = reinterpret_cast<GrantDev*>(g->h_pin[hs]);
+  auto* h_td = reinterpret_cast<TxDesc*>(h_gr + V);
+  auto* d_gr = reinterpret_cast<GrantDev*>(g->d_desc);
+  auto* d_td = reinterpret_cast<TxDesc*>(d_gr + V);
+  // code-block slots in the order of the block length, so that the encoder runs once per length over neighbouring slots
+  std::vector<uint32_t>            order(nof_grants);
+  std::vector<srslte_hip_cbsegm_t> segs(nof_grants);
+  uint32_t                         max_nre = 0;
+  for (uint32_t p = 0; p < nof_grants; p++) {
+    const srslte_hip_dl_grant_t& gr = grants[p].grant;
+    order[p] = p;
+    if (grants[p].sf >= nof_sf || gr.mod < 1 || gr.mod > 4 || gr.rv > 3 || gr.cfi < 1 || gr.cfi > 3 || gr.tbs == 0 || gr.tbs > q->cfg.tbs || (gr.tbs % 8) ||
+        tb_stride < gr.tbs / 8 || srslte_hip_cbsegm(&segs[p], gr.tbs) || segs[p].F || segs[p].C2 || segs[p].C > g->Cmax) {
+      hip_log("[srslte_hip] dl_tx grants: entry %u: unsupported grant (subframe %u of %u, mod %d, tbs %u, rv %u, cfi %u)\n", p, grants[p].sf, nof_sf, gr.mod,
+              gr.tbs, gr.rv, gr.cfi);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+  }
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return segs[a].K1 < segs[b].K1; });
+  uint32_t cb0 = 0;
+  for (uint32_t i = 0; i < nof_grants; i++) {
+    const uint32_t               p  = order[i];
+    const srslte_hip_dl_grant_t& gr = grants[p].grant;
+    GrantDev&                    gd = h_gr[p];
+    memset(&gd, 0, sizeof(gd));
+    gd.sf_idx = (int)((tti0 + grants[p].sf) % 10); gd.lstart = (int)(gr.cfi + (P < 10 ? 1 : 0)); gd.rnti = gr.rnti;
+    const uint32_t nre = pdsch_grant_dev(gr, P, cell_id, npt, gd);
+    if (nre == 0 || (nre % (uint32_t)npt) || nre < segs[p].C * (uint32_t)q->g.Nl) {
+      hip_log("[srslte_hip] dl_tx grants: entry %u: %u REs do not carry %u code blocks on %d ports\n", p, nre, segs[p].C, npt);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    max_nre = nre > max_nre ? nre : max_nre;
+    const uint32_t K  = segs[p].K1;
+    auto           it = g->rm_tbl.find({K, gr.rv});
+    if (it == g->rm_tbl.end()) { // rate matching (rm_turbo.c:100-158) addressed in the encoder's byte streams, as dl_tx_rm_table
+      std::vector<uint32_t> t;
+      lte_rm_rx_table(K, gr.rv, t);
+      for (auto& v : t) {
+        const uint32_t pos = v / 3, sidx = v % 3;
+        v = sidx == 0 ? (pos < K ? pos : (1u << 30) | (pos - K)) : (2u << 30) | (sidx == 1 ? pos : K + 4 + pos);
+      }
+      uint32_t* d = nullptr;
+      if (upload(&d, t)) return SRSLTE_ERROR;
+      it = g->rm_tbl.emplace(std::make_pair(K, gr.rv), d).first;
+    }
+    TxDesc& td = h_td[p];
+    td.row = (int)p; td.sf = (int)grants[p].sf; td.tbs = (int)gr.tbs; td.C = (int)segs[p].C; td.K = (int)K; td.rlenB = (int)((segs[p].C == 1 ? K : K - 24) / 8);
+    td.cb0 = (int)cb0; td.nre = (int)nre; td.mod = gr.mod; td.Qm = 2 * gr.mod; td.rm = it->second;
+    cb0 += segs[p].C;
+  }
+  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_pin[hs], g->desc_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(g->h_ev[hs], st));
+  g->h_used[hs] = true;
+  PdschTxGeom tg = q->g; // ports, N_L, gain; the grid initialiser's maps
+  tg.max_re = (int)g->max_re;
+  tg.cb_stride = (int)g->cb_stride; tg.par_stride = (int)g->par_stride; // the slots of this mode are spaced for the largest block length
+  for (auto& c : tg.src) {
+    for (int port = 0; port < 4; port++) c[port] = g->d_crs_src[port];
+  }
+  tg.tti0 = (int)tti0;
+  hipLaunchKernelGGL(pdsch_tx_map_kernel, dim3(ceil_div(tg.grid_len, 256), nof_sf * npt), dim3(256), 0, st, (const cf32*)g->d_y,
+                     (const cf32*)srslte_hip_chest_dl_pilots(q->crs), q->d_grid, 8 * (int)P, tg);
+  LAUNCH_CHECK();
+  if (nof_grants) {
+    hipLaunchKernelGGL(pdsch_relist_kernel, dim3(nof_grants), dim3(RELIST_THREADS), 0, st, (const GrantDev*)d_gr, g->d_relist, (int)P, (int)cell_id,
+                       (int)g->max_re, npt);
+    hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_grants), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis,
+                       g->d_scr, (int)g->words, (int)cell_id);
+    hipLaunchKernelGGL(tx_tbcrc_grants_kernel, dim3(nof_grants), dim3(256), 0, st, d_tb, (int)tb_stride, (const TxDesc*)d_td, g->d_tbcrc);
+    hipLaunchKernelGGL(tx_seg_grants_kernel, dim3(g->Cmax, nof_grants), dim3(256), 0, st, d_tb, (int)tb_stride, (const uint32_t*)g->d_tbcrc, (const TxDesc*)d_td,
+                       g->d_cb, (int)g->cb_stride);
+    LAUNCH_CHECK();
+    for (uint32_t i = 0; i < nof_grants;) { // the encoder: runs of equal block length
+      uint32_t j = i, n = 0;
+      while (j < nof_grants && segs[order[j]].K1 == segs[order[i]].K1) n += segs[order[j++]].C;
+      const size_t s0 = (size_t)h_td[order[i]].cb0;
+      if (int r = srslte_hip_tcod_encode_bytes_batch(g->d_cb + s0 * g->cb_stride, g->cb_stride, g->d_parity + s0 * g->par_stride, g->par_stride,
+                                                     g->d_sys_tail + s0, segs[order[i]].K1, n, stream))
+        return r;
+      i = j;
+    }
+    hipLaunchKernelGGL(pdsch_tx_mod_grants_kernel, dim3(ceil_div((int)max_nre / npt, 256), nof_grants), dim3(256), 0, st, (const uint8_t*)g->d_cb,
+                       (const uint8_t*)g->d_parity, (const uint8_t*)g->d_sys_tail, (const uint32_t*)g->d_scr, (int)g->words, g->d_y, (const TxDesc*)d_td, g->lv, tg);
+    hipLaunchKernelGGL(pdsch_tx_scatter_kernel, dim3(ceil_div((int)max_nre, 256), nof_grants * npt), dim3(256), 0, st, (const cf32*)g->d_y,
+                       (const uint32_t*)g->d_relist, q->d_grid, (const TxDesc*)d_td, (int)g->max_re, tg.grid_len, npt);
+    LAUNCH_CHECK();
+  }
+  return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf * npt, stream);
 }

@@ -1671,3 +1671,30 @@ def test_ulsch_harq_vs_reference(prb, L, mod, tbs, snr, short, O_ack, O_ri):
                 break
         first_fail_later_ok += (not oks[0]) and oks[-1]
     assert first_fail_later_ok > 0
+
+
+@pytest.mark.parametrize("prb,npt,spans0,spans1,mod,tbs", [(25, 1, [(0, 8)], None, 2, 2216), (25, 2, [(8, 17)], None, 1, 1000), (25, 1, [(0, 2), (10, 14), (20, 23)], None, 1, 776),
+                                                          (25, 2, [(2, 10)], [(14, 20)], 2, 2216), (100, 1, [(0, 4), (40, 60), (90, 100)], None, 2, 9144),
+                                                          (100, 2, [(30, 70)], None, 3, 22152), (25, 4, [(4, 25)], None, 3, 4008), (15, 1, [(5, 11)], None, 2, 1000)])
+def test_pdsch_encode_with_prb_masks_vs_stimulus_generator(prb, npt, spans0, spans1, mod, tbs):
+    """The reference's srslte_pdsch_encode with partial allocations (srslte_pdsch_grant_t.prb_idx of either slot: contiguous, scattered, different
+    in the two slots, across the PSS / SSS / PBCH region of subframes 0 and 5) against the oracle's transmit chain with the same masks: the
+    per-port grids. This is what tests/test_gpu_dl_tx_grants.py compares the device's per-PDSCH transmit mode with."""
+    from lte_sim import RefPdschTx
+    rng = np.random.default_rng(2900 + prb + npt + mod)
+    mask = np.zeros((2, prb), np.uint8)
+    for s, spans in enumerate((spans0, spans0 if spans1 is None else spans1)):
+        for a, b in spans:
+            mask[s, a:b] = 1
+    cfg = DlConfig(prb, 7, mod, tbs, nof_ports=npt, prb_mask=mask)
+    chain = RefPdschTx(cfg)
+    for t, rv in ((0, 0), (5, 2), (3, 1), (8, 0)):
+        if len(cfg.indices(t % 10)) % npt:
+            continue
+        k = {}
+        _, data = make_subframe(cfg, t, rng, rv=rv, keep=k)
+        grids = chain.run(data, t, rv=rv)
+        for port in range(npt):
+            exp = np.zeros(cfg.grid_len, np.complex64)
+            exp[k["idx"]] = k["y"][port] * (np.sqrt(2.0) if npt > 1 else 1.0)
+            assert np.abs(grids[port] - exp).max() <= 1e-6, (t, rv, port)
