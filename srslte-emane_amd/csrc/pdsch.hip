@@ -3464,7 +3464,8 @@ extern "C" int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb
 // srslte_enb_dl_gen_signal. grants[p]: the subframe of the batch, and a srslte_hip_dl_grant_t as the receive side takes it (PRB masks of both
 // slots, modulation, transport block, redundancy version, RNTI, CFI; new_data is not used). Row p of d_tb is its transport block. The grids are
 // initialised with the CRS of every port, each PDSCH's symbols go onto the REs pdsch_relist_kernel lists for its masks (srslte_pdsch_cp, put =
-// true, including upstream's stale-offset rule), overlapping allocations overwrite each other in grant order as they would upstream. The object's
+// true, including upstream's stale-offset rule); allocations that overlap within a subframe are the caller's error (which PDSCH wins an RE is
+// not defined here; upstream the later put would). The object's
 // cell, antenna ports (TM1 / transmit diversity), p_a apply; cfg.tbs bounds every grant's tbs, cfg.max_grants the number of PDSCHs per call.
 extern "C" int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, uint32_t tti0, uint32_t nof_sf,
                                              const srslte_hip_dl_tx_grant_t* grants, uint32_t nof_grants, void* d_iq, void* stream)
