@@ -282,6 +282,9 @@ typedef struct {
 } srslte_hip_dl_grant2_t;
 int srslte_hip_dl_rx_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
                                    uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+/* ... from frequency-domain grids d_grid, as srslte_hip_dl_rx_grid_batch takes them (the caller ran the OFDM demodulation) */
+int srslte_hip_dl_rx_grid_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
+                                        uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,

@@ -526,18 +526,20 @@ class DlRx:
         tb = self.d_tb.to_host(np.uint8).reshape(self.max_batch, self.tb_stride)[:x.shape[0], :self.tbs // 8 + 3]
         return rc, tb, self.d_ok.to_host(np.uint8)[:x.shape[0]]
 
-    def decode_grants2(self, iq, tti0, grants):
+    def decode_grants2(self, iq, tti0, grants, from_grid=False):
         """srslte_hip_dl_rx_batch_grants2: subframe b with grants[b] (DlGrant2: scheme, pmi and a second transport block per subframe).
-        Returns (rc, [tb0 rows, tb1 rows], [ok0, ok1]); on a cell without two-layer grants the second entries are None."""
-        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * self.sf_len)
+        Returns (rc, [tb0 rows, tb1 rows], [ok0, ok1]); on a cell without two-layer grants the second entries are None.
+        from_grid: iq holds frequency-domain grids [nsf][nof_rx][14 * 12 * nof_prb] (srslte_hip_dl_rx_grid_batch_grants2)."""
+        x = np.ascontiguousarray(iq, np.complex64).reshape(-1, self.nof_rx * (14 * 12 * self.cfg.nof_prb if from_grid else self.sf_len))
         n = x.shape[0]
         assert len(grants) == n
         two = self.cfg.nof_ports == 2 and self.cfg.nof_rx_antennas == 2
         arr = (DlGrant2 * n)(*grants)
         din, dtb, dok = DevBuf.from_host(x), DevBuf(self.tb_stride * n * 2), DevBuf(2 * n)
         L = lib()
-        L.srslte_hip_dl_rx_batch_grants2.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
-        rc = L.srslte_hip_dl_rx_batch_grants2(self.h, din.ptr, tti0, n, arr, dtb.ptr, self.tb_stride, dok.ptr, None)
+        fn = L.srslte_hip_dl_rx_grid_batch_grants2 if from_grid else L.srslte_hip_dl_rx_batch_grants2
+        fn.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        rc = fn(self.h, din.ptr, tti0, n, arr, dtb.ptr, self.tb_stride, dok.ptr, None)
         if rc != SRSLTE_SUCCESS:
             return rc, None, None
         sync()

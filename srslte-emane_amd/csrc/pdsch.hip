@@ -1751,6 +1751,17 @@ extern "C" int srslte_hip_dl_rx_batch_grants2(srslte_hip_dl_rx_t* q, const void*
   return grants_run(q, d_iq, tti0, nof_sf, grants, d_tb, tb_stride, d_tb_ok, stream, true);
 }
 
+// The same from frequency-domain grids (what follows srslte_ofdm_rx_sf in ue_dl.c:375-397; d_grid as srslte_hip_dl_rx_grid_batch takes it)
+extern "C" int srslte_hip_dl_rx_grid_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
+                                                   uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream)
+{
+  if (!q || !d_grid) return SRSLTE_ERROR_INVALID_INPUTS;
+  q->grid_in  = (const cf32*)d_grid;
+  const int r = grants_run(q, d_grid, tti0, nof_sf, grants, d_tb, tb_stride, d_tb_ok, stream, true);
+  q->grid_in  = nullptr;
+  return r;
+}
+
 // second_rows: rows nof_sf .. 2 nof_sf - 1 of d_tb / d_tb_ok exist (srslte_hip_dl_rx_batch_grants2 on a cell where two-layer grants can occur)
 static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants, uint8_t* d_tb,
                       uint32_t tb_stride, uint8_t* d_tb_ok, void* stream, bool second_rows)
@@ -1828,7 +1839,7 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
   }
   bd.fill_map(h_map);
   // stages 0, 1: OFDM demodulation and channel estimation do not depend on the grants
-  int r = srslte_hip_dl_rx_stage(q, 0, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
+  int r = q->grid_in ? SRSLTE_SUCCESS : srslte_hip_dl_rx_stage(q, 0, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream); // grids from the caller: no OFDM stage
   if (!r) r = srslte_hip_dl_rx_stage(q, 1, d_iq, tti0, nof_sf, d_tb, tb_stride, d_tb_ok, stream);
   if (r) return r;
   // the descriptors
@@ -1849,7 +1860,7 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
     PdschGeom pg = q->pg;
     pg.desc = d_sf; pg.tti0 = (int)tti0; pg.max_re = (int)g->max_re; pg.max_bits = (int)g->max_bits; pg.csi = g->d_csi; pg.csi_max = g->d_csi_max;
     if (g->d_csi_max) HIP_TRY(hipMemsetAsync(g->d_csi_max, 0, sizeof(uint32_t) * V, st));
-    const cf32* grid = q->d_grid;
+    const cf32* grid = q->grid_in ? q->grid_in : q->d_grid;
     if (pg.nof_ports == 4) {
       if (l8) {
         hipLaunchKernelGGL(pdsch_demod_div4_kernel<int8_t>, dim3(ceil_div((int)g->max_re, 1024), nof_sf), dim3(256), 0, st, grid, (const cf32*)q->d_ce,
