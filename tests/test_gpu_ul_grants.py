@@ -35,10 +35,11 @@ UE_SETS_100 = [
 ]
 
 
-@pytest.mark.parametrize("prb,sets,tti0", [(25, UE_SETS_25, 7), (100, UE_SETS_100, 18)])
-def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
+@pytest.mark.parametrize("prb,sets,tti0,short", [(25, UE_SETS_25, 7, False), (100, UE_SETS_100, 18, False), (25, UE_SETS_25, 2, True)])
+def test_ul_grants_vs_oracle(hp, prb, sets, tti0, short):
     """Every PUSCH: estimator noise figure, de-precoded symbols, de-interleaved LLRs (<= 1 LSB on <= 0.1 %), per-block pass counts, CRC flag
-    and bytes equal the oracle's for that UE on the summed time signal of its subframe."""
+    and bytes equal the oracle's for that UE on the summed time signal of its subframe. short: a cell-wide shortened subframe (11 data symbols,
+    the last one left to the SRS), which moves the UCI columns and every Q'."""
     from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
     rng = np.random.default_rng(4100 + prb)
     nsf = len(sets)
@@ -48,7 +49,7 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
         x, sig = None, []
         for u, (L, n0, n1, mod, tbs, n_dmrs, snr) in enumerate(ue_list):
             rnti = 0x100 + 16 * b + u
-            cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=rnti, n_prb_slot1=n1 if n1 != n0 else None, **dm)
+            cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=rnti, n_prb_slot1=n1 if n1 != n0 else None, shortened=short, **dm)
             gain = (0.7 + 0.1 * u) * np.exp(0.3j * (u + 1))
             # every other PUSCH also carries HARQ-ACK (1 or 2 bits) and, every third, a rank indication
             O_ack, O_ri = ((u + b) % 2) * (1 + (u % 2)), 1 if (u + b) % 3 == 0 else 0
@@ -67,7 +68,7 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
         x = x + min(sig) * (rng.standard_normal(x.size) + 1j * rng.standard_normal(x.size))  # one receiver noise: every UE at its SNR or better
         iq.append(x.astype(np.complex64))
     max_tbs = max(g.tbs for g in grants)
-    rx = hp.UlRx(11, prb, 0x1234, 1, max_tbs, 6, 0, 0, 6, nsf, 2, 5, True, False, max_grants=len(grants))
+    rx = hp.UlRx(11, prb, 0x1234, 1, max_tbs, 6, 0, 0, 6, nsf, 2, 5, True, False, max_grants=len(grants), shortened=short)
     tb, ok = rx.decode_grants(np.stack(iq), tti0, grants)
     n = len(grants)
     res = rx.debug(20, np.float32, n * 5).reshape(n, 5)
@@ -78,7 +79,7 @@ def test_ul_grants_vs_oracle(hp, prb, sets, tti0):
     off = 0
     for p in order:
         zoff_of[p] = off
-        off += 12 * 12 * grants[p].L_prb
+        off += (11 if short else 12) * 12 * grants[p].L_prb
     d_all = rx.debug(21, np.complex64, off)
     e_rows = rx.debug(22, np.int16, n * ((12 * 12 * prb * 8 + 15) & ~15)).reshape(n, -1)
     acks, ris = rx.grants_uci()
