@@ -388,6 +388,7 @@ typedef struct {
   uint32_t ri_len, I_offset_ri;   /* as in srslte_hip_ul_rx_cfg_t (sch.c:1110-1129) */
   uint32_t cqi_len, I_offset_cqi; /* as in srslte_hip_ul_rx_cfg_t (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
   uint32_t hopping, n_prb_slot1;  /* as in srslte_hip_ul_rx_cfg_t */
+  uint32_t max_grants;            /* srslte_hip_ul_tx_batch_grants: PUSCHs per call; 0 = max_batch */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);
@@ -408,6 +409,13 @@ int srslte_hip_ul_tx_batch_uci_cqi(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, u
  * HARQ retransmission sends. d_ack / d_ri / d_cqi as above (NULL when not configured). */
 int srslte_hip_ul_tx_batch_rv(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
                               const uint8_t* d_cqi, uint32_t rv, uint32_t tti0, uint32_t nof_sf, void* d_iq, void* stream);
+/* Per-PUSCH grants on the transmit side: grants[p] as srslte_hip_ul_rx_batch_grants takes them (new_data unused) - what srslte_ue_ul_encode sends
+ * TTI after TTI as the grants come in (ue_ul.c:300-340); several PUSCHs on disjoint PRBs of one subframe give the composite signal of several
+ * UEs. Row p of d_tb is its transport block; d_ack / d_ri [nof_grants][2] and d_cqi [nof_grants][64] device bytes, rows p (NULL when no grant of
+ * the call carries that UCI). cfg.tbs bounds every grant's tbs, cfg.max_grants the PUSCHs per call. */
+int srslte_hip_ul_tx_batch_grants(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                  const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants, uint32_t nof_grants,
+                                  void* d_iq, void* stream);
 /* intermediate device buffers of the last call, for parity tests: 0 code blocks (stride (K/8+15)&~15), 1 parity streams (stride
  * (K/4+1+15)&~15), 2 d (modulated), 3 z (after transform precoding), 4 grid, 5 TB CRCs (one word per subframe) */
 const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which);

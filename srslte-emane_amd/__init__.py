@@ -726,7 +726,7 @@ class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
                 ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32),
-                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32), ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
+                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32), ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32)]
 
 
 class UlTx:
@@ -735,10 +735,11 @@ class UlTx:
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
                  sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0, cqi_len=0, I_offset_cqi=0,
-                 n_prb_slot1=None):
+                 n_prb_slot1=None, max_grants=0):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
-                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0)
+                           ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0,
+                           max_grants)
         L = lib()
         L.srslte_hip_ul_tx_batch_uci_cqi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                      C.c_void_p, C.c_void_p]
@@ -756,6 +757,33 @@ class UlTx:
         self.tbs, self.max_batch = tbs, max_batch
         self.sf_len = 15 * symbol_sz(nof_prb)
         self.d_iq = DevBuf(8 * self.sf_len * max_batch)
+
+    def encode_grants(self, tbs_bytes, tti0, nof_sf, grants, ack=None, ri=None, cqi=None):
+        """srslte_hip_ul_tx_batch_grants: grants = list of UlGrant, tbs_bytes[p] the payload of grants[p]; ack / ri: [nof_grants][<= 2] values,
+        cqi: [nof_grants][<= 64] report bits (rows of grants without that UCI are ignored) -> iq [nof_sf][sf_len]."""
+        n = len(grants)
+        stride = (self.tbs // 8 + 15) & ~15
+        x = np.zeros((max(n, 1), stride), np.uint8)
+        for p_, b in enumerate(tbs_bytes):
+            x[p_, :len(b)] = b
+        din = DevBuf.from_host(x)
+        bufs = []
+        for v, w in ((ack, 2), (ri, 2), (cqi, 64)):
+            if v is None:
+                bufs.append(None)
+                continue
+            a = np.zeros((max(n, 1), w), np.uint8)
+            for p_, row in enumerate(v):
+                a[p_, :len(row)] = row
+            bufs.append(DevBuf.from_host(a))
+        arr = (UlGrant * max(n, 1))(*grants)
+        L = lib()
+        L.srslte_hip_ul_tx_batch_grants.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p,
+                                                    C.c_uint32, C.c_void_p, C.c_void_p]
+        _check(L.srslte_hip_ul_tx_batch_grants(self.h, din.ptr, stride, *[b.ptr if b else None for b in bufs], tti0, nof_sf, arr, n, self.d_iq.ptr, None),
+               "ul_tx_batch_grants")
+        sync()
+        return self.d_iq.to_host(np.complex64).reshape(self.max_batch, self.sf_len)[:nof_sf]
 
     def encode(self, tb, tti0=0, ack=None, ri=None, cqi=None, rv=None):
         """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits,

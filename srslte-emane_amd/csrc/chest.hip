@@ -995,13 +995,10 @@ int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmr
   return SRSLTE_SUCCESS;
 }
 
-// Per-PUSCH grants: n_items PUSCHs of one (L_prb, n_dmrs) - d_items[i] names the subframe of the batch, the PRB offset of each slot and the row
-// of d_res of PUSCH i - in one launch. The table of (L_prb, n_dmrs) is made on first use and kept.
-int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_dmrs, const ChestUlItem* d_items, int n_items,
-                            const void* d_grid, void* d_ce, void* d_res, hipStream_t st)
+// The DMRS table of (L_prb, n_dmrs), [10][2][12 * L_prb], from the per-object cache of the grants modes (made on first use, kept)
+int chest_ul_dmrs_table_cached(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r)
 {
-  if (!q || !d_grid || !d_items || n_items < 0 || L_prb == 0 || L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (n_items == 0) return SRSLTE_SUCCESS;
+  if (!q || !d_r || L_prb == 0 || L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
   auto it = q->tables->find({L_prb, n_dmrs});
   if (it == q->tables->end()) {
     std::vector<cf32> r((size_t)10 * 2 * 12 * L_prb);
@@ -1013,10 +1010,23 @@ int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_
     HIP_TRY(hipMemcpy(d, r.data(), sizeof(cf32) * r.size(), hipMemcpyHostToDevice));
     it = q->tables->emplace(std::make_pair(L_prb, n_dmrs), d).first;
   }
+  *d_r = it->second;
+  return SRSLTE_SUCCESS;
+}
+
+// Per-PUSCH grants: n_items PUSCHs of one (L_prb, n_dmrs) - d_items[i] names the subframe of the batch, the PRB offset of each slot and the row
+// of d_res of PUSCH i - in one launch. The table of (L_prb, n_dmrs) is made on first use and kept.
+int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_dmrs, const ChestUlItem* d_items, int n_items,
+                            const void* d_grid, void* d_ce, void* d_res, hipStream_t st)
+{
+  if (!q || !d_grid || !d_items || n_items < 0 || L_prb == 0 || L_prb > q->nof_prb || n_dmrs >= 8) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (n_items == 0) return SRSLTE_SUCCESS;
+  const void* d_tab = nullptr;
+  if (int rc = chest_ul_dmrs_table_cached(q, L_prb, n_dmrs, &d_tab)) return rc;
   ChestUlGeom g;
   g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = 0; g.n_prb1 = 0; g.tti0 = (int)tti0; g.w = 0.3333f;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(n_items), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, st, (const cf32*)d_grid, (cf32*)d_ce,
-                     (ChestUlResDev*)d_res, (const cf32*)it->second, g, d_items);
+                     (ChestUlResDev*)d_res, (const cf32*)d_tab, g, d_items);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }

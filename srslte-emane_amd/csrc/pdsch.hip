@@ -2806,15 +2806,17 @@ __global__ __launch_bounds__(256) void pusch_tx_seg_kernel(const uint8_t* __rest
 // grid = (ceil(M_sc/256), 12, nof_sf): modulation symbol (n, k) of the interleaved, scrambled stream: its Qm bits are
 // g[(k*12 + n)*Qm + b] (36.212 5.2.2.8 without UCI), all from one code block; bit e of a block = coded bit rm[e mod (3K+12)]
 // (rm: circular-buffer order with the NULLs removed; source 0 = systematic byte stream, 1 = its tail nibble, 2 = parity stream)
-__global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
-                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
-                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ d, PuschTxGeom g)
+// One PUSCH: cs its scrambling bits, cb0 its first code-block slot, ack / ri / qc its UCI inputs (or null), d its [nsymb][M_sc] symbols, lvl the
+// levels of its modulation (the geometry's own lvl member is not read here)
+__device__ __forceinline__ void pusch_tx_mod_body(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity, const uint8_t* __restrict__ sys_tail,
+                                                  const uint32_t* __restrict__ rm, const uint32_t* __restrict__ cs, cf32* __restrict__ d, const PuschTxGeom& g,
+                                                  int k, int n, int cb0, const uint8_t* __restrict__ ack, const uint8_t* __restrict__ rib,
+                                                  const uint8_t* __restrict__ qc, const float* __restrict__ lvl)
 {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y, sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
   if (k >= g.M_sc) return;
-  const int ri = g.ri_bits ? ri_symbol_index(g.ri, n, k, g.M_sc, g.nsymb) : -1; // RI symbol: outside the UL-SCH stream (sch.c:580-598)
+  const int ri = rib ? ri_symbol_index(g.ri, n, k, g.M_sc, g.nsymb) : -1; // RI symbol: outside the UL-SCH stream (sch.c:580-598)
   // symbol index in g order; blocks 0..C_lo-1 carry syms_lo symbols, the rest syms_lo + 1 (sch.c:238-243)
-  const int s0 = ri >= 0 ? 0 : k * g.nsymb + n - (g.ri_bits ? ri_before(g.ri, n, k, g.M_sc, g.nsymb) : 0);
+  const int s0 = ri >= 0 ? 0 : k * g.nsymb + n - (rib ? ri_before(g.ri, n, k, g.M_sc, g.nsymb) : 0);
   // the first Q'_cqi symbols of the stream carry the CQI report, the UL-SCH follows (sch.c:1133-1160)
   const bool is_cqi = ri < 0 && s0 < g.Qp_cqi;
   const int  s      = is_cqi || ri >= 0 ? 0 : s0 - g.Qp_cqi;
@@ -2827,32 +2829,42 @@ __global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __rest
     r           = g.C_lo + u / (g.syms_lo + 1);
     e0          = (u % (g.syms_lo + 1)) * g.Qm;
   }
-  const size_t    cbi = (size_t)sf * g.C + r;
+  const size_t    cbi = (size_t)cb0 + r;
   const uint8_t * xb = cb + cbi * g.cb_stride, *pb = parity + cbi * g.par_stride;
-  const uint32_t* cs  = scr + (size_t)sf_idx * g.scr_words;
   const int       q0  = (n * g.M_sc + k) * g.Qm;
-  const int       ai  = g.ack_bits ? ack_symbol_index(g.ack, n, k, g.M_sc, g.nsymb) : -1;
+  const int       ai  = ack ? ack_symbol_index(g.ack, n, k, g.M_sc, g.nsymb) : -1;
   int             re = 0, im = 0, prev = 0;
   for (int b = 0; b < g.Qm; b++) {
     const uint32_t src = rm[(e0 + b) % g.rm_len], pos = src & 0x3fffffffu;
     const uint8_t  byte = (src >> 30) == 0 ? xb[pos >> 3] : ((src >> 30) == 1 ? sys_tail[cbi] : pb[pos >> 3]);
     int            bit  = (byte >> (7 - (pos & 7))) & 1;
     const int      cbit = (cs[(q0 + b) >> 5] >> ((q0 + b) & 31)) & 1;
-    if (is_cqi) bit = g.q_cqi[(size_t)sf * g.cqi_stride + s0 * g.Qm + b];
+    if (is_cqi) bit = qc[s0 * g.Qm + b];
     bit ^= cbit;
     if (ai >= 0) { // HARQ-ACK symbol: value bits are scrambled, placeholders are 1, a repetition bit copies the transmitted bit before it
-      const int t = ack_bit_type(g.ack_bits + 2 * sf, g.ack.O, g.Qm, ai * g.Qm + b); // (sch.c:1203-1215, pusch.c:386-400)
+      const int t = ack_bit_type(ack, g.ack.O, g.Qm, ai * g.Qm + b); // (sch.c:1203-1215, pusch.c:386-400)
       bit         = t == 3 ? 1 : (t == 2 ? prev : (t ^ cbit));
     }
     if (ri >= 0) { // rank indication: the same encoder (sch.c:1110-1129)
-      const int t = ack_bit_type(g.ri_bits + 2 * sf, g.ri.O, g.Qm, ri * g.Qm + b);
+      const int t = ack_bit_type(rib, g.ri.O, g.Qm, ri * g.Qm + b);
       bit         = t == 3 ? 1 : (t == 2 ? prev : (t ^ cbit));
     }
     prev = bit;
     if (b & 1) im = (im << 1) | bit;
     else re = (re << 1) | bit;
   }
-  d[((size_t)sf * g.nsymb + n) * g.M_sc + k] = make_float2(g.lvl[re], g.lvl[im]);
+  d[(size_t)n * g.M_sc + k] = make_float2(lvl[re], lvl[im]);
+}
+
+
+__global__ __launch_bounds__(256) void pusch_tx_mod_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                           const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ rm,
+                                                           const uint32_t* __restrict__ scr, cf32* __restrict__ d, PuschTxGeom g)
+{
+  const int sf = blockIdx.z, sf_idx = (g.tti0 + sf) % 10;
+  pusch_tx_mod_body(cb, parity, sys_tail, rm, scr + (size_t)sf_idx * g.scr_words, d + (size_t)sf * g.nsymb * g.M_sc, g, blockIdx.x * blockDim.x + threadIdx.x,
+                    blockIdx.y, sf * g.C, g.ack_bits ? g.ack_bits + 2 * sf : nullptr, g.ri_bits ? g.ri_bits + 2 * sf : nullptr,
+                    g.q_cqi ? g.q_cqi + (size_t)sf * g.cqi_stride : nullptr, g.lvl);
 }
 
 // grid = (ceil(cell_nre/256), 14, nof_sf): resource grid of the subframe: z on the granted PRBs of the 12 data symbols, DMRS on
@@ -2888,7 +2900,9 @@ struct srslte_hip_ul_tx {
   uint8_t *              d_cb, *d_parity, *d_sys_tail, *d_qcqi;
   uint16_t*              d_cqi_rm;
   cf32 *                 d_d, *d_z, *d_grid;
+  struct UlTxGrantsState* gs; // srslte_hip_ul_tx_batch_grants: created on first use
 };
+static void ul_tx_grants_free(struct UlTxGrantsState* g);
 
 extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
 {
@@ -2900,6 +2914,7 @@ extern "C" void srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q)
   for (void* b : bufs) {
     if (b) (void)hipFree(b);
   }
+  ul_tx_grants_free(q->gs);
   delete q;
 }
 
@@ -3619,4 +3634,310 @@ extern "C" int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_
     LAUNCH_CHECK();
   }
   return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf * npt, stream);
+}
+
+// ====================================================================================================================
+// Per-PUSCH grants on the transmit side (srslte_hip_ul_tx_batch_grants): every PUSCH of a call has its own allocation, DMRS cyclic shift, RNTI,
+// modulation, transport block, redundancy version and UCI - what srslte_ue_ul_encode sends TTI after TTI as the grants come in (ue_ul.c:300-340),
+// and, with several PUSCHs on disjoint PRBs of one subframe, the composite signal of several UEs as an eNB receives it.
+// ====================================================================================================================
+namespace {
+
+struct PuschTxDesc {
+  int             M_sc, n_prb, n_prb1, zoff, syms_lo, C_lo, Qp_cqi, cqi_O, cqi_wlen, sf_idx;
+  AckGeom         ack, ri;
+  const uint16_t* cqi_w; // srslte_rm_conv_tx order of the report's coded bits (reports above 11 bits), read circularly
+  const cf32*     dmrs;  // table of (L_prb, n_dmrs): [10][2][M_sc]
+};
+
+// grid = nof_pusch: the coded CQI report of each PUSCH that carries one (pusch_cqi_encode_kernel with the sizes of the row's descriptor)
+__global__ __launch_bounds__(256) void pusch_cqi_encode_grants_kernel(const uint8_t* __restrict__ cqi, uint8_t* __restrict__ qb, int q_stride,
+                                                                      const PuschTxDesc* __restrict__ desc, const TxDesc* __restrict__ td)
+{
+  __shared__ uint8_t msg[72], enc[3 * 72];
+  const int          p = blockIdx.x, tid = threadIdx.x, O = desc[p].cqi_O, Q = desc[p].Qp_cqi * td[p].Qm;
+  if (O == 0) return;
+  const uint8_t* in  = cqi + (size_t)p * 64;
+  uint8_t*       out = qb + (size_t)p * q_stride;
+  if (O <= 11) {
+    if (tid < 32) {
+      int b = 0;
+      for (int n = 0; n < O; n++) b ^= in[n] & (CQI_M32[tid] >> n) & 1;
+      enc[tid] = (uint8_t)b;
+    }
+    __syncthreads();
+    for (int i = tid; i < Q; i += 256) out[i] = enc[i & 31];
+    return;
+  }
+  const int F = O + 8;
+  if (tid < O) msg[tid] = in[tid] & 1;
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t c = cqi_crc8(msg, O);
+    for (int i = 0; i < 8; i++) msg[O + i] = (c >> (7 - i)) & 1;
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * F; e += 256) {
+    const int      i = e / 3, pp = e - 3 * i;
+    const uint32_t poly = pp == 0 ? 0x6Du : (pp == 1 ? 0x4Fu : 0x57u);
+    int            b = 0;
+    for (int j = 0; j < 7; j++) b ^= ((poly >> j) & 1u) & msg[(i - j + F) % F];
+    enc[e] = (uint8_t)b;
+  }
+  __syncthreads();
+  const uint16_t* w = desc[p].cqi_w;
+  const int       wlen = desc[p].cqi_wlen;
+  for (int i = tid; i < Q; i += 256) out[i] = enc[w[i % wlen]];
+}
+
+// grid = (ceil(max M_sc / 256), nsymb, nof_pusch)
+__global__ __launch_bounds__(256) void pusch_tx_mod_grants_kernel(const uint8_t* __restrict__ cb, const uint8_t* __restrict__ parity,
+                                                                  const uint8_t* __restrict__ sys_tail, const uint32_t* __restrict__ scr, int scr_words,
+                                                                  cf32* __restrict__ d, const PuschTxDesc* __restrict__ desc, const TxDesc* __restrict__ td,
+                                                                  TxLevels lv, int nsymb, int cb_stride, int par_stride, const uint8_t* __restrict__ ack,
+                                                                  const uint8_t* __restrict__ rib, const uint8_t* __restrict__ qcqi, int cqi_stride)
+{
+  const int          p = blockIdx.z;
+  const PuschTxDesc& pd = desc[p];
+  PuschTxGeom        g; // a local built from the descriptors (its lvl member stays untouched: the levels come through lv)
+  g.M_sc = pd.M_sc; g.Qm = td[p].Qm; g.C = td[p].C; g.rm_len = 3 * td[p].K + 12; g.syms_lo = pd.syms_lo; g.C_lo = pd.C_lo; g.nsymb = nsymb;
+  g.cb_stride = cb_stride; g.par_stride = par_stride; g.ack = pd.ack; g.ri = pd.ri; g.Qp_cqi = pd.Qp_cqi;
+  pusch_tx_mod_body(cb, parity, sys_tail, td[p].rm, scr + (size_t)p * scr_words, d + pd.zoff, g, blockIdx.x * blockDim.x + threadIdx.x, blockIdx.y, td[p].cb0,
+                    pd.ack.O ? ack + 2 * p : nullptr, pd.ri.O ? rib + 2 * p : nullptr, pd.cqi_O ? qcqi + (size_t)p * cqi_stride : nullptr, lv.v[td[p].mod]);
+}
+
+// grid = (ceil(max M_sc / 256), 14, nof_pusch): pusch_put + srslte_refsignal_dmrs_pusch_put of PUSCH p into the (zeroed) grid of its subframe
+__global__ __launch_bounds__(256) void pusch_tx_scatter_kernel(const cf32* __restrict__ z, cf32* __restrict__ grid, const PuschTxDesc* __restrict__ desc,
+                                                               const TxDesc* __restrict__ td, int cell_nre, int nsymb)
+{
+  const int          kk = blockIdx.x * blockDim.x + threadIdx.x, l = blockIdx.y, p = blockIdx.z;
+  const PuschTxDesc& pd = desc[p];
+  if (kk >= pd.M_sc) return;
+  cf32 v;
+  if (l == 3 || l == 10) {
+    v = pd.dmrs[((size_t)pd.sf_idx * 2 + (l == 10)) * pd.M_sc + kk];
+  } else {
+    const int n = l < 3 ? l : (l < 10 ? l - 1 : l - 2);
+    if (n >= nsymb) return; // the last symbol of a shortened subframe stays empty
+    v = z[(size_t)pd.zoff + (size_t)n * pd.M_sc + kk];
+  }
+  grid[((size_t)td[p].sf * 14 + l) * cell_nre + 12 * (l < 7 ? pd.n_prb : pd.n_prb1) + kk] = v;
+}
+
+} // namespace
+
+struct UlTxGrantsState {
+  uint32_t  V, Cmax, words, cb_stride, par_stride, max_sym, cqi_stride;
+  uint32_t *d_scr, *d_basis, *d_tbcrc;
+  uint8_t * d_cb, *d_parity, *d_sys_tail, *d_desc, *d_qcqi;
+  cf32 *    d_d, *d_z;
+  size_t    desc_bytes;
+  uint8_t*   h_pin[4];
+  hipEvent_t h_ev[4];
+  bool       h_used[4];
+  uint32_t   h_slot;
+  TxLevels   lv;
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t*> rm_tbl; // (K, rv)
+  std::map<uint32_t, std::pair<uint16_t*, uint32_t>> cqi_w;  // report size O > 11 -> (device table, length)
+};
+
+static void ul_tx_grants_free(UlTxGrantsState* g)
+{
+  if (!g) return;
+  void* gb[] = {g->d_scr, g->d_basis, g->d_tbcrc, g->d_cb, g->d_parity, g->d_sys_tail, g->d_desc, g->d_qcqi, g->d_d, g->d_z};
+  for (void* b : gb) {
+    if (b) (void)hipFree(b);
+  }
+  for (auto& kv : g->rm_tbl) (void)hipFree(kv.second);
+  for (auto& kv : g->cqi_w) (void)hipFree(kv.second.first);
+  for (int i = 0; i < 4; i++) {
+    if (g->h_pin[i]) {
+      (void)hipHostFree(g->h_pin[i]);
+      (void)hipEventDestroy(g->h_ev[i]);
+    }
+  }
+  delete g;
+}
+
+// grants[p]: as srslte_hip_ul_rx_batch_grants takes them (new_data is not used). Row p of d_tb is its transport block; d_ack / d_ri: [nof_grants][2],
+// d_cqi: [nof_grants][64] device bytes, rows p (each may be NULL when no grant of the call carries that kind of UCI). The object's cell, DMRS
+// configuration and shortened flag apply; cfg.tbs bounds every grant's tbs, cfg.max_grants the number of PUSCHs per call.
+extern "C" int srslte_hip_ul_tx_batch_grants(srslte_hip_ul_tx_t* q, const uint8_t* d_tb, uint32_t tb_stride, const uint8_t* d_ack, const uint8_t* d_ri,
+                                             const uint8_t* d_cqi, uint32_t tti0, uint32_t nof_sf, const srslte_hip_ul_grant_t* grants, uint32_t nof_grants,
+                                             void* d_iq, void* stream)
+{
+  if (!q || !d_tb || !d_iq || !grants || nof_sf > q->cfg.max_batch) return SRSLTE_ERROR_INVALID_INPUTS;
+  const uint32_t V = q->cfg.max_grants ? q->cfg.max_grants : q->cfg.max_batch, P = q->cfg.nof_prb, nsymb = (uint32_t)q->g.nsymb;
+  if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  hipStream_t st = (hipStream_t)stream;
+  if (!q->gs) {
+    auto* g = new UlTxGrantsState(); // value-initialised
+    q->gs         = g;
+    g->V          = V;
+    g->Cmax       = q->seg.C;
+    g->max_sym    = nsymb * 12 * P;
+    g->words      = (g->max_sym * 6 + 31) / 32 + 2;
+    g->cb_stride  = (6144 / 8 + 15) & ~15u;
+    g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
+    g->cqi_stride = (g->max_sym * 6 + 15) & ~15u; // a report may take the whole allocation (min(.., M_sc N_symb - Q'_ri), uci.c:264-281)
+    const size_t nblk = (size_t)V * g->Cmax;
+    g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc) + sizeof(PuschTxDesc)) * V;
+    for (int i = 0; i < 4; i++) {
+      HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
+      HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
+    }
+    if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
+    HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
+    HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
+    HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
+    HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+    HIP_TRY(hipMalloc((void**)&g->d_qcqi, (size_t)g->cqi_stride * V));
+    HIP_TRY(hipMalloc((void**)&g->d_d, sizeof(cf32) * (size_t)g->max_sym * V));
+    HIP_TRY(hipMalloc((void**)&g->d_z, sizeof(cf32) * (size_t)g->max_sym * V));
+    for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
+      for (uint32_t idx = 0; idx < (1u << mod); idx++) {
+        double v = 1.0;
+        for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
+        const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
+        g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
+      }
+    }
+  }
+  UlTxGrantsState* g  = q->gs;
+  const uint32_t   hs = g->h_slot++ & 3u;
+  if (g->h_used[hs]) HIP_TRY(hipEventSynchronize(g->h_ev[hs]));
+  auto* h_gr = reinterpret_cast<GrantDev*>(g->h_pin[hs]);
+  auto* h_td = reinterpret_cast<TxDesc*>(h_gr + V);
+  auto* h_pd = reinterpret_cast<PuschTxDesc*>(h_td + V);
+  auto* d_gr = reinterpret_cast<GrantDev*>(g->d_desc);
+  auto* d_td = reinterpret_cast<TxDesc*>(d_gr + V);
+  auto* d_pd = reinterpret_cast<PuschTxDesc*>(d_td + V);
+  std::vector<srslte_hip_cbsegm_t> segs(nof_grants);
+  std::vector<uint32_t>            by_k(nof_grants), by_l(nof_grants);
+  uint32_t                         max_M = 0;
+  bool                             any_cqi = false;
+  for (uint32_t p = 0; p < nof_grants; p++) {
+    const srslte_hip_ul_grant_t& gr = grants[p];
+    by_k[p] = by_l[p] = p;
+    if (gr.sf >= nof_sf || gr.L_prb == 0 || !srslte_hip_dft_precoding_valid_prb(gr.L_prb) || gr.n_prb + gr.L_prb > P || gr.n_prb_slot1 + gr.L_prb > P ||
+        gr.n_dmrs >= 8 || gr.mod < 1 || gr.mod > 3 || gr.rv > 3 || gr.tbs == 0 || gr.tbs > q->cfg.tbs || (gr.tbs % 8) || tb_stride < gr.tbs / 8 ||
+        srslte_hip_cbsegm(&segs[p], gr.tbs) || segs[p].F || segs[p].C2 || segs[p].C > g->Cmax || (gr.ack_len && !d_ack) || (gr.ri_len && !d_ri) ||
+        (gr.cqi_len && !d_cqi)) {
+      hip_log("[srslte_hip] ul_tx grants: entry %u: unsupported grant (subframe %u of %u, L_prb %u at %u / %u, mod %d, tbs %u, rv %u)\n", p, gr.sf, nof_sf, gr.L_prb,
+              gr.n_prb, gr.n_prb_slot1, gr.mod, gr.tbs, gr.rv);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    max_M = 12 * gr.L_prb > max_M ? 12 * gr.L_prb : max_M;
+    any_cqi = any_cqi || gr.cqi_len;
+  }
+  // code-block slots in block-length order (one encoder launch per length), symbol buffers in L_prb order (one transform-precoding launch per size)
+  std::stable_sort(by_k.begin(), by_k.end(), [&](uint32_t a, uint32_t b) { return segs[a].K1 < segs[b].K1; });
+  std::stable_sort(by_l.begin(), by_l.end(), [&](uint32_t a, uint32_t b) { return grants[a].L_prb < grants[b].L_prb; });
+  uint32_t cb0 = 0, zoff = 0;
+  for (uint32_t i = 0; i < nof_grants; i++) {
+    h_td[by_k[i]].cb0 = (int)cb0;
+    cb0 += segs[by_k[i]].C;
+    h_pd[by_l[i]].zoff = (int)zoff;
+    zoff += nsymb * 12 * grants[by_l[i]].L_prb;
+  }
+  for (uint32_t p = 0; p < nof_grants; p++) {
+    const srslte_hip_ul_grant_t& gr = grants[p];
+    const uint32_t               K = segs[p].K1, C = segs[p].C, nof_re = nsymb * 12 * gr.L_prb;
+    GrantDev&                    gd = h_gr[p];
+    memset(&gd, 0, sizeof(gd));
+    gd.sf_idx = (int)((tti0 + gr.sf) % 10); gd.rnti = gr.rnti;
+    const int Qp_ack = pusch_ack_qprime(gr.ack_len, gr.I_offset_ack, gr.L_prb, nsymb, C * K);
+    const int Qp_ri  = pusch_ack_qprime(gr.ri_len, gr.I_offset_ri, gr.L_prb, nsymb, C * K, true);
+    const int Qp_cqi = Qp_ri >= 0 && gr.cqi_len <= 64 ? pusch_cqi_qprime(gr.cqi_len, gr.I_offset_cqi, gr.L_prb, nsymb, C * K, (uint32_t)Qp_ri) : -1;
+    if (Qp_ack < 0 || Qp_ri < 0 || Qp_cqi < 0 || (uint32_t)(Qp_ri + Qp_cqi) + C >= nof_re) {
+      hip_log("[srslte_hip] ul_tx grants: entry %u: invalid UCI configuration\n", p);
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    }
+    auto it = g->rm_tbl.find({K, gr.rv});
+    if (it == g->rm_tbl.end()) {
+      std::vector<uint32_t> t;
+      lte_rm_rx_table(K, gr.rv, t);
+      for (auto& v : t) {
+        const uint32_t pos = v / 3, sidx = v % 3;
+        v = sidx == 0 ? (pos < K ? pos : (1u << 30) | (pos - K)) : (2u << 30) | (sidx == 1 ? pos : K + 4 + pos);
+      }
+      uint32_t* d = nullptr;
+      if (upload(&d, t)) return SRSLTE_ERROR;
+      it = g->rm_tbl.emplace(std::make_pair(K, gr.rv), d).first;
+    }
+    TxDesc& td = h_td[p];
+    td.row = (int)p; td.sf = (int)gr.sf; td.tbs = (int)gr.tbs; td.C = (int)C; td.K = (int)K; td.rlenB = (int)((C == 1 ? K : K - 24) / 8);
+    td.nre = (int)nof_re; td.mod = gr.mod; td.Qm = 2 * gr.mod; td.rm = it->second;
+    PuschTxDesc& pd = h_pd[p];
+    const uint32_t g_re = nof_re - (uint32_t)Qp_ri - (uint32_t)Qp_cqi; // UL-SCH symbols (sch.c:1157-1160)
+    pd.M_sc = 12 * (int)gr.L_prb; pd.n_prb = (int)gr.n_prb; pd.n_prb1 = (int)gr.n_prb_slot1; pd.syms_lo = (int)(g_re / C); pd.C_lo = (int)(C - g_re % C);
+    pd.Qp_cqi = Qp_cqi; pd.cqi_O = (int)gr.cqi_len; pd.cqi_w = nullptr; pd.cqi_wlen = 1; pd.sf_idx = gd.sf_idx;
+    pd.ack.O = (int)gr.ack_len; pd.ack.Qprime = Qp_ack; pd.ri.O = (int)gr.ri_len; pd.ri.Qprime = Qp_ri;
+    if (gr.cqi_len > 11) { // srslte_rm_conv_tx (rm_conv.c:44-89): the sub-block interleaved streams without their dummies, read circularly
+      auto cw = g->cqi_w.find(gr.cqi_len);
+      if (cw == g->cqi_w.end()) {
+        static const uint8_t perm[32] = {1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31, 0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30};
+        const int             F = (int)gr.cqi_len + 8, nrows = (F - 1) / 32 + 1, ndummy = nrows * 32 - F;
+        std::vector<uint16_t> w;
+        for (int s3 = 0; s3 < 3; s3++) {
+          for (int j = 0; j < 32; j++) {
+            for (int i = 0; i < nrows; i++) {
+              const int pos = i * 32 + perm[j];
+              if (pos >= ndummy) w.push_back((uint16_t)((pos - ndummy) * 3 + s3));
+            }
+          }
+        }
+        uint16_t* d = nullptr;
+        if (upload(&d, w)) return SRSLTE_ERROR;
+        cw = g->cqi_w.emplace(gr.cqi_len, std::make_pair(d, (uint32_t)w.size())).first;
+      }
+      pd.cqi_w = cw->second.first; pd.cqi_wlen = (int)cw->second.second;
+    }
+    const void* d_r = nullptr;
+    if (int r = chest_ul_dmrs_table_cached(q->dmrs, gr.L_prb, gr.n_dmrs, &d_r)) return r;
+    pd.dmrs = (const cf32*)d_r;
+  }
+  HIP_TRY(hipMemcpyAsync(g->d_desc, g->h_pin[hs], g->desc_bytes, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipEventRecord(g->h_ev[hs], st));
+  g->h_used[hs] = true;
+  HIP_TRY(hipMemsetAsync(q->d_grid, 0, sizeof(cf32) * (size_t)14 * 12 * P * nof_sf, st)); // ue_ul.c:320: the grid is cleared, then pusch_put
+  if (nof_grants) {
+    hipLaunchKernelGGL(scr_gen_kernel, dim3(ceil_div((int)g->words, 256), nof_grants), dim3(256), 0, st, (const GrantDev*)d_gr, (const uint32_t*)g->d_basis,
+                       g->d_scr, (int)g->words, (int)q->cfg.cell_id);
+    if (any_cqi) {
+      hipLaunchKernelGGL(pusch_cqi_encode_grants_kernel, dim3(nof_grants), dim3(256), 0, st, d_cqi, g->d_qcqi, (int)g->cqi_stride, (const PuschTxDesc*)d_pd,
+                         (const TxDesc*)d_td);
+    }
+    hipLaunchKernelGGL(tx_tbcrc_grants_kernel, dim3(nof_grants), dim3(256), 0, st, d_tb, (int)tb_stride, (const TxDesc*)d_td, g->d_tbcrc);
+    hipLaunchKernelGGL(tx_seg_grants_kernel, dim3(g->Cmax, nof_grants), dim3(256), 0, st, d_tb, (int)tb_stride, (const uint32_t*)g->d_tbcrc, (const TxDesc*)d_td,
+                       g->d_cb, (int)g->cb_stride);
+    LAUNCH_CHECK();
+    for (uint32_t i = 0; i < nof_grants;) { // the encoder: runs of equal block length
+      uint32_t j = i, n = 0;
+      while (j < nof_grants && segs[by_k[j]].K1 == segs[by_k[i]].K1) n += segs[by_k[j++]].C;
+      const size_t s0 = (size_t)h_td[by_k[i]].cb0;
+      if (int r = srslte_hip_tcod_encode_bytes_batch(g->d_cb + s0 * g->cb_stride, g->cb_stride, g->d_parity + s0 * g->par_stride, g->par_stride,
+                                                     g->d_sys_tail + s0, segs[by_k[i]].K1, n, stream))
+        return r;
+      i = j;
+    }
+    hipLaunchKernelGGL(pusch_tx_mod_grants_kernel, dim3(ceil_div((int)max_M, 256), nsymb, nof_grants), dim3(256), 0, st, (const uint8_t*)g->d_cb,
+                       (const uint8_t*)g->d_parity, (const uint8_t*)g->d_sys_tail, (const uint32_t*)g->d_scr, (int)g->words, g->d_d, (const PuschTxDesc*)d_pd,
+                       (const TxDesc*)d_td, g->lv, (int)nsymb, (int)g->cb_stride, (int)g->par_stride, d_ack, d_ri, (const uint8_t*)g->d_qcqi, (int)g->cqi_stride);
+    LAUNCH_CHECK();
+    for (uint32_t i = 0; i < nof_grants;) { // transform precoding: runs of equal L_prb (srslte_dft_precoding_init_tx: forward, 1/sqrt(N))
+      uint32_t j = i + 1;
+      while (j < nof_grants && grants[by_l[j]].L_prb == grants[by_l[i]].L_prb) j++;
+      const size_t off = (size_t)h_pd[by_l[i]].zoff;
+      if (int r = srslte_hip_dft_precoding_batch(g->d_d + off, g->d_z + off, grants[by_l[i]].L_prb, nsymb * (j - i), 1, stream)) return r;
+      i = j;
+    }
+    hipLaunchKernelGGL(pusch_tx_scatter_kernel, dim3(ceil_div((int)max_M, 256), 14, nof_grants), dim3(256), 0, st, (const cf32*)g->d_z, q->d_grid,
+                       (const PuschTxDesc*)d_pd, (const TxDesc*)d_td, 12 * (int)P, (int)nsymb);
+    LAUNCH_CHECK();
+  }
+  return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf, stream);
 }

@@ -33,6 +33,7 @@ void lte_rm_rx_table(uint32_t K, uint32_t rv, std::vector<uint32_t>& d_index); /
 struct ChestUlItem { int sf, n_prb, n_prb1, row; };
 int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_dmrs, const ChestUlItem* d_items, int n_items,
                             const void* d_grid, void* d_ce, void* d_res, hipStream_t st);
+int chest_ul_dmrs_table_cached(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r); // one table per (L_prb, n_dmrs), all kept
 // chest.hip: device DMRS table of a PUSCH grant, [10][2][12 * L_prb] cf32 (owned by q)
 int chest_ul_dmrs_table(srslte_hip_chest_ul_t* q, uint32_t L_prb, uint32_t n_dmrs, const void** d_r);
 // chest.hip: chest_common.c's stand-alone array helpers on device buffers (filter_len <= nof_ref, nof_ref >= 2 as the extrapolation reads in[0..1])

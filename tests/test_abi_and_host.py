@@ -140,6 +140,10 @@ def test_round2_additions_reject_bad_arguments_without_gpu():
     assert lib.srslte_hip_ul_rx_batch_harq(None, None, 0, 1, 0, 1, None, 0, None, None) == -2
     lib.srslte_hip_ul_tx_batch_rv.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, u32, vp, vp]
     assert lib.srslte_hip_ul_tx_batch_rv(None, None, 0, None, None, None, 0, 0, 1, None, None) == -2
+    lib.srslte_hip_ul_tx_batch_grants.argtypes = [vp, vp, u32, vp, vp, vp, u32, u32, vp, u32, vp, vp]
+    assert lib.srslte_hip_ul_tx_batch_grants(None, None, 0, None, None, None, 0, 1, None, 1, None, None) == -2
+    lib.srslte_hip_dl_rx_grid_batch_grants2.argtypes = [vp, vp, u32, u32, vp, vp, u32, vp, vp]
+    assert lib.srslte_hip_dl_rx_grid_batch_grants2(None, None, 0, 1, None, None, 0, None, None) == -2
     lib.srslte_hip_dl_tx_batch_grants.argtypes = [vp, vp, u32, u32, u32, vp, u32, vp, vp]
     assert lib.srslte_hip_dl_tx_batch_grants(None, None, 0, 0, 1, None, 1, None, None) == -2
     lib.srslte_hip_ul_rx_batch_grants.argtypes = [vp, vp, u32, u32, vp, u32, vp, u32, vp, vp]

@@ -199,3 +199,68 @@ def test_ul_grants_argument_errors(hp):
         with pytest.raises(RuntimeError):
             rx.decode_grants(iq, 0, bad)
     rx.free()
+
+
+@pytest.mark.parametrize("prb,sets,tti0,short", [(25, UE_SETS_25, 7, False), (100, UE_SETS_100, 18, False), (25, UE_SETS_25, 2, True)])
+def test_ul_tx_grants_vs_oracle(hp, prb, sets, tti0, short):
+    """srslte_hip_ul_tx_batch_grants: the composite signal of all PUSCHs of every subframe from ONE call (own allocation, hopping, DMRS shift, RNTI,
+    modulation, transport block, rv, HARQ-ACK / RI / CQI report each) = the sum of the oracle's per-UE signals, in the frequency-domain grid
+    (debug buffer) and in the time samples."""
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(4700 + prb)
+    nsf = len(sets)
+    dm = dict(cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=False)
+    grants, datas, acks, ris, cqis = [], [], [], [], []
+    exp_iq = np.zeros((nsf, 15 * {25: 384, 100: 1536}[prb]), np.complex128)
+    exp_grid = np.zeros((nsf, 14 * 12 * prb), np.complex128)
+    for b, ue_list in enumerate(sets):
+        for u, (L, n0, n1, mod, tbs, n_dmrs, _) in enumerate(ue_list):
+            rnti, rv = 0x100 + 16 * b + u, (u + b) % 4
+            cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=n_dmrs, rnti=rnti, n_prb_slot1=n1 if n1 != n0 else None, shortened=short, **dm)
+            O_ack, O_ri = ((u + b) % 2) * (1 + (u % 2)), 1 if (u + b) % 3 == 0 else 0
+            if L == 1:
+                O_ack = O_ri = 0
+            O_cqi = (8 if b % 2 == 0 else 20) if (u == 0 and L >= 6) else 0
+            ack, ri = tuple(int(v) for v in rng.integers(0, 2, O_ack)), tuple(int(v) for v in rng.integers(0, 2, O_ri))
+            cqi = tuple(int(v) for v in rng.integers(0, 2, O_cqi))
+            k = {}
+            y, data = make_ul_subframe(cfg, tti0 + b, rng, ack=ack, I_offset_ack=9, ri=ri, I_offset_ri=8, cqi=cqi, I_offset_cqi=7, rv=rv, keep=k)
+            exp_iq[b] += y
+            exp_grid[b] += k["grid"]
+            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=n_dmrs, n_prb_slot1=n1, rv=rv, ack_len=O_ack, I_offset_ack=9, ri_len=O_ri, I_offset_ri=8,
+                                          cqi_len=O_cqi, I_offset_cqi=7))
+            datas.append(data); acks.append(ack); ris.append(ri); cqis.append(cqi)
+    tx = hp.UlTx(11, prb, 0x1234, 1, max(g.tbs for g in grants), 6, 0, 0, nsf, 2, 5, True, False, shortened=short, max_grants=len(grants))
+    iq = tx.encode_grants(datas, tti0, nsf, grants, ack=acks, ri=ris, cqi=cqis)
+    grid = tx.debug(4, np.complex64, nsf * 14 * 12 * prb).reshape(nsf, -1)
+    for b in range(nsf):
+        close_c(grid[b], exp_grid[b].astype(np.complex64), "grid sf %d" % b)
+        close_c(iq[b], exp_iq[b].astype(np.complex64), "iq sf %d" % b)
+    tx.free()
+
+
+def test_ul_grants_tx_rx_round_trip(hp):
+    """One transmit call makes 64 subframes with three UEs each (changing sizes, modulations, rv 0, HARQ-ACK on one of them); one receive call
+    decodes all 192 PUSCHs: every transport block and every ACK comes back."""
+    prb, nsf = 50, 64
+    rng = np.random.default_rng(4900)
+    shapes = [(10, 0, 1, 1544), (24, 10, 2, 9144), (15, 35, 3, 7992)]  # L, n_prb, mod, tbs
+    grants, datas, acks = [], [], []
+    for b in range(nsf):
+        for u in range(3):
+            L, n0, mod, tbs = shapes[(u + b) % 3]
+            grants.append(hp.UlGrant.make(b, 0x400 + u, L, n0, mod, tbs, n_dmrs=(u + b) % 8, ack_len=2 if u == 1 else 0, I_offset_ack=8))
+            datas.append(rng.integers(0, 256, tbs // 8, dtype=np.uint8))
+            acks.append(tuple(int(v) for v in rng.integers(0, 2, 2)) if u == 1 else ())
+    tx = hp.UlTx(4, prb, 0x1234, 1, 9144, 6, 0, 0, nsf, max_grants=len(grants))
+    iq = tx.encode_grants(datas, 2, nsf, grants, ack=acks)
+    tx.free()
+    rx = hp.UlRx(4, prb, 0x1234, 1, 9144, 6, 0, 0, 6, nsf, max_grants=len(grants))
+    tb, ok = rx.decode_grants(iq, 2, grants)
+    a, _ = rx.grants_uci()
+    assert ok.all()
+    for p, g in enumerate(grants):
+        assert np.array_equal(tb[p][:g.tbs // 8], datas[p]), p
+        if g.ack_len:
+            assert tuple(a[p]) == acks[p], p
+    rx.free()
