@@ -1772,7 +1772,11 @@ static int grants_run(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, ui
     return SRSLTE_ERROR;
   }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
-  if (!q->gs && grants_init(q)) return SRSLTE_ERROR;
+  if (!q->gs && grants_init(q)) { // a failed start leaves no half-made state behind
+    grants_free(q->gs);
+    q->gs = nullptr;
+    return SRSLTE_ERROR;
+  }
   GrantsState*   g  = q->gs;
   hipStream_t    st = (hipStream_t)stream;
   const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id, B = q->cfg.max_batch, V = g->V;
@@ -2571,6 +2575,24 @@ extern "C" int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_
   return SRSLTE_SUCCESS;
 }
 
+static int ul_rx_grants_init(srslte_hip_ul_rx_t* q, uint32_t V, uint32_t max_re)
+{
+  const uint32_t P = q->cfg.nof_prb;
+  q->gs = new GrantsState();
+  if (grants_alloc(q->gs, 12 * 12 * P, V, q->seg.C, 0, false, (sizeof(PuschDesc) + sizeof(ChestUlItem)) * V)) return SRSLTE_ERROR;
+  HIP_TRY(hipMalloc((void**)&q->g_z, sizeof(cf32) * (size_t)max_re * V));
+  HIP_TRY(hipMalloc((void**)&q->g_d, sizeof(cf32) * (size_t)max_re * V));
+  HIP_TRY(hipMalloc((void**)&q->g_res, sizeof(float) * 5 * V));
+  HIP_TRY(hipMalloc((void**)&q->g_uci_sum, sizeof(int) * 8 * V));
+  HIP_TRY(hipMalloc((void**)&q->g_uci, (size_t)4 * V));
+  HIP_TRY(hipMalloc((void**)&q->g_cqi, (size_t)65 * V));
+  HIP_TRY(hipMemset(q->g_cqi, 0, (size_t)65 * V));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemset(q->g_uci, 0, (size_t)4 * V));
+  HIP_TRY(hipDeviceSynchronize());
+  return SRSLTE_SUCCESS;
+}
+
 // Per-PUSCH grants: what an eNB receives in a run of TTIs - any number of PUSCHs per subframe, each with its own allocation (L_prb, PRB offset per
 // slot), DMRS cyclic shift, RNTI, modulation, transport block and redundancy version (srslte_enb_ul_get_pusch called once per scheduled UE,
 // enb_ul.c:200-235, after one srslte_enb_ul_fft per TTI). The OFDM demodulation runs once per subframe; estimator, equaliser and demapper take
@@ -2586,17 +2608,10 @@ extern "C" int srslte_hip_ul_rx_batch_grants(srslte_hip_ul_rx_t* q, const void* 
   if (nof_sf == 0 || nof_grants == 0) return SRSLTE_SUCCESS;
   hipStream_t    st    = (hipStream_t)stream;
   const uint32_t nsymb = (uint32_t)q->pg.nsymb, max_re = nsymb * 12 * P;
-  if (!q->gs) {
-    q->gs = new GrantsState();
-    if (grants_alloc(q->gs, 12 * 12 * P, V, q->seg.C, 0, false, (sizeof(PuschDesc) + sizeof(ChestUlItem)) * V)) return SRSLTE_ERROR;
-    HIP_TRY(hipMalloc((void**)&q->g_z, sizeof(cf32) * (size_t)max_re * V));
-    HIP_TRY(hipMalloc((void**)&q->g_d, sizeof(cf32) * (size_t)max_re * V));
-    HIP_TRY(hipMalloc((void**)&q->g_res, sizeof(float) * 5 * V));
-    HIP_TRY(hipMalloc((void**)&q->g_uci_sum, sizeof(int) * 8 * V));
-    HIP_TRY(hipMalloc((void**)&q->g_uci, (size_t)4 * V));
-    HIP_TRY(hipMalloc((void**)&q->g_cqi, (size_t)65 * V));
-    HIP_TRY(hipMemset(q->g_cqi, 0, (size_t)65 * V));
-    HIP_TRY(hipDeviceSynchronize());
+  if (!q->gs && ul_rx_grants_init(q, V, max_re)) { // a failed start leaves no half-made state behind
+    grants_free(q->gs);
+    q->gs = nullptr;
+    return SRSLTE_ERROR;
   }
   GrantsState*   g    = q->gs;
   const size_t   nblk = (size_t)V * g->Cmax;
@@ -3485,6 +3500,52 @@ extern "C" int srslte_hip_dl_tx_batch(srslte_hip_dl_tx_t* q, const uint8_t* d_tb
   return srslte_hip_ofdm_tx_sf_batch(q->ofdm, q->d_grid, d_iq, (int)nof_sf * g.nof_ports, stream);
 }
 
+static int dl_tx_grants_init(srslte_hip_dl_tx_t* q, uint32_t V)
+{
+  const uint32_t P = q->cfg.nof_prb, cell_id = q->cfg.cell_id;
+  const int      npt = q->g.nof_ports;
+  auto*          g = new TxGrantsState(); // value-initialised: every pointer and flag starts null / false
+  q->gs         = g;
+  g->V          = V;
+  g->Cmax       = q->seg.C;
+  g->max_re     = 14 * 12 * P;
+  g->words      = (g->max_re * 8 + 31) / 32 + 2;
+  g->cb_stride  = (6144 / 8 + 15) & ~15u;
+  g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
+  const size_t nblk = (size_t)V * g->Cmax;
+  g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc)) * V;
+  for (int i = 0; i < 4; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
+  }
+  if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
+  HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * V));
+  HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
+  HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
+  HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+  HIP_TRY(hipMalloc((void**)&g->d_y, sizeof(cf32) * (size_t)g->max_re * V * npt));
+  for (int port = 0; port < npt; port++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272), as srslte_hip_dl_tx_create maps it
+    std::vector<int32_t> src((size_t)14 * 12 * P, -1);
+    for (int l = 0; l < (port < 2 ? 4 : 2); l++) {
+      const uint32_t sym = port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7), fidx = ((((l + port) & 1) ? 3 : 0) + cell_id % 6) % 6;
+      for (uint32_t i = 0; i < 2 * P; i++) src[sym * 12 * P + fidx + 6 * i] = -(int32_t)(l * 2 * P + i) - 2;
+    }
+    if (upload(&g->d_crs_src[port], src)) return SRSLTE_ERROR;
+  }
+  for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
+    for (uint32_t idx = 0; idx < (1u << mod); idx++) {
+      double v = 1.0;
+      for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
+      const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
+      g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
+    }
+  }
+  return SRSLTE_SUCCESS;
+}
+
 // Per-PDSCH grants on the transmit side: what an eNB sends in a run of TTIs - srslte_enb_dl_put_base once per TTI, then srslte_enb_dl_put_pdsch
 // once per scheduled UE (enb_dl.c:330-398 -> srslte_pdsch_encode, pdsch.c:1059-1185), each with its own srslte_pdsch_grant_t, then
 // srslte_enb_dl_gen_signal. grants[p]: the subframe of the batch, and a srslte_hip_dl_grant_t as the receive side takes it (PRB masks of both
@@ -3502,46 +3563,10 @@ extern "C" int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_
   if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
-  if (!q->gs) {
-    auto* g = new TxGrantsState(); // value-initialised: every pointer and flag starts null / false
-    q->gs         = g;
-    g->V          = V;
-    g->Cmax       = q->seg.C;
-    g->max_re     = 14 * 12 * P;
-    g->words      = (g->max_re * 8 + 31) / 32 + 2;
-    g->cb_stride  = (6144 / 8 + 15) & ~15u;
-    g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
-    const size_t nblk = (size_t)V * g->Cmax;
-    g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc)) * V;
-    for (int i = 0; i < 4; i++) {
-      HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
-      HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
-    }
-    if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
-    HIP_TRY(hipMalloc((void**)&g->d_relist, sizeof(uint32_t) * (size_t)g->max_re * V));
-    HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
-    HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
-    HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
-    HIP_TRY(hipMalloc((void**)&g->d_y, sizeof(cf32) * (size_t)g->max_re * V * npt));
-    for (int port = 0; port < npt; port++) { // srslte_refsignal_cs_put_sf (refsignal_dl.c:253-272), as srslte_hip_dl_tx_create maps it
-      std::vector<int32_t> src((size_t)14 * 12 * P, -1);
-      for (int l = 0; l < (port < 2 ? 4 : 2); l++) {
-        const uint32_t sym = port >= 2 ? 1 + 7 * l : ((l & 1) ? (l / 2 + 1) * 7 - 3 : (l / 2) * 7), fidx = ((((l + port) & 1) ? 3 : 0) + cell_id % 6) % 6;
-        for (uint32_t i = 0; i < 2 * P; i++) src[sym * 12 * P + fidx + 6 * i] = -(int32_t)(l * 2 * P + i) - 2;
-      }
-      if (upload(&g->d_crs_src[port], src)) return SRSLTE_ERROR;
-    }
-    for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
-      for (uint32_t idx = 0; idx < (1u << mod); idx++) {
-        double v = 1.0;
-        for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
-        const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
-        g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
-      }
-    }
+  if (!q->gs && dl_tx_grants_init(q, V)) { // a failed start leaves no half-made state behind
+    tx_grants_free(q->gs);
+    q->gs = nullptr;
+    return SRSLTE_ERROR;
   }
   TxGrantsState* g  = q->gs;
   const uint32_t hs = g->h_slot++ & 3u;
@@ -3759,6 +3784,45 @@ static void ul_tx_grants_free(UlTxGrantsState* g)
   delete g;
 }
 
+static int ul_tx_grants_init(srslte_hip_ul_tx_t* q, uint32_t V)
+{
+  const uint32_t P = q->cfg.nof_prb, nsymb = (uint32_t)q->g.nsymb;
+  auto*          g = new UlTxGrantsState(); // value-initialised
+  q->gs         = g;
+  g->V          = V;
+  g->Cmax       = q->seg.C;
+  g->max_sym    = nsymb * 12 * P;
+  g->words      = (g->max_sym * 6 + 31) / 32 + 2;
+  g->cb_stride  = (6144 / 8 + 15) & ~15u;
+  g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
+  g->cqi_stride = (g->max_sym * 6 + 15) & ~15u; // a report may take the whole allocation (min(.., M_sc N_symb - Q'_ri), uci.c:264-281)
+  const size_t nblk = (size_t)V * g->Cmax;
+  g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc) + sizeof(PuschTxDesc)) * V;
+  for (int i = 0; i < 4; i++) {
+    HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
+    HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
+  }
+  if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
+  HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
+  HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
+  HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
+  HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
+  HIP_TRY(hipMalloc((void**)&g->d_qcqi, (size_t)g->cqi_stride * V));
+  HIP_TRY(hipMalloc((void**)&g->d_d, sizeof(cf32) * (size_t)g->max_sym * V));
+  HIP_TRY(hipMalloc((void**)&g->d_z, sizeof(cf32) * (size_t)g->max_sym * V));
+  for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
+    for (uint32_t idx = 0; idx < (1u << mod); idx++) {
+      double v = 1.0;
+      for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
+      const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
+      g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
+    }
+  }
+  return SRSLTE_SUCCESS;
+}
+
 // grants[p]: as srslte_hip_ul_rx_batch_grants takes them (new_data is not used). Row p of d_tb is its transport block; d_ack / d_ri: [nof_grants][2],
 // d_cqi: [nof_grants][64] device bytes, rows p (each may be NULL when no grant of the call carries that kind of UCI). The object's cell, DMRS
 // configuration and shortened flag apply; cfg.tbs bounds every grant's tbs, cfg.max_grants the number of PUSCHs per call.
@@ -3771,40 +3835,10 @@ extern "C" int srslte_hip_ul_tx_batch_grants(srslte_hip_ul_tx_t* q, const uint8_
   if (nof_grants > V) return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   hipStream_t st = (hipStream_t)stream;
-  if (!q->gs) {
-    auto* g = new UlTxGrantsState(); // value-initialised
-    q->gs         = g;
-    g->V          = V;
-    g->Cmax       = q->seg.C;
-    g->max_sym    = nsymb * 12 * P;
-    g->words      = (g->max_sym * 6 + 31) / 32 + 2;
-    g->cb_stride  = (6144 / 8 + 15) & ~15u;
-    g->par_stride = (6144 / 4 + 1 + 15) & ~15u;
-    g->cqi_stride = (g->max_sym * 6 + 15) & ~15u; // a report may take the whole allocation (min(.., M_sc N_symb - Q'_ri), uci.c:264-281)
-    const size_t nblk = (size_t)V * g->Cmax;
-    g->desc_bytes     = (sizeof(GrantDev) + sizeof(TxDesc) + sizeof(PuschTxDesc)) * V;
-    for (int i = 0; i < 4; i++) {
-      HIP_TRY(hipEventCreateWithFlags(&g->h_ev[i], hipEventDisableTiming));
-      HIP_TRY(hipHostMalloc((void**)&g->h_pin[i], g->desc_bytes));
-    }
-    if (gold_basis_upload(g->words, &g->d_basis)) return SRSLTE_ERROR;
-    HIP_TRY(hipMalloc((void**)&g->d_scr, sizeof(uint32_t) * (size_t)g->words * V));
-    HIP_TRY(hipMalloc((void**)&g->d_tbcrc, sizeof(uint32_t) * V));
-    HIP_TRY(hipMalloc((void**)&g->d_cb, (size_t)g->cb_stride * nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_parity, (size_t)g->par_stride * nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_sys_tail, nblk));
-    HIP_TRY(hipMalloc((void**)&g->d_desc, g->desc_bytes));
-    HIP_TRY(hipMalloc((void**)&g->d_qcqi, (size_t)g->cqi_stride * V));
-    HIP_TRY(hipMalloc((void**)&g->d_d, sizeof(cf32) * (size_t)g->max_sym * V));
-    HIP_TRY(hipMalloc((void**)&g->d_z, sizeof(cf32) * (size_t)g->max_sym * V));
-    for (int mod = 1; mod <= 4; mod++) { // 36.211 7.1.2-7.1.5, one axis (lte_tables.c:57-262)
-      for (uint32_t idx = 0; idx < (1u << mod); idx++) {
-        double v = 1.0;
-        for (int i = mod - 1; i >= 1; i--) v = (double)(1 << (mod - i)) - (1 - 2 * (int)((idx >> (mod - 1 - i)) & 1)) * v;
-        const double norm = mod == 1 ? sqrt(2.0) : (mod == 2 ? sqrt(10.0) : (mod == 3 ? sqrt(42.0) : sqrt(170.0)));
-        g->lv.v[mod][idx] = (float)((1 - 2 * (int)((idx >> (mod - 1)) & 1)) * v / norm);
-      }
-    }
+  if (!q->gs && ul_tx_grants_init(q, V)) { // a failed start leaves no half-made state behind
+    ul_tx_grants_free(q->gs);
+    q->gs = nullptr;
+    return SRSLTE_ERROR;
   }
   UlTxGrantsState* g  = q->gs;
   const uint32_t   hs = g->h_slot++ & 3u;
