@@ -128,3 +128,76 @@ def test_dl_tx_grants_argument_errors(hp):
     iq = tx.encode_grants([], 0, 2, [])  # no PDSCH at all: CRS-only subframes
     assert np.abs(iq).max() > 0
     tx.free()
+
+
+def _valid_tbs(hp, limit):
+    """Transport block sizes the device pipelines take (multiples of 8, no filler bits, one code-block size), largest first, up to `limit` bits."""
+    out = []
+    for tbs in range(limit - limit % 8, 39, -8):
+        rc, s = hp.cbsegm(tbs)
+        if rc == 0 and s.F == 0 and s.C2 == 0:
+            out.append(tbs)
+            if len(out) >= 8:
+                break
+    return out
+
+
+@pytest.mark.parametrize("prb,npt,cell_id", [(15, 1, 3), (25, 2, 10), (50, 1, 77), (75, 2, 150), (100, 1, 501), (6, 1, 1)])
+def test_dl_grants_fuzz_round_trip(hp, prb, npt, cell_id):
+    """Random schedules on even and odd bandwidths: every subframe of a 20-TTI run (both sync subframes included, CFI 1..3) is split between 1..4 UEs
+    at random PRB boundaries, some with the two slots' PRBs swapped between UEs, random modulations, the largest transport block that keeps the
+    code rate under ~0.6 and the pipelines accept. One transmit call for the whole run; per UE slot one receive call: every block comes back."""
+    from lte_sim import DlConfig
+    rng = np.random.default_rng(5500 + prb + npt)
+    nsf, tti0, max_ue = 20, int(rng.integers(0, 10)), 4
+    grants, datas, per_ue = [], [], [[] for _ in range(max_ue)]
+    tbs_max = 0
+    for b in range(nsf):
+        cfi = int(rng.integers(1, 4))
+        nue = int(rng.integers(1, min(max_ue, prb // 2) + 1))
+        cuts = np.sort(rng.choice(np.arange(1, prb), nue - 1, replace=False)) if nue > 1 else np.array([], int)
+        bounds = [0] + [int(c) for c in cuts] + [prb]
+        spans = [(bounds[i], bounds[i + 1]) for i in range(nue)]
+        swap = nue >= 2 and rng.random() < 0.3  # the first two UEs trade PRBs in slot 1 (distributed allocation)
+        for u in range(max_ue):
+            if u >= nue:
+                per_ue[u].append((hp.DlGrant.make(prb, 1, 0, 0x500 + u, cfi=cfi, prb_mask=_mask(prb, [])), None))  # tbs 0: nothing for this UE
+                continue
+            s1 = spans[1 - u] if (swap and u < 2) else spans[u]
+            mask = _mask(prb, [spans[u]], [s1])
+            mod = int(rng.integers(1, 5))
+            cfg = DlConfig(prb, cell_id, mod, 1000, nof_ports=npt, prb_mask=mask, cfi=cfi)
+            nre = len(cfg.indices((tti0 + b) % 10))
+            cand = [t for t in _valid_tbs(hp, min(int(0.6 * nre * 2 * mod), 75376)) if nre >= 2 * npt * hp.cbsegm(t)[1].C] if nre >= 8 * npt and nre % npt == 0 else []
+            if not cand:
+                per_ue[u].append((hp.DlGrant.make(prb, 1, 0, 0x500 + u, cfi=cfi, prb_mask=_mask(prb, [])), None))
+                continue
+            tbs = cand[0]
+            tbs_max = max(tbs_max, tbs)
+            g = hp.DlGrant.make(prb, mod, tbs, 0x500 + u, cfi=cfi, prb_mask=mask)
+            d = rng.integers(0, 256, tbs // 8, dtype=np.uint8)
+            grants.append((b, g))
+            datas.append(d)
+            per_ue[u].append((g, d))
+    assert len(grants) >= nsf
+    tx = hp.DlTx(cell_id, prb, 1, 0x1234, 1, tbs_max, nsf, npt, max_grants=len(grants))
+    iq = tx.encode_grants(datas, tti0, nsf, grants)
+    tx.free()
+    rx_iq = iq[:, 0, :] if npt == 1 else (iq[:, 0, :] + 0.6j * iq[:, 1, :]).astype(np.complex64)
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    n_tb = 0
+    for u in range(max_ue):
+        if not any(d is not None for _, d in per_ue[u]):
+            continue
+        rx = hp.DlRx(cell_id, prb, 1, 0x500 + u, 1, tbs_max, 6, nsf, True, hc, nof_ports=npt, power_scale=npt > 1, p_a=0.0)
+        rc, tb, ok = rx.decode_grants(rx_iq, tti0, [g for g, _ in per_ue[u]])
+        assert rc == 0
+        for b, (g, d) in enumerate(per_ue[u]):
+            if d is None:
+                assert not ok[b]
+            else:
+                n_tb += 1
+                assert ok[b] and np.array_equal(tb[b][:g.tbs // 8], d), (u, b, g.mod, g.tbs)
+        rx.free()
+    assert n_tb == len(grants)

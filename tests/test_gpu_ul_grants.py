@@ -264,3 +264,63 @@ def test_ul_grants_tx_rx_round_trip(hp):
         if g.ack_len:
             assert tuple(a[p]) == acks[p], p
     rx.free()
+
+
+@pytest.mark.parametrize("prb,cell_id,short", [(6, 1, False), (15, 40, True), (25, 10, False), (50, 77, True), (75, 150, False), (100, 501, False)])
+def test_ul_grants_fuzz_round_trip(hp, prb, cell_id, short):
+    """Random uplink schedules: every subframe of a 24-TTI run holds 1..4 PUSCHs at random offsets with random valid sizes (2^a 3^b 5^c PRB),
+    some hopping between the slots, random cyclic shifts, modulations, the largest accepted transport block under a code rate of ~0.55,
+    HARQ-ACK / RI on some. One transmit call, one receive call: every transport block and every UCI bit comes back."""
+    rng = np.random.default_rng(5700 + prb)
+    nsf, tti0 = 24, int(rng.integers(0, 10))
+    nsymb = 11 if short else 12
+    valid = [L for L in range(1, prb + 1) if hp.lib().srslte_hip_dft_precoding_valid_prb(L)]
+
+    def valid_tbs(limit):
+        for tbs in range(limit - limit % 8, 39, -8):
+            rc, s = hp.cbsegm(tbs)
+            if rc == 0 and s.F == 0 and s.C2 == 0:
+                return tbs, s.C
+        return 0, 0
+    grants, datas, acks, ris = [], [], [], []
+    for b in range(nsf):
+        free, k = 0, 0
+        while free < prb and k < 4:
+            room = prb - free
+            cand = [L for L in valid if L <= room]
+            if not cand:
+                break
+            L = int(rng.choice(cand))
+            n0 = free
+            free += L + int(rng.integers(0, 3))
+            mod = int(rng.integers(1, 4))
+            nre = nsymb * 12 * L
+            tbs, C_ = valid_tbs(min(int(0.55 * nre * 2 * mod), 75376))
+            if tbs == 0 or nre < 40:
+                continue
+            O_ack, O_ri = (int(rng.integers(0, 3)), int(rng.integers(0, 2))) if L >= 2 else (0, 0)
+            grants.append(hp.UlGrant.make(b, 0x600 + k, L, n0, mod, tbs, n_dmrs=int(rng.integers(0, 8)), ack_len=O_ack, I_offset_ack=6, ri_len=O_ri, I_offset_ri=5))
+            datas.append(rng.integers(0, 256, tbs // 8, dtype=np.uint8))
+            acks.append(tuple(int(v) for v in rng.integers(0, 2, O_ack)))
+            ris.append(tuple(int(v) for v in rng.integers(0, 2, O_ri)))
+            k += 1
+    # a few PUSCHs hop: slot 1 at another free offset of the same size is hard to guarantee in a packed subframe, so hop the lone ones
+    per_sf = {}
+    for p_, g in enumerate(grants):
+        per_sf.setdefault(g.sf, []).append(p_)
+    for b, lst in per_sf.items():
+        if len(lst) == 1 and grants[lst[0]].L_prb < prb:
+            g = grants[lst[0]]
+            g.n_prb_slot1 = int(rng.integers(0, prb - g.L_prb + 1))
+    tbs_max = max(g.tbs for g in grants)
+    tx = hp.UlTx(cell_id, prb, 0x1234, 1, tbs_max, 6 if prb >= 6 else 1, 0, 0, nsf, 3, 11, True, False, shortened=short, max_grants=len(grants))
+    iq = tx.encode_grants(datas, tti0, nsf, grants, ack=acks, ri=ris)
+    tx.free()
+    rx = hp.UlRx(cell_id, prb, 0x1234, 1, tbs_max, 6 if prb >= 6 else 1, 0, 0, 6, nsf, 3, 11, True, False, shortened=short, max_grants=len(grants))
+    tb, ok = rx.decode_grants(iq, tti0, grants)
+    a, r = rx.grants_uci()
+    assert ok.all(), [(p_, grants[p_].L_prb, grants[p_].mod, grants[p_].tbs) for p_ in np.flatnonzero(ok == 0)][:5]
+    for p_, g in enumerate(grants):
+        assert np.array_equal(tb[p_][:g.tbs // 8], datas[p_]), p_
+        assert tuple(a[p_][:g.ack_len]) == acks[p_] and tuple(r[p_][:g.ri_len]) == ris[p_], p_
+    rx.free()
