@@ -340,7 +340,8 @@ int srslte_hip_ul_rx_batch_harq(srslte_hip_ul_rx_t* q, const void* d_iq, uint32_
  * new-data flag. Slot p of the object is that PUSCH's srslte_softbuffer_rx_t between calls (HARQ as srslte_hip_ul_rx_batch_harq). Rows p of
  * d_tb / d_tb_ok. The object's cell, DMRS configuration, shortened flag, equaliser and pass limit apply (its own grant and UCI fields are those of
  * the fixed pipeline and play no part here); cfg.tbs = the largest transport block, cfg.max_grants >= nof_grants. HARQ-ACK and rank indication
- * per PUSCH (decisions: srslte_hip_ul_rx_grants_ack / _ri, [max_grants][2] device bytes each, row p) and CQI reports (srslte_hip_ul_rx_grants_cqi:
+ * per PUSCH (decisions: srslte_hip_ul_rx_grants_ack / _ri, [max_grants][2] device bytes each, row p; a call in which no grant carries either leaves
+ * the rows as they were) and CQI reports (srslte_hip_ul_rx_grants_cqi:
  * [max_grants][64] bits, then [max_grants] CRC flags, as srslte_hip_ul_rx_cqi; rows whose grant carries no report keep their content). */
 typedef struct {
   uint32_t sf;                       /* 0 .. nof_sf-1 */
