@@ -27,6 +27,24 @@ KERNEL8(k_add32, IND8("v_add_u32", ""))
 KERNEL8(k_max16, IND8("v_max_i16", ""))
 KERNEL8(k_mix, "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %2, %2, %8 clamp\n v_pk_max_i16 %3, %3, %8\n"
                "v_pk_add_i16 %4, %4, %8 clamp\n v_pk_add_i16 %5, %5, %8 clamp\n v_pk_max_i16 %6, %6, %8\n v_pk_max_i16 %7, %7, %8\n")
+// dependent chains: N interleaved chains of v_pk_add_i16 (latency of a dependent packed op), and the decoder's own chain
+// add -> dpp -> max -> add ... with 1, 2 or 4 chains interleaved
+#define DEP1 "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n" \
+             "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n"
+#define DEP2 "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n" \
+             "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n"
+#define DEP4 "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %2, %2, %8 clamp\n v_pk_add_i16 %3, %3, %8 clamp\n" \
+             "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_pk_add_i16 %2, %2, %8 clamp\n v_pk_add_i16 %3, %3, %8 clamp\n"
+#define DPPC(r) "v_pk_add_i16 " r ", " r ", %8 clamp\n s_nop 1\n v_mov_b32_dpp " r ", " r " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_pk_max_i16 " r ", " r ", %8\n"
+#define DPPC2 "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n" \
+              "v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n nop_pad"
+KERNEL8(k_dep1, DEP1)
+KERNEL8(k_dep2, DEP2)
+KERNEL8(k_dep4, DEP4)
+KERNEL8(k_dppc1, DPPC("%0") DPPC("%0"))
+KERNEL8(k_dppc2, "v_pk_add_i16 %0, %0, %8 clamp\n v_pk_add_i16 %1, %1, %8 clamp\n v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_mov_b32_dpp %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_pk_max_i16 %0, %0, %8\n v_pk_max_i16 %1, %1, %8\n"
+                 "v_pk_add_i16 %2, %2, %8 clamp\n v_pk_add_i16 %3, %3, %8 clamp\n")
 template <typename K>
 int run(const char* name, K k, unsigned long long* d)
 {
@@ -49,6 +67,8 @@ int main()
 {
   unsigned long long* d;
   CHK(hipMalloc(&d, 64 * 8));
+  // (dppc1: 6 instructions + 2 s_nop per body of 8 slots; cycles are per 8-instruction body slot)
+  if (run("dep1", k_dep1, d) || run("dep2", k_dep2, d) || run("dep4", k_dep4, d) || run("dppc1", k_dppc1, d) || run("dppc2", k_dppc2, d)) return 1;
   if (run("pk_add", k_pk_add, d) || run("add_u32", k_add32, d) || run("max_i16", k_max16, d) || run("mix_pk", k_mix, d)) return 1;
   return 0;
 }

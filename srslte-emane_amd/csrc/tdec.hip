@@ -972,465 +972,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// 16-window decoder, second mapping: a lane owns ALL EIGHT states of two windows (one packed pair), as a lane of the reference's
-// AVX2 registers does (turbodecoder_win.h:398-679), and a wavefront decodes EIGHT code blocks (lane = block slot * 8 + window pair).
-// A trellis step then is the reference's 12 adds + 8 max on registers - no cross-lane traffic, no phases - and the max-log output
-// a 16-add, 14-max tree in the lane: about 14 instructions per block and step for the four sweeps (warm-ups, beta, beta
-// recomputation, alpha + output) against 34 in the state-per-lane mapping above. The price is parallelism, 8 blocks per wavefront:
-// this kernel is for launches with many blocks (the batch pipelines), the other one for few.
-//   * beta: every LCK-th metric set goes to a per-wave global scratch row (2 x 16 B per lane); the alpha pass recomputes the
-//     LCK - 1 sets between two rows into REGISTERS (88 VGPRs) and consumes them - no LDS, nothing per step in memory. The
-//     Lw mod LCK steps at the top of a window have their sets stored one by one instead.
-//   * operands of a segment (x, y, a-priori) are requested one segment ahead.
-//   * the element-wise phases between the sweeps (extrinsic exchange, interleaver permutations through LDS, CRC syndrome,
-//     decisions) are those of tdec_win_kernel, run block slot by block slot with all 64 lanes.
-//   * blocks stop on their own CRC: a finished slot's stores are switched off and its element-wise work is skipped; the
-//     wavefront ends when all its slots are done.
-// Numerics are those of tdec_win_kernel<16, 0> bit for bit (tests force either mapping on the same inputs).
-// MEASURED (profiles/r02/lane_mapping.txt): 1664 blocks of K = 5824, six passes: 1.88 ms against 0.53 ms for the state-per-lane kernel;
-// 6656 blocks: 2.93 against 1.79 ms. Why: one wavefront per SIMD issues a packed-int16 instruction every 8.5 cycles whatever its
-// instruction-level parallelism (profiles/r02/ubench_issue.txt: 8.5 / 5.9 / 5.0 / 4.5 cycles at 1 / 2 / 4 / 8 wavefronts per SIMD), and this
-// mapping has 8 x fewer wavefronts (208 per 128-subframe batch on 1024 SIMDs) with ~440 registers each. It would need ~20 batches in
-// flight and <= 128 registers to pay. Kept selectable (force 1016 sub-blocks) and tested; the batch pipelines stay on the other kernel.
-// ------------------------------------------------------------------------------------------------------------------
-#ifndef TDEC_LANE_MIN_CB
-#define TDEC_LANE_MIN_CB 0xffffffffu // AUTO never selects this mapping: see the measurements quoted below
-#endif
-constexpr int LANE_EWU = 12; // 16-byte elements in flight per lane in the element-wise phases: a whole 6144-bit block per batch
-constexpr int LCK = 12; // checkpoint spacing = alpha segment length (even: the normalisation parity of a segment is fixed)
-
-struct S8 { pk_t v[8]; };
-
-__device__ __forceinline__ void lane_normalize(S8& s)
-{ // turbodecoder_win.h:332-349 (16-bit): subtract state 0
-#pragma unroll
-  for (int i = 1; i < 8; i++) s.v[i] = pk_sub<true>(s.v[i], s.v[0]);
-  s.v[0] = 0;
-}
-__device__ __forceinline__ void lane_beta_step(S8& b, pk_t x, pk_t y)
-{ // turbodecoder_win.h:479-512
-  const pk_t xy = pk_add<true>(x, y);
-  const pk_t m0 = pk_add<true>(b.v[4], xy), m1 = b.v[4], m2 = pk_add<true>(b.v[5], y), m3 = pk_add<true>(b.v[5], x);
-  const pk_t m4 = pk_add<true>(b.v[6], x), m5 = pk_add<true>(b.v[6], y), m6 = b.v[7], m7 = pk_add<true>(b.v[7], xy);
-  const pk_t n0 = b.v[0], n1 = pk_add<true>(b.v[0], xy), n2 = pk_add<true>(b.v[1], x), n3 = pk_add<true>(b.v[1], y);
-  const pk_t n4 = pk_add<true>(b.v[2], y), n5 = pk_add<true>(b.v[2], x), n6 = pk_add<true>(b.v[3], xy), n7 = b.v[3];
-  b.v[0] = pk_max(m0, n0); b.v[1] = pk_max(m1, n1); b.v[2] = pk_max(m2, n2); b.v[3] = pk_max(m3, n3);
-  b.v[4] = pk_max(m4, n4); b.v[5] = pk_max(m5, n5); b.v[6] = pk_max(m6, n6); b.v[7] = pk_max(m7, n7);
-}
-// OUT: also the max-log extrinsic output from the beta metrics B of the next time step (turbodecoder_win.h:621-668)
-template <bool OUT>
-__device__ __forceinline__ pk_t lane_alpha_step(S8& a, pk_t x, pk_t y, const S8& B)
-{
-  const pk_t xy = pk_add<true>(x, y);
-  pk_t       m[8], n[8];
-  m[0] = a.v[0]; m[1] = pk_add<true>(a.v[3], y); m[2] = pk_add<true>(a.v[4], y); m[3] = a.v[7];
-  m[4] = a.v[1]; m[5] = pk_add<true>(a.v[2], y); m[6] = pk_add<true>(a.v[5], y); m[7] = a.v[6];
-  n[0] = pk_add<true>(a.v[1], xy); n[1] = pk_add<true>(a.v[2], x); n[2] = pk_add<true>(a.v[5], x); n[3] = pk_add<true>(a.v[6], xy);
-  n[4] = pk_add<true>(a.v[0], xy); n[5] = pk_add<true>(a.v[3], x); n[6] = pk_add<true>(a.v[4], x); n[7] = pk_add<true>(a.v[7], xy);
-  pk_t o = 0;
-  if constexpr (OUT) {
-    pk_t m1 = pk_max(pk_add<true>(B.v[0], n[0]), pk_add<true>(B.v[1], n[1]));
-    pk_t m0 = pk_max(pk_add<true>(B.v[0], m[0]), pk_add<true>(B.v[1], m[1]));
-#pragma unroll
-    for (int i = 2; i < 8; i++) {
-      m1 = pk_max(m1, pk_add<true>(B.v[i], n[i]));
-      m0 = pk_max(m0, pk_add<true>(B.v[i], m[i]));
-    }
-    o = pk_sub<true>(m1, m0);
-  }
-#pragma unroll
-  for (int i = 0; i < 8; i++) a.v[i] = pk_max(m[i], n[i]);
-  return o;
-}
-
-struct LaneSrc { // the three operand arrays of a SISO pass as packed window pairs, offset to this lane's pair: element k * 8
-  const pk_t *x, *ap, *y; // ap: a-priori values added to x with saturation, or null (the same choice in every lane)
-};
-template <int N>
-struct LaneOps { pk_t x[N], y[N]; };
-// operands of the N steps k0, k0 + dir, ...; out-of-range steps are clamped (their values are never used)
-template <int N>
-__device__ __forceinline__ LaneOps<N> lane_load(const LaneSrc& S, int k0, int dir, int Lw)
-{
-  LaneOps<N> r;
-  pk_t       t[N];
-#pragma unroll
-  for (int i = 0; i < N; i++) {
-    const int k = min(max(k0 + dir * i, 0), Lw - 1);
-    r.x[i]      = S.x[k * 8];
-    r.y[i]      = S.y[k * 8];
-    t[i]        = S.ap ? S.ap[k * 8] : 0;
-  }
-  if (S.ap) {
-#pragma unroll
-    for (int i = 0; i < N; i++) r.x[i] = pk_add<true>(t[i], r.x[i]);
-  }
-  return r;
-}
-__device__ __forceinline__ void lane_row_store(int4* rows, int row, int lane, const S8& s)
-{
-  int4* p = rows + ((size_t)row * 64 + lane) * 2;
-  p[0]    = make_int4(s.v[0], s.v[1], s.v[2], s.v[3]);
-  p[1]    = make_int4(s.v[4], s.v[5], s.v[6], s.v[7]);
-}
-__device__ __forceinline__ S8 lane_row_load(const int4* rows, int row, int lane)
-{
-  const int4* p = rows + ((size_t)row * 64 + lane) * 2;
-  const int4  a = p[0], b = p[1];
-  S8          s;
-  s.v[0] = a.x; s.v[1] = a.y; s.v[2] = a.z; s.v[3] = a.w; s.v[4] = b.x; s.v[5] = b.y; s.v[6] = b.z; s.v[7] = b.w;
-  return s;
-}
-
-// One SISO pass of the wavefront's eight blocks. tail_x / tail_y: the three tail LLRs of this lane's block (systematic / parity).
-// out: this lane's pair of the output array (element k * 8); lanes of slots that are done get a scratch array. rows: per-wave scratch.
-__device__ __forceinline__ void lane_siso(const LaneSrc& S, const int16_t* tail_x, const int16_t* tail_y, pk_t* __restrict__ out,
-                                          int4* __restrict__ rows, int Lw, int lane)
-{
-  const int  g   = lane & 7;
-  const pk_t NEG = pk_make(-TD_INF, -TD_INF);
-  S8         b;
-  // ---- beta warm-up: steps 39..0 of every window from "unknown" (turbodecoder_win.h:456-478)
-#pragma unroll
-  for (int i = 0; i < 8; i++) b.v[i] = NEG;
-  {
-    LaneOps<8> cur = lane_load<8>(S, WIN_OVERLAP - 1, -1, Lw);
-#pragma unroll
-    for (int blk = 0; blk < WIN_OVERLAP / 8; blk++) {
-      LaneOps<8> nxt = cur;
-      if (blk + 1 < WIN_OVERLAP / 8) nxt = lane_load<8>(S, WIN_OVERLAP - 1 - 8 * (blk + 1), -1, Lw);
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int k = WIN_OVERLAP - 1 - 8 * blk - i;
-        lane_beta_step(b, cur.x[i], cur.y[i]);
-        if ((k & 1) == 0 && k != 0) lane_normalize(b);
-      }
-      cur = nxt;
-    }
-  }
-  // ---- tail trellis of the block's last window (scalar, wrapping int16; turbodecoder_win.h:351-395) and the window shift:
-  //      window w starts from the warm-up of window w + 1, the last one from the tail (:428-448)
-  {
-    int o[8] = {0, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF, -TD_INF};
-    auto WA  = [](int a_, int b_) -> int { return (int)(short)(a_ + b_); };
-    for (int j = 2; j >= 0; j--) {
-      const int x = tail_x[j], y = tail_y[j], xy_ = WA(x, y);
-      int m[8] = {WA(o[4], xy_), o[4], WA(o[5], y), WA(o[5], x), WA(o[6], x), WA(o[6], y), o[7], WA(o[7], xy_)};
-      int n[8] = {o[0], WA(o[0], xy_), WA(o[1], x), WA(o[1], y), WA(o[2], y), WA(o[2], x), WA(o[3], xy_), o[3]};
-      for (int i = 0; i < 8; i++) o[i] = m[i] > n[i] ? m[i] : n[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const pk_t nb = __shfl_down(b.v[i], 1, 8); // pair g + 1 of the same block
-      b.v[i]        = pk_make(pk_hi(b.v[i]), g < 7 ? pk_lo(nb) : o[i]);
-    }
-  }
-  // ---- beta main pass (:466-526): steps Lw-1 .. 0. Kept: beta[j * LCK], j = 1 .. nf, in rows 1 .. nf; beta[nf * LCK + r],
-  //      r = 1 .. t (t = Lw - nf * LCK < LCK; r = t is the start value) in rows nf + r. All as stored upstream: before normalisation.
-  const int nf = Lw / LCK, t = Lw - nf * LCK;
-  lane_row_store(rows, nf + t, lane, b); // t = 0: row nf = beta[Lw], the checkpoint of the last full segment
-  for (int k = Lw - 1; k >= nf * LCK; k--) { // the t steps at the top: every set is kept
-    pk_t x = S.x[k * 8];
-    if (S.ap) x = pk_add<true>(S.ap[k * 8], x);
-    lane_beta_step(b, x, S.y[k * 8]);
-    lane_row_store(rows, nf + (k - nf * LCK), lane, b); // k = nf * LCK: row nf, the checkpoint
-    if ((k & 1) == 0 && k != 0) lane_normalize(b);
-  }
-  {
-    LaneOps<LCK> cur = lane_load<LCK>(S, nf * LCK - 1, -1, Lw), nx1 = lane_load<LCK>(S, (nf - 1) * LCK - 1, -1, Lw);
-    for (int j = nf - 1; j >= 0; j--) { // steps j * LCK + LCK - 1 .. j * LCK; operands two blocks ahead
-      const LaneOps<LCK> nx2 = lane_load<LCK>(S, (j - 1) * LCK - 1, -1, Lw);
-#pragma unroll
-      for (int i = 0; i < LCK; i++) {
-        lane_beta_step(b, cur.x[i], cur.y[i]);
-        if (i == LCK - 1) {
-          if (j > 0) lane_row_store(rows, j, lane, b);
-        }
-        if (((LCK - 1 - i) & 1) == 0 && (i != LCK - 1 || j != 0)) lane_normalize(b);
-      }
-      cur = nx1;
-      nx1 = nx2;
-    }
-  }
-  // ---- alpha warm-up over the last 40 steps of every window (:586-603); normalisation counter 0..39
-  S8 a;
-#pragma unroll
-  for (int i = 0; i < 8; i++) a.v[i] = NEG;
-  {
-    const int  k0  = Lw - WIN_OVERLAP;
-    LaneOps<8> cur = lane_load<8>(S, k0, 1, Lw);
-    S8         dummy;
-#pragma unroll
-    for (int i = 0; i < 8; i++) dummy.v[i] = 0;
-#pragma unroll
-    for (int blk = 0; blk < WIN_OVERLAP / 8; blk++) {
-      LaneOps<8> nxt = cur;
-      if (blk + 1 < WIN_OVERLAP / 8) nxt = lane_load<8>(S, k0 + 8 * (blk + 1), 1, Lw);
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int kk = 8 * blk + i;
-        lane_alpha_step<false>(a, cur.x[i], cur.y[i], dummy);
-        if ((kk & 1) == 0 && kk != 0) lane_normalize(a);
-      }
-      cur = nxt;
-    }
-  }
-  // ---- window shift: window w starts from the end of window w - 1, window 0 from the known state (:560-583)
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const pk_t pa = __shfl_up(a.v[i], 1, 8);
-    a.v[i]        = pk_make(g > 0 ? pk_hi(pa) : (i == 0 ? 0 : -TD_INF), pk_lo(a.v[i]));
-  }
-  // ---- alpha main pass with extrinsic output (:605-679), LCK steps at a time: beta[k0 + 1 .. k0 + LCK - 1] recomputed from
-  //      row j + 1 into registers, then consumed together with the alpha recursion
-  {
-    LaneOps<LCK> cur = lane_load<LCK>(S, 0, 1, Lw);
-    S8           Bnext = lane_row_load(rows, 1, lane);
-    for (int j = 0; j < nf; j++) {
-      const int          k0  = j * LCK;
-      const LaneOps<LCK> nxt = lane_load<LCK>(S, k0 + LCK, 1, Lw);
-      const S8           Btop = Bnext; // beta[k0 + LCK] before its normalisation
-      Bnext                   = lane_row_load(rows, min(j + 2, nf + t), lane);
-      S8                 vb   = Btop;
-      S8                 seg[LCK]; // seg[i] = beta[k0 + i], i = 1 .. LCK - 1
-      if (k0 + LCK < Lw) lane_normalize(vb); // the recursion went on from the normalised value; beta[Lw] is a start value
-#pragma unroll
-      for (int i = LCK - 1; i >= 1; i--) {
-        lane_beta_step(vb, cur.x[i], cur.y[i]);
-        seg[i] = vb;
-        if ((i & 1) == 0) lane_normalize(vb); // (k0 + i) even, never 0
-      }
-#pragma unroll
-      for (int i = 0; i < LCK; i++) {
-        const int  k = k0 + i;
-        const pk_t o = lane_alpha_step<true>(a, cur.x[i], cur.y[i], i == LCK - 1 ? Btop : seg[i + 1]);
-        out[k * 8] = o;
-        if ((i & 1) == 0 && k != 0) lane_normalize(a);
-      }
-      cur = nxt;
-    }
-    // the last t < LCK steps: their beta sets were stored one by one
-    for (int i = 0; i < t; i++) {
-      const int  k = nf * LCK + i;
-      const S8   B = lane_row_load(rows, nf + i + 1, lane);
-      pk_t       x = S.x[k * 8];
-      if (S.ap) x = pk_add<true>(S.ap[k * 8], x);
-      const pk_t o = lane_alpha_step<true>(a, x, S.y[k * 8], B);
-      out[k * 8] = o;
-      if ((k & 1) == 0 && k != 0) lane_normalize(a);
-    }
-  }
-}
-
-__global__ __launch_bounds__(64) void tdec_lane_kernel(TdecArgs a)
-{
-  const int lane = threadIdx.x, slot = lane >> 3, g = lane & 7, K = (int)a.K, Lw = K / 16, K8 = K / 8;
-  constexpr int W = 16;
-  __shared__ __attribute__((aligned(16))) int16_t perm[SRSLTE_HIP_MAX_K];
-  __shared__ int16_t tl[8][12]; // per block slot: systematic tail, parity-0 tail, interleaved systematic tail, parity-1 tail
-  __shared__ int     cbs[8];    // block of each slot, -1 = none
-  if (lane < 8) {
-    const int lcb = blockIdx.x * 8 + lane;
-    int       cb  = -1;
-    if (lcb < (int)a.nof_cb) {
-      cb = a.cb_map ? (int)a.cb_map[lcb] : lcb;
-      if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318)
-        if (a.iters) a.iters[cb] = 0;
-        cb = -1;
-      }
-    }
-    cbs[lane] = cb;
-  }
-  __syncthreads();
-  uint32_t active = 0; // bit c: slot c still decoding
-  int      first  = -1;
-  for (int c = 0; c < 8; c++) {
-    if (cbs[c] >= 0) {
-      active |= 1u << c;
-      if (first < 0) first = c;
-    }
-  }
-  if (!active) return;
-  auto wk_of   = [&](int c) { return a.work + (size_t)(blockIdx.x * 8 + c) * 7 * a.Kp; };
-  auto in_of   = [&](int c) { return a.in + (size_t)cbs[c] * a.in_stride; };
-  const int  tb      = a.sb_layout ? 3 * (K + 32) : 3 * K;
-  const bool inplace = a.sb_layout && ((reinterpret_cast<uintptr_t>(a.in) | (a.in_stride * sizeof(int16_t))) & 15) == 0;
-  // ---- input extraction, block slot by block slot (as tdec_win_kernel)
-  for (int c = 0; c < 8; c++) {
-    if (!((active >> c) & 1)) continue;
-    const int16_t* in = in_of(c);
-    int16_t *      syst = wk_of(c), *par0 = syst + a.Kp, *par1 = syst + 2 * a.Kp;
-    if (!inplace && a.sb_layout) {
-      batched<8>(
-          lane, K, [&](int i) { return I3{in[i], in[K + 32 + i], in[2 * (K + 32) + i]}; },
-          [&](int i, I3 t) {
-            syst[i] = (int16_t)t.a;
-            par0[i] = (int16_t)t.b;
-            par1[i] = (int16_t)t.c;
-          });
-    } else if (!a.sb_layout) {
-      batched<8>(
-          lane, K, [&](int n) { return I3{in[3 * n], in[3 * n + 1], in[3 * n + 2]}; },
-          [&](int n, I3 t) {
-            const int x = win_pos<W>(n, K);
-            syst[x]     = (int16_t)t.a;
-            par0[x]     = (int16_t)t.b;
-            par1[x]     = (int16_t)t.c;
-          });
-    }
-    if (lane < 3) {
-      tl[c][lane]     = in[tb + 2 * lane];
-      tl[c][3 + lane] = in[tb + 2 * lane + 1];
-      tl[c][6 + lane] = in[tb + 6 + 2 * lane];
-      tl[c][9 + lane] = in[tb + 6 + 2 * lane + 1];
-    }
-  }
-  __syncthreads();
-  // this lane's block: a slot without one borrows the first active slot's arrays for its loads and never stores
-  const int      ms    = ((active >> slot) & 1) ? slot : first;
-  int16_t*       wk    = wk_of(ms);
-  const int16_t* syst_r = inplace ? in_of(ms) : wk;
-  const int16_t* par0_r = inplace ? in_of(ms) + (K + 32) : wk + a.Kp;
-  const int16_t* par1_r = inplace ? in_of(ms) + 2 * (K + 32) : wk + 2 * a.Kp;
-  auto           P      = [&](const int16_t* p) { return reinterpret_cast<const pk_t*>(p) + g; };
-  int4*          rows   = reinterpret_cast<int4*>(a.beta + (size_t)blockIdx.x * a.beta_stride);
-  uint32_t       n_iter = 0, dec_app = 0, okmask = 0; // dec_app bit c: slot c's decision metrics are in app1 (else ext1)
-  __shared__ uint32_t it_of[8];
-  while (n_iter < a.nof_iter && active) {
-    const bool mine = (active >> slot) & 1;
-    if (a.dbg & 2) {
-    } else if ((n_iter & 1) == 0) {
-      if (n_iter) { // app1 -= ext1 (srslte_vec_sub_sss, wrapping)
-        for (int c = 0; c < 8; c++) {
-          if (!((active >> c) & 1)) continue;
-          int16_t *app1 = wk_of(c) + 3 * a.Kp, *ext1 = wk_of(c) + 5 * a.Kp;
-          batched<LANE_EWU>(
-              lane, K8, [&](int i8) { return V8x3{ld8(app1, i8), ld8(ext1, i8), v8u{}}; }, [&](int i8, V8x3 t) { st8(app1, i8, t.a - t.b); });
-        }
-        __syncthreads();
-      }
-    } else {
-      for (int c = 0; c < 8; c++) {
-        if (!((active >> c) & 1)) continue;
-        int16_t *  app1 = wk_of(c) + 3 * a.Kp, *app2 = wk_of(c) + 4 * a.Kp, *ext1 = wk_of(c) + 5 * a.Kp;
-        const bool sub  = n_iter > 1; // ext1 -= app1 fused with the scatter app2[deinter[i]] = ext1[i]
-        batched<LANE_EWU>(
-            lane, K8, [&](int i8) { return V8x3{ld8(ext1, i8), sub ? ld8(app1, i8) : v8s{}, ld8u(a.t.deinter, i8)}; },
-            [&](int i8, V8x3 t) {
-              const v8s e = sub ? t.a - t.b : t.a;
-              if (sub) st8(ext1, i8, e);
-#pragma unroll
-              for (int j = 0; j < 8; j++) perm[t.c[j]] = e[j];
-            });
-        __syncthreads();
-        for (int i8 = lane; i8 < K8; i8 += 64) st8(app2, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
-        __syncthreads();
-      }
-    }
-    { // the SISO pass proper: one call site, operands by the pass's parity
-      const bool    odd = n_iter & 1;
-      const LaneSrc S{odd ? P(wk + 4 * a.Kp) : P(syst_r), (!odd && n_iter) ? P(wk + 3 * a.Kp) : nullptr, odd ? P(par1_r) : P(par0_r)};
-      // a slot that is done (or empty) sends its output to the block's combine-pass scratch, which this kernel does not use otherwise
-      pk_t* out = mine ? reinterpret_cast<pk_t*>(wk + (odd ? 6 : 5) * a.Kp) : reinterpret_cast<pk_t*>(a.xy + (size_t)(blockIdx.x * 8 + slot) * a.K);
-      if (!(a.dbg & 1)) lane_siso(S, tl[ms] + (odd ? 6 : 0), tl[ms] + (odd ? 9 : 3), out + g, rows, Lw, lane);
-      __syncthreads();
-    }
-    if ((n_iter & 1) && !(a.dbg & 2)) {
-      for (int c = 0; c < 8; c++) {
-        if (!((active >> c) & 1)) continue;
-        int16_t *app1 = wk_of(c) + 3 * a.Kp, *ext2 = wk_of(c) + 6 * a.Kp;
-        batched<LANE_EWU>(
-            lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
-            [&](int i8, V8x3 t) {
-#pragma unroll
-              for (int j = 0; j < 8; j++) perm[t.c[j]] = t.a[j];
-            });
-        __syncthreads();
-        for (int i8 = lane; i8 < K8; i8 += 64) st8(app1, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
-        __syncthreads();
-      }
-    }
-    n_iter++;
-    // ---- sch.c:362-378: CRC over the hard decisions of this pass, per block
-    if (a.t.crc_rem) {
-      for (int c = 0; c < 8; c++) {
-        if (!((active >> c) & 1)) continue;
-        const int16_t* dec = (n_iter & 1) ? wk_of(c) + 5 * a.Kp : wk_of(c) + 3 * a.Kp;
-        uint32_t       syn = 0;
-        batched<LANE_EWU>(
-            lane, K8,
-            [&](int i8) {
-              const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
-              return V8W{ld8(dec, i8), tp[0], tp[1]};
-            },
-            [&](int i8, V8W t) {
-#pragma unroll
-              for (int j = 0; j < 4; j++) syn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
-            });
-        for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
-        if (syn == 0 && !(a.dbg & 16)) {
-          okmask |= 1u << c;
-          active &= ~(1u << c);
-          if (lane == 0) it_of[c] = n_iter;
-          if (!(n_iter & 1)) dec_app |= 1u << c;
-        }
-      }
-    }
-  }
-  for (int c = 0; c < 8; c++) {
-    if ((active >> c) & 1) { // ran out of passes
-      if (lane == 0) it_of[c] = n_iter;
-      if (!(n_iter & 1)) dec_app |= 1u << c;
-    }
-  }
-  // ---- hard decision bytes and the transport-block CRC share of every block (as tdec_win_kernel)
-  const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw);
-  for (int c = 0; c < 8; c++) {
-    const int cb = cbs[c];
-    if (cb < 0) continue;
-    const int16_t*  dec  = ((dec_app >> c) & 1) ? wk_of(c) + 3 * a.Kp : wk_of(c) + 5 * a.Kp;
-    uint8_t*        o    = a.out + (size_t)cb * a.out_stride;
-    uint32_t        tsyn = 0;
-    const uint32_t* tab  = a.tb_rem ? a.tb_rem + (size_t)(cb % a.tb_C) * K : nullptr;
-    __syncthreads();
-    if (tab) {
-      batched<LANE_EWU>(
-          lane, K8,
-          [&](int i8) {
-            const v4w* tp = reinterpret_cast<const v4w*>(tab + 8 * i8);
-            return V8W{ld8(dec, i8), tp[0], tp[1]};
-          },
-          [&](int i8, V8W t) {
-            *reinterpret_cast<v8s*>(perm + 8 * i8) = t.a;
-#pragma unroll
-            for (int j = 0; j < 4; j++) tsyn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
-          });
-      for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
-    } else {
-      for (int i8 = lane; i8 < K8; i8 += 64) *reinterpret_cast<v8s*>(perm + 8 * i8) = ld8(dec, i8);
-    }
-    __syncthreads();
-    for (int b = lane; b < K8; b += 64) {
-      int      q = (int)__umulhi((uint32_t)(8 * b), magic), r = 8 * b - q * Lw;
-      uint32_t byte = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        byte |= (perm[r * W + q] > 0 ? 0x80u : 0u) >> j;
-        if (++r == Lw) {
-          r = 0;
-          q++;
-        }
-      }
-      o[b] = (uint8_t)byte;
-    }
-    if (lane == 0) {
-      if (a.iters) a.iters[cb] = it_of[c];
-      if (a.crc_ok) a.crc_ok[cb] = (okmask >> c) & 1;
-      if (a.tb_rem) a.tb_syn[cb] = tsyn;
-    }
-  }
-}
+#include "tdec_pair.inc"
 
 // ------------------------------------------------------------------------------------------------------------------
 // Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
@@ -1740,13 +1282,11 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
       (crc_poly && (crc_nbits > K || (crc_poly >> 24) != 1)))
     return SRSLTE_ERROR_INVALID_INPUTS;
   if (nof_cb == 0) return SRSLTE_SUCCESS;
-  // force_w 1016: the 16-window numerics in the eight-blocks-per-wavefront mapping (tdec_lane_kernel); 16: in the block-per-wavefront one
-  bool lane_map = force_w == 1016;
-  if (lane_map) force_w = 16;
+  // force_w 3016: the 16-window numerics in the state-per-lane mapping of rounds 1-2 (tdec_win_kernel<16, 0>: the tests' second opinion on
+  // tdec_pair_kernel, which AUTO and 16 select)
+  const bool old_map = force_w == 3016;
+  if (old_map) force_w = 16;
   const uint32_t W = force_w >= 0 ? (uint32_t)force_w : (llr8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(K) : srslte_hip_tdec_autoimp_get_subblocks(K));
-  if (lane_map && (llr8 || q->start_iter)) return SRSLTE_ERROR_INVALID_INPUTS;
-  // AUTO: the eight-blocks-per-wavefront mapping needs many blocks to fill the machine (one wavefront per 8 blocks, 1024 SIMDs)
-  if (force_w < 0 && !llr8 && W == 16 && !q->start_iter && nof_cb >= TDEC_LANE_MIN_CB) lane_map = true;
   if ((W != 0 && W != 8 && W != 16 && !(llr8 && W == 32)) || (W && (K % W || K / W < WIN_OVERLAP)) || (sb_layout && !W))
     return SRSLTE_ERROR_INVALID_INPUTS;
   const bool ar8 = llr8 && W >= 16; // sse8 / avx8 numerics; below that the 8-bit API widens and runs a 16-bit back-end (turbodecoder.c:465-469)
@@ -1788,9 +1328,9 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
     hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(nof_cb), dim3(64), 0, st, a);
   } else if (ar8) {
     hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a);
-  } else if (W == 16 && lane_map) {
-    a.beta_stride = (K / 16 / LCK + LCK + 2) * 512; // rows of 64 lanes x 8 states
-    hipLaunchKernelGGL(tdec_lane_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a);
+  } else if (W == 16 && !old_map) {
+    a.beta_stride = (K / 16 / PB + 2) * 128; // checkpoint rows of a wavefront: 64 lanes x 2 dwords
+    hipLaunchKernelGGL(tdec_pair_kernel, dim3((nof_cb + 1) / 2), dim3(64), 0, st, a);
   } else if (W == 16) {
     a.beta_stride = (K / 16 + 1) * 64;
     hipLaunchKernelGGL((tdec_win_kernel<16, 0>), dim3(nof_cb), dim3(64), 0, st, a);
@@ -1804,16 +1344,20 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   LAUNCH_CHECK();
 #ifdef TDEC_PROF
   if (a.prof && getenv("SRSLTE_HIP_TDEC_PROF")) {
-    std::vector<unsigned long long> h((size_t)nof_cb * 10);
+    const bool pair = W == 16 && !ar8 && !old_map;
+    const uint32_t nrec = pair ? (nof_cb + 1) / 2 : nof_cb; // the pair kernel writes one record per wavefront
+    std::vector<unsigned long long> h((size_t)nrec * 10);
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipMemcpy(h.data(), a.prof, h.size() * 8, hipMemcpyDeviceToHost));
     double tot[10] = {0}, all = 0;
-    for (uint32_t c = 0; c < nof_cb; c++) {
+    for (uint32_t c = 0; c < nrec; c++) {
       for (int i = 0; i < 10; i++) tot[i] += (double)h[(size_t)c * 10 + i];
     }
     for (int i = 0; i < 10; i++) all += tot[i];
-    static const char* nm[10] = {"extract", "elementwise", "combine", "beta warm-up", "tail+shift+beta main", "alpha warm-up", "alpha main", "crc", "decision+tb", "-"};
-    fprintf(stderr, "[tdec prof] K=%u W=%u blocks=%u mean cycles/block %.0f:", K, W, nof_cb, all / nof_cb);
+    static const char* nm_win[10] = {"extract", "elementwise", "combine", "beta warm-up", "tail+shift+beta main", "alpha warm-up", "alpha main", "crc", "decision+tb", "-"};
+    static const char* nm_pair[10] = {"extract", "before sweeps", "alpha main", "after sweeps", "decisions", "beta warm-up", "tail+shift+beta main", "alpha warm-up", "-", "-"};
+    const char** nm = pair ? nm_pair : nm_win;
+    fprintf(stderr, "[tdec prof] K=%u W=%u blocks=%u mean cycles/block %.0f:", K, W, nrec, all / nrec);
     for (int i = 0; i < 9; i++) fprintf(stderr, " %s %.1f%%", nm[i], 100.0 * tot[i] / all);
     fprintf(stderr, "\n");
   }

@@ -517,12 +517,13 @@ def test_tdec_sb_layout_and_early_stop(hp, K):
 
 
 @pytest.mark.parametrize("K,ncb,sb", [(816, 5, True), (832, 19, False), (1008, 8, True), (2048, 11, True), (3136, 16, False), (5824, 29, True), (6144, 9, True),
-                                       (5824, 13, False)])
-def test_tdec_eight_blocks_per_wavefront_mapping(hp, K, ncb, sb):
-    """tdec_lane_kernel (a lane = all eight states of a window pair, eight code blocks per wavefront; the batch pipelines' decoder) against
-    tdec_win_kernel<16, 0> (a lane = one state; forced with 16 sub-blocks) and the oracle's avx16 restatement: decoded bytes, pass counts and
-    CRC flags of every block, blocks of one wavefront stopping after different numbers of passes, block counts that leave slots empty;
-    with and without early stop; plain [s p0 p1] and rate-dematcher (SB) input layouts."""
+                                       (5824, 13, False), (6144, 1, False), (4160, 2, True), (1024, 3, True)])
+def test_tdec_two_blocks_per_wavefront_mapping(hp, K, ncb, sb):
+    """tdec_pair_kernel (a lane = a butterfly pair of states of a window pair, two code blocks per wavefront: what AUTO runs for K > 800) against
+    tdec_win_kernel<16, 0> (a lane = one state, a block per wavefront: rounds 1-2, forced with 3016 sub-blocks) and the oracle's avx16
+    restatement: decoded bytes, pass counts and CRC flags of every block, the two blocks of a wavefront stopping after different numbers of
+    passes, odd block counts (the last wavefront's second slot shadows the first); with and without early stop; plain [s p0 p1] and
+    rate-dematcher (SB) input layouts; window lengths with every remainder mod 12 and mod 3."""
     rng = np.random.default_rng(31 * K + ncb)
     dec = hp.Tdec(6144, 32)
     stride = (3 * (K + 32) + 12) if sb else (3 * K + 12)
@@ -542,8 +543,8 @@ def test_tdec_eight_blocks_per_wavefront_mapping(hp, K, ncb, sb):
         else:
             w[i] = _noisy_llr(rng, enc, snr - 4.0, 60)
     for poly, nbits, nit in ((hp.CRC24B, K, 6), (0, 0, 3), (0, 0, 4)):
-        rc, out, iters, ok = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=1016)
-        rc2, out2, iters2, ok2 = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=16)
+        rc, out, iters, ok = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=16)
+        rc2, out2, iters2, ok2 = dec.run_all(w, K, nit, sb_layout=sb, crc_poly=poly, crc_nbits=nbits, force_subblocks=3016)
         assert rc == 0 and rc2 == 0
         assert np.array_equal(iters, iters2) and np.array_equal(ok, ok2), (iters, iters2)
         assert np.array_equal(out, out2)
@@ -553,7 +554,7 @@ def test_tdec_eight_blocks_per_wavefront_mapping(hp, K, ncb, sb):
         per = np.zeros((6, K // 8), np.uint8)
         ref = np.zeros(K // 8, np.uint8)
         assert oracle().orc_tdec_run(p(w[i]), sb, K, 6, p(ref), p(per)) == 0
-        rc, out, iters, ok = dec.run_all(w[i:i + 1], K, 4, sb_layout=sb, force_subblocks=1016)
+        rc, out, iters, ok = dec.run_all(w[i:i + 1], K, 4, sb_layout=sb)
         assert np.array_equal(out[0], per[3])
     dec.free()
 
