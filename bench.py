@@ -46,7 +46,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 # 100 PRB, 64QAM MCS 28, TBS 75376 -> 13 x K=5824
 NOF_PRB, MOD, MCS, TBS, CFI, MAX_ITER, BATCH = 100, 3, 28, 75376, 1, 6, 128
 AMP = 0.1
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
+VALU_PEAK_LANE = 256 * 4 * 32 * 2.4e9  # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz = 78.6 T lane-instructions/s (v_fma_f32 class)
 
 
 def algorithmic_bytes(llr8, nof_re_by_sf, ttis):
@@ -65,9 +66,44 @@ def algorithmic_bytes(llr8, nof_re_by_sf, ttis):
     }
 
 
-def file_sha(path):
-    with open(path, "rb") as f:
-        return hashlib.sha256(f.read()).hexdigest()[:16]
+def file_sha(*paths):
+    h = hashlib.sha256()
+    for path in paths:
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def tdec_source_sha():
+    c = os.path.join(ROOT, "srslte-emane_amd", "csrc")
+    return file_sha(os.path.join(c, "tdec.hip"), os.path.join(c, "tdec_pair.inc"))
+
+
+def fftw_probe(n_fft=1536, per_sf=14, seconds=0.5):
+    """if libfftw3f is on this box, time the OFDM demodulator's FFTs with it (per_sf transforms of n_fft points per subframe).
+    Returns seconds per subframe, or None when the library is absent (it is in this image)."""
+    import ctypes.util
+    name = ctypes.util.find_library("fftw3f")
+    if not name:
+        return None
+    try:
+        F = ctypes.CDLL(name)
+        F.fftwf_plan_dft_1d.restype = ctypes.c_void_p
+        F.fftwf_plan_dft_1d.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint]
+        F.fftwf_execute_dft.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        a = np.random.default_rng(0).standard_normal(2 * n_fft * per_sf).astype(np.float32)
+        b = np.zeros_like(a)
+        plan = F.fftwf_plan_dft_1d(n_fft, a.ctypes.data, b.ctypes.data, -1, 0)  # FFTW_FORWARD, FFTW_MEASURE
+        if not plan:
+            return None
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for i in range(per_sf):
+                F.fftwf_execute_dft(plan, a.ctypes.data + 8 * n_fft * i, b.ctypes.data + 8 * n_fft * i)
+            n += 1
+        return (time.perf_counter() - t0) / n
+    except (OSError, AttributeError):
+        return None
 
 
 def cpu_model():
@@ -119,11 +155,11 @@ def cpu_worker(path, lo, hi, seconds, cell_id, rnti, llr8):
     iq = np.load(path, mmap_mode="r")
     mine = np.ascontiguousarray(iq[lo:hi])
     run, kind = cpu_chain(cell_id, rnti, llr8)
-    n, t0 = 0, time.perf_counter()
+    n, t_ofdm, t0 = 0, 0.0, time.perf_counter()
     while time.perf_counter() - t0 < seconds:
-        run(mine, lo)
+        t_ofdm += run(mine, lo)[3]
         n += hi - lo
-    print(json.dumps({"n": n, "dt": time.perf_counter() - t0, "kind": kind}))
+    print(json.dumps({"n": n, "dt": time.perf_counter() - t0, "t_ofdm": t_ofdm, "kind": kind}))
 
 
 def main():
@@ -191,7 +227,8 @@ def main():
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(lo), str(hi), str(args.cpu_seconds),
                                        str(ue["cell_id"]), str(ue["rnti"])] + (["--llr8"] if args.llr8 else []), stdout=subprocess.PIPE) for lo, hi in spans if hi > lo]
             outs = [json.loads(p_.communicate(timeout=120 + 10 * args.cpu_seconds)[0].decode().strip().splitlines()[-1]) for p_ in procs]
-            cpu_multi = {"value": round(sum(o["n"] / o["dt"] for o in outs), 1), "cores": len(procs), "wall_s": round(time.perf_counter() - t0, 1)}
+            cpu_multi = {"value": round(sum(o["n"] / o["dt"] for o in outs), 1), "cores": len(procs), "wall_s": round(time.perf_counter() - t0, 1),
+                         "value_without_fft": round(sum(o["n"] / max(o["dt"] - o.get("t_ofdm", 0.0), 1e-9) for o in outs), 1)}
 
     import torch
 
@@ -239,10 +276,7 @@ def main():
 
     def step(k, src, ev=None):
         s = k % nstreams
-        if grant_arr is not None:
-            if ev is not None:
-                L.srslte_hip_event_record(ev[0], streams[s])
-                L.srslte_hip_event_record(ev[1], streams[s])
+        if grant_arr is not None:  # one call runs every stage: no decoder-only duration in this mode (tdec_ms stays None, roofline fields null)
             rc = L.srslte_hip_dl_rx_batch_grants(rxs[s].h, src.data_ptr(), 0, B, grant_arr, rxs[s].d_tb.ptr, rxs[s].tb_stride, rxs[s].d_ok.ptr, streams[s])
             if rc:
                 raise RuntimeError("dl_rx_batch_grants failed: %d" % rc)
@@ -276,7 +310,7 @@ def main():
 
     def timed_repeats(src, min_s, with_events):
         """Repeats of the contract's timed region: K steps between barriers. Returns (per-repeat max-over-ranks seconds, mean tdec ms)."""
-        evs = [(L.srslte_hip_event_create(), L.srslte_hip_event_create()) for _ in range(args.steps)] if with_events else None
+        evs = [(L.srslte_hip_event_create(), L.srslte_hip_event_create()) for _ in range(args.steps)] if (with_events and grant_arr is None) else None
         times, tdec = [], []
         while True:
             barrier()
@@ -301,6 +335,9 @@ def main():
 
     for k in range(max(args.warmup, nstreams)):
         step(k, d_iq)
+    # the contract's W warm-up steps are a few milliseconds; clocks and first-touch effects last longer (round 2: the first repeats of the
+    # timed region ran at half speed), so whole untimed repeats follow until 0.15 s have passed
+    timed_repeats(d_iq, 0.15, False)
     times, tdec_ms = timed_repeats(d_iq, args.min_timed_s, True)
     t_med = float(np.median(times))
 
@@ -427,8 +464,14 @@ def main():
         multi = cpu_multi
         src = ("reference's compiled srslte_chest_dl_estimate_cfg + srslte_pdsch_decode (oracle/_ref, AVX2; C loop oracle/refdrv.c:refdrv_dl_rx_loop) + "
                "the oracle's FFT (no FFTW in the image: %.0f %% of the time)" % (100 * t_ofdm / dt)) if kind == "reference" else "oracle restatement (scalar C)"
+        t_fftw = fftw_probe()
         cpu = {"value": multi["value"], "unit": "subframes/s", "cores": multi["cores"], "kind": kind, "cpu_model": cpu_model(),
                "single_core_value": round(nsf / dt, 2),
+               # the same runs with the OFDM demodulator's time taken out (the oracle's FFT stands in for FFTW, which this image lacks): the
+               # reference's own code only - srslte_chest_dl_estimate_cfg + srslte_pdsch_decode. A real reference build lies between the two
+               "value_without_fft": multi.get("value_without_fft"), "single_core_value_without_fft": round(nsf / max(dt - t_ofdm, 1e-9), 2),
+               "fftw": ("absent on this box (ctypes.util.find_library('fftw3f') is None)" if t_fftw is None else
+                        {"ofdm_s_per_subframe": round(t_fftw, 7), "single_core_value_with_fftw": round(nsf / (dt - t_ofdm + nsf * t_fftw), 2)}),
                "sample": "one core: %d subframe decodes cycling over the %d benchmark subframes, %.1f s; %d processes over disjoint subframes of the same batch, %.1f s "
                          "each; %s; of the %d subframes %d are delivered by both CPU and GPU, %d of those differ in a byte; CRC flag differs on %d (marginal blocks: "
                          "the reference equaliser's 12-bit _mm256_rcp_ps)" % (nsf, B, dt, multi["cores"], args.cpu_seconds, src, B, len(both), tb_mismatch, flag_mismatch),
@@ -443,34 +486,56 @@ def main():
     # issue rate from the microbenchmark of this chip (profiles/r02/ubench_issue.json: packed-int16 and DPP instructions, the
     # decoder's mix, issue one wave-instruction per ~4.4 cycles per SIMD at saturation - 16 lanes per clock, not the 32 of plain
     # 32-bit VALU ops).
-    tdec_sha = file_sha(os.path.join(ROOT, "srslte-emane_amd", "csrc", "tdec.hip"))
+    tdec_sha = tdec_source_sha()
+    kernel_name = "tdec_win_kernel<32, 1>" if args.llr8 else "tdec_pair_kernel"
     counters, traffic, traffic_src = None, None, None
     cpath = os.path.join(PROFILE_DIR, "tdec_counters.json")
     if os.path.exists(cpath):
         with open(cpath) as f:
             c = json.load(f)
-        if c.get("tdec_hip_sha") == tdec_sha and not args.llr8 and B == c.get("batch"):
+        if c.get("tdec_src_sha") == tdec_sha and not args.llr8 and B == c.get("batch"):
             counters = c
-            traffic, traffic_src = c.get("traffic_bytes_per_launch"), {"file": "profiles/r02/tdec_counters.json", "tdec_hip_sha": c["tdec_hip_sha"], "head": c.get("head")}
+            traffic, traffic_src = c.get("traffic_bytes_per_launch"), {"file": "profiles/r03/tdec_counters.json", "tdec_src_sha": c["tdec_src_sha"], "head": c.get("head")}
+    # the packed-int16 / DPP issue rate measured on this chip (scripts/ubench_issue.hip: one wave-instruction per ~4.2-4.5 cycles per SIMD,
+    # 16 lanes per clock: half of the guide's SIMD-32 figure, which plain 32-bit VALU operations reach)
     cyc_per_instr, clock_ghz = 4.46, 2.4
-    upath = os.path.join(PROFILE_DIR, "ubench_issue.json")
+    upath = os.path.join(ROOT, "profiles", "r02", "ubench_issue.json")
     if os.path.exists(upath):
         with open(upath) as f:
             u = json.load(f)
         mix = [r for r in u["results"] if r["kernel"] == "ind_mix" and r["waves_per_simd"] == 8]
         if mix:
             cyc_per_instr, clock_ghz = mix[0]["cycles_per_wave_instr"], u["clock_ghz"]
-    peak_lane = 256 * 4 * 64 * clock_ghz * 1e9 / cyc_per_instr  # lane-instructions per second, whole chip
+    peak_packed = 256 * 4 * 64 * clock_ghz * 1e9 / cyc_per_instr
     valu = None
-    if counters:
+    if counters and tdec_ms:
+        waves = counters["waves_per_launch"]
         ipw = counters["valu_instr_per_wave_per_pass"] * passes + counters.get("valu_instr_per_wave_fixed", 0)
-        lane_step = ipw * 64 * B * 13 / (ms_per_step * 1e-3)
-        lane_launch = ipw * 64 * B * 13 / (tdec_ms * 1e-3)
-        valu = {"instr_per_wave": int(ipw), "waves": B * 13, "achieved_step": round(lane_step / 1e12, 2), "achieved_launch": round(lane_launch / 1e12, 2),
-                "frac_step": round(lane_step / peak_lane, 3), "frac_launch": round(lane_launch / peak_lane, 3)}
+        lane = ipw * 64 * waves  # lane-instructions of one launch
+        valu = {"instr_per_wave": int(ipw), "waves": int(waves), "lane_instr_per_launch": int(lane),
+                "achieved_launch": round(lane / (tdec_ms * 1e-3) / 1e12, 2), "achieved_step": round(lane / (ms_per_step * 1e-3) / 1e12, 2),
+                "achieved_alone": round(lane / (kernels["tdec"]["ms"] * 1e-3) / 1e12, 2)}
+    frac = (lambda x: round(x * 1e12 / VALU_PEAK_LANE, 4))
     hbm = {"achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
            "frac_alone": round(tdec_alg / (kernels["tdec"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
-           "algorithmic_bytes_per_launch": tdec_alg}
+           "algorithmic_bytes_per_launch": tdec_alg} if tdec_ms else None
+    roofline = {"kernel": kernel_name, "bound": "valu",
+                # the contract's figure: work of one launch / that launch's own average duration (HIP events on its stream, inside the timed
+                # region) / the guide's peak. With --streams > 1 the launches of different batches overlap, so this duration is the time a
+                # launch SHARES the chip; 'frac_step' divides by the step time instead (what the chip delivers), 'frac_alone' by the
+                # duration of a launch that has the chip to itself
+                "achieved": valu["achieved_launch"] if valu else None, "peak": round(VALU_PEAK_LANE / 1e12, 2), "unit": "T lane-instr/s",
+                "frac": frac(valu["achieved_launch"]) if valu else None,
+                "frac_step": frac(valu["achieved_step"]) if valu else None, "frac_alone": frac(valu["achieved_alone"]) if valu else None,
+                "frac_vs_measured_issue": round(valu["achieved_launch"] * 1e12 / peak_packed, 4) if valu else None,
+                "frac_step_vs_measured_issue": round(valu["achieved_step"] * 1e12 / peak_packed, 4) if valu else None,
+                "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz; measured_issue: profiles/r02/ubench_issue.json, %.2f cycles per packed-int16 / DPP "
+                               "wave-instruction per SIMD (%.1f T lane-instr/s)" % (cyc_per_instr, peak_packed / 1e12),
+                "traffic": traffic, "valu": valu, "counters_source": traffic_src,
+                "avg_launch_ms": round(tdec_ms, 4) if tdec_ms else None, "avg_launch_ms_alone": kernels["tdec"]["ms"], "hbm": hbm,
+                "note": "serial-trellis integer kernel: VALU-issue bound, not HBM-bound (SURVEY 8d); the HBM-bound streaming kernels are in 'kernels' / 'kernels_large_batch'"}
+    for v in (roofline["frac"], roofline["frac_step"], roofline["frac_alone"], hbm["frac"] if hbm else None):
+        assert v is None or 0 <= v <= 1, "a roofline fraction above 1 is a measurement error"
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
@@ -486,16 +551,7 @@ def main():
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(world * B * args.steps / max(times), 1),
                    "repeat_max_value": round(world * B * args.steps / min(times), 1), "full_iter": full,
                    "full_iter_value": full["value"] if full else None},
-        "roofline": {"kernel": "tdec_win_kernel<32, 1>" if args.llr8 else "tdec_win_kernel<16, 0>", "bound": "valu",
-                     "achieved": valu["achieved_step"] if valu else None, "peak": round(peak_lane / 1e12, 2), "unit": "T lane-instr/s",
-                     "frac": valu["frac_step"] if valu else None, "traffic": traffic,
-                     "peak_source": "profiles/r02/ubench_issue.json: %.2f cycles per wave-instruction per SIMD for the decoder's mix (v_pk_add_i16 clamp / v_pk_max_i16 / "
-                                    "v_mov_b32_dpp) at 8 waves per SIMD, %.2f GHz, 1024 SIMDs x 64 lanes" % (cyc_per_instr, clock_ghz),
-                     "valu": valu, "counters_source": traffic_src,
-                     # the events bracket the launch on its own stream: with several streams they include the time its workgroups queue behind the
-                     # other streams' kernels (rocprof's kernel duration starts at the first wave); 'frac' is over the whole step for that reason
-                     "avg_launch_ms": round(tdec_ms, 4), "avg_launch_ms_alone": kernels["tdec"]["ms"], "hbm": hbm,
-                     "note": "serial-trellis integer kernel: VALU-issue bound, not HBM-bound (SURVEY §8d); the HBM-bound streaming kernels are in 'kernels' / 'kernels_large_batch'"},
+        "roofline": roofline,
         "kernels": kernels,
         "kernels_large_batch": big,
         "cpu_baseline": cpu,
