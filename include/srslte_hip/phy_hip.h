@@ -456,6 +456,19 @@ int srslte_hip_dl_tx_batch_grants(srslte_hip_dl_tx_t* q, const uint8_t* d_tb, ui
  * 3 grids [nof_sf][nof_ports][14][12*nof_prb] */
 const void* srslte_hip_dl_tx_debug_buffer(const srslte_hip_dl_tx_t* q, int which);
 
+/* ---- one transport block with HOST buffers in one device call: decode_tb_cb behind srslte_dlsch_decode2 / srslte_ulsch_decode
+ * (lib/src/phy/phch/sch.c:299-414,:507-531): rate de-matching of every code block into its soft buffer, turbo decoding with CRC early stop,
+ * decoded bytes. The single-call srslte_tdec_* API costs a host round trip per code block and per SISO pass; this entry costs one per
+ * transport block. include/srslte_hip/srslte_compat.h exports srslte_dlsch_decode2 on top of it. ---- */
+typedef struct srslte_hip_sch srslte_hip_sch_t;
+srslte_hip_sch_t* srslte_hip_sch_create(uint32_t max_tbs, uint32_t max_e_bits, int llr_8bit);
+void              srslte_hip_sch_destroy(srslte_hip_sch_t* q);
+/* e_bits (host): nof_e_bits LLRs, int16 (int8 for an 8-bit object); mod 1 QPSK .. 4 256QAM; Nl 1 or 2 (sch.c:510-514); buffer_f[c] / cb_crc[c]:
+ * the C soft buffers and CRC flags of the srslte_softbuffer_rx_t (in / out, host); cb_bytes [C][768]: K / 8 decoded bytes of every block this
+ * call decoded; sum_passes: SISO passes over those blocks */
+int srslte_hip_sch_decode(srslte_hip_sch_t* q, const void* e_bits, uint32_t nof_e_bits, uint32_t tbs, int mod, uint32_t Nl, uint32_t rv,
+                          uint32_t max_iterations, int16_t** buffer_f, uint8_t* cb_crc, uint8_t* cb_bytes, uint32_t* sum_passes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -182,6 +182,48 @@ uint32_t srslte_tdec_autoimp_get_subblocks_8bit(uint32_t long_cb);
 void srslte_tdec_iteration_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output);
 int  srslte_tdec_run_all_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb);
 
+/* ------------------------------------------------------------------ DL-SCH decoding of one transport block (phch/sch.h:52-110, sch.c:507-531)
+ * srslte_dlsch_decode2 is what srslte_pdsch_codeword_decode calls once per codeword (pdsch.c:786): here all code blocks of the transport block
+ * are rate de-matched, turbo-decoded and CRC-checked in ONE device call instead of one srslte_tdec_iteration round trip per block and pass.
+ * The structs are the reference's (callers allocate them with the reference's headers); this library reads max_iterations, llr_is_8bit and
+ * decoder of srslte_sch_t, grant.tb[] / grant.nof_tb / softbuffers.rx[] of srslte_pdsch_cfg_t, and the whole srslte_softbuffer_rx_t. */
+#define SRSLTE_MAX_CODEWORDS 2          /* phy_common.h:51 */
+#define SRSLTE_MAX_CODEBLOCKS 32        /* phy_common.h:54 */
+typedef enum { SRSLTE_TXSCHEME_PORT0, SRSLTE_TXSCHEME_DIVERSITY, SRSLTE_TXSCHEME_SPATIALMUX, SRSLTE_TXSCHEME_CDD } srslte_tx_scheme_t; /* phy_common.h:232-237 */
+typedef enum { SRSLTE_MIMO_DECODER_ZF, SRSLTE_MIMO_DECODER_MMSE } srslte_mimo_decoder_t;                                                   /* :239 */
+typedef struct { srslte_mod_t mod; int tbs; int rv; uint32_t nof_bits; uint32_t cw_idx; bool enabled; uint32_t mcs_idx; } srslte_ra_tb_t; /* ra.h:43-53 */
+typedef struct { /* pdsch_cfg.h:37-49 */
+  srslte_tx_scheme_t tx_scheme; uint32_t pmi; bool prb_idx[2][SRSLTE_MAX_PRB]; uint32_t nof_prb; uint32_t nof_re; uint32_t nof_symb_slot[2];
+  srslte_ra_tb_t tb[SRSLTE_MAX_CODEWORDS]; int last_tbs[SRSLTE_MAX_CODEWORDS]; uint32_t nof_tb; uint32_t nof_layers;
+} srslte_pdsch_grant_t;
+typedef struct { uint32_t max_cb; int16_t** buffer_f; uint8_t** data; bool* cb_crc; bool tb_crc; } srslte_softbuffer_rx_t; /* softbuffer.h:37-43 */
+typedef struct { uint32_t max_cb; uint8_t** buffer_b; } srslte_softbuffer_tx_t;                                              /* :45-48 */
+typedef struct { /* pdsch_cfg.h:51-73 */
+  srslte_pdsch_grant_t grant; uint16_t rnti; uint32_t max_nof_iterations; srslte_mimo_decoder_t decoder_type; float p_a; uint32_t p_b; float rs_power;
+  bool power_scale; bool csi_enable; bool use_tbs_index_alt;
+  union { srslte_softbuffer_tx_t* tx[SRSLTE_MAX_CODEWORDS]; srslte_softbuffer_rx_t* rx[SRSLTE_MAX_CODEWORDS]; } softbuffers;
+  bool meas_time_en; uint32_t meas_time_value;
+} srslte_pdsch_cfg_t;
+typedef enum { UCI_BIT_0 = 0, UCI_BIT_1 = 1, UCI_BIT_REPETITION = 2, UCI_BIT_PLACEHOLDER = 3 } srslte_uci_bit_type_t; /* uci_cfg.h:65-70 */
+typedef struct { uint32_t position; srslte_uci_bit_type_t type; } srslte_uci_bit_t;
+typedef struct { /* fec/viterbi.h:46-62 */
+  void* ptr; uint32_t R; uint32_t K; uint32_t framebits; bool tail_biting; float gain_quant; int16_t gain_quant_s;
+  int (*decode)(void*, uint8_t*, uint8_t*, uint32_t); int (*decode_s)(void*, uint16_t*, uint8_t*, uint32_t); int (*decode_f)(void*, float*, uint8_t*, uint32_t);
+  void (*free)(void*); uint8_t* tmp; uint16_t* tmp_s; uint8_t* symbols_uc; uint16_t* symbols_us;
+} srslte_viterbi_t;
+#define SRSLTE_UCI_MAX_CQI_LEN_PUSCH 512
+typedef struct { /* phch/uci.h:45-53 */
+  srslte_crc_t crc; srslte_viterbi_t viterbi; uint8_t tmp_cqi[SRSLTE_UCI_MAX_CQI_LEN_PUSCH]; uint8_t encoded_cqi[3 * SRSLTE_UCI_MAX_CQI_LEN_PUSCH];
+  int16_t encoded_cqi_s[3 * SRSLTE_UCI_MAX_CQI_LEN_PUSCH]; uint8_t* cqi_table[11]; int16_t* cqi_table_s[11];
+} srslte_uci_cqi_pusch_t;
+typedef struct { /* phch/sch.h:52-73 */
+  uint32_t max_iterations; float avg_iterations; bool llr_is_8bit;
+  uint8_t* cb_in; uint8_t* parity_bits; void* e; uint8_t* temp_g_bits; uint32_t* ul_interleaver; srslte_uci_bit_t ack_ri_bits[57600];
+  srslte_tcod_t encoder; srslte_tdec_t decoder; srslte_crc_t crc_tb; srslte_crc_t crc_cb; srslte_uci_cqi_pusch_t uci_cqi;
+} srslte_sch_t;
+int srslte_dlsch_decode(srslte_sch_t* q, srslte_pdsch_cfg_t* cfg, int16_t* e_bits, uint8_t* data);
+int srslte_dlsch_decode2(srslte_sch_t* q, srslte_pdsch_cfg_t* cfg, int16_t* e_bits, uint8_t* data, int codeword_idx, uint32_t nof_layers);
+
 /* ------------------------------------------------------------------ DL channel estimator (chest_dl.h:49-156, refsignal_dl.h:49-54, interp.h:63-112) */
 typedef struct { cf_t* diff_vec; uint32_t vector_len; uint32_t max_vector_len; } srslte_interp_linsrslte_vec_t;
 typedef struct { cf_t* diff_vec; cf_t* diff_vec2; float* ramp; uint32_t vector_len; uint32_t M; uint32_t max_vector_len; uint32_t max_M; } srslte_interp_lin_t;

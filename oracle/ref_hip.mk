@@ -42,9 +42,17 @@ $(HOUT)/dropin_log_test: dropin_log_test.c $(HOUT)/libsrslte_upper.a $(HIPLIB)/l
 	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) $< -o $@ $(HOUT)/libsrslte_upper.a -L$(HIPLIB) -lsrslte_phy_hip \
 	    -Wl,-rpath,'$$ORIGIN/../../../srslte-emane_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lstdc++ -lm -lpthread
 
+# SCH_ON_DEVICE=1 (default): srslte_dlsch_decode2 / srslte_dlsch_decode come from libsrslte_phy_hip.so too - every code block of a transport
+# block in one device call instead of one srslte_tdec_iteration round trip per block and pass. The reference's sch.c keeps everything else it
+# defines (encoders, UL-SCH, UCI); its own two functions are compiled under other names (a -D on that one file, nothing is edited or stubbed).
+SCH_ON_DEVICE ?= 1
+ifeq ($(SCH_ON_DEVICE),1)
+$(HOBJ)/phch/sch.o: EXTRA := -Dsrslte_dlsch_decode2=srslte_dlsch_decode2_on_host -Dsrslte_dlsch_decode=srslte_dlsch_decode_on_host
+endif
+
 $(HOBJ)/%.o: $(RLIB)/src/phy/%.c
 	@mkdir -p $(dir $@)
-	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) -c $< -o $@
+	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) $(EXTRA) -c $< -o $@
 
 $(HOBJ)/utils/random.o: $(RLIB)/src/phy/utils/random.cpp
 	@mkdir -p $(dir $@)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <vector>
 
 #define ERROR(fmt, ...) hip_log("[srslte_hip] " fmt "\n", ##__VA_ARGS__)
 
@@ -37,8 +38,83 @@ struct DevStage { // grow-only device staging buffer
   }
 };
 
-bool h2d(void* d, const void* h, size_t n) { return hipMemcpy(d, h, n, hipMemcpyHostToDevice) == hipSuccess; }
-bool d2h(void* h, const void* d, size_t n) { return hipMemcpy(h, d, n, hipMemcpyDeviceToHost) == hipSuccess; }
+// Host <-> device traffic of the single-call API. Every host thread owns a non-blocking stream and a pinned bounce arena: a call copies its
+// operands into the arena, queues the copies, the kernels and the copies back on that stream and waits once at the end. (hipMemcpy on the
+// callers' pageable buffers costs ~50 us per call and serialises every host thread on the null stream; the reference's worker threads -
+// three sf_workers in srsue - call these functions concurrently on distinct objects, SURVEY 8b "Threading".)
+struct HostLink {
+  hipStream_t st  = nullptr;
+  uint8_t*    pin = nullptr;
+  size_t      cap = 0, used = 0;
+  struct Back { void* host; const uint8_t* pinned; size_t n; };
+  std::vector<Back> back; // device -> host copies queued on the stream: their host-side half happens in flush()
+  bool ok = true;
+  hipStream_t stream()
+  {
+    if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    return st;
+  }
+  uint8_t* take(size_t n)
+  { // n bytes of the arena; growing it waits for what is queued (the old arena is still being read / written)
+    n = (n + 255) & ~(size_t)255;
+    if (used + n > cap) {
+      if (!flush()) return nullptr;
+      const size_t want = (cap * 2 > n ? cap * 2 : n) + (1u << 20);
+      if (pin) (void)hipHostFree(pin);
+      pin = nullptr;
+      cap = 0;
+      if (hipHostMalloc((void**)&pin, want) != hipSuccess) {
+        ERROR("hipHostMalloc(%zu) failed", want);
+        return nullptr;
+      }
+      cap = want;
+    }
+    uint8_t* p = pin + used;
+    used += n;
+    return p;
+  }
+  bool flush()
+  { // wait for the stream, hand the results to the caller's buffers, empty the arena
+    bool r = ok && (!st || hipStreamSynchronize(st) == hipSuccess);
+    for (const Back& b : back) {
+      if (r) memcpy(b.host, b.pinned, b.n);
+    }
+    back.clear();
+    used = 0;
+    ok   = true;
+    return r;
+  }
+  ~HostLink()
+  {
+    if (st) (void)hipStreamDestroy(st);
+    if (pin) (void)hipHostFree(pin);
+  }
+};
+thread_local HostLink g_link;
+void* tl_stream() { return g_link.stream(); }
+
+bool h2d(void* d, const void* h, size_t n)
+{
+  if (n == 0) return true;
+  uint8_t* p = g_link.take(n);
+  if (!p || !g_link.stream()) return false;
+  memcpy(p, h, n);
+  const bool r = hipMemcpyAsync(d, p, n, hipMemcpyHostToDevice, g_link.st) == hipSuccess;
+  g_link.ok    = g_link.ok && r;
+  return r;
+}
+// queues the copy back; the data is in `h` after the next flush (d2h() below does both)
+bool d2h_later(void* h, const void* d, size_t n)
+{
+  if (n == 0) return true;
+  uint8_t* p = g_link.take(n);
+  if (!p || !g_link.stream()) return false;
+  const bool r = hipMemcpyAsync(p, d, n, hipMemcpyDeviceToHost, g_link.st) == hipSuccess;
+  g_link.ok    = g_link.ok && r;
+  if (r) g_link.back.push_back({h, p, n});
+  return r;
+}
+bool d2h(void* h, const void* d, size_t n) { return d2h_later(h, d, n) && g_link.flush(); }
 
 void* host_alloc(size_t n)
 { // srslte_vec_malloc: posix_memalign to the SIMD width (vector.c:118-125)
@@ -66,6 +142,12 @@ struct OfdmState {
 struct TdecState {
   srslte_hip_tdec_t* h = nullptr;
   DevStage           in, out;
+  // srslte_dlsch_decode2 on the srslte_sch_t this decoder is embedded in: the transport-block decoder, made on first use and again when a
+  // larger block or the other LLR width comes
+  srslte_hip_sch_t*  sch = nullptr;
+  uint32_t           sch_tbs = 0, sch_e = 0;
+  bool               sch_l8  = false;
+  std::vector<uint8_t> cb_bytes, cb_crc;
 };
 
 struct ChestState {
@@ -235,7 +317,7 @@ static void dft_exec(srslte_dft_plan_t* plan, const cf_t* in, cf_t* out, int how
   const size_t nin = sizeof(cf_t) * ((size_t)(howmany - 1) * idist + plan->size), nout = sizeof(cf_t) * ((size_t)(howmany - 1) * odist + plan->size);
   void *       di = st->in.get(nin), *dout = st->out.get(nout);
   if (!di || !dout || !h2d(di, in, nin)) return;
-  if (srslte_hip_dft_batch(di, dout, plan->size, howmany, idist, odist, plan->forward ? 1 : 0, 1.0f, nullptr)) return;
+  if (srslte_hip_dft_batch(di, dout, plan->size, howmany, idist, odist, plan->forward ? 1 : 0, 1.0f, tl_stream())) return;
   if (howmany > 1 && odist != plan->size) {
     for (int i = 0; i < howmany; i++) d2h(out + (size_t)i * odist, (char*)dout + sizeof(cf_t) * (size_t)i * odist, sizeof(cf_t) * plan->size);
   } else {
@@ -474,9 +556,9 @@ static void ofdm_run(srslte_ofdm_t* q, const cf_t* host_in, cf_t* host_out, int 
   if (!di || !dout || !h2d(di + dev_slot * in_slot, host_in, nslots * in_slot)) return;
   int r;
   if (slots == 2) {
-    r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, nullptr) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, nullptr);
+    r = st->is_rx ? srslte_hip_ofdm_rx_sf_batch(st->h, di, dout, 1, tl_stream()) : srslte_hip_ofdm_tx_sf_batch(st->h, di, dout, 1, tl_stream());
   } else {
-    r = srslte_hip_ofdm_slot_batch(st->h, di, dout, 1, dev_slot, mbsfn_layout, nullptr);
+    r = srslte_hip_ofdm_slot_batch(st->h, di, dout, 1, dev_slot, mbsfn_layout, tl_stream());
   }
   if (r) return;
   if (!st->is_rx && mbsfn_layout && dev_slot == 0) { // leave the caller's guard samples untouched, as upstream
@@ -565,7 +647,7 @@ int srslte_dft_precoding(srslte_dft_precoding_t* q, cf_t* input, cf_t* output, u
   const size_t       n    = sizeof(cf_t) * (size_t)N * nof_symbols;
   void *             di = st->in.get(n), *dout = st->out.get(n);
   if (!di || !dout || !h2d(di, input, n)) return SRSLTE_ERROR;
-  if (srslte_hip_dft_precoding_batch(di, dout, nof_prb, nof_symbols, plan->forward ? 1 : 0, nullptr)) return SRSLTE_ERROR;
+  if (srslte_hip_dft_precoding_batch(di, dout, nof_prb, nof_symbols, plan->forward ? 1 : 0, tl_stream())) return SRSLTE_ERROR;
   return d2h(output, dout, n) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 
@@ -611,7 +693,7 @@ int srslte_tcod_encode(srslte_tcod_t* h, uint8_t* input, uint8_t* output, uint32
   }
   void *di = g_tcod_in.get(long_cb), *dout = g_tcod_out.get(3 * long_cb + 12);
   if (!di || !dout || !h2d(di, input, long_cb)) return SRSLTE_ERROR;
-  if (srslte_hip_tcod_encode_batch((const uint8_t*)di, (uint8_t*)dout, long_cb, 1, nullptr)) return SRSLTE_ERROR;
+  if (srslte_hip_tcod_encode_batch((const uint8_t*)di, (uint8_t*)dout, long_cb, 1, tl_stream())) return SRSLTE_ERROR;
   return d2h(output, dout, 3 * long_cb + 12) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 
@@ -659,7 +741,7 @@ int srslte_tcod_encode_lut(srslte_tcod_t* h, srslte_crc_t* crc_tb, srslte_crc_t*
   const uint32_t npar = long_cb / 4 + 1;
   uint8_t *      di = (uint8_t*)g_tcod_in.get(nbytes), *dout = (uint8_t*)g_tcod_out.get(npar + 1);
   if (!di || !dout || !h2d(di, input, nbytes)) return SRSLTE_ERROR;
-  if (srslte_hip_tcod_encode_bytes_batch(di, nbytes, dout, npar, dout + npar, long_cb, 1, nullptr)) return SRSLTE_ERROR;
+  if (srslte_hip_tcod_encode_bytes_batch(di, nbytes, dout, npar, dout + npar, long_cb, 1, tl_stream())) return SRSLTE_ERROR;
   if (!d2h(parity, dout, npar) || !d2h(&input[nbytes], dout + npar, 1)) return SRSLTE_ERROR;
   return (int)(3 * long_cb + 12);
 }
@@ -701,6 +783,7 @@ void srslte_tdec_free(srslte_tdec_t* h)
   auto* st = (TdecState*)h->dec16_hdlr[0];
   if (st) {
     srslte_hip_tdec_destroy(st->h);
+    srslte_hip_sch_destroy(st->sch);
     st->in.release();
     st->out.release();
     delete st;
@@ -752,7 +835,10 @@ static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* 
   const size_t   esz = dec8 ? 1 : 2;
   void *         di = st->in.get(len * esz), *dout = st->out.get(K / 8);
   if (!di || !dout) return SRSLTE_ERROR;
-  if (dec8 == api8) {
+  if (start > 0) {
+    // later passes of the same block: upstream reads the input on pass 0 only (extract_input, turbodecoder_iter.h:84-99); the device copy
+    // of this object is still there
+  } else if (dec8 == api8) {
     if (!h2d(di, input, len * esz)) return SRSLTE_ERROR;
   } else if (dec8) { // 16-bit API on a manual 8-bit back-end
     std::vector<int8_t> c(len);
@@ -764,14 +850,14 @@ static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* 
     if (!h2d(di, c.data(), len * 2)) return SRSLTE_ERROR;
   }
   tdec_set_resume(st->h, start);
-  if (tdec_run_batch_w(st->h, di, dec8 ? 1 : 0, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, nullptr))
+  if (tdec_run_batch_w(st->h, di, dec8 ? 1 : 0, len, sb, K, W, 1, passes, 0, 0, (uint8_t*)dout, K / 8, nullptr, nullptr, (hipStream_t)tl_stream()))
     return SRSLTE_ERROR;
   return d2h(output, dout, K / 8) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 
 static void tdec_one_more(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output)
 { // turbodecoder.c:539-545,:565-571. One more SISO pass: the decoder's work arrays for this object's block slot stay on the device
-  // between calls, so pass n_iter continues from them (the input is uploaded again: upstream reads it on every pass too).
+  // between calls, so pass n_iter continues from them; the input went up with pass 0.
   if (h->current_cbidx >= 0) {
     if (tdec_passes(h, input, api8, output, (uint32_t)h->n_iter + 1, (uint32_t)h->n_iter) == SRSLTE_SUCCESS) h->n_iter++;
   } else {
@@ -780,6 +866,84 @@ static void tdec_one_more(srslte_tdec_t* h, const void* input, bool api8, uint8_
 }
 void srslte_tdec_iteration(srslte_tdec_t* h, int16_t* input, uint8_t* output) { tdec_one_more(h, input, false, output); }
 void srslte_tdec_iteration_8bit(srslte_tdec_t* h, int8_t* input, uint8_t* output) { tdec_one_more(h, input, true, output); }
+
+// ---- srslte_dlsch_decode2 (sch.c:507-531) = decode_tb (sch.c:429-500) with all code blocks in one device call (srslte_hip_sch_decode)
+int srslte_dlsch_decode2(srslte_sch_t* q, srslte_pdsch_cfg_t* cfg, int16_t* e_bits, uint8_t* data, int tb_idx, uint32_t nof_layers)
+{
+  if (!q || !cfg || tb_idx < 0 || tb_idx >= SRSLTE_MAX_CODEWORDS) return SRSLTE_ERROR_INVALID_INPUTS;
+  const uint32_t   Nl = nof_layers != cfg->grant.nof_tb ? 2 : 1; // :510-514
+  srslte_cbsegm_t  seg;
+  const srslte_ra_tb_t& tb = cfg->grant.tb[tb_idx];
+  if (srslte_cbsegm(&seg, (uint32_t)tb.tbs)) {
+    ERROR("Error computing Codeword (%d) segmentation for TBS=%d", tb_idx, tb.tbs);
+    return SRSLTE_ERROR;
+  }
+  srslte_softbuffer_rx_t* sb = cfg->softbuffers.rx[tb_idx];
+  if (!data || !sb || !e_bits) { // decode_tb :437-441,:491-498
+    ERROR("Missing inputs: data=%d, softbuffer=%d, e_bits=%d", data != 0, sb != 0, e_bits != 0);
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  if (seg.tbs == 0 || seg.C == 0) return SRSLTE_SUCCESS; // :444-446
+  if (seg.F) {
+    fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // :448-451
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  if (seg.C > sb->max_cb) {
+    fprintf(stderr, "Error number of CB to decode (%d) exceeds soft buffer size (%d CBs)\n", seg.C, sb->max_cb); // :453-457
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  auto* st = (TdecState*)q->decoder.dec16_hdlr[0];
+  if (!st || tb.mod < SRSLTE_MOD_QPSK || tb.mod > SRSLTE_MOD_256QAM || tb.nof_bits == 0) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (!st->sch || (uint32_t)tb.tbs > st->sch_tbs || tb.nof_bits > st->sch_e || st->sch_l8 != q->llr_is_8bit) {
+    srslte_hip_sch_destroy(st->sch);
+    st->sch_tbs = (uint32_t)tb.tbs > st->sch_tbs ? (uint32_t)tb.tbs : st->sch_tbs;
+    st->sch_e   = tb.nof_bits > st->sch_e ? tb.nof_bits : st->sch_e;
+    st->sch_l8  = q->llr_is_8bit;
+    st->sch     = srslte_hip_sch_create(st->sch_tbs, st->sch_e, st->sch_l8 ? 1 : 0);
+    if (!st->sch) {
+      st->sch_tbs = st->sch_e = 0;
+      return SRSLTE_ERROR;
+    }
+  }
+  const uint32_t C = seg.C, tbs8 = seg.tbs / 8;
+  data[tbs8 + 0] = data[tbs8 + 1] = data[tbs8 + 2] = 0; // :461-463
+  st->cb_bytes.resize((size_t)C * 768);
+  st->cb_crc.resize(C);
+  for (uint32_t i = 0; i < C; i++) st->cb_crc[i] = sb->cb_crc[i] ? 1 : 0;
+  uint32_t passes = 0;
+  const int r = srslte_hip_sch_decode(st->sch, e_bits, tb.nof_bits, (uint32_t)tb.tbs, (int)tb.mod, Nl, (uint32_t)tb.rv, q->max_iterations, sb->buffer_f,
+                                      st->cb_crc.data(), st->cb_bytes.data(), &passes);
+  if (r) return r == SRSLTE_ERROR_INVALID_INPUTS ? SRSLTE_ERROR_INVALID_INPUTS : SRSLTE_ERROR;
+  // decode_tb_cb :312-412: bytes of every block in order (a decoded block's K / 8 bytes start where its rlen / 8 payload bytes go; the next
+  // block overwrites its 24 CRC bits), blocks decoded in an earlier transmission from the soft buffer's copy
+  for (uint32_t i = 0; i < C; i++) {
+    const uint32_t K = i < seg.C1 ? seg.K1 : seg.K2, rlen = C == 1 ? K : K - 24;
+    if (sb->cb_crc[i]) {
+      memcpy(&data[(size_t)i * rlen / 8], sb->data[i], rlen / 8);
+    } else {
+      memcpy(&data[(size_t)i * rlen / 8], &st->cb_bytes[(size_t)i * 768], K / 8);
+      sb->cb_crc[i] = st->cb_crc[i] != 0;
+    }
+  }
+  q->avg_iterations = (float)passes / (float)C; // :313,:361,:412
+  sb->tb_crc = true;
+  for (uint32_t i = 0; i < C && sb->tb_crc; i++) sb->tb_crc = sb->cb_crc[i];
+  if (!sb->tb_crc) { // save the blocks that passed for the next transmission (:400-410)
+    for (uint32_t i = 0; i < C; i++) {
+      const uint32_t K = i < seg.C1 ? seg.K1 : seg.K2, rlen = C == 1 ? K : K - 24;
+      if (sb->cb_crc[i]) memcpy(sb->data[i], &data[(size_t)i * rlen / 8], rlen / 8);
+    }
+    return SRSLTE_ERROR;
+  }
+  // transport block CRC24A over the payload against the three bytes behind it (:470-488), with the table of q->crc_tb (crc.c:139-153)
+  srslte_crc_t* c = &q->crc_tb;
+  c->crcinit      = 0;
+  for (uint32_t i = 0; i < tbs8; i++) crc_put_byte(c, data[i]);
+  const uint32_t par_rx = (uint32_t)(c->crcinit & c->crcmask);
+  const uint32_t par_tx = ((uint32_t)data[tbs8] << 16) | ((uint32_t)data[tbs8 + 1] << 8) | (uint32_t)data[tbs8 + 2];
+  return (par_rx == par_tx && par_rx) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
+}
+int srslte_dlsch_decode(srslte_sch_t* q, srslte_pdsch_cfg_t* cfg, int16_t* e_bits, uint8_t* data) { return srslte_dlsch_decode2(q, cfg, e_bits, data, 0, 1); }
 
 static int tdec_all(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t nof_iterations, uint32_t long_cb)
 { // turbodecoder.c:547-562,:573-588
@@ -919,7 +1083,7 @@ static int chest_dl_estimate_mbsfn(srslte_chest_dl_t* q, ChestState* st, srslte_
   memset(&hc, 0, sizeof(hc));
   hc.noise_alg = cfg->noise_alg; hc.filter_type = cfg->filter_type; hc.filter_coef[0] = cfg->filter_coef[0]; hc.filter_coef[1] = cfg->filter_coef[1];
   hc.interpolate_subframe = cfg->interpolate_subframe; hc.mbsfn_area_id = cfg->mbsfn_area_id;
-  if (srslte_hip_chest_dl_estimate_mbsfn_batch(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dnoise, 1, (int)nrx, nullptr)) return SRSLTE_ERROR;
+  if (srslte_hip_chest_dl_estimate_mbsfn_batch(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dnoise, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   if (cfg->noise_alg == SRSLTE_NOISE_ALG_REFS) {
     float nz[16];
     if (!d2h(nz, dnoise, sizeof(float) * nrx * npt)) return SRSLTE_ERROR;
@@ -997,22 +1161,22 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
     }
     if (chest_dl_set_noise_state(st->h, state)) return SRSLTE_ERROR;
   }
-  if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, nullptr)) return SRSLTE_ERROR;
+  if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
-  if (!d2h(&r, dres, sizeof(r))) return SRSLTE_ERROR;
+  float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}
+  if (!d2h_later(&r, dres, sizeof(r))) return SRSLTE_ERROR;
   for (uint32_t pt = 0; pt < npt; pt++) {
     for (uint32_t a = 0; a < nrx; a++) {
-      if (res->ce[pt][a] && !d2h(res->ce[pt][a], dce + (pt * nrx + a) * n, n)) return SRSLTE_ERROR;
+      if (res->ce[pt][a] && !d2h_later(res->ce[pt][a], dce + (pt * nrx + a) * n, n)) return SRSLTE_ERROR;
     }
   }
+  if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 6 * nrx * npt)) return SRSLTE_ERROR; // one wait for everything queued
   // fill_res, chest_dl.c:845-871
   if (hc.cfo_estimate_enable) q->cfo = r.cfo;
   q->sync_err[0][0]   = r.sync_error;
   res->noise_estimate = r.noise_estimate; res->noise_estimate_dbm = r.noise_estimate_dbm; res->snr_db = r.snr_db;
   res->rsrp = r.rsrp; res->rsrp_dbm = r.rsrp_dbm; res->rsrq = r.rsrq; res->rsrq_db = r.rsrq_db; res->rssi_dbm = r.rssi_dbm;
   res->cfo = q->cfo; res->sync_error = r.sync_error;
-  float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}
-  if (!d2h(raw, srslte_hip_chest_dl_last_raw(st->h), sizeof(float) * 6 * nrx * npt)) return SRSLTE_ERROR;
   if (hc.rsrp_neighbour) {
     for (uint32_t pt = 0; pt < npt; pt++) {
       for (uint32_t a = 0; a < nrx; a++) q->rsrp_corr[a][pt] = raw[pt * nrx + a][5];
@@ -1072,7 +1236,7 @@ static int demod_host(int type, srslte_mod_t mod, const cf_t* symbols, void* llr
   const size_t nin = sizeof(cf_t) * nsymbols, nout = llr_elem * Qm * nsymbols;
   void *       di = g_demod_in.get(nin), *dout = g_demod_out.get(nout);
   if (!di || !dout || !h2d(di, symbols, nin)) return SRSLTE_ERROR;
-  if (demod_launch(type, (int)mod, di, dout, nsymbols, 1, nullptr, 0, 0, nullptr)) return SRSLTE_ERROR;
+  if (demod_launch(type, (int)mod, di, dout, nsymbols, 1, nullptr, 0, 0, (hipStream_t)tl_stream())) return SRSLTE_ERROR;
   return d2h(llr, dout, nout) ? SRSLTE_SUCCESS : SRSLTE_ERROR;
 }
 int srslte_demod_soft_demodulate(srslte_mod_t m, const cf_t* s, float* llr, int n) { return demod_host(0, m, s, llr, n, sizeof(float)); }

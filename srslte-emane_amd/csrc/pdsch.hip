@@ -30,6 +30,7 @@
 #include "pdsch_kernels.inc"
 #include "pdsch_rx.inc"
 #include "pdsch_rx_grants.inc"
+#include "sch_host.inc"
 #include "pusch_rx.inc"
 #include "pusch_tx.inc"
 #include "pdsch_tx.inc"

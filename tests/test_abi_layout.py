@@ -34,6 +34,17 @@ STRUCTS = {
                           "tmp_noise", "tmp_cfo_estimate", "srslte_interp_linvec", "srslte_interp_lin", "srslte_interp_lin_3",
                           "srslte_interp_lin_mbsfn", "rssi", "rsrp", "rsrp_corr", "noise_estimate", "sync_err", "cfo", "pss_signal", "tmp_pss",
                           "tmp_pss_noisy"],
+    "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled", "mcs_idx"],
+    "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "last_tbs", "nof_tb", "nof_layers"],
+    "srslte_softbuffer_rx_t": ["max_cb", "buffer_f", "data", "cb_crc", "tb_crc"],
+    "srslte_pdsch_cfg_t": ["grant", "rnti", "max_nof_iterations", "decoder_type", "p_a", "p_b", "rs_power", "power_scale", "csi_enable",
+                           "use_tbs_index_alt", "softbuffers", "meas_time_en", "meas_time_value"],
+    "srslte_uci_bit_t": ["position", "type"],
+    "srslte_viterbi_t": ["ptr", "R", "K", "framebits", "tail_biting", "gain_quant", "gain_quant_s", "decode", "decode_s", "decode_f", "free", "tmp",
+                         "tmp_s", "symbols_uc", "symbols_us"],
+    "srslte_uci_cqi_pusch_t": ["crc", "viterbi", "tmp_cqi", "encoded_cqi", "encoded_cqi_s", "cqi_table", "cqi_table_s"],
+    "srslte_sch_t": ["max_iterations", "avg_iterations", "llr_is_8bit", "cb_in", "parity_bits", "e", "temp_g_bits", "ul_interleaver", "ack_ri_bits",
+                     "encoder", "decoder", "crc_tb", "crc_cb", "uci_cqi"],
     "srslte_chest_dl_cfg_t": ["noise_alg", "filter_type", "filter_coef", "mbsfn_area_id", "interpolate_subframe", "rsrp_neighbour",
                               "cfo_estimate_enable", "cfo_estimate_sf_mask", "sync_error_enable"],
 }
@@ -52,7 +63,8 @@ def layout(includes, incdirs):
 
 def test_struct_layouts_match_reference():
     ref = layout(["srslte/phy/dft/ofdm.h", "srslte/phy/dft/dft_precoding.h", "srslte/phy/fec/cbsegm.h", "srslte/phy/fec/tc_interl.h",
-                  "srslte/phy/fec/turbocoder.h", "srslte/phy/fec/turbodecoder.h", "srslte/phy/ch_estimation/chest_dl.h"], [REF_INC])
+                  "srslte/phy/fec/turbocoder.h", "srslte/phy/fec/turbodecoder.h", "srslte/phy/ch_estimation/chest_dl.h", "srslte/phy/phch/sch.h"],
+                 [REF_INC])
     ours = layout(["srslte_hip/srslte_compat.h"], [os.path.join(ROOT, "include")])
     diff = {k: (ref[k], ours.get(k)) for k in ref if ref[k] != ours.get(k)}
     assert not diff, "layout differences (reference, ours): %s" % diff

@@ -656,3 +656,47 @@ def test_concurrent_host_threads():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_four_host_threads_overlap():
+    """SURVEY 8b 'Threading': the reference's worker threads (three sf_workers in srsue) call the single-call API concurrently on distinct
+    objects. Every host thread has its own non-blocking stream and pinned arena in the library: four threads, each decoding its own code
+    blocks through srslte_tdec_run_all, must give the single-thread results and finish well before four times the single-thread time
+    (on the null stream they serialised)."""
+    import threading
+    import time
+    L, K, reps = hip(), 5824, 24
+    rng = np.random.default_rng(5)
+    jobs = []
+    for t in range(4):
+        tdec = opaque(1 << 16)
+        assert L.srslte_tdec_init(tdec, 6144) == 0
+        bits = rng.integers(0, 2, K).astype(np.uint8)
+        enc = np.zeros(3 * K + 12, np.uint8)
+        oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+        llr = (100 * ((2.0 * enc - 1) + 0.8 * rng.standard_normal(enc.shape))).astype(np.int16)
+        L.srslte_tdec_force_not_sb(tdec)
+        ref = np.zeros(K // 8, np.uint8)
+        oracle().orc_tdec_run(p(llr), False, K, 4, p(ref), None)
+        jobs.append((tdec, llr, ref, np.zeros(K // 8, np.uint8)))
+
+    def work(j):
+        tdec, llr, ref, out = j
+        for _ in range(reps):
+            assert L.srslte_tdec_run_all(tdec, p(llr), p(out), 4, K) == 0
+
+    work(jobs[0])  # warm up (tables, first-touch)
+    t0 = time.perf_counter()
+    work(jobs[0])
+    t_one = time.perf_counter() - t0
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    t0 = time.perf_counter()
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    t_four = time.perf_counter() - t0
+    for tdec, llr, ref, out in jobs:
+        assert np.array_equal(out, ref)
+        L.srslte_tdec_free(tdec)
+    assert t_four < 2.5 * t_one, "four threads took %.1f x one thread: the calls do not overlap" % (t_four / t_one)
