@@ -136,7 +136,8 @@ static float noise_pilots(cf* est, uint32_t nref, uint32_t nsym, uint32_t fidx0,
    (antenna, port). Ports 0/1 have 4 pilot symbols per subframe, ports 2/3 two (symbols 1 and 8). est is the estimator's
    q->pilot_estimates, [4][2 nof_prb], SHARED by the ports of an antenna as upstream: chest_estimate_cfo (:573-596) always pairs its
    first and second half, so for ports 2/3 it multiplies their two symbols with what port 1 left in the second half.
-   interpolate_subframe with ports 2/3 is refused: upstream then copies the never-written symbol 0 of ce over the subframe (:467-471). */
+   interpolate_subframe with ports 2/3: their nsymbols is 2 < 3, so upstream takes the copy branch (:467-471) and replicates symbol 0 of ce
+   over the subframe - a symbol this call did not write (the two interpolated rows, symbols 1 and 8, are overwritten): ce is in / out. */
 void orc_pss_generate(uint32_t N_id_2, orc_cf_t* signal /* [62] */)
 { /* srslte_pss_generate (pss.c:348-376): Zadoff-Chu roots 25, 29, 34 with the DC element left out */
   const float root_value[] = {25.0, 29.0, 34.0};
@@ -154,7 +155,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
   const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = port < 2 ? 4 : 2, nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
   if (port > 3) return -1;
-  if (port > 1 && ce && cfg->interpolate_subframe) return -3;
+  const bool stale = port > 1 && ce && cfg->interpolate_subframe;
   cf* known = malloc(sizeof(cf) * 4 * nref);
   cf* recv  = malloc(sizeof(cf) * 4 * nref);
   cf* avg   = malloc(sizeof(cf) * 4 * nref);
@@ -242,7 +243,9 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
       pil = avg;
     }
     /* interpolate_pilots, chest_dl.c:415-511 */
-    if (!cfg->interpolate_subframe) {
+    if (stale) {
+      for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);
+    } else if (!cfg->interpolate_subframe) {
       uint32_t off = cell->id % 3;
       interp_linear_offset(pil, ce, 4 * P, 3, off, 3 - off);
       for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);

@@ -286,8 +286,9 @@ class ChestDl:
         sync()
         return rc, dce.to_host(np.complex64).reshape(n, self.nof_ports, nof_rx, self.grid_len), dn.to_host(np.float32).reshape(n, self.nof_ports, nof_rx)
 
-    def estimate_multi(self, grid, tti0, cfg, nof_rx=1):
-        """grid [nof_sf][nof_rx][14*12*prb] -> (rc, ce [nof_sf][nof_ports][nof_rx][...], res dict, raw [nof_sf][nof_ports][nof_rx][6])."""
+    def estimate_multi(self, grid, tti0, cfg, nof_rx=1, ce_in=None):
+        """grid [nof_sf][nof_rx][14*12*prb] -> (rc, ce [nof_sf][nof_ports][nof_rx][...], res dict, raw [nof_sf][nof_ports][nof_rx][6]).
+        ce_in: what the estimate buffer holds before the call (4-port cells with interpolate_subframe keep symbol 0 of ports 2/3)."""
         L = lib()
         L.srslte_hip_chest_dl_estimate_batch_multi.argtypes = [C.c_void_p, C.POINTER(ChestDlCfg), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
                                                                C.c_int, C.c_int, C.c_void_p]
@@ -295,7 +296,8 @@ class ChestDl:
         L.srslte_hip_chest_dl_last_raw.argtypes = [C.c_void_p]
         g = np.ascontiguousarray(grid, np.complex64).reshape(-1, nof_rx, self.grid_len)
         n = g.shape[0]
-        dg, dce, dres = DevBuf.from_host(g), DevBuf(g.nbytes * self.nof_ports), DevBuf(n * 40)
+        dg, dres = DevBuf.from_host(g), DevBuf(n * 40)
+        dce = DevBuf(g.nbytes * self.nof_ports) if ce_in is None else DevBuf.from_host(np.ascontiguousarray(ce_in, np.complex64))
         rc = L.srslte_hip_chest_dl_estimate_batch_multi(self.h, C.byref(cfg), tti0, dg.ptr, dce.ptr, dres.ptr, n, nof_rx, None)
         if rc != SRSLTE_SUCCESS:
             return rc, None, None, None

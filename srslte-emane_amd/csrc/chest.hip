@@ -259,7 +259,14 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     }
 
     cf32* o = ce + (size_t)sf * 2 * p.nsl * nre;
-    if (!p.interpolate_subframe) { // chest_dl.c:448-471
+    if (p.interpolate_subframe && port >= 2) {
+      // ports 2/3 have two pilot symbols: upstream takes the copy branch (nsymbols < 3, chest_dl.c:467-471) and replicates symbol 0 of ce -
+      // which this call does not write for them - over the subframe. ce is in / out here exactly as there.
+      for (int k = tid; k < nre; k += CH_THREADS) {
+        const cf32 v = o[k];
+        for (int l = 1; l < 2 * p.nsl; l++) o[l * nre + k] = v;
+      }
+    } else if (!p.interpolate_subframe) { // chest_dl.c:448-471
       const int off = p.cell_id % 3;
       for (int k = tid; k < nre; k += CH_THREADS) {
         const cf32 v = interp_offset_at(pil, 4 * P, 3, off, k);
@@ -665,11 +672,6 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
     return SRSLTE_ERROR;
   }
   if (cfg->filter_type == 0 && cfg->filter_coef[0] > 62) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->nof_ports == 4 && cfg->interpolate_subframe && d_ce) {
-    // upstream then copies symbol 0 of the ports-2/3 estimates, which nothing wrote, over the subframe (chest_dl.c:467-471): no defined result
-    hip_log("[srslte_hip] chest_dl: interpolate_subframe is not defined for the ports 2/3 of a 4-port cell\n");
-    return SRSLTE_ERROR;
-  }
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   ChestParams p;
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;

@@ -1161,6 +1161,15 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
     }
     if (chest_dl_set_noise_state(st->h, state)) return SRSLTE_ERROR;
   }
+  if (want_ce && npt == 4 && hc.interpolate_subframe) {
+    // ports 2/3: upstream replicates symbol 0 of the caller's estimates over the subframe (chest_dl.c:467-471, see chest_dl_kernel): that
+    // symbol goes up so that the device has it
+    for (uint32_t pt = 2; pt < npt; pt++) {
+      for (uint32_t a = 0; a < nrx; a++) {
+        if (res->ce[pt][a] && !h2d(dce + (pt * nrx + a) * n, res->ce[pt][a], sizeof(cf_t) * 12 * q->cell.nof_prb)) return SRSLTE_ERROR;
+      }
+    }
+  }
   if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
   float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}

@@ -241,17 +241,18 @@ def oracle_rx_mimo(cfg, iq, tti, keep=False, grid_in=None, rv=(0, 0)):
     out = {"tb": [], "ok": [], "iters": [], "cb_ok": [], "e": [], "e_raw": []}
     for cw in range(cfg.nof_tb):
         mod, Qm, tbs, seg = cfg.mods[cw], MOD_BITS[cfg.mods[cw]], cfg.tbss[cw], cfg.segs[cw]
-        e = np.zeros(nre * Qm, np.int16)
-        orc.orc_demod_soft_s(mod, p(x[cw]), p(e), nre)
+        llr8 = getattr(cfg, "llr8", False)  # pdsch.c:760-779 takes q->llr_is_8bit with any scheme
+        e = np.zeros(nre * Qm, np.int8 if llr8 else np.int16)
+        (orc.orc_demod_soft_b if llr8 else orc.orc_demod_soft_s)(mod, p(x[cw]), p(e), nre)
         c = np.zeros(nre * Qm, np.uint8)
         orc.orc_gold(C.c_uint32(orc.orc_pdsch_cinit(cfg.rnti, cw, sf_idx, cfg.cell_id)), nre * Qm, p(c))
-        orc.orc_scramble_s(p(e), p(c), nre * Qm)
+        (orc.orc_scramble_b if llr8 else orc.orc_scramble_s)(p(e), p(c), nre * Qm)
         out["e_raw"].append(e.copy())
         if cfg.csi:
-            orc.orc_csi_correction_s(p(e), p(csi[cw]), nre, mod)
+            (orc.orc_csi_correction_b if llr8 else orc.orc_csi_correction_s)(p(e), p(csi[cw]), nre, mod)
         sch = OrcSchCfg(tbs, nre * Qm, Qm, rv[cw], cfg.max_iter)
         tb, iters, cbok = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(seg.C, np.uint32), np.zeros(seg.C, np.uint8)
-        rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+        rc = (orc.orc_dlsch_decode_8bit if llr8 else orc.orc_dlsch_decode)(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
         out["tb"].append(tb[:tbs // 8 + 3])
         out["ok"].append(rc == 0)
         out["iters"].append(iters)

@@ -77,6 +77,42 @@ def test_dl_rx_two_layer_modes(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, 
     rx.free()
 
 
+@pytest.mark.parametrize("prb,cid,mod,tbs,mod2,tbs2,scheme,pmi,cfi,tti0,nsf,snr", [CASES[0], CASES[3], CASES[6], CASES[8], CASES[10]])
+@pytest.mark.parametrize("csi", [False, True])
+def test_dl_rx_two_layer_modes_8bit(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti0, nsf, snr, csi):
+    """The two-layer modes with 8-bit LLRs (pdsch.c:760-779 takes q->llr_is_8bit with any scheme: srslte_demod_soft_demodulate_b,
+    srslte_scrambling_sb_offset, csi_correction's 8-bit twin, srslte_rm_turbo_rx_lut_8bit, the 8-bit decoder back-ends): LLRs of both
+    codewords, pass counts, CRC verdicts and bytes vs the oracle chain on identical IQ."""
+    from lte_sim import DlConfig, make_subframe_mimo, oracle_rx_mimo
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, csi=csi, tx_scheme=scheme, pmi=pmi, mod2=mod2 or None, tbs2=tbs2, llr8=True)
+    rng = np.random.default_rng(5000 + prb + cid + tti0 + pmi)
+    iq, data = zip(*[make_subframe_mimo(cfg, tti0 + b, rng, snr_db=snr + 3.0, amp=0.2) for b in range(nsf)])
+    rx = hp.DlRx(cid, prb, cfi, 0x1234, mod, tbs, 6, nsf, True, _chest(hp), llr_8bit=True, nof_rx=2, nof_ports=2, csi=csi, tx_scheme=SCHEME[scheme], pmi=pmi,
+                 mod2=mod2, tbs2=tbs2)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    if not tbs2:
+        tb, ok = [tb], [ok]
+    max_re = max(rx.nof_re(s) for s in (0, 1, 5))
+    n_ok = 0
+    for cw in range(cfg.nof_tb):
+        off, C_, Qm = 100 * cw, cfg.segs[cw].C, Q[cfg.mods[cw]]
+        e_stride = (max_re * Qm + 15) & ~15
+        it = rx.debug(off + 6, np.uint32, nsf * C_).reshape(nsf, C_)
+        e_all = rx.debug(off + 4, np.int8, nsf * e_stride).reshape(nsf, -1)
+        for b in range(nsf):
+            r = oracle_rx_mimo(cfg, iq[b], tti0 + b, keep=True)
+            nre = rx.nof_re((tti0 + b) % 10)
+            diff = np.abs(e_all[b, :nre * Qm].astype(np.int32) - r["e_raw"][cw].astype(np.int32))
+            assert diff.max() <= 1 and (diff != 0).sum() <= 2e-3 * diff.size + 1, (cw, b, int(diff.max()), int((diff != 0).sum()))
+            if diff.max() == 0:
+                assert bool(ok[cw][b]) == r["ok"][cw] and np.array_equal(it[b], r["iters"][cw]) and np.array_equal(tb[cw][b], r["tb"][cw]), (cw, b)
+            if r["ok"][cw]:
+                n_ok += 1
+                assert bool(ok[cw][b]) and np.array_equal(tb[cw][b][:cfg.tbss[cw] // 8], data[b][cw]), (cw, b)
+    assert n_ok > 0
+    rx.free()
+
+
 def test_dl_rx_two_layer_noise_free_and_zf(hp):
     """Noise-free subframes through the zero-forcing setting (cfg.mmse = 0: the noise term is dropped, pdsch.c:866): every transport block
     of every mode comes back."""
@@ -176,7 +212,7 @@ def test_dl_rx_two_layer_config_errors(hp):
     """Creation refuses what the reference's grant logic and pre-decoders refuse (ra_dl.c:556-600, precoding.c:1087-1114,:1710-1759)."""
     ok = dict(nof_rx=2, nof_ports=2, tx_scheme=3, mod2=2, tbs2=4008)
     for bad in (dict(ok, nof_rx=1), dict(ok, nof_ports=1), dict(ok, nof_ports=4), dict(ok, tbs2=0), dict(ok, tx_scheme=2, pmi=2), dict(ok, tx_scheme=2, tbs2=0, pmi=4),
-                dict(ok, tx_scheme=1), dict(ok, llr_8bit=True), dict(ok, mod2=0)):
+                dict(ok, tx_scheme=1), dict(ok, mod2=0)):
         with pytest.raises(RuntimeError):
             hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **bad)
     rx = hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, 2, True, _chest(hp), **ok)

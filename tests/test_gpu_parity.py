@@ -202,7 +202,7 @@ def test_chest_dl_noise_pss_empty(hp, prb, cid, npt, nrx, alg):
     est = hp.ChestDl(cid, prb, npt)
     state = np.zeros(16, np.float32)  # oracle's, [antenna][port]
     for call, (tti0, nsf, kw) in enumerate([(8, 9, {"filter_coef": (4.0, 1.5)}), (17, 5, {"filter_type": 1, "filter_coef": (0.1, 0.0)}),
-                                            (22, 1, {}), (23, 4, {"filter_type": 2, "interpolate_subframe": npt < 4})]):
+                                            (22, 1, {}), (23, 4, {"filter_type": 2, "interpolate_subframe": True})]):
         grids = np.zeros((nsf, nrx, n), np.complex64)
         for b in range(nsf):
             sf_idx = (tti0 + b) % 10
@@ -226,10 +226,12 @@ def test_chest_dl_noise_pss_empty(hp, prb, cid, npt, nrx, alg):
                 setattr(hc, k_, 1 if v is True else (0 if v is False else v))
                 setattr(oc, k_, v)
         hc.noise_alg = oc.noise_alg = alg
-        rc, ce, res, raw = est.estimate_multi(grids, tti0, hc, nrx)
+        # what the estimate buffers hold before the call matters for ports 2/3 with interpolate_subframe: upstream replicates their symbol 0
+        ce0 = (rng.standard_normal((nsf, npt, nrx, n)) + 1j * rng.standard_normal((nsf, npt, nrx, n))).astype(np.complex64)
+        rc, ce, res, raw = est.estimate_multi(grids, tti0, hc, nrx, ce_in=ce0)
         assert rc == 0
         for b in range(nsf):
-            ce2 = [np.zeros(n, np.complex64) for _ in range(npt * nrx)]
+            ce2 = [ce0[b, i // nrx, i % nrx].copy() for i in range(npt * nrx)]
             ores = OrcChestRes()
             gl = [np.ascontiguousarray(grids[b, a]) for a in range(nrx)]
             gp, cp = (C.c_void_p * nrx)(*[x.ctypes.data for x in gl]), (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce2])

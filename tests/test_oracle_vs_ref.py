@@ -528,8 +528,9 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx, npt):
     cell = OrcCell(cid, prb, npt, True)
     oracle().orc_chest_dl_ports.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     cfo_cfg = {"filter_coef": (4.0, 2.0), "cfo_estimate_enable": True}
+    # 4-port cells with interpolate_subframe (sf 2, 8): ports 2/3 come out as symbol 0 of what the caller's buffer held, replicated (chest_dl.c:467-471)
     for sf_idx, kw in ((0, CHEST_CFGS[0]), (3, CHEST_CFGS[2] if npt == 2 else cfo_cfg), (5, CHEST_CFGS[1]), (9, CHEST_CFGS[3] if npt == 2 else CHEST_CFGS[5]),
-                       (4, CHEST_CFGS[4]), (7, CHEST_CFGS[6])):
+                       (4, CHEST_CFGS[4]), (7, CHEST_CFGS[6]), (2, CHEST_CFGS[2]), (8, CHEST_CFGS[3])):
         k, l = np.arange(n) % nre, np.arange(n) // nre
         tx = []
         for port in range(npt):  # each port: its own CRS (zeros at the other ports' positions) and some data
@@ -562,13 +563,15 @@ def test_chest_dl_two_ports_vs_ref(prb, cid, nrx, npt):
         rc.cfo_estimate_sf_mask = 0x3FF
         res, sf = RefChestRes(), RefDlSfCfg()
         ce_r = [[aligned(2 * n, np.float32) for _ in range(nrx)] for _ in range(npt)]
+        before = (rng.standard_normal((npt, nrx, n)) + 1j * rng.standard_normal((npt, nrx, n))).astype(np.complex64)
         for port in range(npt):
             for a_ in range(nrx):
+                ce_r[port][a_].view(np.complex64)[:] = before[port, a_]
                 res.ce[port][a_] = ce_r[port][a_].ctypes.data
         sf.tti = sf_idx
         inp = (C.c_void_p * 4)(*([g.ctypes.data for g in grids] + [0] * (4 - nrx)))
         assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
-        ce_o, ores = [np.zeros(n, np.complex64) for _ in range(npt * nrx)], OrcChestRes()
+        ce_o, ores = [before[i // nrx, i % nrx].copy() for i in range(npt * nrx)], OrcChestRes()
         gp = (C.c_void_p * nrx)(*[g.ctypes.data for g in grids])
         cp = (C.c_void_p * (npt * nrx))(*[c.ctypes.data for c in ce_o])
         raw = np.zeros(nrx * npt * 4, np.float32)
