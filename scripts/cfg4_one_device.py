@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""cfg4 of BASELINE.json on ONE device - a REHEARSAL, not a scaling figure: the 8 UE identities of sharding.ue_for_rank (RNTI 0x1234+u, cell id
+1+u: CRS positions and sequences, scrambling, RE maps all differ) as 8 pipeline objects on 8 HIP streams of one GPU, every UE a batch of 20 MHz
+subframes (100 PRB, 64QAM MCS 28, 13 x K=5824). What runs on 8 GPUs as one process each (bench.py --gpus 8: one RCCL gather per batch) runs
+here as one process; the per-UE result records go through sharding.gather_results' single-process path into the rows of one host array, as
+rank 0 would hold them. Every UE's transport blocks are checked against what was sent, a sample against the oracle chain.
+
+    python scripts/cfg4_one_device.py [--ues 8] [--batch 128] [--steps 8] [--oracle-sample 2]
+
+There is NO N > 1 hardware run behind this (the pool has one GPU per box): the JSON says so."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in (ROOT, os.path.join(ROOT, "tests")):
+    if d not in sys.path:
+        sys.path.insert(0, d)
+NOF_PRB, MOD, TBS, CFI, MAX_ITER = 100, 3, 75376, 1, 6
+
+
+def run(ues=8, batch=128, steps=8, snr=18.0, oracle_sample=2, quiet=False):
+    import torch
+    from lte_sim import DlConfig, make_subframe, oracle_rx
+    pkg = importlib.import_module("srslte-emane_amd")
+    sharding = importlib.import_module("srslte-emane_amd.sharding")
+    L = pkg.lib()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    hc = pkg.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    tb_stride = (TBS // 8 + 6 + 15) & ~15
+    res_bytes, ok_off = sharding.result_layout(tb_stride, batch)
+    cfgs, iqs, datas, rxs, t_res, streams = [], [], [], [], [], []
+    for u in range(ues):
+        ue = sharding.ue_for_rank(u)
+        rng = np.random.default_rng(1000 + u)
+        cfg = DlConfig(NOF_PRB, ue["cell_id"], MOD, TBS, cfi=CFI, rnti=ue["rnti"], max_iter=MAX_ITER)
+        sub = [make_subframe(cfg, t, rng, snr_db=snr, amp=0.1) for t in range(batch)]
+        cfgs.append(cfg)
+        iqs.append(np.stack([s[0] for s in sub]))
+        datas.append([s[1] for s in sub])
+        t_res.append(torch.zeros(res_bytes, dtype=torch.uint8, device=dev))
+        rxs.append(pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, batch, True, hc,
+                            out_ptrs=(t_res[u].data_ptr(), t_res[u].data_ptr() + ok_off)))
+        streams.append(torch.cuda.Stream())
+    d_iq = [torch.from_numpy(x.view(np.float32)).to(dev) for x in iqs]
+    gathered = torch.zeros((ues, res_bytes), dtype=torch.uint8).pin_memory()  # rank 0's host copy: row u = UE u's record
+
+    def step(k):
+        u = k % ues
+        for stage in range(6):
+            rc = rxs[u].stage(stage, d_iq[u].data_ptr(), 0, batch, streams[u].cuda_stream)
+            assert rc == 0, (u, stage, rc)
+        with torch.cuda.stream(streams[u]):
+            gathered[u].copy_(t_res[u], non_blocking=True)  # sharding.gather_results without a process group is this copy into row 0 ... row u here
+
+    for k in range(2 * ues):
+        step(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps * ues):
+        step(k)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    good = wrong = checked = agree = 0
+    per_ue = []
+    for u in range(ues):
+        rec = gathered[u].numpy()
+        ok, tb = rec[ok_off:ok_off + batch], rec[:ok_off].reshape(batch, tb_stride)
+        g = int(sum(bool(ok[b]) and np.array_equal(tb[b, :TBS // 8], datas[u][b]) for b in range(batch)))
+        w = int(sum(bool(ok[b]) and not np.array_equal(tb[b, :TBS // 8], datas[u][b]) for b in range(batch)))
+        good, wrong = good + g, wrong + w
+        per_ue.append({"rnti": cfgs[u].rnti, "cell_id": cfgs[u].cell_id, "delivered": g, "undetected_errors": w})
+        for b in list(range(0, batch, max(1, batch // max(1, oracle_sample))))[:oracle_sample]:  # the oracle chain on a sample of this UE's subframes
+            r = oracle_rx(cfgs[u], iqs[u][b], b)
+            checked += 1
+            agree += int(bool(ok[b]) == r["ok"] and (not r["ok"] or np.array_equal(tb[b, :TBS // 8 + 3], r["tb"])))
+    for rx in rxs:
+        rx.free()
+    out = {"metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(ues * steps * batch / dt, 1), "unit": "subframes/s", "n_gpus": 1,
+           "rehearsal": True,
+           "note": "cfg4 REHEARSAL on one device: %d UE identities as %d pipeline objects on %d streams of ONE GPU. No N > 1 hardware run exists; this is "
+                   "not a scaling figure." % (ues, ues, ues),
+           "config": {"workload": "%d UEs x 20 MHz (100 PRB) DL subframe batch=%d, 64QAM MCS 28 (13 x K=5824), one GPU" % (ues, batch), "snr_db": snr,
+                      "bler": round(1 - good / (ues * batch), 4), "undetected_errors": wrong, "oracle_sample": checked, "oracle_sample_agrees": agree,
+                      "per_ue": per_ue},
+           "ms_per_ue_batch": round(1e3 * dt / (steps * ues), 4)}
+    if not quiet:
+        print(json.dumps(out))
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ues", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--snr", type=float, default=18.0)
+    ap.add_argument("--oracle-sample", type=int, default=2)
+    a = ap.parse_args()
+    run(a.ues, a.batch, a.steps, a.snr, a.oracle_sample)

@@ -2,11 +2,13 @@
 subframe: size-independent properties instead - transmit -> receive round trips on the device, the gain of HARQ combining, no undetected
 errors, agreement between entry points and between the 16- and 8-bit LLR paths - plus the oracle on a sample of the batch."""
 import importlib
+import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -173,3 +175,18 @@ def test_cfg5_full_batch_256qam(hp):
         tb, ok = rx.decode(iq, 0)
         assert ok.all() and np.array_equal(tb[:, :tbs // 8], data), llr8
         rx.free()
+
+
+def test_cfg4_eight_ues_on_one_device():
+    """BASELINE cfg4 as far as a one-GPU box goes (a rehearsal, not a scaling figure): the eight UE identities of sharding.ue_for_rank as eight
+    pipeline objects on eight streams of one device, 20 MHz / 64QAM MCS 28 / 13 code blocks each; every UE's delivered transport blocks equal
+    what was sent, none is wrong, and a sample of every UE's subframes agrees with the oracle chain (verdict and bytes)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("cfg4_one_device", os.path.join(ROOT, "scripts", "cfg4_one_device.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    out = m.run(ues=8, batch=16, steps=2, snr=18.0, oracle_sample=2, quiet=True)
+    c = out["config"]
+    assert out["rehearsal"] and c["undetected_errors"] == 0 and c["oracle_sample"] == 16 and c["oracle_sample_agrees"] == 16, c
+    assert len({u["rnti"] for u in c["per_ue"]}) == 8 and len({u["cell_id"] for u in c["per_ue"]}) == 8
+    assert sum(u["delivered"] for u in c["per_ue"]) >= 8 * 16 * 0.5, c["per_ue"]
