@@ -93,7 +93,7 @@ class Side:
 
 @pytest.mark.skipif(ref() is None, reason="oracle/_ref/libsrslte_ref.so not built")
 @pytest.mark.parametrize("prb,tbs,mod,nre,Nl,llr8,snr", [(25, 4008, 2, 3000, 1, False, -5.0), (100, 75376, 3, 14580, 1, False, 3.5), (100, 30576, 2, 14580, 2, False, -1.5),
-                                                         (6, 328, 1, 600, 1, False, -5.5), (50, 21384, 3, 6600, 1, True, -1.0), (100, 75376, 3, 14580, 1, True, 4.0)])
+                                                         (6, 328, 1, 600, 1, False, -5.5), (50, 21384, 3, 6600, 1, True, 1.5), (100, 75376, 3, 14580, 1, True, 4.0)])
 def test_dlsch_decode2_vs_reference_with_harq(prb, tbs, mod, nre, Nl, llr8, snr):
     from lte_sim import OrcSchCfg
     orc, rng = oracle(), np.random.default_rng(tbs + nre)
