@@ -561,9 +561,19 @@ def test_chest_dl_object_two_ports(prb, cid, nrx, npt):
                 assert abs(res.snr_ant_port_db[a][port] - 10 * np.log10(raw[a, port, 1] / raw[a, port, 0])) < 1e-3
                 assert abs(res.rsrp_ant_port_dbm[a][port] - (10 * np.log10(raw[a, port, 1]) + 30)) < 1e-3
                 assert abs(res.rsrq_ant_port_db[a][port] - 10 * np.log10(prb * raw[a, port, 1] / raw[a, port, 2])) < 1e-3
-    if npt == 4:  # upstream replicates a never-written symbol there (chest_dl.c:467-471): refused, not guessed
-        rc.interpolate_subframe = True
-        assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) != 0
+    if npt == 4:  # interpolate_subframe: ports 2/3 take upstream's copy branch (chest_dl.c:467-471) - symbol 0 of what the CALLER's buffer held
+        rc.interpolate_subframe = oc.interpolate_subframe = True
+        before = [(rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) for _ in range(npt * nrx)]
+        for i, c_ in enumerate(ce):
+            c_.view(np.complex64)[:] = before[i]
+        assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+        ce_o = [b_.copy() for b_ in before]
+        cp = (C.c_void_p * (npt * nrx))(*[c_.ctypes.data for c_ in ce_o])
+        assert oracle().orc_chest_dl_ports(C.byref(cell), sf_idx, C.byref(oc), nrx, gp, cp, C.byref(ores), p(np.zeros(nrx * npt * 4, np.float32))) == 0
+        for i in range(npt * nrx):
+            assert close(ce[i].view(np.complex64), ce_o[i]), ("interpolate_subframe", i)
+            if i // nrx >= 2:
+                assert np.array_equal(ce[i].view(np.complex64).reshape(14, nre), np.tile(before[i][:nre], (14, 1)))
     L.srslte_chest_dl_free(est)
 
 
