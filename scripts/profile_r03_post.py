@@ -27,8 +27,7 @@ def find(d, name, suffix):
 
 
 def short(name):
-    n = name.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "").strip()
-    return n
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
 
 
 def by_grid_counters(path):
@@ -47,7 +46,7 @@ def by_grid_counters(path):
 def by_grid_durations(path):
     tot, n = defaultdict(float), defaultdict(int)
     for r in csv.DictReader(open(path)):
-        k = (short(r["Kernel_Name"]), int(r["Grid_Size"]))
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))  # threads, as the counter passes report it
         tot[k] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
         n[k] += 1
     return {k: (tot[k] / n[k], n[k]) for k in tot}
