@@ -15,9 +15,13 @@ been timed; `value` / `ms_per_step` are the median repeat, the spread is in `con
 
 Extra objects on that line:
   roofline      dominant kernel (turbo decoder). It is a serial-trellis integer kernel: bound by VALU issue, not by HBM
-                (SURVEY §8d). `bound` says so; achieved / peak are lane-instructions per second against the issue rate
-                measured on this chip for its instruction mix (profiles/r02/ubench_issue.json); the HBM figures
-                (algorithmic bytes / live HIP-event duration vs 8 TB/s, PMC traffic) are in `roofline.hbm`.
+                (SURVEY §8d). `bound` says so. `achieved` = lane-instructions the launch issues (the committed SQ-counter pass,
+                profiles/r03/tdec_counters.json, tagged with the sha of the decoder source) / the launch's own average duration
+                (HIP events on its stream, inside the timed region); `frac` = that / the guide's VALU peak (78.6 T lane-instr/s).
+                Named extras: `frac_step` (per step time: what the chip delivers when launches overlap), `frac_alone` (a launch
+                that has the chip to itself), `frac_vs_measured_issue` (against the packed-int16 issue rate measured on this chip),
+                `algorithmic` (SURVEY §8d's 80 K int16 ops per pass: the fewest lane-instructions the work needs, and how many
+                times that the kernel issues). The HBM figures (algorithmic bytes, PMC traffic) are in `roofline.hbm`.
   kernels       every kernel of the chain timed in isolation (HIP events) with its algorithmic bytes
   cpu_baseline  the same chain on the host CPU: the reference's own compiled code (oracle/_ref) driven from a C loop
                 (oracle/refdrv.c; its FFT is the oracle's, FFTW being absent) on one core and on all cores of the box's
@@ -516,6 +520,15 @@ def main():
                 "achieved_launch": round(lane / (tdec_ms * 1e-3) / 1e12, 2), "achieved_step": round(lane / (ms_per_step * 1e-3) / 1e12, 2),
                 "achieved_alone": round(lane / (kernels["tdec"]["ms"] * 1e-3) / 1e12, 2)}
     frac = (lambda x: round(x * 1e12 / VALU_PEAK_LANE, 4))
+    # ~80 K int16 operations per SISO pass and code block; a packed instruction does two per lane, so the fewest lane-instructions
+    # one launch can do with are 40 K x passes x blocks. 'issued_over_algorithmic' is what the mapping spends on top (window warm-ups, beta
+    # recomputation, cross-lane moves, element-wise phases): 4.3 in round 2, see DESIGN.md for the account of this round's.
+    K_cb, n_cb = 5824, 13 * B
+    alg_lane = 40.0 * K_cb * passes * n_cb
+    algorithmic = {"int16_ops_per_launch": int(2 * alg_lane), "lane_instr_per_launch": int(alg_lane),
+                   "issued_over_algorithmic": round(valu["lane_instr_per_launch"] / alg_lane, 2) if valu else None,
+                   "frac_step": frac(alg_lane / (ms_per_step * 1e-3) / 1e12), "frac_launch": frac(alg_lane / (tdec_ms * 1e-3) / 1e12) if tdec_ms else None,
+                   "source": "SURVEY.md 8(d): 80 K int16 ops per SISO pass; K = 5824, %d blocks, %.3f passes" % (n_cb, passes)}
     hbm = {"achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
            "frac_alone": round(tdec_alg / (kernels["tdec"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
            "algorithmic_bytes_per_launch": tdec_alg} if tdec_ms else None
@@ -531,7 +544,7 @@ def main():
                 "frac_step_vs_measured_issue": round(valu["achieved_step"] * 1e12 / peak_packed, 4) if valu else None,
                 "peak_source": "MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 x 2.4 GHz; measured_issue: profiles/r02/ubench_issue.json, %.2f cycles per packed-int16 / DPP "
                                "wave-instruction per SIMD (%.1f T lane-instr/s)" % (cyc_per_instr, peak_packed / 1e12),
-                "traffic": traffic, "valu": valu, "counters_source": traffic_src,
+                "traffic": traffic, "valu": valu, "algorithmic": algorithmic, "counters_source": traffic_src,
                 "avg_launch_ms": round(tdec_ms, 4) if tdec_ms else None, "avg_launch_ms_alone": kernels["tdec"]["ms"], "hbm": hbm,
                 "note": "serial-trellis integer kernel: VALU-issue bound, not HBM-bound (SURVEY 8d); the HBM-bound streaming kernels are in 'kernels' / 'kernels_large_batch'"}
     for v in (roofline["frac"], roofline["frac_step"], roofline["frac_alone"], hbm["frac"] if hbm else None):
