@@ -70,3 +70,19 @@ $(HOUT)/$(notdir $(1)): $(REF)/$(1).c $(HOUT)/libsrslte_upper.a $(HIPLIB)/libsrs
 	    -Wl,-rpath,'$$$$ORIGIN/../../../srslte-emane_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lstdc++ -lm -lpthread
 endef
 $(foreach t,$(TESTS),$(eval $(call TEST_RULE,$(t))))
+
+# phy_dl_test_sz: the same drop-in with ONE flag changed on ONE translation unit of the REFERENCE's own (not replaced) code -
+# mimo/precoding.c with -fsigned-zeros, as libsrslte_ref_sz.so in ref.mk. With this image's gcc 11.4 the reference's -Ofast folds the two
+# sign masks of its SIMD large-delay-CDD pre-decoders into one constant; `phy_dl_test -t 3` fails for that reason in every build made here,
+# with or without this library. With the flag the test passes through this library's OFDM, estimator and decoder
+# (tests/test_gpu_dropin.py::test_tm3_with_the_reference_predecoder_as_written).
+$(HOBJ)/mimo/precoding_sz.o: $(RLIB)/src/phy/mimo/precoding.c
+	@mkdir -p $(dir $@)
+	gcc -std=c99 $(if $(shell grep -l 'srslte/srslte\.h' $<),$(REF_FLAGS) $(FORCEINC),$(filter-out -DSRSLTE_SRSLTE_H,$(REF_FLAGS))) -fsigned-zeros -c $< -o $@
+$(HOUT)/libsrslte_upper_sz.a: $(UP_OBJS) $(HOBJ)/mimo/precoding_sz.o ref_hip.mk
+	@rm -f $@
+	ar rcs $@ $(filter-out $(HOBJ)/mimo/precoding.o,$(UP_OBJS)) $(HOBJ)/mimo/precoding_sz.o
+$(HOUT)/phy_dl_test_sz: $(REF)/lib/test/phy/phy_dl_test.c $(HOUT)/libsrslte_upper_sz.a $(HIPLIB)/libsrslte_phy_hip.so
+	gcc -std=c99 $(REF_FLAGS) $(FORCEINC) -I$(REF)/lib/test/phy/ $< -o $@ $(HOUT)/libsrslte_upper_sz.a -L$(HIPLIB) -lsrslte_phy_hip \
+	    -Wl,-rpath,'$$ORIGIN/../../../srslte-emane_amd/csrc' -Wl,-rpath,/opt/rocm/lib -lstdc++ -lm -lpthread
+ref_hip: $(HOUT)/phy_dl_test_sz

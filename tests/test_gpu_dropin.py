@@ -54,9 +54,22 @@ CASES = [
     ("phy_dl_test", ["-p", "15", "-t", "1", "-m", "28"]), ("phy_dl_test", ["-p", "75", "-t", "2", "-m", "14"]),
 ]
 # Not in the list: phy_dl_test -t 3 (TM3, large-delay CDD). It fails here with every code block KO, and the failing link is the
-# reference's own srslte_predecoding_type(..., SRSLTE_TXSCHEME_CDD, ...), which no translation unit of ours replaces: called on its own
-# on the CPU with the test's noise-free "perfect crossed channel" it returns NaN (tests/test_oracle_vs_ref.py::
-# test_reference_cdd_predecoder_on_a_noise_free_channel). TM4 (spatial multiplexing, same estimator / OFDM / decoder calls) passes.
+# reference's own srslte_predecoding_type(..., SRSLTE_TXSCHEME_CDD, ...), which no translation unit of ours replaces: as compiled in this
+# image (gcc 11.4, the reference's -Ofast) its two sign masks come out as one constant (oracle/ref.mk, tests/test_oracle_vs_ref.py::
+# test_reference_cdd_predecoder_on_a_noise_free_channel). test_tm3_with_the_reference_predecoder_as_written below runs the same test program
+# with that ONE unit of the reference compiled with -fsigned-zeros: TM3 then passes through this library's OFDM, estimator and decoder.
+TM3_CASES = [["-p", "25", "-t", "3", "-m", "14"], ["-p", "50", "-t", "3", "-m", "21"], ["-p", "100", "-t", "3", "-m", "28"], ["-p", "6", "-t", "3", "-m", "7"],
+             ["-p", "75", "-t", "3", "-q", "-m", "27"]]
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(BIN, "phy_dl_test_sz")), reason="oracle/_ref/hip/phy_dl_test_sz not built")
+@pytest.mark.parametrize("args", TM3_CASES, ids=[" ".join(a) for a in TM3_CASES])
+def test_tm3_with_the_reference_predecoder_as_written(args):
+    """lib/test/phy/CMakeLists.txt:33-54 runs TM3 at every bandwidth. The drop-in build of phy_dl_test whose only difference is
+    -fsigned-zeros on the reference's mimo/precoding.c (oracle/ref_hip.mk: phy_dl_test_sz) passes them: what fails in `phy_dl_test -t 3` is
+    the reference's predecoder as this image's compiler builds it, not what libsrslte_phy_hip.so serves."""
+    rc, out = run("phy_dl_test_sz", args)
+    assert rc == 0, out[-3000:]
 
 
 @need_bin
