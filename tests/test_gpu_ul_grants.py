@@ -189,7 +189,9 @@ def test_ul_grants_argument_errors(hp):
     iq = np.zeros((2, rx.sf_len), np.complex64)
     G = hp.UlGrant.make
     for bad in ([G(2, 1, 10, 0, 2, 4008)], [G(0, 1, 7, 0, 2, 4008)], [G(0, 1, 10, 16, 2, 4008)], [G(0, 1, 10, 0, 4, 4008)], [G(0, 1, 10, 0, 2, 4016)],
-                [G(0, 1, 10, 0, 2, 6200)], [G(0, 1, 10, 0, 2, 4008, n_dmrs=8)], [G(0, 1, 10, 0, 2, 4008, rv=4)], [G(0, 1, 10, 0, 2, 4008)] * 3):
+                [G(0, 1, 10, 0, 2, 6200)], [G(0, 1, 10, 0, 2, 4008, n_dmrs=8)], [G(0, 1, 10, 0, 2, 4008, rv=4)], [G(0, 1, 10, 0, 2, 4008)] * 3,
+                # no transport block (a UCI-only PUSCH is not served): an error code, not a division by the block count (round-2 advice)
+                [G(0, 1, 10, 0, 2, 0)], [G(0, 1, 10, 0, 2, 0, ack_len=1, I_offset_ack=9)], [G(0, 1, 10, 0, 2, 4008), G(1, 1, 10, 0, 2, 0)]):
         with pytest.raises(RuntimeError):
             rx.decode_grants(iq, 0, bad)
     tb, ok = rx.decode_grants(iq, 0, [])

@@ -1175,6 +1175,35 @@ def test_ri_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, 
     assert n_ok > 0
 
 
+def test_reference_mbsfn_estimate_without_interpolate_subframe_reads_stale_symbols():
+    """Fact about the reference, recorded because libsrslte_phy_hip.so REFUSES this call (SRSLTE_ERROR + message): with sf_type MBSFN and
+    interpolate_subframe off, chest_dl.c:430-433 interpolates symbol 0 only in frequency, yet the MBSFN time interpolation of :475-479
+    still runs between symbols 0, 2, 6 and 10 of `ce` - three of which this call never wrote. The result is a function of what the
+    caller's buffer held before: the same grid estimated into two differently prefilled buffers gives two different answers (and the
+    pilot averaging of :527-545 walks the 2 + 3 x 6 references per PRB as if they were CRS rows). There is nothing to be bit-exact with."""
+    R, rng = ref(), np.random.default_rng(4242)
+    prb, cid, area, n = 25, 7, 3, 14 * 12 * 25
+    q = opaque(1 << 20)
+    assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert R.srslte_chest_dl_set_mbsfn_area_id(q, area) == 0
+    grid = acopy(((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64).view(np.float32))
+    outs = []
+    for fill in (0.0, 5.0):
+        rc, res, sf = RefChestCfg(), RefChestRes(), RefDlSfCfg()
+        rc.interpolate_subframe, rc.mbsfn_area_id = False, area
+        ce = aligned(2 * n, np.float32)
+        ce[:] = fill
+        res.ce[0][0] = ce.ctypes.data
+        sf.tti, sf.sf_type = 1, 1
+        assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+        outs.append(ce.copy())
+    sym = lambda a, l: a.view(np.complex64)[l * 12 * prb:(l + 1) * 12 * prb]
+    assert np.array_equal(sym(outs[0], 0), sym(outs[1], 0))            # what the call does compute
+    for l in (1, 3, 7, 11):                                            # interpolated FROM symbols 2 / 6 / 10, which nothing wrote
+        assert not np.allclose(sym(outs[0], l), sym(outs[1], l)), l
+    R.srslte_chest_dl_free(q)
+
+
 def test_reference_cdd_predecoder_on_a_noise_free_channel():
     """Fact about the reference, recorded because tests/test_gpu_dropin.py leaves `phy_dl_test -t 3` out: the reference's own compiled
     large-delay-CDD predecoder (mimo/precoding.c:1067-1102 -> srslte_predecoding_ccd_2x2_mmse[_csi], :915-1065), fed what that test
