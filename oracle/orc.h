@@ -228,6 +228,7 @@ int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32
 
 /* ---------------------------------------------------------------- HARQ-ACK on the PUSCH (orc_uci.c): 1 or 2 bits, no RI / CQI */
 int orc_uci_ack_qprime(uint32_t O_ack, uint32_t I_offset_ack, uint32_t L_prb, uint32_t nof_symb, uint32_t K_segm);
+int orc_uci_ack_ri_qprime_nodata(uint32_t O, uint32_t I_offset, int is_ri, uint32_t O_cqi, uint32_t I_offset_cqi, uint32_t L_prb, uint32_t nof_symb);
 int orc_uci_ack_insert(uint8_t* q_bits, const uint8_t* c_seq, const uint8_t ack[2], uint32_t O_ack, uint32_t Qm, uint32_t nof_re, uint32_t nof_symb,
                        uint32_t Qprime);
 int orc_uci_ack_extract(int16_t* q_llr, const uint8_t* c_seq, uint8_t ack[2], uint32_t O_ack, uint32_t Qm, uint32_t nof_re, uint32_t nof_symb,

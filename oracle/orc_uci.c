@@ -22,6 +22,23 @@ int orc_uci_ack_qprime(uint32_t O_ack, uint32_t I_offset_ack, uint32_t L_prb, ui
   return (int)(x < m ? x : m);
 }
 
+/* The same WITHOUT UL-SCH data (a CQI-only PUSCH, grant.tb.tbs == 0; 36.212 5.2.4.1): the callers divide the offset by the CQI's
+   (sch.c:943-946,:970-973 on the receive side, :1111-1114,:1171-1174 on the transmit side) and Q_prime_ri_ack takes the CQI report's
+   size - with its 8 CRC bits above 11 - in the place of sum K_r (uci.c:557-564). is_ri: the rank indication's offset table. */
+static const float BETA_CQI_[16] = {-1.0f, -1.0f, 1.125f, 1.25f, 1.375f, 1.625f, 1.750f, 2.0f, 2.25f, 2.5f, 2.875f, 3.125f, 3.5f, 4.0f, 5.0f, 6.25f}; /* sch.c:51-52 */
+static const float BETA_RI_[16] = {1.25f, 1.625f, 2.0f, 2.5f, 3.125f, 4.0f, 5.0f, 6.25f, 8.0f, 10.0f, 12.625f, 15.875f, 20.0f, -1.0f, -1.0f, -1.0f};
+int orc_uci_ack_ri_qprime_nodata(uint32_t O, uint32_t I_offset, int is_ri, uint32_t O_cqi, uint32_t I_offset_cqi, uint32_t L_prb, uint32_t nof_symb)
+{
+  const float* tab = is_ri ? BETA_RI_ : BETA_HARQ;
+  if (I_offset > 15 || I_offset_cqi > 15 || tab[I_offset] < 0 || BETA_CQI_[I_offset_cqi] < 0 || O_cqi == 0) return -1;
+  float beta = tab[I_offset];
+  beta /= BETA_CQI_[I_offset_cqi];
+  uint32_t K = O_cqi <= 11 ? O_cqi : O_cqi + 8;
+  uint32_t x = (uint32_t)ceilf((float)O * L_prb * 12 * nof_symb * beta / K);
+  uint32_t m = 4 * L_prb * 12;
+  return (int)(x < m ? x : m);
+}
+
 /* ACK symbol i (0 .. Q'-1) sits in row R-1-i/4 (sub-carrier) of column {2,3,8,9}[(3i)%4] (data symbol) of the interleaver matrix
    (uci.c:497-520; the extended-CP / shortened set {1,2,6,7} when there are at most 10 columns): first q-bit index of that symbol */
 static int g_is_ri = 0; /* which column set the helpers below use (set by the entry points; the oracle is single-threaded) */

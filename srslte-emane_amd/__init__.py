@@ -790,8 +790,11 @@ class UlTx:
     def encode(self, tb, tti0=0, ack=None, ri=None, cqi=None, rv=None):
         """tb: [nof_sf][tbs/8] payload bytes (ack: [nof_sf][ack_len] HARQ-ACK values, ri: [nof_sf][ri_len] rank-indication bits,
         cqi: [nof_sf][cqi_len] report bits; rv: redundancy version through srslte_hip_ul_tx_batch_rv) -> iq [nof_sf][sf_len] (left on the
-        device in self.d_iq)."""
-        x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
+        device in self.d_iq). tbs = 0 (a PUSCH without UL-SCH data): tb is ignored, one subframe per row of cqi."""
+        if self.tbs == 0:
+            x = np.zeros((len(cqi), 1), np.uint8)
+        else:
+            x = np.ascontiguousarray(tb, np.uint8).reshape(-1, self.tbs // 8)
         din = DevBuf.from_host(x)
         if rv is not None:
             bufs = []

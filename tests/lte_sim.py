@@ -746,7 +746,7 @@ def ref_sch_decode(self, e, nbits):
 
 # ------------------------------------------------------------------------------------------------------------------ UL
 class UlConfig:
-    """One PUSCH configuration: UL-SCH data only (no UCI), same allocation in both slots, rv 0, normal CP, not shortened."""
+    """One PUSCH configuration (the UCI goes in per subframe): normal CP; tbs = 0 is a PUSCH without UL-SCH data (CQI-only, sch.c:943-975)."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0, n_prb_slot1=None,
                  group_hopping=False, sequence_hopping=False, shortened=False):
@@ -808,10 +808,20 @@ def ack_type_map(cfg, ack, Qp):
     return types
 
 
-def ul_ri_layout(cfg, O_ri, I_offset_ri):
+def ul_ack_ri_qprime(cfg, O, I_offset, is_ri, O_cqi=0, I_offset_cqi=0):
+    """Q' of a HARQ-ACK / rank indication (0 without one); on a PUSCH without UL-SCH data the CQI report's size and offset enter (uci.c:557-564)"""
+    orc = oracle()
+    if not O:
+        return 0
+    if cfg.tbs == 0:
+        return orc.orc_uci_ack_ri_qprime_nodata(O, I_offset, 1 if is_ri else 0, O_cqi, I_offset_cqi, cfg.L_prb, cfg.nsymb)
+    return (orc.orc_uci_ri_qprime if is_ri else orc.orc_uci_ack_qprime)(O, I_offset, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+
+
+def ul_ri_layout(cfg, O_ri, I_offset_ri, O_cqi=0, I_offset_cqi=0):
     """(Q'_ri, lut, RI mask, G): the channel interleaver with the rank-indication symbols left out (ulsch_interleave_gen, sch.c:580-598)."""
     orc = oracle()
-    Qp = orc.orc_uci_ri_qprime(O_ri, I_offset_ri, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1) if O_ri else 0
+    Qp = ul_ack_ri_qprime(cfg, O_ri, I_offset_ri, True, O_cqi, I_offset_cqi)
     assert Qp >= 0
     lut = np.zeros(cfg.nbits, np.uint32)
     G = orc.orc_ulsch_interleaver_lut(cfg.Qm, cfg.nof_re, cfg.nsymb, Qp, p(lut))
@@ -834,7 +844,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     sf_idx = tti % 10
     if data is None:
         data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
-    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, len(ri), I_offset_ri)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, len(ri), I_offset_ri, len(cqi), I_offset_cqi)
     # the CQI's coded bits come first in the stream the interleaver reads, the UL-SCH is rate-matched to the rest (sch.c:1133-1160)
     Qp_cqi = ul_cqi_qprime(cfg, len(cqi), I_offset_cqi, Qp_ri)
     n_cqi = Qp_cqi * cfg.Qm
@@ -844,9 +854,12 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
         qc = np.zeros(n_cqi, np.uint8)
         assert orc.orc_uci_cqi_encode(p(np.ascontiguousarray(cqi, np.uint8)), len(cqi), p(qc), n_cqi) == 0
         g[:n_cqi] = qc
-    gs = np.zeros(G - n_cqi, np.uint8)
-    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(gs)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
-    g[n_cqi:] = gs
+    if cfg.tbs:
+        gs = np.zeros(G - n_cqi, np.uint8)
+        assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(gs)) == 0  # UL-SCH data path = segmentation + coder + rate matching (sch.c:1068-1160)
+        g[n_cqi:] = gs
+    else:  # no UL-SCH (sch.c:1157: cb_segm.tbs == 0): the report fills what the rank indication leaves (Q_prime_cqi with K = 0, uci.c:266-281)
+        assert n_cqi == G and len(cqi)
     q = np.zeros(cfg.nbits, np.uint8)
     q[~ri_mask] = g[lut[~ri_mask]]
     if not len(ri):
@@ -857,7 +870,7 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
         r2 = np.array(list(ri) + [0], np.uint8)[:2]
         assert Qp_ri > 0 and orc.orc_uci_ri_insert(p(q), p(c), p(r2), len(ri), cfg.Qm, cfg.nof_re, cfg.nsymb, Qp_ri) == 0
     if len(ack):  # HARQ-ACK symbols overwrite UL-SCH symbols next to the DMRS (36.212 5.2.2.6-5.2.2.8; orc_uci.c)
-        Qp = orc.orc_uci_ack_qprime(len(ack), I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+        Qp = ul_ack_ri_qprime(cfg, len(ack), I_offset_ack, False, len(cqi), I_offset_cqi)
         a2 = np.array(list(ack) + [0], np.uint8)[:2]
         assert Qp > 0 and orc.orc_uci_ack_insert(p(q), p(c), p(a2), len(ack), cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
         if keep is not None:
@@ -913,10 +926,10 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
     q_before_ack = qllr.copy()
     ack_out = np.zeros(2, np.uint8)
     if O_ack:  # uci_decode_ri_ack (sch.c:929-966): ACK decisions from the interleaved LLRs, then those positions are zeroed
-        Qp = orc.orc_uci_ack_qprime(O_ack, I_offset_ack, cfg.L_prb, cfg.nsymb, cfg.seg.C * cfg.seg.K1)
+        Qp = ul_ack_ri_qprime(cfg, O_ack, I_offset_ack, False, O_cqi, I_offset_cqi)
         assert Qp > 0 and orc.orc_uci_ack_extract(p(qllr), p(c_seq), p(ack_out), O_ack, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp) == 0
     ri_out = np.zeros(2, np.uint8)
-    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_offset_ri)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_offset_ri, O_cqi, I_offset_cqi)
     if O_ri:  # after the ACK (sch.c:968-979); the RI LLRs stay in q, and the scatter below leaves the last of them in g[0] (sch.c:891-918)
         assert orc.orc_uci_ri_extract(p(qllr), p(c_seq), p(ri_out), O_ri, cfg.Qm, cfg.nof_re, cfg.nsymb, Qp_ri) == 0
     g_full = np.zeros(cfg.nbits, np.int16)
@@ -931,7 +944,9 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
         assert orc.orc_uci_cqi_decode(p(g[:n_cqi].copy()), n_cqi, O_cqi, p(cqi_out), C.byref(cqi_ok)) == 0
     sch = OrcSchCfg(cfg.tbs, G - n_cqi, cfg.Qm, rv, cfg.max_iter)
     tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
-    if harq is not None:  # an OrcHarq kept between the transmissions of one transport block (cfg->softbuffers.rx, sch.c:1063)
+    if cfg.tbs == 0:  # no UL-SCH to decode (sch.c:1062-1065)
+        rc = -1
+    elif harq is not None:  # an OrcHarq kept between the transmissions of one transport block (cfg->softbuffers.rx, sch.c:1063)
         rc = orc.orc_dlsch_decode_harq(C.byref(sch), p(np.ascontiguousarray(g[n_cqi:])), 0, 1 if new_data else 0, p(harq.w), p(harq.crc), p(harq.data),
                                        p(tb), p(iters), p(cbok))
     else:

@@ -1237,6 +1237,87 @@ def test_ul_tx_rx_loop_cqi(hp):
         rx.free()
 
 
+UL_NODATA_CASES = [  # prb, L, n_prb, mod, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, short
+    (25, 4, 3, 1, 6.0, 2, 5, 4, 7, 0, 0, 0, 0, False), (50, 4, 10, 1, 5.0, 7, 4, 11, 12, 0, 0, 1, 9, False), (100, 3, 0, 1, 6.0, 0, 6, 20, 9, 1, 7, 2, 9, False),
+    (15, 2, 1, 2, 11.0, 5, 3, 10, 8, 0, 0, 0, 0, True), (50, 6, 0, 2, 12.0, 9, 4, 40, 10, 2, 6, 1, 8, False), (100, 4, 2, 1, 2.0, 3, 6, 64, 6, 2, 5, 0, 0, False),
+    (25, 1, 7, 1, 7.0, 8, 3, 5, 15, 1, 7, 1, 9, False)]
+
+
+@pytest.mark.parametrize("prb,L,n_prb,mod,snr,tti0,nsf,O_cqi,I_cqi,O_ri,I_ri,O_ack,I_ack,short", UL_NODATA_CASES)
+def test_ul_chains_without_ulsch_data(hp, prb, L, n_prb, mod, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, short):
+    """A PUSCH that carries a CQI report and no transport block (tbs = 0; srslte_ulsch_encode / _decode with cb_segm.tbs == 0, sch.c:1062-1065,
+    :1157-1165): the report fills what the rank indication leaves (uci.c:266-281), HARQ-ACK and RI are sized by the report (uci.c:557-564).
+    Transmit pipeline vs the oracle's stimulus (pinned on srslte_ulsch_encode, test_pusch_without_ulsch_data_vs_reference): modulated symbols
+    exact; receive pipeline vs the oracle chain on the same noisy subframes: report bits + CRC flag, RI / ACK decisions, LLRs; no transport
+    block is delivered."""
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(3100 + prb + L + mod + O_cqi)
+    cfg = UlConfig(prb, 11, mod, 0, L, n_prb, shortened=short, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=L >= 6)
+    cqis = _cqi_bits(nsf, O_cqi)
+    ris = np.array([[(b >> j) & 1 for j in range(O_ri)] for b in range(nsf)], np.uint8) if O_ri else None
+    acks = np.array([[((b + 1) >> j) & 1 for j in range(O_ack)] for b in range(nsf)], np.uint8) if O_ack else None
+    kw = dict(shortened=short, ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri, I_offset_ri=I_ri, cqi_len=O_cqi, I_offset_cqi=I_cqi)
+    tx = hp.UlTx(11, prb, 0x1234, mod, 0, L, n_prb, 3, nsf, 2, 5, True, L >= 6, **kw)
+    iq = tx.encode(np.zeros((nsf, 1), np.uint8), tti0, ack=acks, ri=ris, cqi=cqis)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    okw = lambda b: dict(ack=tuple(acks[b]) if O_ack else (), I_offset_ack=I_ack, ri=tuple(ris[b]) if O_ri else (), I_offset_ri=I_ri, cqi=tuple(cqis[b]),
+                         I_offset_cqi=I_cqi)
+    for b in range(nsf):
+        k = {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, keep=k, **okw(b))
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), "modulated symbols sf %d" % b
+        assert_close_c(iq[b], iq_o, "iq sf %d" % b)
+    tx.free()
+    G = ul_ri_layout(cfg, O_ri, I_ri, O_cqi, I_cqi)[3]
+    iqn = [make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), **okw(b))[0] for b in range(nsf)]
+    rx = hp.UlRx(11, prb, 0x1234, mod, 0, L, n_prb, 3, 6, nsf, 2, 5, True, L >= 6, **kw)
+    tb, ok = rx.decode(np.stack(iqn), tti0)
+    assert not ok.any()
+    ri, ack = rx.ri(), rx.ack()
+    cqi, cqi_ok = rx.cqi()
+    g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+    n_good = 0
+    for b in range(nsf):
+        r = oracle_ul_rx(cfg, iqn[b], tti0 + b, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri, O_cqi=O_cqi, I_offset_cqi=I_cqi)
+        diff = np.abs(g[b, :G].astype(np.int32) - r["g"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 1e-3 * diff.size + 1, (b, int(diff.max()), int((diff != 0).sum()))
+        if O_ri:
+            assert np.array_equal(ri[b], r["ri"][:O_ri]), "ri sf %d" % b
+        if O_ack:
+            assert np.array_equal(ack[b], r["ack"][:O_ack]), "ack sf %d" % b
+        if diff.max() == 0 or snr > 5:
+            assert bool(cqi_ok[b]) == r["cqi_ok"], "cqi crc sf %d" % b
+            if r["cqi_ok"]:
+                assert np.array_equal(cqi[b], r["cqi"]), "cqi sf %d" % b
+        n_good += int(r["cqi_ok"] and np.array_equal(r["cqi"], cqis[b]))
+    assert n_good >= nsf - 1 or snr < 5
+    rx.free()
+
+
+def test_ul_tx_rx_loop_without_ulsch_data(hp):
+    """Device transmit chain into device receive chain for a CQI-only PUSCH (noise-free), block-coded and convolutionally coded reports, with
+    HARQ-ACK and rank indication beside them; and what such an object refuses: grants mode, and creation without a report."""
+    prb, L, n_prb, mod, nsf = 50, 4, 20, 1, 10
+    rng = np.random.default_rng(81)
+    acks, ris = rng.integers(0, 2, (nsf, 2), dtype=np.uint8), rng.integers(0, 2, (nsf, 1), dtype=np.uint8)
+    for O in (4, 11, 12, 30, 64):
+        cqis = rng.integers(0, 2, (nsf, O), dtype=np.uint8)
+        kw = dict(ack_len=2, I_offset_ack=8, ri_len=1, I_offset_ri=7, cqi_len=O, I_offset_cqi=9)
+        tx = hp.UlTx(3, prb, 0x77, mod, 0, L, n_prb, 1, nsf, **kw)
+        rx = hp.UlRx(3, prb, 0x77, mod, 0, L, n_prb, 1, 6, nsf, **kw)
+        tb, ok = rx.decode(tx.encode(np.zeros((nsf, 1), np.uint8), 5, ack=acks, ri=ris, cqi=cqis), 5)
+        cqi, cqi_ok = rx.cqi()
+        assert not ok.any() and np.array_equal(rx.ack(), acks) and np.array_equal(rx.ri(), ris)
+        assert cqi_ok.all() and np.array_equal(cqi, cqis), O
+        with pytest.raises(RuntimeError):
+            rx.decode_grants(np.zeros((1, rx.sf_len), np.complex64), 0, [hp.UlGrant.make(0, 0x77, L, n_prb, mod, 0, cqi_len=O, I_offset_cqi=9)])
+        tx.free()
+        rx.free()
+    for cls, args in ((hp.UlRx, (3, prb, 0x77, mod, 0, L, n_prb, 1, 6, nsf)), (hp.UlTx, (3, prb, 0x77, mod, 0, L, n_prb, 1, nsf))):
+        with pytest.raises(RuntimeError):
+            cls(*args)
+
+
 def test_ul_cqi_config_errors(hp):
     """Creation fails for a reserved CQI offset index (beta < 0, sch.c:51-52) or more than 64 report bits; the plain entry points refuse
     a pipeline with a configured report."""

@@ -1638,6 +1638,39 @@ def test_uci_cqi_pusch_vs_reference(O):
     R.srslte_uci_cqi_free(q)
 
 
+@pytest.mark.parametrize("prb,L_prb,n_prb,mod,cqi_N,I_cqi,O_ack,O_ri,short", [(25, 4, 3, 1, 0, 7, 0, 0, False), (50, 4, 10, 1, 0, 12, 1, 0, False), (100, 3, 0, 1, 0, 9, 2, 1, False),
+                                                                              (15, 2, 1, 2, 3, 8, 0, 0, True), (50, 6, 0, 2, 9, 10, 1, 1, False), (100, 4, 2, 1, 13, 6, 0, 2, False),
+                                                                              (25, 1, 7, 1, 0, 15, 1, 1, False)])
+def test_pusch_without_ulsch_data_vs_reference(prb, L_prb, n_prb, mod, cqi_N, I_cqi, O_ack, O_ri, short):
+    """A PUSCH that carries a CQI report and no transport block (grant.tb.tbs == 0: srslte_ulsch_encode / _decode skip the UL-SCH,
+    sch.c:1062-1065,:1157-1165; Q'_cqi = everything the rank indication leaves, uci.c:266-281; HARQ-ACK and RI sized by the report,
+    uci.c:557-564 with beta_harq / beta_cqi, sch.c:943-946,:970-973): the oracle's transmit side puts the reference's bits in the
+    reference's places, and on a noisy subframe both receivers return the same ACK, RI and - for the block-coded reports - the same report."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(77 + prb + L_prb + cqi_N)
+    cfg = UlConfig(prb, 3, mod, 0, L_prb, n_prb=n_prb, shortened=short)
+    I_ack, I_ri = 9, 7
+    chain = RefUlsch(cfg, O_ack, I_ack, O_ri, I_ri, cqi_N=cqi_N, I_offset_cqi=I_cqi)
+    for trial in range(3):
+        wb, diff = int(rng.integers(0, 16)), int(rng.integers(0, 1 << (2 * cqi_N))) if cqi_N else 0
+        bits = chain.cqi_bits(wb, diff)
+        ack, ri = tuple(rng.integers(0, 2, O_ack)), tuple(rng.integers(0, 2, O_ri))
+        keep = {}
+        iq, _ = make_ul_subframe(cfg, 4, rng, snr_db=None, keep=keep, ack=ack, I_offset_ack=I_ack, ri=ri, I_offset_ri=I_ri, cqi=bits, I_offset_cqi=I_cqi)
+        g_ref, q_ref = chain.encode(np.zeros(0, np.uint8), ack=ack, ri=(ri[0] if O_ri else None), cqi=(wb, diff))
+        assert np.array_equal(keep["g"], g_ref[:len(keep["g"])])  # the report's code word fills the stream
+        snr = {1: 4.0, 2: 10.0}[mod]
+        iq, _ = make_ul_subframe(cfg, 4, rng, snr_db=snr, ack=ack, I_offset_ack=I_ack, ri=ri, I_offset_ri=I_ri, cqi=bits, I_offset_cqi=I_cqi)
+        r = oracle_ul_rx(cfg, iq, 4, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri, O_cqi=len(bits), I_offset_cqi=I_cqi)
+        d = chain.decode(r["q_before_ack"], cfg.scramble(4))
+        assert np.array_equal(d["ack"][:O_ack], r["ack"][:O_ack]) and np.array_equal(r["ack"][:O_ack], ack)
+        if O_ri:
+            assert d["ri"] == r["ri"][0] == ri[0]
+        assert np.array_equal(r["cqi"], bits) and r["cqi_ok"] and not r["ok"]
+        if cqi_N == 0:
+            assert d["cqi"] == (wb, 0) and d["cqi_crc"]
+
+
 @pytest.mark.parametrize("prb,L_prb,n_prb,mod,tbs,cqi_N,I_cqi,O_ack,O_ri,short", [(25, 25, 0, 2, 4008, 0, 7, 0, 0, False), (50, 40, 5, 1, 2792, 0, 12, 1, 0, False),
                                                                                   (100, 100, 0, 3, 61664, 0, 9, 2, 2, False), (15, 12, 1, 2, 1800, 3, 8, 0, 0, True),
                                                                                   (50, 50, 0, 2, 11448, 9, 10, 1, 1, False), (100, 96, 2, 3, 43816, 13, 6, 0, 2, False)])
