@@ -308,7 +308,8 @@ typedef struct {
   int      mod;            /* srslte_mod_t: QPSK, 16QAM, 64QAM */
   uint32_t tbs;            /* grant.tb.tbs. 0 with cqi_len > 0: a PUSCH WITHOUT UL-SCH data (36.212 5.2.4.1; srslte_ulsch_decode with cb_segm.tbs == 0,
                             * sch.c:943-975,:1031-1065): the CQI report fills what the rank indication leaves (uci.c:266-281), HARQ-ACK and RI are sized by
-                            * the report (uci.c:557-564); the batch calls decode the UCI and set d_tb_ok to 0. Fixed pipeline only (not in grants mode) */
+                            * the report (uci.c:557-564); the batch calls decode the UCI and set d_tb_ok to 0. In grants mode: per grant (tbs = 0 with cqi_len > 0),
+                            * on an object made with the largest transport-block size */
   uint32_t L_prb, n_prb, n_dmrs; /* grant: srslte_pusch_grant_t.L_prb / n_prb_tilde / n_dmrs (pusch_cfg.h:47-60) */
   uint32_t max_iterations, max_batch;
   int      mmse;           /* 1: noise_estimate from chest_ul (pusch.c:475) */
@@ -383,7 +384,7 @@ typedef struct {
   uint16_t rnti;
   int      mod;            /* srslte_mod_t: QPSK, 16QAM, 64QAM */
   uint32_t tbs;            /* 0 with cqi_len > 0: a PUSCH without UL-SCH data (srslte_ulsch_encode with cb_segm.tbs == 0, sch.c:1111-1114,:1157-1174):
-                            * d_tb of the batch calls is not read (may be NULL). Fixed pipeline only */
+                            * d_tb of the batch calls is not read (may be NULL). In grants mode: per grant, on an object made with tbs > 0 */
   uint32_t L_prb, n_prb, n_dmrs;
   uint32_t max_batch;
   srslte_hip_dmrs_pusch_cfg_t dmrs_cfg;

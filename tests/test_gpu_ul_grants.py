@@ -241,6 +241,54 @@ def test_ul_tx_grants_vs_oracle(hp, prb, sets, tti0, short):
     tx.free()
 
 
+def test_ul_grants_with_puschs_without_ulsch_data(hp):
+    """Per-PUSCH grants with tbs = 0 (a CQI report and no transport block, sch.c:943-975,:1157-1174) next to data-bearing PUSCHs in the same
+    subframes: the transmit call's composite signal = the sum of the oracle's per-UE signals (grid and time samples), and the receive call on
+    it (noise-free) returns every transport block, every report with its CRC flag, every ACK / RI; the rows of the CQI-only PUSCHs report
+    no transport block."""
+    from lte_sim import UlConfig, make_ul_subframe
+    prb, nsf, tti0 = 25, 5, 6
+    rng = np.random.default_rng(5100)
+    dm = dict(cyclic_shift=2, delta_ss=5, group_hopping=True, sequence_hopping=False)
+    ues = [(10, 0, 2, 4008, 0, 1, 0), (4, 12, 1, 0, 20, 1, 1), (3, 18, 1, 0, 6, 2, 0), (2, 22, 2, 1544 // 2 // 8 * 8, 0, 0, 0)]  # L, n_prb, mod, tbs, O_cqi, O_ack, O_ri
+    ues[3] = (2, 22, 2, 776, 0, 0, 0)
+    grants, datas, acks, ris, cqis = [], [], [], [], []
+    exp_iq, exp_grid = np.zeros((nsf, 15 * 384), np.complex128), np.zeros((nsf, 14 * 12 * prb), np.complex128)
+    for b in range(nsf):
+        for u, (L, n0, mod, tbs, O_cqi, O_ack, O_ri) in enumerate(ues):
+            rnti = 0x200 + 8 * b + u
+            cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=(u + b) % 8, rnti=rnti, **dm)
+            ack, ri = tuple(int(v) for v in rng.integers(0, 2, O_ack)), tuple(int(v) for v in rng.integers(0, 2, O_ri))
+            cqi = tuple(int(v) for v in rng.integers(0, 2, O_cqi))
+            k = {}
+            y, data = make_ul_subframe(cfg, tti0 + b, rng, ack=ack, I_offset_ack=9, ri=ri, I_offset_ri=8, cqi=cqi, I_offset_cqi=7, keep=k)
+            exp_iq[b] += y
+            exp_grid[b] += k["grid"]
+            grants.append(hp.UlGrant.make(b, rnti, L, n0, mod, tbs, n_dmrs=(u + b) % 8, ack_len=O_ack, I_offset_ack=9, ri_len=O_ri, I_offset_ri=8,
+                                          cqi_len=O_cqi, I_offset_cqi=7))
+            datas.append(data); acks.append(ack); ris.append(ri); cqis.append(cqi)
+    tx = hp.UlTx(11, prb, 0x1234, 1, 4008, 6, 0, 0, nsf, 2, 5, True, False, max_grants=len(grants))
+    iq = tx.encode_grants(datas, tti0, nsf, grants, ack=acks, ri=ris, cqi=cqis)
+    grid = tx.debug(4, np.complex64, nsf * 14 * 12 * prb).reshape(nsf, -1)
+    for b in range(nsf):
+        close_c(grid[b], exp_grid[b].astype(np.complex64), "grid sf %d" % b)
+        close_c(iq[b], exp_iq[b].astype(np.complex64), "iq sf %d" % b)
+    tx.free()
+    rx = hp.UlRx(11, prb, 0x1234, 1, 4008, 6, 0, 0, 6, nsf, 2, 5, True, False, max_grants=len(grants))
+    tb, ok = rx.decode_grants(iq, tti0, grants)
+    a, r = rx.grants_uci()
+    cq, cq_ok = rx.grants_cqi()
+    for p, g in enumerate(grants):
+        if g.tbs:
+            assert ok[p] and np.array_equal(tb[p, :g.tbs // 8], datas[p]), p
+        else:
+            assert not ok[p], p
+        assert tuple(a[p, :g.ack_len]) == acks[p] and tuple(r[p, :g.ri_len]) == ris[p], p
+        if g.cqi_len:
+            assert cq_ok[p] and tuple(cq[p, :g.cqi_len]) == cqis[p], p
+    rx.free()
+
+
 def test_ul_grants_tx_rx_round_trip(hp):
     """One transmit call makes 64 subframes with three UEs each (changing sizes, modulations, rv 0, HARQ-ACK on one of them); one receive call
     decodes all 192 PUSCHs: every transport block and every ACK comes back."""
