@@ -644,7 +644,8 @@ def test_cbsegm_and_interleaver(hp):
 
 # ---------------------------------------------------------------- end to end
 @pytest.mark.parametrize("prb,mod,tbs,snr,tti0,nsf", [(6, 1, 936, 12.0, 1, 4), (6, 1, 936, 2.5, 1, 4), (100, 3, 75376, 30.0, 8, 4),
-                                                       (100, 3, 75376, 19.0, 9, 3), (100, 4, 97896, 35.0, 4, 3)])
+                                                       (100, 3, 75376, 19.0, 9, 3), (100, 4, 97896, 35.0, 4, 3),
+                                                       (25, 2, 6200, 11.0, 3, 4)])  # 6200: not a 36.213 table size; 2 x 3136, no filler (cbsegm.c:77-107)
 def test_dl_rx_chain(hp, prb, mod, tbs, snr, tti0, nsf):
     """IQ -> TB on the device vs the oracle chain on identical IQ: TB bytes, CRC flags and per-CB iteration counts equal."""
     rng = np.random.default_rng(prb + mod + int(snr * 10))
@@ -927,7 +928,8 @@ def test_chest_ul_pusch_batch(hp, cell_id, prb, L, n_prb):
 
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf", [(6, 6, 0, 1, 1000, 3.5, 2, 4), (25, 10, 5, 2, 4008, 9.5, 8, 4), (100, 100, 0, 2, 43816, 12.5, 0, 3),
                                                                 (100, 48, 20, 3, 30576, 17.0, 7, 3), (100, 100, 0, 2, 43816, 9.0, 5, 2),
-                                                                (25, 1, 7, 1, 104, 4.0, 3, 6), (50, 2, 31, 2, 328, 10.0, 0, 4)])
+                                                                (25, 1, 7, 1, 104, 4.0, 3, 6), (50, 2, 31, 2, 328, 10.0, 0, 4),
+                                                                (50, 30, 4, 2, 6200, 6.0, 1, 3)])  # a non-table size without filler bits
 @pytest.mark.parametrize("short", [False, True])
 def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, short):
     """eNB PUSCH receive chain on the device (cfg3's receive side) vs the oracle chain on identical IQ: grid, ce, noise,
@@ -968,7 +970,7 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, short):
 
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf", [(6, 6, 0, 1, 1000, 2, 4), (25, 10, 5, 2, 4008, 8, 11), (100, 100, 0, 2, 43816, 0, 3),
                                                             (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2),
-                                                            (25, 1, 7, 1, 104, 3, 6), (50, 2, 31, 2, 328, 0, 4)])
+                                                            (25, 1, 7, 1, 104, 3, 6), (50, 2, 31, 2, 328, 0, 4), (50, 30, 4, 2, 6200, 1, 3)])
 @pytest.mark.parametrize("short", [False, True])
 def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf, short):
     """UE PUSCH transmit chain on the device vs the oracle's: code blocks with both CRCs, modulated symbols (exact: the

@@ -1204,6 +1204,49 @@ def test_reference_mbsfn_estimate_without_interpolate_subframe_reads_stale_symbo
     R.srslte_chest_dl_free(q)
 
 
+def _ref_ulsch_round_trip(tbs):
+    """the reference's srslte_ulsch_encode, its q bits as clean LLRs into its srslte_ulsch_decode: (encode return code, decoded ok, bytes equal)"""
+    from lte_sim import RefUlsch, UlConfig
+    cfg = UlConfig(50, 3, 2, 4008, 40, 0)
+    cfg.tbs = tbs
+    chain = RefUlsch(cfg)
+    R = chain.R
+    data = np.random.default_rng(tbs).integers(0, 256, tbs // 8, dtype=np.uint8)
+    chain.pc[chain.rv_off:chain.rv_off + 4].view(np.uint32)[0] = 0
+    chain.pc[chain.sb_off:chain.sb_off + 8].view(np.uint64)[0] = C.addressof(chain.sb_tx)
+    R.srslte_softbuffer_tx_reset(chain.sb_tx)
+    d = np.zeros(tbs // 8 + 64, np.uint8)
+    d[:tbs // 8] = data
+    uci, g, q = np.zeros(4096, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8), np.zeros(cfg.nbits // 8 + 64, np.uint8)
+    rc = R.srslte_ulsch_encode(chain.q, p(chain.pc), p(d), p(uci), p(g), p(q))
+    if rc < 0:
+        out = chain.decode(np.zeros(cfg.nbits, np.int16), np.zeros(cfg.nbits, np.uint8))
+        return rc, out["ok"], False
+    llr = ((2 * np.unpackbits(q)[:cfg.nbits].astype(np.int16) - 1) * 40).astype(np.int16)
+    out = chain.decode(llr, np.zeros(cfg.nbits, np.uint8))
+    return rc, out["ok"], bool(np.array_equal(out["tb"][:tbs // 8], data))
+
+
+def test_reference_refuses_filler_bits_and_cannot_round_trip_two_block_sizes():
+    """Facts about the reference, recorded because the batched pipelines refuse such transport-block sizes (SRSLTE_ERROR + message):
+    (1) a size whose segmentation needs filler bits (36.212 5.1.2 F > 0: e.g. 4016 -> K = 4096) is refused by encode_tb_off and by decode_tb
+    themselves ("Error filler bits are not supported. Use standard TBS", sch.c:193-196,:450-453);
+    (2) a size that segments into TWO block lengths without filler (6264 -> 3200 + 3136; 6392 -> 3264 + 3200) is accepted, but the encoder
+    puts the K2 blocks first (i < C2, sch.c:222-229) and the decoder expects the K1 blocks first (cb_idx < C1, sch.c:318-319), and the two
+    compute the longer blocks' share of the bits differently (sch.c:232-236 vs :331-334): the reference's own noise-free round trip fails.
+    A standard size (4008, and the non-table 6200 = 2 x 3136 exactly) goes through: the harness is sound. No table size of 36.213 needs either."""
+    from _libs import OrcCbsegm
+    assert _ref_ulsch_round_trip(4008) == (0, True, True)
+    assert _ref_ulsch_round_trip(6200) == (0, True, True)
+    rc, ok, same = _ref_ulsch_round_trip(4016)
+    assert rc < 0 and not ok
+    for tbs in (6264, 6392):
+        seg = OrcCbsegm()
+        assert oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 > 0
+        rc, ok, same = _ref_ulsch_round_trip(tbs)
+        assert rc == 0 and not ok and not same
+
+
 def test_reference_cdd_predecoder_on_a_noise_free_channel():
     """Fact about the reference, recorded because tests/test_gpu_dropin.py leaves `phy_dl_test -t 3` out: the reference's own compiled
     large-delay-CDD predecoder (mimo/precoding.c:1067-1102 -> srslte_predecoding_ccd_2x2_mmse[_csi], :915-1065), fed what that test
