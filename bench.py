@@ -528,6 +528,7 @@ def main():
     algorithmic = {"int16_ops_per_launch": int(2 * alg_lane), "lane_instr_per_launch": int(alg_lane),
                    "issued_over_algorithmic": round(valu["lane_instr_per_launch"] / alg_lane, 2) if valu else None,
                    "frac_step": frac(alg_lane / (ms_per_step * 1e-3) / 1e12), "frac_launch": frac(alg_lane / (tdec_ms * 1e-3) / 1e12) if tdec_ms else None,
+                   "frac_alone": frac(alg_lane / (kernels["tdec"]["ms"] * 1e-3) / 1e12),
                    "source": "SURVEY.md 8(d): 80 K int16 ops per SISO pass; K = 5824, %d blocks, %.3f passes" % (n_cb, passes)}
     hbm = {"achieved": round(tdec_alg / (tdec_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(tdec_alg / (tdec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
            "frac_alone": round(tdec_alg / (kernels["tdec"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,

@@ -144,11 +144,17 @@ def _check(rc, what):
 class DevBuf:
     """A device allocation owned through the C ABI."""
 
+    _poison = 0
+
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
         self.ptr = lib().srslte_hip_malloc(self.nbytes)
         if not self.ptr:
             raise MemoryError("srslte_hip_malloc(%d)" % nbytes)
+        if os.environ.get("SRSLTE_HIP_TEST_POISON"):  # tests: every allocation starts with its own byte pattern, so that comparing or
+            DevBuf._poison = (DevBuf._poison * 37 + 11) & 0xFF  # reading bytes nobody wrote fails every time, not once in a while
+            fill = np.full(self.nbytes, DevBuf._poison, np.uint8)
+            _check(lib().srslte_hip_memcpy_h2d(self.ptr, fill.ctypes.data, fill.nbytes), "memcpy_h2d")
 
     @classmethod
     def from_host(cls, arr):
