@@ -1,6 +1,6 @@
 #!/bin/bash
 # Timing experiments on the GPU box: -DTDEC_DEBUG builds of tdec.hip with extra flags per variant ($VARIANTS = "name:flags;name:flags"),
-# decoder time for $DBGS (default 80: six passes, no element-wise phases). Results of the P_EXP_* variants are wrong by construction.
+# decoder time for $DBGS (default 80: six passes, no element-wise phases).
 cd "$(dirname "$0")/../srslte-emane_amd/csrc"
 cp libsrslte_phy_hip.so /tmp/lib_keep.so
 OBJS=$(ls build/*.o | grep -v tdec.o | tr '\n' ' ')
