@@ -21,7 +21,9 @@ Extra objects on that line:
                 Named extras: `frac_step` (per step time: what the chip delivers when launches overlap), `frac_alone` (a launch
                 that has the chip to itself), `frac_vs_measured_issue` (against the packed-int16 issue rate measured on this chip),
                 `algorithmic` (SURVEY §8d's 80 K int16 ops per pass: the fewest lane-instructions the work needs, and how many
-                times that the kernel issues). The HBM figures (algorithmic bytes, PMC traffic) are in `roofline.hbm`.
+                times that the kernel issues). The HBM figures (algorithmic bytes, PMC traffic) are in `roofline.hbm`;
+                `roofline.pipeline_hbm` prices the WHOLE step (decoder + front end, PMC bytes) against 8 TB/s: the pipeline's
+                phases add up in time because they share the memory system (profiles/r03/overlap_probe.txt).
   kernels       every kernel of the chain timed in isolation (HIP events) with its algorithmic bytes
   cpu_baseline  the same chain on the host CPU: the reference's own compiled code (oracle/_ref) driven from a C loop
                 (oracle/refdrv.c; its FFT is the oracle's, FFTW being absent) on one core and on all cores of the box's
@@ -548,7 +550,27 @@ def main():
                 "traffic": traffic, "valu": valu, "algorithmic": algorithmic, "counters_source": traffic_src,
                 "avg_launch_ms": round(tdec_ms, 4) if tdec_ms else None, "avg_launch_ms_alone": kernels["tdec"]["ms"], "hbm": hbm,
                 "note": "serial-trellis integer kernel: VALU-issue bound, not HBM-bound (SURVEY 8d); the HBM-bound streaming kernels are in 'kernels' / 'kernels_large_batch'"}
-    for v in (roofline["frac"], roofline["frac_step"], roofline["frac_alone"], hbm["frac"] if hbm else None):
+    # The pipeline as a whole against the HBM: bytes per step by the committed PMC passes (decoder: tdec_counters.json; the five front-end
+    # kernels' batch-128 launches: kernels_by_grid.json, same rocprofv3 runs) / the measured step time. profiles/r03/overlap_probe.txt shows
+    # why this is the figure to read: decoder-only and front-end-only steady states ADD up to the pipeline's step time - what they share is
+    # the memory system.
+    pipeline_hbm = None
+    kpath = os.path.join(PROFILE_DIR, "kernels_by_grid.json")
+    if traffic and os.path.exists(kpath) and not args.llr8 and not args.grants:
+        with open(kpath) as f:
+            rows = json.load(f).get("rows", [])
+        fe = {}
+        for r_ in rows:  # the launches of the timed loop: several hundred per grid size (the batch-2048 launches number a handful)
+            if r_.get("launches", 0) >= 100 and r_.get("traffic_MB") and r_["kernel"] != kernel_name and not r_["kernel"].startswith("__amd"):
+                fe[r_["kernel"]] = r_["traffic_MB"]
+        if fe:
+            per_step = traffic + sum(fe.values()) * 1e6
+            pipeline_hbm = {"bound": "hbm", "traffic_bytes_per_step": int(per_step), "decoder_bytes": int(traffic), "front_end_MB": {k: round(v, 1) for k, v in fe.items()},
+                            "achieved": round(per_step / (ms_per_step * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(per_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "source": "profiles/r03/tdec_counters.json + kernels_by_grid.json (2 x FETCH_SIZE + WRITE_SIZE per launch), batch %d" % B}
+    roofline["pipeline_hbm"] = pipeline_hbm
+    for v in (roofline["frac"], roofline["frac_step"], roofline["frac_alone"], hbm["frac"] if hbm else None, pipeline_hbm["frac"] if pipeline_hbm else None):
         assert v is None or 0 <= v <= 1, "a roofline fraction above 1 is a measurement error"
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
