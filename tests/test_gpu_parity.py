@@ -561,6 +561,36 @@ def test_tdec_two_blocks_per_wavefront_mapping(hp, K, ncb, sb):
     dec.free()
 
 
+def test_tdec_two_blocks_per_wavefront_every_block_length(hp):
+    """Every LTE block length that takes the 16-window decoder (36.212 Table 5.1.3-3, K = 816 .. 6144: window lengths 51 .. 384, every
+    remainder of the 12-step segments and of the trellis phases, every interleaver) through tdec_pair_kernel and through the state-per-lane
+    kernel of rounds 1-2 on the same three noisy code words (an odd count: the last wavefront runs with a shadow slot; SNRs such that
+    the blocks stop after different numbers of passes): bytes, pass counts and CRC flags identical."""
+    L = hp.lib()
+    sizes = [K for K in list(range(40, 512, 8)) + list(range(512, 1024, 16)) + list(range(1024, 2048, 32)) + list(range(2048, 6145, 64))
+             if L.srslte_hip_tdec_autoimp_get_subblocks(K) == 16]
+    assert len(sizes) > 90 and sizes[0] == 816 and sizes[-1] == 6144
+    dec = hp.Tdec(6144, 4)
+    spread = set()
+    for K in sizes:
+        rng = np.random.default_rng(K)
+        w = np.zeros((3, 3 * K + 12), np.int16)
+        for i in range(3):
+            payload = rng.integers(0, 256, (K - 24) // 8, dtype=np.uint8)
+            crc = oracle().orc_crc_bytes(0x1800063, 24, p(payload), K - 24)
+            bits = np.unpackbits(np.concatenate([payload, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)]))
+            enc = np.zeros(3 * K + 12, np.uint8)
+            oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+            w[i] = _noisy_llr(rng, enc, (4.0, -1.0, -3.5)[i], 60)
+        rc, out, iters, ok = dec.run_all(w, K, 6, sb_layout=False, crc_poly=hp.CRC24B, crc_nbits=K, force_subblocks=16)
+        rc2, out2, iters2, ok2 = dec.run_all(w, K, 6, sb_layout=False, crc_poly=hp.CRC24B, crc_nbits=K, force_subblocks=3016)
+        assert rc == 0 and rc2 == 0
+        assert np.array_equal(iters, iters2) and np.array_equal(ok, ok2) and np.array_equal(out, out2), (K, iters, iters2)
+        spread.update(iters.tolist())
+    assert len(spread) >= 4  # early and late stops both occurred
+    dec.free()
+
+
 @pytest.mark.parametrize("K", [40, 408, 800, 816, 1008, 2048, 2112, 3136, 5824, 6144])
 def test_tdec_run_all_8bit(hp, K):
     """srslte_tdec_run_all_8bit (turbodecoder.c:573-588): avx8 for K > 2048, sse8 for K > 800, widening fall-backs below."""
