@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """What the front-end kernels cost the decoder when batches overlap: N pipeline instances on N streams, steady state,
-(a) all six stages per step, (b) only the turbo decoder + TB stage (stages 4, 5) per step, (c) only stages 0-3.
+(a) all six stages per step, (b) only the turbo decoder + TB stage (stages 4, 5) per step, (c) only the decoder: back-to-back launches
+of the one kernel on every stream, (d) only stages 0-3.
   python scripts/overlap_probe.py [streams] [batch]"""
 import importlib
 import os
@@ -29,7 +30,7 @@ tst = [torch.cuda.Stream() for _ in range(ns)]
 for s in range(ns):
     assert rxs[s].run_device(iq.data_ptr(), 0, B, tst[s].cuda_stream) == 0
 torch.cuda.synchronize()
-for name, stages in (("all six stages", range(6)), ("decoder + TB only", (4, 5)), ("front end only (0-3)", range(4))):
+for name, stages in (("all six stages", range(6)), ("decoder + TB only", (4, 5)), ("decoder only (4)", (4,)), ("front end only (0-3)", range(4))):
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
