@@ -359,6 +359,9 @@ def main():
     good, wrong, rec0 = checks[0]
     instances_agree = all(np.array_equal(c[2], rec0) for c in checks)  # same input on every instance: same records
     iters = rx.debug(13 if args.grants else 6, np.uint32, B * 13)
+    # the decoder runs two code blocks per wavefront, in lockstep: a wavefront runs as many passes as the slower of its two blocks
+    pass_hist = [int((iters == n).sum()) for n in range(7)]
+    passes_per_wavefront = float(np.maximum(iters[0::2], iters[1::2]).mean()) if not args.llr8 and iters.size % 2 == 0 else None
     good_all, wrong_all, n_all, it_all, agree_all = sharding.reduce_counts([good, wrong, B, int(iters.sum()), int(instances_agree)], dist if world > 1 else None, cdev)
     # rank 0: the host copy of the gathered records holds every rank's record in rank order
     gather_ok = None
@@ -580,6 +583,8 @@ def main():
                                "soft demap + rate dematch + turbo max 6 SISO passes with CRC early stop + TB CRC + results to rank 0's host memory" % B,
                    "snr_db": args.snr, "bler": round(1 - good_all / n_all, 4), "undetected_errors": wrong_all,
                    "avg_siso_passes_per_cb": round(passes, 3),
+                   "siso_passes_histogram_0_to_6": pass_hist,
+                   "avg_siso_passes_per_wavefront": round(passes_per_wavefront, 3) if passes_per_wavefront is not None else None,
                    "sharding": "one UE per GPU; one gather of TBs + CRC flags per batch to rank 0 (%s), inside the timed region" % ("RCCL" if on_device else args.backend)
                    if world > 1 else "one UE per GPU; single GPU: results copied to host inside the timed region",
                    "entry_point": "srslte_hip_dl_rx_batch_grants (a grant per subframe)" if args.grants else "srslte_hip_dl_rx_stage x 6 (one fixed grant)",
