@@ -350,15 +350,20 @@ __device__ __forceinline__ StRegs stage_load(const Src& S, const Stage& st, int 
   r.b = *reinterpret_cast<const int4*>(S.y + off);
   return r;
 }
+// AR (the 8-bit back-ends with 16 / 32 windows): the y rows come straight from the parity array (int8 values in int16 containers) and move
+// to the high bytes HERE, where the row is consumed - not behind the load, which would wait for it (the rows are requested two blocks
+// ahead). The combine pass then reads and writes one array less. (Forming x = sat(a-priori + systematic) here as well, i.e. no combine
+// pass at all, is bit-exact too but takes the kernel from 168 to 242 VGPRs: profiles/r03/ab_llr8_staging.txt.)
+template <int AR = 0>
 __device__ __forceinline__ void stage_store(const Stage& st, int buf, int n, const StRegs& r)
 {
   if (st.sj < n) {
-    pk_t* d = st.lds + buf * ST_BUF + st.sj * 8 + st.sp * 4;
+    pk_t*      d = st.lds + buf * ST_BUF + st.sj * 8 + st.sp * 4;
+    const int4 y = AR ? make_int4((r.b.x & 0x00FF00FF) << 8, (r.b.y & 0x00FF00FF) << 8, (r.b.z & 0x00FF00FF) << 8, (r.b.w & 0x00FF00FF) << 8) : r.b;
     *reinterpret_cast<int4*>(d)              = r.a;
-    *reinterpret_cast<int4*>(d + ST_ARR)     = r.b;
+    *reinterpret_cast<int4*>(d + ST_ARR)     = y;
     // x + y (turbodecoder_win.h:472-491), saturating; for the 8-bit back-ends a 0x7fff here is harmless (see M8)
-    *reinterpret_cast<int4*>(d + 2 * ST_ARR) =
-        make_int4(pk_add<true>(r.a.x, r.b.x), pk_add<true>(r.a.y, r.b.y), pk_add<true>(r.a.z, r.b.z), pk_add<true>(r.a.w, r.b.w));
+    *reinterpret_cast<int4*>(d + 2 * ST_ARR) = make_int4(pk_add<true>(r.a.x, y.x), pk_add<true>(r.a.y, y.y), pk_add<true>(r.a.z, y.z), pk_add<true>(r.a.w, y.w));
   }
   // One wavefront per workgroup and the LDS executes a wave's instructions in order: the reads that follow see these writes.
   // Only the compiler has to be kept from reordering them; a __syncthreads() here would also drain vmcnt, i.e. wait for the
@@ -393,7 +398,7 @@ __device__ __forceinline__ void win_run(const LaneGeom& L, pk_t& v, const Src& S
   if (nb > 1) r2 = stage_load<G>(S, st, lo(1), BLK);
   for (int b = 0; b < nb; b++) {
     const int k0 = k_first + DIR * BLK * b, n0 = n_first + DIR * BLK * b, buf = b & 1;
-    stage_store(st, buf, BLK, r);
+    stage_store<(W == 8 ? 0 : AR)>(st, buf, BLK, r);
     r = r2;
     if (b + 2 < nb) r2 = stage_load<G>(S, st, lo(b + 2), BLK);
     pk_t c[BLK];
@@ -437,7 +442,7 @@ __device__ __forceinline__ void win_rem(const LaneGeom& L, pk_t& v, const Src& S
   constexpr int G = pairs_per_step<W>();
   if (r <= 0) return;
   const int k_lo = DIR > 0 ? k_first : k_first - (r - 1);
-  stage_store(st, 0, r, stage_load<G>(S, st, k_lo, r));
+  stage_store<(W == 8 ? 0 : AR)>(st, 0, r, stage_load<G>(S, st, k_lo, r));
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     if (j < r) {
@@ -514,7 +519,8 @@ __device__ __forceinline__ void win_siso(const LaneGeom& L, const int16_t* __res
   const int      NE     = G * Lw;
   pk_t *         Xb = scratch + NE, *Yb = scratch + 2 * NE;
   const pk_t*    Xs = DIRECT && !app ? reinterpret_cast<const pk_t*>(in) : Xb;
-  const pk_t*    Ys = DIRECT ? reinterpret_cast<const pk_t*>(par) : Yb;
+  constexpr bool Y_INPLACE = DIRECT || (AR && W != 8); // the parity array already is the y array (8-bit: up to the byte move of stage_store)
+  const pk_t*    Ys = Y_INPLACE ? reinterpret_cast<const pk_t*>(par) : Yb;
   if constexpr (W == 8) {
     batched<8>(
         L.lane, NE, [&](int i) { return I3{ld_pair<W, AR>(in, i), app ? ld_pair<W, AR>(app, i) : 0, ld_pair<W, AR>(par, i)}; },
@@ -532,11 +538,11 @@ __device__ __forceinline__ void win_siso(const LaneGeom& L, const int16_t* __res
     int4 *      X4 = reinterpret_cast<int4*>(Xb), *Y4 = reinterpret_cast<int4*>(Yb);
     batched<TDEC_EWU>(
         L.lane, NE / 4,
-        [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), DIRECT ? make_int4(0, 0, 0, 0) : hi8(par4[i])}; },
+        [&](int i) { return Q3{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0), Y_INPLACE ? make_int4(0, 0, 0, 0) : hi8(par4[i])}; },
         [&](int i, Q3 t) {
           const int4 x = app ? make_int4(s_add<AR>(t.b.x, t.a.x), s_add<AR>(t.b.y, t.a.y), s_add<AR>(t.b.z, t.a.z), s_add<AR>(t.b.w, t.a.w)) : t.a;
           X4[i] = x;
-          if (!DIRECT) Y4[i] = t.c;
+          if (!Y_INPLACE) Y4[i] = t.c;
         });
   }
   __syncthreads();
@@ -661,7 +667,7 @@ __device__ __forceinline__ void win_siso(const LaneGeom& L, const int16_t* __res
     if (nf > 1) sr2 = stage_load<G>(S[h], st, CKPT, CKPT);
     for (int j = 0; j < nf; j++) {
       const int k0 = CKPT * j, buf = j & 1;
-      stage_store(st, buf, CKPT, sr);
+      stage_store<(W == 8 ? 0 : AR)>(st, buf, CKPT, sr);
       sr = sr2;
       if (j + 2 < nf) sr2 = stage_load<G>(S[h], st, k0 + 2 * CKPT, CKPT); // two segments of rows in flight
       pk_t c[CKPT];
@@ -705,7 +711,7 @@ __device__ __forceinline__ void win_siso(const LaneGeom& L, const int16_t* __res
     { // last, shorter segment [CKPT*nf, Lw): run-time phases, same scheme
       const int k0 = CKPT * nf, t = Lw - k0;
       if (t > 0) {
-        stage_store(st, 0, t, stage_load<G>(S[h], st, k0, t));
+        stage_store<(W == 8 ? 0 : AR)>(st, 0, t, stage_load<G>(S[h], st, k0, t));
         const pk_t Btop = bh[top * 64 + L.lane];
         pk_t       vb   = Btop, dummy = 0;
         for (int i = t - 1; i >= 1; i--) {
