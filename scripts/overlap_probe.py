@@ -30,7 +30,7 @@ tst = [torch.cuda.Stream() for _ in range(ns)]
 for s in range(ns):
     assert rxs[s].run_device(iq.data_ptr(), 0, B, tst[s].cuda_stream) == 0
 torch.cuda.synchronize()
-for name, stages in (("all six stages", range(6)), ("decoder + TB only", (4, 5)), ("decoder only (4)", (4,)), ("front end only (0-3)", range(4))):
+for name, stages in (("all six stages", range(6)), ("all but the TB stage", range(5)), ("decoder + TB only", (4, 5)), ("decoder only (4)", (4,)), ("front end only (0-3)", range(4))):
     for rep in range(2):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
