@@ -30,3 +30,37 @@ def test_streaming_kernel_fractions_have_a_rocprof_record():
         grids.setdefault(r["kernel"], set()).add(r["grid_size"])
     assert any(len(g) >= 2 for n, g in grids.items() if "ofdm_rx_kernel" in n), "batch-128 and batch-2048 launches of the OFDM demodulator"
     assert all(r["rocprof_avg_us_default"] > 0 for r in k["rows"])
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The line `python bench.py` printed on the final source (profiles/r03/final_bench.json): the contract's fields, BASELINE.json's metric
+    and workload, fractions that can be recomputed from the numbers beside them, and the rocprof record they rest on."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03", "final_bench.json")))
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "subframes/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["vs_baseline"] is None  # BASELINE.md holds no published number for this metric
+    assert "subframes/s" in json.dumps(base) and "batch=128" in d["config"]["workload"] and "model" not in d["config"]
+    # whole-job throughput = subframes of K steps / their time
+    assert abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+    assert abs(r["achieved"] - r["valu"]["lane_instr_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) < 0.02  # instructions / the launch's own duration
+    c = json.load(open(os.path.join(ROOT, "profiles", "r03", "tdec_counters.json")))
+    assert r["counters_source"]["tdec_src_sha"] == c["tdec_src_sha"] and r["traffic"] == c["traffic_bytes_per_launch"]
+    # the event-timed launch duration of the line and rocprof's average for the same kernel in the same command agree
+    assert abs(r["avg_launch_ms"] * 1e6 - c["rocprof_avg_ns_default"]) / c["rocprof_avg_ns_default"] < 0.1
+    p = r["pipeline_hbm"]
+    assert p["bound"] == "hbm" and abs(p["frac"] - p["achieved"] / p["peak"]) < 2e-3 and p["frac"] <= 1
+    assert abs(p["achieved"] - p["traffic_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9) / p["achieved"] < 0.01
+    cb = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cb, key
+    assert cb["kind"] in ("reference", "port") and cb["unit"] == d["unit"] and cb["cores"] >= 1 and cb["value"] > 0
+    cfg = d["config"]
+    assert cfg["undetected_errors"] == 0 and cfg["results_on_host_verified"] is True and cfg["pipeline_instances_verified"] == cfg["streams"]
+    assert sum(cfg["siso_passes_histogram_0_to_6"]) == 128 * 13 and cfg["avg_siso_passes_per_wavefront"] >= cfg["avg_siso_passes_per_cb"]
