@@ -300,7 +300,9 @@ int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
  * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +
  * descramble + UL channel de-interleaver (pusch.c:423-520, sch.c:891-913,:991-1066) -> rate de-matching -> turbo decode -> TB CRC.
  * UL-SCH with optional HARQ-ACK / RI / CQI multiplexing (cfg fields below), one grant per object (optionally hopping between the slots), normal CP,
- * 16-bit LLRs; redundancy versions and soft combining through srslte_hip_ul_rx_batch_harq. */
+ * 16-bit LLRs (pusch.llr_is_8bit has no counterpart here: with it the reference hands int8 LLRs to an int16 channel deinterleaver,
+ * pusch.c:481-503 / sch.c:890-918, and fails its own noise-free round trip - tests/test_oracle_vs_ref.py); redundancy versions and soft
+ * combining through srslte_hip_ul_rx_batch_harq. */
 typedef struct srslte_hip_ul_rx srslte_hip_ul_rx_t;
 typedef struct {
   uint32_t cell_id, nof_prb;

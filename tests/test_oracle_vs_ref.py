@@ -1247,6 +1247,35 @@ def test_reference_refuses_filler_bits_and_cannot_round_trip_two_block_sizes():
         assert rc == 0 and not ok and not same
 
 
+def test_reference_8bit_pusch_receive_cannot_decode_a_clean_transmission():
+    """Fact about the reference, recorded because the uplink receive pipelines have no 8-bit LLR option although srsenb can select one
+    (`expert.pusch_8bit_decoder`, "Experimental": srsenb/src/phy/sf_worker.cc:148-149 sets pusch.llr_is_8bit and ul_sch.llr_is_8bit).
+    With the flag, srslte_pusch_decode demaps and descrambles into int8 LLRs (pusch.c:481-500) and hands the buffer to
+    srslte_ulsch_decode as int16_t* (pusch.c:503); uci_decode_ri_ack and ulsch_deinterleave (srslte_vec_lut_sis, sch.c:890-918,:1014-1034)
+    move int16 ELEMENTS - two int8 LLRs at a time, to twice the byte offset - and decode_tb then reads the result as int8
+    (srslte_rm_turbo_rx_lut_8bit, sch.c:336-340): the channel deinterleaver is not inverted. The reference's own noise-free round trip,
+    fed exactly as pusch.c feeds it, fails with the flag and passes without: there is no working 8-bit PUSCH chain upstream to be equal to."""
+    from _libs import ref_layout
+    from lte_sim import RefUlsch, UlConfig
+    cfg = UlConfig(50, 3, 2, 4008, 40, 0)
+    flag = ref_layout({"srslte_sch_t": ["llr_is_8bit"]}, ["srslte/phy/phch/sch.h"])["srslte_sch_t.llr_is_8bit"]
+    data = np.random.default_rng(8).integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    res = {}
+    for llr8 in (False, True):
+        chain = RefUlsch(cfg)
+        _, q = chain.encode(data)
+        C.cast(C.addressof(chain.q) + flag, C.POINTER(C.c_uint8))[0] = 1 if llr8 else 0
+        llr = (2 * q.astype(np.int16) - 1) * 40
+        if llr8:  # int8 LLRs at the start of the buffer, the rest of it as the demapper's buffer is left: whatever was there (here zeros)
+            buf = np.zeros(cfg.nbits, np.int16)
+            buf.view(np.int8)[:cfg.nbits] = llr.astype(np.int8)
+            llr = buf
+        out = chain.decode(llr, np.zeros(cfg.nbits, np.uint8))
+        res[llr8] = (out["ok"], bool(np.array_equal(out["tb"][:cfg.tbs // 8], data)))
+    assert res[False] == (True, True)
+    assert res[True] == (False, False)
+
+
 def test_reference_cdd_predecoder_on_a_noise_free_channel():
     """Fact about the reference, recorded because tests/test_gpu_dropin.py leaves `phy_dl_test -t 3` out: the reference's own compiled
     large-delay-CDD predecoder (mimo/precoding.c:1067-1102 -> srslte_predecoding_ccd_2x2_mmse[_csi], :915-1065), fed what that test
