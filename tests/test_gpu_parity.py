@@ -746,6 +746,63 @@ def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
     rx.free()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_dl_rx_chain_drawn_configurations(hp, seed):
+    """test_dl_rx_chain on configurations DRAWN from the space the pipeline accepts instead of listed: bandwidth, cell id, RNTI, CFI-independent
+    modulation, a transport-block size that is not taken from a table (any multiple of 8 that segments into one block length without filler,
+    cbsegm.c:77-107) at a drawn code rate, a drawn first TTI and an SNR a few dB either side of the waterfall; 16- and 8-bit LLRs, one and
+    two receive antennas. TB bytes, CRC flags and per-block pass counts equal the oracle chain's on identical samples."""
+    from _libs import OrcCbsegm, OrcSchCfg
+    rng = np.random.default_rng(7000 + seed)
+    prb = int(rng.choice([6, 15, 25, 50]))
+    mod = int(rng.choice([1, 2, 3]))
+    llr8, nrx = bool(seed % 3 == 2), 1 + int(seed % 4 == 1)
+    cell_id, rnti = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0))
+    probe = DlConfig(prb, cell_id, mod, 16, rnti=rnti)
+    nbits = min(len(probe.indices(s)) for s in (0, 1, 5)) * probe.Qm
+    rate = float(rng.uniform(0.25, 0.8))
+    tbs = max(40, int(rate * nbits) // 8 * 8)
+    while True:  # the next size below that needs neither filler bits nor two block lengths
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = DlConfig(prb, cell_id, mod, tbs, rnti=rnti, nof_rx=nrx, llr8=llr8)
+    tti0, nsf = int(rng.integers(0, 10240)), 3
+    # rough waterfall of a rate-r code at this modulation, +- a few dB: some blocks fail, some pass, either is fine - equality is the test
+    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / nbits - 0.4) + float(rng.uniform(-2.0, 4.0)) - (3.0 if nrx == 2 else 0.0)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(cell_id, prb, 1, rnti, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8, nof_rx=nrx)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    it = rx.debug(6, np.uint32, nsf * cfg.seg.C).reshape(nsf, -1)
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+    n_diff = n_tot = 0
+    for b in range(nsf):
+        what = (prb, mod, tbs, nrx, llr8, tti0 + b, snr)
+        r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+        # floating-point part (OFDM, estimator, equaliser, demapper): LLRs within one LSB of the oracle's, on at most one in a thousand
+        nb = rx.nof_re((tti0 + b) % 10) * cfg.Qm
+        e = np.ascontiguousarray(e_all[b, :nb])
+        diff = np.abs(e.astype(np.int32) - r["e"].astype(np.int32))
+        assert len(r["e"]) == nb and diff.max() <= 1, what
+        n_diff += int((diff != 0).sum())
+        n_tot += nb
+        # integer part (rate de-matching, turbo decoder, CRCs, assembly): the oracle's back end on the DEVICE's LLRs - exact, also for a
+        # transport block that fails (one LSB on one LLR changes the bytes of a block that does not converge)
+        sch = OrcSchCfg(tbs, nb, cfg.Qm_sch, 0, cfg.max_iter)
+        otb, oit, ocb = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+        rc = (oracle().orc_dlsch_decode_8bit if llr8 else oracle().orc_dlsch_decode)(C.byref(sch), p(e), p(otb), p(oit), p(ocb))
+        assert bool(ok[b]) == (rc == 0) and np.array_equal(it[b], oit) and np.array_equal(tb[b], otb[:tbs // 8 + 3]), what
+        if ok[b]:
+            assert np.array_equal(tb[b][:tbs // 8], data[b]), what
+        if not diff.any():  # identical LLRs: the oracle chain end to end says the same
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]) and np.array_equal(tb[b], r["tb"]), what
+    assert n_diff <= 1e-3 * n_tot, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
+    rx.free()
+
+
 def test_cfg4_multi_ue(hp):
     """several UEs, each with its own cell id and RNTI (CRS position/sequence, scrambling, RE map differ)."""
     for u, (prb, mod, tbs, snr) in enumerate([(100, 3, 75376, 24.0), (100, 3, 75376, 21.0), (6, 1, 936, 6.0), (25, 2, 11448, 16.0)]):
