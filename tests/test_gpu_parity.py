@@ -1055,6 +1055,66 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, short):
     rx.free()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_ul_rx_chain_drawn_configurations(hp, seed):
+    """test_ul_rx_chain on configurations DRAWN from what the pipeline accepts: bandwidth, cell id, RNTI, an allocation of 2^a 3^b 5^c PRBs at a
+    drawn offset (with or without hopping between the slots), modulation, DMRS cyclic shifts and group / sequence hopping, a transport-block
+    size not taken from a table at a drawn code rate, shortened subframes, a drawn first TTI, an SNR around the waterfall. The float stages
+    (OFDM, estimator, equaliser, transform de-precoding, demapper) stay within one LSB of the oracle's LLRs on at most 1 in 1000; the integer
+    back end (rate de-matching, turbo decoder, CRCs) equals the oracle's run on the DEVICE's LLRs exactly, failing blocks included."""
+    from _libs import OrcCbsegm, OrcSchCfg
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(7100 + seed)
+    prb = int(rng.choice([6, 15, 25, 50, 100]))
+    sizes = [n for n in range(1, prb + 1) if _is_235(n)]
+    L = int(rng.choice(sizes))
+    n_prb = int(rng.integers(0, prb - L + 1))
+    hop = None if seed % 3 else int(rng.integers(0, prb - L + 1))
+    mod = int(rng.choice([1, 2, 3]))
+    short, ghop, shop = bool(seed % 2), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and L >= 6
+    cell_id, rnti, n_dmrs, cs, dss = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(0, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 30))
+    probe = UlConfig(prb, cell_id, mod, 16, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, shortened=short)
+    tbs = max(16, int(float(rng.uniform(0.2, 0.75)) * probe.nbits) // 8 * 8)
+    while True:  # the next size below that needs neither filler bits nor two block lengths
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = UlConfig(prb, cell_id, mod, tbs, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, cyclic_shift=cs, delta_ss=dss, n_prb_slot1=hop, group_hopping=ghop,
+                   sequence_hopping=shop, shortened=short)
+    tti0, nsf = int(rng.integers(0, 10240)), 3
+    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / cfg.nbits - 0.4) + float(rng.uniform(-2.0, 4.0)) + (3.0 if L < 3 else 0.0)
+    iq, data = zip(*[make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.9 * np.exp(-0.4j)) for b in range(nsf)])
+    rx = hp.UlRx(cell_id, prb, rnti, mod, tbs, L, n_prb, n_dmrs, 6, nsf, cs, dss, ghop, shop, shortened=short, n_prb_slot1=hop)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    it = rx.debug(6, np.uint32, nsf * cfg.seg.C).reshape(nsf, -1)
+    g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+    n_diff = 0
+    for b in range(nsf):
+        what = (prb, L, n_prb, hop, mod, tbs, short, ghop, shop, tti0 + b, snr)
+        r = oracle_ul_rx(cfg, iq[b], tti0 + b, keep=True)
+        diff = np.abs(g[b].astype(np.int32) - r["g"].astype(np.int32))
+        assert diff.max() <= 1, what
+        n_diff += int((diff != 0).sum())
+        sch = OrcSchCfg(tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+        otb, oit, ocb = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+        rc = oracle().orc_dlsch_decode(C.byref(sch), p(np.ascontiguousarray(g[b])), p(otb), p(oit), p(ocb))
+        assert bool(ok[b]) == (rc == 0) and np.array_equal(it[b], oit) and np.array_equal(tb[b], otb[:tbs // 8 + 3]), what
+        if ok[b]:
+            assert np.array_equal(tb[b][:tbs // 8], data[b]), what
+        if not diff.any():
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]) and np.array_equal(tb[b], r["tb"]), what
+    assert n_diff <= max(4, 1e-3 * nsf * cfg.nbits)  # a one-PRB allocation has 792 LLRs per subframe: a floor of four
+    rx.free()
+
+
+def _is_235(n):
+    for f in (2, 3, 5):
+        while n % f == 0:
+            n //= f
+    return n == 1
+
+
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf", [(6, 6, 0, 1, 1000, 2, 4), (25, 10, 5, 2, 4008, 8, 11), (100, 100, 0, 2, 43816, 0, 3),
                                                             (100, 100, 0, 3, 75376, 4, 3), (100, 48, 20, 3, 30576, 7, 3), (15, 3, 12, 1, 328, 9, 2),
                                                             (25, 1, 7, 1, 104, 3, 6), (50, 2, 31, 2, 328, 0, 4), (50, 30, 4, 2, 6200, 1, 3)])
