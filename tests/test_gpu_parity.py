@@ -1730,6 +1730,51 @@ def test_dl_tx_chain(hp, prb, mod, tbs, npt, tti0, nsf, rv, p_a):
     tx.free()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_dl_tx_chain_drawn_configurations(hp, seed):
+    """test_dl_tx_chain on configurations drawn from what the transmit pipeline accepts: bandwidth, cell id, RNTI, 1 / 2 / 4 ports, modulation, a
+    transport-block size not taken from a table (one block length, no filler) at a drawn code rate, redundancy version, power offset, first TTI."""
+    from lte_sim import DlConfig, make_subframe
+    from _libs import OrcCbsegm, OrcOfdm
+    rng = np.random.default_rng(7200 + seed)
+    prb, mod, npt = int(rng.choice([6, 15, 25, 50, 100])), int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2, 4]))
+    cell_id, rnti, rv = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(0, 4))
+    p_a = float(rng.choice([0.0, -3.0, 1.77, -1.0]))
+    probe = DlConfig(prb, cell_id, mod, 16, rnti=rnti, nof_ports=npt)
+    nbits = min(len(probe.indices(s)) for s in (0, 1, 5)) * probe.Qm
+    tbs = max(40, int(float(rng.uniform(0.2, 0.85)) * nbits) // 8 * 8)
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = DlConfig(prb, cell_id, mod, tbs, rnti=rnti, nof_ports=npt, p_a=p_a)
+    tti0, nsf = int(rng.integers(0, 10240)), 3
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.DlTx(cell_id, prb, 1, rnti, mod, tbs, nsf, npt, p_a)
+    iq = tx.encode(data, tti0, rv)
+    max_re = max(len(cfg.indices(s)) for s in (0, 1, 5))
+    y = tx.debug(2, np.complex64, nsf * npt * max_re).reshape(nsf, npt, -1)
+    grid = tx.debug(3, np.complex64, nsf * npt * cfg.grid_len).reshape(nsf, npt, -1)
+    q = OrcOfdm()
+    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    q.normalize = True
+    for b in range(nsf):
+        k = {}
+        make_subframe(cfg, tti0 + b, rng, rv=rv, data=data[b], keep=k)
+        for port in range(npt):
+            what, ye = (prb, mod, npt, cell_id, tbs, rv, p_a, tti0 + b, port), k["y"][port]
+            assert np.abs(y[b, port, :len(ye)] - ye).max() <= 3e-7 * max(1.0, cfg.scaling), what
+            exp = np.zeros(cfg.grid_len, np.complex64)
+            exp[k["idx"]] = ye
+            oracle().orc_crs_put_sf(C.byref(cfg.cell), (tti0 + b) % 10, port, p(exp))
+            assert np.abs(grid[b, port] - exp).max() <= 3e-7 * max(1.0, cfg.scaling), what
+            iq_o = np.zeros(cfg.sf_len, np.complex64)
+            oracle().orc_ofdm_tx_sf(C.byref(q), p(exp), p(iq_o))
+            assert_close_c(iq[b, port], iq_o, "iq %s" % (what,))
+    tx.free()
+
+
 @pytest.mark.parametrize("npt,nrx", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2)])
 def test_dl_tx_rx_loop(hp, npt, nrx):
     """Device transmit chain into the device receive chain (noise-free; the ports of a 2-port cell reach the antennas with different
