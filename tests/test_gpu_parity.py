@@ -1142,6 +1142,46 @@ def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf, short):
     tx.free()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_ul_tx_chain_drawn_configurations(hp, seed):
+    """test_ul_tx_chain on configurations drawn from what the transmit pipeline accepts (the draw of test_ul_rx_chain_drawn_configurations):
+    modulated symbols exactly, transform-precoded symbols, grid with DMRS and time samples to the float tolerance of the other tests."""
+    from _libs import OrcCbsegm
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(7300 + seed)
+    prb = int(rng.choice([6, 15, 25, 50, 100]))
+    L = int(rng.choice([n for n in range(1, prb + 1) if _is_235(n)]))
+    n_prb = int(rng.integers(0, prb - L + 1))
+    hop = None if seed % 3 else int(rng.integers(0, prb - L + 1))
+    mod = int(rng.choice([1, 2, 3]))
+    short, ghop, shop = bool(seed % 2), bool(rng.integers(0, 2)), bool(rng.integers(0, 2)) and L >= 6
+    cell_id, rnti, n_dmrs, cs, dss = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(0, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 30))
+    probe = UlConfig(prb, cell_id, mod, 16, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, shortened=short)
+    tbs = max(16, int(float(rng.uniform(0.2, 0.85)) * probe.nbits) // 8 * 8)
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = UlConfig(prb, cell_id, mod, tbs, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, cyclic_shift=cs, delta_ss=dss, n_prb_slot1=hop, group_hopping=ghop,
+                   sequence_hopping=shop, shortened=short)
+    tti0, nsf = int(rng.integers(0, 10240)), 3
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    tx = hp.UlTx(cell_id, prb, rnti, mod, tbs, L, n_prb, n_dmrs, nsf, cs, dss, ghop, shop, shortened=short, n_prb_slot1=hop)
+    iq = tx.encode(data, tti0)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    z = tx.debug(3, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    grid = tx.debug(4, np.complex64, nsf * cfg.grid_len).reshape(nsf, -1)
+    for b in range(nsf):
+        k, what = {}, (prb, L, n_prb, hop, mod, tbs, short, ghop, shop, cell_id, tti0 + b)
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k)
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), what
+        assert_close_c(z[b], k["z"], "z %s" % (what,))
+        assert_close_c(grid[b], k["grid"], "grid %s" % (what,))
+        assert_close_c(iq[b], iq_o, "iq %s" % (what,))
+    tx.free()
+
+
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,tti0,nsf,O,Ioff,short", [(25, 10, 5, 2, 4008, 8, 6, 1, 9, False), (25, 10, 5, 2, 4008, 1, 6, 2, 9, False),
                                                                         (6, 6, 0, 1, 1000, 2, 4, 2, 5, True), (100, 48, 20, 3, 30576, 7, 4, 1, 12, False),
                                                                         (100, 100, 0, 3, 75376, 4, 4, 2, 14, True), (25, 1, 7, 1, 104, 3, 4, 2, 10, False),
