@@ -385,6 +385,20 @@ def test_tcod_encode(hp, K):
         assert np.array_equal(out[i], ref), "tcod K=%d block %d" % (K, i)
 
 
+def test_tcod_encode_every_block_length(hp):
+    """All 188 block lengths of 36.212 Table 5.1.3-3 (every QPP interleaver) through the device encoder against the oracle's."""
+    sizes = list(range(40, 512, 8)) + list(range(512, 1024, 16)) + list(range(1024, 2048, 32)) + list(range(2048, 6145, 64))
+    assert len(sizes) == 188
+    for K in sizes:
+        bits = np.random.default_rng(5000 + K).integers(0, 2, (2, K)).astype(np.uint8)
+        rc, out = hp.tcod_encode(bits, K)
+        assert rc == 0, K
+        for i in range(2):
+            ref = np.zeros(3 * K + 12, np.uint8)
+            assert oracle().orc_tcod_encode_bits(p(bits[i]), p(ref), K) == 0
+            assert np.array_equal(out[i], ref), "tcod K=%d block %d" % (K, i)
+
+
 def test_tcod_invalid_len(hp):
     rc, _ = hp.tcod_encode(np.zeros(41, np.uint8), 41)
     assert rc == hp.SRSLTE_ERROR  # turbocoder.c:89-93
@@ -588,6 +602,33 @@ def test_tdec_two_blocks_per_wavefront_every_block_length(hp):
         assert np.array_equal(iters, iters2) and np.array_equal(ok, ok2) and np.array_equal(out, out2), (K, iters, iters2)
         spread.update(iters.tolist())
     assert len(spread) >= 4  # early and late stops both occurred
+    dec.free()
+
+
+def test_tdec_every_block_length_both_widths_vs_oracle(hp):
+    """All 188 LTE block lengths (36.212 Table 5.1.3-3) through srslte_tdec_run_all and srslte_tdec_run_all_8bit with the back-end the
+    reference's AUTO selection takes for each (turbodecoder.c:421-487: generic / 8 / 16 windows in 16 bits; widening fall-back / sse8 / avx8 in 8
+    bits) against the oracle decoders on the same three noisy code words and pass counts 1 .. 6 drawn per length: bytes identical."""
+    sizes = list(range(40, 512, 8)) + list(range(512, 1024, 16)) + list(range(1024, 2048, 32)) + list(range(2048, 6145, 64))
+    assert len(sizes) == 188
+    dec = hp.Tdec(6144, 4)
+    for K in sizes:
+        rng = np.random.default_rng(9000 + K)
+        bits = rng.integers(0, 2, (3, K)).astype(np.uint8)
+        enc = np.zeros((3, 3 * K + 12), np.uint8)
+        for i in range(3):
+            oracle().orc_tcod_encode_bits(p(bits[i]), p(enc[i]), K)
+        nit = int(rng.integers(1, 7))
+        llr = _noisy_llr(rng, enc, float(rng.uniform(-3.0, 3.0)), int(rng.choice([60, 200, 1500])))
+        llr8 = (int(rng.choice([10, 25, 60])) * ((2.0 * enc - 1) + 10 ** (-float(rng.uniform(-2.0, 3.0)) / 20) * rng.standard_normal(enc.shape))).clip(-128, 127).astype(np.int8)
+        rc, out, _, _ = dec.run_all(llr, K, nit)
+        rc8, out8, _, _ = dec.run_all(llr8, K, nit, llr8=True)
+        assert rc == 0 and rc8 == 0, K
+        for i in range(3):
+            ref, ref8 = np.zeros(K // 8, np.uint8), np.zeros(K // 8, np.uint8)
+            assert oracle().orc_tdec_run(p(llr[i]), False, K, nit, p(ref), None) == 0 and oracle().orc_tdec_run_8bit(p(llr8[i]), False, K, nit, p(ref8), None) == 0
+            assert np.array_equal(out[i], ref), "16-bit K=%d nit=%d cb=%d: %d byte mismatches" % (K, nit, i, (out[i] != ref).sum())
+            assert np.array_equal(out8[i], ref8), "8-bit K=%d nit=%d cb=%d: %d byte mismatches" % (K, nit, i, (out8[i] != ref8).sum())
     dec.free()
 
 
