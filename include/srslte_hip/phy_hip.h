@@ -44,6 +44,9 @@ void  srslte_hip_event_destroy(void* event);
  * lib/include/srslte/phy/dft/ofdm.h:82-153, lib/src/phy/dft/ofdm.c:384-594, and FFTW behind dft_fftw.c) */
 typedef struct srslte_hip_ofdm srslte_hip_ofdm_t;
 srslte_hip_ofdm_t* srslte_hip_ofdm_create(int nof_prb, int cp_is_norm, int is_rx);     /* ofdm.c:235-273 */
+/* the same with the symbol size given, as srslte_ofdm_init_ takes it (ofdm.c:38-57): srslte_symbol_sz(nof_prb) of either rate family - 128 / 256 /
+ * 384 / 768 / 1024 / 1536, or 128 / 256 / 512 / 1024 / 1536 / 2048 with srslte_use_standard_symbol_size(true) (phy_common.c:304-345) */
+srslte_hip_ofdm_t* srslte_hip_ofdm_create_sz(int nof_prb, int symbol_sz, int cp_is_norm, int is_rx);
 void               srslte_hip_ofdm_destroy(srslte_hip_ofdm_t* q);                      /* ofdm.c:214-233 */
 int                srslte_hip_ofdm_set_normalize(srslte_hip_ofdm_t* q, int enable);    /* ofdm.c:576-578 */
 int                srslte_hip_ofdm_set_freq_shift(srslte_hip_ofdm_t* q, float shift);  /* ofdm.c:360-378 */
@@ -86,6 +89,9 @@ typedef struct {             /* scalar members of srslte_chest_dl_res_t (chest_d
 /* cp_is_norm = 0: extended-CP cell, 12 symbols per subframe: every "[14]" below reads "[12]" then (CRS on symbols 0, 3, 6, 9; chest_dl.c:497-502) */
 srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm); /* chest_dl.c:69-160,193-300 */
 void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
+/* the symbol size the CFO and timing-error estimates scale with (chest_dl.c:575,:695: srslte_symbol_sz(cell.nof_prb), read at every call);
+ * default: the default rate family's; e.g. 2048 for 100 PRB after srslte_use_standard_symbol_size(true) */
+int                    srslte_hip_chest_dl_set_symbol_sz(srslte_hip_chest_dl_t* q, int symbol_sz);
 const void*            srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q); /* device CRS table [10][4][2*prb] (refsignal_dl.c:66-116) */
 int srslte_hip_chest_dl_estimate_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid,
                                        void* d_ce, void* d_res, int nof_sf, void* stream);

@@ -56,6 +56,8 @@ typedef struct {
 typedef struct { srslte_tdd_config_t tdd_config; uint32_t tti; uint32_t cfi; srslte_sf_t sf_type; uint32_t non_mbsfn_region; } srslte_dl_sf_cfg_t;
 
 int  srslte_symbol_sz(uint32_t nof_prb); /* phy_common.c:322-345 */
+int  srslte_symbol_sz_power2(uint32_t nof_prb); /* phy_common.c:304-320 */
+void srslte_use_standard_symbol_size(bool enabled); /* phy_common.c:297-299: srslte_symbol_sz then returns the power-of-two family */
 
 /* ------------------------------------------------------------------ DFT (dft.h:46-152, dft_fftw.c) */
 typedef enum { SRSLTE_DFT_COMPLEX, SRSLTE_REAL } srslte_dft_mode_t;

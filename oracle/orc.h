@@ -95,6 +95,9 @@ typedef struct {
   int  non_mbsfn_region; /* 0: regular subframe; 1|2: MBSFN subframe (extended-CP object), ofdm.c:424-437,:558-574 */
 } orc_ofdm_t;
 int  orc_ofdm_init(orc_ofdm_t* q, int nof_prb, bool cp_norm);
+int  orc_ofdm_init_sz(orc_ofdm_t* q, int nof_prb, int symbol_sz, bool cp_norm); /* symbol size as srslte_ofdm_init_ takes it (ofdm.c:38-57) */
+int  orc_symbol_sz_power2(int nof_prb);                                         /* phy_common.c:304-320 */
+void orc_use_standard_symbol_size(bool enabled);                                /* phy_common.c:292-299: orc_symbol_sz then returns that family */
 void orc_ofdm_rx_sf(const orc_ofdm_t* q, const orc_cf_t* in_time, orc_cf_t* out_grid);
 void orc_ofdm_tx_sf(const orc_ofdm_t* q, const orc_cf_t* in_grid, orc_cf_t* out_time);
 bool orc_dft_precoding_valid_prb(uint32_t nof_prb);

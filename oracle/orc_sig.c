@@ -11,9 +11,13 @@
 
 /* ------------------------------------------------------------------ numerology */
 
+static bool use_standard_rates = false; /* phy_common.c:292-299: a process-wide switch, as upstream */
+void orc_use_standard_symbol_size(bool enabled) { use_standard_rates = enabled; }
+
 int orc_symbol_sz(int nof_prb)
-{ /* phy_common.c:322-345, default (non FORCE_STANDARD_RATE) table */
+{ /* phy_common.c:322-345: the default table, or the power-of-two family after srslte_use_standard_symbol_size(true) */
   if (nof_prb <= 0) return -1;
+  if (use_standard_rates) return orc_symbol_sz_power2(nof_prb);
   if (nof_prb <= 6) return 128;
   if (nof_prb <= 15) return 256;
   if (nof_prb <= 25) return 384;
@@ -261,11 +265,25 @@ void orc_dft_r2hc(const float* in, float* out, int N, int forward)
 
 /* ------------------------------------------------------------------ OFDM */
 
-int orc_ofdm_init(orc_ofdm_t* q, int nof_prb, bool cp_norm)
-{ /* ofdm.c:43-57 */
+int orc_symbol_sz_power2(int nof_prb)
+{ /* phy_common.c:304-320: the sizes srslte_symbol_sz returns after srslte_use_standard_symbol_size(true) */
+  if (nof_prb <= 0) return -1;
+  if (nof_prb <= 6) return 128;
+  if (nof_prb <= 15) return 256;
+  if (nof_prb <= 25) return 512;
+  if (nof_prb <= 50) return 1024;
+  if (nof_prb <= 75) return 1536;
+  if (nof_prb <= 110) return 2048;
+  return -1;
+}
+
+int orc_ofdm_init(orc_ofdm_t* q, int nof_prb, bool cp_norm) { return orc_ofdm_init_sz(q, nof_prb, orc_symbol_sz(nof_prb), cp_norm); }
+
+int orc_ofdm_init_sz(orc_ofdm_t* q, int nof_prb, int symbol_sz, bool cp_norm)
+{ /* ofdm.c:38-57: srslte_ofdm_init_ takes the symbol size from its caller (srslte_symbol_sz of either rate family, ofdm.c:235-273) */
   memset(q, 0, sizeof(*q));
-  int N = orc_symbol_sz(nof_prb);
-  if (N < 0) return -1;
+  int N = symbol_sz;
+  if (N < 0 || nof_prb <= 0 || 12 * nof_prb >= N) return -1;
   q->nof_prb = nof_prb; q->symbol_sz = N; q->nof_re = 12 * nof_prb; q->nof_symbols = cp_norm ? 7 : 6;
   q->sf_sz = 15 * N; q->slot_sz = 15 * N / 2; q->cp_norm = cp_norm;
   return 0;

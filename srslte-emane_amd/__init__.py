@@ -86,6 +86,8 @@ def lib():
         L.srslte_hip_event_destroy.argtypes = [vp]
         L.srslte_hip_ofdm_create.restype = vp
         L.srslte_hip_ofdm_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.srslte_hip_ofdm_create_sz.restype = vp
+        L.srslte_hip_ofdm_create_sz.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         L.srslte_hip_ofdm_destroy.argtypes = [vp]
         L.srslte_hip_ofdm_set_normalize.argtypes = [vp, C.c_int]
         L.srslte_hip_ofdm_set_freq_shift.argtypes = [vp, C.c_float]
@@ -207,8 +209,13 @@ def symbol_sz(nof_prb):
 class Ofdm:
     """srslte_ofdm_t: srslte_ofdm_rx_init/tx_init + set_normalize/set_freq_shift + rx_sf/tx_sf (ofdm.h), batched."""
 
-    def __init__(self, nof_prb, cp_norm=True, rx=True):
-        self.h = lib().srslte_hip_ofdm_create(nof_prb, 1 if cp_norm else 0, 1 if rx else 0)
+    def __init__(self, nof_prb, cp_norm=True, rx=True, symbol_sz=None):
+        """symbol_sz: None = srslte_symbol_sz(nof_prb) of the default rate family; else as srslte_ofdm_init_ takes it (e.g. 2048 for 100 PRB
+        after srslte_use_standard_symbol_size(true))."""
+        if symbol_sz is None:
+            self.h = lib().srslte_hip_ofdm_create(nof_prb, 1 if cp_norm else 0, 1 if rx else 0)
+        else:
+            self.h = lib().srslte_hip_ofdm_create_sz(nof_prb, symbol_sz, 1 if cp_norm else 0, 1 if rx else 0)
         if not self.h:
             raise RuntimeError("srslte_hip_ofdm_create failed")
         self.nof_prb, self.rx = nof_prb, rx

@@ -516,6 +516,7 @@ struct srslte_hip_chest_dl {
   cf32*     d_mbsfn[256]; // per MBSFN area id: [10][3][6*nof_prb] (set_mbsfn_area_id), or null
   cf32*     d_pss;        // the cell's 62 PSS values (pss.c:348-376), for the PSS noise algorithm
   float*    d_noise_state; // [port][antenna] noise estimates kept between calls by the PSS / EMPTY algorithms
+  int       symbol_sz;     // srslte_symbol_sz(nof_prb) as the CFO and timing estimates use it (chest_dl.c:575,:695)
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
@@ -551,6 +552,7 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   for (auto& m : q->d_mbsfn) m = nullptr;
   q->d_pss = nullptr;
   q->d_noise_state = nullptr;
+  q->symbol_sz     = lte_symbol_sz((int)nof_prb);
   cf32 pss[62];
   {
     const float root_value[] = {25.0, 29.0, 34.0};
@@ -570,6 +572,13 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
     return nullptr;
   }
   return q;
+}
+
+extern "C" int srslte_hip_chest_dl_set_symbol_sz(srslte_hip_chest_dl_t* q, int symbol_sz)
+{ // chest_dl.c:575,:695 read srslte_symbol_sz(cell.nof_prb) at every call: the other rate family after srslte_use_standard_symbol_size(true)
+  if (!q || symbol_sz <= 12 * q->nof_prb || symbol_sz > 2048) return SRSLTE_ERROR_INVALID_INPUTS;
+  q->symbol_sz = symbol_sz;
+  return SRSLTE_SUCCESS;
 }
 
 extern "C" void srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q)
@@ -680,7 +689,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.sync_enable = cfg->sync_error_enable ? 1 : 0;
   p.corr_enable = cfg->rsrp_neighbour ? 1 : 0;
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
-  p.symbol_sz = lte_symbol_sz(q->nof_prb);
+  p.symbol_sz = q->symbol_sz;
   p.cp1 = lte_cp_len_norm(1, p.symbol_sz);
   p.nof_rx = nof_rx;
   p.nof_ports = q->nof_ports;

@@ -165,7 +165,25 @@ int cp_nsymb(srslte_cp_t cp) { return cp == SRSLTE_CP_NORM ? 7 : 6; }
 
 extern "C" {
 
-int srslte_symbol_sz(uint32_t nof_prb) { return lte_symbol_sz((int)nof_prb); }
+// phy_common.c:294-345. When the reference's own common/phy_common.c is linked into the program its definitions are the ones
+// in effect, for this library's calls too (ordinary symbol interposition): the OFDM objects below ask srslte_symbol_sz(), not a table of their own.
+static bool g_use_standard_rates = false;
+void srslte_use_standard_symbol_size(bool enabled) { g_use_standard_rates = enabled; }
+int  srslte_symbol_sz_power2(uint32_t nof_prb)
+{
+  if (nof_prb <= 6) return 128;
+  if (nof_prb <= 15) return 256;
+  if (nof_prb <= 25) return 512;
+  if (nof_prb <= 50) return 1024;
+  if (nof_prb <= 75) return 1536;
+  if (nof_prb <= 110) return 2048;
+  return -1;
+}
+int srslte_symbol_sz(uint32_t nof_prb)
+{
+  if (nof_prb == 0) return SRSLTE_ERROR;
+  return g_use_standard_rates ? srslte_symbol_sz_power2(nof_prb) : lte_symbol_sz((int)nof_prb);
+}
 
 // ====================================================================================================== DFT
 void srslte_dft_load(void) {} // FFTW wisdom import/export (dft_fftw.c:44-57): nothing to persist
@@ -412,9 +430,9 @@ void srslte_dft_run_guru_c(srslte_dft_plan_t* plan)
 }
 
 // ====================================================================================================== OFDM
-static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb, bool rx, srslte_sf_t sf_type)
-{ // ofdm.c:43-133
-  const int N = lte_symbol_sz((int)nof_prb);
+static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, uint32_t nof_prb, bool rx, srslte_sf_t sf_type, int symbol_sz = 0)
+{ // ofdm.c:43-133; symbol_sz 0: srslte_symbol_sz(nof_prb) as srslte_ofdm_rx_init / tx_init / set_prb ask for it (ofdm.c:235-273,:307-350)
+  const int N = symbol_sz > 0 ? symbol_sz : srslte_symbol_sz(nof_prb);
   if (!q || N < 0) {
     ERROR("Error: Invalid nof_prb=%u", nof_prb);
     return SRSLTE_ERROR;
@@ -431,7 +449,7 @@ static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* ou
   q->fft_plan.dc      = true;
   auto* st            = new OfdmState();
   st->is_rx           = rx;
-  st->h               = srslte_hip_ofdm_create((int)nof_prb, cp == SRSLTE_CP_NORM, rx);
+  st->h               = srslte_hip_ofdm_create_sz((int)nof_prb, N, cp == SRSLTE_CP_NORM, rx);
   if (!st->h) {
     delete st;
     return SRSLTE_ERROR;
@@ -447,12 +465,12 @@ static int ofdm_init(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* ou
 
 int srslte_ofdm_init_mbsfn_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir,
                             srslte_sf_t sf_type)
-{ // ofdm.c:43-133; the symbol size is a function of nof_prb in every upstream caller
-  if (symbol_sz != lte_symbol_sz(nof_prb)) {
-    ERROR("Error: symbol_sz=%d does not match nof_prb=%d", symbol_sz, nof_prb);
+{ // ofdm.c:43-133: the symbol size is the caller's (srslte_symbol_sz of either rate family in every upstream caller)
+  if (symbol_sz <= 0 || nof_prb <= 0) {
+    ERROR("Error: Invalid symbol_sz=%d / nof_prb=%d", symbol_sz, nof_prb);
     return SRSLTE_ERROR;
   }
-  return ofdm_init(q, cp, in_buffer, out_buffer, (uint32_t)nof_prb, dir == SRSLTE_DFT_FORWARD, sf_type);
+  return ofdm_init(q, cp, in_buffer, out_buffer, (uint32_t)nof_prb, dir == SRSLTE_DFT_FORWARD, sf_type, symbol_sz);
 }
 int srslte_ofdm_init_(srslte_ofdm_t* q, srslte_cp_t cp, cf_t* in_buffer, cf_t* out_buffer, int symbol_sz, int nof_prb, srslte_dft_dir_t dir)
 { // ofdm.c:38-40
@@ -1083,6 +1101,7 @@ static int chest_dl_estimate_mbsfn(srslte_chest_dl_t* q, ChestState* st, srslte_
   memset(&hc, 0, sizeof(hc));
   hc.noise_alg = cfg->noise_alg; hc.filter_type = cfg->filter_type; hc.filter_coef[0] = cfg->filter_coef[0]; hc.filter_coef[1] = cfg->filter_coef[1];
   hc.interpolate_subframe = cfg->interpolate_subframe; hc.mbsfn_area_id = cfg->mbsfn_area_id;
+  srslte_hip_chest_dl_set_symbol_sz(st->h, srslte_symbol_sz(q->cell.nof_prb)); // chest_dl.c:575,:695: read at every call
   if (srslte_hip_chest_dl_estimate_mbsfn_batch(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dnoise, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   if (cfg->noise_alg == SRSLTE_NOISE_ALG_REFS) {
     float nz[16];
@@ -1170,6 +1189,7 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
       }
     }
   }
+  srslte_hip_chest_dl_set_symbol_sz(st->h, srslte_symbol_sz(q->cell.nof_prb)); // chest_dl.c:575,:695: read at every call
   if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
   float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}

@@ -422,9 +422,18 @@ struct srslte_hip_ofdm {
 
 extern "C" srslte_hip_ofdm_t* srslte_hip_ofdm_create(int nof_prb, int cp_is_norm, int is_rx)
 {
-  const int N = lte_symbol_sz(nof_prb);
-  if (N < 0) {
-    hip_log("[srslte_hip] Error: Invalid nof_prb=%d\n", nof_prb);
+  return srslte_hip_ofdm_create_sz(nof_prb, lte_symbol_sz(nof_prb), cp_is_norm, is_rx);
+}
+
+// The symbol size is the caller's to choose (srslte_ofdm_init_ takes it as an argument, ofdm.c:38-57): srslte_symbol_sz gives 128 / 256 / 384 /
+// 768 / 1024 / 1536 by default and 128 / 256 / 512 / 1024 / 1536 / 2048 after srslte_use_standard_symbol_size(true) (phy_common.c:304-345, what
+// rf_uhd_imp.c:457,:473 selects for some radios). Any of these sizes that holds the carriers: guards (N - 12 nof_prb) / 2, CP lengths scaled with N.
+extern "C" srslte_hip_ofdm_t* srslte_hip_ofdm_create_sz(int nof_prb, int symbol_sz, int cp_is_norm, int is_rx)
+{
+  const int N = symbol_sz;
+  const bool size_ok = N == 128 || N == 256 || N == 384 || N == 512 || N == 768 || N == 1024 || N == 1536 || N == 2048;
+  if (nof_prb <= 0 || nof_prb > 110 || !size_ok || 12 * nof_prb >= N) {
+    hip_log("[srslte_hip] Error: Invalid nof_prb=%d / symbol_sz=%d\n", nof_prb, symbol_sz);
     return nullptr;
   }
   auto* q = new srslte_hip_ofdm();

@@ -21,11 +21,24 @@ def close(a, b, tol=1e-4):
     return np.abs(a - b).max() <= tol * max(np.abs(b).max(), np.sqrt((np.abs(b) ** 2).mean()))
 
 
-@pytest.mark.parametrize("prb", [6, 25, 100])
-def test_ofdm_objects(prb):
-    """ofdm_test.c:74-179: tx -> rx round trip through srslte_ofdm_t objects bound to caller buffers."""
-    L, rng = hip(), np.random.default_rng(prb)
+@pytest.mark.parametrize("prb,std", [(6, False), (25, False), (100, False), (25, True), (50, True), (100, True)])
+def test_ofdm_objects(prb, std):
+    """ofdm_test.c:74-179: tx -> rx round trip through srslte_ofdm_t objects bound to caller buffers. std: after
+    srslte_use_standard_symbol_size(true) (phy_common.c:292-345, as rf_uhd_imp.c:457,:473 selects it for some radios) srslte_symbol_sz and
+    with it srslte_ofdm_tx_init / rx_init use the power-of-two family: 512 / 1024 / 2048 for 25 / 50 / 100 PRB."""
+    L = hip()
+    L.srslte_use_standard_symbol_size.argtypes = [C.c_bool]
+    L.srslte_use_standard_symbol_size(std)
+    try:
+        _ofdm_objects(L, prb, std)
+    finally:
+        L.srslte_use_standard_symbol_size(False)
+
+
+def _ofdm_objects(L, prb, std):
+    rng = np.random.default_rng(prb)
     N = L.srslte_symbol_sz(prb)
+    assert N == ({6: 128, 25: 512, 50: 1024, 100: 2048} if std else {6: 128, 25: 384, 100: 1536})[prb]
     nre, sf = 14 * 12 * prb, 15 * N
     grid_in, time_buf, grid_out = aligned(2 * nre, np.float32), aligned(2 * sf, np.float32), aligned(2 * nre, np.float32)
     tx, rx = opaque(4096), opaque(4096)
@@ -37,13 +50,27 @@ def test_ofdm_objects(prb):
     grid_in.view(np.complex64)[:] = g
     L.srslte_ofdm_tx_sf(tx)
     q = OrcOfdm()
-    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    assert oracle().orc_ofdm_init_sz(C.byref(q), prb, N, True) == 0
     q.normalize = True
     ref_t = np.zeros(sf, np.complex64)
     oracle().orc_ofdm_tx_sf(C.byref(q), p(g), p(ref_t))
     assert close(time_buf.view(np.complex64), ref_t)
     L.srslte_ofdm_rx_sf(rx)
     assert np.mean(np.abs(grid_out.view(np.complex64) - g) ** 2) < 1e-9  # ofdm_test.c:155 accepts 0.07
+    # srslte_ofdm_init_ takes the symbol size from its caller (ofdm.c:38-57): the other family's size on the same carrier count
+    other = {128: 128, 384: 512, 512: 384, 768: 1024, 1024: 768, 1536: 2048, 2048: 1536}[N]
+    rx2, t2, g2 = opaque(4096), aligned(2 * 15 * other, np.float32), aligned(2 * nre, np.float32)
+    assert L.srslte_ofdm_init_(rx2, 0, p(t2), p(g2), other, prb, 0) == 0
+    q2 = OrcOfdm()
+    assert oracle().orc_ofdm_init_sz(C.byref(q2), prb, other, True) == 0
+    t_in = (rng.standard_normal(15 * other) + 1j * rng.standard_normal(15 * other)).astype(np.complex64)
+    t2.view(np.complex64)[:] = t_in
+    L.srslte_ofdm_rx_sf(rx2)
+    g_ref = np.zeros(nre, np.complex64)
+    oracle().orc_ofdm_rx_sf(C.byref(q2), p(t_in), p(g_ref))
+    assert close(g2.view(np.complex64), g_ref)
+    L.srslte_ofdm_rx_free(rx2)
+    assert L.srslte_ofdm_init_(rx2, 0, p(t2), p(g2), 1000, prb, 0) == -1  # not a size of either family
     L.srslte_ofdm_tx_free(tx)
     L.srslte_ofdm_rx_free(rx)
     assert L.srslte_ofdm_rx_init(rx, 0, p(time_buf), p(grid_out), 111) == -1  # ofdm.c:237-240
@@ -303,6 +330,48 @@ def test_chest_dl_object():
         assert close(ce, ref)
         assert abs(res.noise_estimate - rres.noise_estimate) <= 1e-4 * rres.noise_estimate and abs(res.snr_db - rres.snr_db) < 1e-3
         assert abs(res.rsrp_dbm - rres.rsrp_dbm) < 1e-3 and np.isnan(res.sync_error)
+    L.srslte_chest_dl_res_free(C.byref(res))
+    L.srslte_chest_dl_free(est)
+
+
+def test_chest_dl_object_standard_symbol_sizes():
+    """srslte_chest_dl_estimate_cfg reads srslte_symbol_sz(cell.nof_prb) at every call for its timing-error figure (chest_dl.c:695): after
+    srslte_use_standard_symbol_size(true) the same object on the same grid reports 4/3 of it (512 against 384 points at 25 PRB), as the
+    reference's compiled estimator does (tests/test_oracle_vs_ref.py::test_chest_dl_standard_symbol_sizes_vs_ref); estimates and CFO stay."""
+    L, rng = hip(), np.random.default_rng(14)
+    L.srslte_use_standard_symbol_size.argtypes = [C.c_bool]
+    prb, cid, sf_idx = 25, 2, 4
+    est, res = opaque(1 << 16), RefChestRes()
+    assert L.srslte_chest_dl_init(est, prb, 1) == 0 and L.srslte_chest_dl_set_cell(est, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+    assert L.srslte_chest_dl_res_init(C.byref(res), prb) == 0
+    n, nre = 14 * 12 * prb, 12 * prb
+    cell = OrcCell(cid, prb, 1, True)
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    grid = acopy((g * ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 90.0 + 0.12 * l))) + 0.05 * rng.standard_normal(n)).astype(np.complex64).view(np.float32))
+    got = {}
+    try:
+        for std in (True, False):
+            L.srslte_use_standard_symbol_size(std)
+            oracle().orc_use_standard_symbol_size(std)
+            sf, rc, oc = RefDlSfCfg(), RefChestCfg(), OrcChestCfg()
+            sf.tti = sf_idx
+            rc.filter_coef[0], rc.filter_coef[1], oc.filter_coef[0], oc.filter_coef[1] = 4.0, 1.0, 4.0, 1.0
+            rc.cfo_estimate_enable = oc.cfo_estimate_enable = True
+            rc.sync_error_enable = oc.sync_error_enable = True
+            rc.cfo_estimate_sf_mask = 0x3FF
+            assert L.srslte_chest_dl_estimate_cfg(est, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+            ref, rres = np.zeros(n, np.complex64), OrcChestRes()
+            assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ref), C.byref(rres)) == 0
+            ce = np.ctypeslib.as_array(C.cast(res.ce[0][0], C.POINTER(C.c_float)), (2 * n,)).view(np.complex64)
+            assert close(ce, ref)
+            assert abs(res.cfo - rres.cfo) <= 1e-4 * abs(rres.cfo) + 1e-6 and abs(res.sync_error - rres.sync_error) <= 2e-3 * abs(rres.sync_error) + 1e-4
+            got[std] = (res.cfo, res.sync_error)
+    finally:
+        L.srslte_use_standard_symbol_size(False)
+        oracle().orc_use_standard_symbol_size(False)
+    assert abs(got[True][1] / got[False][1] - 4.0 / 3.0) < 1e-3 and abs(got[True][0] - got[False][0]) <= 1e-5 * abs(got[False][0])
     L.srslte_chest_dl_res_free(C.byref(res))
     L.srslte_chest_dl_free(est)
 

@@ -45,19 +45,26 @@ def test_dft_sizes(hp, N):
         assert_close_c(y, ref, "dft N=%d fwd=%s" % (N, fwd))
 
 
-@pytest.mark.parametrize("prb", [6, 15, 25, 50, 75, 100])
+# symbol size None: srslte_symbol_sz of the default rate family; else the power-of-two family of srslte_use_standard_symbol_size(true)
+# (phy_common.c:304-345), handed over as srslte_ofdm_init_ takes it (ofdm.c:38-57)
+@pytest.mark.parametrize("prb,N", [(6, None), (15, None), (25, None), (50, None), (75, None), (100, None), (110, None),
+                                   (25, 512), (50, 1024), (75, 1536), (100, 2048), (110, 2048)])
 @pytest.mark.parametrize("norm,shift", [(False, 0.0), (True, 0.0), (True, 0.5), (False, -0.5)])
-def test_ofdm_rx_tx(hp, prb, norm, shift):
+def test_ofdm_rx_tx(hp, prb, N, norm, shift):
     rng = np.random.default_rng(prb)
     q = OrcOfdm()
-    oracle().orc_ofdm_init(C.byref(q), prb, True)
+    if N is None:
+        assert oracle().orc_ofdm_init(C.byref(q), prb, True) == 0
+    else:
+        assert oracle().orc_ofdm_init_sz(C.byref(q), prb, N, True) == 0 and q.symbol_sz == N
     q.normalize, q.exact = norm, prb <= 25
     if shift:
         q.freq_shift, q.freq_shift_f = True, shift
     nsf = 3
     grid = (rng.standard_normal((nsf, 14 * 12 * prb)) + 1j * rng.standard_normal((nsf, 14 * 12 * prb))).astype(np.complex64)
-    tx = hp.Ofdm(prb, True, rx=False)
-    rx = hp.Ofdm(prb, True, rx=True)
+    tx = hp.Ofdm(prb, True, rx=False, symbol_sz=N)
+    rx = hp.Ofdm(prb, True, rx=True, symbol_sz=N)
+    assert tx.sf_len == rx.sf_len == q.sf_sz
     for o in (tx, rx):
         o.set_normalize(norm)
         if shift:

@@ -88,6 +88,37 @@ def test_ofdm_mbsfn_and_r2hc_definitions():
         assert np.abs(back / N - x).max() < 1e-4
 
 
+def test_ofdm_standard_rate_symbol_sizes_first_principles():
+    """The power-of-two symbol sizes srslte_symbol_sz returns after srslte_use_standard_symbol_size(true) (phy_common.c:304-345: 512 / 1024 /
+    1536 / 2048 for 25 / 50 / 75 / 100-110 PRB) through the oracle's modulator and demodulator against numpy on first principles: guards
+    (N - 12 nof_prb) / 2, DC skipped, CP lengths ceil(160 N / 2048) and ceil(144 N / 2048) (ofdm.c:43-57,:384-393, phy_common.h:93-99)."""
+    from _libs import OrcOfdm
+    rng = np.random.default_rng(6)
+    for prb, N in ((25, 512), (50, 1024), (75, 1536), (100, 2048), (110, 2048), (6, 128), (15, 256)):
+        assert oracle().orc_symbol_sz_power2(prb) == N
+        q = OrcOfdm()
+        assert oracle().orc_ofdm_init_sz(C.byref(q), prb, N, True) == 0 and q.symbol_sz == N and q.sf_sz == 15 * N
+        q.exact, q.normalize = True, False
+        nre, n0, n1 = 12 * prb, -(-160 * N // 2048), -(-144 * N // 2048)
+        g = (rng.standard_normal(14 * nre) + 1j * rng.standard_normal(14 * nre)).astype(np.complex64)
+        t = np.zeros(15 * N, np.complex64)
+        oracle().orc_ofdm_tx_sf(C.byref(q), p(g), p(t))
+        pos, exp = 0, np.zeros(15 * N, np.complex64)
+        for s in range(14):
+            cp = n0 if s % 7 == 0 else n1
+            X = np.zeros(N, np.complex128)
+            X[1: nre // 2 + 1], X[N - nre // 2:] = g[s * nre + nre // 2: (s + 1) * nre], g[s * nre: s * nre + nre // 2]
+            x = np.fft.ifft(X) * N
+            exp[pos: pos + cp], exp[pos + cp: pos + cp + N] = x[N - cp:], x
+            pos += cp + N
+        assert pos == 15 * N and np.abs(t - exp).max() < 1e-4 * np.abs(exp).max(), (prb, N)
+        back = np.zeros(14 * nre, np.complex64)
+        oracle().orc_ofdm_rx_sf(C.byref(q), p(t), p(back))
+        assert np.abs(back / N - g).max() < 1e-4, (prb, N)
+    q = OrcOfdm()
+    assert oracle().orc_ofdm_init_sz(C.byref(q), 100, 1024, True) < 0  # the carriers do not fit
+
+
 @pytest.mark.parametrize("K", [40, 176, 504, 1008, 5824, 6144])
 def test_tdec_golden(K):
     g = load("tdec.npz")

@@ -255,6 +255,52 @@ def test_chest_dl_vs_ref(prb, cid):
             R.srslte_chest_dl_free(q)
 
 
+@pytest.mark.parametrize("prb,cid", [(25, 2), (50, 3), (100, 4)])
+def test_chest_dl_standard_symbol_sizes_vs_ref(prb, cid):
+    """After srslte_use_standard_symbol_size(true) (phy_common.c:292-345; rf_uhd_imp.c:457,:473 does it for some radios) srslte_symbol_sz returns
+    512 / 1024 / 2048 for 25 / 50 / 100 PRB, and the estimator's timing-error figure scales with it (chest_dl.c:695; the CFO's :575 cancels): the
+    reference's compiled estimator with the switch on against the oracle with ITS switch on; then both off again, and the figures differ."""
+    R, rng = ref(), np.random.default_rng(40 + prb)
+    R.srslte_use_standard_symbol_size.argtypes = [C.c_bool]
+    nre, n, sf_idx = 12 * prb, 14 * 12 * prb, 4
+    cell = OrcCell(cid, prb, 1, True)
+    g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+    oracle().orc_crs_put_sf(C.byref(cell), sf_idx, 0, p(g))
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 90.0 + 0.12 * l))).astype(np.complex64)  # a slope over the carriers and over the symbols
+    grid = acopy((g * h + 0.05 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+    got = {}
+    try:
+        for std in (True, False):
+            R.srslte_use_standard_symbol_size(std)
+            oracle().orc_use_standard_symbol_size(std)
+            assert R.srslte_symbol_sz(prb) == oracle().orc_symbol_sz(prb) == ({25: 512, 50: 1024, 100: 2048} if std else {25: 384, 50: 768, 100: 1536})[prb]
+            q = opaque(1 << 20)
+            assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, 1, cid, 0, 0, 0, 0)) == 0
+            rc, oc = RefChestCfg(), OrcChestCfg()
+            rc.filter_coef[0], rc.filter_coef[1], oc.filter_coef[0], oc.filter_coef[1] = 4.0, 1.0, 4.0, 1.0
+            rc.cfo_estimate_enable = oc.cfo_estimate_enable = True
+            rc.sync_error_enable = oc.sync_error_enable = True
+            rc.cfo_estimate_sf_mask = 0x3FF
+            ce1, res, sf = aligned(2 * n, np.float32), RefChestRes(), RefDlSfCfg()
+            res.ce[0][0] = ce1.ctypes.data
+            sf.tti = sf_idx
+            inp = (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)
+            assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), inp, C.byref(res)) == 0
+            ce2, ores = np.zeros(n, np.complex64), OrcChestRes()
+            assert oracle().orc_chest_dl(C.byref(cell), sf_idx, C.byref(oc), p(grid), p(ce2), C.byref(ores)) == 0
+            assert abs(res.cfo - ores.cfo) <= 1e-4 * abs(res.cfo) + 1e-6, (std, res.cfo, ores.cfo)
+            assert abs(res.sync_error - ores.sync_error) <= 2e-3 * abs(ores.sync_error) + 1e-4, (std, res.sync_error, ores.sync_error)
+            got[std] = (res.cfo, res.sync_error, ce1.view(np.complex64).copy())
+            R.srslte_chest_dl_free(q)
+    finally:
+        R.srslte_use_standard_symbol_size(False)
+        oracle().orc_use_standard_symbol_size(False)
+    assert np.array_equal(got[True][2], got[False][2])                      # the estimates do not depend on the rate family,
+    assert abs(got[True][1] / got[False][1] - 4.0 / 3.0) < 1e-3            # the timing error scales with the symbol size (x 4/3),
+    assert abs(got[True][0] - got[False][0]) <= 1e-6 * abs(got[False][0])  # the CFO does not: N / (7.5 N + CP) is the same in both families
+
+
 @pytest.mark.parametrize("prb,cid,npt", [(6, 1, 1), (25, 2, 1), (50, 3, 2), (100, 4, 1), (100, 5, 2)])
 @pytest.mark.parametrize("alg", [1, 2])
 def test_chest_dl_noise_pss_empty_vs_ref(prb, cid, npt, alg):
