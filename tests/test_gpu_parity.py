@@ -1403,6 +1403,62 @@ def test_ul_tx_chain_cqi(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_cqi, I_c
     tx.free()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_ul_chains_uci_drawn_configurations(hp, seed):
+    """PUSCH with control information DRAWN from the space the pipelines accept: a CQI report of 0 .. 64 bits (block code / convolutional code),
+    0-2 rank-indication and 0-2 HARQ-ACK bits, every beta-offset index of 36.213 Tables 8.6.3-1/2/3, allocation, modulation, a transport-block
+    size not taken from a table, shortened subframes. Transmit side: modulated symbols equal the oracle's exactly (the Q' of every field,
+    the placement around the DMRS, the interleaver with RI symbols left out, the rate matching to what remains). Receive side on the same
+    noise-free samples: every field and the transport block come back."""
+    from _libs import OrcCbsegm
+    from lte_sim import UlConfig, make_ul_subframe
+    rng = np.random.default_rng(7400 + seed)
+    prb = int(rng.choice([15, 25, 50, 100]))
+    L = int(rng.choice([n for n in range(3, prb + 1) if _is_235(n)]))
+    n_prb, mod, short = int(rng.integers(0, prb - L + 1)), int(rng.choice([1, 2, 3])), bool(seed % 2)
+    O_cqi = int(rng.choice([0, int(rng.integers(1, 12)), int(rng.integers(12, 65))]))
+    O_ri, O_ack = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    I_cqi, I_ri, I_ack = int(rng.integers(2, 16)), int(rng.integers(0, 13)), int(rng.integers(0, 15))
+    cell_id, rnti, n_dmrs, cs, dss = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(0, 8)), int(rng.integers(0, 8)), int(rng.integers(0, 30))
+    probe = UlConfig(prb, cell_id, mod, 16, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, shortened=short)
+    tbs = max(40, int(float(rng.uniform(0.15, 0.45)) * probe.nbits) // 8 * 8)  # low enough that the control information still fits
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = UlConfig(prb, cell_id, mod, tbs, L, n_prb, n_dmrs=n_dmrs, rnti=rnti, cyclic_shift=cs, delta_ss=dss, group_hopping=bool(seed & 4),
+                   sequence_hopping=bool(seed & 8) and L >= 6, shortened=short)
+    tti0, nsf = int(rng.integers(0, 10240)), 4
+    what = (prb, L, n_prb, mod, tbs, short, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, cell_id, tti0)
+    data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
+    cqis = rng.integers(0, 2, (nsf, O_cqi), dtype=np.uint8)
+    ris = rng.integers(0, 2, (nsf, O_ri), dtype=np.uint8) if O_ri else None
+    acks = rng.integers(0, 2, (nsf, O_ack), dtype=np.uint8) if O_ack else None
+    uci = dict(ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri, I_offset_ri=I_ri, cqi_len=O_cqi, I_offset_cqi=I_cqi)
+    tx = hp.UlTx(cell_id, prb, rnti, mod, tbs, L, n_prb, n_dmrs, nsf, cs, dss, bool(seed & 4), bool(seed & 8) and L >= 6, shortened=short, **uci)
+    iq = tx.encode(data, tti0, ack=acks, ri=ris, cqi=cqis if O_cqi else None)
+    d = tx.debug(2, np.complex64, nsf * cfg.nof_re).reshape(nsf, -1)
+    for b in range(nsf):
+        k = {}
+        iq_o, _ = make_ul_subframe(cfg, tti0 + b, rng, data=data[b], keep=k, ack=tuple(acks[b]) if O_ack else (), I_offset_ack=I_ack,
+                                   ri=tuple(ris[b]) if O_ri else (), I_offset_ri=I_ri, cqi=tuple(cqis[b]), I_offset_cqi=I_cqi)
+        assert np.array_equal(d[b].view(np.float32), k["d"].view(np.float32)), what + (b,)
+        assert_close_c(iq[b], iq_o, "iq %s" % (what,))
+    rx = hp.UlRx(cell_id, prb, rnti, mod, tbs, L, n_prb, n_dmrs, 6, nsf, cs, dss, bool(seed & 4), bool(seed & 8) and L >= 6, shortened=short, **uci)
+    tb, ok = rx.decode(iq, tti0)
+    assert ok.all() and np.array_equal(tb[:, :tbs // 8], data), what
+    if O_ri:
+        assert np.array_equal(rx.ri()[:nsf], ris), what
+    if O_ack:
+        assert np.array_equal(rx.ack()[:nsf], acks), what
+    if O_cqi:
+        cq, cq_ok = rx.cqi()
+        assert np.array_equal(cq[:nsf, :O_cqi], cqis) and (O_cqi <= 11 or cq_ok[:nsf].all()), what
+    tx.free()
+    rx.free()
+
+
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr,tti0,nsf,O_cqi,I_cqi,O_ri,I_ri,O_ack,I_ack,short", UL_CQI_CASES)
 def test_ul_rx_chain_cqi(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, O_cqi, I_cqi, O_ri, I_ri, O_ack, I_ack, short):
     """PUSCH receive chain with a CQI report vs the oracle chain (pinned on srslte_ulsch_decode / srslte_uci_decode_cqi_pusch, the long
