@@ -77,6 +77,62 @@ def test_dl_rx_two_layer_modes(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, 
     rx.free()
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_dl_rx_two_layer_modes_drawn_configurations(hp, seed):
+    """The two-layer modes on configurations DRAWN from what srslte_hip_dl_rx_create accepts: bandwidth, cell id, CFI, large-delay CDD or
+    codebook multiplexing with one or two transport blocks and every allowed codebook index, modulation and a transport-block size not taken
+    from a table per codeword, first TTI, SNR. Per codeword: LLRs within the float tolerance of test_dl_rx_two_layer_modes; then the oracle's
+    integer back end on the DEVICE's LLRs against the device's pass counts, CRC verdicts and bytes exactly, failing blocks included."""
+    import ctypes as C
+    from _libs import OrcCbsegm, OrcSchCfg, oracle, p
+    from lte_sim import DlConfig, make_subframe_mimo, oracle_rx_mimo
+    rng = np.random.default_rng(7500 + seed)
+    prb, cid, cfi = int(rng.choice([6, 15, 25, 50])), int(rng.integers(0, 504)), int(rng.integers(1, 4))
+    scheme = "cdd" if seed % 2 else "mux"
+    two = scheme == "cdd" or bool(seed % 4)
+    pmi = 0 if scheme == "cdd" else int(rng.integers(0, 2 if two else 4))
+    mods = [int(rng.choice([1, 2, 3])), int(rng.choice([1, 2, 3, 4]))]
+    probe = DlConfig(prb, cid, 1, 16, cfi=cfi, nof_rx=2, nof_ports=2, tx_scheme=scheme, pmi=0, mod2=1 if two else None, tbs2=16 if two else 0)
+    nre_min = min(len(probe.indices(sf)) for sf in (0, 1, 5))
+    tbss = []
+    for m in mods:
+        tbs = max(40, int(float(rng.uniform(0.2, 0.6)) * nre_min * Q[m]) // 8 * 8)
+        while True:
+            seg = OrcCbsegm()
+            if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+                break
+            tbs -= 8
+        tbss.append(tbs)
+    mod, tbs, mod2, tbs2 = mods[0], tbss[0], (mods[1] if two else 0), (tbss[1] if two else 0)
+    cfg = DlConfig(prb, cid, mod, tbs, cfi=cfi, nof_rx=2, nof_ports=2, tx_scheme=scheme, pmi=pmi, mod2=mod2 or None, tbs2=tbs2)
+    tti0, nsf, snr = int(rng.integers(0, 10240)), 3, float(rng.uniform(6.0, 24.0))
+    what = (prb, cid, cfi, scheme, pmi, mod, tbs, mod2, tbs2, tti0, snr)
+    iq, data = zip(*[make_subframe_mimo(cfg, tti0 + b, rng, snr_db=snr, amp=0.2) for b in range(nsf)])
+    rx = hp.DlRx(cid, prb, cfi, 0x1234, mod, tbs, 6, nsf, True, _chest(hp), nof_rx=2, nof_ports=2, tx_scheme=SCHEME[scheme], pmi=pmi, mod2=mod2, tbs2=tbs2)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    if not tbs2:
+        tb, ok = [tb], [ok]
+    max_re = max(rx.nof_re(sf) for sf in (0, 1, 5))
+    for cw in range(cfg.nof_tb):
+        off, C_, Qm, t = 100 * cw, cfg.segs[cw].C, Q[cfg.mods[cw]], cfg.tbss[cw]
+        e_stride = (max_re * Qm + 15) & ~15
+        it = rx.debug(off + 6, np.uint32, nsf * C_).reshape(nsf, C_)
+        e_all = rx.debug(off + 4, np.int16, nsf * e_stride).reshape(nsf, -1)
+        for b in range(nsf):
+            r = oracle_rx_mimo(cfg, iq[b], tti0 + b)
+            nre = rx.nof_re((tti0 + b) % 10)
+            e = np.ascontiguousarray(e_all[b, :nre * Qm])
+            diff = np.abs(e.astype(np.int32) - r["e_raw"][cw].astype(np.int32))
+            assert diff.max() <= 1 + np.abs(r["e_raw"][cw]).max() // 2000 and (diff != 0).sum() <= 2e-3 * diff.size + 1, what + (cw, b, int(diff.max()), int((diff != 0).sum()))
+            sch = OrcSchCfg(t, nre * Qm, Qm, 0, cfg.max_iter)
+            otb, oit, ocb = np.zeros(t // 8 + 16, np.uint8), np.zeros(C_, np.uint32), np.zeros(C_, np.uint8)
+            rc = oracle().orc_dlsch_decode(C.byref(sch), p(e), p(otb), p(oit), p(ocb))
+            assert bool(ok[cw][b]) == (rc == 0) and np.array_equal(it[b], oit) and np.array_equal(tb[cw][b], otb[:t // 8 + 3]), what + (cw, b)
+            if ok[cw][b]:
+                assert np.array_equal(tb[cw][b][:t // 8], data[b][cw]), what + (cw, b)
+    rx.free()
+
+
 @pytest.mark.parametrize("prb,cid,mod,tbs,mod2,tbs2,scheme,pmi,cfi,tti0,nsf,snr", [CASES[0], CASES[3], CASES[6], CASES[8], CASES[10]])
 @pytest.mark.parametrize("csi", [False, True])
 def test_dl_rx_two_layer_modes_8bit(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, cfi, tti0, nsf, snr, csi):
