@@ -244,7 +244,10 @@ int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti
 /* HARQ (decode_tb_cb sch.c:299-414 on a srslte_softbuffer_rx_t per transport block, softbuffer.c:46-150): slot b of the object keeps
  * its blocks' soft buffers, CRC flags and decoded bytes between calls. new_data != 0: new transport blocks (the MAC's
  * srslte_softbuffer_rx_reset_tbs on a toggled NDI). new_data == 0: retransmission with redundancy version rv, de-matched LLRs are
- * added to the kept soft buffers (rm_turbo.c:407-409), blocks whose CRC already passed are left alone (sch.c:317-318) */
+ * added to the kept soft buffers (rm_turbo.c:407-409), blocks whose CRC already passed are left alone (sch.c:317-318). A retransmission
+ * into a slot whose transport block has already passed (the MAC does not schedule one) is answered as upstream answers it: d_tb_ok 0
+ * (decode_tb_cb saves passed blocks' bytes only while the block as a whole has failed, sch.c:399-410, and the reassembled block fails its
+ * CRC-24A); the same holds for every HARQ entry point of this header (uplink, per-subframe grants) */
 int srslte_hip_dl_rx_batch_harq(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint32_t rv, int new_data,
                                 uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
 /* the same with a redundancy version and a new-data flag per transport block (two-layer modes: grant.tb[0 / 1].rv and the state of

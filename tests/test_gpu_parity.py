@@ -1839,6 +1839,66 @@ def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
     rx.free()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_dl_rx_harq_drawn_sequences(hp, seed):
+    """HARQ on the device with redundancy-version SEQUENCES drawn at random - any start version, repeats, up to five transmissions, a new
+    transport block in the middle of the run - on drawn configurations (bandwidth, modulation, a non-table size, 16- / 8-bit LLRs). After
+    every transmission, per slot: the oracle's soft-combining back end (orc_dlsch_decode_harq: rate de-matching into the kept soft buffer,
+    blocks with a passed CRC skipped, sch.c:299-414) fed the DEVICE's LLRs of that transmission gives the device's CRC flag, per-block pass
+    counts and bytes exactly."""
+    from _libs import OrcCbsegm, OrcSchCfg
+    from lte_sim import OrcHarq
+    rng = np.random.default_rng(7600 + seed)
+    prb, mod, llr8 = int(rng.choice([6, 15, 25, 50])), int(rng.choice([1, 2, 3])), bool(seed % 3 == 1)
+    cell_id, rnti = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0))
+    probe = DlConfig(prb, cell_id, mod, 16, rnti=rnti)
+    nbits = min(len(probe.indices(sf)) for sf in (0, 1, 5)) * probe.Qm
+    tbs = max(40, int(float(rng.uniform(0.5, 0.95)) * nbits) // 8 * 8)  # high rates: the first transmission often fails
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = DlConfig(prb, cell_id, mod, tbs, rnti=rnti, llr8=llr8)
+    nsf, C_ = 3, cfg.seg.C
+    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / nbits - 0.4) - float(rng.uniform(1.0, 4.0))  # below the waterfall of one transmission
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(cell_id, prb, 1, rnti, mod, tbs, 6, nsf, True, hc, llr_8bit=llr8)
+    harq = [OrcHarq(cfg) for _ in range(nsf)]
+    data = [None] * nsf
+    n_tx = int(rng.integers(3, 6))
+    restart = int(rng.integers(1, n_tx))  # this transmission carries new data
+    n_ok = n_carried = 0
+    for n in range(n_tx):
+        new = n == 0 or n == restart
+        rv, tti0 = int(rng.integers(0, 4)), int(rng.integers(0, 10240))
+        if new:
+            data = [None] * nsf
+        iq = []
+        for b in range(nsf):
+            x, data[b] = make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, rv=rv, data=data[b])
+            iq.append(x)
+        tb, ok = rx.decode_harq(np.stack(iq), tti0, rv, new)
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+        for b in range(nsf):
+            what = (prb, mod, tbs, llr8, n, rv, new, tti0 + b, snr)
+            nb = rx.nof_re((tti0 + b) % 10) * cfg.Qm
+            e = np.ascontiguousarray(e_all[b, :nb])
+            sch = OrcSchCfg(tbs, nb, cfg.Qm_sch, rv, cfg.max_iter)
+            otb, oit, ocb = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(C_, np.uint32), np.zeros(C_, np.uint8)
+            rc = oracle().orc_dlsch_decode_harq(C.byref(sch), p(e), 1 if llr8 else 0, 1 if new else 0, p(harq[b].w), p(harq[b].crc), p(harq[b].data),
+                                                p(otb), p(oit), p(ocb))
+            assert bool(ok[b]) == (rc == 0) and np.array_equal(it[b], oit), what + (it[b], oit)
+            n_carried += int((oit == 0).sum())
+            if ok[b]:
+                n_ok += 1
+                assert np.array_equal(tb[b], otb[:tbs // 8 + 3]) and np.array_equal(tb[b][:tbs // 8], data[b]), what
+    assert n_ok > 0 or llr8
+    rx.free()
+
+
 @pytest.mark.parametrize("prb,mod,tbs,npt,tti0,nsf,rv,p_a", [(6, 1, 152, 1, 0, 10, 0, 0.0), (25, 2, 4008, 2, 8, 4, 0, 0.0), (100, 3, 75376, 1, 4, 3, 0, -3.0),
                                                              (100, 3, 75376, 2, 9, 3, 2, 0.0), (50, 4, 48936, 1, 5, 2, 1, 0.0), (15, 1, 1000, 2, 0, 6, 3, 1.77),
                                                              (25, 2, 4008, 4, 8, 4, 0, 0.0), (100, 3, 61664, 4, 4, 3, 2, 0.0), (6, 1, 152, 4, 0, 10, 1, -1.0)])

@@ -100,3 +100,45 @@ def test_ul_rx_harq(hp, prb, L, n_prb, mod, tbs, snr, uci):
     if C_ > 4:
         assert n_carried > 0
     rx.free()
+
+
+@pytest.mark.parametrize("direction", ["ul", "dl"])
+def test_retransmission_after_a_success_fails_as_upstream(hp, direction):
+    """decode_tb_cb keeps the bytes of passed code blocks for the next transmission only while the transport block as a whole has failed
+    (sch.c:399-410): a retransmission (no new data) into a soft buffer whose block already passed skips every code block, reassembles what
+    that array holds - not what the successful call decoded - and fails the CRC-24A (sch.c:470-488). The MAC never asks for it (it discards
+    duplicates and repeats the ACK); the pipelines answer as upstream's PHY would: CRC flag 0, no block decoded - and the oracle chain, which
+    is pinned on srslte_pdsch_decode / srslte_ulsch_decode with their soft buffers, says the same. New data afterwards decodes again."""
+    from lte_sim import DlConfig, OrcHarq, UlConfig, make_subframe, make_ul_subframe, oracle_rx, oracle_ul_rx
+    rng = np.random.default_rng(77)
+    nsf = 3
+    if direction == "ul":
+        cfg = UlConfig(25, 11, 2, 4008, 10, 5, n_dmrs=3, cyclic_shift=2, delta_ss=5)
+        rx = hp.UlRx(11, 25, 0x1234, 2, 4008, 10, 5, 3, 6, nsf, 2, 5)
+        make = lambda t, rv, d: make_ul_subframe(cfg, t, rng, snr_db=25.0, amp=0.1, rv=rv, data=d)
+        orc = lambda x, t, h, rv, new: oracle_ul_rx(cfg, x, t, harq=h, rv=rv, new_data=new)
+    else:
+        cfg = DlConfig(25, 7, 2, 4008)
+        hc = hp.ChestDlCfg()
+        hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+        rx = hp.DlRx(7, 25, 1, 0x1234, 2, 4008, 6, nsf, True, hc)
+        make = lambda t, rv, d: make_subframe(cfg, t, rng, snr_db=25.0, amp=0.1, rv=rv, data=d)
+        orc = lambda x, t, h, rv, new: oracle_rx(cfg, x, t, harq=h, rv=rv, new_data=new)
+    harq, data = [OrcHarq(cfg) for _ in range(nsf)], [None] * nsf
+    for n, (rv, tti0, new, expect) in enumerate(((0, 3, True, True), (2, 11, False, False), (3, 19, False, False), (0, 27, True, True))):
+        if new:
+            data = [None] * nsf
+        iq = []
+        for b in range(nsf):
+            x, data[b] = make(tti0 + b, rv, data[b])
+            iq.append(x)
+        tb, ok = rx.decode_harq(np.stack(iq), tti0, rv, new)
+        it = rx.debug(6, np.uint32, nsf * cfg.seg.C).reshape(nsf, -1)
+        for b in range(nsf):
+            r = orc(iq[b], tti0 + b, harq[b], rv, new)
+            assert bool(ok[b]) == r["ok"] == expect, (direction, n, b, ok[b], r["ok"])
+            assert np.array_equal(it[b], r["iters"]) and (it[b] > 0).all() == expect, (direction, n, b, it[b], r["iters"])
+            if expect:
+                assert np.array_equal(tb[b], r["tb"]) and np.array_equal(tb[b][:cfg.tbs // 8], data[b])
+    rx.free()
+
