@@ -245,3 +245,101 @@ def test_grants_harq(hp):
             done[b] = bool(ok[b])
     assert not all(outcomes) and any(outcomes)  # the retransmissions were needed, and helped
     rx.free()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_grants_harq_drawn_sequences(hp, seed):
+    """test_grants_harq with everything drawn: per call and HARQ slot either a retransmission of the slot's transport block - with a drawn
+    redundancy version, a NEW allocation (other PRBs in each slot of the subframe, so another number of LLRs), possibly another modulation,
+    another CFI - or a new transport block of a drawn size; now and then a retransmission into a slot that has already passed (answered with
+    CRC 0, as decode_tb_cb does, sch.c:399-410). The oracle's soft-combining back end on the DEVICE's LLRs of every transmission gives the
+    device's CRC flags, pass counts per block (0 = carried over) and bytes exactly."""
+    import ctypes as C
+    from _libs import OrcCbsegm, OrcSchCfg, oracle, p
+    rng = np.random.default_rng(7700 + seed)
+    P, cell_id, nsf = int(rng.choice([15, 25, 50])), int(rng.integers(0, 504)), 3
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+
+    def draw_mask():
+        m = np.zeros((2, P), np.uint8)
+        n = int(rng.integers(max(2, P // 5), P + 1))
+        if rng.integers(0, 2):
+            m[:, rng.choice(P, n, replace=False)] = 1
+        else:  # another set of PRBs in the second slot (distributed allocations)
+            m[0, rng.choice(P, n, replace=False)] = 1
+            m[1, rng.choice(P, n, replace=False)] = 1
+        return m
+
+    def draw_tb(slot):
+        mod = int(rng.choice([1, 2, 3]))
+        m = draw_mask()
+        nre = min(len(DlConfig(P, cell_id, mod, 16, cfi=3, rnti=0x50 + slot, prb_mask=m).indices(sf)) for sf in (0, 1, 5))
+        tbs = max(40, int(float(rng.uniform(0.55, 0.95)) * nre * 2 * mod) // 8 * 8)
+        while True:
+            seg = OrcCbsegm()
+            if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+                return {"tbs": tbs, "mod": mod, "mask": m, "data": rng.integers(0, 256, tbs // 8, dtype=np.uint8), "done": False, "new": True}
+            tbs -= 8
+
+    tbs_max = 12 * P * 11 * 6  # more than any drawn block
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs_max) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs_max -= 8
+    Cmax = seg.C
+    rx = hp.DlRx(cell_id, P, 1, 0, 3, tbs_max, 6, nsf, True, hc)
+    e_stride = 16 * ((14 * 12 * P * 8 + 15) // 16)
+    slots = [draw_tb(b) for b in range(nsf)]
+    harq = [None] * nsf
+    n_ok = n_retx_ok = n_after = 0
+    for call in range(6):
+        tti0 = int(rng.integers(0, 10240))
+        cfgs, grants, iq = [], [], []
+        for b in range(nsf):
+            sl = slots[b]
+            if not sl["new"]:
+                if sl["done"] and rng.integers(0, 3):  # acknowledged: usually a new block next, sometimes a duplicate retransmission
+                    slots[b] = sl = draw_tb(b)
+                else:  # retransmission: other allocation, maybe another modulation (the soft buffer holds coded bits)
+                    sl["mask"] = draw_mask()
+                    if rng.integers(0, 3) == 0:
+                        sl["mod"] = int(rng.choice([2, 3]))
+            rv, cfi = (0 if sl["new"] and rng.integers(0, 2) else int(rng.integers(0, 4))), int(rng.integers(1, 4))
+            c = DlConfig(P, cell_id, sl["mod"], sl["tbs"], cfi=cfi, rnti=0x50 + b, prb_mask=sl["mask"])
+            if len(c.indices((tti0 + b) % 10)) * c.Qm < 64:  # too few LLRs to mean anything: take the whole band
+                sl["mask"] = np.ones((2, P), np.uint8)
+                c = DlConfig(P, cell_id, sl["mod"], sl["tbs"], cfi=cfi, rnti=0x50 + b, prb_mask=sl["mask"])
+            snr = {1: 1.0, 2: 7.0, 3: 12.0}[sl["mod"]] + 10.0 * (sl["tbs"] / (len(c.indices((tti0 + b) % 10)) * c.Qm) - 0.4) - float(rng.uniform(0.0, 3.0))
+            iq.append(make_subframe(c, tti0 + b, rng, snr_db=snr, rv=rv, data=sl["data"])[0])
+            grants.append(hp.DlGrant.make(P, sl["mod"], sl["tbs"], 0x50 + b, cfi=cfi, rv=rv, new_data=sl["new"], prb_mask=sl["mask"]))
+            cfgs.append((c, rv))
+            if sl["new"]:
+                harq[b] = OrcHarq(c)
+        rc, tb, ok = rx.decode_grants(np.stack(iq), tti0, grants)
+        assert rc == 0
+        e = rx.debug(11, np.int16, nsf * e_stride).reshape(nsf, e_stride)
+        iters = rx.debug(13, np.uint32, nsf * Cmax).reshape(nsf, -1)
+        for b in range(nsf):
+            (c, rv), sl = cfgs[b], slots[b]
+            what = (seed, call, b, P, sl["mod"], sl["tbs"], rv, sl["new"], sl["done"])
+            nbits = len(c.indices((tti0 + b) % 10)) * c.Qm
+            sch = OrcSchCfg(c.tbs, nbits, c.Qm_sch, rv, c.max_iter)
+            otb, oit, ocb = np.zeros(c.tbs // 8 + 16, np.uint8), np.zeros(c.seg.C, np.uint32), np.zeros(c.seg.C, np.uint8)
+            orc = oracle().orc_dlsch_decode_harq(C.byref(sch), p(np.ascontiguousarray(e[b, :nbits])), 0, 1 if sl["new"] else 0, p(harq[b].w), p(harq[b].crc),
+                                                 p(harq[b].data), p(otb), p(oit), p(ocb))
+            assert bool(ok[b]) == (orc == 0) and np.array_equal(iters[b, :c.seg.C], oit), what + (bool(ok[b]), orc, iters[b, :c.seg.C], oit)
+            if sl["done"] and not sl["new"]:
+                assert not ok[b] and not oit.any()  # the duplicate retransmission
+                n_after += 1
+            if ok[b]:
+                assert np.array_equal(tb[b, :c.tbs // 8 + 3], otb[:c.tbs // 8 + 3]) and np.array_equal(tb[b, :c.tbs // 8], sl["data"]), what
+                n_ok += 1
+                n_retx_ok += not sl["new"]
+                sl["done"] = True
+            sl["new"] = False
+    print("drawn grants HARQ: %d blocks delivered, %d of them by a retransmission, %d duplicate retransmissions refused" % (n_ok, n_retx_ok, n_after))
+    assert n_ok > 0
+    rx.free()
+
