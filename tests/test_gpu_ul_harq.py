@@ -142,3 +142,77 @@ def test_retransmission_after_a_success_fails_as_upstream(hp, direction):
                 assert np.array_equal(tb[b], r["tb"]) and np.array_equal(tb[b][:cfg.tbs // 8], data[b])
     rx.free()
 
+
+def _is_235(n):
+    for f in (2, 3, 5):
+        while n % f == 0:
+            n //= f
+    return n == 1
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_ul_rx_harq_drawn_sequences(hp, seed):
+    """Uplink HARQ with redundancy-version sequences drawn at random (any start, repeats, new data in the middle, duplicate retransmissions
+    after a success) on drawn PUSCH configurations - allocation, modulation, a non-table transport-block size, shortened subframes, and a
+    drawn set of control information (CQI report in front of the UL-SCH, rank indication left out by the interleaver, HARQ-ACK punctured in).
+    The oracle's soft-combining back end on the DEVICE's de-interleaved LLRs of every transmission (behind the report's) gives the device's
+    CRC flags, pass counts per block and bytes exactly."""
+    import ctypes as C
+    from _libs import OrcCbsegm, OrcSchCfg, oracle, p
+    from lte_sim import OrcHarq, UlConfig, make_ul_subframe, ul_cqi_qprime, ul_ri_layout
+    rng = np.random.default_rng(7800 + seed)
+    prb = int(rng.choice([15, 25, 50]))
+    L = int(rng.choice([n for n in range(3, prb + 1) if _is_235(n)]))
+    n_prb, mod, short = int(rng.integers(0, prb - L + 1)), int(rng.choice([1, 2, 3])), bool(seed % 2)
+    O_cqi = int(rng.choice([0, int(rng.integers(1, 12)), int(rng.integers(12, 41))])) if seed % 3 else 0
+    O_ri, O_ack = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+    I_cqi, I_ri, I_ack = int(rng.integers(2, 16)), int(rng.integers(0, 13)), int(rng.integers(0, 15))
+    cell_id, rnti = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0))
+    probe = UlConfig(prb, cell_id, mod, 16, L, n_prb, rnti=rnti, shortened=short)
+    tbs = max(40, int(float(rng.uniform(0.5, 0.8)) * probe.nbits) // 8 * 8)
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = UlConfig(prb, cell_id, mod, tbs, L, n_prb, n_dmrs=2, rnti=rnti, cyclic_shift=1, delta_ss=3, shortened=short)
+    nsf, C_ = 3, cfg.seg.C
+    Qp_ri, _, _, G = ul_ri_layout(cfg, O_ri, I_ri, O_cqi, I_cqi)
+    n_cqi = ul_cqi_qprime(cfg, O_cqi, I_cqi, Qp_ri) * cfg.Qm
+    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / (G - n_cqi) - 0.4) - float(rng.uniform(1.0, 3.5))
+    uci = dict(ack_len=O_ack, I_offset_ack=I_ack, ri_len=O_ri, I_offset_ri=I_ri, cqi_len=O_cqi, I_offset_cqi=I_cqi)
+    rx = hp.UlRx(cell_id, prb, rnti, mod, tbs, L, n_prb, 2, 6, nsf, 1, 3, shortened=short, **uci)
+    harq, data, done = [OrcHarq(cfg) for _ in range(nsf)], [None] * nsf, [False] * nsf
+    n_tx = int(rng.integers(3, 6))
+    restart = int(rng.integers(1, n_tx))
+    n_ok = 0
+    for n in range(n_tx):
+        new = n == 0 or n == restart
+        rv, tti0 = int(rng.integers(0, 4)), int(rng.integers(0, 10240))
+        if new:
+            data, done = [None] * nsf, [False] * nsf
+        iq = []
+        for b in range(nsf):
+            extra = dict(ack=tuple(rng.integers(0, 2, O_ack)), I_offset_ack=I_ack, ri=tuple(rng.integers(0, 2, O_ri)), I_offset_ri=I_ri,
+                         cqi=tuple(rng.integers(0, 2, O_cqi)), I_offset_cqi=I_cqi)
+            x, data[b] = make_ul_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j), rv=rv, data=data[b], **extra)
+            iq.append(x)
+        tb, ok = rx.decode_harq(np.stack(iq), tti0, rv, new)
+        it = rx.debug(6, np.uint32, nsf * C_).reshape(nsf, C_)
+        g = rx.debug(4, np.int16, nsf * cfg.nbits).reshape(nsf, -1)
+        for b in range(nsf):
+            what = (seed, n, b, prb, L, mod, tbs, short, O_cqi, O_ri, O_ack, rv, new, done[b])
+            sch = OrcSchCfg(tbs, G - n_cqi, cfg.Qm, rv, cfg.max_iter)
+            otb, oit, ocb = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(C_, np.uint32), np.zeros(C_, np.uint8)
+            rc = oracle().orc_dlsch_decode_harq(C.byref(sch), p(np.ascontiguousarray(g[b, n_cqi:G])), 0, 1 if new else 0, p(harq[b].w), p(harq[b].crc),
+                                                p(harq[b].data), p(otb), p(oit), p(ocb))
+            assert bool(ok[b]) == (rc == 0) and np.array_equal(it[b], oit), what + (bool(ok[b]), rc, it[b], oit)
+            if done[b]:
+                assert not ok[b] and not oit.any(), what  # a duplicate retransmission
+            if ok[b]:
+                assert np.array_equal(tb[b], otb[:tbs // 8 + 3]) and np.array_equal(tb[b][:tbs // 8], data[b]), what
+                done[b] = True
+                n_ok += 1
+    assert n_ok > 0
+    rx.free()
+
