@@ -1839,6 +1839,63 @@ def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
     rx.free()
 
 
+@pytest.mark.parametrize("seed", range(14))
+def test_dl_rx_ports_antennas_csi_drawn_configurations(hp, seed):
+    """The single-layer receive pipeline over its option space, drawn: 1 / 2 / 4 transmit ports (transmit diversity), 1 / 2 receive antennas,
+    CSI weighting on or off (csi_correction, pdsch.c:574-690), 16- / 8-bit LLRs, ZF or MMSE, CFI, bandwidth, cell id, RNTI, modulation, a
+    non-table transport-block size. LLRs (before the weighting) within one LSB of the oracle's on at most 2 in 1000; then the oracle's
+    csi_correction applied to the DEVICE's LLRs with the DEVICE's per-RE gains, and its integer back end on the result: CRC flags, pass
+    counts and bytes equal the device's exactly - so the weighting's rounding, its group handling and the decoder are checked bit for bit."""
+    from _libs import OrcCbsegm, OrcSchCfg
+    rng = np.random.default_rng(7900 + seed)
+    prb, mod = int(rng.choice([6, 15, 25, 50])), int(rng.choice([1, 2, 3]))
+    npt, nrx, csi, llr8, mmse = int(rng.choice([1, 2, 4])), int(rng.choice([1, 2])), bool(seed % 3 != 1), bool(seed % 4 == 3), bool(seed % 5 != 4)
+    cell_id, rnti, cfi = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(1, 4))
+    probe = DlConfig(prb, cell_id, mod, 16, cfi=cfi, rnti=rnti, nof_ports=npt)
+    nbits = min(len(probe.indices(sf)) for sf in (0, 1, 5)) * probe.Qm
+    tbs = max(40, int(float(rng.uniform(0.25, 0.75)) * nbits) // 8 * 8)
+    while True:
+        seg = OrcCbsegm()
+        if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+            break
+        tbs -= 8
+    cfg = DlConfig(prb, cell_id, mod, tbs, cfi=cfi, rnti=rnti, nof_rx=nrx, nof_ports=npt, llr8=llr8, csi=csi)
+    tti0, nsf = int(rng.integers(0, 10240)), 3
+    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / nbits - 0.4) + float(rng.uniform(-2.0, 4.0)) - (3.0 if nrx == 2 else 0.0)
+    iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rx = hp.DlRx(cell_id, prb, cfi, rnti, mod, tbs, 6, nsf, mmse, hc, llr_8bit=llr8, nof_rx=nrx, nof_ports=npt, csi=csi)
+    tb, ok = rx.decode(np.stack(iq), tti0)
+    it = rx.debug(6, np.uint32, nsf * cfg.seg.C).reshape(nsf, -1)
+    max_re = max(rx.nof_re(sf) for sf in (0, 1, 5))
+    e_all = rx.debug(4, np.int8 if llr8 else np.int16, nsf * rx.e_stride).reshape(nsf, -1)
+    gains = rx.debug(9, np.float32, nsf * max_re).reshape(nsf, -1) if csi else None
+    n_diff = n_tot = 0
+    for b in range(nsf):
+        what = (seed, prb, mod, npt, nrx, csi, llr8, mmse, cfi, tbs, tti0 + b, snr)
+        nre = rx.nof_re((tti0 + b) % 10)
+        nb = nre * cfg.Qm
+        e = np.ascontiguousarray(e_all[b, :nb])
+        if mmse:  # the oracle chain always equalises with the noise estimate
+            r = oracle_rx(cfg, iq[b], tti0 + b, keep=True)
+            diff = np.abs(e.astype(np.int32) - r["e_raw"].astype(np.int32))
+            assert diff.max() <= 1, what
+            n_diff += int((diff != 0).sum())
+            n_tot += nb
+        if csi:
+            g = np.ascontiguousarray(gains[b, :nre])
+            (oracle().orc_csi_correction_b if llr8 else oracle().orc_csi_correction_s)(p(e), p(g), nre, mod)
+        sch = OrcSchCfg(tbs, nb, cfg.Qm_sch, 0, cfg.max_iter)
+        otb, oit, ocb = np.zeros(tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+        rc = (oracle().orc_dlsch_decode_8bit if llr8 else oracle().orc_dlsch_decode)(C.byref(sch), p(e), p(otb), p(oit), p(ocb))
+        assert bool(ok[b]) == (rc == 0) and np.array_equal(it[b], oit) and np.array_equal(tb[b], otb[:tbs // 8 + 3]), what + (bool(ok[b]), rc, it[b], oit)
+        if ok[b]:
+            assert np.array_equal(tb[b][:tbs // 8], data[b]), what
+    assert n_diff <= 2e-3 * n_tot + 2, "LLR LSB differences on %d of %d" % (n_diff, n_tot)
+    rx.free()
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_dl_rx_harq_drawn_sequences(hp, seed):
     """HARQ on the device with redundancy-version SEQUENCES drawn at random - any start version, repeats, up to five transmissions, a new
