@@ -59,8 +59,9 @@ def test_cfg2_full_batch_round_trip_and_oracle_sample(hp):
 
 def test_cfg2_full_batch_harq_gain(hp):
     """HARQ at full batch (srslte_hip_dl_rx_batch_harq): at an SNR where a single transmission of MCS 28 almost never decodes, the rv 2
-    retransmission combined into the kept soft buffers decodes almost every block; blocks that passed in the first round keep their
-    bytes (they are neither combined nor decoded again, sch.c:317-318); no block that passes its CRC is wrong."""
+    retransmission combined into the kept soft buffers decodes almost every block that failed; the few that passed in the first round are
+    neither combined nor decoded again (sch.c:317-318) and their duplicate retransmission is refused as upstream refuses it; no block that
+    passes its CRC is wrong."""
     prb, mod, tbs, B = 100, 3, 75376, 128
     rng = np.random.default_rng(7)
     data = rng.integers(0, 256, (B, tbs // 8), dtype=np.uint8)
@@ -76,8 +77,11 @@ def test_cfg2_full_batch_harq_gain(hp):
             if ok[b]:
                 assert np.array_equal(tb[b][:tbs // 8], data[b]), (rv, b)
         oks.append(ok.copy())
-    assert oks[0].sum() < B // 4 and oks[1].sum() > 3 * B // 4, (int(oks[0].sum()), int(oks[1].sum()))
-    assert (oks[1] >= oks[0]).all()
+    first = oks[0].astype(bool)
+    assert first.sum() < B // 4 and oks[1][~first].sum() > 3 * (~first).sum() // 4, (int(first.sum()), int(oks[1].sum()))
+    # the MAC would not retransmit a block it has acknowledged; sent anyway, the duplicate is refused as upstream's decode_tb_cb refuses it
+    # (sch.c:399-410: the bytes of passed blocks are kept only while the transport block as a whole has failed)
+    assert not oks[1][first].any()
     tx.free()
     rx.free()
 
@@ -124,8 +128,11 @@ def test_cfg3_full_batch_uplink_harq_gain(hp):
             if ok[b]:
                 assert np.array_equal(tb[b][:tbs // 8], data[b]), (rv, b)
         oks.append(ok.copy())
-    assert oks[0].sum() < B // 4 and oks[1].sum() > 3 * B // 4, (int(oks[0].sum()), int(oks[1].sum()))
-    assert (oks[1] >= oks[0]).all()
+    first = oks[0].astype(bool)
+    assert first.sum() < B // 4 and oks[1][~first].sum() > 3 * (~first).sum() // 4, (int(first.sum()), int(oks[1].sum()))
+    # the MAC would not retransmit a block it has acknowledged; sent anyway, the duplicate is refused as upstream's decode_tb_cb refuses it
+    # (sch.c:399-410: the bytes of passed blocks are kept only while the transport block as a whole has failed)
+    assert not oks[1][first].any()
     tx.free()
     rx.free()
 

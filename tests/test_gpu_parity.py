@@ -2039,7 +2039,9 @@ def test_dl_tx_chain_drawn_configurations(hp, seed):
 @pytest.mark.parametrize("npt,nrx", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2)])
 def test_dl_tx_rx_loop(hp, npt, nrx):
     """Device transmit chain into the device receive chain (noise-free; the ports of a 2-port cell reach the antennas with different
-    flat gains): every transport block comes back; then the same blocks as a HARQ retransmission (rv 2) into the kept soft buffers."""
+    flat gains): every transport block comes back; then new blocks under noise that no block survives, their retransmission (rv 2,
+    noise-free) into the kept soft buffers, which delivers them all; and a duplicate retransmission of the delivered blocks, which is
+    refused as upstream's decode_tb_cb refuses it (sch.c:399-410: CRC flag 0, see the HARQ section of DESIGN.md)."""
     prb, mod, tbs, nsf = 50, 3, 30576, 12
     rng = np.random.default_rng(78)
     data = rng.integers(0, 256, (nsf, tbs // 8), dtype=np.uint8)
@@ -2049,11 +2051,23 @@ def test_dl_tx_rx_loop(hp, npt, nrx):
     rx = hp.DlRx(5, prb, 1, 0x4321, mod, tbs, 6, nsf, True, hc, nof_rx=nrx, nof_ports=npt, power_scale=True, p_a=0.0)  # phy_dl_test.c:176-178,:219-221
     gains = np.array([[1.0, 0.7 * np.exp(1.1j), 0.9 * np.exp(-2.0j), 0.6 * np.exp(0.4j)],
                       [0.8 * np.exp(-0.6j), 0.9 * np.exp(2.2j), 0.7 * np.exp(1.5j), 1.1 * np.exp(-1.2j)]], np.complex64)  # [antenna][port]
-    for rv, new in ((0, True), (2, False)):
+    delivered = np.zeros(nsf, bool)
+    for step, (rv, new, noisy) in enumerate(((0, True, False), (0, True, True), (2, False, False), (3, False, False))):
         iq = tx.encode(data, 3, rv)  # [nsf][npt][sf_len]
         ant = np.stack([sum(gains[a, port] * iq[:, port] for port in range(npt)) for a in range(nrx)], axis=1)  # [nsf][nrx][sf_len]
+        if noisy:  # about 10 dB: below the waterfall of this rate, the soft buffers still hold something to combine with
+            ant = ant + np.std(ant) * 0.3 * ((rng.standard_normal(ant.shape) + 1j * rng.standard_normal(ant.shape)) / np.sqrt(2))
         tb, ok = rx.decode_harq(np.ascontiguousarray(ant, np.complex64), 3, rv, new)
-        assert ok.all() and np.array_equal(tb[:, :tbs // 8], data), rv
+        ok = ok.astype(bool)
+        if new:
+            delivered[:] = False
+        assert not ok[delivered].any(), (step, rv, ok)  # duplicates of delivered blocks are refused
+        if not noisy:
+            assert ok[~delivered].all(), (step, rv, ok)  # a clean (re)transmission delivers what was still missing
+        else:
+            assert not ok.all(), (step, rv, ok)
+        assert np.array_equal(tb[ok, :tbs // 8], data[ok]), (step, rv)
+        delivered |= ok
     tx.free()
     rx.free()
 
