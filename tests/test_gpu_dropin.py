@@ -80,6 +80,25 @@ def test_reference_ctest(prog, args):
 
 
 @need_bin
+def test_whole_default_ctest_matrix_of_pdsch_test_and_pusch_test():
+    """Every pdsch_test line of lib/src/phy/phch/test/CMakeLists.txt:97-200 (76: TM1-4, one and two codewords, every codebook index, codeword
+    swap, 256QAM, six bandwidths; their argument lists are in tests/golden/ctest_pdsch_test_args.json) and the default pusch_test loops of
+    :248-316 (36: with and without HARQ-ACK and a wide-band CQI report). scripts/dropin_full_matrix.py runs these plus the 241 phy_dl_test
+    invocations of lib/test/phy/CMakeLists.txt:27-58 (profiles/r03/dropin_full_ctest_matrix.txt: 353 of 353 exit 0)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import dropin_full_matrix
+    rows = [r for r in dropin_full_matrix.matrix() if r[0] in ("pdsch_test", "pusch_test")]
+    assert len(rows) == 76 + 36
+    bad = []
+    for prog, args in rows:
+        rc, out = run(prog, args)
+        if rc != 0:
+            bad.append((prog, args, rc, out[-300:]))
+    assert not bad, bad
+
+
+@need_bin
 def test_recorded_iq_ctests():
     """lib/src/phy/phch/test/CMakeLists.txt:233-238: the reference's file tests on its own captures (tests/golden/iq/)."""
     for prog, args, name in (("pbch_file_test", [], "signal.1.92M.dat"), ("pcfich_file_test", ["-c", "150", "-n", "50", "-p", "2"], "signal.10M.dat"),
