@@ -48,6 +48,10 @@ CASES = [
     ("pusch_test", ["-n", "50", "-L", "50", "-m", "20"]),
     # :206-208 - PMCH over the MBSFN (extended-CP) OFDM modulator / demodulator and the decoder
     ("pmch_test", ["-m", "6", "-n", "50"]), ("pmch_test", ["-m", "15", "-n", "100"]), ("pmch_test", ["-m", "25", "-n", "100"]),
+    # lib/src/phy/sync/test/CMakeLists.txt:69-77 - the reference's PSS / SSS search (FFT convolutions on srslte_dft_*) on subframes from srslte_ofdm_tx_*
+    ("sync_test", ["-o", "100", "-c", "501"]), ("sync_test", ["-o", "400", "-c", "2"]), ("sync_test", ["-o", "100", "-e", "-c", "150"]),
+    ("sync_test", ["-o", "400", "-e", "-c", "151"]), ("sync_test", ["-o", "100", "-p", "50", "-c", "501"]), ("sync_test", ["-o", "400", "-p", "50", "-c", "500"]),
+    ("sync_test", ["-o", "100", "-e", "-p", "50", "-c", "133"]), ("sync_test", ["-o", "400", "-e", "-p", "50", "-c", "123"]),
     # lib/test/phy/CMakeLists.txt: the whole chain eNB -> UE, all four transmission modes go through our OFDM / estimator / decoder
     ("phy_dl_test", ["-p", "6", "-t", "1", "-m", "7"]), ("phy_dl_test", ["-p", "25", "-t", "2", "-m", "21"]), ("phy_dl_test", ["-p", "50", "-t", "4", "-m", "14"]),
     ("phy_dl_test", ["-p", "25", "-t", "4", "-m", "28"]), ("phy_dl_test", ["-p", "100", "-t", "1", "-q", "-m", "27"]),
