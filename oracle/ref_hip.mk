@@ -6,7 +6,9 @@
 #   lib/test/phy/phy_dl_test.c, phch/test/{pdsch_test,pusch_test,pdsch_pdcch_file_test,pcfich_file_test,pbch_file_test,pmch_file_test}.c,
 #   phch/test/pmch_test.c, fec/test/{turbodecoder_test,turbocoder_test}.c, dft/test/ofdm_test.c, utils/test/dft_test.c,
 #   ch_estimation/test/{chest_test_dl,chest_test_ul}.c,
-#   modem/test/{soft_demod_test,modem_test}.c, sync/test/sync_test.c (the reference's PSS / SSS search over this library's OFDM modulator and DFTs)
+#   modem/test/{soft_demod_test,modem_test}.c, sync/test/sync_test.c (the reference's PSS / SSS search over this library's OFDM modulator and DFTs),
+#   phch/test/{pbch_test,pcfich_test,pdcch_test,phich_test,phich_file_test}.c (control channels: the reference's own code over this library's
+#   srslte_chest_dl_res_* / srslte_refsignal_cs_* / OFDM / estimator)
 # tests/test_gpu_dropin.py runs them on the GPU box with the reference's CTest arguments and asserts exit code 0.
 # Nothing is stubbed: the same flags / force-include handling of the cmake-generated version.h as ref.mk.
 #
@@ -31,7 +33,9 @@ TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/ph
             lib/src/phy/phch/test/pcfich_file_test lib/src/phy/phch/test/pbch_file_test lib/src/phy/phch/test/pmch_file_test \
             lib/src/phy/fec/test/turbodecoder_test lib/src/phy/fec/test/turbocoder_test lib/src/phy/dft/test/ofdm_test lib/src/phy/utils/test/dft_test \
             lib/src/phy/ch_estimation/test/chest_test_dl lib/src/phy/ch_estimation/test/chest_test_ul lib/src/phy/phch/test/pmch_test \
-            lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test lib/src/phy/sync/test/sync_test
+            lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test lib/src/phy/sync/test/sync_test \
+            lib/src/phy/phch/test/pbch_test lib/src/phy/phch/test/pcfich_test lib/src/phy/phch/test/pdcch_test lib/src/phy/phch/test/phich_test \
+            lib/src/phy/phch/test/phich_file_test
 TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
 
 .PHONY: ref_hip

@@ -52,6 +52,18 @@ CASES = [
     ("sync_test", ["-o", "100", "-c", "501"]), ("sync_test", ["-o", "400", "-c", "2"]), ("sync_test", ["-o", "100", "-e", "-c", "150"]),
     ("sync_test", ["-o", "400", "-e", "-c", "151"]), ("sync_test", ["-o", "100", "-p", "50", "-c", "501"]), ("sync_test", ["-o", "400", "-p", "50", "-c", "500"]),
     ("sync_test", ["-o", "100", "-e", "-p", "50", "-c", "133"]), ("sync_test", ["-o", "400", "-e", "-p", "50", "-c", "123"]),
+    # lib/src/phy/phch/test/CMakeLists.txt:28-88 - the control channels' own tests: the reference's code over this library's srslte_chest_dl_res_*
+    # and CRS functions (the channels themselves are outside the path)
+    ("pbch_test", ["-p", "1", "-n", "6", "-c", "100"]), ("pbch_test", ["-p", "2", "-n", "6", "-c", "100"]), ("pbch_test", ["-p", "4", "-n", "6", "-c", "100"]),
+    ("pbch_test", ["-p", "1", "-n", "50", "-c", "50"]), ("pbch_test", ["-p", "2", "-n", "50", "-c", "50"]), ("pbch_test", ["-p", "4", "-n", "50", "-c", "50"]),
+    ("pcfich_test", ["-p", "1", "-n", "6"]), ("pcfich_test", ["-p", "2", "-n", "6"]), ("pcfich_test", ["-p", "4", "-n", "6"]),
+    ("pcfich_test", ["-p", "1", "-n", "10"]), ("pcfich_test", ["-p", "2", "-n", "10"]), ("pcfich_test", ["-p", "4", "-n", "10"]),
+    ("phich_test", ["-p", "1", "-n", "6"]), ("phich_test", ["-p", "2", "-n", "6"]), ("phich_test", ["-p", "4", "-n", "6", "-g", "1/6"]),
+    ("phich_test", ["-p", "1", "-n", "6", "-e"]), ("phich_test", ["-p", "2", "-n", "6", "-e", "-l"]), ("phich_test", ["-p", "4", "-n", "6", "-e", "-l", "-g", "2"]),
+    ("phich_test", ["-p", "1", "-n", "10", "-e"]), ("phich_test", ["-p", "2", "-n", "10", "-g", "2"]), ("phich_test", ["-p", "4", "-n", "10", "-e", "-l", "-g", "1/2"]),
+    ("pdcch_test", ["-n", "6"]), ("pdcch_test", ["-n", "15"]), ("pdcch_test", ["-n", "25"]), ("pdcch_test", ["-n", "50"]), ("pdcch_test", ["-n", "75"]),
+    ("pdcch_test", ["-n", "100"]), ("pdcch_test", ["-n", "6", "-p", "2"]), ("pdcch_test", ["-n", "15", "-p", "2"]), ("pdcch_test", ["-n", "25", "-p", "2"]),
+    ("pdcch_test", ["-n", "50", "-p", "2"]), ("pdcch_test", ["-n", "75", "-p", "2"]), ("pdcch_test", ["-n", "100", "-p", "2"]),
     # lib/test/phy/CMakeLists.txt: the whole chain eNB -> UE, all four transmission modes go through our OFDM / estimator / decoder
     ("phy_dl_test", ["-p", "6", "-t", "1", "-m", "7"]), ("phy_dl_test", ["-p", "25", "-t", "2", "-m", "21"]), ("phy_dl_test", ["-p", "50", "-t", "4", "-m", "14"]),
     ("phy_dl_test", ["-p", "25", "-t", "4", "-m", "28"]), ("phy_dl_test", ["-p", "100", "-t", "1", "-q", "-m", "27"]),
@@ -106,6 +118,7 @@ def test_whole_default_ctest_matrix_of_pdsch_test_and_pusch_test():
 def test_recorded_iq_ctests():
     """lib/src/phy/phch/test/CMakeLists.txt:233-238: the reference's file tests on its own captures (tests/golden/iq/)."""
     for prog, args, name in (("pbch_file_test", [], "signal.1.92M.dat"), ("pcfich_file_test", ["-c", "150", "-n", "50", "-p", "2"], "signal.10M.dat"),
+                             ("phich_file_test", ["-c", "150", "-n", "50", "-p", "2"], "signal.10M.dat"),
                              ("pdsch_pdcch_file_test", ["-c", "1", "-f", "3", "-n", "6", "-p", "1"], "signal.1.92M.amar.dat"),
                              ("pmch_file_test", [], "pmch_100prbs_MCS2_SR0.bin")):
         rc, out = run(prog, args + ["-i", os.path.join(IQ_DIR, name)])
