@@ -64,6 +64,13 @@ CASES = [
     ("pdcch_test", ["-n", "6"]), ("pdcch_test", ["-n", "15"]), ("pdcch_test", ["-n", "25"]), ("pdcch_test", ["-n", "50"]), ("pdcch_test", ["-n", "75"]),
     ("pdcch_test", ["-n", "100"]), ("pdcch_test", ["-n", "6", "-p", "2"]), ("pdcch_test", ["-n", "15", "-p", "2"]), ("pdcch_test", ["-n", "25", "-p", "2"]),
     ("pdcch_test", ["-n", "50", "-p", "2"]), ("pdcch_test", ["-n", "75", "-p", "2"]), ("pdcch_test", ["-n", "100", "-p", "2"]),
+    # lib/src/phy/phch/test/CMakeLists.txt:335-364 - the reference's PRACH generator and detector (prach.c) over srslte_dft_*: 839- / 139-point
+    # Zadoff-Chu transforms and the long (I)FFTs of every bandwidth, formats 0-3, root sequences, zero-correlation zones, several preambles at once
+    ("prach_test", []), ("prach_test", ["-n", "15"]), ("prach_test", ["-n", "25"]), ("prach_test", ["-n", "50"]), ("prach_test", ["-n", "75"]),
+    ("prach_test", ["-n", "100"]), ("prach_test", ["-f", "0"]), ("prach_test", ["-f", "1"]), ("prach_test", ["-f", "2"]), ("prach_test", ["-f", "3"]),
+    ("prach_test", ["-r", "1"]), ("prach_test", ["-r", "2"]), ("prach_test", ["-r", "3"]), ("prach_test", ["-z", "0"]), ("prach_test", ["-z", "2"]),
+    ("prach_test", ["-z", "3"]), ("prach_test_multi", []), ("prach_test_multi", ["-n", "32"]), ("prach_test_multi", ["-n", "16"]),
+    ("prach_test_multi", ["-n", "8"]), ("prach_test_multi", ["-n", "4"]),
     # lib/test/phy/CMakeLists.txt: the whole chain eNB -> UE, all four transmission modes go through our OFDM / estimator / decoder
     ("phy_dl_test", ["-p", "6", "-t", "1", "-m", "7"]), ("phy_dl_test", ["-p", "25", "-t", "2", "-m", "21"]), ("phy_dl_test", ["-p", "50", "-t", "4", "-m", "14"]),
     ("phy_dl_test", ["-p", "25", "-t", "4", "-m", "28"]), ("phy_dl_test", ["-p", "100", "-t", "1", "-q", "-m", "27"]),
