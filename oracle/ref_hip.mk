@@ -9,7 +9,7 @@
 #   modem/test/{soft_demod_test,modem_test}.c, sync/test/sync_test.c (the reference's PSS / SSS search over this library's OFDM modulator and DFTs),
 #   phch/test/{pbch_test,pcfich_test,pdcch_test,phich_test,phich_file_test}.c (control channels: the reference's own code over this library's
 #   srslte_chest_dl_res_* / srslte_refsignal_cs_* / OFDM / estimator), phch/test/{prach_test,prach_test_multi}.c (the reference's PRACH generator and
-#   detector over srslte_dft_*: 839- and 139-point sequences, 1536- to 24576-point transforms)
+#   detector over srslte_dft_*: 839- and 139-point sequences, 1536- to 24576-point transforms), phch/test/{pucch_test,pdcch_file_test}.c
 # tests/test_gpu_dropin.py runs them on the GPU box with the reference's CTest arguments and asserts exit code 0.
 # Nothing is stubbed: the same flags / force-include handling of the cmake-generated version.h as ref.mk.
 #
@@ -36,7 +36,8 @@ TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/ph
             lib/src/phy/ch_estimation/test/chest_test_dl lib/src/phy/ch_estimation/test/chest_test_ul lib/src/phy/phch/test/pmch_test \
             lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test lib/src/phy/sync/test/sync_test \
             lib/src/phy/phch/test/pbch_test lib/src/phy/phch/test/pcfich_test lib/src/phy/phch/test/pdcch_test lib/src/phy/phch/test/phich_test \
-            lib/src/phy/phch/test/phich_file_test lib/src/phy/phch/test/prach_test lib/src/phy/phch/test/prach_test_multi
+            lib/src/phy/phch/test/phich_file_test lib/src/phy/phch/test/prach_test lib/src/phy/phch/test/prach_test_multi \
+            lib/src/phy/phch/test/pdcch_file_test lib/src/phy/phch/test/pucch_test
 TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
 
 .PHONY: ref_hip

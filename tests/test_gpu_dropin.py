@@ -71,6 +71,8 @@ CASES = [
     ("prach_test", ["-r", "1"]), ("prach_test", ["-r", "2"]), ("prach_test", ["-r", "3"]), ("prach_test", ["-z", "0"]), ("prach_test", ["-z", "2"]),
     ("prach_test", ["-z", "3"]), ("prach_test_multi", []), ("prach_test_multi", ["-n", "32"]), ("prach_test_multi", ["-n", "16"]),
     ("prach_test_multi", ["-n", "8"]), ("prach_test_multi", ["-n", "4"]),
+    # :325-326 - PUCCH: the reference's chest_ul.c / pucch.c over this library's pilot averaging, noise estimation and filter taps (chest_common.c)
+    ("pucch_test", []), ("pucch_test", ["-q"]),
     # lib/test/phy/CMakeLists.txt: the whole chain eNB -> UE, all four transmission modes go through our OFDM / estimator / decoder
     ("phy_dl_test", ["-p", "6", "-t", "1", "-m", "7"]), ("phy_dl_test", ["-p", "25", "-t", "2", "-m", "21"]), ("phy_dl_test", ["-p", "50", "-t", "4", "-m", "14"]),
     ("phy_dl_test", ["-p", "25", "-t", "4", "-m", "28"]), ("phy_dl_test", ["-p", "100", "-t", "1", "-q", "-m", "27"]),
@@ -126,6 +128,7 @@ def test_recorded_iq_ctests():
     """lib/src/phy/phch/test/CMakeLists.txt:233-238: the reference's file tests on its own captures (tests/golden/iq/)."""
     for prog, args, name in (("pbch_file_test", [], "signal.1.92M.dat"), ("pcfich_file_test", ["-c", "150", "-n", "50", "-p", "2"], "signal.10M.dat"),
                              ("phich_file_test", ["-c", "150", "-n", "50", "-p", "2"], "signal.10M.dat"),
+                             ("pdcch_file_test", ["-c", "1", "-f", "3", "-n", "6", "-p", "1"], "signal.1.92M.amar.dat"),
                              ("pdsch_pdcch_file_test", ["-c", "1", "-f", "3", "-n", "6", "-p", "1"], "signal.1.92M.amar.dat"),
                              ("pmch_file_test", [], "pmch_100prbs_MCS2_SR0.bin")):
         rc, out = run(prog, args + ["-i", os.path.join(IQ_DIR, name)])
