@@ -37,7 +37,7 @@ TESTS    := lib/test/phy/phy_dl_test lib/src/phy/phch/test/pdsch_test lib/src/ph
             lib/src/phy/modem/test/soft_demod_test lib/src/phy/modem/test/modem_test lib/src/phy/sync/test/sync_test \
             lib/src/phy/phch/test/pbch_test lib/src/phy/phch/test/pcfich_test lib/src/phy/phch/test/pdcch_test lib/src/phy/phch/test/phich_test \
             lib/src/phy/phch/test/phich_file_test lib/src/phy/phch/test/prach_test lib/src/phy/phch/test/prach_test_multi \
-            lib/src/phy/phch/test/pdcch_file_test lib/src/phy/phch/test/pucch_test
+            lib/src/phy/phch/test/pdcch_file_test lib/src/phy/phch/test/pucch_test lib/src/phy/fec/test/rm_turbo_test
 TEST_BIN := $(addprefix $(HOUT)/,$(notdir $(TESTS)))
 
 .PHONY: ref_hip

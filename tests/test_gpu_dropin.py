@@ -33,6 +33,8 @@ CASES = [
     # lib/src/phy/fec/test/CMakeLists.txt:44-51
     ("turbodecoder_test", ["-n", "100", "-s", "1", "-l", "504", "-e", "1.0", "-t"]), ("turbodecoder_test", ["-n", "100", "-s", "1", "-l", "504", "-e", "2.0", "-t"]),
     ("turbodecoder_test", ["-n", "100", "-s", "1", "-l", "6144", "-e", "1.5", "-t"]), ("turbodecoder_test", ["-n", "1", "-s", "1", "-k", "-e", "0.5"]),
+    # :35-36 - the reference's rate matcher over this library's srslte_cbsegm_* tables
+    ("rm_turbo_test", ["-e", "1920"]), ("rm_turbo_test", ["-e", "8192"]),
     # lib/src/phy/ch_estimation/test/CMakeLists.txt:28-34
     ("chest_test_dl", ["-c", "0"]), ("chest_test_dl", ["-c", "1"]), ("chest_test_dl", ["-c", "2"]), ("chest_test_dl", ["-c", "0", "-r", "50"]),
     ("chest_test_dl", ["-c", "1", "-r", "50"]), ("chest_test_dl", ["-c", "2", "-r", "50"]),
