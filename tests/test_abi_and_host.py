@@ -165,3 +165,28 @@ def test_round2_additions_reject_bad_arguments_without_gpu():
     for tail in ((4, 0, 0, 0), (4, 16, 0, 0), (65, 5, 0, 0), (0, 0, 1, 20)):  # cqi_len, I_offset_cqi, hopping, n_prb_slot1 (20 + 10 PRB > 25)
         assert lib.srslte_hip_ul_tx_create(C.byref(pkg.UlTxCfg(1, 25, 0x1234, 2, 4008, 10, 5, 0, 4, dm, 0, 0, 0, 0, 0, *tail))) is None, tail
         assert lib.srslte_hip_ul_rx_create(C.byref(pkg.UlRxCfg(1, 25, 0x1234, 2, 4008, 10, 5, 0, 6, 4, 1, dm, 0, 0, 0, 0, 0, *tail))) is None, tail
+
+
+def test_symbol_size_families_without_gpu():
+    """srslte_symbol_sz / srslte_symbol_sz_power2 / srslte_use_standard_symbol_size as phy_common.c:292-345 defines them (the library's own
+    definitions serve where the reference's phy_common.c is not linked in), against the oracle's; and the argument checks of the entry points
+    that take a symbol size (no kernel is launched: they fail before any device work)."""
+    lib = C.CDLL(HIP_SO)
+    lib.srslte_use_standard_symbol_size.argtypes = [C.c_bool]
+    lib.srslte_hip_ofdm_create_sz.restype = C.c_void_p
+    try:
+        for std in (False, True):
+            lib.srslte_use_standard_symbol_size(std)
+            oracle().orc_use_standard_symbol_size(std)
+            for prb in range(0, 112):
+                want = oracle().orc_symbol_sz(prb) if 0 < prb <= 110 else -1
+                assert lib.srslte_symbol_sz(prb) == want, (std, prb)
+                if prb > 0:
+                    assert lib.srslte_symbol_sz_power2(prb) == (oracle().orc_symbol_sz_power2(prb) if prb <= 110 else -1), prb
+    finally:
+        lib.srslte_use_standard_symbol_size(False)
+        oracle().orc_use_standard_symbol_size(False)
+    assert lib.srslte_symbol_sz(100) == 1536 and lib.srslte_symbol_sz_power2(100) == 2048 and lib.srslte_symbol_sz_power2(25) == 512
+    for prb, n in ((100, 1024), (25, 300), (50, 1000), (0, 128), (111, 2048), (6, 64)):  # carriers do not fit / not a size of either family / no such cell
+        assert not lib.srslte_hip_ofdm_create_sz(prb, n, 1, 1), (prb, n)
+    assert lib.srslte_hip_chest_dl_set_symbol_sz(None, 2048) == -2  # SRSLTE_ERROR_INVALID_INPUTS
