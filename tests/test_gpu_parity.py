@@ -794,8 +794,15 @@ def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
     rx.free()
 
 
+@pytest.mark.parametrize("prb", [7, 20, 33, 64, 91, 110])
+def test_dl_rx_chain_any_bandwidth(hp, prb):
+    """srslte_cell_isvalid takes any 6 .. 110 PRB (phy_common.c:43-52), not only the six of 36.101: the drawn-configuration test at bandwidths
+    between them (symbol size of the next one up, odd and even carrier counts, the half-PRB rule of srslte_pdsch_cp for odd counts)."""
+    test_dl_rx_chain_drawn_configurations(hp, 100 + prb, prb)
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_dl_rx_chain_drawn_configurations(hp, seed):
+def test_dl_rx_chain_drawn_configurations(hp, seed, force_prb=None):
     """test_dl_rx_chain on configurations DRAWN from the space the pipeline accepts instead of listed: bandwidth, cell id, RNTI, CFI-independent
     modulation, a transport-block size that is not taken from a table (any multiple of 8 that segments into one block length without filler,
     cbsegm.c:77-107) at a drawn code rate, a drawn first TTI and an SNR a few dB either side of the waterfall; 16- and 8-bit LLRs, one and
@@ -803,6 +810,8 @@ def test_dl_rx_chain_drawn_configurations(hp, seed):
     from _libs import OrcCbsegm, OrcSchCfg
     rng = np.random.default_rng(7000 + seed)
     prb = int(rng.choice([6, 15, 25, 50]))
+    if force_prb:
+        prb = force_prb
     mod = int(rng.choice([1, 2, 3]))
     llr8, nrx = bool(seed % 3 == 2), 1 + int(seed % 4 == 1)
     cell_id, rnti = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0))
@@ -1103,8 +1112,14 @@ def test_ul_rx_chain(hp, prb, L, n_prb, mod, tbs, snr, tti0, nsf, short):
     rx.free()
 
 
+@pytest.mark.parametrize("prb", [7, 20, 33, 64, 91, 110])
+def test_ul_rx_chain_any_bandwidth(hp, prb):
+    """The PUSCH receive chain at cell bandwidths between the six of 36.101 (any 6 .. 110 PRB is a valid cell, phy_common.c:43-52)."""
+    test_ul_rx_chain_drawn_configurations(hp, 100 + prb, prb)
+
+
 @pytest.mark.parametrize("seed", range(10))
-def test_ul_rx_chain_drawn_configurations(hp, seed):
+def test_ul_rx_chain_drawn_configurations(hp, seed, force_prb=None):
     """test_ul_rx_chain on configurations DRAWN from what the pipeline accepts: bandwidth, cell id, RNTI, an allocation of 2^a 3^b 5^c PRBs at a
     drawn offset (with or without hopping between the slots), modulation, DMRS cyclic shifts and group / sequence hopping, a transport-block
     size not taken from a table at a drawn code rate, shortened subframes, a drawn first TTI, an SNR around the waterfall. The float stages
@@ -1114,6 +1129,8 @@ def test_ul_rx_chain_drawn_configurations(hp, seed):
     from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
     rng = np.random.default_rng(7100 + seed)
     prb = int(rng.choice([6, 15, 25, 50, 100]))
+    if force_prb:
+        prb = force_prb
     sizes = [n for n in range(1, prb + 1) if _is_235(n)]
     L = int(rng.choice(sizes))
     n_prb = int(rng.integers(0, prb - L + 1))
