@@ -77,8 +77,14 @@ def test_dl_rx_two_layer_modes(hp, prb, cid, mod, tbs, mod2, tbs2, scheme, pmi, 
     rx.free()
 
 
+@pytest.mark.parametrize("prb", [7, 20, 33, 64])
+def test_dl_rx_two_layer_modes_any_bandwidth(hp, prb):
+    """The two-layer modes at cell bandwidths between the six of 36.101."""
+    test_dl_rx_two_layer_modes_drawn_configurations(hp, 100 + prb, prb)
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_dl_rx_two_layer_modes_drawn_configurations(hp, seed):
+def test_dl_rx_two_layer_modes_drawn_configurations(hp, seed, force_prb=None):
     """The two-layer modes on configurations DRAWN from what srslte_hip_dl_rx_create accepts: bandwidth, cell id, CFI, large-delay CDD or
     codebook multiplexing with one or two transport blocks and every allowed codebook index, modulation and a transport-block size not taken
     from a table per codeword, first TTI, SNR. Per codeword: LLRs within the float tolerance of test_dl_rx_two_layer_modes; then the oracle's
@@ -88,6 +94,7 @@ def test_dl_rx_two_layer_modes_drawn_configurations(hp, seed):
     from lte_sim import DlConfig, make_subframe_mimo, oracle_rx_mimo
     rng = np.random.default_rng(7500 + seed)
     prb, cid, cfi = int(rng.choice([6, 15, 25, 50])), int(rng.integers(0, 504)), int(rng.integers(1, 4))
+    prb = force_prb or prb
     scheme = "cdd" if seed % 2 else "mux"
     two = scheme == "cdd" or bool(seed % 4)
     pmi = 0 if scheme == "cdd" else int(rng.integers(0, 2 if two else 4))

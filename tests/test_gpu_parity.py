@@ -1208,13 +1208,13 @@ def test_ul_tx_chain(hp, prb, L, n_prb, mod, tbs, tti0, nsf, short):
 
 
 @pytest.mark.parametrize("seed", range(10))
-def test_ul_tx_chain_drawn_configurations(hp, seed):
+def test_ul_tx_chain_drawn_configurations(hp, seed, force_prb=None):
     """test_ul_tx_chain on configurations drawn from what the transmit pipeline accepts (the draw of test_ul_rx_chain_drawn_configurations):
     modulated symbols exactly, transform-precoded symbols, grid with DMRS and time samples to the float tolerance of the other tests."""
     from _libs import OrcCbsegm
     from lte_sim import UlConfig, make_ul_subframe
     rng = np.random.default_rng(7300 + seed)
-    prb = int(rng.choice([6, 15, 25, 50, 100]))
+    prb = force_prb or int(rng.choice([6, 15, 25, 50, 100]))
     L = int(rng.choice([n for n in range(1, prb + 1) if _is_235(n)]))
     n_prb = int(rng.integers(0, prb - L + 1))
     hop = None if seed % 3 else int(rng.integers(0, prb - L + 1))
@@ -2008,14 +2008,22 @@ def test_dl_tx_chain(hp, prb, mod, tbs, npt, tti0, nsf, rv, p_a):
     tx.free()
 
 
+@pytest.mark.parametrize("prb", [7, 20, 33, 64, 91, 110])
+def test_tx_chains_any_bandwidth(hp, prb):
+    """Both transmit chains at cell bandwidths between the six of 36.101."""
+    test_dl_tx_chain_drawn_configurations(hp, 100 + prb, prb)
+    test_ul_tx_chain_drawn_configurations(hp, 100 + prb, prb)
+
+
 @pytest.mark.parametrize("seed", range(10))
-def test_dl_tx_chain_drawn_configurations(hp, seed):
+def test_dl_tx_chain_drawn_configurations(hp, seed, force_prb=None):
     """test_dl_tx_chain on configurations drawn from what the transmit pipeline accepts: bandwidth, cell id, RNTI, 1 / 2 / 4 ports, modulation, a
     transport-block size not taken from a table (one block length, no filler) at a drawn code rate, redundancy version, power offset, first TTI."""
     from lte_sim import DlConfig, make_subframe
     from _libs import OrcCbsegm, OrcOfdm
     rng = np.random.default_rng(7200 + seed)
     prb, mod, npt = int(rng.choice([6, 15, 25, 50, 100])), int(rng.choice([1, 2, 3, 4])), int(rng.choice([1, 2, 4]))
+    prb = force_prb or prb
     cell_id, rnti, rv = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0)), int(rng.integers(0, 4))
     p_a = float(rng.choice([0.0, -3.0, 1.77, -1.0]))
     probe = DlConfig(prb, cell_id, mod, 16, rnti=rnti, nof_ports=npt)
