@@ -801,8 +801,14 @@ def test_dl_rx_chain_any_bandwidth(hp, prb):
     test_dl_rx_chain_drawn_configurations(hp, 100 + prb, prb)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_dl_rx_chain_drawn_configurations_256qam(hp, seed):
+    """The drawn-configuration test with 256QAM (srslte_mod_t 4; the 8-bit demapper's and the 16-bit one's 256QAM branches, Qm = 8)."""
+    test_dl_rx_chain_drawn_configurations(hp, 200 + seed, None, 4)
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_dl_rx_chain_drawn_configurations(hp, seed, force_prb=None):
+def test_dl_rx_chain_drawn_configurations(hp, seed, force_prb=None, force_mod=None):
     """test_dl_rx_chain on configurations DRAWN from the space the pipeline accepts instead of listed: bandwidth, cell id, RNTI, CFI-independent
     modulation, a transport-block size that is not taken from a table (any multiple of 8 that segments into one block length without filler,
     cbsegm.c:77-107) at a drawn code rate, a drawn first TTI and an SNR a few dB either side of the waterfall; 16- and 8-bit LLRs, one and
@@ -812,7 +818,7 @@ def test_dl_rx_chain_drawn_configurations(hp, seed, force_prb=None):
     prb = int(rng.choice([6, 15, 25, 50]))
     if force_prb:
         prb = force_prb
-    mod = int(rng.choice([1, 2, 3]))
+    mod = force_mod or int(rng.choice([1, 2, 3]))
     llr8, nrx = bool(seed % 3 == 2), 1 + int(seed % 4 == 1)
     cell_id, rnti = int(rng.integers(0, 504)), int(rng.integers(1, 0xFFF0))
     probe = DlConfig(prb, cell_id, mod, 16, rnti=rnti)
@@ -827,7 +833,7 @@ def test_dl_rx_chain_drawn_configurations(hp, seed, force_prb=None):
     cfg = DlConfig(prb, cell_id, mod, tbs, rnti=rnti, nof_rx=nrx, llr8=llr8)
     tti0, nsf = int(rng.integers(0, 10240)), 3
     # rough waterfall of a rate-r code at this modulation, +- a few dB: some blocks fail, some pass, either is fine - equality is the test
-    snr = {1: 1.0, 2: 7.0, 3: 12.0}[mod] + 10.0 * (tbs / nbits - 0.4) + float(rng.uniform(-2.0, 4.0)) - (3.0 if nrx == 2 else 0.0)
+    snr = {1: 1.0, 2: 7.0, 3: 12.0, 4: 18.0}[mod] + 10.0 * (tbs / nbits - 0.4) + float(rng.uniform(-2.0, 4.0)) - (3.0 if nrx == 2 else 0.0)
     iq, data = zip(*[make_subframe(cfg, tti0 + b, rng, snr_db=snr, amp=0.1) for b in range(nsf)])
     hc = hp.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
