@@ -794,6 +794,60 @@ def test_dl_rx_chain_8bit(hp, prb, mod, tbs, snr, tti0, nsf):
     rx.free()
 
 
+def test_smallest_and_largest_transport_blocks(hp):
+    """The ends of the size range through the fused receive pipelines, both directions: transport blocks of 16 / 24 / 40 bits (one code block
+    of K = 40 / 48 / 64: the generic decoder, and for 8-bit LLRs the widening fall-back of turbodecoder.c:438-469) on a 6-PRB cell, and
+    the largest a 110-PRB cell carries at 256QAM (117 256 bits in 20 code blocks; uplink 83 864 bits in 14) - CRC flags, pass counts and
+    the bytes of delivered blocks equal the oracle chain's on identical samples."""
+    from _libs import OrcCbsegm
+    from lte_sim import UlConfig, make_ul_subframe, oracle_ul_rx
+    rng = np.random.default_rng(1)
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+
+    def check(rx, cfg, iq, tti0, orc):
+        tb, ok = rx.decode(np.stack(iq), tti0)
+        it = rx.debug(6, np.uint32, len(iq) * cfg.seg.C).reshape(len(iq), -1)
+        for b in range(len(iq)):
+            r = orc(cfg, iq[b], tti0 + b)
+            assert bool(ok[b]) == r["ok"] and np.array_equal(it[b], r["iters"]), (cfg.tbs, b, ok[b], r["ok"], it[b], r["iters"])
+            if r["ok"]:
+                assert np.array_equal(tb[b], r["tb"]), (cfg.tbs, b)
+        rx.free()
+        return int(ok.sum())
+
+    n_ok = 0
+    for tbs in (16, 24, 40):
+        for llr8 in (False, True):
+            cfg = DlConfig(6, 9, 1, tbs, llr8=llr8)
+            iq = [make_subframe(cfg, 3 + b, rng, snr_db=-2.0, amp=0.1)[0] for b in range(3)]
+            n_ok += check(hp.DlRx(9, 6, 1, 0x1234, 1, tbs, 6, 3, True, hc, llr_8bit=llr8), cfg, iq, 3, oracle_rx)
+        cfg = UlConfig(6, 9, 1, tbs, 1, 2, n_dmrs=1)
+        iq = [make_ul_subframe(cfg, 3 + b, rng, snr_db=3.0, amp=0.1)[0] for b in range(3)]
+        n_ok += check(hp.UlRx(9, 6, 0x1234, 1, tbs, 1, 2, 1, 6, 3), cfg, iq, 3, oracle_ul_rx)
+
+    def largest(nbits, rate):
+        tbs = int(rate * nbits) // 8 * 8
+        while True:
+            seg = OrcCbsegm()
+            if oracle().orc_cbsegm(C.byref(seg), tbs) == 0 and seg.F == 0 and seg.C2 == 0:
+                return tbs
+            tbs -= 8
+
+    probe = DlConfig(110, 5, 4, 16)
+    tbs = largest(min(len(probe.indices(sf)) for sf in (0, 1, 5)) * probe.Qm, 0.92)
+    for llr8 in (False, True):
+        cfg = DlConfig(110, 5, 4, tbs, llr8=llr8)
+        assert cfg.seg.C == 20
+        iq = [make_subframe(cfg, 1 + b, rng, snr_db=34.0, amp=0.1)[0] for b in range(2)]
+        n_ok += check(hp.DlRx(5, 110, 1, 0x1234, 4, tbs, 6, 2, True, hc, llr_8bit=llr8), cfg, iq, 1, oracle_rx)
+    tbs = largest(UlConfig(110, 5, 3, 16, 108, 0).nbits, 0.9)
+    cfg = UlConfig(110, 5, 3, tbs, 108, 0, n_dmrs=1)
+    iq = [make_ul_subframe(cfg, 1 + b, rng, snr_db=30.0, amp=0.1)[0] for b in range(2)]
+    n_ok += check(hp.UlRx(5, 110, 0x1234, 3, tbs, 108, 0, 1, 6, 2), cfg, iq, 1, oracle_ul_rx)
+    assert n_ok >= 25
+
+
 @pytest.mark.parametrize("prb", [7, 20, 33, 64, 91, 110])
 def test_dl_rx_chain_any_bandwidth(hp, prb):
     """srslte_cell_isvalid takes any 6 .. 110 PRB (phy_common.c:43-52), not only the six of 36.101: the drawn-configuration test at bandwidths
