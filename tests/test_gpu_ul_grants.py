@@ -316,7 +316,8 @@ def test_ul_grants_tx_rx_round_trip(hp):
     rx.free()
 
 
-@pytest.mark.parametrize("prb,cell_id,short", [(6, 1, False), (15, 40, True), (25, 10, False), (50, 77, True), (75, 150, False), (100, 501, False)])
+@pytest.mark.parametrize("prb,cell_id,short", [(6, 1, False), (15, 40, True), (25, 10, False), (50, 77, True), (75, 150, False), (100, 501, False),
+                                               (33, 44, False), (110, 301, True), (7, 9, False)])
 def test_ul_grants_fuzz_round_trip(hp, prb, cell_id, short):
     """Random uplink schedules: every subframe of a 24-TTI run holds 1..4 PUSCHs at random offsets with random valid sizes (2^a 3^b 5^c PRB),
     some hopping between the slots, random cyclic shifts, modulations, the largest accepted transport block under a code rate of ~0.55,
