@@ -8,7 +8,8 @@ pass criterion. TM3 rows of phy_dl_test run the binary whose one difference is -
 
   python scripts/dropin_full_matrix.py --regen     (where /root/reference exists) rewrites tests/golden/ctest_pdsch_test_args.json: the
                                                    argument lists of the pdsch_test lines (data of the reference's test configuration)
-  python scripts/dropin_full_matrix.py [out.txt]   (GPU box) runs everything, prints a summary, writes one line per invocation"""
+  python scripts/dropin_full_matrix.py [out.txt]   (GPU box) runs everything, prints a summary, writes one line per invocation
+  python scripts/dropin_full_matrix.py --paranoid-sample [out.txt]   a slice of upstream's "Paranoid" pusch_test extension: every allocation size"""
 import json
 import os
 import re
@@ -58,11 +59,35 @@ def matrix():
     return rows
 
 
+def paranoid_sample():
+    """A slice of the "Paranoid" extension of the pusch_test loops (CMakeLists.txt:250-262): EVERY valid PUSCH allocation size of a 100-PRB cell
+    (34 sizes 2^a 3^b 5^c: every SC-FDMA transform length) x MCS 0 / 14 / 28 (27 with HARQ-ACK, as upstream's loop) x without / with a
+    HARQ-ACK bit x without / with a CQI report; the 64QAM rows with `-p enable_64qam`."""
+    sizes = (1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100)
+    rows = []
+    for n_prb in sizes:
+        for mcs in (0, 14, 28):
+            for ack in (-1, 1):
+                for cqi in ("none", "wideband"):
+                    m, a = mcs, ["-n", "100", "-L", str(n_prb)]
+                    if ack != -1:
+                        a += ["-p", "uci_ack", str(ack)]
+                        m = 27 if m == 28 else m
+                    if cqi != "none":
+                        a += ["-p", "cqi", cqi]
+                    if m >= 21:  # pusch_test leaves 64QAM off by default, pusch.c:326-331 then sends these MCS as 16QAM - at a code rate above 1
+                        a += ["-p", "enable_64qam", "1"]  # for the top MCS, which nothing can decode; with 64QAM on they are what the table says
+                    rows.append(("pusch_test", a + ["-m", str(m)]))
+    return rows
+
+
 def main():
     if "--regen" in sys.argv:
         return regen()
-    out = sys.argv[1] if len(sys.argv) > 1 else None
-    rows, bad, lines, t0 = matrix(), [], [], time.time()
+    sample = "--paranoid-sample" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    out = args[0] if args else None
+    rows, bad, lines, t0 = (paranoid_sample() if sample else matrix()), [], [], time.time()
     for i, (prog, args) in enumerate(rows):
         t = time.time()
         try:
@@ -81,7 +106,7 @@ def main():
         print("FAIL rc=%d: %s %s\n%s\n" % (rc, prog, " ".join(args), tail))
     if out:
         with open(out, "w") as f:
-            f.write("# scripts/dropin_full_matrix.py: the reference's default CTest matrix of pdsch_test, pusch_test and phy_dl_test through the drop-in\n")
+            f.write("# scripts/dropin_full_matrix.py%s: %s through the drop-in\n" % (" --paranoid-sample" if sample else "", "every valid PUSCH allocation size of a 100-PRB cell (pusch_test, a slice of upstream's Paranoid extension)" if sample else "the reference's default CTest matrix of pdsch_test, pusch_test and phy_dl_test"))
             f.write("# " + summary + "\n" + "\n".join(lines) + "\n")
             for prog, args, rc, tail in bad:
                 f.write("\nFAIL rc=%d: %s %s\n%s\n" % (rc, prog, " ".join(args), tail))
