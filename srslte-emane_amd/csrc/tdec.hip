@@ -203,6 +203,7 @@ struct TdecTables {            // per (K, W) device tables
   const uint16_t* inter;       // app1[inter[i]] = ext2[i]
   const uint16_t* deinter;     // app2[deinter[i]] = ext1[i]
   const uint32_t* crc_rem;     // x^(nbits-1-nat(i)) mod g for array position i (0 beyond nbits); nullptr = no early stop
+  const uint32_t* crc_rem_i;   // crc_rem[inter[j]]: the same remainders for position j of the INTERLEAVED sequence (tdec_pair_kernel)
 };
 
 struct TdecArgs {
@@ -1133,7 +1134,7 @@ struct TabKey {
 };
 struct TabDev {
   uint16_t *inter, *deinter;
-  uint32_t* crc_rem;
+  uint32_t *crc_rem, *crc_rem_i;
 };
 
 } // namespace
@@ -1213,6 +1214,7 @@ extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
     (void)hipFree(kv.second.inter);
     (void)hipFree(kv.second.deinter);
     if (kv.second.crc_rem) (void)hipFree(kv.second.crc_rem);
+    if (kv.second.crc_rem_i) (void)hipFree(kv.second.crc_rem_i);
   }
   (void)hipFree(q->d_work);
   (void)hipFree(q->d_beta);
@@ -1232,7 +1234,7 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
   if (it == q->tabs.end()) {
     std::vector<uint16_t> f, r;
     lte_qpp_tables(K, W, f, r);
-    TabDev d = {nullptr, nullptr, nullptr};
+    TabDev d = {nullptr, nullptr, nullptr, nullptr};
     HIP_TRY(hipMalloc((void**)&d.inter, K * 2));
     HIP_TRY(hipMalloc((void**)&d.deinter, K * 2));
     HIP_TRY(hipMemcpy(d.inter, f.data(), K * 2, hipMemcpyHostToDevice));
@@ -1249,12 +1251,19 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
       for (uint32_t n = 0; n < K; n++) pos[W ? (n % (K / W)) * W + n / (K / W) : n] = nat[n];
       HIP_TRY(hipMalloc((void**)&d.crc_rem, K * 4));
       HIP_TRY(hipMemcpy(d.crc_rem, pos.data(), K * 4, hipMemcpyHostToDevice));
+      if (W == 16) { // sign(app1'[inter[j]]) = sign(ext2[j]): the syndrome of a DEC2 pass is taken before the interleaver (tdec_pair.inc)
+        std::vector<uint32_t> posi(K);
+        for (uint32_t j = 0; j < K; j++) posi[j] = pos[f[j]];
+        HIP_TRY(hipMalloc((void**)&d.crc_rem_i, K * 4));
+        HIP_TRY(hipMemcpy(d.crc_rem_i, posi.data(), K * 4, hipMemcpyHostToDevice));
+      }
     }
     it = q->tabs.emplace(key, d).first;
   }
   t->inter   = it->second.inter;
   t->deinter = it->second.deinter;
   t->crc_rem = it->second.crc_rem;
+  t->crc_rem_i = it->second.crc_rem_i;
   return SRSLTE_SUCCESS;
 }
 

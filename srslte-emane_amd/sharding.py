@@ -20,8 +20,9 @@ def result_layout(tb_stride, batch):
 def gather_results(result, gathered, dist=None, dst=0, async_op=False):
     """ONE collective per batch: every rank's `result` (1-D uint8 tensor, the record of result_layout) lands in row `rank` of
     `gathered` ([world, nbytes] on rank `dst`, None elsewhere). Device tensors with the nccl (= RCCL) backend, CPU tensors with gloo.
-    Ordered after the work already queued on torch's current stream. Without a process group: a copy into row 0."""
-    if dist is None or not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    Ordered after the work already queued on torch's current stream. Without a process group: a copy into row 0; a one-rank group takes
+    the collective like any other (bench.py --force-dist: the RCCL calls on a one-GPU box)."""
+    if dist is None or not dist.is_available() or not dist.is_initialized():
         if gathered is not None:
             gathered[0].copy_(result, non_blocking=True)
         return None

@@ -192,7 +192,7 @@ def test_cfg4_eight_ues_on_one_device():
     spec = importlib.util.spec_from_file_location("cfg4_one_device", os.path.join(ROOT, "scripts", "cfg4_one_device.py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
-    out = m.run(ues=8, batch=16, steps=2, snr=18.0, oracle_sample=2, quiet=True)
+    out = m.run(ues=8, batch=16, steps=2, snr=18.0, oracle_sample=2, quiet=True, warm_s=0.0, timed_s=0.0)
     c = out["config"]
     assert out["rehearsal"] and c["undetected_errors"] == 0 and c["oracle_sample"] == 16 and c["oracle_sample_agrees"] == 16, c
     assert len({u["rnti"] for u in c["per_ue"]}) == 8 and len({u["cell_id"] for u in c["per_ue"]}) == 8
