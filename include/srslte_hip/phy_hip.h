@@ -39,6 +39,13 @@ void* srslte_hip_event_create(void);                      /* HIP events on the c
 int   srslte_hip_event_record(void* event, void* stream);
 float srslte_hip_event_elapsed_ms(void* start, void* stop);
 void  srslte_hip_event_destroy(void* event);
+/* The single-call (compat) layer gives every host thread its own stream (SURVEY 8b "Threading": one object per worker thread, calls from
+ * several threads at once). Returns the CALLING thread's stream, created on first use, and its hipStreamGetFlags value in *flags. */
+void* srslte_hip_compat_thread_stream(unsigned* flags);
+/* Counters of the compat layer since process start: [0] stream waits (one per synchronous call), [1] srslte_dlsch_decode2 calls served by the
+ * device pipeline, [2] single-code-block decoder calls (srslte_tdec_run_all / _iteration), [3] reserved. With SRSLTE_HIP_STATS set in the
+ * environment the library prints them to stderr at exit ("[srslte_hip] stats: ..."): how a caller's processes used the boundary. */
+void  srslte_hip_compat_stats(unsigned long long out[4]);
 
 /* ------------------------------------------------------------------ OFDM (replaces srslte_ofdm_rx_sf / srslte_ofdm_tx_sf,
  * lib/include/srslte/phy/dft/ofdm.h:82-153, lib/src/phy/dft/ofdm.c:384-594, and FFTW behind dft_fftw.c) */

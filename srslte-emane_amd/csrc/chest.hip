@@ -28,6 +28,7 @@ struct ChestParams {
   int   nof_rx;         // receive antennas, tx ports: block v = (sf * nof_ports + port) * nof_rx + antenna reads grid [sf][antenna]
   int   nof_ports;      // and writes ce [sf][port][antenna]
   int   nsl;            // symbols per slot: 7, or 6 in an extended-CP cell (grids and estimates are then [12][12 nof_prb])
+  int   ce_compact;     // !interpolate_subframe only: ONE row of 12 nof_prb estimates per (subframe, port, antenna) instead of 2 nsl equal ones
 };
 struct ChestRaw { float noise, rsrp, rssi, cfo, sync, corr; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
 
@@ -258,7 +259,8 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
       pil = avg;
     }
 
-    cf32* o = ce + (size_t)sf * 2 * p.nsl * nre;
+    const int rows = p.ce_compact ? 1 : 2 * p.nsl;
+    cf32*     o    = ce + (size_t)sf * rows * nre;
     if (p.interpolate_subframe && port >= 2) {
       // ports 2/3 have two pilot symbols: upstream takes the copy branch (nsymbols < 3, chest_dl.c:467-471) and replicates symbol 0 of ce -
       // which this call does not write for them - over the subframe. ce is in / out here exactly as there.
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
         const cf32 v = interp_offset_at(pil, 4 * P, 3, off, k);
 #pragma unroll
         for (int l = 0; l < 14; l++) {
-          if (l < 2 * p.nsl) o[l * nre + k] = v;
+          if (l < rows) o[l * nre + k] = v;
         }
       }
     } else { // chest_dl.c:456-495
@@ -313,11 +315,12 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     }
     if (p.noise_alg != 0 && (sf_idx == 0 || sf_idx == 5)) {
       const int k_pss = (p.nsl - 1) * nre + nre / 2 - 31, k_sss = (p.nsl - 2) * nre + nre / 2 - 31;
+      const int h_pss = p.ce_compact ? nre / 2 - 31 : k_pss; // the estimate of the PSS symbol: every row holds the same values
       __syncthreads(); // the estimates of symbol 6 written above, read back by other lanes
       acc = 0;
       if (p.noise_alg == 1) { // estimate_noise_pss (chest_dl.c:381-398)
         if (tid < 62) {
-          const cf32 h = o[k_pss + tid], x = pss[tid], y = g[k_pss + tid];
+          const cf32 h = o[h_pss + tid], x = pss[tid], y = g[k_pss + tid];
           const cf32 d = make_float2(h.x * x.x - h.y * x.y - y.x, h.x * x.y + h.y * x.x - y.y);
           acc          = d.x * d.x + d.y * d.y;
         }
@@ -673,7 +676,16 @@ extern "C" const void* srslte_hip_chest_dl_pilots(const srslte_hip_chest_dl_t* q
 extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
                                                         const void* d_grid, void* d_ce, void* d_res, int nof_sf, int nof_rx, void* stream)
 {
+  return chest_dl_estimate_batch_rows(q, cfg, tti0, d_grid, d_ce, d_res, nof_sf, nof_rx, 0, stream);
+}
+
+// ce_compact: d_ce is [nof_sf][nof_ports][nof_rx][12*prb] - without interpolate_subframe the reference copies ONE row of estimates to
+// every symbol of the subframe (chest_dl.c:467-471); the fused receive pipeline keeps that row only (its demapper reads it for every symbol)
+int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                                 void* d_res, int nof_sf, int nof_rx, int ce_compact, void* stream)
+{
   if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (ce_compact && cfg->interpolate_subframe) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->noise_alg < 0 || cfg->noise_alg > 2) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->noise_alg != 0 && cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && nof_sf > 1 && d_ce) {
     // the automatic Gauss filter of a subframe then depends on the estimates of the subframes before it: a sequential chain
@@ -694,6 +706,7 @@ extern "C" int srslte_hip_chest_dl_estimate_batch_multi(srslte_hip_chest_dl_t* q
   p.nof_rx = nof_rx;
   p.nof_ports = q->nof_ports;
   p.nsl = q->nsl;
+  p.ce_compact = ce_compact ? 1 : 0;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
   if (d_res || cfg->noise_alg) {

@@ -3,7 +3,9 @@
 // (SURVEY §8b "Threading"); staging buffers are per object, so distinct objects may be used from distinct threads.
 #include "phy_hip_internal.hpp"
 #include "srslte_hip/srslte_compat.h"
+#include <atomic>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
@@ -42,6 +44,19 @@ struct DevStage { // grow-only device staging buffer
 // operands into the arena, queues the copies, the kernels and the copies back on that stream and waits once at the end. (hipMemcpy on the
 // callers' pageable buffers costs ~50 us per call and serialises every host thread on the null stream; the reference's worker threads -
 // three sf_workers in srsue - call these functions concurrently on distinct objects, SURVEY 8b "Threading".)
+std::atomic<unsigned long long> g_stats[4];
+void stats_at_exit()
+{
+  fprintf(stderr, "[srslte_hip] stats: stream_waits=%llu dlsch_decode2=%llu tdec_single_block_calls=%llu\n", g_stats[0].load(), g_stats[1].load(),
+          g_stats[2].load());
+}
+struct StatsInit {
+  StatsInit()
+  {
+    if (getenv("SRSLTE_HIP_STATS")) atexit(stats_at_exit);
+  }
+} g_stats_init;
+
 struct HostLink {
   hipStream_t st  = nullptr;
   uint8_t*    pin = nullptr;
@@ -76,6 +91,7 @@ struct HostLink {
   bool flush()
   { // wait for the stream, hand the results to the caller's buffers, empty the arena
     bool r = ok && (!st || hipStreamSynchronize(st) == hipSuccess);
+    g_stats[0]++;
     for (const Back& b : back) {
       if (r) memcpy(b.host, b.pinned, b.n);
     }
@@ -162,6 +178,20 @@ thread_local DevStage g_demod_in, g_demod_out, g_tcod_in, g_tcod_out;
 int cp_nsymb(srslte_cp_t cp) { return cp == SRSLTE_CP_NORM ? 7 : 6; }
 
 } // namespace
+
+extern "C" void* srslte_hip_compat_thread_stream(unsigned* flags)
+{
+  hipStream_t st = g_link.stream();
+  if (flags) {
+    *flags = 0;
+    if (st) (void)hipStreamGetFlags(st, flags);
+  }
+  return st;
+}
+extern "C" void srslte_hip_compat_stats(unsigned long long out[4])
+{
+  for (int i = 0; i < 4; i++) out[i] = g_stats[i].load();
+}
 
 extern "C" {
 
@@ -832,7 +862,8 @@ int srslte_tdec_new_cb(srslte_tdec_t* h, uint32_t long_cb)
 // and per LLR width; a manual type fixes width and window count, and the other API width is converted with a C cast
 // (convert_8_to_16 / convert_16_to_8, :451-463).
 static int tdec_passes(srslte_tdec_t* h, const void* input, bool api8, uint8_t* output, uint32_t passes, uint32_t start = 0)
-{ // start > 0: passes 0..start-1 were run by the previous call on this object for this code block; only the rest is run
+{
+  g_stats[2]++; // start > 0: passes 0..start-1 were run by the previous call on this object for this code block; only the rest is run
   auto*          st = (TdecState*)h->dec16_hdlr[0];
   const uint32_t K  = h->current_long_cb;
   int            W  = -1;   // AUTO
@@ -902,6 +933,7 @@ int srslte_dlsch_decode2(srslte_sch_t* q, srslte_pdsch_cfg_t* cfg, int16_t* e_bi
     return SRSLTE_ERROR_INVALID_INPUTS;
   }
   if (seg.tbs == 0 || seg.C == 0) return SRSLTE_SUCCESS; // :444-446
+  g_stats[1]++;
   if (seg.F) {
     fprintf(stderr, "Error filler bits are not supported. Use standard TBS\n"); // :448-451
     return SRSLTE_ERROR_INVALID_INPUTS;

@@ -41,6 +41,10 @@ int chest_average_pilots_launch(const void* d_in, void* d_out, const float* d_fi
 int chest_noise_pilots_launch(const void* d_noisy, const void* d_noiseless, void* d_noise_vec, int n, float* d_power, hipStream_t st);
 // chest.hip: the noise estimates [port][antenna] the PSS / EMPTY algorithms keep between calls (q->noise_estimate of the reference)
 int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise);
+// chest.hip: srslte_hip_chest_dl_estimate_batch_multi with the estimates kept as ONE row per (subframe, port, antenna) (ce_compact; only
+// without interpolate_subframe, where every symbol of the subframe gets the same row)
+int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                                 void* d_res, int nof_sf, int nof_rx, int ce_compact, void* stream);
 // tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).
 // d_rem: [C][K] words, x^(tbs+24-1-position in the TB) mod g for the block's payload bits in the decoder's array order, 0 elsewhere
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);
