@@ -468,6 +468,9 @@ def main():
             rx.stage(s, d_iq.data_ptr(), 0, B, stream)
         L.srslte_hip_event_record(b, stream)
         ms = L.srslte_hip_event_elapsed_ms(a, b) / reps
+        if name == "tb_crc" and ms < 0.002:  # no launch behind this stage: the 16-bit decoder assembles the transport blocks and gives the verdicts itself
+            kernels[name] = {"ms": round(ms, 4), "algorithmic_MB": round(alg[name] / 1e6, 3), "GBps": None, "frac_hbm": None, "note": "folded into the decoder's last phase"}
+            continue
         gbs = alg[name] / (ms * 1e-3) / 1e9
         kernels[name] = {"ms": round(ms, 4), "algorithmic_MB": round(alg[name] / 1e6, 3), "GBps": round(gbs, 1), "frac_hbm": round(gbs / HBM_PEAK_GBS, 4)}
     torch.cuda.synchronize()

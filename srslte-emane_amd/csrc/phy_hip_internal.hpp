@@ -48,6 +48,10 @@ int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_ches
 // tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).
 // d_rem: [C][K] words, x^(tbs+24-1-position in the TB) mod g for the block's payload bits in the decoder's array order, 0 elsewhere
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);
+// tdec.hip: the NEXT run (16-window 16-bit decoder with tdec_set_tb_syndrome, no skip flags, no block map) writes every block's payload bytes
+// straight into its transport block d_tb[cb / C][...] and the last block of a transport block to finish writes d_tb_ok[cb / C] (all block CRCs,
+// the XOR of the TB-CRC shares, a non-zero parity: sch.c:470-488): no assembly kernel behind the decoder. d_tb = nullptr: off
+int tdec_set_tb_direct(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint32_t payload_bytes_per_block, uint8_t* d_tb_ok);
 // tdec.hip: blocks with d_skip[cb] != 0 are left alone by the following runs: bytes, CRC flag, TB-CRC share stay (nullptr: off)
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip);
 // tdec.hip: the following runs work on the block slots d_map[0 .. nof_cb) instead of 0 .. nof_cb-1 (input, output, iteration count, CRC flag,

@@ -229,6 +229,12 @@ struct TdecArgs {
   const uint8_t*  skip;        // optional [nof_cb]: blocks whose CRC passed in an earlier transmission keep their bytes and flags (sch.c:317-318)
   const uint32_t* cb_map;      // optional [nof_cb]: launched block i works on block slot cb_map[i] of in / out / iters / crc_ok / skip (ragged
                                // batches: the blocks of one length are scattered over the batch); the work arrays stay per launched block
+  // tdec_pair_kernel, optional: the blocks of transport block cb / tb_C write their payload bytes straight into it (sch.c:360,:401-410) and
+  // the last one to finish gives the verdict of sch.c:470-488 - no assembly kernel behind the decoder (tdec_set_tb_direct)
+  uint8_t*        tb_out;      // [nof_cb / tb_C][tb_out_stride] or nullptr
+  uint32_t        tb_out_stride, tb_rb; // tb_rb: payload bytes per block (K / 8 - 3 with several blocks, K / 8 with one)
+  uint8_t*        tb_ok_out;   // [nof_cb / tb_C]
+  uint32_t*       tb_acc;      // [nof_cb / tb_C][4]: syndrome xor, flags, finished blocks, -; zero between launches (the last block clears them)
   unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
@@ -1154,6 +1160,10 @@ struct srslte_hip_tdec {
   const uint8_t*           skip   = nullptr; // see tdec_set_skip
   const uint32_t*          cb_map = nullptr; // see tdec_set_cb_map
   uint32_t                 start_iter = 0;   // see tdec_set_resume; consumed by the next run
+  uint8_t*                 tb_out = nullptr; // see tdec_set_tb_direct; consumed by the next run
+  uint32_t                 tb_out_stride = 0, tb_rb = 0;
+  uint8_t*                 tb_ok_out = nullptr;
+  uint32_t*                d_tb_acc = nullptr;
   std::mutex               mtx;
 };
 
@@ -1220,6 +1230,7 @@ extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
   (void)hipFree(q->d_beta);
   (void)hipFree(q->d_xy);
   (void)hipFree(q->d_zeros);
+  if (q->d_tb_acc) (void)hipFree(q->d_tb_acc);
   if (q->d_conv) (void)hipFree(q->d_conv);
   delete q;
 }
@@ -1270,6 +1281,17 @@ static int tdec_get_tables(srslte_hip_tdec_t* q, uint32_t K, uint32_t W, uint32_
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip) { q->skip = d_skip; }
 void tdec_set_cb_map(srslte_hip_tdec_t* q, const uint32_t* d_map) { q->cb_map = d_map; }
 void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter) { q->start_iter = start_iter; }
+
+int tdec_set_tb_direct(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint32_t payload_bytes_per_block, uint8_t* d_tb_ok)
+{ // the NEXT run (16 windows, 16 bit, with tdec_set_tb_syndrome, without skip flags or a block map) assembles the transport blocks itself
+  if (d_tb && !q->d_tb_acc) {
+    HIP_TRY(hipMalloc((void**)&q->d_tb_acc, sizeof(uint32_t) * 4 * q->max_nof_cb));
+    HIP_TRY(hipMemset(q->d_tb_acc, 0, sizeof(uint32_t) * 4 * q->max_nof_cb));
+    HIP_TRY(hipDeviceSynchronize());
+  }
+  q->tb_out = d_tb; q->tb_out_stride = tb_stride; q->tb_rb = payload_bytes_per_block; q->tb_ok_out = d_tb_ok;
+  return SRSLTE_SUCCESS;
+}
 
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn)
 { // windowed decoders only; the caller (pdsch.hip) builds d_rem in the decoder's array order
@@ -1331,6 +1353,13 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   a.cb_map = q->cb_map;
   a.start_iter = q->start_iter < nof_iterations ? q->start_iter : 0;
   q->start_iter = 0;
+  a.tb_out = nullptr; a.tb_out_stride = 0; a.tb_rb = 0; a.tb_ok_out = nullptr; a.tb_acc = q->d_tb_acc;
+  if (q->tb_out) { // consumed by this run, whichever kernel it takes
+    const bool pair = !llr8 && W == 16 && !old_map;
+    if (!pair || !a.tb_rem || a.skip || a.cb_map || nof_cb % a.tb_C || a.start_iter) return SRSLTE_ERROR_INVALID_INPUTS;
+    a.tb_out = q->tb_out; a.tb_out_stride = q->tb_out_stride; a.tb_rb = q->tb_rb; a.tb_ok_out = q->tb_ok_out;
+    q->tb_out = nullptr;
+  }
   a.prof = nullptr;
 #ifdef TDEC_PROF
   static unsigned long long* d_prof = nullptr;

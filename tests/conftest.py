@@ -13,6 +13,15 @@ for d in (HERE, ROOT):
 # for the library's internal allocations (LD_PRELOAD).
 os.environ.setdefault("SRSLTE_HIP_TEST_POISON", "1")
 
+# torch brings its own HIP runtime (libamdhip64.so of its ROCm build); the product library links the system's. Whichever is loaded first serves
+# both, and torch only finds the GPU through its own: a selection of tests that loads the library before anything imports torch then fails in
+# the one test that uses torch.cuda ("No HIP GPUs are available", tests/test_gpu_fullsize.py::test_cfg4_eight_ues_on_one_device run on its own).
+# The whole suite never saw it because test_dist_gloo.py imports torch at collection time. Make that order a property of every selection.
+try:
+    import torch  # noqa: F401,E402
+except ImportError:  # the CPU-side tests that need no torch still run
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
