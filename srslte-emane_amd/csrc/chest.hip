@@ -58,6 +58,29 @@ __device__ float block_sum(float v, float* red)
   return r;
 }
 
+// two sums with one pair of barriers (red: 2 x CH_THREADS / 64 floats)
+__device__ void block_sum2(float v, float w, float* red, float* rv, float* rw)
+{
+  for (int o = 32; o > 0; o >>= 1) {
+    v += __shfl_down(v, o, 64);
+    w += __shfl_down(w, o, 64);
+  }
+  const int wv = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[wv]                   = v;
+    red[CH_THREADS / 64 + wv] = w;
+  }
+  __syncthreads();
+  float r = 0, q = 0;
+  for (int i = 0; i < CH_THREADS / 64; i++) {
+    r += red[i];
+    q += red[CH_THREADS / 64 + i];
+  }
+  *rv = r;
+  *rw = q;
+}
+
 // "same" convolution with upstream's edge extrapolation (convolution.c:180-218)
 __device__ __forceinline__ cf32 conv_at(const cf32* in, const float* h, int N, int M, int i)
 {
@@ -101,7 +124,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   cf32*  est = reinterpret_cast<cf32*>(lds_raw); // [4][nref]
   cf32*  avg = est + 4 * nref;                   // [4][nref]
   cf32*  fr  = avg + 4 * nref;                   // [4][nre], only when interpolate_subframe
-  __shared__ float red[CH_THREADS / 64];
+  __shared__ float red[2 * CH_THREADS / 64];
   __shared__ float filt[64];
 
   const int   sf = blockIdx.x, tid = threadIdx.x; // sf: (subframe, port, antenna) index
@@ -111,23 +134,65 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   // ports 0 and 1 share their values (refsignal_dl.c pilots[port / 2]), [10][4][nref]; ports 2 and 3 theirs, [10][2][nref] behind
   const cf32* known = port < 2 ? pilots + (size_t)sf_idx * 4 * nref : pilots + (size_t)10 * 4 * nref + (size_t)sf_idx * 2 * nref;
 
-  // ---- pilots, LS, RSRP
-  float acc = 0;
-  for (int i = tid; i < npil; i += CH_THREADS) {
-    const int l = i / nref, k = i - l * nref;
-    cf32      r = g[crs_nsymbol(l, port, p.nsl) * nre + crs_fidx(p.cell_id, l, port) + 6 * k];
-    est[i]      = c_mulconj(r, known[i]);
-    acc += r.x * r.x + r.y * r.y;
+  // ---- smoothing filter taps (chest_dl.c:626-646): every tap by its own lane, then the normalisation in upstream's order (the taps' sum,
+  //      i ascending). With a given order and width (or the triangular filter) they do not depend on anything measured here: made first,
+  //      under the latency of the loads below; the barriers of the reductions order them before their use
+  auto make_taps = [&](float noise_) {
+    if (p.filter_type == 0) {
+      const int   order = p.coef0 <= 0 ? 4 : (int)p.coef0;
+      const float sd    = p.coef0 <= 0 ? noise_ * 200.0f : p.coef1;
+      const int   len = order + 1, center = (len - 1) / 2;
+      if (tid < 64) {
+        const float raw = tid < len ? expf(-powf((float)(tid - center), 2) / (2.0f * powf(sd, 2))) : 0.f;
+        float       norm = 0;
+        for (int i = 0; i < len; i++) norm += __shfl(raw, i, 64);
+        if (tid < len) filt[tid] = raw * (1.0f / norm);
+      }
+    } else if (p.filter_type == 1 && tid == 0) {
+      filt[0] = p.coef0;
+      filt[2] = p.coef0;
+      filt[1] = 1 - 2 * p.coef0;
+    }
+  };
+  const bool taps_early = ce && (p.filter_type == 1 || (p.filter_type == 0 && p.coef0 > 0));
+  if (taps_early) make_taps(0.f);
+
+  // ---- pilots, LS, RSRP and RSSI in ONE coalesced pass over the pilot-bearing symbols (the pilots sit on every sixth sub-carrier of exactly
+  //      the symbols the RSSI is taken over: a strided gather of its own was a second trip to memory behind a barrier)
+  float acc = 0, acc2 = 0;
+  {
+    int l = 0, k = tid;
+    while (k >= nre) { k -= nre; l++; }
+    constexpr int U = 5; // loads in flight per thread
+    for (int base = 0; base < nsym * nre; base += U * CH_THREADS) {
+      cf32 v[U];
+      int  ll[U], kk[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        ll[u] = l; kk[u] = k;
+        const bool in = l < nsym;
+        v[u] = in ? g[crs_nsymbol(l, port, p.nsl) * nre + k] : make_float2(0.f, 0.f);
+        k += CH_THREADS;
+        while (k >= nre) { k -= nre; l++; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        if (ll[u] >= nsym) continue;
+        const float pw = v[u].x * v[u].x + v[u].y * v[u].y;
+        acc2 += pw;
+        const int d = kk[u] - crs_fidx(p.cell_id, ll[u], port);
+        if (d >= 0 && d % 6 == 0) {
+          const int i = ll[u] * nref + d / 6;
+          est[i]      = c_mulconj(v[u], known[i]);
+          acc += pw;
+        }
+      }
+    }
   }
-  const float rsrp = block_sum(acc, red) / npil;
-  // ---- RSSI
-  acc = 0;
-  for (int i = tid; i < nsym * nre; i += CH_THREADS) {
-    const int l = i / nre;
-    cf32      v = g[crs_nsymbol(l, port, p.nsl) * nre + (i - l * nre)];
-    acc += v.x * v.x + v.y * v.y;
-  }
-  const float rssi = block_sum(acc, red) / (float)nsym;
+  float rsrp, rssi;
+  block_sum2(acc, acc2, red, &rsrp, &rssi);
+  rsrp /= npil;
+  rssi /= (float)nsym;
 
   // ---- synchronisation error (chest_dl.c:692-703; srslte_vec_estimate_frequency, vector_simd.c:1606-1656, with exact divisions)
   float sync = NAN;
@@ -208,28 +273,36 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     noise = block_sum(acc, red) / nref / (float)nsym * sqrtf(5.0f);
   }
 
+  // ---- fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna, as soon as its inputs are there (res is only given with the REFS noise
+  //      algorithm, whose estimate is final here): the five double-precision logarithms by five lanes of the LAST wavefront, side by side,
+  //      while the first one goes on to the filter taps - one lane doing them at the kernel's end was 2 us of its 17
+  if (res && p.nof_rx * p.nof_ports == 1 && tid >= CH_THREADS - 64) {
+    const int   j    = tid - (CH_THREADS - 64);
+    const float rsrq = P * rsrp / rssi;
+    const float arg  = j == 0 ? noise : (j == 1 ? rsrp : (j == 2 ? rsrq : (j == 3 ? rsrp / noise : 4 * rssi / P / 12)));
+    const float lg   = (j == 0 || j == 1 || j == 4) ? (float)(10 * log10((double)arg) + 30) : (float)(10 * log10((double)arg));
+    ChestResDev r;
+    r.noise_estimate     = noise;
+    r.noise_estimate_dbm = __shfl(lg, 0, 64);
+    r.cfo                = cfo;
+    r.rsrp               = rsrp;
+    r.rsrp_dbm           = __shfl(lg, 1, 64);
+    r.rsrq               = rsrq;
+    r.rsrq_db            = __shfl(lg, 2, 64);
+    r.snr_db             = __shfl(lg, 3, 64);
+    r.rssi_dbm           = __shfl(lg, 4, 64);
+    r.sync_error         = sync;
+    if (j == 0) res[sf] = r;
+  }
+
   if (ce) {
     // ---- smoothing filter taps (chest_dl.c:626-646)
-    int flen = 0;
-    if (tid == 0) {
-      if (p.filter_type == 0) {
-        const int   order = p.coef0 <= 0 ? 4 : (int)p.coef0;
-        const float sd    = p.coef0 <= 0 ? noise * 200.0f : p.coef1;
-        const int   len = order + 1, center = (len - 1) / 2;
-        float       norm = 0;
-        for (int i = 0; i < len; i++) {
-          filt[i] = expf(-powf((float)(i - center), 2) / (2.0f * powf(sd, 2)));
-          norm += filt[i];
-        }
-        for (int i = 0; i < len; i++) filt[i] *= 1.0f / norm;
-      } else if (p.filter_type == 1) {
-        filt[0] = p.coef0;
-        filt[2] = p.coef0;
-        filt[1] = 1 - 2 * p.coef0;
-      }
+    // smoothing filter taps: made at the top of the kernel unless they depend on the noise estimate (automatic Gauss filter)
+    const int flen = p.filter_type == 0 ? (p.coef0 <= 0 ? 5 : (int)p.coef0 + 1) : (p.filter_type == 1 ? 3 : 0);
+    if (!taps_early) {
+      make_taps(noise);
+      __syncthreads();
     }
-    flen = p.filter_type == 0 ? (p.coef0 <= 0 ? 5 : (int)p.coef0 + 1) : (p.filter_type == 1 ? 3 : 0);
-    __syncthreads();
 
     const cf32* pil = est;
     if (p.filter_type != 2) { // average_pilots
@@ -246,17 +319,18 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
           avg[2 * k + 1] = c_scale(first_low ? b : a, 2.0f / (float)nsym);
         }
         __syncthreads();
-        for (int k = tid; k < 2 * nref; k += CH_THREADS) est[k] = avg[k];
-        n  = 2 * nref;
-        ns = 1;
+        // the one time-averaged row (2 nref values) sits in the lower half of avg, its smoothed version goes to the upper half
+        for (int i = tid; i < 2 * nref; i += CH_THREADS) avg[2 * nref + i] = conv_at(avg, filt, 2 * nref, flen, i);
         __syncthreads();
+        pil = avg + 2 * nref;
+      } else {
+        for (int i = tid; i < ns * n; i += CH_THREADS) {
+          const int l = i / n;
+          avg[i]      = conv_at(est + l * n, filt, n, flen, i - l * n);
+        }
+        __syncthreads();
+        pil = avg;
       }
-      for (int i = tid; i < ns * n; i += CH_THREADS) {
-        const int l = i / n;
-        avg[i]      = conv_at(est + l * n, filt, n, flen, i - l * n);
-      }
-      __syncthreads();
-      pil = avg;
     }
 
     const int rows = p.ce_compact ? 1 : 2 * p.nsl;
@@ -337,20 +411,6 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   }
 
   if (tid == 0 && raw) raw[sf] = ChestRaw{noise, rsrp, rssi, cfo, sync, corr};
-  if (tid == 0 && res && p.nof_rx * p.nof_ports == 1) { // fill_res (chest_dl.c:845-871), 1 port / 1 rx antenna
-    ChestResDev r;
-    r.noise_estimate     = noise;
-    r.noise_estimate_dbm = (float)(10 * log10((double)noise) + 30);
-    r.cfo                = cfo;
-    r.rsrp               = rsrp;
-    r.rsrp_dbm           = (float)(10 * log10((double)rsrp) + 30);
-    r.rsrq               = P * rsrp / rssi;
-    r.rsrq_db            = (float)(10 * log10((double)r.rsrq));
-    r.snr_db             = (float)(10 * log10((double)(rsrp / noise)));
-    r.rssi_dbm           = (float)(10 * log10((double)(4 * rssi / P / 12)) + 30);
-    r.sync_error         = sync;
-    res[sf]              = r;
-  }
 }
 
 // MBSFN subframes (chest_dl.c:718-745 with the MBSFN branches of :304-556): one workgroup per (subframe, port, antenna). The 12-symbol
