@@ -209,12 +209,19 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
     ap.add_argument("--grants", action="store_true", help="run the same workload through srslte_hip_dl_rx_batch_grants: one grant per subframe "
                     "(here 128 equal full-band MCS-28 grants), RE lists and scrambling sequences made on the device from the grants on every call")
+    ap.add_argument("--grants-mix", action="store_true", help="the mixed-grant workload (scripts/bench_grants_mix.py): 128 subframes of one cell, a different grant "
+                    "per subframe - 40 %% small allocations (2-25 PRB QPSK/16QAM), 30 %% medium, 30 %% large - through srslte_hip_dl_rx_batch_grants")
     ap.add_argument("--cpu-worker", nargs=6, metavar=("NPY", "LO", "HI", "SECONDS", "CELL", "RNTI"), help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_worker:
         w = args.cpu_worker
         return cpu_worker(w[0], int(w[1]), int(w[2]), float(w[3]), int(w[4]), int(w[5]), args.llr8)
 
+    if args.grants_mix:
+        if args.gpus != 1:
+            raise SystemExit("--grants-mix is a one-GPU side workload")
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        return importlib.import_module("bench_grants_mix").main(args)
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))

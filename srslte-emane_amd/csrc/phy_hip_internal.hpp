@@ -60,6 +60,13 @@ void tdec_set_cb_map(srslte_hip_tdec_t* q, const uint32_t* d_map);
 // tdec.hip: the NEXT run continues blocks whose passes 0..start_iter-1 the previous run on this object did (same inputs, same block
 // slots): srslte_tdec_iteration's one-more-pass without redoing the earlier ones (turbodecoder.c:539-545)
 void tdec_set_resume(srslte_hip_tdec_t* q, uint32_t start_iter);
+// tdec.hip: a ragged batch in one call - groups of equal block length, in the order of the block map set with tdec_set_cb_map - with ONE launch
+// per decoder kernel the lengths need instead of one per length (back-ends chosen per length as on an AVX2 host; CRC per group for the early stop)
+struct srslte_hip_tdec_group_t {
+  uint32_t K, nof_cb, crc_poly, crc_nbits;
+};
+int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input, int llr8, uint32_t in_stride, const srslte_hip_tdec_group_t* groups, uint32_t nof_groups,
+                    uint32_t nof_iterations, uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st);
 // tdec.hip: srslte_hip_tdec_run_batch with an optional forced back-end (force_w = -1 auto, 0 generic, 8, 16, 32 with llr8);
 // llr8: d_input is int8 and the 8-bit numerics / fall-backs of turbodecoder.c:438-487 apply
 int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input, int llr8, uint32_t in_stride, int sb_layout, uint32_t K, int force_w,

@@ -240,6 +240,40 @@ struct TdecArgs {
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
 };
 
+// Several block lengths in ONE launch (ragged batches: tdec_run_groups). A launch per length is a serial chain of latency-bound kernels - a few
+// blocks each, up to six passes - and that chain, not the work, is what a mixed batch then takes. The table travels by value as a kernel
+// argument of its own (read with scalar loads at a dynamic index; TdecArgs stays free of arrays, so its patched copy lives in registers).
+constexpr int TDEC_MAX_GROUPS = 24;
+struct TdecGroup {
+  uint32_t   K, nof_cb, first_lcb, first_wave; // block length; blocks; first launched block / first wavefront of the group within the launch
+  TdecTables t;
+};
+struct TdecGroups {
+  uint32_t  n; // 0: a launch of one length, described by TdecArgs alone
+  uint32_t  xy_stride;
+  TdecGroup g[TDEC_MAX_GROUPS];
+};
+// Returns this wavefront's index within its group and makes `a` describe that group alone: its length and tables, its share of the block map,
+// of the work arrays (7 Kp per launched block), of the combine rows and of the checkpoint / beta rows (beta_stride per wavefront).
+__device__ __forceinline__ uint32_t tdec_enter_group(TdecArgs& a, const TdecGroups& gs)
+{
+  uint32_t bx = blockIdx.x;
+  if (gs.n) {
+    uint32_t gi = 0;
+    for (uint32_t i = 1; i < gs.n; i++) gi = bx >= gs.g[i].first_wave ? i : gi; // ascending first_wave
+    const uint32_t first_lcb = gs.g[gi].first_lcb, first_wave = gs.g[gi].first_wave;
+    bx -= first_wave;
+    a.K      = gs.g[gi].K;
+    a.nof_cb = gs.g[gi].nof_cb;
+    a.t      = gs.g[gi].t;
+    if (a.cb_map) a.cb_map += first_lcb;
+    a.work += (size_t)first_lcb * 7 * a.Kp;
+    a.xy += (size_t)first_lcb * gs.xy_stride;
+    a.beta += (size_t)first_wave * a.beta_stride;
+  }
+  return bx;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // Windowed SISO (W = 16: packed pairs w = 2g+h; W = 8: w = g in the low half, high half idle)
 // ------------------------------------------------------------------------------------------------------------------
@@ -764,10 +798,12 @@ __device__ __forceinline__ int win_pos(int n, int K)
 #define TDEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TDEC_WAVES, TDEC_WAVES)))
 // AR = 1: int8 LLRs in (a.in is an int8 array), the work arrays hold int8 values in int16 containers
 template <int W, int AR>
-__global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a)
+__global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a0, TdecGroups gs)
 {
+  TdecArgs       a  = a0;
+  const uint32_t bx = tdec_enter_group(a, gs);
   using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
-  const int      lcb = blockIdx.x, cb = a.cb_map ? (int)a.cb_map[lcb] : lcb, K = (int)a.K;
+  const int      lcb = (int)bx, cb = a.cb_map ? (int)a.cb_map[lcb] : lcb, K = (int)a.K;
   if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
     if (threadIdx.x == 0 && a.iters) a.iters[cb] = 0;
     return;
@@ -1031,11 +1067,13 @@ __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
 #undef ACS
 }
 
-__global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
+__global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a0, TdecGroups gs)
 {
+  TdecArgs       a  = a0;
+  const uint32_t bx = tdec_enter_group(a, gs);
   const LaneGeom L      = lane_geom();
   const int      K      = (int)a.K;
-  const uint32_t cb_raw = blockIdx.x * 8 + L.g;
+  const uint32_t cb_raw = bx * 8 + L.g;
   const uint32_t lcb    = cb_raw < a.nof_cb ? cb_raw : a.nof_cb - 1; // idle groups shadow the last block, stores predicated
   const uint32_t cb     = a.cb_map ? a.cb_map[lcb] : lcb;
   const bool     skipped = cb_raw < a.nof_cb && a.skip && a.skip[cb]; // sch.c:317-318
@@ -1044,7 +1082,7 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a)
   int16_t*       wk     = a.work + (size_t)lcb * 7 * a.Kp;
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
-  pk_t* beta = a.beta + (size_t)blockIdx.x * a.beta_stride;
+  pk_t* beta = a.beta + (size_t)bx * a.beta_stride;
 
   // extraction (turbodecoder_gen.c:235-253): each group's 8 slots stride over their block
   if (active) {
@@ -1368,22 +1406,23 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
 #endif
   int r = tdec_get_tables(q, K, W, crc_poly, crc_nbits, &a.t);
   if (r) return r;
+  static const TdecGroups no_groups = {};
   if (ar8 && W == 32) {
-    hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (ar8) {
-    hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (W == 16 && !old_map) {
     a.beta_stride = (K / 16 / PB + 2) * 128; // checkpoint rows of a wavefront: 64 lanes x 2 dwords
-    hipLaunchKernelGGL(tdec_pair_kernel, dim3((nof_cb + 1) / 2), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(tdec_pair_kernel, dim3((nof_cb + 1) / 2), dim3(64), 0, st, a, no_groups);
   } else if (W == 16) {
     a.beta_stride = (K / 16 + 1) * 64;
-    hipLaunchKernelGGL((tdec_win_kernel<16, 0>), dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<16, 0>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (W == 8) {
     a.beta_stride = (K / 8 + 1) * 64;
-    hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(nof_cb), dim3(64), 0, st, a);
+    hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else {
     a.beta_stride = (K + 4) * 64;
-    hipLaunchKernelGGL(tdec_gen_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(tdec_gen_kernel, dim3((nof_cb + 7) / 8), dim3(64), 0, st, a, no_groups);
   }
   LAUNCH_CHECK();
 #ifdef TDEC_PROF
@@ -1406,6 +1445,81 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
     fprintf(stderr, "\n");
   }
 #endif
+  return SRSLTE_SUCCESS;
+}
+
+// One call for a ragged batch: groups[i] = nof_cb blocks of length K, in the order of the block map (tdec_set_cb_map: group i's slots behind those
+// of groups 0 .. i-1). ONE launch per decoder kernel the lengths need - the two-blocks-per-wavefront kernel for every K > 800, the 8-window one,
+// the unwindowed one (8-bit LLRs: the 32- and 16-window 8-bit kernels, the rest widened) - instead of one per length. Skip flags as set.
+int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uint32_t in_stride, const srslte_hip_tdec_group_t* groups, uint32_t nof_groups,
+                    uint32_t nof_iterations, uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st)
+{
+  if (!q || !d_input_any || !d_output || !groups || nof_groups > (uint32_t)TDEC_MAX_GROUPS || nof_iterations == 0) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->tb_out || q->start_iter || q->tb_rem) return SRSLTE_ERROR_INVALID_INPUTS; // modes of the one-length call
+  enum { T_PAIR, T_WIN8, T_GEN, T_AR32, T_AR16, T_N };
+  struct Plan { TdecGroups gs; uint32_t waves, stride, blocks; bool widened; };
+  static const TdecGroups none = {};
+  Plan     plan[T_N];
+  for (auto& p_ : plan) { p_.gs = none; p_.waves = p_.stride = p_.blocks = 0; p_.widened = false; }
+  uint32_t total = 0;
+  bool     any_widen = false;
+  for (uint32_t i = 0; i < nof_groups; i++) {
+    const srslte_hip_tdec_group_t& g = groups[i];
+    const int idx = lte_cb_index(g.K);
+    if (g.K > q->max_long_cb || idx < 0 || lte_qpp_table[idx].K != g.K) {
+      hip_log("[srslte_hip] Invalid CB length %u\n", g.K);
+      return SRSLTE_ERROR;
+    }
+    if (g.nof_cb == 0) continue;
+    const uint32_t W    = llr8 ? srslte_hip_tdec_autoimp_get_subblocks_8bit(g.K) : srslte_hip_tdec_autoimp_get_subblocks(g.K);
+    const bool     ar8  = llr8 && W >= 16;
+    const int      type = ar8 ? (W == 32 ? T_AR32 : T_AR16) : (W == 16 ? T_PAIR : (W == 8 ? T_WIN8 : T_GEN));
+    if (out_stride < g.K / 8 || in_stride < srslte_hip_tdec_input_len(g.K, W != 0) || (g.crc_poly && (g.crc_nbits > g.K || (g.crc_poly >> 24) != 1)) ||
+        (type == T_GEN && g.K + 4 > q->max_long_cb / 8 + 2))
+      return SRSLTE_ERROR_INVALID_INPUTS;
+    Plan&      p_ = plan[type];
+    TdecGroup& d  = p_.gs.g[p_.gs.n++];
+    d.K = g.K; d.nof_cb = g.nof_cb; d.first_lcb = total; d.first_wave = p_.waves;
+    if (int r = tdec_get_tables(q, g.K, W, g.crc_poly, g.crc_nbits, &d.t)) return r;
+    const uint32_t waves = type == T_PAIR ? (g.nof_cb + 1) / 2 : (type == T_GEN ? (g.nof_cb + 7) / 8 : g.nof_cb);
+    const uint32_t stride = type == T_PAIR ? (g.K / 16 / PB + 2) * 128 : (type == T_GEN ? (g.K + 4) * 64 : (g.K / (W == 32 ? 16 : W) + 1) * 64);
+    p_.waves += waves;
+    p_.stride = stride > p_.stride ? stride : p_.stride;
+    p_.blocks += g.nof_cb;
+    p_.widened = llr8 && !ar8;
+    any_widen = any_widen || p_.widened;
+    total += g.nof_cb;
+  }
+  if (total > q->max_nof_cb) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (total == 0) return SRSLTE_SUCCESS;
+  if (any_widen) { // the 8-bit API's 16-bit fall-backs (turbodecoder.c:465-469): every slot of the buffer, as tdec_run_batch_w does with a block map
+    const size_t per_max = ((size_t)3 * (q->max_long_cb + 32) + 12 + 31) & ~(size_t)31;
+    const size_t n = (size_t)q->max_nof_cb * in_stride;
+    if (in_stride > per_max) return SRSLTE_ERROR_INVALID_INPUTS;
+    if (!q->d_conv) HIP_TRY(hipMalloc((void**)&q->d_conv, (size_t)q->max_nof_cb * per_max * sizeof(int16_t)));
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, st, (const int8_t*)d_input_any, q->d_conv, n);
+    LAUNCH_CHECK();
+  }
+  for (int type = 0; type < T_N; type++) {
+    Plan& p_ = plan[type];
+    if (!p_.gs.n) continue;
+    p_.gs.xy_stride = q->max_long_cb;
+    TdecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = p_.widened ? q->d_conv : (const int16_t*)d_input_any; a.in_stride = in_stride; a.sb_layout = type != T_GEN; a.nof_iter = nof_iterations;
+    a.K = p_.gs.g[0].K; a.nof_cb = p_.gs.g[0].nof_cb; a.t = p_.gs.g[0].t; // replaced per wavefront (tdec_enter_group)
+    a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy; a.zeros = q->d_zeros; a.beta_stride = p_.stride;
+    a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok; a.tb_C = 1;
+    a.skip = q->skip; a.cb_map = q->cb_map;
+    switch (type) {
+      case T_PAIR: hipLaunchKernelGGL(tdec_pair_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      case T_WIN8: hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      case T_GEN: hipLaunchKernelGGL(tdec_gen_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      case T_AR32: hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      default: hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+    }
+    LAUNCH_CHECK();
+  }
   return SRSLTE_SUCCESS;
 }
 
