@@ -792,6 +792,35 @@ __device__ __forceinline__ int win_pos(int n, int K)
   return (n % Lw) * W + n / Lw;
 }
 
+#include "tdec_pair.inc"
+
+// avx8 (32 windows, 8 bit) on the pair mapping: the combine pass of win_siso<32, 1> (x = sat(a-priori + systematic) in the high bytes, to the
+// xy scratch; the parity array is read in place), then the sweeps of tdec_pair.inc with the wavefront's 16 window pairs = the block's 32 windows.
+// Every beta checkpoint of a window of at most 192 steps fits the LDS rows (P_CK_LDS); `ckg` only backs the clamped prefetch.
+#ifndef TDEC_AR32_PAIR
+#define TDEC_AR32_PAIR 1
+#endif
+__device__ __forceinline__ void pair_siso_ar32(const PLane& PL, int lane, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
+                                               const int16_t* __restrict__ par, const int16_t* tail_in, const int16_t* tail_par, int16_t* __restrict__ out,
+                                               pk_t* __restrict__ pool, int2* __restrict__ ckg, pk_t* __restrict__ scratch, int K PROF_ARGS)
+{
+  const int NE = 16 * (K / 32);
+  pk_t*     Xb = scratch + NE;
+  struct Q2 { int4 a, b; };
+  auto hi8 = [](int4 v) { return make_int4((v.x & 0x00FF00FF) << 8, (v.y & 0x00FF00FF) << 8, (v.z & 0x00FF00FF) << 8, (v.w & 0x00FF00FF) << 8); };
+  const int4 *in4 = reinterpret_cast<const int4*>(in), *app4 = reinterpret_cast<const int4*>(app);
+  int4*       X4  = reinterpret_cast<int4*>(Xb);
+  batched<TDEC_EWU>(
+      lane, NE / 4, [&](int i) { return Q2{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0)}; },
+      [&](int i, Q2 t) { X4[i] = app ? make_int4(s_add<1>(t.b.x, t.a.x), s_add<1>(t.b.y, t.a.y), s_add<1>(t.b.z, t.a.z), s_add<1>(t.b.w, t.a.w)) : t.a; });
+  __syncthreads();
+  PROF(2)
+  PSrc S;
+  S.x0 = Xb; S.x1 = Xb + 8; S.y0 = reinterpret_cast<const pk_t*>(par); S.y1 = S.y0 + 8;
+  S.dbg = 0; S.dead0 = S.dead1 = false; S.rs = 16;
+  p_siso<1, true>(PL, S, tail_in, tail_par, reinterpret_cast<pk_t*>(out), pool, ckg, K PROF_PASS);
+}
+
 #ifndef TDEC_WAVES
 #define TDEC_WAVES 2
 #endif
@@ -824,10 +853,17 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   pk_t *                                       beta = pool, *seg = pool + POOL_BETA, *mt = pool + POOL_BETA + POOL_SEG;
   int16_t*                                     perm = reinterpret_cast<int16_t*>(pool);
   static_assert(2 * (POOL_BETA + POOL_SEG + 2 * ST_BUF) >= SRSLTE_HIP_MAX_K, "permutation buffer must hold one code block");
+  constexpr bool  PAIR32 = W == 32 && AR && TDEC_AR32_PAIR; // the sweeps of tdec_pair.inc; this kernel keeps extraction, exchange, CRC and decisions
   Stage st;
-  stage_init(st, mt, L);
+  if constexpr (!PAIR32) stage_init(st, mt, L);
   PROF_DECL;
   pk_t*           xy = reinterpret_cast<pk_t*>(a.xy + (size_t)lcb * a.K); // 16 B per trellis step: room for the x, y and x + y arrays
+  static_assert(!PAIR32 || POOL_BETA + POOL_SEG + ST_TOTAL >= P_POOL, "the pair sweeps' LDS pool");
+  const PLane     PL = p_lane<true>();
+  int2*           ckg = reinterpret_cast<int2*>(a.beta) + (size_t)bx * ((K / 32 / PB + 3) * 64);
+  if constexpr (PAIR32) {
+    for (int i = L.lane; i < P_ARR; i += 64) pool[P_ZERO + i] = 0; // the constant zero metric, outside the permutation overlay
+  }
 
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91). The 12 tail LLRs go to LDS. A 16-bit
   //      SB-layout buffer already is three window-ordered arrays: like upstream (turbodecoder_iter.h:84-91) the decoder then
@@ -899,7 +935,11 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
         __syncthreads();
       }
       PROF(1)
-      if (!(a.dbg & 1)) win_siso<W, AR>(L, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, beta, seg, xy, st, K PROF_PASS);
+      if constexpr (PAIR32) {
+        if (!(a.dbg & 1)) pair_siso_ar32(PL, L.lane, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, pool, ckg, xy, K PROF_PASS);
+      } else {
+        if (!(a.dbg & 1)) win_siso<W, AR>(L, syst_r, n_iter ? app1 : nullptr, par0_r, tl, tl + 3, ext1, beta, seg, xy, st, K PROF_PASS);
+      }
       dec = ext1;
     } else {
       const bool sub = n_iter > 1 && !(a.dbg & 2); // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
@@ -915,7 +955,11 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
       for (int i8 = L.lane; i8 < K8; i8 += 64) st8(app2, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
       __syncthreads();
       PROF(1)
-      if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K PROF_PASS);
+      if constexpr (PAIR32) {
+        if (!(a.dbg & 1)) pair_siso_ar32(PL, L.lane, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, pool, ckg, xy, K PROF_PASS);
+      } else {
+        if (!(a.dbg & 1)) win_siso<W, AR>(L, app2, nullptr, par1_r, tl + 6, tl + 9, ext2, beta, seg, xy, st, K PROF_PASS);
+      }
       __syncthreads();
       batched<EWU>(
           L.lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
@@ -1021,7 +1065,6 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
   }
 }
 
-#include "tdec_pair.inc"
 
 // ------------------------------------------------------------------------------------------------------------------
 // Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
