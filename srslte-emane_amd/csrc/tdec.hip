@@ -827,7 +827,24 @@ __device__ __forceinline__ void pair_siso_ar32(const PLane& PL, int lane, const 
 #define TDEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TDEC_WAVES, TDEC_WAVES)))
 // AR = 1: int8 LLRs in (a.in is an int8 array), the work arrays hold int8 values in int16 containers
 template <int W, int AR>
+__device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGroups& gs);
+template <int W, int AR>
 __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a0, TdecGroups gs)
+{
+  tdec_win_body<W, AR>(a0, gs);
+}
+// the avx8 back-end with the pair-mapped sweeps has its own register budget (see tdec_pair.inc on the 216-register rule)
+#ifndef TDEC_AR32_NVGPR
+#define TDEC_AR32_NVGPR 108
+#endif
+#if TDEC_AR32_NVGPR > 0
+#define AR32_NVGPR_ATTR __attribute__((amdgpu_num_vgpr(TDEC_AR32_NVGPR)))
+#else
+#define AR32_NVGPR_ATTR
+#endif
+__global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR32_NVGPR_ATTR void tdec_ar32_kernel(TdecArgs a0, TdecGroups gs) { tdec_win_body<32, 1>(a0, gs); }
+template <int W, int AR>
+__device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGroups& gs)
 {
   TdecArgs       a  = a0;
   const uint32_t bx = tdec_enter_group(a, gs);
@@ -1451,7 +1468,7 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   if (r) return r;
   static const TdecGroups no_groups = {};
   if (ar8 && W == 32) {
-    hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
+    hipLaunchKernelGGL(tdec_ar32_kernel, dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (ar8) {
     hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (W == 16 && !old_map) {
@@ -1558,7 +1575,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
       case T_PAIR: hipLaunchKernelGGL(tdec_pair_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_WIN8: hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_GEN: hipLaunchKernelGGL(tdec_gen_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
-      case T_AR32: hipLaunchKernelGGL((tdec_win_kernel<32, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      case T_AR32: hipLaunchKernelGGL(tdec_ar32_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       default: hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
     }
     LAUNCH_CHECK();
