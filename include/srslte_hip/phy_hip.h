@@ -241,6 +241,9 @@ typedef struct {
   int      mod2;            /* grant.tb[1].mod */
   uint32_t tbs2;            /* grant.tb[1].tbs; 0: one transport block. With two, d_tb / d_tb_ok of the batch calls have 2 * nof_sf rows:
                                row b = transport block 0 of subframe b, row nof_sf + b = transport block 1; tb_stride covers the larger */
+  int      cp_ext;          /* 1: extended-CP cell (srslte_cell_t.cp = SRSLTE_CP_EXT): 12 symbols per subframe - grids, estimates and RE lists
+                               are [12][12 * nof_prb] -, CRS on symbols 0 and 3 of each slot, PSS / SSS on symbols 5 and 4 of slot 0
+                               (ofdm.c:424-437, chest_dl.c:497-502, pdsch.c:81-206 with nof_symb_slot = 6) */
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -446,7 +449,7 @@ const void* srslte_hip_ul_tx_debug_buffer(const srslte_hip_ul_tx_t* q, int which
 /* ------------------------------------------------------------------ PDSCH transmit pipeline (eNB side): srslte_pdsch_encode
  * (pdsch.c:1059-1185: DL-SCH coding, scrambling, modulation, layer mapping + SFBC precoding, RE mapping) + CRS
  * (srslte_refsignal_cs_put_sf refsignal_dl.c:253-272) + srslte_ofdm_tx_sf with 1/sqrt(N) (enb_dl.c:56-62). One codeword, TM1 or 2-port
- * TM2, full-band grant, normal CP; no control region, PSS/SSS or PBCH content (their REs stay zero). */
+ * TM2, full-band grant; no control region, PSS/SSS or PBCH content (their REs stay zero). */
 typedef struct srslte_hip_dl_tx srslte_hip_dl_tx_t;
 typedef struct {
   uint32_t cell_id, nof_prb, cfi;
@@ -457,6 +460,8 @@ typedef struct {
   uint32_t nof_ports;      /* 0 or 1: TM1; 2 or 4: transmit diversity */
   float    p_a;            /* dB; rho_a = 10^(p_a/20) (x sqrt(2) for 2 ports), pdsch.c:518-554 with p_b giving rho_b = 1 */
   uint32_t max_grants;     /* srslte_hip_dl_tx_batch_grants: PDSCHs per call; 0 = max_batch */
+  int      cp_ext;         /* 1: extended-CP cell (as srslte_hip_dl_rx_cfg_t.cp_ext): grids [12][12 * nof_prb], CRS on symbols 0 and 3 of each slot
+                              with the extended-CP sequences (N_CP = 0 in c_init, refsignal_dl.c:79-99), srslte_ofdm_tx_sf with the long prefix */
 } srslte_hip_dl_tx_cfg_t;
 srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);
 void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);

@@ -19,8 +19,10 @@ class DlConfig:
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None,
-                 prb_mask=None, tx_scheme=None, pmi=0, mod2=None, tbs2=0):
+                 prb_mask=None, tx_scheme=None, pmi=0, mod2=None, tbs2=0, cp_ext=False):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
+        # extended-CP cell: 6 symbols per slot, CRS on symbols 0 and 3, PSS / SSS on symbols 5 and 4 of slot 0 (phy_common.h:101-141, pdsch.c:81-206)
+        self.cp_ext, self.cp_norm, self.nsym = bool(cp_ext), not cp_ext, 12 if cp_ext else 14
         # two-layer modes of a 2-port cell with 2 receive antennas (SURVEY §8f N4): tx_scheme "cdd" (TM3, two transport blocks) or "mux"
         # (TM4: two transport blocks with pmi 0/1, or one - tbs2 = 0 - with pmi 0..3); srslte_pdsch_grant_t.tx_scheme / pmi / tb[1]
         self.tx_scheme, self.pmi = tx_scheme, pmi
@@ -43,9 +45,9 @@ class DlConfig:
         self.p_a = p_a
         self.scaling = 1.0 if p_a is None else float(np.float32(10.0) ** np.float32(p_a / 20.0) * (np.float32(np.sqrt(np.float32(2.0))) if nof_ports > 1 else np.float32(1.0)))
         self.csi = csi  # srslte_pdsch_cfg_t.csi_enable: LLRs weighted by the channel gain (pdsch.c:574-690), the srsUE default
-        self.cell = OrcCell(cell_id, nof_prb, nof_ports, True)
+        self.cell = OrcCell(cell_id, nof_prb, nof_ports, self.cp_norm)
         self.nre = 12 * nof_prb
-        self.grid_len = 14 * self.nre
+        self.grid_len = self.nsym * self.nre
         self.lstart = cfi + (1 if nof_prb < 10 else 0)
         self.N = oracle().orc_symbol_sz(nof_prb)
         self.sf_len = 15 * self.N
@@ -94,7 +96,7 @@ def make_subframe(cfg, tti, rng, snr_db=None, amp=1.0, rv=0, data=None, keep=Non
     syms = np.zeros(len(idx), np.complex64)
     orc.orc_modulate(cfg.mod, p(e), p(syms), nbits)
     q = OrcOfdm()
-    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, cfg.cp_norm)
     q.normalize = True
     if cfg.nof_ports > 1:
         return _make_subframe_2ports(cfg, sf_idx, idx, syms, q, rng, snr_db, amp, keep), data
@@ -198,7 +200,7 @@ def make_subframe_mimo(cfg, tti, rng, snr_db=None, amp=1.0, rv=(0, 0), data=None
     if keep is not None:
         keep.update(x=x, y=[v.copy() for v in y], idx=idx)
     q = OrcOfdm()
-    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+    orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, cfg.cp_norm)
     q.normalize = True
     return _ports_to_iq(cfg, sf_idx, idx, y, q, rng, snr_db, amp), data
 
@@ -213,7 +215,7 @@ def oracle_rx_mimo(cfg, iq, tti, keep=False, grid_in=None, rv=(0, 0)):
         grid = np.ascontiguousarray(grid_in, np.complex64).reshape(nrx, cfg.grid_len)
     else:
         q = OrcOfdm()
-        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, cfg.cp_norm)
         grid = np.zeros((nrx, cfg.grid_len), np.complex64)
         iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
         for a in range(nrx):
@@ -308,7 +310,7 @@ def oracle_rx(cfg, iq, tti, keep=False, grid_in=None, harq=None, rv=0, new_data=
         grid = np.ascontiguousarray(grid_in, np.complex64).reshape(nrx, cfg.grid_len)
     else:
         q = OrcOfdm()
-        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, True)
+        orc.orc_ofdm_init(C.byref(q), cfg.nof_prb, cfg.cp_norm)
         grid = np.zeros((nrx, cfg.grid_len), np.complex64)
         iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
         for a in range(nrx):
@@ -393,7 +395,7 @@ class RefRx:
         self.aligned = aligned
         self.chest = opaque(1 << 20)
         assert self.R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0
-        assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)) == 0
+        assert self.R.srslte_chest_dl_set_cell(self.chest, RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)) == 0
         self.rc = RefChestCfg()
         for k, v in cfg.chest.items():
             if k == "filter_coef":
@@ -416,7 +418,7 @@ class RefRx:
         self.R.srslte_crc_checksum_byte.restype = C.c_uint32
         self.R.srslte_cbsegm_cbindex.restype = C.c_int
         self.q = OrcOfdm()
-        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, True)
+        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, cfg.cp_norm)
         self.idx = {s: cfg.indices(s) for s in range(10)}
         self.scr = {}
 
@@ -483,7 +485,7 @@ class RefPdsch:
                                  "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]}, ["srslte/phy/phch/pdsch.h"])
-        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
+        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)  # srslte_cp_t: SRSLTE_CP_NORM 0, SRSLTE_CP_EXT 1
         self.chest = opaque(1 << 20)
         assert R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_chest_dl_set_cell(self.chest, cell) == 0
         self.rc = RefChestCfg()
@@ -514,8 +516,8 @@ class RefPdsch:
         u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1 if cfg.prb_mask is None else cfg.prb_mask
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb if cfg.prb_mask is None else int(cfg.prb_mask[0].sum()))
-        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
-        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], cfg.nsym // 2)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, cfg.nsym // 2)
         u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)
         u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_tb if cfg.tx_scheme else cfg.nof_ports)
         self.tb0 = L["srslte_pdsch_grant_t.tb"]
@@ -540,7 +542,7 @@ class RefPdsch:
             g[L["srslte_pdsch_cfg_t.softbuffers"] + 8:L["srslte_pdsch_cfg_t.softbuffers"] + 16].view(np.uint64)[0] = C.addressof(self.sb1)
         self.u32 = u32
         self.ofdm = OrcOfdm()
-        oracle().orc_ofdm_init(C.byref(self.ofdm), cfg.nof_prb, True)
+        oracle().orc_ofdm_init(C.byref(self.ofdm), cfg.nof_prb, cfg.cp_norm)
         self.nre = {s_: len(cfg.indices(s_)) for s_ in (0, 5, 1)}
 
     def _ptr(self, name, dtype, count, cw=0):
@@ -628,7 +630,7 @@ class RefPdschTx:
                                  "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"], "srslte_softbuffer_tx_t": []},
                                 ["srslte/phy/phch/pdsch.h"])
-        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 0, 0, 0, 0)
+        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)
         self.q = opaque(L["srslte_pdsch_t"] + 64)
         assert R.srslte_pdsch_init_enb(self.q, cfg.nof_prb) == 0 and R.srslte_pdsch_set_cell(self.q, cell) == 0
         R.srslte_pdsch_set_rnti.argtypes = [C.c_void_p, C.c_uint16]
@@ -643,8 +645,8 @@ class RefPdschTx:
         u32(L["srslte_pdsch_grant_t.pmi"], cfg.pmi)
         g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1 if cfg.prb_mask is None else cfg.prb_mask
         u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb if cfg.prb_mask is None else int(cfg.prb_mask[0].sum()))
-        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], 7)
-        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, 7)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"], cfg.nsym // 2)
+        u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4, cfg.nsym // 2)
         u32(L["srslte_pdsch_grant_t.nof_tb"], cfg.nof_tb)
         u32(L["srslte_pdsch_grant_t.nof_layers"], cfg.nof_tb if cfg.tx_scheme else cfg.nof_ports)
         self.tb0 = L["srslte_pdsch_grant_t.tb"]

@@ -51,18 +51,58 @@ MIX = {
 }
 
 
-def build_stream(P, cell_id, tti0, rng, csi=False, llr8=False, npt=1, nrx=1, mix=None):
+need_ref_later = pytest.mark.skipif(refdrv.lib() is None, reason="oracle/_ref did not travel with the repo")
+
+
+def build_stream(P, cell_id, tti0, rng, csi=False, llr8=False, npt=1, nrx=1, mix=None, cp_ext=False):
     """Grants from the reference where it is there (it is on the GPU box: oracle/_ref travels), subframes from the oracle's transmitter."""
-    rx = refdrv.RefDl(P, npt, cell_id)
+    rx = refdrv.RefDl(P, npt, cell_id, cp_ext=cp_ext)
     out = []
     for b, (how, mcs, cfi, snr) in enumerate(mix or MIX[P]):
         sf, rnti = (tti0 + b) % 10, 0x100 + 7 * b
         info = ref_grant(rx, P, sf, how, mcs, rnti, cfi, rng, tm=1 if npt > 1 else 0)  # srslte_tm_t: SRSLTE_TM2 = 1
-        cfg = DlConfig(P, cell_id, info["mod"], info["tbs"], cfi=cfi, rnti=rnti, prb_mask=info["prb_mask"], csi=csi, llr8=llr8, nof_ports=npt, nof_rx=nrx)
+        cfg = DlConfig(P, cell_id, info["mod"], info["tbs"], cfi=cfi, rnti=rnti, prb_mask=info["prb_mask"], csi=csi, llr8=llr8, nof_ports=npt, nof_rx=nrx,
+                       cp_ext=cp_ext)
         iq, data = make_subframe(cfg, tti0 + b, rng, snr_db=snr)
         out.append({"cfg": cfg, "iq": iq, "data": data, "info": info})
     rx.free()
     return out
+
+
+@need_ref_later
+@pytest.mark.parametrize("P,cell_id,tti0", [(100, 1, 0), (25, 150, 5), (15, 2, 0)])
+def test_mixed_grants_on_an_extended_cp_cell(hp, P, cell_id, tti0):
+    """The per-subframe-grant entry point on an extended-CP cell (cfg.cp_ext): the RE lists the device makes from the grants' PRB masks
+    (pdsch_relist_kernel with six symbols per slot: CRS symbols 0 and 3, PSS / SSS symbols 5 and 4, the stale-offset rule of the odd
+    bandwidth's half PRBs) equal srslte_pdsch_cp's order, LLRs within one LSB of the oracle chain, verdicts and transport blocks equal."""
+    rng = np.random.default_rng(31 * P + tti0)
+    mix = [(how, mcs, cfi, snr + 1.5) for how, mcs, cfi, snr in MIX[P] if mcs <= 24]  # fewer REs per PRB than with the normal CP: the top MCS would not fit
+    stream = build_stream(P, cell_id, tti0, rng, mix=mix, cp_ext=True)
+    tbs_max = max(s["cfg"].tbs for s in stream)
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    rxg = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, len(stream), True, hc, cp_ext=True)
+    grants = [hp.DlGrant.make(P, s["cfg"].mod, s["cfg"].tbs, s["cfg"].rnti, cfi=s["cfg"].cfi, prb_mask=s["cfg"].prb_mask) for s in stream]
+    rc, tb, ok = rxg.decode_grants(np.stack([s["iq"] for s in stream]), tti0, grants)
+    assert rc == 0
+    n = len(stream)
+    e = rxg.debug(11, np.int16, n * 16 * ((14 * 12 * P * 8 + 15) // 16)).reshape(n, -1)
+    relist = rxg.debug(15, np.uint32, n * 14 * 12 * P).reshape(n, -1)
+    nok = 0
+    for b, s in enumerate(stream):
+        cfg = s["cfg"]
+        r = oracle_rx(cfg, s["iq"], tti0 + b, keep=True)
+        idx = cfg.indices((tti0 + b) % 10)
+        assert len(idx) == s["info"]["nof_re"], b                                   # the reference's own count for its grant (srslte_ra_dl_grant_nof_re)
+        assert np.array_equal(relist[b, :len(idx)], idx), b
+        diff = np.abs(e[b, :len(r["e_raw"])].astype(int) - r["e_raw"].astype(int))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (b, diff.max(), (diff > 0).mean())
+        assert bool(ok[b]) == bool(r["ok"]), b
+        if ok[b]:
+            assert np.array_equal(tb[b, :cfg.tbs // 8 + 3], r["tb"]) and np.array_equal(tb[b, :cfg.tbs // 8], s["data"]), b
+            nok += 1
+    assert nok >= n - 2
+    rxg.free()
 
 
 need_ref = pytest.mark.skipif(refdrv.lib() is None, reason="oracle/_ref did not travel with the repo")
