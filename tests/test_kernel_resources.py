@@ -41,6 +41,13 @@ def test_no_kernel_uses_scratch_and_decoder_occupancy():
         assert kernels, f
         for k, r in kernels.items():
             total += 1
+            if "tdec_ar32_kernel" in k:
+                # the one measured exception: the 8-bit avx8 kernel under a 216-register budget spills around its loops (extraction, exchange and
+                # decision phases keep their state there while the pair-mapped sweeps run) and is 3 % FASTER in the four-stream pipeline than
+                # without the budget (256 VGPRs, 92 B of scratch): profiles/r04/ab_llr8_pair.txt. Bounded, so that a change that spills inside
+                # the sweeps shows up
+                assert r.get("ScratchSize [bytes/lane]", 0) <= 256 and r["VGPRs"] <= 216, (f, k, r)
+                continue
             assert r.get("ScratchSize [bytes/lane]", 0) == 0 and r.get("VGPRs Spill", 0) == 0, (f, k, r)
     assert total >= 40
     dec = [r for k, r in res["tdec.hip"].items() if "tdec_pair_kernel" in k]
