@@ -106,7 +106,16 @@ int  orc_dft_precoding(const orc_cf_t* in, orc_cf_t* out, uint32_t nof_prb, uint
 /* ---------------------------------------------------------------- CRS + channel estimator */
 typedef struct {
   uint32_t id, nof_prb, nof_ports; bool cp_norm;
+  /* srslte_cell_t.frame_type (0 FDD, 1 TDD) and the srslte_tdd_config_t of the subframes (phy_common.h:381-388): uplink-downlink
+     configuration 0-6 and special-subframe configuration 0-9. All zero: an FDD cell, as before these fields existed */
+  uint32_t frame_type, tdd_sf_config, tdd_ss_config;
 } orc_cell_t;
+/* phy_common.c:101-134: 0 downlink, 1 uplink, 2 special subframe; DwPTS symbols of the special subframe; symbols of slot 0 / 1 that carry
+   downlink (ra_dl.c:453-455 srslte_sfidx_tdd_nof_dw_slot); CRS-bearing symbols of a port in a subframe (refsignal_dl.c:162-225) */
+int      orc_tdd_sf_type(const orc_cell_t* cell, uint32_t sf_idx);
+uint32_t orc_tdd_nof_dw(const orc_cell_t* cell);
+uint32_t orc_nof_symb_slot(const orc_cell_t* cell, uint32_t sf_idx, uint32_t slot);
+uint32_t orc_crs_nof_symbols(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id);
 /* pilots for one subframe/port pair: [nsym][2*nof_prb] (refsignal_dl.c:66-116) */
 int orc_crs_pilots(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, orc_cf_t* pilots);
 int orc_crs_put_sf(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, orc_cf_t* grid);

@@ -97,6 +97,13 @@ static void interp_vector(const cf* in0, const cf* in1, const cf* start, cf* bet
 /* estimate_noise_pilots (chest_dl.c:304-379): rows[nsym][nref] pilot estimates; tmp holds 3 (nref + 2) values */
 static float noise_pilots(cf* est, uint32_t nref, uint32_t nsym, uint32_t fidx0, cf* tmp)
 {
+  if (nsym == 1) { /* "Special case for 1 symbol" (chest_dl.c:322-331): residual against the mean of the two neighbours and the pilot itself */
+    for (uint32_t k = 0; k + 2 < nref; k++) {
+      cf t = c_add(c_add(est[k + 1], est[k]), est[k + 2]);
+      tmp[k] = c_sub(est[k + 1], c_scale(t, 1.0f / 3.0f));
+    }
+    return avg_power(tmp, nref - 2);
+  }
   cf* in2d[6];
   for (uint32_t i = 0; i < nsym; i++) in2d[i + 1] = &est[i * nref];
   in2d[0]        = &tmp[nref];
@@ -152,9 +159,13 @@ void orc_pss_generate(uint32_t N_id_2, orc_cf_t* signal /* [62] */)
 static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_cfg_t* cfg, const orc_cf_t* grid, orc_cf_t* ce, uint32_t port,
                       cf* est, float raw[6], float noise_prev)
 {
-  const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = port < 2 ? 4 : 2, nref = 2 * P, npil = nsym * nref;
+  /* pilot symbols of this port in this subframe: 4 / 2, fewer in a TDD special subframe (refsignal_dl.c:162-225) */
+  const uint32_t P = cell->nof_prb, nre = 12 * P, nsym = orc_crs_nof_symbols(cell, sf_idx, port), nref = 2 * P, npil = nsym * nref;
   const uint32_t nsymb_sf = cell->cp_norm ? 14 : 12;
   if (port > 3) return -1;
+  /* what upstream computes from rows the shortened subframe does not have: chest_estimate_cfo pairs rows (0, 2) and (1, 3) of a NORMAL subframe
+     (:577-590), the extended-CP time interpolation has no special-subframe branch ("TODO", :497-502) */
+  if (nsym < (port < 2 ? 4u : 2u) && (cfg->cfo_estimate_enable || (!cell->cp_norm && cfg->interpolate_subframe && nsym >= 3))) return -3;
   const bool stale = port > 1 && ce && cfg->interpolate_subframe;
   cf* known = malloc(sizeof(cf) * 4 * nref);
   cf* recv  = malloc(sizeof(cf) * 4 * nref);
@@ -224,7 +235,7 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
     const cf* pil = est;
     if (cfg->filter_type != 2) { /* average_pilots, chest_dl.c:513-556 */
       uint32_t n = nref, ns = nsym;
-      if (!cfg->interpolate_subframe) {
+      if (!cfg->interpolate_subframe && nsym > 1) { /* :527-545; with three rows only the first two are summed, yet scaled by 2 / 3 */
         bool first_low = orc_crs_fidx(cell, 0, port) < 3;
         for (uint32_t k = 0; k < nref; k++) {
           cf a = est[k], b = est[nref + k];
@@ -245,9 +256,15 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
     /* interpolate_pilots, chest_dl.c:415-511 */
     if (stale) {
       for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);
-    } else if (!cfg->interpolate_subframe) {
+    } else if (!cfg->interpolate_subframe && nsym > 1) {
       uint32_t off = cell->id % 3;
       interp_linear_offset(pil, ce, 4 * P, 3, off, 3 - off);
+      for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);
+    } else if (!cfg->interpolate_subframe || nsym < 3) { /* one pilot symbol, or two with interpolate_subframe (:433,:456-471): the rows, then symbol 0 everywhere */
+      for (uint32_t l = 0; l < (cfg->interpolate_subframe ? nsym : 1); l++) {
+        uint32_t off = orc_crs_fidx(cell, l, port);
+        interp_linear_offset(&pil[nref * l], &ce[orc_crs_nsymbol(l, cell->cp_norm, port) * nre], nref, 6, off, 6 - off);
+      }
       for (uint32_t l = 1; l < nsymb_sf; l++) memcpy(&ce[l * nre], ce, sizeof(cf) * nre);
     } else {
       for (uint32_t l = 0; l < nsym; l++) {
@@ -255,7 +272,11 @@ static int chest_port(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_c
         interp_linear_offset(&pil[nref * l], &ce[orc_crs_nsymbol(l, cell->cp_norm, port) * nre], nref, 6, off, 6 - off);
       }
 #define S(i) (&ce[(i) * nre])
-      if (cell->cp_norm) {
+      if (cell->cp_norm && nsym == 3) { /* :481-488: symbols 8-13 continue the 4 -> 7 slope */
+        interp_vector(S(0), S(4), NULL, S(1), 4, 3, nre);
+        interp_vector(S(4), S(7), NULL, S(5), 3, 2, nre);
+        interp_vector(S(4), S(7), S(7), S(8), 3, 6, nre);
+      } else if (cell->cp_norm) {
         interp_vector(S(0), S(4), NULL, S(1), 4, 3, nre);
         interp_vector(S(4), S(7), NULL, S(5), 3, 2, nre);
         interp_vector(S(7), S(11), NULL, S(8), 4, 3, nre);

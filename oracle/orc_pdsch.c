@@ -19,11 +19,17 @@ int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, 
   uint32_t P = cell->nof_prb, nre = 12 * P, nsymb = cell->cp_norm ? 7 : 6, n = 0;
   uint32_t nof_refs = cell->nof_ports == 1 ? 2 : 4;
   uint32_t offset_var = 0; /* the reference's `offset`, pdsch.c:91 */
+  /* grant->nof_symb_slot[s] (ra_dl.c:446-460): the cyclic prefix's count, or the DwPTS share of a TDD special subframe */
+  const uint32_t nss[2] = {orc_nof_symb_slot(cell, sf_idx, 0), orc_nof_symb_slot(cell, sf_idx, 1)};
   for (uint32_t s = 0; s < 2; s++) {
-    for (uint32_t l = (s == 0 ? lstart : 0); l < nsymb; l++) {
+    for (uint32_t l = (s == 0 ? lstart : 0); l < nss[s]; l++) {
       bool has_ref = (l == 1 && cell->nof_ports == 4) || l == 0 || l == nsymb - 3; /* phy_common.h:139-141 */
       uint32_t offset = nof_refs == 2 ? (l == 0 ? cell->id % 6 : (cell->id + 3) % 6) : cell->id % 3;
-      bool sync = (s == 0 && (sf_idx == 0 || sf_idx == 5) && l >= nsymb - 2) || (s == 1 && sf_idx == 0 && l < 4);
+      /* pdsch.c:124-140: FDD PSS / SSS on the last two symbols of slot 0; TDD SSS on the last symbol of slot 1 (subframes 0 / 5) and PSS
+         on symbol 2 of slot 0 (subframes 1 / 6); PBCH the same in both */
+      bool sync = cell->frame_type ? ((s == 1 && (sf_idx == 0 || sf_idx == 5) && l + 1 >= nss[1]) || (s == 0 && (sf_idx == 1 || sf_idx == 6) && l == 2))
+                                   : (s == 0 && (sf_idx == 0 || sf_idx == 5) && l + 2 >= nss[0]);
+      sync      = sync || (s == 1 && sf_idx == 0 && l < 4);
       for (uint32_t p = 0; p < P; p++) {
         if (prb_mask && !prb_mask[s * P + p]) continue;
         bool centre = p >= P / 2 - 3 && p < P / 2 + 3 + (P % 2);
@@ -37,7 +43,7 @@ int orc_pdsch_indices(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, 
         for (uint32_t k = 12 * p; k < 12 * p + 12; k++) {
           if (sync && k + 36 >= nre / 2 && k < nre / 2 + 36) continue;
           if (has_ref && (k % (12 / nof_refs)) == off_used % (12 / nof_refs)) continue;
-          idx[n++] = (s * nsymb + l) * nre + k;
+          idx[n++] = (s * nss[0] + l) * nre + k; /* lp = l + s * nof_symb_slot[0], pdsch.c:142 */
         }
       }
     }

@@ -98,10 +98,42 @@ int orc_crs_pilots(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, or
   return 0;
 }
 
+/* TDD frame structure (36.211 Tables 4.2-1 and 4.2-2 as phy_common.c:85-99 holds them) */
+int orc_tdd_sf_type(const orc_cell_t* cell, uint32_t sf_idx)
+{ /* srslte_sfidx_tdd_type, phy_common.c:101-108 */
+  static const char* const cfgs[7] = {"DSUUUDSUUU", "DSUUDDSUUD", "DSUDDDSUDD", "DSUUUDDDDD", "DSUUDDDDDD", "DSUDDDDDDD", "DSUUUDSUUD"};
+  if (!cell->frame_type || cell->tdd_sf_config > 6 || sf_idx > 9) return 0;
+  const char c = cfgs[cell->tdd_sf_config][sf_idx];
+  return c == 'D' ? 0 : (c == 'U' ? 1 : 2);
+}
+uint32_t orc_tdd_nof_dw(const orc_cell_t* cell)
+{ /* srslte_sfidx_tdd_nof_dw, phy_common.c:128-135: the table's first column, whatever the cyclic prefix */
+  static const uint32_t dw[10] = {3, 9, 10, 11, 12, 3, 9, 10, 11, 6};
+  return cell->tdd_ss_config < 10 ? dw[cell->tdd_ss_config] : 0;
+}
+uint32_t orc_nof_symb_slot(const orc_cell_t* cell, uint32_t sf_idx, uint32_t slot)
+{ /* srslte_ra_dl_compute_nof_re (ra_dl.c:446-460) with srslte_sfidx_tdd_nof_dw_slot (phy_common.c:110-126) */
+  const uint32_t nsymb = cell->cp_norm ? 7 : 6;
+  if (orc_tdd_sf_type(cell, sf_idx) != 2) return nsymb;
+  const uint32_t n = orc_tdd_nof_dw(cell);
+  if (n < nsymb) return slot == 1 ? 0 : n;
+  return slot == 1 ? n - nsymb : nsymb;
+}
+uint32_t orc_crs_nof_symbols(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id)
+{ /* srslte_refsignal_cs_nof_symbols, refsignal_dl.c:162-225 */
+  if (orc_tdd_sf_type(cell, sf_idx) == 0 || !cell->frame_type) return port_id < 2 ? 4 : 2;
+  const uint32_t dw = orc_tdd_nof_dw(cell);
+  const uint32_t t3 = cell->cp_norm ? 12 : 10, t2 = cell->cp_norm ? 9 : 8, t1 = cell->cp_norm ? 5 : 4;
+  if (dw >= t3) return port_id < 2 ? 4 : 2;
+  if (dw >= t2) return port_id < 2 ? 3 : 2;
+  if (dw >= t1) return port_id < 2 ? 2 : 1;
+  return 1;
+}
+
 int orc_crs_put_sf(const orc_cell_t* cell, uint32_t sf_idx, uint32_t port_id, orc_cf_t* grid)
-{ /* refsignal_dl.c:253-272 */
-  uint32_t  nsym   = crs_nof_symbols(port_id), nre = 12 * cell->nof_prb;
-  orc_cf_t* pilots = malloc(sizeof(orc_cf_t) * nsym * 2 * cell->nof_prb);
+{ /* refsignal_dl.c:253-272: the CRS symbols the subframe has (all of a port's outside TDD special subframes) */
+  uint32_t  nsym   = orc_crs_nof_symbols(cell, sf_idx, port_id), nre = 12 * cell->nof_prb;
+  orc_cf_t* pilots = malloc(sizeof(orc_cf_t) * crs_nof_symbols(port_id) * 2 * cell->nof_prb);
   orc_crs_pilots(cell, sf_idx, port_id, pilots);
   for (uint32_t l = 0; l < nsym; l++) {
     uint32_t sym = orc_crs_nsymbol(l, cell->cp_norm, port_id), fidx = orc_crs_fidx(cell, l, port_id);

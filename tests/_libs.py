@@ -93,7 +93,9 @@ def hip():
 
 # ---------------------------------------------------------------- oracle structs
 class OrcCell(C.Structure):
-    _fields_ = [("id", C.c_uint32), ("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("cp_norm", C.c_bool)]
+    # frame_type 1 = TDD with its uplink-downlink and special-subframe configurations (all zero: FDD, as before the fields existed)
+    _fields_ = [("id", C.c_uint32), ("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("cp_norm", C.c_bool), ("frame_type", C.c_uint32),
+                ("tdd_sf_config", C.c_uint32), ("tdd_ss_config", C.c_uint32)]
 
 
 class OrcChestCfg(C.Structure):

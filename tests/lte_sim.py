@@ -19,7 +19,7 @@ class DlConfig:
     nof_ports = 2: 2-port transmit diversity (TM2)."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, cfi=1, rnti=0x1234, max_iter=6, chest=None, llr8=False, nof_rx=1, nof_ports=1, csi=False, p_a=None,
-                 prb_mask=None, tx_scheme=None, pmi=0, mod2=None, tbs2=0, cp_ext=False):
+                 prb_mask=None, tx_scheme=None, pmi=0, mod2=None, tbs2=0, cp_ext=False, tdd=None):
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.cfi, self.rnti, self.max_iter = nof_prb, cell_id, mod, tbs, cfi, rnti, max_iter
         # extended-CP cell: 6 symbols per slot, CRS on symbols 0 and 3, PSS / SSS on symbols 5 and 4 of slot 0 (phy_common.h:101-141, pdsch.c:81-206)
         self.cp_ext, self.cp_norm, self.nsym = bool(cp_ext), not cp_ext, 12 if cp_ext else 14
@@ -45,7 +45,9 @@ class DlConfig:
         self.p_a = p_a
         self.scaling = 1.0 if p_a is None else float(np.float32(10.0) ** np.float32(p_a / 20.0) * (np.float32(np.sqrt(np.float32(2.0))) if nof_ports > 1 else np.float32(1.0)))
         self.csi = csi  # srslte_pdsch_cfg_t.csi_enable: LLRs weighted by the channel gain (pdsch.c:574-690), the srsUE default
-        self.cell = OrcCell(cell_id, nof_prb, nof_ports, self.cp_norm)
+        # tdd = (uplink-downlink configuration 0-6, special-subframe configuration 0-9): srslte_cell_t.frame_type = SRSLTE_TDD + srslte_tdd_config_t
+        self.tdd = tdd
+        self.cell = OrcCell(cell_id, nof_prb, nof_ports, self.cp_norm, 1 if tdd else 0, tdd[0] if tdd else 0, tdd[1] if tdd else 0)
         self.nre = 12 * nof_prb
         self.grid_len = self.nsym * self.nre
         self.lstart = cfi + (1 if nof_prb < 10 else 0)
@@ -485,7 +487,7 @@ class RefPdsch:
                                  "srslte_pdsch_grant_t": ["tx_scheme", "pmi", "prb_idx", "nof_prb", "nof_re", "nof_symb_slot", "tb", "nof_tb", "nof_layers"],
                                  "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
                                  "srslte_softbuffer_rx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]}, ["srslte/phy/phch/pdsch.h"])
-        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)  # srslte_cp_t: SRSLTE_CP_NORM 0, SRSLTE_CP_EXT 1
+        cell = RefCell(cfg.nof_prb, cfg.nof_ports, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 1 if cfg.tdd else 0)  # srslte_cp_t NORM 0 / EXT 1; frame type FDD 0 / TDD 1
         self.chest = opaque(1 << 20)
         assert R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_chest_dl_set_cell(self.chest, cell) == 0
         self.rc = RefChestCfg()
@@ -599,9 +601,16 @@ class RefPdsch:
             for a_ in range(nrx):
                 oracle().orc_ofdm_rx_sf(C.byref(self.ofdm), p(iq2[a_]), p(grids[a_]))
         self.sf.tti, self.sf.cfi = tti, cfg.cfi
+        nre = self.nre[0 if sf_idx == 0 else (5 if sf_idx == 5 else 1)]
+        if cfg.tdd:  # srslte_dl_sf_cfg_t.tdd_config and what srslte_ra_dl_compute_nof_re derives from it (ra_dl.c:446-460)
+            self.sf.tdd_config.sf_config, self.sf.tdd_config.ss_config, self.sf.tdd_config.configured = cfg.tdd[0], cfg.tdd[1], True
+            orc_ = oracle()
+            orc_.orc_nof_symb_slot.restype = C.c_uint32
+            for s_ in (0, 1):
+                self.u32(L["srslte_pdsch_grant_t.nof_symb_slot"] + 4 * s_, orc_.orc_nof_symb_slot(C.byref(cfg.cell), sf_idx, s_))
+            nre = len(cfg.indices(sf_idx))
         inp = (C.c_void_p * 4)(*([g_.ctypes.data for g_ in grids] + [0] * (4 - nrx)))
         assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
-        nre = self.nre[0 if sf_idx == 0 else (5 if sf_idx == 5 else 1)]
         self.u32(L["srslte_pdsch_grant_t.nof_re"], nre)
         self.u32(self.tb0 + L["srslte_ra_tb_t.nof_bits"], nre * cfg.Qm)
         self.u32(self.tb0 + L["srslte_ra_tb_t.rv"], rv)

