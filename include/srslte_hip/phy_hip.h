@@ -95,6 +95,9 @@ typedef struct {             /* scalar members of srslte_chest_dl_res_t (chest_d
 } srslte_hip_chest_dl_res_t;
 /* cp_is_norm = 0: extended-CP cell, 12 symbols per subframe: every "[14]" below reads "[12]" then (CRS on symbols 0, 3, 6, 9; chest_dl.c:497-502) */
 srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm); /* chest_dl.c:69-160,193-300 */
+/* TDD cell (srslte_cell_t.frame_type = SRSLTE_TDD; sf_config / ss_config = srslte_tdd_config_t of srslte_dl_sf_cfg_t, phy_common.h:381-388): special
+ * subframes are estimated from the CRS symbols their DwPTS holds (refsignal_dl.c:162-225). sf_config < 0: FDD again. */
+int srslte_hip_chest_dl_set_tdd(srslte_hip_chest_dl_t* q, int sf_config, int ss_config);
 void                   srslte_hip_chest_dl_destroy(srslte_hip_chest_dl_t* q);
 /* the symbol size the CFO and timing-error estimates scale with (chest_dl.c:575,:695: srslte_symbol_sz(cell.nof_prb), read at every call);
  * default: the default rate family's; e.g. 2048 for 100 PRB after srslte_use_standard_symbol_size(true) */
@@ -244,6 +247,13 @@ typedef struct {
   int      cp_ext;          /* 1: extended-CP cell (srslte_cell_t.cp = SRSLTE_CP_EXT): 12 symbols per subframe - grids, estimates and RE lists
                                are [12][12 * nof_prb] -, CRS on symbols 0 and 3 of each slot, PSS / SSS on symbols 5 and 4 of slot 0
                                (ofdm.c:424-437, chest_dl.c:497-502, pdsch.c:81-206 with nof_symb_slot = 6) */
+  int      tdd;             /* 1: TDD cell (srslte_cell_t.frame_type = SRSLTE_TDD) with tdd_sf_config (uplink-downlink configuration 0-6) and
+                               tdd_ss_config (special-subframe configuration 0-9) = the srslte_tdd_config_t of its subframes. Served by the
+                               per-subframe-grant entry points (srslte_hip_dl_rx_batch_grants*): SSS on the last symbol of slot 1 in subframes
+                               0 / 5, PSS on symbol 2 of subframes 1 / 6, and in the special subframes PDSCH and CRS on the DwPTS symbols only
+                               (pdsch.c:124-140, ra_dl.c:446-460, refsignal_dl.c:162-225); uplink subframes of the batch carry tbs = 0. The
+                               fixed-grant calls refuse a TDD cell (their three subframe classes are FDD's) */
+  uint32_t tdd_sf_config, tdd_ss_config;
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -462,6 +472,9 @@ typedef struct {
   uint32_t max_grants;     /* srslte_hip_dl_tx_batch_grants: PDSCHs per call; 0 = max_batch */
   int      cp_ext;         /* 1: extended-CP cell (as srslte_hip_dl_rx_cfg_t.cp_ext): grids [12][12 * nof_prb], CRS on symbols 0 and 3 of each slot
                               with the extended-CP sequences (N_CP = 0 in c_init, refsignal_dl.c:79-99), srslte_ofdm_tx_sf with the long prefix */
+  int      tdd;            /* as srslte_hip_dl_rx_cfg_t.tdd: TDD cell, per-PDSCH grants only (srslte_hip_dl_tx_batch_grants); special subframes get the
+                              CRS symbols of their DwPTS (srslte_refsignal_cs_put_sf, refsignal_dl.c:253-272) and PDSCH there */
+  uint32_t tdd_sf_config, tdd_ss_config;
 } srslte_hip_dl_tx_cfg_t;
 srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);
 void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);

@@ -29,7 +29,21 @@ struct ChestParams {
   int   nof_ports;      // and writes ce [sf][port][antenna]
   int   nsl;            // symbols per slot: 7, or 6 in an extended-CP cell (grids and estimates are then [12][12 nof_prb])
   int   ce_compact;     // !interpolate_subframe only: ONE row of 12 nof_prb estimates per (subframe, port, antenna) instead of 2 nsl equal ones
+  int   tdd_s6;         // TDD cell (srslte_cell_t.frame_type, srslte_tdd_config_t): -1 = FDD; else 1 if subframe 6 is a special subframe too
+                        // (uplink-downlink configurations 0, 1, 2, 6; subframe 1 always is), 0 if not
+  int   tdd_dw;         // DwPTS symbols of a special subframe (phy_common.c:128-135): only those carry CRS (refsignal_dl.c:162-225)
 };
+// pilot symbols of a port in a subframe (srslte_refsignal_cs_nof_symbols)
+__device__ __forceinline__ int crs_nof_symbols(const ChestParams& p, int sf_idx, int port)
+{
+  const int full = port < 2 ? 4 : 2;
+  if (p.tdd_s6 < 0 || !(sf_idx == 1 || (sf_idx == 6 && p.tdd_s6))) return full;
+  const int t3 = p.nsl == 7 ? 12 : 10, t2 = p.nsl == 7 ? 9 : 8, t1 = p.nsl == 7 ? 5 : 4;
+  if (p.tdd_dw >= t3) return full;
+  if (p.tdd_dw >= t2) return port < 2 ? 3 : 2;
+  if (p.tdd_dw >= t1) return port < 2 ? 2 : 1;
+  return 1;
+}
 struct ChestRaw { float noise, rsrp, rssi, cfo, sync, corr; }; // per (subframe, port, antenna), combined by chest_fill_res_kernel
 
 struct ChestResDev { // mirrors the scalar tail of srslte_chest_dl_res_t (chest_dl.h:49-67) for 1 port / 1 antenna
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   const int   sf = blockIdx.x, tid = threadIdx.x; // sf: (subframe, port, antenna) index
   const int   ant = sf % p.nof_rx, port = (sf / p.nof_rx) % p.nof_ports, sfn = sf / (p.nof_rx * p.nof_ports), sf_idx = (p.tti0 + sfn) % 10;
   const cf32* g      = grid + ((size_t)sfn * p.nof_rx + ant) * 2 * p.nsl * nre;
-  const int   nsym = port < 2 ? 4 : 2, npil = nsym * nref; // ports 2/3: two pilot symbols per subframe
+  const int   nsym = crs_nof_symbols(p, sf_idx, port), npil = nsym * nref; // 4 (ports 2/3: 2), fewer in a TDD special subframe
   // ports 0 and 1 share their values (refsignal_dl.c pilots[port / 2]), [10][4][nref]; ports 2 and 3 theirs, [10][2][nref] behind
   const cf32* known = port < 2 ? pilots + (size_t)sf_idx * 4 * nref : pilots + (size_t)10 * 4 * nref + (size_t)sf_idx * 2 * nref;
 
@@ -247,8 +261,15 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
   // ---- noise from pilots (REFS): residual of the last pilot symbol only (chest_dl.c:352-378); PSS / EMPTY: the estimator's kept
   // estimate [port][antenna], renewed below in subframes 0 and 5 once ce is there (:657-672)
   float noise = p.noise_alg == 0 ? 0.f : noise_state[sf % (p.nof_rx * p.nof_ports)];
-  if (p.noise_alg == 0) {
-    const int   off = crs_fidx(p.cell_id, 0, port) < 3 ? 0 : 1;
+  if (p.noise_alg == 0 && nsym == 1) { // "Special case for 1 symbol" (chest_dl.c:322-331): against the mean of the pilot and its two neighbours
+    acc = 0;
+    for (int k = tid; k + 2 < nref; k += CH_THREADS) {
+      const cf32 t = c_sub(est[k + 1], c_scale(c_add(c_add(est[k + 1], est[k]), est[k + 2]), 1.0f / 3.0f));
+      acc += t.x * t.x + t.y * t.y;
+    }
+    noise = block_sum(acc, red) / (float)(nref - 2);
+  } else if (p.noise_alg == 0) {
+    const int   off = ((crs_fidx(p.cell_id, 0, port) < 3) != ((nsym & 1) != 0)) ? 0 : 1; // the LAST row's offset (:353): ((fidx < 3) ^ (i & 1)) with i = nsym
     // the last pilot row, its predecessor, and the row before that (4 symbols: rows 3, 2, 0; 2 symbols: rows 1, 0, -)
     const cf32 *r0 = est, *r2 = est + (nsym - 2) * nref, *r3 = est + (nsym - 1) * nref;
     acc = 0;
@@ -307,7 +328,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
     const cf32* pil = est;
     if (p.filter_type != 2) { // average_pilots
       int n = nref, ns = 4;
-      if (!p.interpolate_subframe) {
+      if (!p.interpolate_subframe && nsym > 1) { // with three rows only the first two are summed, yet scaled by 2 / 3 (chest_dl.c:527-545)
         const bool first_low = crs_fidx(p.cell_id, 0, port) < 3;
         for (int k = tid; k < nref; k += CH_THREADS) {
           cf32 a = est[k], b = est[nref + k];
@@ -335,12 +356,22 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
 
     const int rows = p.ce_compact ? 1 : 2 * p.nsl;
     cf32*     o    = ce + (size_t)sf * rows * nre;
-    if (p.interpolate_subframe && port >= 2) {
+    if (port >= 2 && (p.interpolate_subframe || nsym == 1)) { // (nsym == 1: a special subframe's single row goes to symbol 1, then symbol 0 is copied over it)
       // ports 2/3 have two pilot symbols: upstream takes the copy branch (nsymbols < 3, chest_dl.c:467-471) and replicates symbol 0 of ce -
       // which this call does not write for them - over the subframe. ce is in / out here exactly as there.
       for (int k = tid; k < nre; k += CH_THREADS) {
         const cf32 v = o[k];
         for (int l = 1; l < 2 * p.nsl; l++) o[l * nre + k] = v;
+      }
+    } else if (nsym < 3 && (p.interpolate_subframe || nsym == 1)) {
+      // a special subframe's one pilot row, or its two with interpolate_subframe (chest_dl.c:433,:456-471): interpolated in frequency, then
+      // symbol 0 is what every symbol of the subframe gets
+      for (int k = tid; k < nre; k += CH_THREADS) {
+        const cf32 v = interp_offset_at(pil, nref, 6, crs_fidx(p.cell_id, 0, port), k);
+#pragma unroll
+        for (int l = 0; l < 14; l++) {
+          if (l < rows) o[l * nre + k] = v;
+        }
       }
     } else if (!p.interpolate_subframe) { // chest_dl.c:448-471
       const int off = p.cell_id % 3;
@@ -352,13 +383,25 @@ __global__ __launch_bounds__(CH_THREADS) void chest_dl_kernel(const cf32* __rest
         }
       }
     } else { // chest_dl.c:456-495
-      for (int i = tid; i < 4 * nre; i += CH_THREADS) {
+      for (int i = tid; i < nsym * nre; i += CH_THREADS) {
         const int l = i / nre;
         fr[i]       = interp_offset_at(pil + nref * l, nref, 6, crs_fidx(p.cell_id, l, port), i - l * nre);
       }
       __syncthreads();
       for (int k = tid; k < nre; k += CH_THREADS) {
         const cf32 s0 = fr[k], s4 = fr[nre + k], s7 = fr[2 * nre + k], s11 = fr[3 * nre + k];
+        if (nsym == 3) { // special subframe with three pilot symbols (normal CP; :481-488): symbols 8 .. 13 continue the 4 -> 7 slope
+          cf32 d = c_scale(c_sub(s4, s0), 1.0f / 4), v = s0;
+          o[k] = s0;
+          for (int l = 1; l <= 3; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+          o[4 * nre + k] = s4;
+          d = c_scale(c_sub(s7, s4), 1.0f / 3); v = s4;
+          for (int l = 5; l <= 6; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+          o[7 * nre + k] = s7;
+          v = s7;
+          for (int l = 8; l <= 13; l++) { v = c_add(v, d); o[l * nre + k] = v; }
+          continue;
+        }
         if (p.nsl == 6) { // extended CP: pilot symbols 0, 3, 6, 9 (chest_dl.c:497-502); the last step extrapolates with the 6-9 slope
           const cf32 pil4[4] = {s0, s4, s7, s11};
           cf32       dd = make_float2(0.f, 0.f);
@@ -580,6 +623,7 @@ struct srslte_hip_chest_dl {
   cf32*     d_pss;        // the cell's 62 PSS values (pss.c:348-376), for the PSS noise algorithm
   float*    d_noise_state; // [port][antenna] noise estimates kept between calls by the PSS / EMPTY algorithms
   int       symbol_sz;     // srslte_symbol_sz(nof_prb) as the CFO and timing estimates use it (chest_dl.c:575,:695)
+  int       tdd_s6, tdd_dw; // srslte_hip_chest_dl_set_tdd: -1 = FDD (ChestParams)
 };
 
 extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, uint32_t nof_prb, uint32_t nof_ports, int cp_is_norm)
@@ -609,6 +653,8 @@ extern "C" srslte_hip_chest_dl_t* srslte_hip_chest_dl_create(uint32_t cell_id, u
   q->nof_prb  = nof_prb;
   q->nof_ports = (int)nof_ports;
   q->nsl      = cp_is_norm ? 7 : 6;
+  q->tdd_s6   = -1;
+  q->tdd_dw   = 0;
   q->d_pilots = nullptr;
   q->d_raw    = nullptr;
   q->raw_cap  = 0;
@@ -711,6 +757,7 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
   if (nof_sf == 0) return SRSLTE_SUCCESS;
   ChestParams p;
   p = ChestParams{};
+  p.tdd_s6 = -1;
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;
   p.noise_alg = cfg->noise_alg; p.filter_type = cfg->filter_type; p.interpolate_subframe = 1;
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
@@ -719,6 +766,19 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
                      (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce, d_noise, (const cf32*)q->d_pilots,
                      (const cf32*)q->d_mbsfn[cfg->mbsfn_area_id], p);
   LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
+// TDD cell (srslte_cell_t.frame_type = SRSLTE_TDD with the subframes' srslte_tdd_config_t): in special subframes (1, and 6 in uplink-downlink
+// configurations 0, 1, 2, 6) only the DwPTS symbols carry CRS and the estimator works on 4, 3, 2 or 1 pilot symbols (refsignal_dl.c:162-225,
+// chest_dl.c:322-331,:481-488,:527-545). sf_config < 0: back to FDD. Not with cfo_estimate_enable (upstream pairs rows a shortened subframe lacks)
+// nor, on an extended-CP cell, with interpolate_subframe (upstream's TODO, chest_dl.c:497): those calls are refused.
+extern "C" int srslte_hip_chest_dl_set_tdd(srslte_hip_chest_dl_t* q, int sf_config, int ss_config)
+{
+  static const int dw[10] = {3, 9, 10, 11, 12, 3, 9, 10, 11, 6}; // phy_common.c:98-99, first column
+  if (!q || sf_config > 6 || (sf_config >= 0 && (ss_config < 0 || ss_config > 9))) return SRSLTE_ERROR_INVALID_INPUTS;
+  q->tdd_s6 = sf_config < 0 ? -1 : ((sf_config <= 2 || sf_config == 6) ? 1 : 0);
+  q->tdd_dw = sf_config < 0 ? 0 : dw[ss_config];
   return SRSLTE_SUCCESS;
 }
 
@@ -746,6 +806,10 @@ int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_ches
 {
   if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4) return SRSLTE_ERROR_INVALID_INPUTS;
   if (ce_compact && cfg->interpolate_subframe) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (q->tdd_s6 >= 0 && q->tdd_dw < (q->nsl == 7 ? 12 : 10) && (cfg->cfo_estimate_enable || (q->nsl == 6 && cfg->interpolate_subframe && d_ce))) {
+    hip_log("[srslte_hip] chest_dl: TDD special subframes with fewer pilot symbols: no CFO estimate, no interpolate_subframe on an extended-CP cell\n");
+    return SRSLTE_ERROR;
+  }
   if (cfg->noise_alg < 0 || cfg->noise_alg > 2) return SRSLTE_ERROR_INVALID_INPUTS;
   if (cfg->noise_alg != 0 && cfg->filter_type == 0 && cfg->filter_coef[0] <= 0 && nof_sf > 1 && d_ce) {
     // the automatic Gauss filter of a subframe then depends on the estimates of the subframes before it: a sequential chain
@@ -767,6 +831,7 @@ int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_ches
   p.nof_ports = q->nof_ports;
   p.nsl = q->nsl;
   p.ce_compact = ce_compact ? 1 : 0;
+  p.tdd_s6 = q->tdd_s6; p.tdd_dw = q->tdd_dw;
   const int nslice = nof_rx * q->nof_ports;
   ChestRaw* raw = nullptr;
   if (d_res || cfg->noise_alg) {

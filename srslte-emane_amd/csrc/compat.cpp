@@ -1222,6 +1222,9 @@ int srslte_chest_dl_estimate_cfg(srslte_chest_dl_t* q, srslte_dl_sf_cfg_t* sf, s
     }
   }
   srslte_hip_chest_dl_set_symbol_sz(st->h, srslte_symbol_sz(q->cell.nof_prb)); // chest_dl.c:575,:695: read at every call
+  // TDD cell: a special subframe has only the CRS symbols of its DwPTS (srslte_refsignal_cs_nof_symbols reads sf->tdd_config at every call)
+  const bool tdd = q->cell.frame_type == SRSLTE_TDD && sf->tdd_config.configured && sf->tdd_config.sf_config < 7 && sf->tdd_config.ss_config < 10;
+  if (srslte_hip_chest_dl_set_tdd(st->h, tdd ? (int)sf->tdd_config.sf_config : -1, tdd ? (int)sf->tdd_config.ss_config : 0)) return SRSLTE_ERROR;
   if (srslte_hip_chest_dl_estimate_batch_multi(st->h, &hc, sf->tti % 10, dg, want_ce ? dce : nullptr, dres, 1, (int)nrx, tl_stream())) return SRSLTE_ERROR;
   srslte_hip_chest_dl_res_t r;
   float raw[SRSLTE_MAX_PORTS * SRSLTE_MAX_PORTS][6]; // [port][antenna] {noise, rsrp, rssi, cfo, sync, corr}
