@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
     ap.add_argument("--grants", action="store_true", help="run the same workload through srslte_hip_dl_rx_batch_grants: one grant per subframe "
                     "(here 128 equal full-band MCS-28 grants), RE lists and scrambling sequences made on the device from the grants on every call")
+    ap.add_argument("--pool", action="store_true", help="submit the batches through srslte_hip_dl_rx_pool_* (ONE submission call per batch from this one host "
+                    "thread; the library owns --streams pipeline objects and their streams) instead of round-robining objects here")
     ap.add_argument("--grants-mix", action="store_true", help="the mixed-grant workload (scripts/bench_grants_mix.py): 128 subframes of one cell, a different grant "
                     "per subframe - 40 %% small allocations (2-25 PRB QPSK/16QAM), 30 %% medium, 30 %% large - through srslte_hip_dl_rx_batch_grants")
     ap.add_argument("--cpu-worker", nargs=6, metavar=("NPY", "LO", "HI", "SECONDS", "CELL", "RNTI"), help=argparse.SUPPRESS)
@@ -319,6 +321,21 @@ def main():
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     streams = [t.cuda_stream for t in tstreams]
     rx, stream = rxs[0], streams[0]
+    pool = None
+    if args.pool:  # the library's own pool: its objects replace rxs[] in the timed loop (rxs[0] stays for the isolated kernel timings and the checks)
+        if world > 1 or args.grants:
+            raise SystemExit("--pool is the single-GPU, fixed-grant submission path")
+        L.srslte_hip_dl_rx_pool_create.restype = ctypes.c_void_p
+        L.srslte_hip_dl_rx_pool_create.argtypes = [ctypes.c_void_p, ctypes.c_uint32]
+        L.srslte_hip_dl_rx_pool_submit.restype = ctypes.c_int64
+        L.srslte_hip_dl_rx_pool_submit.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                                                   ctypes.c_void_p, ctypes.c_void_p]
+        L.srslte_hip_dl_rx_pool_wait.argtypes = [ctypes.c_void_p, ctypes.c_int64]
+        L.srslte_hip_dl_rx_pool_destroy.argtypes = [ctypes.c_void_p]
+        pool = L.srslte_hip_dl_rx_pool_create(ctypes.byref(rxs[0].cfg), nstreams)
+        if not pool:
+            raise RuntimeError("srslte_hip_dl_rx_pool_create failed")
+        pool_tickets = [None] * nstreams
     # where the results go: rank 0's host memory (pinned), directly (N = 1) or through the gather
     t_gath = [torch.zeros((world, res_bytes), dtype=torch.uint8, device=cdev) for _ in range(nstreams)] if (rank == 0 and use_dist) else None
     h_stage = [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)] if (use_dist and not on_device) else None
@@ -332,6 +349,12 @@ def main():
         s = k % nstreams
         if isinstance(src, list):  # rotating inputs: step k takes batch k mod n
             src = src[k % len(src)]
+        if pool is not None and ev is None:  # one call per batch; the results go to the pinned host record on the batch's own stream inside the pool
+            t = L.srslte_hip_dl_rx_pool_submit(pool, src.data_ptr(), 0, B, None, t_res[s].data_ptr(), tb_stride, t_res[s].data_ptr() + ok_off, h_out[s][0].data_ptr())
+            if t < 0:
+                raise RuntimeError("pool submit failed: %d" % t)
+            pool_tickets[s] = t
+            return
         if grant_arr is not None:  # one call runs every stage: no decoder-only duration in this mode (tdec_ms stays None, roofline fields null)
             rc = L.srslte_hip_dl_rx_batch_grants(rxs[s].h, src.data_ptr(), 0, B, grant_arr, rxs[s].d_tb.ptr, rxs[s].tb_stride, rxs[s].d_ok.ptr, streams[s])
             if rc:
@@ -359,6 +382,10 @@ def main():
                     h_out[s].copy_(t_gath[s])
 
     def barrier():
+        if pool is not None:
+            for t in pool_tickets:
+                if t is not None and L.srslte_hip_dl_rx_pool_wait(pool, t):
+                    raise RuntimeError("pool wait failed")
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -396,7 +423,7 @@ def main():
     # the contract's W warm-up steps are a few milliseconds; clocks and first-touch effects last longer (round 2: the first repeats of the
     # timed region ran at half speed), so whole untimed repeats follow until 0.15 s have passed
     timed_repeats(d_inputs, 0.15, False)
-    times, tdec_ms = timed_repeats(d_inputs, args.min_timed_s, True)
+    times, tdec_ms = timed_repeats(d_inputs, args.min_timed_s, pool is None)  # pool mode: one call per batch, no per-stage events
     t_med = float(np.median(times))
     # round 3's loop for comparison: every step and every pipeline instance fed the SAME batch (it then stays in the Infinity Cache)
     same_times, _ = timed_repeats(d_iq, args.min_timed_s / 2, False) if n_inputs > 1 else (times, None)
@@ -662,7 +689,8 @@ def main():
                    "avg_siso_passes_per_wavefront": round(passes_per_wavefront, 3) if passes_per_wavefront is not None else None,
                    "sharding": "one UE per GPU; one gather of TBs + CRC flags per batch to rank 0 (%s), inside the timed region" % ("RCCL" if on_device else args.backend)
                    if use_dist else "one UE per GPU; single GPU: results copied to host inside the timed region",
-                   "entry_point": "srslte_hip_dl_rx_batch_grants (a grant per subframe)" if args.grants else "srslte_hip_dl_rx_stage x 6 (one fixed grant)",
+                   "entry_point": "srslte_hip_dl_rx_batch_grants (a grant per subframe)" if args.grants else
+                   ("srslte_hip_dl_rx_pool_submit (one call per batch, %d objects inside the library)" % nstreams if pool is not None else "srslte_hip_dl_rx_stage x 6 (one fixed grant)"),
                    "input_batches": n_inputs, "input_MB": round(n_inputs * d_iq.numel() * 4 / 1e6, 1),
                    "same_input_value": round(world * B * args.steps / float(np.median(same_times)), 1),
                    "streams": nstreams, "pipeline_instances_verified": nstreams if agree_all == world else 0, "results_on_host_verified": gather_ok,
@@ -675,6 +703,8 @@ def main():
         "cpu_baseline": cpu,
     }
     print(json.dumps(out))
+    if pool is not None:
+        L.srslte_hip_dl_rx_pool_destroy(pool)
     if use_dist:
         dist.destroy_process_group()
 

@@ -314,6 +314,21 @@ int srslte_hip_dl_rx_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_iq, uint
 /* ... from frequency-domain grids d_grid, as srslte_hip_dl_rx_grid_batch takes them (the caller ran the OFDM demodulation) */
 int srslte_hip_dl_rx_grid_batch_grants2(srslte_hip_dl_rx_t* q, const void* d_grid, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant2_t* grants,
                                         uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* stream);
+/* A pool of `depth` receive pipelines behind ONE submission call. A batch of 128 subframes is 832 decoder wavefronts for 1024 SIMDs and a chain of
+ * dependent launches: one object on one stream reaches 0.4 of what the chip does with four batches in flight ("One call, one stream").
+ * The pool owns the objects, a non-blocking stream and a completion event each, and takes the batches round-robin: the caller - one host thread, one
+ * call per batch, as a worker of srsue / srsenb would make it - gets the overlapped rate without managing streams. submit() queues batch n on object
+ * n % depth (waiting first, on the host, for the batch that used that object `depth` submissions ago) and returns a ticket; wait(ticket) blocks
+ * until that batch's d_tb / d_tb_ok are final (their device buffers are the caller's; copy them on any stream after wait, or pass a pinned host
+ * record to have the pool copy [nof_sf][tb_stride] bytes + [nof_sf] flags there on the batch's stream before the event). grants may be NULL (the
+ * object's fixed grant). All calls from one host thread. */
+typedef struct srslte_hip_dl_rx_pool srslte_hip_dl_rx_pool_t;
+srslte_hip_dl_rx_pool_t* srslte_hip_dl_rx_pool_create(const srslte_hip_dl_rx_cfg_t* cfg, uint32_t depth);
+void                     srslte_hip_dl_rx_pool_destroy(srslte_hip_dl_rx_pool_t* p);
+int64_t srslte_hip_dl_rx_pool_submit(srslte_hip_dl_rx_pool_t* p, const void* d_iq, uint32_t tti0, uint32_t nof_sf, const srslte_hip_dl_grant_t* grants,
+                                     uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, void* h_record /* pinned, or NULL */);
+int     srslte_hip_dl_rx_pool_wait(srslte_hip_dl_rx_pool_t* p, int64_t ticket);
+
 /* one stage of the chain (0 OFDM RX, 1 chest_dl, 2 extract+equalise+demap+descramble, 3 rate de-matching, 4 turbo decode, 5 TB CRC):
  * what srslte_hip_dl_rx_batch runs in order; exposed so that each kernel can be timed on its own */
 int srslte_hip_dl_rx_stage(srslte_hip_dl_rx_t* q, int stage, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb,

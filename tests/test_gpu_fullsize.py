@@ -197,3 +197,43 @@ def test_cfg4_eight_ues_on_one_device():
     assert out["rehearsal"] and c["undetected_errors"] == 0 and c["oracle_sample"] == 16 and c["oracle_sample_agrees"] == 16, c
     assert len({u["rnti"] for u in c["per_ue"]}) == 8 and len({u["cell_id"] for u in c["per_ue"]}) == 8
     assert sum(u["delivered"] for u in c["per_ue"]) >= 8 * 16 * 0.5, c["per_ue"]
+
+
+def test_pool_one_call_per_batch(hp):
+    """srslte_hip_dl_rx_pool_*: one host thread, ONE submission call per batch; the pool round-robins its objects and streams. Eight batches of a
+    25-PRB cell through a pool of three: every batch's transport blocks (device buffers and the pinned host record the pool fills on the batch's
+    own stream) equal those of a plain object, tickets complete in any order of waiting, and a submission re-uses an object only after its
+    previous batch."""
+    import ctypes as C
+    from lte_sim import DlConfig, make_subframe
+    L = hp.lib()
+    L.srslte_hip_dl_rx_pool_create.restype = C.c_void_p
+    L.srslte_hip_dl_rx_pool_create.argtypes = [C.c_void_p, C.c_uint32]
+    L.srslte_hip_dl_rx_pool_submit.restype = C.c_int64
+    L.srslte_hip_dl_rx_pool_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    L.srslte_hip_dl_rx_pool_wait.argtypes = [C.c_void_p, C.c_int64]
+    L.srslte_hip_dl_rx_pool_destroy.argtypes = [C.c_void_p]
+    prb, mod, tbs, B, nb = 25, 2, 4008, 6, 8
+    rng = np.random.default_rng(4)
+    cfg = DlConfig(prb, 3, mod, tbs)
+    batches = [[make_subframe(cfg, 10 * n + b, rng, snr_db=12.0, amp=0.1) for b in range(B)] for n in range(nb)]
+    rx = hp.DlRx(3, prb, 1, 0x1234, mod, tbs, 6, B, True, _chest(hp))
+    want = [rx.decode(np.stack([s[0] for s in bt]), 10 * n) for n, bt in enumerate(batches)]
+    pool = L.srslte_hip_dl_rx_pool_create(C.byref(rx.cfg), 3)
+    assert pool
+    stride = rx.tb_stride
+    d_iq = [hp.DevBuf.from_host(np.stack([s[0] for s in bt])) for bt in batches]
+    d_tb, d_ok = [hp.DevBuf(stride * B) for _ in range(nb)], [hp.DevBuf(B) for _ in range(nb)]
+    tickets = [L.srslte_hip_dl_rx_pool_submit(pool, d_iq[n].ptr, 10 * n, B, None, d_tb[n].ptr, stride, d_ok[n].ptr, None) for n in range(nb)]
+    assert tickets == list(range(nb))
+    for n in (5, 0, 7, 3, 1, 2, 4, 6):
+        assert L.srslte_hip_dl_rx_pool_wait(pool, tickets[n]) == 0
+        tb = d_tb[n].to_host(np.uint8).reshape(B, stride)[:, :tbs // 8 + 3]
+        ok = d_ok[n].to_host(np.uint8)[:B]
+        assert np.array_equal(ok, want[n][1]) and np.array_equal(tb[:, :tbs // 8 + 3], want[n][0][:, :tbs // 8 + 3]), n
+        for b in range(B):
+            if ok[b]:
+                assert np.array_equal(tb[b, :tbs // 8], batches[n][b][1])
+    assert L.srslte_hip_dl_rx_pool_wait(pool, 99) != 0 and L.srslte_hip_dl_rx_pool_submit(pool, None, 0, B, None, d_tb[0].ptr, stride, d_ok[0].ptr, None) < 0
+    L.srslte_hip_dl_rx_pool_destroy(pool)
+    rx.free()
