@@ -41,6 +41,12 @@ def test_no_kernel_uses_scratch_and_decoder_occupancy():
         assert kernels, f
         for k, r in kernels.items():
             total += 1
+            if "tdec_pair_kernel" in k:
+                # the second measured exception: a 184-register budget (the kernel needs 194) leaves room for TWO front-end wavefronts of the other
+                # streams beside two decoder wavefronts on a SIMD and is 2.4 % faster in the pipeline (profiles/r04/ab_tdec_bytes.txt, table 6);
+                # the 20 bytes of scratch sit outside the sweeps. Bounded: spills in the loops would show up as more
+                assert r.get("ScratchSize [bytes/lane]", 0) <= 32 and r["VGPRs"] <= 184, (f, k, r)
+                continue
             if "tdec_ar32_kernel" in k:
                 # the one measured exception: the 8-bit avx8 kernel under a 216-register budget spills around its loops (extraction, exchange and
                 # decision phases keep their state there while the pair-mapped sweeps run) and is 3 % FASTER in the four-stream pipeline than
