@@ -143,7 +143,8 @@ void* host_alloc(size_t n)
 struct DftState {
   DevStage in, out;
   cf_t *   g_in = nullptr, *g_out = nullptr; // guru: caller buffers captured at plan time (dft_fftw.c:137-165)
-  int      how_many = 0, idist = 0, odist = 0;
+  int      how_many = 0, idist = 0, odist = 0, istride = 1, ostride = 1;
+  std::vector<cf_t> pack_in, pack_out; // guru plans with an element stride: contiguous host images of the strided caller buffers
 };
 
 // ---- state behind srslte_ofdm_t.fft_plan.p
@@ -262,10 +263,7 @@ int srslte_dft_plan_guru_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_d
                            int ostride, int how_many, int idist, int odist)
 { // dft_fftw.c:137-165: batched strided transform bound to caller buffers
   if (!plan || !in_buffer || !out_buffer) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (istride != 1 || ostride != 1) {
-    ERROR("guru plans with element stride != 1 are not supported");
-    return SRSLTE_ERROR;
-  }
+  if (istride < 1 || ostride < 1 || how_many < 1) return SRSLTE_ERROR_INVALID_INPUTS;
   FftFactors  f;
   const cf32* tw;
   if (fft_get_plan(dft_points, &f, &tw)) return SRSLTE_ERROR;
@@ -276,6 +274,8 @@ int srslte_dft_plan_guru_c(srslte_dft_plan_t* plan, int dft_points, srslte_dft_d
   st->how_many = how_many;
   st->idist    = idist;
   st->odist    = odist;
+  st->istride  = istride;
+  st->ostride  = ostride;
   plan->p      = st;
   plan->size = plan->init_size = dft_points;
   plan->mode    = SRSLTE_DFT_COMPLEX;
@@ -456,7 +456,27 @@ void srslte_dft_run_guru_c(srslte_dft_plan_t* plan)
     return;
   }
   auto* st = (DftState*)plan->p;
-  dft_exec(plan, st->g_in, st->g_out, st->how_many, st->idist, st->odist);
+  if (st->istride == 1 && st->ostride == 1) {
+    dft_exec(plan, st->g_in, st->g_out, st->how_many, st->idist, st->odist);
+    return;
+  }
+  // fftw_plan_many_dft's general layout: element j of transform i at in[i * idist + j * istride] (and the same with odist / ostride on the
+  // way out). The device kernels read unit-stride rows, so the host side packs the strided caller buffer into rows of N, transforms them as
+  // one batch and scatters the rows back; only the addressed elements of the caller's output are written, as FFTW does.
+  const int    N = plan->size, M = st->how_many;
+  st->pack_in.resize((size_t)N * M);
+  st->pack_out.resize((size_t)N * M);
+  for (int i = 0; i < M; i++) {
+    const cf_t* src = st->g_in + (size_t)i * st->idist;
+    cf_t*       dst = st->pack_in.data() + (size_t)i * N;
+    for (int j = 0; j < N; j++) dst[j] = src[(size_t)j * st->istride];
+  }
+  dft_exec(plan, st->pack_in.data(), st->pack_out.data(), M, N, N);
+  for (int i = 0; i < M; i++) {
+    const cf_t* src = st->pack_out.data() + (size_t)i * N;
+    cf_t*       dst = st->g_out + (size_t)i * st->odist;
+    for (int j = 0; j < N; j++) dst[(size_t)j * st->ostride] = src[j];
+  }
 }
 
 // ====================================================================================================== OFDM

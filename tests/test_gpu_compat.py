@@ -230,6 +230,42 @@ def test_dft_plan_options(N):
     assert L.srslte_dft_plan_c(C.byref(bad), 0, 0) != 0 and L.srslte_dft_plan_c(C.byref(bad), 1 << 20, 0) != 0
 
 
+@pytest.mark.parametrize("N,M,istride,idist,ostride,odist", [(128, 7, 1, 137, 1, 128), (64, 5, 5, 1, 1, 64), (300, 3, 2, 700, 3, 1), (12, 6, 6, 1, 6, 1)])
+def test_dft_guru_plan_layouts(N, M, istride, idist, ostride, odist):
+    """srslte_dft_plan_guru_c / srslte_dft_run_guru_c (dft_fftw.c:137-165,:307-313): fftw_plan_many_dft's layout - element j of transform i at
+    [i * dist + j * stride] - on caller buffers captured at plan time; elements of the output that the layout does not address stay untouched."""
+    L, rng = hip(), np.random.default_rng(N + M)
+    nin, nout = (M - 1) * idist + (N - 1) * istride + 1, (M - 1) * odist + (N - 1) * ostride + 1
+    x = aligned(nin, np.complex64)
+    x[:] = (rng.standard_normal(nin) + 1j * rng.standard_normal(nin)).astype(np.complex64)
+    y = aligned(nout, np.complex64)
+    y[:] = -7.0
+    pl = DftPlan()
+    assert L.srslte_dft_plan_guru_c(C.byref(pl), N, 0, p(x), p(y), istride, ostride, M, idist, odist) == 0 and pl.is_guru
+    L.srslte_dft_run_guru_c(C.byref(pl))
+    touched = np.zeros(nout, bool)
+    for i in range(M):
+        xi, ref = np.ascontiguousarray(x[i * idist:i * idist + (N - 1) * istride + 1:istride]), np.zeros(N, np.complex64)
+        oracle().orc_dft_exact(p(xi), p(ref), N, 1)
+        sl = slice(i * odist, i * odist + (N - 1) * ostride + 1, ostride)
+        assert close(y[sl], ref), i
+        touched[sl] = True
+    assert np.all(y[~touched] == -7.0)
+    # replan on the same buffers to a shorter transform (dft_fftw.c:93-118), backward this time through the plan's direction
+    N2 = N // 2
+    assert L.srslte_dft_replan_guru_c(C.byref(pl), N2, p(x), p(y), istride, ostride, M, idist, odist) == 0 and pl.size == N2
+    L.srslte_dft_run_guru_c(C.byref(pl))
+    xi, ref = np.ascontiguousarray(x[0:(N2 - 1) * istride + 1:istride]), np.zeros(N2, np.complex64)
+    oracle().orc_dft_exact(p(xi), p(ref), N2, 1)
+    assert close(y[0:(N2 - 1) * ostride + 1:ostride], ref)
+    L.srslte_dft_plan_free(C.byref(pl))
+    plain = DftPlan()
+    assert L.srslte_dft_plan_c(C.byref(plain), N, 0) == 0
+    L.srslte_dft_run_guru_c(C.byref(plain))  # "the selected plan is not guru": an error line and no transform
+    L.srslte_dft_plan_free(C.byref(plain))
+    assert L.srslte_dft_plan_guru_c(C.byref(pl), N, 0, p(x), p(y), 0, 1, M, idist, odist) != 0
+
+
 def test_dft_precoding_object():
     L, rng = hip(), np.random.default_rng(3)
     q = opaque(1 << 16)
