@@ -343,7 +343,7 @@ int         srslte_hip_dl_rx_keep_symbols(srslte_hip_dl_rx_t* q, int enable);
 /* ------------------------------------------------------------------ PUSCH receive pipeline (eNB side): OFDM RX with the
  * -1/2 carrier shift (enb_ul.c:58-63) -> chest_ul -> RE extraction + one-tap MMSE -> inverse transform precoding -> soft demap +
  * descramble + UL channel de-interleaver (pusch.c:423-520, sch.c:891-913,:991-1066) -> rate de-matching -> turbo decode -> TB CRC.
- * UL-SCH with optional HARQ-ACK / RI / CQI multiplexing (cfg fields below), one grant per object (optionally hopping between the slots), normal CP,
+ * UL-SCH with optional HARQ-ACK / RI / CQI multiplexing (cfg fields below), one grant per object (optionally hopping between the slots), normal or extended CP (cfg.cp_ext),
  * 16-bit LLRs (pusch.llr_is_8bit has no counterpart here: with it the reference hands int8 LLRs to an int16 channel deinterleaver,
  * pusch.c:481-503 / sch.c:890-918, and fails its own noise-free round trip - tests/test_oracle_vs_ref.py); redundancy versions and soft
  * combining through srslte_hip_ul_rx_batch_harq. */
@@ -371,6 +371,9 @@ typedef struct {
   uint32_t hopping, n_prb_slot1;  /* hopping != 0: intra-subframe hopping, slot 1 at PRB offset n_prb_slot1 (srslte_pusch_grant_t.n_prb[1] /
                                      n_prb_tilde[1]; pusch.c:52-91, chest_ul.c:244-266, refsignal_ul.c:316-346); 0: both slots at n_prb */
   uint32_t max_grants;            /* srslte_hip_ul_rx_batch_grants: PUSCHs (= HARQ slots) per call; 0 = max_batch */
+  int      cp_ext;                /* 1: extended cyclic prefix (srslte_cell_t.cp): 6 symbols per slot, DMRS in symbol 2 of each slot (refsignal_ul.h:43,
+                                     pusch.c:57-60), 10 data symbols (9 shortened; ra_ul.c:234), the UCI column sets of uci.c:502,:527, the DMRS
+                                     cyclic-shift hopping read at a stride of 8 x 6 bits (refsignal_ul.c:127-133); d_iq is [nof_sf][15*N] as before */
 } srslte_hip_ul_rx_cfg_t;
 srslte_hip_ul_rx_t* srslte_hip_ul_rx_create(const srslte_hip_ul_rx_cfg_t* cfg);
 void                srslte_hip_ul_rx_destroy(srslte_hip_ul_rx_t* q);
@@ -440,6 +443,7 @@ typedef struct {
   uint32_t cqi_len, I_offset_cqi; /* as in srslte_hip_ul_rx_cfg_t (srslte_uci_encode_cqi_pusch, sch.c:1133-1150) */
   uint32_t hopping, n_prb_slot1;  /* as in srslte_hip_ul_rx_cfg_t */
   uint32_t max_grants;            /* srslte_hip_ul_tx_batch_grants: PUSCHs per call; 0 = max_batch */
+  int      cp_ext;                /* as in srslte_hip_ul_rx_cfg_t */
 } srslte_hip_ul_tx_cfg_t;
 srslte_hip_ul_tx_t* srslte_hip_ul_tx_create(const srslte_hip_ul_tx_cfg_t* cfg);
 void                srslte_hip_ul_tx_destroy(srslte_hip_ul_tx_t* q);

@@ -228,6 +228,7 @@ typedef struct { /* scalar part of srslte_chest_ul_res_t, chest_ul.h:47-55 */
   float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo;
 } orc_chest_ul_res_t;
 int orc_ul_dmrs_init(orc_ul_dmrs_t* q, uint32_t cell_id);
+int orc_ul_dmrs_init_cp(orc_ul_dmrs_t* q, uint32_t cell_id, uint32_t nsl); /* nsl: 7, or 6 on an extended-CP cell */
 /* r: [2][12*nof_prb] (slot-major); -2 for the tabulated 1- and 2-PRB sequences */
 int orc_ul_dmrs_pusch_gen(const orc_ul_dmrs_t* q, const orc_ul_dmrs_cfg_t* cfg, uint32_t nof_prb, uint32_t sf_idx, uint32_t n_dmrs, orc_cf_t* r);
 /* grid, ce: [14][12*cell_nof_prb]; only the granted PRBs of ce are written, as upstream */
@@ -236,6 +237,9 @@ int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L
 /* the same with a PRB offset per slot (srslte_pusch_grant_t.n_prb[2]: intra-subframe hopping) */
 int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, const orc_cf_t* grid,
                            orc_cf_t* ce, orc_chest_ul_res_t* res);
+/* ... on a cell with nsl symbols per slot (grid, ce: [2 nsl][12*cell_nof_prb]) */
+int orc_chest_ul_pusch_hop_cp(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, uint32_t nsl,
+                              const orc_cf_t* grid, orc_cf_t* ce, orc_chest_ul_res_t* res);
 
 
 /* ---------------------------------------------------------------- HARQ-ACK on the PUSCH (orc_uci.c): 1 or 2 bits, no RI / CQI */

@@ -516,17 +516,21 @@ int orc_chest_dl_mbsfn(const orc_cell_t* cell, uint32_t sf_idx, const orc_chest_
 static const uint32_t N_DMRS_1[8] = {0, 2, 3, 4, 6, 8, 9, 10}; /* 36.211 Table 5.5.2.1.1-2 (refsignal_ul.c:42) */
 static const uint32_t N_DMRS_2[8] = {0, 6, 3, 4, 2, 8, 10, 9}; /* 36.211 Table 5.5.2.1.1-1 (refsignal_ul.c:39) */
 
-int orc_ul_dmrs_init(orc_ul_dmrs_t* q, uint32_t cell_id)
-{ /* srslte_refsignal_ul_set_cell (refsignal_ul.c:206-238), normal CP */
+int orc_ul_dmrs_init(orc_ul_dmrs_t* q, uint32_t cell_id) { return orc_ul_dmrs_init_cp(q, cell_id, 7); }
+
+int orc_ul_dmrs_init_cp(orc_ul_dmrs_t* q, uint32_t cell_id, uint32_t nsl)
+{ /* srslte_refsignal_ul_set_cell (refsignal_ul.c:206-238); nsl = SRSLTE_CP_NSYMB(cell.cp): the cyclic-shift hopping n_PRS reads 8 bits per
+     SC-FDMA symbol of the slot, so the CP sets the stride (:127-133) */
   memset(q, 0, sizeof(*q));
   q->cell_id = cell_id;
   uint8_t c[8 * 7 * 20];
+  if (nsl != 6 && nsl != 7) return -1;
   for (uint32_t ds = 0; ds < 30; ds++) { /* generate_n_prs :118-141 and generate_srslte_sequence_hopping_v :149-163 share the seed */
     uint32_t c_init = ((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30);
-    orc_gold(c_init, 8 * 7 * 20, c);
+    orc_gold(c_init, 8 * nsl * 20, c);
     for (uint32_t ns = 0; ns < 20; ns++) {
       uint32_t n = 0;
-      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * 7 * ns + i] << i;
+      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * nsl * ns + i] << i;
       q->n_prs[ds][ns] = n;
       q->v[ns][ds]     = c[ns];
     }
@@ -662,7 +666,13 @@ int orc_chest_ul_pusch(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L
 
 int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, const orc_cf_t* grid,
                            orc_cf_t* ce, orc_chest_ul_res_t* res)
-{ /* srslte_chest_ul_estimate_pusch (chest_ul.c:268-327) with the defaults of srslte_chest_ul_init (:101-102: 3-tap filter, w = 0.3333),
+{
+  return orc_chest_ul_pusch_hop_cp(r_dmrs, cell_nof_prb, L_prb, n_prb0, n_prb1, 7, grid, ce, res);
+}
+
+int orc_chest_ul_pusch_hop_cp(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32_t L_prb, uint32_t n_prb0, uint32_t n_prb1, uint32_t nsl,
+                              const orc_cf_t* grid, orc_cf_t* ce, orc_chest_ul_res_t* res)
+{ /* nsl = SRSLTE_CP_NSYMB(cell.cp): the DMRS symbol of slot s is SRSLTE_REFSIGNAL_UL_L(s, cp) = (s + 1) nsl - 4 (refsignal_ul.h:43) */ /* srslte_chest_ul_estimate_pusch (chest_ul.c:268-327) with the defaults of srslte_chest_ul_init (:101-102: 3-tap filter, w = 0.3333),
      no linear interpolation (DO_LINEAR_INTERPOLATION is not defined, :244-258): every slot's estimate is copied over that slot at the
      slot's own PRB offset grant.n_prb[s] - intra-subframe hopping works, upstream only prints a complaint (:293-295) */
   const uint32_t n_prbs[2] = {n_prb0, n_prb1};
@@ -672,7 +682,7 @@ int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32
   const float    w = 0.3333f;
   filter[0] = w; filter[2] = w; filter[1] = 1 - 2 * w;
   for (uint32_t s = 0; s < 2; s++) {
-    const uint32_t L = (s + 1) * 7 - 4; /* SRSLTE_REFSIGNAL_UL_L */
+    const uint32_t L = (s + 1) * nsl - 4; /* SRSLTE_REFSIGNAL_UL_L */
     for (uint32_t i = 0; i < nrefs; i++) {
       recv[s * nrefs + i] = grid[L * nre + n_prbs[s] * 12 + i];
       est[s * nrefs + i]  = c_mulconj(recv[s * nrefs + i], r_dmrs[s * nrefs + i]);
@@ -680,11 +690,11 @@ int orc_chest_ul_pusch_hop(const orc_cf_t* r_dmrs, uint32_t cell_nof_prb, uint32
   }
   float power = 0;
   for (uint32_t s = 0; s < 2; s++) {
-    const uint32_t L = (s + 1) * 7 - 4;
+    const uint32_t L = (s + 1) * nsl - 4;
     cf*            dst = &ce[L * nre + n_prbs[s] * 12];
     conv_same_cf(&est[s * nrefs], filter, dst, nrefs, 3);
-    for (uint32_t l = 0; l < 7; l++) {
-      if (s * 7 + l != L) memcpy(&ce[(s * 7 + l) * nre + n_prbs[s] * 12], dst, sizeof(cf) * nrefs);
+    for (uint32_t l = 0; l < nsl; l++) {
+      if (s * nsl + l != L) memcpy(&ce[(s * nsl + l) * nre + n_prbs[s] * 12], dst, sizeof(cf) * nrefs);
     }
     for (uint32_t i = 0; i < nrefs; i++) tmp[i] = c_sub(dst[i], est[s * nrefs + i]); /* srslte_chest_estimate_noise_pilots */
     power += avg_power(tmp, nrefs);

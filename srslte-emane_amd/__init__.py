@@ -432,14 +432,14 @@ class ChestUlRes(C.Structure):
 class ChestUl:
     """srslte_chest_ul_t: init + set_cell + pregen + estimate_pusch (chest_ul.h:78-104), batched over subframes tti0, tti0+1, ..."""
 
-    def __init__(self, cell_id, nof_prb, cyclic_shift=0, delta_ss=0, group_hopping=False, sequence_hopping=False):
+    def __init__(self, cell_id, nof_prb, cyclic_shift=0, delta_ss=0, group_hopping=False, sequence_hopping=False, cp_ext=False):
         self.cfg = DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0)
         lib().srslte_hip_chest_ul_create.restype = C.c_void_p
         lib().srslte_hip_chest_ul_create.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.POINTER(DmrsPuschCfg)]
-        self.h = lib().srslte_hip_chest_ul_create(cell_id, nof_prb, 1, C.byref(self.cfg))
+        self.h = lib().srslte_hip_chest_ul_create(cell_id, nof_prb, 0 if cp_ext else 1, C.byref(self.cfg))
         if not self.h:
             raise RuntimeError("srslte_hip_chest_ul_create failed")
-        self.nof_prb = nof_prb
+        self.nof_prb, self.nof_symb = nof_prb, 12 if cp_ext else 14
 
     def dmrs(self, L_prb, sf_idx, n_dmrs):
         r = np.zeros(2 * 12 * L_prb, np.complex64)
@@ -448,7 +448,7 @@ class ChestUl:
         return rc, r
 
     def estimate_pusch(self, grid, tti0, L_prb, n_prb, n_dmrs, ce_init=None):
-        x = np.ascontiguousarray(grid, np.complex64).reshape(-1, 14 * 12 * self.nof_prb)
+        x = np.ascontiguousarray(grid, np.complex64).reshape(-1, self.nof_symb * 12 * self.nof_prb)
         n = x.shape[0]
         dg = DevBuf.from_host(x)
         dce = DevBuf.from_host(np.zeros_like(x) if ce_init is None else np.ascontiguousarray(ce_init, np.complex64))
@@ -608,7 +608,7 @@ class UlRxCfg(C.Structure):
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int),
                 ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int), ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32),
                 ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32), ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32),
-                ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32)]
+                ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32), ("cp_ext", C.c_int)]
 
 
 class UlGrant(C.Structure):
@@ -629,11 +629,11 @@ class UlRx:
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, cyclic_shift=0, delta_ss=0,
                  group_hopping=False, sequence_hopping=False, mmse=True, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0,
-                 cqi_len=0, I_offset_cqi=0, n_prb_slot1=None, max_grants=0):
+                 cqi_len=0, I_offset_cqi=0, n_prb_slot1=None, max_grants=0, cp_ext=False):
         self.cfg = UlRxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_iterations, max_batch, 1 if mmse else 0,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
                            ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0,
-                           max_grants)
+                           max_grants, 1 if cp_ext else 0)
         L = lib()
         L.srslte_hip_ul_rx_ri.restype = C.c_void_p
         L.srslte_hip_ul_rx_ri.argtypes = [C.c_void_p]
@@ -749,7 +749,8 @@ class UlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32), ("L_prb", C.c_uint32),
                 ("n_prb", C.c_uint32), ("n_dmrs", C.c_uint32), ("max_batch", C.c_uint32), ("dmrs_cfg", DmrsPuschCfg), ("shortened", C.c_int),
                 ("ack_len", C.c_uint32), ("I_offset_ack", C.c_uint32), ("ri_len", C.c_uint32), ("I_offset_ri", C.c_uint32),
-                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32), ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32)]
+                ("cqi_len", C.c_uint32), ("I_offset_cqi", C.c_uint32), ("hopping", C.c_uint32), ("n_prb_slot1", C.c_uint32), ("max_grants", C.c_uint32),
+                ("cp_ext", C.c_int)]
 
 
 class UlTx:
@@ -758,11 +759,11 @@ class UlTx:
 
     def __init__(self, cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch, cyclic_shift=0, delta_ss=0, group_hopping=False,
                  sequence_hopping=False, shortened=False, ack_len=0, I_offset_ack=0, ri_len=0, I_offset_ri=0, cqi_len=0, I_offset_cqi=0,
-                 n_prb_slot1=None, max_grants=0):
+                 n_prb_slot1=None, max_grants=0, cp_ext=False):
         self.cfg = UlTxCfg(cell_id, nof_prb, rnti, mod, tbs, L_prb, n_prb, n_dmrs, max_batch,
                            DmrsPuschCfg(cyclic_shift, delta_ss, 1 if group_hopping else 0, 1 if sequence_hopping else 0), 1 if shortened else 0,
                            ack_len, I_offset_ack, ri_len, I_offset_ri, cqi_len, I_offset_cqi, 0 if n_prb_slot1 is None else 1, n_prb_slot1 or 0,
-                           max_grants)
+                           max_grants, 1 if cp_ext else 0)
         L = lib()
         L.srslte_hip_ul_tx_batch_uci_cqi.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                                      C.c_void_p, C.c_void_p]

@@ -966,12 +966,13 @@ uint32_t largest_prime_below(uint32_t x)
 
 struct ChestUlGeom {
   int   cell_nre, L_prb, n_prb, n_prb1, tti0; // 12 * cell nof_prb; grant: PRB offset of slot 0 and of slot 1 (srslte_pusch_grant_t.n_prb[2])
+  int   nsl;                          // symbols per slot: 7, or 6 with the extended CP (DMRS in symbol nsl - 4 of each slot, refsignal_ul.h:43)
   float w;                            // 3-tap smoothing filter {w, 1-2w, w} (chest_ul.c:101-102)
 };
 struct ChestUlResDev { float noise_estimate, noise_estimate_dbm, snr, snr_db, cfo; };
 
 // One workgroup per subframe (chest_ul.c:268-327): LS estimates at the two DMRS symbols, 3-tap "same" convolution with the
-// edge extrapolation of srslte_conv_same_cf (convolution.c:180-218), the result copied to the 7 symbols of its slot
+// edge extrapolation of srslte_conv_same_cf (convolution.c:180-218), the result copied to the 7 (6: extended CP) symbols of its slot
 // (DO_LINEAR_INTERPOLATION is not defined upstream), noise from the difference smoothed - raw, SNR from the pilot power.
 // d_r: [10][2][12 * L_prb] DMRS of the grant per subframe index.
 // items != null (per-PUSCH grants): workgroup i estimates items[i] - its subframe of the batch, its PRB offsets, its result row - and all
@@ -986,12 +987,12 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
   const int   n_prb0 = items ? items[blockIdx.x].n_prb : g.n_prb, n_prb1 = items ? items[blockIdx.x].n_prb1 : g.n_prb1;
   const int   sf_idx = (g.tti0 + sf) % 10, tid = threadIdx.x, nrefs = 12 * g.L_prb;
   cf32*       est = reinterpret_cast<cf32*>(lds_raw); // [2][nrefs]
-  const cf32* gs  = grid + (size_t)sf * 14 * g.cell_nre;
-  cf32*       cs  = ce ? ce + (size_t)sf * 14 * g.cell_nre : nullptr;
+  const cf32* gs  = grid + (size_t)sf * 2 * g.nsl * g.cell_nre;
+  cf32*       cs  = ce ? ce + (size_t)sf * 2 * g.nsl * g.cell_nre : nullptr;
   const cf32* r   = d_r + (size_t)sf_idx * 2 * nrefs;
   float       pw  = 0.f;
   for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
-    const int  s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
+    const int  s = i / nrefs, k = i - s * nrefs, L = (s + 1) * g.nsl - 4;
     const cf32 y = gs[L * g.cell_nre + (s ? n_prb1 : n_prb0) * 12 + k];
     est[i]       = c_mulconj(y, r[i]);
     pw += y.x * y.x + y.y * y.y;
@@ -1001,7 +1002,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
   const float f0 = g.w, f1 = 1 - 2 * g.w;
   float       npw[2] = {0.f, 0.f};
   for (int i = tid; i < 2 * nrefs; i += CH_THREADS) {
-    const int   s = i / nrefs, k = i - s * nrefs, L = (s + 1) * 7 - 4;
+    const int   s = i / nrefs, k = i - s * nrefs;
     const cf32* e = est + s * nrefs;
     // conv_same with M = 3: out[k] = f0 * in[k-1] + f1 * in[k] + f0 * in[k+1]; at the two ends the missing neighbour is upstream's
     // "extrapolated" value 3 * in[1] - 2 * in[0] resp. 3 * in[N-1] - 2 * in[N-2] (convolution.c:180-218, reproduced as it is)
@@ -1018,11 +1019,10 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
       o = c_add(c_add(c_scale(e[k - 1], f0), c_scale(e[k], f1)), c_scale(e[k + 1], f0));
     }
     if (cs) {
-      for (int l = 0; l < 7; l++) cs[(s * 7 + l) * g.cell_nre + (s ? n_prb1 : n_prb0) * 12 + k] = o;
+      for (int l = 0; l < g.nsl; l++) cs[(s * g.nsl + l) * g.cell_nre + (s ? n_prb1 : n_prb0) * 12 + k] = o;
     }
     const cf32 d = c_sub(o, e[k]);
     npw[s] += d.x * d.x + d.y * d.y;
-    (void)L;
   }
   const float p0 = block_sum(npw[0], red) / (float)nrefs, p1 = block_sum(npw[1], red) / (float)nrefs;
   if (tid == 0 && res) {
@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(CH_THREADS) void chest_ul_kernel(const cf32* __rest
 } // namespace
 
 struct srslte_hip_chest_ul {
-  uint32_t cell_id, nof_prb;
+  uint32_t cell_id, nof_prb, nsl; // nsl: symbols per slot (7, or 6 with the extended CP)
   srslte_hip_dmrs_pusch_cfg_t cfg;
   uint32_t n_prs[30][20], f_gh[20], v[20][30];
   // device DMRS of the grant last used: [10][2][12 * L_prb]
@@ -1053,23 +1053,24 @@ struct srslte_hip_chest_ul {
 
 extern "C" srslte_hip_chest_ul_t* srslte_hip_chest_ul_create(uint32_t cell_id, uint32_t nof_prb, int cp_is_norm, const srslte_hip_dmrs_pusch_cfg_t* cfg)
 { // srslte_chest_ul_init + srslte_chest_ul_set_cell (chest_ul.c:51-194, refsignal_ul.c:206-238) + srslte_chest_ul_pregen
-  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || !cp_is_norm || !cfg || cfg->cyclic_shift >= 8 || cfg->delta_ss >= 30) {
+  if (cell_id > 503 || nof_prb < 6 || nof_prb > 110 || !cfg || cfg->cyclic_shift >= 8 || cfg->delta_ss >= 30) {
     hip_log("[srslte_hip] chest_ul: unsupported cell / DMRS configuration (id=%u prb=%u cp_norm=%d)\n", cell_id, nof_prb, cp_is_norm);
     return nullptr;
   }
   auto* q    = new srslte_hip_chest_ul();
   q->cell_id = cell_id;
   q->nof_prb = nof_prb;
+  q->nsl     = cp_is_norm ? 7 : 6;
   q->cfg     = *cfg;
   q->d_r     = nullptr;
   q->r_L = q->r_n_dmrs = 0xffffffffu;
   q->tables = new std::map<std::pair<uint32_t, uint32_t>, cf32*>();
   std::vector<uint8_t> c;
   for (uint32_t ds = 0; ds < 30; ds++) { // generate_n_prs :118-141 and generate_srslte_sequence_hopping_v :149-163 share the seed
-    gold(((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30), 8 * 7 * 20, c);
+    gold(((cell_id / 30) << 5) + (((cell_id % 30) + ds) % 30), 8 * q->nsl * 20, c); // 8 bits per SC-FDMA symbol: the CP sets the stride
     for (uint32_t ns = 0; ns < 20; ns++) {
       uint32_t n = 0;
-      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * 7 * ns + i] << i;
+      for (int i = 0; i < 8; i++) n += (uint32_t)c[8 * q->nsl * ns + i] << i;
       q->n_prs[ds][ns] = n;
       q->v[ns][ds]     = c[ns];
     }
@@ -1173,14 +1174,14 @@ int chest_ul_estimate_items(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_
   const void* d_tab = nullptr;
   if (int rc = chest_ul_dmrs_table_cached(q, L_prb, n_dmrs, &d_tab)) return rc;
   ChestUlGeom g;
-  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = 0; g.n_prb1 = 0; g.tti0 = (int)tti0; g.w = 0.3333f;
+  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = 0; g.n_prb1 = 0; g.tti0 = (int)tti0; g.w = 0.3333f; g.nsl = (int)q->nsl;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(n_items), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, st, (const cf32*)d_grid, (cf32*)d_ce,
                      (ChestUlResDev*)d_res, (const cf32*)d_tab, g, d_items);
   LAUNCH_CHECK();
   return SRSLTE_SUCCESS;
 }
 
-// d_grid: [nof_sf][14][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
+// d_grid: [nof_sf][14 (12: extended CP)][12 * cell nof_prb]; d_ce: same shape (only the granted PRBs are written, as upstream) or NULL;
 // d_res: [nof_sf] srslte_hip_chest_ul_res_t or NULL. Same grant (L_prb, n_prb in both slots, n_dmrs) for every subframe of the batch.
 extern "C" int srslte_hip_chest_ul_estimate_pusch_batch(srslte_hip_chest_ul_t* q, uint32_t tti0, uint32_t L_prb, uint32_t n_prb, uint32_t n_dmrs,
                                                         const void* d_grid, void* d_ce, void* d_res, int nof_sf, void* stream)
@@ -1202,7 +1203,7 @@ extern "C" int srslte_hip_chest_ul_estimate_pusch_batch_hop(srslte_hip_chest_ul_
   const void* d_r = nullptr;
   if (int rc = chest_ul_dmrs_table(q, L_prb, n_dmrs, &d_r)) return rc;
   ChestUlGeom g;
-  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.n_prb1 = (int)n_prb_slot1; g.tti0 = (int)tti0; g.w = 0.3333f;
+  g.cell_nre = 12 * (int)q->nof_prb; g.L_prb = (int)L_prb; g.n_prb = (int)n_prb; g.n_prb1 = (int)n_prb_slot1; g.tti0 = (int)tti0; g.w = 0.3333f; g.nsl = (int)q->nsl;
   hipLaunchKernelGGL(chest_ul_kernel, dim3(nof_sf), dim3(CH_THREADS), sizeof(cf32) * 2 * 12 * L_prb, (hipStream_t)stream, (const cf32*)d_grid,
                      (cf32*)d_ce, (ChestUlResDev*)d_res, (const cf32*)q->d_r, g, (const ChestUlItem*)nullptr);
   LAUNCH_CHECK();

@@ -757,10 +757,11 @@ def ref_sch_decode(self, e, nbits):
 
 # ------------------------------------------------------------------------------------------------------------------ UL
 class UlConfig:
-    """One PUSCH configuration (the UCI goes in per subframe): normal CP; tbs = 0 is a PUSCH without UL-SCH data (CQI-only, sch.c:943-975)."""
+    """One PUSCH configuration (the UCI goes in per subframe); tbs = 0 is a PUSCH without UL-SCH data (CQI-only, sch.c:943-975); cp_ext: a cell
+    with the extended CP (6 symbols per slot, DMRS in symbol 2 of each slot)."""
 
     def __init__(self, nof_prb, cell_id, mod, tbs, L_prb, n_prb=0, n_dmrs=0, rnti=0x1234, max_iter=6, cyclic_shift=0, delta_ss=0, n_prb_slot1=None,
-                 group_hopping=False, sequence_hopping=False, shortened=False):
+                 group_hopping=False, sequence_hopping=False, shortened=False, cp_ext=False):
         from _libs import OrcUlDmrs, OrcUlDmrsCfg
         self.nof_prb, self.cell_id, self.mod, self.tbs, self.L_prb, self.n_prb, self.n_dmrs = nof_prb, cell_id, mod, tbs, L_prb, n_prb, n_dmrs
         # srslte_pusch_grant_t.n_prb[2] / n_prb_tilde[2]: the PRB offset of each slot (intra-subframe hopping when they differ)
@@ -768,19 +769,21 @@ class UlConfig:
         self.rnti, self.max_iter = rnti, max_iter
         self.Qm = MOD_BITS[mod]
         self.nre = 12 * nof_prb
-        self.grid_len = 14 * self.nre
+        self.cp_ext, self.nsl = cp_ext, 6 if cp_ext else 7
+        self.grid_len = 2 * self.nsl * self.nre
         self.M_sc = 12 * L_prb
-        self.nsymb = 11 if shortened else 12  # data symbols: 2 (7 - 1) - N_srs (pusch.c:52-91,:335-343); the SRS takes the last one
+        self.nsymb = 2 * (self.nsl - 1) - (1 if shortened else 0)  # data symbols: 2 (N_symb - 1) - N_srs (ra_ul.c:234, pusch.c:52-91); the SRS takes the last one
         self.nof_re = self.nsymb * self.M_sc
         self.nbits = self.nof_re * self.Qm
         self.N = oracle().orc_symbol_sz(nof_prb)
         self.sf_len = 15 * self.N
         self.dmrs_cfg = OrcUlDmrsCfg(cyclic_shift, delta_ss, group_hopping, sequence_hopping)
         self.dmrs = OrcUlDmrs()
-        assert oracle().orc_ul_dmrs_init(C.byref(self.dmrs), cell_id) == 0
+        assert oracle().orc_ul_dmrs_init_cp(C.byref(self.dmrs), cell_id, self.nsl) == 0
+        self.dmrs_syms = (self.nsl - 4, 2 * self.nsl - 4)  # SRSLTE_REFSIGNAL_UL_L (refsignal_ul.h:43): 3, 10 / 2, 8
         self.seg = OrcCbsegm()
         assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
-        self.data_syms = [l for l in range(14) if l not in (3, 10)][:self.nsymb]
+        self.data_syms = [l for l in range(2 * self.nsl) if l not in self.dmrs_syms][:self.nsymb]
         # UL channel interleaver without UCI (36.212 5.2.2.8, sch.c:580-598,:891-913): q[(i*R + j)*Qm + k] = g[(j*12 + i)*Qm + k]
         j, i, k = np.meshgrid(np.arange(self.M_sc), np.arange(self.nsymb), np.arange(self.Qm), indexing="ij")
         self.q_of_g = ((i * self.M_sc + j) * self.Qm + k).reshape(-1)  # g index (j, i, k) row-major -> q index
@@ -891,15 +894,15 @@ def make_ul_subframe(cfg, tti, rng, snr_db=None, amp=1.0, gain=1.0 + 0j, data=No
     z = np.zeros_like(d)
     orc.orc_dft_precoding(p(d), p(z), cfg.L_prb, cfg.nsymb, 1, True)
     grid = np.zeros(cfg.grid_len, np.complex64)
-    for n, l in enumerate(cfg.data_syms):  # pusch_cp (pusch.c:52-91): slot l // 7 at its own offset n_prb_tilde[slot]
-        o = l * cfg.nre + 12 * cfg.n_prbs[l // 7]
+    for n, l in enumerate(cfg.data_syms):  # pusch_cp (pusch.c:52-91): slot l // N_symb at its own offset n_prb_tilde[slot]
+        o = l * cfg.nre + 12 * cfg.n_prbs[l // cfg.nsl]
         grid[o:o + cfg.M_sc] = z[n * cfg.M_sc:(n + 1) * cfg.M_sc]
     r = cfg.r_dmrs(sf_idx)
-    for s_, l in enumerate((3, 10)):  # srslte_refsignal_dmrs_pusch_put (refsignal_ul.c:316-330)
+    for s_, l in enumerate(cfg.dmrs_syms):  # srslte_refsignal_dmrs_pusch_put (refsignal_ul.c:316-330)
         o = l * cfg.nre + 12 * cfg.n_prbs[s_]
         grid[o:o + cfg.M_sc] = r[s_ * cfg.M_sc:(s_ + 1) * cfg.M_sc]
     tx = OrcOfdm()
-    orc.orc_ofdm_init(C.byref(tx), cfg.nof_prb, True)
+    orc.orc_ofdm_init(C.byref(tx), cfg.nof_prb, not cfg.cp_ext)
     tx.normalize, tx.freq_shift, tx.freq_shift_f = True, True, 0.5  # ue_ul.c:63-64
     iq = np.zeros(cfg.sf_len, np.complex64)
     orc.orc_ofdm_tx_sf(C.byref(tx), p(grid), p(iq))
@@ -919,13 +922,14 @@ def oracle_ul_rx(cfg, iq, tti, keep=False, O_ack=0, I_offset_ack=0, O_ri=0, I_of
     orc = oracle()
     sf_idx = tti % 10
     rxo = OrcOfdm()
-    orc.orc_ofdm_init(C.byref(rxo), cfg.nof_prb, True)
+    orc.orc_ofdm_init(C.byref(rxo), cfg.nof_prb, not cfg.cp_ext)
     rxo.normalize, rxo.freq_shift, rxo.freq_shift_f = False, True, -0.5
     grid = np.zeros(cfg.grid_len, np.complex64)
     orc.orc_ofdm_rx_sf(C.byref(rxo), p(np.ascontiguousarray(iq, np.complex64)), p(grid))
     ce, res = np.zeros(cfg.grid_len, np.complex64), OrcChestUlRes()
-    assert orc.orc_chest_ul_pusch_hop(p(cfg.r_dmrs(sf_idx)), cfg.nof_prb, cfg.L_prb, cfg.n_prbs[0], cfg.n_prbs[1], p(grid), p(ce), C.byref(res)) == 0
-    sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // 7], l * cfg.nre + 12 * cfg.n_prbs[l // 7] + cfg.M_sc) for l in cfg.data_syms])
+    assert orc.orc_chest_ul_pusch_hop_cp(p(cfg.r_dmrs(sf_idx)), cfg.nof_prb, cfg.L_prb, cfg.n_prbs[0], cfg.n_prbs[1], cfg.nsl, p(grid), p(ce),
+                                         C.byref(res)) == 0
+    sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // cfg.nsl], l * cfg.nre + 12 * cfg.n_prbs[l // cfg.nsl] + cfg.M_sc) for l in cfg.data_syms])
     y, h = np.ascontiguousarray(grid[sel]), np.ascontiguousarray(ce[sel])
     z, d = np.zeros(cfg.nof_re, np.complex64), np.zeros(cfg.nof_re, np.complex64)
     orc.orc_predecoding_single(p(y), p(h), p(z), cfg.nof_re, 1.0, res.noise_estimate)
@@ -981,7 +985,7 @@ class RefUlRx:
         self.cfg, self.aligned = cfg, aligned
         self.chest = opaque(1 << 16)
         assert R.srslte_chest_ul_init(self.chest, cfg.nof_prb) == 0
-        assert R.srslte_chest_ul_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 0, 0, 0, 0)) == 0
+        assert R.srslte_chest_ul_set_cell(self.chest, RefCell(cfg.nof_prb, 1, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)) == 0
         R.srslte_chest_ul_pregen(self.chest, C.byref(cfg.dmrs_cfg))
         self.pcfg = ref_pusch_cfg(cfg.L_prb, cfg.n_prb, cfg.n_dmrs, cfg.n_prbs[1])
         self.res = RefChestUlRes()
@@ -995,9 +999,9 @@ class RefUlRx:
         R.srslte_crc_checksum_byte.restype = C.c_uint32
         R.srslte_cbsegm_cbindex.restype = C.c_int
         self.q = OrcOfdm()
-        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, True)
+        oracle().orc_ofdm_init(C.byref(self.q), cfg.nof_prb, not cfg.cp_ext)
         self.q.normalize, self.q.freq_shift, self.q.freq_shift_f = False, True, -0.5
-        self.sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // 7], l * cfg.nre + 12 * cfg.n_prbs[l // 7] + cfg.M_sc) for l in cfg.data_syms])
+        self.sel = np.concatenate([np.arange(l * cfg.nre + 12 * cfg.n_prbs[l // cfg.nsl], l * cfg.nre + 12 * cfg.n_prbs[l // cfg.nsl] + cfg.M_sc) for l in cfg.data_syms])
 
     def run(self, iq, tti):
         from _libs import ref_ul_sf_cfg

@@ -1203,6 +1203,119 @@ def test_pusch_chain_with_hopping_vs_reference_code(prb, L, n0, n1, mod, tbs, sn
     capfd.readouterr()
 
 
+@pytest.mark.parametrize("cell_id,prb,L,n0,n1", [(1, 6, 2, 0, 4), (77, 25, 10, 12, 12), (301, 100, 48, 2, 50), (150, 50, 50, 0, 0)])
+def test_ul_dmrs_and_chest_ul_extended_cp_vs_ref(cell_id, prb, L, n0, n1, capfd):
+    """An extended-CP cell on the uplink: the cyclic-shift hopping n_PRS is read at a stride of 8 x 6 bits (refsignal_ul.c:127-133), the DMRS sit in
+    symbol 2 of each slot (SRSLTE_REFSIGNAL_UL_L, refsignal_ul.h:43), the estimate is copied over the 6 symbols of its slot (chest_ul.c:244-258)."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg, RefChestUlRes, ref_pusch_cfg, ref_ul_sf_cfg
+    R, rng = ref(), np.random.default_rng(cell_id + prb)
+    cell = RefCell(prb, 1, cell_id, 1, 0, 0, 0)  # SRSLTE_CP_EXT
+    rs = opaque(1 << 16)
+    assert R.srslte_refsignal_ul_init(rs, prb) == 0 and R.srslte_refsignal_ul_set_cell(rs, cell) == 0
+    q = opaque(1 << 16)
+    assert R.srslte_chest_ul_init(q, prb) == 0 and R.srslte_chest_ul_set_cell(q, cell) == 0
+    dcfg = OrcUlDmrsCfg(3, 7, True, False)
+    R.srslte_chest_ul_pregen(q, C.byref(dcfg))
+    o, o7 = OrcUlDmrs(), OrcUlDmrs()
+    assert oracle().orc_ul_dmrs_init_cp(C.byref(o), cell_id, 6) == 0 and oracle().orc_ul_dmrs_init(C.byref(o7), cell_id) == 0
+    nre, n = 12 * prb, 12 * 12 * prb
+    differs = 0
+    for tti, n_dmrs, nz in ((7, 5, 0.05), (12, 1, 0.25), (9, 7, 0.1)):
+        a, r, r7 = aligned(2 * 2 * 12 * L, np.float32), np.zeros(2 * 12 * L, np.complex64), np.zeros(2 * 12 * L, np.complex64)
+        assert R.srslte_refsignal_dmrs_pusch_gen(rs, C.byref(dcfg), L, tti % 10, n_dmrs, p(a)) == 0
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        assert oracle().orc_ul_dmrs_pusch_gen(C.byref(o7), C.byref(dcfg), L, tti % 10, n_dmrs, p(r7)) == 0
+        assert np.abs(a.view(np.complex64) - r).max() <= 2e-6
+        differs += int(np.abs(r - r7).max() > 0.1)
+        grid = (0.5 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        k = np.arange(12 * L)
+        for s_, (sym, npb) in enumerate(((2, n0), (8, n1))):
+            h = ((1.5 - 0.5 * s_ + 0.4 * np.sin(k / 30.0)) * np.exp(1j * (0.4 + s_ + k / 150.0))).astype(np.complex64)
+            grid[sym * nre + 12 * npb: sym * nre + 12 * (npb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grid = acopy((grid + nz * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64).view(np.float32))
+        ce_r, res = aligned(2 * n, np.float32), RefChestUlRes()
+        ce_r[:] = 0
+        res.ce = ce_r.ctypes.data
+        assert R.srslte_chest_ul_estimate_pusch(q, ref_ul_sf_cfg(tti), ref_pusch_cfg(L, n0, n_dmrs, n1), p(grid), C.byref(res)) == 0
+        ce_o, ores = np.zeros(n, np.complex64), OrcChestUlRes()
+        oracle().orc_chest_ul_pusch_hop_cp.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        assert oracle().orc_chest_ul_pusch_hop_cp(p(r), prb, L, n0, n1, 6, p(grid), p(ce_o), C.byref(ores)) == 0
+        av = ce_r.view(np.complex64)
+        assert np.abs(av - ce_o).max() <= 1e-4 * np.abs(av).max()
+        filled = np.zeros(n, bool)
+        for sym in range(12):
+            npb = n0 if sym < 6 else n1
+            filled[sym * nre + 12 * npb: sym * nre + 12 * (npb + L)] = True
+        assert not av[~filled].any() and np.abs(av[filled]).min() > 0
+        for nm in ("noise_estimate", "noise_estimate_dbm", "snr", "snr_db"):
+            x, y = getattr(res, nm), getattr(ores, nm)
+            assert abs(x - y) <= 1e-4 * abs(x) + 1e-6, (nm, x, y)
+    assert differs > 0  # the hopping stride is the CP's: the normal-CP sequences are other sequences
+    R.srslte_chest_ul_free(q)
+    R.srslte_refsignal_ul_free(rs)
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()
+
+
+@pytest.mark.parametrize("prb,L,n0,n1,mod,tbs,snr,short", [(25, 10, 5, 5, 2, 3240, 9.5, False), (100, 48, 50, 1, 3, 24496, 17.0, False), (6, 2, 0, 4, 1, 208, 5.0, True)])
+def test_pusch_chain_extended_cp_vs_reference_code(prb, L, n0, n1, mod, tbs, snr, short, capfd):
+    """The eNB receive chain on an extended-CP cell: 12 symbols per subframe, DMRS in symbols 2 and 8, 10 data symbols (9 shortened, ra_ul.c:234)
+    - reference-code chain and oracle chain on identical IQ give the same transport blocks, CRC flags and pass counts."""
+    rng = np.random.default_rng(990 + prb + L)
+    cfg = UlConfig(prb, 11, mod, tbs, L, n0, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, n_prb_slot1=n1, shortened=short, cp_ext=True)
+    assert cfg.nsymb == (9 if short else 10) and cfg.data_syms[:3] == [0, 1, 3]
+    chain = RefUlRx(cfg)
+    nok = 0
+    for t in (0, 4, 9):
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j))
+        r, o = chain.run(iq, t), oracle_ul_rx(cfg, iq, t)
+        assert r["ok"] == o["ok"] and np.array_equal(r["iters"], o["iters"])
+        if r["ok"]:
+            nok += 1
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+    assert nok > 0
+    C.CDLL(None).fflush(None)
+    capfd.readouterr()
+
+
+@pytest.mark.parametrize("prb,L,mod,tbs,snr,short,O_ri,I_ri,O_ack,I_ack", [(25, 10, 2, 3240, 12.0, False, 1, 9, 2, 9), (6, 6, 1, 808, 6.0, True, 1, 5, 1, 5),
+                                                                          (100, 48, 3, 24496, 19.0, False, 2, 8, 1, 8), (50, 20, 2, 6200, 12.0, True, 0, 0, 2, 10)])
+def test_uci_on_pusch_extended_cp_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, O_ri, I_ri, O_ack, I_ack):
+    """HARQ-ACK and rank indication with grant.nof_symb = 10 / 9: the column sets {1, 2, 6, 7} and {0, 3, 5, 8} of uci.c:502,:527 (chosen by
+    N_pusch_symbs <= 10), against srslte_ulsch_encode / srslte_ulsch_decode."""
+    from lte_sim import RefUlsch, UlConfig, make_ul_subframe, oracle_ul_rx, ul_ri_layout
+    rng = np.random.default_rng(1300 + prb + L + O_ri + O_ack)
+    cfg = UlConfig(prb, 11, mod, tbs, L, (prb - L) // 2, n_dmrs=3, shortened=short, cp_ext=True)
+    chain = RefUlsch(cfg, O_ack, I_ack, O_ri, I_ri)
+    Qp_ri, lut, ri_mask, G = ul_ri_layout(cfg, O_ri, I_ri)
+    n_ok = 0
+    for t, ri, ack in ((2, 1, (1, 0)), (7, 0, (0, 1)), (9, 1, (1, 1))):
+        ack = ack[:O_ack]
+        k = {}
+        iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k, ack=ack, I_offset_ack=I_ack, ri=(ri, 0)[:O_ri], I_offset_ri=I_ri)
+        g_r, q_r = chain.encode(data, ack, ri if O_ri else None)
+        assert np.array_equal(g_r[:G], k["g"]), "UL-SCH bits rate-matched to G = %d" % G
+        c = cfg.scramble(t % 10)
+        ack_pos = k["ack_types"] >= 0
+        q_plain = np.zeros(cfg.nbits, np.uint8)
+        q_plain[~ri_mask] = k["g"][lut[~ri_mask]]
+        sel = ~ri_mask & ~ack_pos
+        assert np.array_equal(q_r[sel], q_plain[sel]), t
+        # the reference leaves the value bits in the ACK / RI positions of q (0 for repetitions and placeholders): same positions as the oracle's
+        vb = np.flatnonzero(k["ack_types"] == 1)
+        assert q_r[vb].all()
+        o = oracle_ul_rx(cfg, iq, t, keep=True, O_ack=O_ack, I_offset_ack=I_ack, O_ri=O_ri, I_offset_ri=I_ri)
+        r = chain.decode(o["q_before_ack"], c)
+        if O_ri:
+            assert r["ri"] == o["ri"][0] == ri, (t, r["ri"], o["ri"])
+        assert np.array_equal(r["ack"][:O_ack], o["ack"][:O_ack]) and np.array_equal(o["ack"][:O_ack], np.array(ack, np.uint8))
+        assert np.array_equal(r["g"][:G], o["g"]) and r["ok"] == o["ok"], t
+        if r["ok"]:
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data)
+        n_ok += r["ok"]
+    assert n_ok > 0
+
+
 @pytest.mark.parametrize("prb,L,n_prb,mod,tbs,snr", [(6, 6, 0, 1, 1000, 3.5), (25, 10, 5, 2, 4008, 9.5), (100, 100, 0, 2, 43816, 12.5), (100, 48, 20, 3, 30576, 17.0)])
 def test_pusch_chain_vs_reference_code(prb, L, n_prb, mod, tbs, snr):
     """eNB PUSCH receive chain: reference-code chain vs oracle chain on identical IQ - same TBs, CRC flags, pass counts."""
