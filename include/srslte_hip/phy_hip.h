@@ -254,6 +254,14 @@ typedef struct {
                                (pdsch.c:124-140, ra_dl.c:446-460, refsignal_dl.c:162-225); uplink subframes of the batch carry tbs = 0. The
                                fixed-grant calls refuse a TDD cell (their three subframe classes are FDD's) */
   uint32_t tdd_sf_config, tdd_ss_config;
+  int      mbsfn;           /* 1: the batch is MBSFN subframes carrying the PMCH of MBSFN area mbsfn_area_id (0-255) - srslte_ofdm_rx_sf on an MBSFN
+                               object with non_mbsfn_region (1 or 2) symbols in front (ofdm.c:424-437), srslte_chest_dl_estimate_cfg with sf_type
+                               MBSFN (chest_dl.c:718-745; chest_cfg.interpolate_subframe is implied, the estimate is undefined without it) and
+                               srslte_pmch_decode (pmch.c:291-394): every PRB from symbol SRSLTE_NOF_CTRL_SYMBOLS(cfi) on, every second RE in the
+                               symbols of the MBSFN reference signal, the area's scrambling sequence (sequences.c:76-80), rv 0. Grids, estimates
+                               and RE lists are [12][12 * nof_prb] whatever the cell's CP (cp_ext: the CRS sequence of symbol 0); single-port
+                               cell, 16-bit LLRs, 1-4 receive antennas; mod / tbs = the PMCH's (srslte_configure_pmch). Fixed-grant calls only */
+  uint32_t mbsfn_area_id, non_mbsfn_region;
 } srslte_hip_dl_rx_cfg_t;
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
@@ -494,6 +502,10 @@ typedef struct {
   int      tdd;            /* as srslte_hip_dl_rx_cfg_t.tdd: TDD cell, per-PDSCH grants only (srslte_hip_dl_tx_batch_grants); special subframes get the
                               CRS symbols of their DwPTS (srslte_refsignal_cs_put_sf, refsignal_dl.c:253-272) and PDSCH there */
   uint32_t tdd_sf_config, tdd_ss_config;
+  int      mbsfn;          /* as srslte_hip_dl_rx_cfg_t.mbsfn: srslte_pmch_encode (pmch.c:423-483) + srslte_refsignal_mbsfn_put_sf (refsignal_dl.c:297-326:
+                              the CRS of symbol 0 and the MBSFN reference signal in symbols 2, 6, 10) + srslte_ofdm_tx_sf on an MBSFN object
+                              (ofdm.c:558-574); single port, rv 0, fixed-grant calls only; rnti is not used */
+  uint32_t mbsfn_area_id, non_mbsfn_region;
 } srslte_hip_dl_tx_cfg_t;
 srslte_hip_dl_tx_t* srslte_hip_dl_tx_create(const srslte_hip_dl_tx_cfg_t* cfg);
 void                srslte_hip_dl_tx_destroy(srslte_hip_dl_tx_t* q);

@@ -197,6 +197,9 @@ int orc_pdsch_cp(const orc_cell_t* cell, uint32_t sf_idx, uint32_t lstart, const
 void orc_scramble_s(int16_t* llr, const uint8_t* c, int len); /* scrambling.c:45-48 */
 void orc_scramble_b(int8_t* llr, const uint8_t* c, int len);  /* scrambling.c:48-51 */
 uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t cell_id); /* 36.211 6.3.1; sequences.c */
+/* PMCH: RE of the 12-symbol MBSFN subframe in mapping order (pmch.c:44-99), returns their number; scrambling seed (sequences.c:76-80) */
+int      orc_pmch_indices(uint32_t nof_prb, uint32_t lstart, uint32_t* idx);
+uint32_t orc_pmch_cinit(uint32_t sf_idx, uint32_t area_id);
 
 typedef struct {
   uint32_t tbs, nof_bits, Qm, rv, max_iter;

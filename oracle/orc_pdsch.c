@@ -116,6 +116,32 @@ uint32_t orc_pdsch_cinit(uint16_t rnti, uint32_t cw, uint32_t sf_idx, uint32_t c
   return ((uint32_t)rnti << 14) + (cw << 13) + (((2 * sf_idx) / 2) << 9) + cell_id;
 }
 
+/* ------------------------------------------------------------------ PMCH in an MBSFN subframe */
+
+int orc_pmch_indices(uint32_t nof_prb, uint32_t lstart, uint32_t* idx)
+{ /* pmch_cp (pmch.c:44-99): every PRB of the 12-symbol (extended-CP) subframe from symbol lstart on; in the symbols that carry the MBSFN
+     reference signal (SRSLTE_SYMBOL_HAS_REF_MBSFN, phy_common.h:145: l = 2 of slot 0, l = 0 and 4 of slot 1) prb_cp_ref with 6 references per
+     PRB (prb_dl.c:45-76) leaves every second RE: the odd sub-carriers, the even ones in symbol 0 of slot 1 (offset 1) */
+  int n = 0;
+  for (uint32_t s = 0; s < 2; s++) {
+    for (uint32_t l = 0; l < 6; l++) {
+      if (s == 0 && l < lstart) continue;
+      const int has_ref = (l == 2 && s == 0) || (l == 0 && s == 1) || (l == 4 && s == 1);
+      const uint32_t keep = (l == 0 && s == 1) ? 0 : 1; /* parity of the sub-carriers that carry data */
+      for (uint32_t k = 0; k < 12 * nof_prb; k++) {
+        if (has_ref && (k & 1) != keep) continue;
+        idx[n++] = (l + 6 * s) * 12 * nof_prb + k;
+      }
+    }
+  }
+  return n;
+}
+
+uint32_t orc_pmch_cinit(uint32_t sf_idx, uint32_t area_id)
+{ /* srslte_sequence_pmch (sequences.c:76-80) called with nslot = 2 * sf_idx (pmch.c:263-275) */
+  return (((2 * sf_idx) / 2) << 9) + area_id;
+}
+
 /* ------------------------------------------------------------------ 2-port transmit diversity (SFBC), SURVEY §8f N4 */
 
 void orc_precoding_diversity2(const orc_cf_t* d, orc_cf_t* y0, orc_cf_t* y1, int nof_symbols, float scaling)

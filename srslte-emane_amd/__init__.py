@@ -43,7 +43,8 @@ class DlRxCfg(C.Structure):
                 ("tbs", C.c_uint32), ("max_iterations", C.c_uint32), ("max_batch", C.c_uint32), ("mmse", C.c_int), ("chest_cfg", ChestDlCfg),
                 ("llr_8bit", C.c_int), ("nof_rx_antennas", C.c_uint32), ("nof_ports", C.c_uint32), ("csi_enable", C.c_int), ("power_scale", C.c_int), ("p_a", C.c_float),
                 ("tx_scheme", C.c_int), ("pmi", C.c_uint32), ("mod2", C.c_int), ("tbs2", C.c_uint32), ("cp_ext", C.c_int),
-                ("tdd", C.c_int), ("tdd_sf_config", C.c_uint32), ("tdd_ss_config", C.c_uint32)]
+                ("tdd", C.c_int), ("tdd_sf_config", C.c_uint32), ("tdd_ss_config", C.c_uint32),
+                ("mbsfn", C.c_int), ("mbsfn_area_id", C.c_uint32), ("non_mbsfn_region", C.c_uint32)]
 
 
 class DlGrant(C.Structure):
@@ -478,12 +479,14 @@ class DlRx:
     """Batched PDSCH receive chain (ue_dl.c:369-384 + pdsch.c:833-997 + sch.c:507-532 for one codeword)."""
 
     def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, mmse=True, chest_cfg=None, llr_8bit=False, nof_rx=1,
-                 nof_ports=1, csi=False, power_scale=False, p_a=0.0, out_ptrs=None, tx_scheme=0, pmi=0, mod2=0, tbs2=0, cp_ext=False, tdd=None):
-        """tx_scheme 3 (large-delay CDD) / 2 (closed-loop multiplexing) with pmi, and mod2 / tbs2 for a second transport block: the two-layer
+                 nof_ports=1, csi=False, power_scale=False, p_a=0.0, out_ptrs=None, tx_scheme=0, pmi=0, mod2=0, tbs2=0, cp_ext=False, tdd=None,
+                 mbsfn=None):
+        """mbsfn = (area id, non-MBSFN region length): a PMCH pipeline (MBSFN subframes; rnti unused).
+        tx_scheme 3 (large-delay CDD) / 2 (closed-loop multiplexing) with pmi, and mod2 / tbs2 for a second transport block: the two-layer
         modes; decode() then returns lists [transport block 0, transport block 1] of tb and ok arrays."""
         self.cfg = DlRxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_iterations, max_batch, 1 if mmse else 0, chest_cfg or ChestDlCfg(),
                            1 if llr_8bit else 0, nof_rx, nof_ports, 1 if csi else 0, 1 if power_scale else 0, p_a, tx_scheme, pmi, mod2, tbs2, 1 if cp_ext else 0,
-                           1 if tdd else 0, tdd[0] if tdd else 0, tdd[1] if tdd else 0)
+                           1 if tdd else 0, tdd[0] if tdd else 0, tdd[1] if tdd else 0, 1 if mbsfn else 0, mbsfn[0] if mbsfn else 0, mbsfn[1] if mbsfn else 0)
         self.nof_rx = nof_rx
         self.h = lib().srslte_hip_dl_rx_create(C.byref(self.cfg))
         if not self.h:
@@ -874,15 +877,16 @@ class UlTx:
 class DlTxCfg(C.Structure):
     _fields_ = [("cell_id", C.c_uint32), ("nof_prb", C.c_uint32), ("cfi", C.c_uint32), ("rnti", C.c_uint16), ("mod", C.c_int), ("tbs", C.c_uint32),
                 ("max_batch", C.c_uint32), ("nof_ports", C.c_uint32), ("p_a", C.c_float), ("max_grants", C.c_uint32), ("cp_ext", C.c_int),
-                ("tdd", C.c_int), ("tdd_sf_config", C.c_uint32), ("tdd_ss_config", C.c_uint32)]
+                ("tdd", C.c_int), ("tdd_sf_config", C.c_uint32), ("tdd_ss_config", C.c_uint32),
+                ("mbsfn", C.c_int), ("mbsfn_area_id", C.c_uint32), ("non_mbsfn_region", C.c_uint32)]
 
 
 class DlTx:
     """Batched PDSCH transmit chain (srslte_pdsch_encode pdsch.c:1059-1185 + CRS + srslte_ofdm_tx_sf, enb_dl.c)."""
 
-    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports=1, p_a=0.0, max_grants=0, cp_ext=False, tdd=None):
+    def __init__(self, cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports=1, p_a=0.0, max_grants=0, cp_ext=False, tdd=None, mbsfn=None):
         self.cfg = DlTxCfg(cell_id, nof_prb, cfi, rnti, mod, tbs, max_batch, nof_ports, p_a, max_grants, 1 if cp_ext else 0,
-                           1 if tdd else 0, tdd[0] if tdd else 0, tdd[1] if tdd else 0)
+                           1 if tdd else 0, tdd[0] if tdd else 0, tdd[1] if tdd else 0, 1 if mbsfn else 0, mbsfn[0] if mbsfn else 0, mbsfn[1] if mbsfn else 0)
         L = lib()
         L.srslte_hip_dl_tx_create.restype = C.c_void_p
         L.srslte_hip_dl_tx_create.argtypes = [C.POINTER(DlTxCfg)]

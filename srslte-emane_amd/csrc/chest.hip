@@ -736,8 +736,64 @@ extern "C" const void* srslte_hip_chest_dl_mbsfn_pilots(const srslte_hip_chest_d
   return q && mbsfn_area_id < 256 ? q->d_mbsfn[mbsfn_area_id] : nullptr;
 }
 
+// fill_res after an MBSFN estimate (chest_dl.c:845-871): only the noise figure is new - get_noise (:747-758), the mean over the antennas of the
+// mean over the ports of the REFS estimates; the other fields keep the last normal subframe's values upstream, zero here (the pipeline reads the
+// noise figure only). noise: [nof_sf][nof_ports][nof_rx]
+__global__ void chest_mbsfn_res_kernel(const float* __restrict__ noise, ChestResDev* __restrict__ res, int nof_sf, int nof_rx, int nof_ports)
+{
+  const int sf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sf >= nof_sf) return;
+  const float* r = noise + (size_t)sf * nof_ports * nof_rx;
+  float        n = 0;
+  for (int a = 0; a < nof_rx; a++) {
+    float m = 0;
+    for (int pt = 0; pt < nof_ports; pt++) m += r[pt * nof_rx + a];
+    n += m / nof_ports;
+  }
+  n /= nof_rx;
+  ChestResDev o = {};
+  o.noise_estimate     = n;
+  o.noise_estimate_dbm = (float)(10 * log10((double)n) + 30);
+  res[sf]              = o;
+}
+
+static int chest_dl_mbsfn_impl(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                               float* d_noise, int nof_sf, int nof_rx, int nsl, void* stream);
+
 extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0,
                                                         const void* d_grid, void* d_ce, float* d_noise, int nof_sf, int nof_rx, void* stream)
+{
+  return chest_dl_mbsfn_impl(q, cfg, tti0, d_grid, d_ce, d_noise, nof_sf, nof_rx, q ? q->nsl : 0, stream);
+}
+
+// The PMCH pipeline's call: grids and estimates of 12 symbols per subframe whatever the cell's CP (nsl = 6), and a result record per subframe
+// whose noise figure is get_noise over the antennas (REFS algorithm; with PSS / EMPTY an MBSFN subframe measures nothing upstream)
+int chest_dl_estimate_mbsfn_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                                 int nof_sf, int nof_rx, int nsl, void* d_res, void* stream)
+{
+  if (!q || !cfg || !d_res || nof_sf < 0 || cfg->noise_alg != 0) {
+    hip_log("[srslte_hip] chest_dl: the MBSFN pipeline needs the REFS noise estimate\n");
+    return SRSLTE_ERROR_INVALID_INPUTS;
+  }
+  if (nof_sf == 0) return SRSLTE_SUCCESS;
+  const size_t need = ((size_t)nof_sf * nof_rx * q->nof_ports * sizeof(float) + sizeof(ChestRaw) - 1) / sizeof(ChestRaw);
+  if (need > q->raw_cap) {
+    if (q->d_raw) (void)hipFree(q->d_raw);
+    q->d_raw = nullptr;
+    q->raw_cap = 0;
+    HIP_TRY(hipMalloc((void**)&q->d_raw, sizeof(ChestRaw) * need));
+    q->raw_cap = need;
+  }
+  float* d_noise = reinterpret_cast<float*>(q->d_raw);
+  if (int rc = chest_dl_mbsfn_impl(q, cfg, tti0, d_grid, d_ce, d_noise, nof_sf, nof_rx, nsl, stream)) return rc;
+  hipLaunchKernelGGL(chest_mbsfn_res_kernel, dim3(ceil_div(nof_sf, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)d_noise, (ChestResDev*)d_res,
+                     nof_sf, nof_rx, q->nof_ports);
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+
+static int chest_dl_mbsfn_impl(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                               float* d_noise, int nof_sf, int nof_rx, int nsl, void* stream)
 {
   if (!q || !cfg || !d_grid || nof_sf < 0 || nof_rx < 1 || nof_rx > 4 || cfg->mbsfn_area_id > 255) return SRSLTE_ERROR_INVALID_INPUTS;
   if (!q->d_mbsfn[cfg->mbsfn_area_id]) {
@@ -761,7 +817,7 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
   p.cell_id = q->cell_id; p.nof_prb = q->nof_prb; p.tti0 = (int)tti0;
   p.noise_alg = cfg->noise_alg; p.filter_type = cfg->filter_type; p.interpolate_subframe = 1;
   p.coef0 = cfg->filter_coef[0]; p.coef1 = cfg->filter_coef[1];
-  p.nof_rx = nof_rx; p.nof_ports = q->nof_ports; p.nsl = q->nsl;
+  p.nof_rx = nof_rx; p.nof_ports = q->nof_ports; p.nsl = nsl;
   hipLaunchKernelGGL(chest_dl_mbsfn_kernel, dim3(nof_sf * nof_rx * q->nof_ports), dim3(CH_THREADS), sizeof(cf32) * 40 * q->nof_prb,
                      (hipStream_t)stream, (const cf32*)d_grid, (cf32*)d_ce, d_noise, (const cf32*)q->d_pilots,
                      (const cf32*)q->d_mbsfn[cfg->mbsfn_area_id], p);

@@ -45,6 +45,9 @@ int chest_dl_set_noise_state(srslte_hip_chest_dl_t* q, const float* noise);
 // without interpolate_subframe, where every symbol of the subframe gets the same row)
 int chest_dl_estimate_batch_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
                                  void* d_res, int nof_sf, int nof_rx, int ce_compact, void* stream);
+// chest.hip: the MBSFN estimate on grids of 2 nsl symbols per subframe with a result record (noise figure) per subframe, for the PMCH pipeline
+int chest_dl_estimate_mbsfn_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
+                                 int nof_sf, int nof_rx, int nsl, void* d_res, void* stream);
 // tdec.hip: let the windowed decoders also emit each block's share of the transport-block CRC syndrome (nullptr: off).
 // d_rem: [C][K] words, x^(tbs+24-1-position in the TB) mod g for the block's payload bits in the decoder's array order, 0 elsewhere
 void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t C, uint32_t* d_syn);

@@ -626,6 +626,220 @@ class RefPdsch:
                 "csi": self._ptr("csi", np.float32, nre), "noise": self.res.noise_estimate}
 
 
+class PmchConfig:
+    """One PMCH configuration (pmch.c): an MBSFN subframe of MBSFN area `area_id` on a single-port cell - 12 extended-CP symbols
+    behind a non-MBSFN region of `non_mbsfn_region` symbols, all PRBs, rv 0, scrambled with the area's sequence. cp_ext is the CELL's
+    cyclic prefix: it only selects the CRS sequence of symbol 0 (N_CP in c_init)."""
+
+    def __init__(self, nof_prb, cell_id, area_id, mod, tbs, cfi=2, non_mbsfn_region=2, max_iter=6, chest=None, nof_rx=1, cp_ext=True):
+        self.nof_prb, self.cell_id, self.area_id, self.mod, self.tbs, self.cfi, self.max_iter = nof_prb, cell_id, area_id, mod, tbs, cfi, max_iter
+        self.non_mbsfn_region, self.nof_rx, self.cp_ext = non_mbsfn_region, nof_rx, bool(cp_ext)
+        self.Qm = MOD_BITS[mod]
+        self.cell = OrcCell(cell_id, nof_prb, 1, not cp_ext, 0, 0, 0)
+        self.nre = 12 * nof_prb
+        self.grid_len = 12 * self.nre
+        self.lstart = cfi + (1 if nof_prb < 10 else 0)  # SRSLTE_NOF_CTRL_SYMBOLS (pmch.c:322)
+        self.N = oracle().orc_symbol_sz(nof_prb)
+        self.sf_len = 15 * self.N
+        self.chest = chest or {"filter_coef": (4.0, 1.0)}
+        self.chest = dict(self.chest, interpolate_subframe=True)  # the MBSFN estimate is only defined with it (chest_dl.c:430-478)
+        self.seg = OrcCbsegm()
+        assert oracle().orc_cbsegm(C.byref(self.seg), tbs) == 0 and self.seg.F == 0
+        idx = np.zeros(self.grid_len, np.uint32)
+        self.idx = idx[:oracle().orc_pmch_indices(nof_prb, self.lstart, p(idx))].copy()
+        self.nof_re, self.nbits = len(self.idx), len(self.idx) * self.Qm
+
+    def orc_chest_cfg(self):
+        return DlConfig.orc_chest_cfg(self)
+
+    def ofdm(self, normalize):
+        q = OrcOfdm()
+        oracle().orc_ofdm_init(C.byref(q), self.nof_prb, False)
+        q.non_mbsfn_region, q.normalize = self.non_mbsfn_region, normalize
+        return q
+
+    def scramble(self, sf_idx):
+        c = np.zeros(self.nbits, np.uint8)
+        orc = oracle()
+        orc.orc_pmch_cinit.restype = C.c_uint32
+        orc.orc_gold(C.c_uint32(orc.orc_pmch_cinit(sf_idx, self.area_id)), self.nbits, p(c))
+        return c
+
+
+def make_pmch_subframe(cfg, tti, rng, snr_db=None, amp=1.0, data=None, keep=None):
+    """eNB side of an MBSFN subframe: srslte_pmch_encode (pmch.c:423-483) + srslte_refsignal_mbsfn_put_sf (enb_dl.c put_mbsfn_base_signals) +
+    srslte_ofdm_tx_sf on an MBSFN OFDM object (ofdm.c:558-574) -> (iq [nof_rx][sf_len] or [sf_len], payload bytes)."""
+    orc = oracle()
+    sf_idx = tti % 10
+    if data is None:
+        data = rng.integers(0, 256, cfg.tbs // 8, dtype=np.uint8)
+    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+    e = np.zeros(cfg.nbits, np.uint8)
+    assert orc.orc_dlsch_encode(C.byref(sch), p(data), p(e)) == 0
+    e ^= cfg.scramble(sf_idx)
+    syms = np.zeros(cfg.nof_re, np.complex64)
+    orc.orc_modulate(cfg.mod, p(e), p(syms), cfg.nbits)
+    grid = np.zeros(cfg.grid_len, np.complex64)
+    grid[cfg.idx] = syms
+    assert orc.orc_mbsfn_put_sf(C.byref(cfg.cell), sf_idx, 0, cfg.area_id, p(grid)) == 0
+    if keep is not None:
+        keep.update(d=syms.copy(), grid=grid.copy(), e=e.copy())
+    q = cfg.ofdm(True)
+    iq = np.zeros(cfg.sf_len, np.complex64)
+    orc.orc_ofdm_tx_sf(C.byref(q), p(grid), p(iq))
+    iq *= np.float32(amp)
+    sigma = 0.0 if snr_db is None else np.sqrt(amp * amp * cfg.nre / cfg.N / 2) * 10 ** (-snr_db / 20)
+
+    def noisy(x):
+        return x if snr_db is None else x + (sigma * (rng.standard_normal(cfg.sf_len) + 1j * rng.standard_normal(cfg.sf_len))).astype(np.complex64)
+
+    if cfg.nof_rx == 1:
+        return noisy(iq).astype(np.complex64), data
+    gains = (1.0, 0.6 * np.exp(1j * 1.0), 0.8 * np.exp(-1j * 2.0), 0.4j)[:cfg.nof_rx]
+    return np.stack([noisy(np.complex64(g) * iq) for g in gains]).astype(np.complex64), data
+
+
+def oracle_pmch_rx(cfg, iq, tti, keep=False):
+    """UE side of an MBSFN subframe: srslte_ofdm_rx_sf on the MBSFN object (ofdm.c:424-437), srslte_chest_dl_estimate_cfg with sf_type MBSFN
+    (chest_dl.c:718-745; noise = the REFS estimate averaged over the antennas, :757-764) and srslte_pmch_decode (pmch.c:291-394)."""
+    orc = oracle()
+    sf_idx, nrx = tti % 10, cfg.nof_rx
+    q = cfg.ofdm(False)
+    grid, ce = np.zeros((nrx, cfg.grid_len), np.complex64), np.zeros((nrx, cfg.grid_len), np.complex64)
+    iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+    ccfg = cfg.orc_chest_cfg()
+    noise = np.zeros(nrx, np.float32)
+    orc.orc_chest_dl_mbsfn.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    for a in range(nrx):
+        orc.orc_ofdm_rx_sf(C.byref(q), p(iq2[a]), p(grid[a]))
+        n_ = C.c_float(0)
+        assert orc.orc_chest_dl_mbsfn(C.byref(cfg.cell), sf_idx, C.byref(ccfg), cfg.area_id, 0, p(grid[a]), p(ce[a]), C.byref(n_)) == 0
+        noise[a] = n_.value
+    n0 = np.float32(0)
+    for a in range(nrx):  # get_noise (chest_dl.c:747-758): float sums in antenna order
+        n0 = np.float32(n0 + noise[a])
+    n0 = np.float32(n0 / np.float32(nrx)) if nrx > 1 else noise[0]
+    d = np.zeros(cfg.nof_re, np.complex64)
+    ys, hs = [np.ascontiguousarray(g[cfg.idx]) for g in grid], [np.ascontiguousarray(c[cfg.idx]) for c in ce]
+    if nrx == 1:
+        orc.orc_predecoding_single(p(ys[0]), p(hs[0]), p(d), cfg.nof_re, 1.0, float(n0))
+    else:
+        yp, hp = (C.c_void_p * nrx)(*[v.ctypes.data for v in ys]), (C.c_void_p * nrx)(*[v.ctypes.data for v in hs])
+        orc.orc_predecoding_single_multi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        orc.orc_predecoding_single_multi(yp, hp, p(d), nrx, cfg.nof_re, 1.0, float(n0))
+    e = np.zeros(cfg.nbits, np.int16)
+    orc.orc_demod_soft_s(cfg.mod, p(d), p(e), cfg.nof_re)
+    orc.orc_scramble_s(p(e), p(cfg.scramble(sf_idx)), cfg.nbits)
+    sch = OrcSchCfg(cfg.tbs, cfg.nbits, cfg.Qm, 0, cfg.max_iter)
+    tb, iters, cbok = np.zeros(cfg.tbs // 8 + 16, np.uint8), np.zeros(cfg.seg.C, np.uint32), np.zeros(cfg.seg.C, np.uint8)
+    rc = orc.orc_dlsch_decode(C.byref(sch), p(e), p(tb), p(iters), p(cbok))
+    out = {"tb": tb[:cfg.tbs // 8 + 3], "ok": rc == 0, "iters": iters, "cb_ok": cbok}
+    if keep:
+        out.update(grid=grid, ce=ce, noise=float(n0), d=d, e=e)
+    return out
+
+
+class RefPmch:
+    """The reference's own srslte_pmch_encode / srslte_pmch_decode (pmch.c:291-483) and its MBSFN channel estimate on the compiled code, with a
+    hand-filled srslte_pmch_cfg_t; only the FFT around them is the oracle's (FFTW is absent). Pins orc_pmch_indices, orc_pmch_cinit and the
+    PMCH chains of make_pmch_subframe / oracle_pmch_rx."""
+
+    def __init__(self, cfg):
+        from _libs import RefCell, RefChestCfg, RefChestRes, RefDlSfCfg, aligned, opaque, ref, ref_layout
+        R = self.R = ref()
+        self.cfg, self.aligned = cfg, aligned
+        L = self.L = ref_layout({"srslte_pmch_t": ["d", "e"], "srslte_pmch_cfg_t": ["pdsch_cfg", "area_id"],
+                                 "srslte_pdsch_cfg_t": ["max_nof_iterations", "softbuffers"],
+                                 "srslte_pdsch_grant_t": ["prb_idx", "nof_prb", "nof_re", "tb", "nof_tb", "nof_layers"],
+                                 "srslte_ra_tb_t": ["mod", "tbs", "rv", "nof_bits", "cw_idx", "enabled"],
+                                 "srslte_softbuffer_rx_t": [], "srslte_softbuffer_tx_t": [], "srslte_pdsch_res_t": ["payload", "crc"]},
+                                ["srslte/phy/phch/pmch.h"])
+        cell = RefCell(cfg.nof_prb, 1, cfg.cell_id, 1 if cfg.cp_ext else 0, 0, 0, 0)
+        self.chest = opaque(1 << 20)
+        assert R.srslte_chest_dl_init(self.chest, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_chest_dl_set_cell(self.chest, cell) == 0
+        R.srslte_chest_dl_set_mbsfn_area_id.argtypes = [C.c_void_p, C.c_uint16]
+        assert R.srslte_chest_dl_set_mbsfn_area_id(self.chest, cfg.area_id) == 0
+        self.rc = RefChestCfg()
+        for k, v in cfg.chest.items():
+            if k == "filter_coef":
+                self.rc.filter_coef[0], self.rc.filter_coef[1] = v
+            else:
+                setattr(self.rc, k, v)
+        self.rc.mbsfn_area_id = cfg.area_id
+        self.res, self.sf = RefChestRes(), RefDlSfCfg()
+        self.sf.sf_type, self.sf.cfi, self.sf.non_mbsfn_region = 1, cfg.cfi, cfg.non_mbsfn_region  # SRSLTE_SF_MBSFN
+        self.glen = 14 * cfg.nre  # the reference's buffers hold a normal-CP subframe's worth; an MBSFN subframe uses the first 12 symbols
+        self.ces = [aligned(2 * self.glen, np.float32) for _ in range(cfg.nof_rx)]
+        for a_, c_ in enumerate(self.ces):
+            self.res.ce[0][a_] = c_.ctypes.data
+        self.q = opaque(L["srslte_pmch_t"] + 64)
+        assert R.srslte_pmch_init(self.q, cfg.nof_prb, cfg.nof_rx) == 0 and R.srslte_pmch_set_cell(self.q, cell) == 0
+        R.srslte_pmch_set_area_id.argtypes = [C.c_void_p, C.c_uint16]
+        assert R.srslte_pmch_set_area_id(self.q, cfg.area_id) == 0
+        self.sb_rx, self.sb_tx = opaque(L["srslte_softbuffer_rx_t"] + 64), opaque(L["srslte_softbuffer_tx_t"] + 64)
+        assert R.srslte_softbuffer_rx_init(self.sb_rx, cfg.nof_prb) == 0 and R.srslte_softbuffer_tx_init(self.sb_tx, cfg.nof_prb) == 0
+        self.pc = np.zeros(L["srslte_pmch_cfg_t"], np.uint8)
+        g = self.pc
+
+        def u32(off, v):
+            g[off:off + 4].view(np.uint32)[0] = v
+        g[L["srslte_pdsch_grant_t.prb_idx"]:L["srslte_pdsch_grant_t.prb_idx"] + 220].reshape(2, 110)[:, :cfg.nof_prb] = 1
+        u32(L["srslte_pdsch_grant_t.nof_prb"], cfg.nof_prb)
+        u32(L["srslte_pdsch_grant_t.nof_re"], cfg.nof_re)
+        u32(L["srslte_pdsch_grant_t.nof_tb"], 1)
+        u32(L["srslte_pdsch_grant_t.nof_layers"], 1)
+        o = L["srslte_pdsch_grant_t.tb"]
+        u32(o + L["srslte_ra_tb_t.mod"], cfg.mod)
+        u32(o + L["srslte_ra_tb_t.tbs"], cfg.tbs)
+        u32(o + L["srslte_ra_tb_t.nof_bits"], cfg.nbits)
+        g[o + L["srslte_ra_tb_t.enabled"]] = 1
+        u32(L["srslte_pdsch_cfg_t.max_nof_iterations"], cfg.max_iter)
+        g[L["srslte_pmch_cfg_t.area_id"]:L["srslte_pmch_cfg_t.area_id"] + 2].view(np.uint16)[0] = cfg.area_id
+        self.sb_off = L["srslte_pdsch_cfg_t.softbuffers"]
+
+    def encode(self, data, tti):
+        """payload -> the resource grid after srslte_pmch_encode (the MBSFN reference signals are not part of it)"""
+        cfg, R = self.cfg, self.R
+        self.sf.tti = tti
+        self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_tx)  # a union of tx[] and rx[] pointers (pdsch_cfg.h:65-68)
+        R.srslte_softbuffer_tx_reset(self.sb_tx)
+        d = np.zeros(cfg.tbs // 8 + 64, np.uint8)
+        d[:cfg.tbs // 8] = data
+        grid = self.aligned(2 * self.glen, np.float32)
+        grid[:] = 0
+        assert R.srslte_pmch_encode(self.q, C.byref(self.sf), p(self.pc), p(d), (C.c_void_p * 4)(grid.ctypes.data, 0, 0, 0)) == 0
+        return grid.view(np.complex64)[:cfg.grid_len].copy()
+
+    def decode(self, iq, tti):
+        cfg, R, L = self.cfg, self.R, self.L
+        nrx = cfg.nof_rx
+        q = cfg.ofdm(False)
+        grids = [self.aligned(2 * self.glen, np.float32) for _ in range(nrx)]
+        iq2 = np.ascontiguousarray(iq, np.complex64).reshape(nrx, cfg.sf_len)
+        for a_ in range(nrx):
+            grids[a_][:] = 0
+            oracle().orc_ofdm_rx_sf(C.byref(q), p(iq2[a_]), p(grids[a_]))
+        self.sf.tti = tti
+        inp = (C.c_void_p * 4)(*([g_.ctypes.data for g_ in grids] + [0] * (4 - nrx)))
+        assert R.srslte_chest_dl_estimate_cfg(self.chest, C.byref(self.sf), C.byref(self.rc), inp, C.byref(self.res)) == 0
+        return self._decode(inp, grids)
+
+    def _decode(self, inp, grids):
+        cfg, R, L = self.cfg, self.R, self.L
+        self.pc[self.sb_off:self.sb_off + 8].view(np.uint64)[0] = C.addressof(self.sb_rx)
+        R.srslte_softbuffer_rx_reset(self.sb_rx)
+        payload = np.zeros(cfg.tbs // 8 + 64, np.uint8)
+        data = np.zeros(2 * L["srslte_pdsch_res_t"], np.uint8)
+        data[:8].view(np.uint64)[0] = payload.ctypes.data
+        assert R.srslte_pmch_decode(self.q, C.byref(self.sf), p(self.pc), C.byref(self.res), inp, p(data)) == 0
+
+        def ptr(name, dtype, count):
+            addr = np.frombuffer(self.q, np.uint64, 1, L["srslte_pmch_t." + name])[0]
+            return np.frombuffer(C.string_at(int(addr), count * np.dtype(dtype).itemsize), dtype).copy()
+        return {"tb": payload[:cfg.tbs // 8 + 3].copy(), "ok": bool(data[L["srslte_pdsch_res_t.crc"]]), "d": ptr("d", np.complex64, cfg.nof_re),
+                "e": ptr("e", np.int16, cfg.nbits), "noise": self.res.noise_estimate, "ce": [c_.view(np.complex64)[:cfg.grid_len].copy() for c_ in self.ces]}
+
+
 class RefPdschTx:
     """The reference's own srslte_pdsch_encode (pdsch.c:1059-1185, eNB object): TB -> DL-SCH coding -> scrambling -> modulation -> layer
     mapping / SFBC precoding -> RE mapping, one resource grid per port (without CRS: srslte_enb_dl_put_base adds them). Pins the

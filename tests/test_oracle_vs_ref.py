@@ -1461,6 +1461,42 @@ def test_ri_on_pusch_vs_reference_ulsch_functions(prb, L, mod, tbs, snr, short, 
     assert n_ok > 0
 
 
+@pytest.mark.parametrize("prb,cell_id,area,mod,tbs,cfi,region,snr,nrx,cp_ext", [(6, 1, 1, 1, 488, 2, 2, 7.0, 1, True), (25, 7, 3, 2, 4584, 2, 2, 12.0, 1, True),
+                                                                                (50, 101, 200, 3, 15264, 1, 1, 19.0, 1, False),
+                                                                                (100, 301, 77, 2, 18336, 2, 2, 11.0, 2, False),
+                                                                                (15, 44, 255, 2, 2216, 1, 1, 12.0, 1, True)])
+def test_pmch_encode_decode_vs_oracle_chain(prb, cell_id, area, mod, tbs, cfi, region, snr, nrx, cp_ext):
+    """The reference's srslte_pmch_encode and srslte_pmch_decode (pmch.c:291-483) with its MBSFN channel estimate against the oracle's PMCH chain
+    (SURVEY §8f N4's pmch_test): the RE mapping of pmch_cp around the MBSFN reference signal, the area's scrambling sequence, the single-port
+    equaliser with the MBSFN noise estimate, LLRs, transport blocks and CRC verdicts on identical time samples."""
+    from lte_sim import PmchConfig, RefPmch, make_pmch_subframe, oracle_pmch_rx
+    rng = np.random.default_rng(3300 + prb + area)
+    cfg = PmchConfig(prb, cell_id, area, mod, tbs, cfi=cfi, non_mbsfn_region=region, nof_rx=nrx, cp_ext=cp_ext)
+    assert cfg.nof_re == ((6 - cfg.lstart) * 12 - (6 if cfg.lstart <= 2 else 0) + 60) * prb  # ra_re_x_prb with sf_type MBSFN (ra_dl.c:50-158)
+    chain = RefPmch(cfg)
+    nok = 0
+    for t in (1, 3, 8, 12):
+        k = {}
+        iq, data = make_pmch_subframe(cfg, t, rng, snr_db=snr, amp=0.1, keep=k)
+        g_ref = chain.encode(data, t)
+        mask = np.zeros(cfg.grid_len, bool)
+        mask[cfg.idx] = True
+        assert np.array_equal(g_ref[mask].view(np.float32), k["d"].view(np.float32)) and not g_ref[~mask].any(), t  # symbols and where they go
+        r, o = chain.decode(iq, t), oracle_pmch_rx(cfg, iq, t, keep=True)
+        for a in range(nrx):
+            assert np.abs(r["ce"][a] - o["ce"][a]).max() <= 1e-4 * np.abs(r["ce"][a]).max(), (t, a)
+        assert abs(r["noise"] - o["noise"]) <= 1e-4 * abs(r["noise"]), t
+        assert np.abs(r["d"] - o["d"]).max() <= 2e-4 * np.abs(r["d"]).max(), t
+        diff = np.abs(r["e"].astype(np.int32) - o["e"].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 2e-3 * diff.size + 1, (t, int(diff.max()), int((diff != 0).sum()))
+        if diff.max() == 0 or (r["ok"] and o["ok"]):
+            assert r["ok"] == o["ok"], t
+        if r["ok"] and o["ok"]:
+            nok += 1
+            assert np.array_equal(r["tb"], o["tb"]) and np.array_equal(r["tb"][:tbs // 8], data), t
+    assert nok >= 2
+
+
 def test_reference_mbsfn_estimate_without_interpolate_subframe_reads_stale_symbols():
     """Fact about the reference, recorded because libsrslte_phy_hip.so REFUSES this call (SRSLTE_ERROR + message): with sf_type MBSFN and
     interpolate_subframe off, chest_dl.c:430-433 interpolates symbol 0 only in frequency, yet the MBSFN time interpolation of :475-479
