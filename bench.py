@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--stream-batch", type=int, default=2048, help="subframes for the isolated large-batch streaming-kernel timings (0 = skip)")
     ap.add_argument("--grants", action="store_true", help="run the same workload through srslte_hip_dl_rx_batch_grants: one grant per subframe "
                     "(here 128 equal full-band MCS-28 grants), RE lists and scrambling sequences made on the device from the grants on every call")
+    ap.add_argument("--no-zero-copy", action="store_true", help="N = 1 writes transport blocks and CRC flags straight into rank 0's pinned host record (d_tb / "
+                    "d_tb_ok of the C-ABI may be device-visible host memory; +2.3 %%, profiles/r04/ab_frontend_priority_zero_copy.txt); with this flag: "
+                    "a device record that a hipMemcpyAsync brings out after every batch, as N > 1 needs for the gather")
     ap.add_argument("--pool", action="store_true", help="submit the batches through srslte_hip_dl_rx_pool_* (ONE submission call per batch from this one host "
                     "thread; the library owns --streams pipeline objects and their streams) instead of round-robining objects here")
     ap.add_argument("--grants-mix", action="store_true", help="the mixed-grant workload (scripts/bench_grants_mix.py): 128 subframes of one cell, a different grant "
@@ -315,7 +318,9 @@ def main():
     nstreams = max(1, args.streams)
     tb_stride = (TBS // 8 + 6 + 15) & ~15
     res_bytes, ok_off = sharding.result_layout(tb_stride, B)
-    t_res = [torch.zeros(res_bytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]  # this rank's record: TBs, then CRC flags
+    zero_copy = (not args.no_zero_copy) and world == 1 and not args.force_dist and not args.grants
+    # this rank's record: TBs, then CRC flags - in HBM, or (--zero-copy) in pinned host memory the kernels write through the same pointer
+    t_res = [(torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() if zero_copy else torch.zeros(res_bytes, dtype=torch.uint8, device=dev)) for _ in range(nstreams)]
     rxs = [pkg.DlRx(ue["cell_id"], NOF_PRB, CFI, ue["rnti"], MOD, TBS, MAX_ITER, B, True, hc, llr_8bit=args.llr8,
                     out_ptrs=(t_res[s].data_ptr(), t_res[s].data_ptr() + ok_off)) for s in range(nstreams)]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
@@ -340,6 +345,8 @@ def main():
     t_gath = [torch.zeros((world, res_bytes), dtype=torch.uint8, device=cdev) for _ in range(nstreams)] if (rank == 0 and use_dist) else None
     h_stage = [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)] if (use_dist and not on_device) else None
     h_out = [torch.zeros((world, res_bytes), dtype=torch.uint8).pin_memory() for _ in range(nstreams)] if rank == 0 else None
+    if zero_copy:
+        h_out = [t.view(1, -1) for t in t_res]
 
     grant_arr = None
     if args.grants:
@@ -350,7 +357,7 @@ def main():
         if isinstance(src, list):  # rotating inputs: step k takes batch k mod n
             src = src[k % len(src)]
         if pool is not None and ev is None and not plain:  # one call per batch; the results go to the pinned host record on the batch's own stream inside the pool
-            t = L.srslte_hip_dl_rx_pool_submit(pool, src.data_ptr(), 0, B, None, t_res[s].data_ptr(), tb_stride, t_res[s].data_ptr() + ok_off, h_out[s][0].data_ptr())
+            t = L.srslte_hip_dl_rx_pool_submit(pool, src.data_ptr(), 0, B, None, t_res[s].data_ptr(), tb_stride, t_res[s].data_ptr() + ok_off, None if zero_copy else h_out[s][0].data_ptr())
             if t < 0:
                 raise RuntimeError("pool submit failed: %d" % t)
             pool_tickets[s] = t
@@ -368,7 +375,9 @@ def main():
             if rc:
                 raise RuntimeError("stage %d failed: %d" % (stage, rc))
         with torch.cuda.stream(tstreams[s]):
-            if not use_dist:
+            if zero_copy:
+                pass  # the record IS host memory
+            elif not use_dist:
                 h_out[s][0].copy_(t_res[s], non_blocking=True)
             elif on_device:  # ONE collective per batch, device tensors, ordered after the batch's kernels on this stream
                 sharding.gather_results(t_res[s], t_gath[s] if rank == 0 else None, dist)
@@ -688,7 +697,9 @@ def main():
                    "siso_passes_histogram_0_to_6": pass_hist,
                    "avg_siso_passes_per_wavefront": round(passes_per_wavefront, 3) if passes_per_wavefront is not None else None,
                    "sharding": "one UE per GPU; one gather of TBs + CRC flags per batch to rank 0 (%s), inside the timed region" % ("RCCL" if on_device else args.backend)
-                   if use_dist else "one UE per GPU; single GPU: results copied to host inside the timed region",
+                   if use_dist else ("one UE per GPU; single GPU: the pipelines write the results into pinned host memory (zero-copy) inside the timed region" if zero_copy
+                                     else "one UE per GPU; single GPU: results copied to host inside the timed region"),
+                   "results_to_host": "zero-copy" if zero_copy else ("gather + copy" if use_dist else "copy"),
                    "entry_point": "srslte_hip_dl_rx_batch_grants (a grant per subframe)" if args.grants else
                    ("srslte_hip_dl_rx_pool_submit (one call per batch, %d objects inside the library)" % nstreams if pool is not None else "srslte_hip_dl_rx_stage x 6 (one fixed grant)"),
                    "input_batches": n_inputs, "input_MB": round(n_inputs * d_iq.numel() * 4 / 1e6, 1),

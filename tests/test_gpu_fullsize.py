@@ -237,3 +237,35 @@ def test_pool_one_call_per_batch(hp):
     assert L.srslte_hip_dl_rx_pool_wait(pool, 99) != 0 and L.srslte_hip_dl_rx_pool_submit(pool, None, 0, B, None, d_tb[0].ptr, stride, d_ok[0].ptr, None) < 0
     L.srslte_hip_dl_rx_pool_destroy(pool)
     rx.free()
+
+
+@pytest.mark.parametrize("prb,mod,tbs,snr,llr8", [(100, 3, 75376, 18.0, False), (25, 2, 4008, 10.0, False), (6, 1, 152, 4.0, False), (100, 3, 75376, 30.0, True)])
+def test_results_straight_into_pinned_host_memory(hp, prb, mod, tbs, snr, llr8):
+    """d_tb / d_tb_ok of the C-ABI may point into device-visible (pinned) host memory: the pipeline's last phase - the decoder itself for blocks of
+    more than 800 bits (tdec_set_tb_direct), tb_asm / tb_crc otherwise - stores the transport blocks and CRC flags there, no copy after the batch
+    (bench.py's N = 1 line, +2.3 %). Same bytes and flags as with a device record, for decodable and undecodable blocks."""
+    import torch
+    from lte_sim import DlConfig, make_subframe
+    B = 8
+    rng = np.random.default_rng(prb + mod)
+    cfg = DlConfig(prb, 5, mod, tbs, llr8=llr8)
+    sub = [make_subframe(cfg, t, rng, snr_db=snr, amp=0.1) for t in range(B)]
+    iq = np.stack([s[0] for s in sub])
+    rx = hp.DlRx(5, prb, 1, 0x1234, mod, tbs, 6, B, True, _chest(hp), llr_8bit=llr8)
+    tb_d, ok_d = rx.decode(iq, 0)
+    stride = rx.tb_stride
+    rec = torch.full((stride * B + B,), 0xA5, dtype=torch.uint8).pin_memory()
+    rx2 = hp.DlRx(5, prb, 1, 0x1234, mod, tbs, 6, B, True, _chest(hp), llr_8bit=llr8, out_ptrs=(rec.data_ptr(), rec.data_ptr() + stride * B))
+    d_iq = hp.DevBuf.from_host(iq)
+    for stage in range(6):
+        assert rx2.stage(stage, d_iq.ptr, 0, B, None) == 0
+    hp.sync()
+    r = rec.numpy()
+    tb_h, ok_h = r[:stride * B].reshape(B, stride), r[stride * B:]
+    assert np.array_equal(ok_h, ok_d) and 0 < int(ok_d.sum())
+    assert np.array_equal(tb_h[:, :tbs // 8 + 3], tb_d[:, :tbs // 8 + 3])
+    for b in range(B):
+        if ok_d[b]:
+            assert np.array_equal(tb_h[b, :tbs // 8], sub[b][1])
+    rx.free()
+    rx2.free()
