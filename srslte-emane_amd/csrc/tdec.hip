@@ -1084,6 +1084,275 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// sse8 (16 windows, 8 bit: 800 < K <= 2048 under the 8-bit API) on the pair mapping: TWO code blocks per wavefront, as tdec_pair_kernel
+// runs the 16-bit blocks - lanes 0-31 sweep block slot 0, lanes 32-63 slot 1, eight window pairs each - with the 8-bit arithmetic of the
+// sweeps' AR template (turbodecoder_win.h:92-173). Everything around the sweeps is tdec_win_body<16, 1>'s, slot after slot: extraction,
+// srslte_vec_sub_bbb's order of operations (saturating in the 32-wide body, wrapping in the scalar tail, vector_simd.c:158-185), the two
+// permutations through LDS, the CRC syndrome of every pass, decisions. A slot whose block has passed its CRC (or that has no block: an odd
+// count, a skipped block) waits in lockstep: its lanes read its partner's first rows over and over and store nothing.
+// ------------------------------------------------------------------------------------------------------------------
+#ifndef TDEC_AR16_PAIR
+#define TDEC_AR16_PAIR 1 // 0: the state-per-lane kernel of rounds 1-3 (tdec_win_kernel<16, 1>), for A/B builds
+#endif
+#ifndef TDEC_AR16_NVGPR
+#define TDEC_AR16_NVGPR 108
+#endif
+#if TDEC_AR16_NVGPR > 0
+#define AR16_NVGPR_ATTR __attribute__((amdgpu_num_vgpr(TDEC_AR16_NVGPR)))
+#else
+#define AR16_NVGPR_ATTR
+#endif
+__global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_kernel(TdecArgs a0, TdecGroups gs)
+{
+  TdecArgs       a  = a0;
+  const uint32_t bx = tdec_enter_group(a, gs);
+  const int      K = (int)a.K, K8 = K / 8, Kp = (int)a.Kp;
+  struct Blk {
+    int  cb, lcb;
+    bool ok; // passed its CRC, or nothing to decode in this slot
+    bool live;
+    uint32_t its;
+    const int16_t* dec;
+  } B[2];
+  for (int s_ = 0; s_ < 2; s_++) {
+    const int lcb = 2 * (int)bx + s_;
+    B[s_].live = lcb < (int)a.nof_cb;
+    B[s_].lcb  = B[s_].live ? lcb : 2 * (int)bx;
+    B[s_].cb   = a.cb_map ? (int)a.cb_map[B[s_].lcb] : B[s_].lcb;
+    if (B[s_].live && a.skip && a.skip[B[s_].cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
+      if (threadIdx.x == 0 && a.iters) a.iters[B[s_].cb] = 0;
+      B[s_].live = false;
+    }
+    B[s_].ok  = !B[s_].live;
+    B[s_].its = a.start_iter;
+    B[s_].dec = nullptr;
+  }
+  if (!B[0].live && !B[1].live) return;
+  const int      lane = threadIdx.x & 63;
+  const PLane    PL   = p_lane<false>();
+  __shared__ __attribute__((aligned(16))) pk_t pool[P_POOL];
+  __shared__ int16_t tl[2][12]; // per slot: [0..2] systematic tail, [3..5] parity-0 tail, [6..8] interleaved systematic tail, [9..11] parity-1 tail
+  int16_t*       perm = reinterpret_cast<int16_t*>(pool);
+  static_assert(2 * P_OVER >= 2048, "permutation buffer must hold one sse8 code block");
+  for (int i = lane; i < P_ARR; i += 64) pool[P_ZERO + i] = 0; // the constant zero metric, outside the permutation overlay
+  PROF_DECL;
+  int2*          ckg = reinterpret_cast<int2*>(a.beta) + (size_t)bx * ((K / 16 / PB + 3) * 64);
+  auto WKA = [&](const Blk& b, int i) { return a.work + (size_t)b.lcb * 7 * Kp + (size_t)i * Kp; }; // 0 syst 1 par0 2 par1 3 app1 4 app2 5 ext1 6 ext2
+  auto XB  = [&](const Blk& b) { return reinterpret_cast<pk_t*>(a.xy + (size_t)b.lcb * a.K) + K / 2; };     // the combined x rows of the slot's block
+
+  // ---- input extraction (turbodecoder_win.h:727-769): int8 LLRs to int16 containers in window order, the 12 tail LLRs to LDS
+  const int tb = a.sb_layout ? 3 * (K + 32) : 3 * K;
+  for (int s_ = 0; s_ < 2; s_++) {
+    if (!B[s_].live) continue;
+    const int8_t* in = reinterpret_cast<const int8_t*>(a.in) + (size_t)B[s_].cb * a.in_stride;
+    int16_t *syst = WKA(B[s_], 0), *par0 = WKA(B[s_], 1), *par1 = WKA(B[s_], 2);
+    if (a.sb_layout) {
+      batched<8>(
+          lane, K, [&](int i) { return I3{in[i], in[K + 32 + i], in[2 * (K + 32) + i]}; },
+          [&](int i, I3 t) {
+            syst[i] = (int16_t)t.a;
+            par0[i] = (int16_t)t.b;
+            par1[i] = (int16_t)t.c;
+          });
+    } else {
+      batched<8>(
+          lane, K, [&](int n) { return I3{in[3 * n], in[3 * n + 1], in[3 * n + 2]}; },
+          [&](int n, I3 t) {
+            const int x = win_pos<16>(n, K);
+            syst[x]     = (int16_t)t.a;
+            par0[x]     = (int16_t)t.b;
+            par1[x]     = (int16_t)t.c;
+          });
+    }
+    if (lane < 3) {
+      tl[s_][lane]     = in[tb + 2 * lane];
+      tl[s_][3 + lane] = in[tb + 2 * lane + 1];
+      tl[s_][6 + lane] = in[tb + 6 + 2 * lane];
+      tl[s_][9 + lane] = in[tb + 6 + 2 * lane + 1];
+    }
+  }
+  if (!B[0].live || !B[1].live) { // the empty slot's lanes read the other slot's tails (their results go nowhere)
+    const int from = B[0].live ? 0 : 1;
+    __syncthreads();
+    if (lane < 12) tl[1 - from][lane] = tl[from][lane];
+  }
+  __syncthreads();
+  PROF(0)
+  const int sat_body = K / 32 * 32; // srslte_vec_sub_bbb: saturating int8 in the 32-wide body, wrapping in the scalar tail
+  auto      vsub8    = [&](int i8, v8s x, v8s y) -> v8s {
+    v8s r;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      const int d = (int)x[e] - (int)y[e];
+      r[e]        = (short)(8 * i8 + e < sat_body ? max(-128, min(127, d)) : (int)(signed char)d);
+    }
+    return r;
+  };
+  constexpr int EWU = TDEC_EWU;
+  // x = sat(a-priori + systematic) in the high bytes, to the slot's scratch rows (the combine pass of win_siso<16, 1>)
+  auto combine = [&](const Blk& b, const int16_t* in, const int16_t* app) {
+    struct Q2 { int4 a, b; };
+    auto hi8 = [](int4 v) { return make_int4((v.x & 0x00FF00FF) << 8, (v.y & 0x00FF00FF) << 8, (v.z & 0x00FF00FF) << 8, (v.w & 0x00FF00FF) << 8); };
+    const int4 *in4 = reinterpret_cast<const int4*>(in), *app4 = reinterpret_cast<const int4*>(app);
+    int4*       X4  = reinterpret_cast<int4*>(XB(b));
+    batched<EWU>(
+        lane, K / 8, [&](int i) { return Q2{hi8(in4[i]), app ? hi8(app4[i]) : make_int4(0, 0, 0, 0)}; },
+        [&](int i, Q2 t) { X4[i] = app ? make_int4(s_add<1>(t.b.x, t.a.x), s_add<1>(t.b.y, t.a.y), s_add<1>(t.b.z, t.a.z), s_add<1>(t.b.w, t.a.w)) : t.a; });
+  };
+  uint32_t n_iter = a.start_iter; // > 0: the work arrays hold the state after that many passes (tdec_set_resume)
+  while (n_iter < a.nof_iter && !(B[0].ok && B[1].ok)) {
+    const bool odd = (n_iter & 1) != 0;
+    for (int s_ = 0; s_ < 2; s_++) {
+      Blk& b = B[s_];
+      if (b.ok) continue;
+      int16_t *syst = WKA(b, 0), *app1 = WKA(b, 3), *app2 = WKA(b, 4), *ext1 = WKA(b, 5);
+      if (!odd) {
+        if (n_iter) {
+          batched<EWU>(
+              lane, K8, [&](int i8) { return V8x3{ld8(app1, i8), ld8(ext1, i8), v8u{}}; },
+              [&](int i8, V8x3 t) { st8(app1, i8, vsub8(i8, t.a, t.b)); });
+          __syncthreads();
+        }
+        combine(b, syst, n_iter ? app1 : nullptr);
+      } else {
+        const bool sub = n_iter > 1; // ext1 -= app1 (srslte_vec_sub) fused with the scatter app2[deinter[i]] = ext1[i] (srslte_vec_lut)
+        batched<EWU>(
+            lane, K8, [&](int i8) { return V8x3{ld8(ext1, i8), sub ? ld8(app1, i8) : v8s{}, ld8u(a.t.deinter, i8)}; },
+            [&](int i8, V8x3 t) {
+              const v8s e = sub ? vsub8(i8, t.a, t.b) : t.a;
+              if (sub) st8(ext1, i8, e);
+#pragma unroll
+              for (int j = 0; j < 8; j++) perm[t.c[j]] = e[j];
+            });
+        __syncthreads();
+        for (int i8 = lane; i8 < K8; i8 += 64) st8(app2, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
+        __syncthreads();
+        combine(b, app2, nullptr);
+      }
+    }
+    __syncthreads();
+    PROF(1)
+    {
+      const Blk& f = B[0].ok ? B[1] : B[0]; // a stopped slot reads valid memory: the running one's rows
+      auto       src = [&](int s_) -> const Blk& { return B[s_].ok ? f : B[s_]; };
+      PSrc       S;
+      S.x0 = XB(src(0)); S.x1 = XB(src(1));
+      S.y0 = reinterpret_cast<const pk_t*>(WKA(src(0), odd ? 2 : 1)); S.y1 = reinterpret_cast<const pk_t*>(WKA(src(1), odd ? 2 : 1));
+      S.dbg = 0; S.dead0 = B[0].ok; S.dead1 = B[1].ok; S.rs = 8;
+      pk_t* out = reinterpret_cast<pk_t*>(WKA(src(PL.h), odd ? 6 : 5)); // a dead slot's lanes store nothing (p_siso: wr)
+      p_siso<1, false>(PL, S, tl[PL.h] + (odd ? 6 : 0), tl[PL.h] + (odd ? 9 : 3), out, pool, ckg, K PROF_PASS);
+    }
+    __syncthreads();
+    n_iter++;
+    for (int s_ = 0; s_ < 2; s_++) {
+      Blk& b = B[s_];
+      if (b.ok) continue;
+      b.its = n_iter;
+      int16_t *app1 = WKA(b, 3), *ext1 = WKA(b, 5), *ext2 = WKA(b, 6);
+      uint32_t syn = 0;
+      if (!odd) {
+        b.dec = ext1;
+        if (a.t.crc_rem) { // sch.c:362-378: CRC over the hard decision of this pass
+          batched<EWU>(
+              lane, K8,
+              [&](int i8) {
+                const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
+                return V8W{ld8(ext1, i8), tp[0], tp[1]};
+              },
+              [&](int i8, V8W t) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) syn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+              });
+        }
+      } else {
+        batched<EWU>(
+            lane, K8, [&](int i8) { return V8x3{ld8(ext2, i8), v8s{}, ld8u(a.t.inter, i8)}; },
+            [&](int i8, V8x3 t) {
+#pragma unroll
+              for (int j = 0; j < 8; j++) perm[t.c[j]] = t.a[j];
+            });
+        __syncthreads();
+        if (a.t.crc_rem) { // the interleaved extrinsic values are this pass's decision metrics: their CRC syndrome is taken on the way out
+          batched<EWU>(
+              lane, K8,
+              [&](int i8) {
+                const v4w* tp = reinterpret_cast<const v4w*>(a.t.crc_rem + 8 * i8);
+                return V8W{*reinterpret_cast<const v8s*>(perm + 8 * i8), tp[0], tp[1]};
+              },
+              [&](int i8, V8W t) {
+                st8(app1, i8, t.a);
+#pragma unroll
+                for (int j = 0; j < 4; j++) syn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+              });
+        } else {
+          for (int i8 = lane; i8 < K8; i8 += 64) st8(app1, i8, *reinterpret_cast<const v8s*>(perm + 8 * i8));
+        }
+        b.dec = app1;
+        __syncthreads(); // perm is free again, app1 written
+      }
+      if (a.t.crc_rem) {
+        for (int o = 32; o > 0; o >>= 1) syn ^= __shfl_xor(syn, o, 64);
+        b.ok = syn == 0;
+      }
+    }
+    __syncthreads();
+    PROF(7)
+  }
+  // ---- hard decision bytes, MSB first, natural bit order (turbodecoder_win.h:771-838), and the block's share of the transport-block
+  //      CRC24A syndrome (sch.c:470-488), slot after slot as tdec_win_body does for its one block
+  for (int s_ = 0; s_ < 2; s_++) {
+    const Blk& b = B[s_];
+    if (!b.live) continue;
+    const int16_t*  dec  = b.dec ? b.dec : WKA(b, (a.start_iter & 1) ? 3 : 5); // resumed at the pass limit: the kept state's decision metrics
+    uint8_t*        o    = a.out + (size_t)b.cb * a.out_stride;
+    uint32_t        tsyn = 0;
+    const uint32_t* tab  = a.tb_rem ? a.tb_rem + (size_t)(b.cb % a.tb_C) * K : nullptr;
+    __syncthreads(); // perm is free again
+    if (tab) {
+      batched<TDEC_EWU>(
+          lane, K8,
+          [&](int i8) {
+            const v4w* tp = reinterpret_cast<const v4w*>(tab + 8 * i8);
+            return V8W{ld8(dec, i8), tp[0], tp[1]};
+          },
+          [&](int i8, V8W t) {
+            *reinterpret_cast<v8s*>(perm + 8 * i8) = t.a;
+#pragma unroll
+            for (int j = 0; j < 4; j++) tsyn ^= (t.a[j] > 0 ? t.t0[j] : 0u) ^ (t.a[4 + j] > 0 ? t.t1[j] : 0u);
+          });
+      for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
+    } else {
+      for (int i8 = lane; i8 < K8; i8 += 64) *reinterpret_cast<v8s*>(perm + 8 * i8) = ld8(dec, i8);
+    }
+    __syncthreads();
+    {
+      const int      Lw    = K / 16;
+      const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw); // n / Lw = (n * magic) >> 32 for n < 2^32 / Lw
+      for (int bb = lane; bb < K8; bb += 64) {
+        int      q = (int)__umulhi((uint32_t)(8 * bb), magic), r = 8 * bb - q * Lw; // natural index n -> array position (n % Lw) * 16 + n / Lw
+        uint32_t byte = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          byte |= (perm[r * 16 + q] > 0 ? 0x80u : 0u) >> j;
+          if (++r == Lw) {
+            r = 0;
+            q++;
+          }
+        }
+        o[bb] = (uint8_t)byte;
+      }
+    }
+    if (lane == 0) {
+      if (a.iters) a.iters[b.cb] = b.its;
+      if (a.crc_ok) a.crc_ok[b.cb] = (b.ok && a.t.crc_rem) ? 1 : 0;
+      if (a.tb_rem) a.tb_syn[b.cb] = tsyn;
+    }
+  }
+  PROF(8)
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
 // ------------------------------------------------------------------------------------------------------------------
 __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
@@ -1469,6 +1738,8 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   static const TdecGroups no_groups = {};
   if (ar8 && W == 32) {
     hipLaunchKernelGGL(tdec_ar32_kernel, dim3(nof_cb), dim3(64), 0, st, a, no_groups);
+  } else if (ar8 && !old_map && TDEC_AR16_PAIR) {
+    hipLaunchKernelGGL(tdec_ar16_kernel, dim3((nof_cb + 1) / 2), dim3(64), 0, st, a, no_groups);
   } else if (ar8) {
     hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(nof_cb), dim3(64), 0, st, a, no_groups);
   } else if (W == 16 && !old_map) {
@@ -1541,7 +1812,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     TdecGroup& d  = p_.gs.g[p_.gs.n++];
     d.K = g.K; d.nof_cb = g.nof_cb; d.first_lcb = total; d.first_wave = p_.waves;
     if (int r = tdec_get_tables(q, g.K, W, g.crc_poly, g.crc_nbits, &d.t)) return r;
-    const uint32_t waves = type == T_PAIR ? (g.nof_cb + 1) / 2 : (type == T_GEN ? (g.nof_cb + 7) / 8 : g.nof_cb);
+    const uint32_t waves = (type == T_PAIR || (type == T_AR16 && TDEC_AR16_PAIR)) ? (g.nof_cb + 1) / 2 : (type == T_GEN ? (g.nof_cb + 7) / 8 : g.nof_cb);
     const uint32_t stride = type == T_PAIR ? (g.K / 16 / PB + 2) * 128 : (type == T_GEN ? (g.K + 4) * 64 : (g.K / (W == 32 ? 16 : W) + 1) * 64);
     p_.waves += waves;
     p_.stride = stride > p_.stride ? stride : p_.stride;
@@ -1576,7 +1847,10 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
       case T_WIN8: hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_GEN: hipLaunchKernelGGL(tdec_gen_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_AR32: hipLaunchKernelGGL(tdec_ar32_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
-      default: hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
+      default:
+        if (TDEC_AR16_PAIR) hipLaunchKernelGGL(tdec_ar16_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs);
+        else hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs);
+        break;
     }
     LAUNCH_CHECK();
   }

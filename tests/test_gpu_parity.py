@@ -696,6 +696,60 @@ def test_tdec_8bit_sb_layout_and_early_stop(hp, K):
     dec.free()
 
 
+def test_tdec_sse8_two_blocks_per_wavefront_every_block_length(hp):
+    """tdec_ar16_kernel - the 8-bit API's 16-window back-end (sse8 numerics, 800 < K <= 2048) with two code blocks per wavefront around the
+    pair-mapped sweeps - on every block length it serves, against the oracle's sse8 restatement: three blocks (an odd count: the last wavefront
+    has an empty slot) at SNRs that make them stop after different numbers of passes (a wavefront's slots stop at different times), rate-dematcher
+    (SB) and plain layouts alternating; bytes of the stopping pass, pass counts and CRC flags of every block."""
+    L = hp.lib()
+    sizes = [K for K in list(range(40, 512, 8)) + list(range(512, 1024, 16)) + list(range(1024, 2048, 32)) + list(range(2048, 6145, 64))
+             if L.srslte_hip_tdec_autoimp_get_subblocks_8bit(K) == 16]
+    assert len(sizes) > 40 and sizes[0] == 816 and sizes[-1] == 2048
+    dec = hp.Tdec(2048, 4)
+    spread = set()
+    for n_, K in enumerate(sizes):
+        rng = np.random.default_rng(K + 1)
+        sb = bool(n_ & 1)
+        n_e = (3 * K * 9 // 10) // 6 * 6
+        w = np.zeros((3, (3 * (K + 32) + 12) if sb else (3 * K + 12)), np.int8)
+        for i in range(3):
+            payload = rng.integers(0, 256, (K - 24) // 8, dtype=np.uint8)
+            crc = oracle().orc_crc_bytes(0x1800063, 24, p(payload), K - 24)
+            bits = np.unpackbits(np.concatenate([payload, np.array([crc >> 16, (crc >> 8) & 255, crc & 255], np.uint8)]))
+            enc = np.zeros(3 * K + 12, np.uint8)
+            oracle().orc_tcod_encode_bits(p(bits), p(enc), K)
+            snr = (6.0, 1.0, -3.0)[(i + n_) % 3]
+            if sb:
+                e = np.zeros(n_e, np.uint8)
+                oracle().orc_rm_turbo_tx_bits(p(enc), p(e), n_e, K, 0)
+                llr = (20 * ((2.0 * e - 1) + 10 ** (-(snr + 1.0) / 20) * rng.standard_normal(n_e))).clip(-128, 127).astype(np.int8)
+                oracle().orc_rm_turbo_rx_8bit(p(llr), p(w[i]), n_e, K, 0, 16)
+            else:
+                w[i] = (20 * ((2.0 * enc - 1) + 10 ** (-(snr - 3.0) / 20) * rng.standard_normal(3 * K + 12))).clip(-128, 127).astype(np.int8)
+        rc, out, iters, ok = dec.run_all(w, K, 6, sb_layout=sb, crc_poly=hp.CRC24B, crc_nbits=K, llr8=True)
+        assert rc == 0
+        for i in range(3):
+            per = np.zeros((6, K // 8), np.uint8)
+            assert oracle().orc_tdec_run_8bit(p(w[i]), sb, K, 6, None, p(per)) == 0
+            n, good = 0, False
+            while n < 6 and not good:
+                good = oracle().orc_crc_bytes(0x1800063, 24, p(per[n]), K) == 0
+                n += 1
+            assert iters[i] == n and bool(ok[i]) == good, (K, i, iters[i], n, ok[i], good)
+            assert np.array_equal(out[i], per[n - 1]), (K, i)
+        spread.update(iters.tolist())
+        # no CRC: a fixed number of passes for every block, two blocks (both slots run to the end together) and one (a lone slot)
+        for cnt, nit in ((2, 3), (1, 2)):
+            rc, out, iters, ok = dec.run_all(w[:cnt], K, nit, sb_layout=sb, llr8=True)
+            assert rc == 0 and (iters == nit).all()
+            for i in range(cnt):
+                per = np.zeros((6, K // 8), np.uint8)
+                assert oracle().orc_tdec_run_8bit(p(w[i]), sb, K, 6, None, p(per)) == 0
+                assert np.array_equal(out[i], per[nit - 1]), (K, i, nit)
+    assert len(spread) >= 4
+    dec.free()
+
+
 def test_tdec_errors(hp):
     dec = hp.Tdec(1024, 4)
     rc, *_ = dec.run_all(np.zeros((1, 3 * 2048 + 12), np.int16), 2048, 1)

@@ -47,6 +47,11 @@ def test_no_kernel_uses_scratch_and_decoder_occupancy():
                 # the 20 bytes of scratch sit outside the sweeps. Bounded: spills in the loops would show up as more
                 assert r.get("ScratchSize [bytes/lane]", 0) <= 32 and r["VGPRs"] <= 184, (f, k, r)
                 continue
+            if "tdec_ar16_kernel" in k:
+                # the sse8 twin of the exception below (two blocks per wavefront around the same sweeps, same 216-register budget): 64 bytes of
+                # scratch outside the sweeps
+                assert r.get("ScratchSize [bytes/lane]", 0) <= 128 and r["VGPRs"] <= 216, (f, k, r)
+                continue
             if "tdec_ar32_kernel" in k:
                 # the one measured exception: the 8-bit avx8 kernel under a 216-register budget spills around its loops (extraction, exchange and
                 # decision phases keep their state there while the pair-mapped sweeps run) and is 3 % FASTER in the four-stream pipeline than
