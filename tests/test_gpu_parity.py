@@ -1971,7 +1971,8 @@ def test_dl_rx_chain_csi_weighting(hp, prb, mod, tbs, nrx, npt, snr, llr8, tti0,
 
 @pytest.mark.parametrize("prb,mod,tbs,nrx,npt,snr,llr8", [(25, 2, 4008, 1, 1, 3.0, False), (100, 3, 75376, 1, 1, 17.2, False), (50, 3, 11448, 1, 2, 8.2, True),
                                                             (100, 3, 75376, 2, 2, 12.0, False), (6, 1, 152, 1, 1, -6.0, False), (100, 2, 43816, 1, 2, 7.5, False),
-                                                            (50, 3, 30576, 1, 4, 12.5, False)])
+                                                            (50, 3, 30576, 1, 4, 12.5, False),
+                                                            (15, 2, 1544, 1, 1, -2.5, True), (25, 1, 1800, 1, 1, -4.5, True)])  # K = 1568 / 1824, 8 bit: the two-block sse8 kernel with skipped blocks
 def test_dl_rx_harq(hp, prb, mod, tbs, nrx, npt, snr, llr8):
     """HARQ on the device (srslte_hip_dl_rx_batch_harq): four slots, each its own transport block, sent with rv 0, 2, 3, 1 in different
     subframes with fresh noise; soft buffers, per-block CRC flags and bytes persist in the object. Per transmission and slot: CRC
