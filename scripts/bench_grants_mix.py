@@ -143,11 +143,12 @@ def main(args):
     nstreams, n_inputs = max(1, args.streams), max(1, args.inputs)
     tb_stride = (tbs_max // 8 + 6 + 15) & ~15
     res_bytes, ok_off = sharding.result_layout(tb_stride, B)
-    t_res = [torch.zeros(res_bytes, dtype=torch.uint8, device=dev) for _ in range(nstreams)]
+    zero_copy = not getattr(args, "no_zero_copy", False)  # the pipelines store into the pinned host record itself (bench.py --no-zero-copy: a device record + a copy)
+    t_res = [(torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() if zero_copy else torch.zeros(res_bytes, dtype=torch.uint8, device=dev)) for _ in range(nstreams)]
     rxs = [pkg.DlRx(CELL_ID, NOF_PRB, CFI, RNTI, 3, tbs_max, MAX_ITER, B, True, hc, out_ptrs=(t_res[s].data_ptr(), t_res[s].data_ptr() + ok_off)) for s in range(nstreams)]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     streams = [t.cuda_stream for t in tstreams]
-    h_out = [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)]
+    h_out = t_res if zero_copy else [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)]
     grants = (pkg.DlGrant * B)(*[pkg.DlGrant.make(NOF_PRB, s["cfg"].mod, s["cfg"].tbs, RNTI, cfi=CFI, prb_mask=s["cfg"].prb_mask) for s in sub])
     d_iq = torch.from_numpy(iq_host.view(np.float32)).to(dev)
     d_clean = torch.from_numpy(np.stack([s["clean"] for s in sub]).view(np.float32)).to(dev)
@@ -162,8 +163,9 @@ def main(args):
         rc = L.srslte_hip_dl_rx_batch_grants(rxs[s].h, src.data_ptr(), 0, B, grants, rxs[s].d_tb.ptr, rxs[s].tb_stride, rxs[s].d_ok.ptr, streams[s])
         if rc:
             raise RuntimeError("dl_rx_batch_grants failed: %d" % rc)
-        with torch.cuda.stream(tstreams[s]):
-            h_out[s].copy_(t_res[s], non_blocking=True)
+        if not zero_copy:
+            with torch.cuda.stream(tstreams[s]):
+                h_out[s].copy_(t_res[s], non_blocking=True)
 
     def repeats(min_s):
         ts, k0 = [], 0
@@ -245,7 +247,7 @@ def main(args):
                    "block_lengths": [k for k, _ in ks], "decoder_launches_per_step": len({sg.K1 for sg in segs}),
                    "code_blocks_per_step": blocks // n_inputs, "avg_siso_passes_per_cb": round(passes_sum / max(blocks, 1), 3),
                    "bler": round(1 - good / (B * n_inputs), 4), "undetected_errors": wrong, "streams": nstreams,
-                   "pipeline_instances_verified": nstreams if agree else 0, "results_on_host_verified": bool(host_ok), "input_batches": n_inputs,
+                   "pipeline_instances_verified": nstreams if agree else 0, "results_on_host_verified": bool(host_ok), "results_to_host": "zero-copy" if zero_copy else "copy", "input_batches": n_inputs,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(B * args.steps / max(times), 1),
                    "repeat_max_value": round(B * args.steps / min(times), 1)},
         "roofline": {"kernel": "tdec_pair_kernel / tdec_win_kernel<8, 0> / tdec_gen_kernel (one launch per block length)", "bound": "valu",

@@ -771,7 +771,8 @@ extern "C" int srslte_hip_chest_dl_estimate_mbsfn_batch(srslte_hip_chest_dl_t* q
 int chest_dl_estimate_mbsfn_rows(srslte_hip_chest_dl_t* q, const srslte_hip_chest_dl_cfg_t* cfg, uint32_t tti0, const void* d_grid, void* d_ce,
                                  int nof_sf, int nof_rx, int nsl, void* d_res, void* stream)
 {
-  if (!q || !cfg || !d_res || nof_sf < 0 || cfg->noise_alg != 0) {
+  if (!q || !cfg || !d_res || nof_sf < 0) return SRSLTE_ERROR_INVALID_INPUTS;
+  if (cfg->noise_alg != 0) { // with PSS / EMPTY an MBSFN subframe measures nothing (they are never subframe 0 or 5): the equaliser would get a stale figure
     hip_log("[srslte_hip] chest_dl: the MBSFN pipeline needs the REFS noise estimate\n");
     return SRSLTE_ERROR_INVALID_INPUTS;
   }
