@@ -1355,6 +1355,11 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_
 // ------------------------------------------------------------------------------------------------------------------
 // Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
 // ------------------------------------------------------------------------------------------------------------------
+// The two recursions are chains of K + 3 / K dependent steps; what a step NEEDS from memory (systematic, a-priori and parity value of its
+// index, and the beta row in the alpha pass) does not depend on the chain. GEN_CH steps' worth is requested at once, ahead of the
+// steps that use it: a step per load round trip (230 cycles, the round-2 form) becomes twelve (profiles/r04/ab_gen_prefetch.txt). The
+// arithmetic of every step is unchanged.
+constexpr int GEN_CH = 12; // multiple of 3 (trellis phases) and of 4 (normalisation period)
 __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, const int16_t* __restrict__ app,
                          const int16_t* __restrict__ par, int16_t* __restrict__ out, pk_t* __restrict__ beta, int K, bool active)
 {
@@ -1370,7 +1375,8 @@ __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
   // beta (:54-110): known end state after the 3 tail steps
   v                        = pk_make(L.p == 0 ? 0 : -TD_INF, 0);
   beta[end * 64 + L.lane] = v;
-  for (int k = end - 1, ph = (end - 1) % 3; k >= 0; k--, ph = ph ? ph - 1 : 2) {
+  int k = end - 1;
+  for (int ph = k % 3; (k + 1) % GEN_CH != 0; k--, ph = ph ? ph - 1 : 2) { // the steps above the last multiple of GEN_CH: the tail among them
     int xi = in[k];
     if (app && k < K) xi += app[k];
     const pk_t x = pk_make(xi, 0), y = pk_make(par[k], 0), xy = pk_add<SAT>(x, y);
@@ -1378,20 +1384,56 @@ __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
     beta[k * 64 + L.lane] = v;
     if ((k & 3) == 0 && k < K) v = pk_sub<SAT>(v, bcast_slot0(v));
   }
+  for (; k >= 0; k -= GEN_CH) { // k = GEN_CH - 1 (mod GEN_CH): phases 2, 1, 0, ..., normalisation where (k - i) % 4 == 0
+    int xs[GEN_CH], as[GEN_CH], ys[GEN_CH];
+#pragma unroll
+    for (int i = 0; i < GEN_CH; i++) {
+      xs[i] = in[k - i];
+      as[i] = app ? app[k - i] : 0;
+      ys[i] = par[k - i];
+    }
+#pragma unroll
+    for (int i = 0; i < GEN_CH; i++) {
+      const int  kk = k - i;
+      const int  xi = xs[i] + ((app && kk < K) ? as[i] : 0);
+      const pk_t x = pk_make(xi, 0), y = pk_make(ys[i], 0), xy = pk_add<SAT>(x, y);
+      if (i % 3 == 0) v = acs<2, SAT>(L, v, x, y, xy, &to, &tp);
+      else if (i % 3 == 1) v = acs<1, SAT>(L, v, x, y, xy, &to, &tp);
+      else v = acs<0, SAT>(L, v, x, y, xy, &to, &tp);
+      beta[kk * 64 + L.lane] = v;
+      if ((GEN_CH - 1 - i) % 4 == 0 && kk < K) v = pk_sub<SAT>(v, bcast_slot0(v));
+    }
+  }
   __syncthreads();
   // alpha (:112-194)
   v = pk_make(L.p == 0 ? 0 : -TD_INF, 0);
-  for (int k = 1, ph = 0; k < K + 1; k++, ph = ph == 2 ? 0 : ph + 1) {
-    int xi = in[k - 1];
-    if (app) xi += app[k - 1];
-    const pk_t x = pk_make(xi, 0), y = pk_make(par[k - 1], 0), xy = pk_add<SAT>(x, y);
-    const pk_t B = beta[k * 64 + L.lane];
+  auto alpha_step = [&](int kk, int ph, int xi, int yv, pk_t B) {
+    const pk_t x = pk_make(xi, 0), y = pk_make(yv, 0), xy = pk_add<SAT>(x, y);
     ACS(ph);
     const bool b0 = ph == 0 ? L.p1 : (ph == 1 ? L.p2 : L.p0);
     pk_t       m0 = group_max(pk_add<SAT>(B, b0 ? tp : to));
     pk_t       m1 = group_max(pk_add<SAT>(B, b0 ? to : tp));
-    if ((k & 3) == 0) v = pk_sub<SAT>(v, bcast_slot0(v));
-    if (L.p == 0 && active) out[k - 1] = (int16_t)pk_lo(pk_sub<SAT>(m1, m0));
+    if ((kk & 3) == 0) v = pk_sub<SAT>(v, bcast_slot0(v));
+    if (L.p == 0 && active) out[kk - 1] = (int16_t)pk_lo(pk_sub<SAT>(m1, m0));
+  };
+  k = 1;
+  for (; k + GEN_CH <= K + 1; k += GEN_CH) { // k = 1 (mod GEN_CH): phases 0, 1, 2, ..., normalisation where (1 + i) % 4 == 0
+    int  xs[GEN_CH], as[GEN_CH], ys[GEN_CH];
+    pk_t Bs[GEN_CH];
+#pragma unroll
+    for (int i = 0; i < GEN_CH; i++) {
+      xs[i] = in[k - 1 + i];
+      as[i] = app ? app[k - 1 + i] : 0;
+      ys[i] = par[k - 1 + i];
+      Bs[i] = beta[(k + i) * 64 + L.lane];
+    }
+#pragma unroll
+    for (int i = 0; i < GEN_CH; i++) alpha_step(k + i, i % 3, xs[i] + as[i], ys[i], Bs[i]);
+  }
+  for (int ph = (k - 1) % 3; k < K + 1; k++, ph = ph == 2 ? 0 : ph + 1) {
+    int xi = in[k - 1];
+    if (app) xi += app[k - 1];
+    alpha_step(k, ph, xi, par[k - 1], beta[k * 64 + L.lane]);
   }
 #undef ACS
 }
