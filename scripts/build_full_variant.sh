@@ -7,7 +7,7 @@ mkdir -p ../../gpurun_ab
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
   d=/tmp/fullvar_$name; rm -rf $d; mkdir -p $d
-  for f in fft.hip demod.hip chest.hip tdec.hip tcod.hip pdsch.hip api.cpp fec_tables.cpp compat.cpp compat_refsignal.cpp; do
+  for f in fft.hip demod.hip chest.hip tdec.hip tdec_mix.hip tcod.hip pdsch.hip api.cpp fec_tables.cpp compat.cpp compat_refsignal.cpp; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wno-unused-function -I../../include -I. $flags -x hip -c $f -o $d/${f%.*}.o &
   done
   wait

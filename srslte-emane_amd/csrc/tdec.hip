@@ -252,7 +252,9 @@ struct TdecGroups {
   uint32_t  n; // 0: a launch of one length, described by TdecArgs alone
   uint32_t  xy_stride;
   TdecGroup g[TDEC_MAX_GROUPS];
+  uint8_t   kind[TDEC_MAX_GROUPS]; // tdec_mix_kernel only (behind everything the other kernels read): which decoder the group's blocks take
 };
+enum { TDEC_KIND_PAIR = 0, TDEC_KIND_WIN8 = 1, TDEC_KIND_GEN = 2 };
 // Returns this wavefront's index within its group and makes `a` describe that group alone: its length and tables, its share of the block map,
 // of the work arrays (7 Kp per launched block), of the combine rows and of the checkpoint / beta rows (beta_stride per wavefront).
 __device__ __forceinline__ uint32_t tdec_enter_group(TdecArgs& a, const TdecGroups& gs)
@@ -826,6 +828,7 @@ __device__ __forceinline__ void pair_siso_ar32(const PLane& PL, int lane, const 
 #endif
 #define TDEC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(TDEC_WAVES, TDEC_WAVES)))
 // AR = 1: int8 LLRs in (a.in is an int8 array), the work arrays hold int8 values in int16 containers
+#ifndef TDEC_MIX_TU
 template <int W, int AR>
 __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGroups& gs);
 template <int W, int AR>
@@ -833,6 +836,7 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
 {
   tdec_win_body<W, AR>(a0, gs);
 }
+#endif
 // the avx8 back-end with the pair-mapped sweeps has its own register budget (see tdec_pair.inc on the 216-register rule)
 #ifndef TDEC_AR32_NVGPR
 #define TDEC_AR32_NVGPR 108
@@ -842,12 +846,24 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR void tdec_win_kernel(TdecArgs a
 #else
 #define AR32_NVGPR_ATTR
 #endif
+#ifndef TDEC_MIX_TU
 __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR32_NVGPR_ATTR void tdec_ar32_kernel(TdecArgs a0, TdecGroups gs) { tdec_win_body<32, 1>(a0, gs); }
+#endif
+#ifdef TDEC_MIX_TU
+// tdec_mix.hip: the body for a wavefront of a mixed launch - `a` already describes its group, pool / tl are the mixed kernel's LDS, laid out for
+// blocks of at most WIN_MAX_K bits (AUTO gives the 8-window decoder K <= 800 only: 6 checkpoint rows instead of 34)
+constexpr int WIN_MAX_K = 800;
+template <int W, int AR>
+__device__ __forceinline__ void tdec_win_body(TdecArgs& a, const uint32_t bx, pk_t* pool, int16_t* tl)
+{
+#else
+constexpr int WIN_MAX_K = SRSLTE_HIP_MAX_K;
 template <int W, int AR>
 __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGroups& gs)
 {
   TdecArgs       a  = a0;
   const uint32_t bx = tdec_enter_group(a, gs);
+#endif
   using in_t = typename std::conditional<AR != 0, int8_t, int16_t>::type;
   const int      lcb = (int)bx, cb = a.cb_map ? (int)a.cb_map[lcb] : lcb, K = (int)a.K;
   if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
@@ -860,16 +876,18 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
   int16_t *syst = wk, *par0 = wk + a.Kp, *par1 = wk + 2 * a.Kp, *app1 = wk + 3 * a.Kp, *app2 = wk + 4 * a.Kp, *ext1 = wk + 5 * a.Kp,
           *ext2 = wk + 6 * a.Kp;
   // beta checkpoints (lane-private columns): ceil(Lw / CKPT) + 1 rows per half; Lw <= MAX_K / W (two halves for W = 32)
-  constexpr int BETA_ROWS = (W == 32 ? 2 : 1) * (SRSLTE_HIP_MAX_K / W / CKPT + 2);
+  constexpr int BETA_ROWS = (W == 32 ? 2 : 1) * (WIN_MAX_K / W / CKPT + 2);
   // One LDS pool: beta checkpoints | beta metrics of the segment being consumed | branch-metric staging (Stage). Between SISO
   // passes the front of it (everything but the staging area's constant zero region) doubles as the buffer in which the
   // interleaver permutations are done: a 2-byte scatter costs the L1 one cache line per lane (64 cycles per wavefront
   // instruction), an LDS scatter a few bank-conflict cycles.
   constexpr int POOL_BETA = BETA_ROWS * 64, POOL_SEG = (CKPT + 1) * 64;
+#ifndef TDEC_MIX_TU
   __shared__ __attribute__((aligned(16))) pk_t pool[POOL_BETA + POOL_SEG + ST_TOTAL];
+#endif
   pk_t *                                       beta = pool, *seg = pool + POOL_BETA, *mt = pool + POOL_BETA + POOL_SEG;
   int16_t*                                     perm = reinterpret_cast<int16_t*>(pool);
-  static_assert(2 * (POOL_BETA + POOL_SEG + 2 * ST_BUF) >= SRSLTE_HIP_MAX_K, "permutation buffer must hold one code block");
+  static_assert(2 * (POOL_BETA + POOL_SEG + 2 * ST_BUF) >= WIN_MAX_K, "permutation buffer must hold one code block");
   constexpr bool  PAIR32 = W == 32 && AR && TDEC_AR32_PAIR; // the sweeps of tdec_pair.inc; this kernel keeps extraction, exchange, CRC and decisions
   Stage st;
   if constexpr (!PAIR32) stage_init(st, mt, L);
@@ -885,7 +903,9 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
   // ---- input extraction (turbodecoder_win.h:727-769 / turbodecoder_iter.h:58-68,84-91). The 12 tail LLRs go to LDS. A 16-bit
   //      SB-layout buffer already is three window-ordered arrays: like upstream (turbodecoder_iter.h:84-91) the decoder then
   //      reads systematic and parity LLRs in place instead of copying them.
+#ifndef TDEC_MIX_TU
   __shared__ int16_t tl[12]; // [0..2] systematic tail, [3..5] parity-0 tail, [6..8] interleaved systematic tail, [9..11] parity-1 tail
+#endif
   const int  tb      = a.sb_layout ? 3 * (K + 32) : 3 * K;
   const bool inplace = !AR && a.sb_layout && ((reinterpret_cast<uintptr_t>(in) | (a.in_stride * sizeof(int16_t))) & 15) == 0;
   const int16_t *syst_r = syst, *par0_r = par0, *par1_r = par1;
@@ -1102,6 +1122,7 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
 #else
 #define AR16_NVGPR_ATTR
 #endif
+#ifndef TDEC_MIX_TU
 __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_kernel(TdecArgs a0, TdecGroups gs)
 {
   TdecArgs       a  = a0;
@@ -1352,6 +1373,8 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_
 }
 
 
+#endif // !TDEC_MIX_TU
+
 // ------------------------------------------------------------------------------------------------------------------
 // Generic decoder (turbodecoder_gen.c:54-233): 8 code blocks per wave (group g = block slot), low half only, wrapping
 // ------------------------------------------------------------------------------------------------------------------
@@ -1438,10 +1461,15 @@ __device__ void gen_siso(const LaneGeom& L, const int16_t* __restrict__ in, cons
 #undef ACS
 }
 
+#ifdef TDEC_MIX_TU
+__device__ __forceinline__ void tdec_gen_body(TdecArgs& a, const uint32_t bx)
+{
+#else
 __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a0, TdecGroups gs)
 {
   TdecArgs       a  = a0;
   const uint32_t bx = tdec_enter_group(a, gs);
+#endif
   const LaneGeom L      = lane_geom();
   const int      K      = (int)a.K;
   const uint32_t cb_raw = bx * 8 + L.g;
@@ -1534,6 +1562,43 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a0, TdecGroups gs
   if (L.p == 0 && skipped && a.iters) a.iters[cb] = 0;
 }
 
+#ifdef TDEC_MIX_TU
+// ------------------------------------------------------------------------------------------------------------------
+// A ragged batch (tdec_run_groups) in ONE launch: its groups of equal block length may be of different KINDS - the two-blocks-per-wavefront
+// decoder (K > 800), the 8-window one (400 < K <= 800), the unwindowed one (K <= 400). Launched one kind after the other on the batch's stream
+// they were a chain: the short-block launches are a few wavefronts each and as long as their longest recursion (unwindowed 127 us, 8-window
+// 59 us behind the 376 us of the long blocks in the mixed-grant workload). Here every wavefront looks up its group, reads its kind and runs
+// that decoder's body; the LDS pool is laid out for the larger need (pair sweeps / the 8-window body with the checkpoint rows of K <= 800).
+// Register budget and occupancy: the pair kernel's. Mixed-grant line 622 k -> 791 k subframes/s (profiles/r04/ab_mix_kernel.txt).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int MIX_WIN8_POOL = (WIN_MAX_K / 8 / CKPT + 2) * 64 + (CKPT + 1) * 64 + ST_TOTAL;
+constexpr int MIX_POOL      = MIX_WIN8_POOL > P_POOL ? MIX_WIN8_POOL : P_POOL;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TDEC_PAIR_MINW, TDEC_PAIR_WAVES))) P_NVGPR_ATTR void tdec_mix_kernel(TdecArgs a0, TdecGroups gs)
+{
+  TdecArgs       a = a0;
+  uint32_t       gi = 0;
+  for (uint32_t i = 1; i < gs.n; i++) gi = blockIdx.x >= gs.g[i].first_wave ? i : gi;
+  const uint32_t kind = gs.kind[gi];
+  const uint32_t bx   = tdec_enter_group(a, gs);
+  __shared__ __attribute__((aligned(16))) pk_t pool[MIX_POOL];
+  __shared__ int16_t tl[2][12];
+  a.sb_layout = kind != TDEC_KIND_GEN; // the unwindowed decoder reads the plain [s p0 p1] layout, the windowed ones the rate de-matcher's
+  if (kind == TDEC_KIND_PAIR) tdec_pair_body(a, bx, pool, tl);
+  else if (kind == TDEC_KIND_WIN8) tdec_win_body<8, 0>(a, bx, pool, tl[0]);
+  else tdec_gen_body(a, bx);
+}
+} // namespace
+// called by tdec_run_groups (tdec.hip); args / groups: that unit's TdecArgs / TdecGroups (the same definitions)
+int tdec_mix_launch(const void* args, const void* groups, unsigned waves, hipStream_t st)
+{
+  hipLaunchKernelGGL(tdec_mix_kernel, dim3(waves), dim3(64), 0, st, *static_cast<const TdecArgs*>(args), *static_cast<const TdecGroups*>(groups));
+  LAUNCH_CHECK();
+  return SRSLTE_SUCCESS;
+}
+#else // !TDEC_MIX_TU: the rest of this file
+} // namespace
+int tdec_mix_launch(const void* args, const void* groups, unsigned waves, hipStream_t st); // tdec_mix.hip
+namespace {
 // int8 -> int16 widening for the 8-bit API's 16-bit fall-backs (convert_8_to_16, turbodecoder.c:451-456)
 __global__ void widen_kernel(const int8_t* __restrict__ in, int16_t* __restrict__ out, size_t n)
 {
@@ -1834,7 +1899,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
   static const TdecGroups none = {};
   Plan     plan[T_N];
   for (auto& p_ : plan) { p_.gs = none; p_.waves = p_.stride = p_.blocks = 0; p_.widened = false; }
-  uint32_t total = 0;
+  uint32_t total = 0, kinds = 0; // kinds: bit per 16-bit kind present
   bool     any_widen = false;
   for (uint32_t i = 0; i < nof_groups; i++) {
     const srslte_hip_tdec_group_t& g = groups[i];
@@ -1850,7 +1915,10 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     if (out_stride < g.K / 8 || in_stride < srslte_hip_tdec_input_len(g.K, W != 0) || (g.crc_poly && (g.crc_nbits > g.K || (g.crc_poly >> 24) != 1)) ||
         (type == T_GEN && g.K + 4 > q->max_long_cb / 8 + 2))
       return SRSLTE_ERROR_INVALID_INPUTS;
-    Plan&      p_ = plan[type];
+    // the 16-bit kinds (pair, 8-window, unwindowed - for 8-bit LLRs the widened fall-backs) go into ONE plan, slot T_PAIR, each group with its kind
+    const bool mixable = type == T_PAIR || type == T_WIN8 || type == T_GEN;
+    Plan&      p_ = plan[mixable ? T_PAIR : type];
+    p_.gs.kind[p_.gs.n] = (uint8_t)(type == T_WIN8 ? TDEC_KIND_WIN8 : (type == T_GEN ? TDEC_KIND_GEN : TDEC_KIND_PAIR));
     TdecGroup& d  = p_.gs.g[p_.gs.n++];
     d.K = g.K; d.nof_cb = g.nof_cb; d.first_lcb = total; d.first_wave = p_.waves;
     if (int r = tdec_get_tables(q, g.K, W, g.crc_poly, g.crc_nbits, &d.t)) return r;
@@ -1860,6 +1928,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     p_.stride = stride > p_.stride ? stride : p_.stride;
     p_.blocks += g.nof_cb;
     p_.widened = llr8 && !ar8;
+    if (mixable) kinds |= 1u << type;
     any_widen = any_widen || p_.widened;
     total += g.nof_cb;
   }
@@ -1877,21 +1946,26 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     Plan& p_ = plan[type];
     if (!p_.gs.n) continue;
     p_.gs.xy_stride = q->max_long_cb;
+    // slot T_PAIR: one kind -> that kind's own kernel, several -> the mixed launch (tdec_mix.hip)
+    const int run = type != T_PAIR ? type : (kinds == (1u << T_PAIR) ? T_PAIR : (kinds == (1u << T_WIN8) ? T_WIN8 : (kinds == (1u << T_GEN) ? T_GEN : T_N)));
     TdecArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = p_.widened ? q->d_conv : (const int16_t*)d_input_any; a.in_stride = in_stride; a.sb_layout = type != T_GEN; a.nof_iter = nof_iterations;
+    a.in = p_.widened ? q->d_conv : (const int16_t*)d_input_any; a.in_stride = in_stride; a.sb_layout = run != T_GEN; a.nof_iter = nof_iterations;
     a.K = p_.gs.g[0].K; a.nof_cb = p_.gs.g[0].nof_cb; a.t = p_.gs.g[0].t; // replaced per wavefront (tdec_enter_group)
     a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy; a.zeros = q->d_zeros; a.beta_stride = p_.stride;
     a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok; a.tb_C = 1;
     a.skip = q->skip; a.cb_map = q->cb_map;
-    switch (type) {
+    switch (run) {
       case T_PAIR: hipLaunchKernelGGL(tdec_pair_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_WIN8: hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_GEN: hipLaunchKernelGGL(tdec_gen_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_AR32: hipLaunchKernelGGL(tdec_ar32_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
-      default:
+      case T_AR16:
         if (TDEC_AR16_PAIR) hipLaunchKernelGGL(tdec_ar16_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs);
         else hipLaunchKernelGGL((tdec_win_kernel<16, 1>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs);
+        break;
+      default: // the mixed launch sets sb_layout per kind itself
+        if (int r = tdec_mix_launch(&a, &p_.gs, p_.waves, st)) return r;
         break;
     }
     LAUNCH_CHECK();
@@ -1925,3 +1999,4 @@ extern "C" int srslte_hip_tdec_run_batch_manual(srslte_hip_tdec_t* q, const int1
   return tdec_run_batch_w(q, d_input, 0, in_stride, sb_layout, long_cb, (int)nof_subblocks, nof_cb, nof_iterations, crc_poly, crc_nbits,
                           d_output, out_stride, d_iters, d_crc_ok, (hipStream_t)stream);
 }
+#endif // TDEC_MIX_TU
