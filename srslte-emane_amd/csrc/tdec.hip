@@ -823,6 +823,22 @@ __device__ __forceinline__ void pair_siso_ar32(const PLane& PL, int lane, const 
   p_siso<1, true>(PL, S, tail_in, tail_par, reinterpret_cast<pk_t*>(out), pool, ckg, K PROF_PASS);
 }
 
+// A block's contribution to its transport block's verdict (sch.c:470-488) and, from the last block to arrive, the verdict: tdec_pair_kernel's
+// protocol (tdec_pair.inc, end of finish): agent-scope atomics at the memory side, the count last, after the two contributions have come back.
+__device__ __forceinline__ void tdec_tb_fold(const TdecArgs& a, int tbi, int tbr, uint32_t tsyn, bool ok, bool par_nz)
+{
+  uint32_t*      acc = a.tb_acc + 4 * (size_t)tbi;
+  const uint32_t o1  = atomicXor(acc, tsyn);
+  const uint32_t o2  = atomicOr(acc + 1, (ok ? 0u : 1u) | ((tbr == (int)a.tb_C - 1 && par_nz) ? 2u : 0u));
+  uint32_t       dep = o1 | o2;
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(dep)::"memory");
+  if (atomicAdd(acc + 2, 1u) == a.tb_C - 1) {
+    const uint32_t syn = atomicExch(acc, 0u), fl = atomicExch(acc + 1, 0u);
+    atomicExch(acc + 2, 0u); // clean for the next launch
+    a.tb_ok_out[tbi] = (syn == 0 && fl == 2u) ? 1 : 0;
+  }
+}
+
 #ifndef TDEC_WAVES
 #define TDEC_WAVES 2
 #endif
@@ -1072,6 +1088,12 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
     for (int i8 = L.lane; i8 < K8; i8 += 64) *reinterpret_cast<v8s*>(perm + 8 * i8) = ld8(dec, i8);
   }
   __syncthreads();
+  // transport-block assembly by the decoder itself (tdec_set_tb_direct, as tdec_pair_kernel's last phase; sch.c:360,:401-410,:470-488): block r of
+  // transport block cb / C owns bytes [r rb, r rb + rb) of it, the last block also leaves its own CRC behind the TB's
+  const int tbr = (int)(cb % a.tb_C), tbi = (int)(cb / a.tb_C), rb = (int)a.tb_rb;
+  uint8_t*  tbo = a.tb_out ? a.tb_out + (size_t)tbi * a.tb_out_stride + (size_t)tbr * rb : nullptr;
+  const int tlim = tbr == (int)a.tb_C - 1 ? K8 : rb;
+  bool      par_nz = false; // the TB's CRC24A bytes, the last three of the last block's rb: not all zero (sch.c:481)
   {
     const int      Lw    = K / W;
     const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw); // n / Lw = (n * magic) >> 32 for n < 2^32 / Lw
@@ -1087,10 +1109,14 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
         }
       }
       o[b] = (uint8_t)byte;
+      if (tbo && b < tlim) tbo[b] = (uint8_t)byte;
+      par_nz = par_nz || (b >= rb - 3 && b < rb && byte != 0);
     }
   }
+  if (tbo) par_nz = __ballot(par_nz) != 0;
   PROF(8)
   if (L.lane == 0) {
+    if (tbo) tdec_tb_fold(a, tbi, tbr, tsyn, ok, par_nz);
     if (a.iters) a.iters[cb] = n_iter;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
     if (a.tb_rem) a.tb_syn[cb] = tsyn;
@@ -1346,6 +1372,10 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_
       for (int i8 = lane; i8 < K8; i8 += 64) *reinterpret_cast<v8s*>(perm + 8 * i8) = ld8(dec, i8);
     }
     __syncthreads();
+    const int tbr = (int)(b.cb % a.tb_C), tbi = (int)(b.cb / a.tb_C), rb = (int)a.tb_rb; // transport-block assembly, as tdec_win_body
+    uint8_t*  tbo = a.tb_out ? a.tb_out + (size_t)tbi * a.tb_out_stride + (size_t)tbr * rb : nullptr;
+    const int tlim = tbr == (int)a.tb_C - 1 ? K8 : rb;
+    bool      par_nz = false;
     {
       const int      Lw    = K / 16;
       const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw); // n / Lw = (n * magic) >> 32 for n < 2^32 / Lw
@@ -1361,9 +1391,13 @@ __global__ __launch_bounds__(64) TDEC_WAVES_ATTR AR16_NVGPR_ATTR void tdec_ar16_
           }
         }
         o[bb] = (uint8_t)byte;
+        if (tbo && bb < tlim) tbo[bb] = (uint8_t)byte;
+        par_nz = par_nz || (bb >= rb - 3 && bb < rb && byte != 0);
       }
     }
+    if (tbo) par_nz = __ballot(par_nz) != 0;
     if (lane == 0) {
+      if (tbo) tdec_tb_fold(a, tbi, tbr, tsyn, b.ok && a.t.crc_rem, par_nz);
       if (a.iters) a.iters[b.cb] = b.its;
       if (a.crc_ok) a.crc_ok[b.cb] = (b.ok && a.t.crc_rem) ? 1 : 0;
       if (a.tb_rem) a.tb_syn[b.cb] = tsyn;
@@ -1829,8 +1863,8 @@ int tdec_run_batch_w(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, ui
   q->start_iter = 0;
   a.tb_out = nullptr; a.tb_out_stride = 0; a.tb_rb = 0; a.tb_ok_out = nullptr; a.tb_acc = q->d_tb_acc;
   if (q->tb_out) { // consumed by this run, whichever kernel it takes
-    const bool pair = !llr8 && W == 16 && !old_map;
-    if (!pair || !a.tb_rem || a.skip || a.cb_map || nof_cb % a.tb_C || a.start_iter) return SRSLTE_ERROR_INVALID_INPUTS;
+    const bool direct = llr8 ? ar8 : (W == 16 && !old_map); // the kernels whose last phase assembles: pair, avx8 (tdec_win_body), sse8
+    if (!direct || !a.tb_rem || a.skip || a.cb_map || nof_cb % a.tb_C || a.start_iter) return SRSLTE_ERROR_INVALID_INPUTS;
     a.tb_out = q->tb_out; a.tb_out_stride = q->tb_out_stride; a.tb_rb = q->tb_rb; a.tb_ok_out = q->tb_ok_out;
     q->tb_out = nullptr;
   }
