@@ -329,7 +329,87 @@ def chest_mbsfn():
     print("chest_mbsfn.npz", os.path.getsize(os.path.join(OUT, "chest_mbsfn.npz")), "bytes")
 
 
+def pmch():
+    """The reference's srslte_pmch_encode (the PMCH's RE of the MBSFN grid) and srslte_pmch_decode with its MBSFN estimate (noise figure, equalised
+    symbols, LLRs, transport block, CRC verdict) on time samples made by the oracle's generator (tests/lte_sim.make_pmch_subframe). 12-symbol grids."""
+    from lte_sim import PMCH_GOLDEN_CHEST as PMCH_CHEST, PmchConfig, RefPmch, make_pmch_subframe
+    rng, out = np.random.default_rng(2026100501), {}
+    for tag, (prb, cid, area, mod, tbs, cfi, region, snr, cp_ext, ttis) in {"a": (6, 1, 1, 1, 488, 2, 2, 8.0, True, (1, 8)), "b": (15, 44, 255, 2, 2216, 1, 1, 13.0, False, (3,)),
+                                                                           "c": (25, 7, 3, 3, 6200, 2, 2, 20.0, False, (12,))}.items():
+        # "b": the applications' smoothing filter (triangle 0.1); the others the Gauss filter of phy_dl_test (upstream warns and computes)
+        cfg = PmchConfig(prb, cid, area, mod, tbs, cfi=cfi, non_mbsfn_region=region, cp_ext=cp_ext, chest=PMCH_CHEST[tag])
+        chain = RefPmch(cfg)
+        out[tag + "_meta"] = np.array([prb, cid, area, mod, tbs, cfi, region, 1 if cp_ext else 0], np.int32)
+        out[tag + "_ttis"] = np.array(ttis, np.int32)
+        for t in ttis:
+            iq, data = make_pmch_subframe(cfg, t, rng, snr_db=snr, amp=0.1)
+            g = chain.encode(data, t)
+            r = chain.decode(iq, t)
+            assert r["ok"], "fixture subframes are chosen to decode"
+            out["%s_iq_%d" % (tag, t)], out["%s_data_%d" % (tag, t)] = iq.astype(np.complex64), data
+            out["%s_txsym_%d" % (tag, t)] = g[cfg.idx].copy()  # srslte_pmch_encode's symbols, in mapping order
+            out["%s_tb_%d" % (tag, t)], out["%s_e_%d" % (tag, t)] = r["tb"].copy(), r["e"].copy()
+            out["%s_noise_%d" % (tag, t)] = np.array([r["noise"]], np.float32)
+            out["%s_d_%d" % (tag, t)] = r["d"].copy()
+    np.savez_compressed(os.path.join(OUT, "pmch.npz"), **out)
+    print("pmch.npz", os.path.getsize(os.path.join(OUT, "pmch.npz")), "bytes")
+
+
+def ul_extcp():
+    """Extended-CP cells on the uplink: the reference's DMRS (srslte_refsignal_dmrs_pusch_gen with cell.cp = EXT), srslte_chest_ul_estimate_pusch on
+    12-symbol grids, and the PUSCH receive chain on the reference's compiled stages (RefUlRx) on the oracle generator's time samples."""
+    from _libs import OrcUlDmrsCfg, RefChestUlRes, ref_pusch_cfg, ref_ul_sf_cfg
+    from lte_sim import RefUlRx, UlConfig, make_ul_subframe
+    R, rng, out = ref(), np.random.default_rng(2026100502), {}
+    for n, (cell_id, prb, L, n0, n1, cs, ds, gh, sh, tti, n_dmrs) in enumerate(((1, 6, 2, 0, 4, 0, 0, 0, 0, 4, 3), (77, 25, 10, 12, 12, 3, 7, 1, 0, 19, 0),
+                                                                               (150, 50, 50, 0, 0, 5, 13, 1, 1, 7, 6))):
+        cell = RefCell(prb, 1, cell_id, 1, 0, 0, 0)
+        q, rs = opaque(1 << 16), opaque(1 << 16)
+        assert R.srslte_chest_ul_init(q, prb) == 0 and R.srslte_chest_ul_set_cell(q, cell) == 0
+        dcfg = OrcUlDmrsCfg(cs, ds, bool(gh), bool(sh))
+        R.srslte_chest_ul_pregen(q, C.byref(dcfg))
+        assert R.srslte_refsignal_ul_init(rs, prb) == 0 and R.srslte_refsignal_ul_set_cell(rs, cell) == 0
+        r = aligned(2 * 2 * 12 * L, np.float32)
+        assert R.srslte_refsignal_dmrs_pusch_gen(rs, C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        r = np.array(r).view(np.complex64)
+        nre, ng = 12 * prb, 12 * 12 * prb
+        grid = (0.5 * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))).astype(np.complex64)
+        k = np.arange(12 * L)
+        for s_, (sym, npb) in enumerate(((2, n0), (8, n1))):
+            h = ((1.5 - 0.5 * s_ + 0.4 * np.sin(k / 30.0)) * np.exp(1j * (0.4 + s_ + k / 150.0))).astype(np.complex64)
+            grid[sym * nre + 12 * npb: sym * nre + 12 * (npb + L)] = r[s_ * 12 * L:(s_ + 1) * 12 * L] * h
+        grid = acopy((grid + 0.1 * (rng.standard_normal(ng) + 1j * rng.standard_normal(ng))).astype(np.complex64).view(np.float32))
+        ce, res = aligned(2 * ng, np.float32), RefChestUlRes()
+        ce[:] = 0
+        res.ce = ce.ctypes.data
+        assert R.srslte_chest_ul_estimate_pusch(q, ref_ul_sf_cfg(tti), ref_pusch_cfg(L, n0, n_dmrs, n1), p(grid), C.byref(res)) == 0
+        out["meta_%d" % n] = np.array([cell_id, prb, L, n0, n1, cs, ds, gh, sh, tti, n_dmrs], np.int32)
+        out["r_%d" % n], out["grid_%d" % n] = r.copy(), np.array(grid).view(np.complex64).copy()
+        sel = np.concatenate([np.arange(l * nre + 12 * (n0 if l < 6 else n1), l * nre + 12 * ((n0 if l < 6 else n1) + L)) for l in range(12)])
+        out["ce_%d" % n] = np.array(ce).view(np.complex64)[sel].copy()
+        out["scal_%d" % n] = np.array([res.noise_estimate, res.noise_estimate_dbm, res.snr, res.snr_db], np.float32)
+        R.srslte_chest_ul_free(q)
+        R.srslte_refsignal_ul_free(rs)
+    for tag, (prb, L, n_prb, mod, tbs, snr, short, ttis) in {"a": (6, 6, 0, 1, 808, 5.0, True, (2, 7)), "b": (25, 10, 5, 2, 3240, 10.0, False, (9,))}.items():
+        cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, shortened=short, cp_ext=True)
+        chain = RefUlRx(cfg)
+        out[tag + "_meta"] = np.array([prb, L, n_prb, mod, tbs, 1 if short else 0], np.int32)
+        out[tag + "_ttis"] = np.array(ttis, np.int32)
+        for t in ttis:
+            iq, data = make_ul_subframe(cfg, t, rng, snr_db=snr, amp=0.1, gain=0.8 * np.exp(0.7j))
+            r = chain.run(iq, t)
+            assert r["ok"], "fixture subframes are chosen to decode"
+            out["%s_iq_%d" % (tag, t)], out["%s_tb_%d" % (tag, t)] = iq.astype(np.complex64), r["tb"].copy()
+            out["%s_iters_%d" % (tag, t)], out["%s_data_%d" % (tag, t)] = r["iters"].copy(), data
+    np.savez_compressed(os.path.join(OUT, "ul_extcp.npz"), **out)
+    print("ul_extcp.npz", os.path.getsize(os.path.join(OUT, "ul_extcp.npz")), "bytes")
+
+
 if __name__ == "__main__":
+    if "--round4-only" in sys.argv:
+        pmch()
+        ul_extcp()
+        sys.exit(0)
     if "--mbsfn-only" in sys.argv:
         chest_mbsfn()
         sys.exit(0)
@@ -341,3 +421,5 @@ if __name__ == "__main__":
     extra()
     pdsch_function()
     chest_mbsfn()
+    pmch()
+    ul_extcp()

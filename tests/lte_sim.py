@@ -626,6 +626,10 @@ class RefPdsch:
                 "csi": self._ptr("csi", np.float32, nre), "noise": self.res.noise_estimate}
 
 
+# smoothing filters of the three configurations of tests/golden/pmch.npz: "b" the applications' (triangle 0.1), the others phy_dl_test's Gauss filter
+PMCH_GOLDEN_CHEST = {"a": None, "b": {"filter_type": 1, "filter_coef": (0.1, 0.0)}, "c": None}
+
+
 class PmchConfig:
     """One PMCH configuration (pmch.c): an MBSFN subframe of MBSFN area `area_id` on a single-port cell - 12 extended-CP symbols
     behind a non-MBSFN region of `non_mbsfn_region` symbols, all PRBs, rv 0, scrambled with the area's sequence. cp_ext is the CELL's

@@ -191,3 +191,66 @@ def test_chest_mbsfn_golden(hp, tag):
     if alg == 0:
         assert abs(noise[0, 0, 0] - float(g[tag + "_noise"][0])) <= 1e-4 * noise[0, 0, 0]
     est.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_pmch_golden(hp, tag):
+    """The fused PMCH pipelines vs outputs of the reference's srslte_pmch_encode / srslte_pmch_decode (tests/gen_golden.py:pmch): the transmit side's
+    symbols bit for bit, the receive side's noise figure, LLRs (one LSB on <= 0.2 %), CRC verdict and transport block."""
+    from lte_sim import PMCH_GOLDEN_CHEST
+    g = load("pmch.npz")
+    prb, cid, area, mod, tbs, cfi, region, cp_ext = [int(x) for x in g[tag + "_meta"]]
+    ttis = [int(x) for x in g[tag + "_ttis"]]
+    hc = hp.ChestDlCfg()
+    ch = PMCH_GOLDEN_CHEST[tag] or {"filter_coef": (4.0, 1.0)}
+    hc.filter_type = ch.get("filter_type", 0)
+    hc.filter_coef[0], hc.filter_coef[1] = ch["filter_coef"]
+    rx = hp.DlRx(cid, prb, cfi, 0, mod, tbs, 6, 1, True, hc, cp_ext=bool(cp_ext), mbsfn=(area, region))
+    tx = hp.DlTx(cid, prb, cfi, 0, mod, tbs, 1, 1, 0.0, cp_ext=bool(cp_ext), mbsfn=(area, region))
+    nbits = rx.nof_re(1) * {1: 2, 2: 4, 3: 6}[mod]
+    for t in ttis:
+        tx.encode(g["%s_data_%d" % (tag, t)][None], t, 0)
+        y = tx.debug(2, np.complex64, rx.nof_re(1))
+        assert np.array_equal(y.view(np.float32), g["%s_txsym_%d" % (tag, t)].view(np.float32)), t
+        tb, ok = rx.decode(g["%s_iq_%d" % (tag, t)][None], t)
+        res = rx.debug(2, np.float32, 10)
+        want = float(g["%s_noise_%d" % (tag, t)][0])
+        assert abs(res[0] - want) <= 1e-4 * want, (t, res[0], want)
+        e = rx.debug(4, np.int16, nbits)
+        diff = np.abs(e.astype(np.int32) - g["%s_e_%d" % (tag, t)].astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 2e-3 * diff.size + 1, (t, int(diff.max()), int((diff != 0).sum()))
+        assert ok[0] and np.array_equal(tb[0][:tbs // 8 + 3], g["%s_tb_%d" % (tag, t)]) and np.array_equal(tb[0][:tbs // 8], g["%s_data_%d" % (tag, t)])
+    rx.free()
+    tx.free()
+
+
+@pytest.mark.gpu
+def test_ul_extended_cp_golden(hp):
+    """Extended-CP uplink on the device vs the reference's outputs (tests/gen_golden.py:ul_extcp): DMRS, srslte_chest_ul_estimate_pusch with a PRB offset
+    per slot on 12-symbol grids, and the PUSCH receive pipeline (transport blocks and per-block pass counts of the reference-code chain)."""
+    g = load("ul_extcp.npz")
+    for n in range(3):
+        cell_id, prb, L, n0, n1, cs, ds, gh, sh, tti, n_dmrs = [int(x) for x in g["meta_%d" % n]]
+        q = hp.ChestUl(cell_id, prb, cs, ds, bool(gh), bool(sh), cp_ext=True)
+        rc, r = q.dmrs(L, tti % 10, n_dmrs)
+        assert rc == 0 and np.abs(r - g["r_%d" % n]).max() <= 2e-6
+        if n0 == n1:  # the wrapper's estimate call takes one PRB offset (hopping: through the pipeline below and tests/test_gpu_ul_extcp.py)
+            rc, ce, res = q.estimate_pusch(g["grid_%d" % n][None], tti, L, n0, n_dmrs)
+            nre = 12 * prb
+            sel = np.concatenate([np.arange(l * nre + 12 * n0, l * nre + 12 * (n0 + L)) for l in range(12)])
+            want = g["ce_%d" % n]
+            assert rc == 0 and np.abs(ce[0][sel] - want).max() <= 1e-4 * np.abs(want).max()
+            for j in range(4):
+                x = float(g["scal_%d" % n][j])
+                assert abs(res[0, j] - x) <= 1e-4 * abs(x) + 1e-5, j
+        q.free()
+    for tag in ("a", "b"):
+        prb, L, n_prb, mod, tbs, short = [int(x) for x in g[tag + "_meta"]]
+        rx = hp.UlRx(11, prb, 0x1234, mod, tbs, L, n_prb, 3, 6, 1, 2, 5, True, False, shortened=bool(short), cp_ext=True)
+        C_ = -(-(tbs + 24) // 6120) if tbs + 24 > 6144 else 1
+        for t in [int(x) for x in g[tag + "_ttis"]]:
+            tb, ok = rx.decode(g["%s_iq_%d" % (tag, t)][None], t)
+            it = rx.debug(6, np.uint32, C_)
+            assert ok[0] and np.array_equal(tb[0][:tbs // 8 + 3], g["%s_tb_%d" % (tag, t)]) and np.array_equal(it, g["%s_iters_%d" % (tag, t)])
+        rx.free()

@@ -280,3 +280,56 @@ def test_chest_mbsfn_golden(tag):
     assert np.abs(ce[:want.size] - want).max() <= 1e-4 * max(np.abs(want).max(), np.sqrt((np.abs(want) ** 2).mean()))
     if alg == 0:
         assert abs(nz.value - float(g[tag + "_noise"][0])) <= 1e-4 * nz.value
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_pmch_golden(tag):
+    """Oracle PMCH chain vs outputs of the reference's srslte_pmch_encode / srslte_pmch_decode with its MBSFN estimate (tests/gen_golden.py:pmch)."""
+    from lte_sim import PMCH_GOLDEN_CHEST as PMCH_CHEST, PmchConfig, make_pmch_subframe, oracle_pmch_rx
+    g = np.load(os.path.join(G, "pmch.npz"))
+    prb, cid, area, mod, tbs, cfi, region, cp_ext = [int(x) for x in g[tag + "_meta"]]
+    cfg = PmchConfig(prb, cid, area, mod, tbs, cfi=cfi, non_mbsfn_region=region, cp_ext=bool(cp_ext), chest=PMCH_CHEST[tag])
+    for t in [int(x) for x in g[tag + "_ttis"]]:
+        k = {}
+        make_pmch_subframe(cfg, t, np.random.default_rng(0), data=g["%s_data_%d" % (tag, t)], keep=k)
+        assert np.array_equal(k["d"].view(np.float32), g["%s_txsym_%d" % (tag, t)].view(np.float32)), t  # the transmit side, symbol for symbol
+        r = oracle_pmch_rx(cfg, g["%s_iq_%d" % (tag, t)], t, keep=True)
+        assert abs(r["noise"] - float(g["%s_noise_%d" % (tag, t)][0])) <= 1e-4 * r["noise"]
+        want_d, want_e = g["%s_d_%d" % (tag, t)], g["%s_e_%d" % (tag, t)]
+        assert np.abs(r["d"] - want_d).max() <= 2e-4 * np.abs(want_d).max()
+        diff = np.abs(r["e"].astype(np.int32) - want_e.astype(np.int32))
+        assert diff.max() <= 1 and (diff != 0).sum() <= 2e-3 * diff.size + 1
+        assert r["ok"] and np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)]) and np.array_equal(r["tb"][:tbs // 8], g["%s_data_%d" % (tag, t)])
+
+
+def test_ul_extended_cp_golden():
+    """Oracle vs the reference on an extended-CP cell (tests/gen_golden.py:ul_extcp): DMRS, srslte_chest_ul_estimate_pusch on 12-symbol grids, and the
+    PUSCH receive chain on the reference's compiled stages."""
+    from _libs import OrcChestUlRes, OrcUlDmrs, OrcUlDmrsCfg
+    from lte_sim import UlConfig, oracle_ul_rx
+    g = np.load(os.path.join(G, "ul_extcp.npz"))
+    orc = oracle()
+    orc.orc_chest_ul_pusch_hop_cp.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    for n in range(3):
+        cell_id, prb, L, n0, n1, cs, ds, gh, sh, tti, n_dmrs = [int(x) for x in g["meta_%d" % n]]
+        o, dcfg = OrcUlDmrs(), OrcUlDmrsCfg(cs, ds, bool(gh), bool(sh))
+        assert orc.orc_ul_dmrs_init_cp(C.byref(o), cell_id, 6) == 0
+        r = np.zeros(2 * 12 * L, np.complex64)
+        assert orc.orc_ul_dmrs_pusch_gen(C.byref(o), C.byref(dcfg), L, tti % 10, n_dmrs, p(r)) == 0
+        assert np.abs(r - g["r_%d" % n]).max() <= 2e-6
+        nre, ng = 12 * prb, 12 * 12 * prb
+        ce, res = np.zeros(ng, np.complex64), OrcChestUlRes()
+        assert orc.orc_chest_ul_pusch_hop_cp(p(np.ascontiguousarray(g["r_%d" % n])), prb, L, n0, n1, 6, p(np.ascontiguousarray(g["grid_%d" % n])), p(ce), C.byref(res)) == 0
+        sel = np.concatenate([np.arange(l * nre + 12 * (n0 if l < 6 else n1), l * nre + 12 * ((n0 if l < 6 else n1) + L)) for l in range(12)])
+        want = g["ce_%d" % n]
+        assert np.abs(ce[sel] - want).max() <= 1e-4 * np.abs(want).max()
+        for j, nm in enumerate(("noise_estimate", "noise_estimate_dbm", "snr", "snr_db")):
+            x = float(g["scal_%d" % n][j])
+            assert abs(getattr(res, nm) - x) <= 1e-4 * abs(x) + 1e-6, nm
+    for tag in ("a", "b"):
+        prb, L, n_prb, mod, tbs, short = [int(x) for x in g[tag + "_meta"]]
+        cfg = UlConfig(prb, 11, mod, tbs, L, n_prb, n_dmrs=3, cyclic_shift=2, delta_ss=5, group_hopping=True, shortened=bool(short), cp_ext=True)
+        for t in [int(x) for x in g[tag + "_ttis"]]:
+            r = oracle_ul_rx(cfg, g["%s_iq_%d" % (tag, t)], t)
+            assert r["ok"] and np.array_equal(r["tb"], g["%s_tb_%d" % (tag, t)]) and np.array_equal(r["iters"], g["%s_iters_%d" % (tag, t)])
+            assert np.array_equal(r["tb"][:tbs // 8], g["%s_data_%d" % (tag, t)])
