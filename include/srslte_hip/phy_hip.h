@@ -266,7 +266,9 @@ typedef struct {
 srslte_hip_dl_rx_t* srslte_hip_dl_rx_create(const srslte_hip_dl_rx_cfg_t* cfg);
 void                srslte_hip_dl_rx_destroy(srslte_hip_dl_rx_t* q);
 uint32_t            srslte_hip_dl_rx_nof_re(const srslte_hip_dl_rx_t* q, uint32_t sf_idx);
-/* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf] */
+/* d_iq: [nof_sf][15*N]; outputs: d_tb [nof_sf][tb_stride] bytes (tbs/8 + 3 CRC bytes used), d_tb_ok [nof_sf]. The two output pointers may be
+ * device-visible HOST memory (hipHostMalloc / a pinned allocation): the pipeline's last phase then stores the results where the MAC reads them and no
+ * copy follows the batch (bench.py's N = 1 line; tests/test_gpu_fullsize.py::test_results_straight_into_pinned_host_memory) */
 int srslte_hip_dl_rx_batch(srslte_hip_dl_rx_t* q, const void* d_iq, uint32_t tti0, uint32_t nof_sf, uint8_t* d_tb, uint32_t tb_stride,
                            uint8_t* d_tb_ok, void* stream);
 /* HARQ (decode_tb_cb sch.c:299-414 on a srslte_softbuffer_rx_t per transport block, softbuffer.c:46-150): slot b of the object keeps
