@@ -201,7 +201,8 @@ def main():
     ap.add_argument("--llr8", action="store_true", help="8-bit LLR path (SURVEY §8f N2: demod_b, rm_turbo_rx_lut_8bit, avx8 decoder) instead of the 16-bit one")
     ap.add_argument("--inputs", type=int, default=16, help="distinct input batches (same transmission, independent noise) rotating through the timed loop; "
                     "16 x 23.6 MB exceed the 256 MB Infinity Cache")
-    ap.add_argument("--streams", type=int, default=4, help="pipeline instances / HIP streams that consecutive steps alternate over")
+    ap.add_argument("--streams", type=int, default=8, help="pipeline instances / HIP streams that consecutive steps alternate over (more than 4: with "
+                    "GPU_MAX_HW_QUEUES raised to match, unless the environment already sets it)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' + --force-device 0 rehearses N>1 on a one-GPU box")
     ap.add_argument("--force-device", type=int, default=-1, help="use this GPU for every rank (rehearsal only)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and take the N > 1 code path (gather, all_reduce, barrier) even "
@@ -222,6 +223,12 @@ def main():
         w = args.cpu_worker
         return cpu_worker(w[0], int(w[1]), int(w[2]), float(w[3]), int(w[4]), int(w[5]), args.llr8)
 
+    # HIP maps its streams onto FOUR hardware queues unless told otherwise, and kernels of one queue start in order: a fifth pipeline object then
+    # queues behind another one's decoder launch (5 streams: 396 k). With a hardware queue per object eight objects beat four by 3.9 % on this
+    # line and by 22 % on the mixed-grant one (profiles/r04/ab_hw_queues.txt). The runtime reads the variable when it starts: set before torch
+    # is imported, here and (inherited) in the ranks of a self-launched run; an application sets it in its own environment
+    if args.streams > 4:
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(args.streams, 16)))
     if args.grants_mix:
         if args.gpus != 1:
             raise SystemExit("--grants-mix is a one-GPU side workload")
@@ -704,7 +711,7 @@ def main():
                    ("srslte_hip_dl_rx_pool_submit (one call per batch, %d objects inside the library)" % nstreams if pool is not None else "srslte_hip_dl_rx_stage x 6 (one fixed grant)"),
                    "input_batches": n_inputs, "input_MB": round(n_inputs * d_iq.numel() * 4 / 1e6, 1),
                    "same_input_value": round(world * B * args.steps / float(np.median(same_times)), 1),
-                   "streams": nstreams, "pipeline_instances_verified": nstreams if agree_all == world else 0, "results_on_host_verified": gather_ok,
+                   "streams": nstreams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "pipeline_instances_verified": nstreams if agree_all == world else 0, "results_on_host_verified": gather_ok,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(world * B * args.steps / max(times), 1),
                    "repeat_max_value": round(world * B * args.steps / min(times), 1), "full_iter": full,
                    "full_iter_value": full["value"] if full else None},

@@ -246,7 +246,7 @@ def main(args):
                             "delivered": per_cls[i][0], "of": per_cls[i][1]} for i, m in enumerate(MIX)],
                    "block_lengths": [k for k, _ in ks], "decoder_launches_per_step": len({sg.K1 for sg in segs}),
                    "code_blocks_per_step": blocks // n_inputs, "avg_siso_passes_per_cb": round(passes_sum / max(blocks, 1), 3),
-                   "bler": round(1 - good / (B * n_inputs), 4), "undetected_errors": wrong, "streams": nstreams,
+                   "bler": round(1 - good / (B * n_inputs), 4), "undetected_errors": wrong, "streams": nstreams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "pipeline_instances_verified": nstreams if agree else 0, "results_on_host_verified": bool(host_ok), "results_to_host": "zero-copy" if zero_copy else "copy", "input_batches": n_inputs,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(B * args.steps / max(times), 1),
                    "repeat_max_value": round(B * args.steps / min(times), 1)},

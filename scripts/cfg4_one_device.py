@@ -25,6 +25,7 @@ NOF_PRB, MOD, TBS, CFI, MAX_ITER = 100, 3, 75376, 1, 6
 
 
 def run(ues=8, batch=128, steps=8, snr=18.0, oracle_sample=2, quiet=False, warm_s=0.15, timed_s=0.5):
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(max(ues, 4), 16)))  # a hardware queue per stream (bench.py does the same; read when HIP starts)
     import torch
     from lte_sim import DlConfig, make_subframe, oracle_rx
     pkg = importlib.import_module("srslte-emane_amd")
