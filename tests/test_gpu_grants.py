@@ -383,3 +383,48 @@ def test_grants_harq_drawn_sequences(hp, seed):
     assert n_ok > 0
     rx.free()
 
+
+
+@pytest.mark.parametrize("llr8", [False, True])
+def test_every_decoder_kind_in_one_call(hp, llr8):
+    """One grants call whose transport blocks need every decoder kind at once - unwindowed (K = 320), 8 windows (K = 640), two blocks per wavefront
+    (K = 1568, 4032, and 6144 x 2 as a pair of one transport block), each kind with an odd number of blocks - so that tdec_run_groups takes the
+    mixed launch (tdec_mix_kernel; with 8-bit LLRs: avx8 / sse8 launches beside the widened mix of the two short kinds). SNRs around each
+    block's threshold: early stops at different passes and failures in one wavefront. Verdicts, transport blocks and the pass count of every
+    code block against the oracle chain."""
+    P, cell_id, tti0 = 50, 21, 3
+    rng = np.random.default_rng(77 + llr8)
+    # (first PRB, PRBs, mod, tbs, snr): K = 320 x3, 640 x3, 1568 x3, 4032 x1, 6144 x2 (one TB)
+    plan = [(0, 3, 1, 296, 1.0), (5, 3, 1, 296, -1.0), (9, 4, 1, 296, 6.0), (0, 5, 1, 616, 2.0), (10, 5, 1, 616, 0.2), (20, 6, 1, 616, 5.0),
+            (0, 12, 1, 1544, 1.5), (14, 12, 1, 1544, 0.3), (30, 14, 1, 1544, 5.0), (0, 25, 2, 4008, 6.5), (0, 50, 2, 12216, 8.5)]
+    if llr8:  # the 8-bit waterfalls sit a little higher
+        plan = [(a, n, m, t, s + 1.0) for a, n, m, t, s in plan]
+    stream = []
+    for b, (first, n, mod, tbs, snr) in enumerate(plan):
+        mask = np.zeros((2, P), np.uint8)
+        mask[:, first:first + n] = 1
+        cfg = DlConfig(P, cell_id, mod, tbs, cfi=1 + b % 3, rnti=0x200 + b, prb_mask=mask, llr8=llr8)
+        iq, data = make_subframe(cfg, tti0 + b, rng, snr_db=snr)
+        stream.append((cfg, iq, data))
+    Ks = sorted({int(c.seg.K1) for c, _, _ in stream})
+    assert Ks == [320, 640, 1568, 4032, 6144]
+    hc = hp.ChestDlCfg()
+    hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
+    tbs_max = max(c.tbs for c, _, _ in stream)
+    rxg = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, len(stream), True, hc, llr_8bit=llr8)
+    grants = [hp.DlGrant.make(P, c.mod, c.tbs, c.rnti, cfi=c.cfi, prb_mask=c.prb_mask) for c, _, _ in stream]
+    rc, tb, ok = rxg.decode_grants(np.stack([iq for _, iq, _ in stream]), tti0, grants)
+    assert rc == 0
+    Cmax = -(-(tbs_max + 24) // 6120) if tbs_max + 24 > 6144 else 1
+    iters = rxg.debug(13, np.uint32, len(stream) * Cmax).reshape(len(stream), Cmax)
+    spread, n_ok = set(), 0
+    for b, (cfg, iq, data) in enumerate(stream):
+        r = oracle_rx(cfg, iq, tti0 + b, keep=True)
+        assert bool(ok[b]) == bool(r["ok"]), (b, cfg.seg.K1)
+        assert np.array_equal(iters[b, :cfg.seg.C], r["iters"]), (b, cfg.seg.K1, iters[b, :cfg.seg.C], r["iters"])
+        spread.update(int(x) for x in r["iters"])
+        if r["ok"]:
+            n_ok += 1
+            assert np.array_equal(tb[b, :cfg.tbs // 8 + 3], r["tb"]) and np.array_equal(tb[b, :cfg.tbs // 8], data), b
+    assert n_ok >= 5 and len(spread) >= 3, (n_ok, spread)  # decoded and failed blocks, early and late stops
+    rxg.free()
