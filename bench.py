@@ -407,18 +407,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def timed_repeats(src, min_s, with_events):
-        """Repeats of the contract's timed region: K steps between barriers. Returns (per-repeat max-over-ranks seconds, mean tdec ms)."""
-        evs = [(L.srslte_hip_event_create(), L.srslte_hip_event_create()) for _ in range(args.steps)] if (with_events and grant_arr is None) else None
+    def timed_repeats(src, min_s, with_events, nsteps=None):
+        """Repeats of the contract's timed region: K steps between barriers. Returns (per-repeat max-over-ranks seconds, mean tdec ms).
+        nsteps: a region of another length (the steady-state figure)."""
+        nsteps = nsteps or args.steps
+        evs = [(L.srslte_hip_event_create(), L.srslte_hip_event_create()) for _ in range(nsteps)] if (with_events and grant_arr is None) else None
         times, tdec = [], []
         k0 = 0  # the rotation over streams and input batches goes on across repeats (nstreams and n_inputs need not divide K)
         while True:
             barrier()
             t0 = time.perf_counter()
-            for k in range(args.steps):
+            for k in range(nsteps):
                 step(k0 + k, src, evs[k] if evs else None)
             barrier()
-            k0 += args.steps
+            k0 += nsteps
             el = time.perf_counter() - t0
             if use_dist:
                 t = torch.tensor([el, float(sum(times) + el >= min_s)], device=cdev, dtype=torch.float64)
@@ -441,6 +443,11 @@ def main():
     timed_repeats(d_inputs, 0.15, False)
     times, tdec_ms = timed_repeats(d_inputs, args.min_timed_s, pool is None)  # pool mode: one call per batch, no per-stage events
     t_med = float(np.median(times))
+    # What the K-step region costs beyond K steps of a pipeline that never drains: the same loop over 4 K steps per region; the slope between the
+    # two region lengths is the steady-state step, the rest of the K-step region is filling and draining the streams around the two barriers.
+    long_times, _ = timed_repeats(d_inputs, args.min_timed_s / 2, False, nsteps=4 * args.steps)
+    t_long = float(np.median(long_times))
+    steady_step = max((t_long - t_med) / (3 * args.steps), 1e-9)
     # round 3's loop for comparison: every step and every pipeline instance fed the SAME batch (it then stays in the Infinity Cache)
     same_times, _ = timed_repeats(d_iq, args.min_timed_s / 2, False) if n_inputs > 1 else (times, None)
 
@@ -715,6 +722,11 @@ def main():
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(world * B * args.steps / max(times), 1),
                    "repeat_max_value": round(world * B * args.steps / min(times), 1), "full_iter": full,
                    "full_iter_value": full["value"] if full else None},
+        "steady_state": {"value": round(world * B / steady_step, 1), "ms_per_step": round(steady_step * 1e3, 4),
+                         "fill_drain_ms_per_region": round((t_med - args.steps * steady_step) * 1e3, 4), "long_region_steps": 4 * args.steps,
+                         "long_region_value": round(world * B * 4 * args.steps / t_long, 1),
+                         "method": "median region of K steps against median region of 4 K steps (same loop, same barriers): slope = a step of a pipeline that "
+                                   "never drains, intercept = filling and draining the streams around the barriers; `value` above is the K-step region as the contract times it"},
         "roofline": roofline,
         "kernels": kernels,
         "kernels_large_batch": big,

@@ -55,6 +55,10 @@ void tdec_set_tb_syndrome(srslte_hip_tdec_t* q, const uint32_t* d_rem, uint32_t 
 // straight into its transport block d_tb[cb / C][...] and the last block of a transport block to finish writes d_tb_ok[cb / C] (all block CRCs,
 // the XOR of the TB-CRC shares, a non-zero parity: sch.c:470-488): no assembly kernel behind the decoder. d_tb = nullptr: off
 int tdec_set_tb_direct(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint32_t payload_bytes_per_block, uint8_t* d_tb_ok);
+// ... for the next tdec_run_groups (a ragged batch of 16-bit blocks, none skipped): transport-block slot v = block slot / width has d_Cof[v] blocks and
+// row v (v < B) or rows0 + v - B of d_tb / d_tb_ok
+int tdec_set_tb_ragged(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, const uint8_t* d_Cof, uint32_t width, uint32_t B,
+                       uint32_t rows0);
 // tdec.hip: blocks with d_skip[cb] != 0 are left alone by the following runs: bytes, CRC flag, TB-CRC share stay (nullptr: off)
 void tdec_set_skip(srslte_hip_tdec_t* q, const uint8_t* d_skip);
 // tdec.hip: the following runs work on the block slots d_map[0 .. nof_cb) instead of 0 .. nof_cb-1 (input, output, iteration count, CRC flag,

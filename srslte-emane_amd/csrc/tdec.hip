@@ -238,6 +238,12 @@ struct TdecArgs {
   unsigned long long* prof;    // -DTDEC_PROF builds: [nof_cb][10] cycles per phase, else unused
   int            dbg;          // timing experiments only (SRSLTE_HIP_TDEC_DBG): 1 skips the SISO sweeps, 2 the element-wise subtractions,
                                // 4 replaces the interleaver scatters by in-order stores, 8 points every branch-metric load at the zero buffer
+  // tdec_mix_kernel only (behind everything the other kernels read), with tb_out: transport blocks of DIFFERENT sizes (a ragged batch, tdec_set_tb_ragged).
+  // Block slot cb belongs to transport-block slot cb / tb_C (tb_C = the slots' width), which has tb_Cof[cb / tb_C] blocks; its row of tb_out /
+  // tb_ok_out is the slot itself below tb_B, tb_rows0 + slot - tb_B from there on (second codewords). tbA: the group's CRC24A tables (tdec_tbA_table)
+  const uint8_t*  tb_Cof;
+  uint32_t        tb_B, tb_rows0;
+  const uint32_t* tbA;
 };
 
 // Several block lengths in ONE launch (ragged batches: tdec_run_groups). A launch per length is a serial chain of latency-bound kernels - a few
@@ -253,6 +259,7 @@ struct TdecGroups {
   uint32_t  xy_stride;
   TdecGroup g[TDEC_MAX_GROUPS];
   uint8_t   kind[TDEC_MAX_GROUPS]; // tdec_mix_kernel only (behind everything the other kernels read): which decoder the group's blocks take
+  const uint32_t* tbA[TDEC_MAX_GROUPS]; // ... and, with tb_Cof, the group's CRC24A share tables: [K] whole block, [K] payload only, [16] x^(j (K - 24))
 };
 enum { TDEC_KIND_PAIR = 0, TDEC_KIND_WIN8 = 1, TDEC_KIND_GEN = 2 };
 // Returns this wavefront's index within its group and makes `a` describe that group alone: its length and tables, its share of the block map,
@@ -274,6 +281,17 @@ __device__ __forceinline__ uint32_t tdec_enter_group(TdecArgs& a, const TdecGrou
     a.beta += (size_t)first_wave * a.beta_stride;
   }
   return bx;
+}
+
+__device__ __forceinline__ uint32_t tdec_gf24_mul(uint32_t a, uint32_t b)
+{ // a(x) b(x) mod g_CRC24A
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r <<= 1;
+    if (r & 0x1000000u) r ^= 0x1864CFBu;
+    if ((b >> i) & 1) r ^= a;
+  }
+  return r;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1090,9 +1108,18 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
   __syncthreads();
   // transport-block assembly by the decoder itself (tdec_set_tb_direct, as tdec_pair_kernel's last phase; sch.c:360,:401-410,:470-488): block r of
   // transport block cb / C owns bytes [r rb, r rb + rb) of it, the last block also leaves its own CRC behind the TB's
-  const int tbr = (int)(cb % a.tb_C), tbi = (int)(cb / a.tb_C), rb = (int)a.tb_rb;
-  uint8_t*  tbo = a.tb_out ? a.tb_out + (size_t)tbi * a.tb_out_stride + (size_t)tbr * rb : nullptr;
-  const int tlim = tbr == (int)a.tb_C - 1 ? K8 : rb;
+  const int tbr = (int)(cb % a.tb_C), tbi = (int)(cb / a.tb_C);
+  int       rb = (int)a.tb_rb, tbC = (int)a.tb_C;
+  size_t    row = (size_t)tbi;
+#ifdef TDEC_MIX_TU
+  if (a.tb_Cof) { // a ragged batch: the blocks this decoder takes (K <= 800) are transport blocks of their own, their CRC24A is the block's CRC
+    tbC = 1;
+    rb  = K8;
+    row = (uint32_t)tbi < a.tb_B ? (size_t)tbi : (size_t)a.tb_rows0 + tbi - a.tb_B;
+  }
+#endif
+  uint8_t*  tbo = a.tb_out ? a.tb_out + row * a.tb_out_stride + (size_t)tbr * rb : nullptr;
+  const int tlim = tbr == tbC - 1 ? K8 : rb;
   bool      par_nz = false; // the TB's CRC24A bytes, the last three of the last block's rb: not all zero (sch.c:481)
   {
     const int      Lw    = K / W;
@@ -1116,6 +1143,10 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
   if (tbo) par_nz = __ballot(par_nz) != 0;
   PROF(8)
   if (L.lane == 0) {
+#ifdef TDEC_MIX_TU
+    if (tbo && a.tb_Cof) a.tb_ok_out[row] = (ok && par_nz) ? 1 : 0; // one block: the verdict of sch.c:470-488 is the block's CRC and a non-zero parity
+    else
+#endif
     if (tbo) tdec_tb_fold(a, tbi, tbr, tsyn, ok, par_nz);
     if (a.iters) a.iters[cb] = n_iter;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
@@ -1589,6 +1620,24 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a0, TdecGroups gs
     }
     if (__all(ok || !active)) break; // sch.c:383 per block; the wave leaves when every block has stopped
   }
+#ifdef TDEC_MIX_TU
+  if (a.tb_out && a.tb_Cof && active) { // a ragged batch: the block is a transport block of its own (K <= 400): its bytes and its verdict
+    const uint32_t tbi = cb / a.tb_C;
+    const size_t   row = tbi < a.tb_B ? (size_t)tbi : (size_t)a.tb_rows0 + tbi - a.tb_B;
+    uint8_t*       tbo = a.tb_out + row * a.tb_out_stride;
+    bool           par_nz = false;
+    for (uint32_t b = L.p; b < nbytes; b += 8) { // the bytes this lane wrote in the block's last pass
+      const uint8_t v = o[b];
+      tbo[b]          = v;
+      par_nz          = par_nz || (b + 3 >= nbytes && v != 0);
+    }
+    uint32_t pz = par_nz ? 1u : 0u;
+    pz |= __builtin_amdgcn_update_dpp(pz, pz, 0xB1, 0xf, 0xf, false);
+    pz |= __builtin_amdgcn_update_dpp(pz, pz, 0x4E, 0xf, 0xf, false);
+    pz |= __builtin_amdgcn_update_dpp(pz, pz, 0x128, 0xf, 0xf, false);
+    if (L.p == 0) a.tb_ok_out[row] = (ok && pz) ? 1 : 0;
+  }
+#endif
   if (L.p == 0 && active) {
     if (a.iters) a.iters[cb] = my_iters;
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
@@ -1617,6 +1666,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(TDEC_PAIR_MI
   __shared__ __attribute__((aligned(16))) pk_t pool[MIX_POOL];
   __shared__ int16_t tl[2][12];
   a.sb_layout = kind != TDEC_KIND_GEN; // the unwindowed decoder reads the plain [s p0 p1] layout, the windowed ones the rate de-matcher's
+  a.tbA       = gs.tbA[gi];
   if (kind == TDEC_KIND_PAIR) tdec_pair_body(a, bx, pool, tl);
   else if (kind == TDEC_KIND_WIN8) tdec_win_body<8, 0>(a, bx, pool, tl[0]);
   else tdec_gen_body(a, bx);
@@ -1672,6 +1722,9 @@ struct srslte_hip_tdec {
   uint32_t                 tb_out_stride = 0, tb_rb = 0;
   uint8_t*                 tb_ok_out = nullptr;
   uint32_t*                d_tb_acc = nullptr;
+  const uint8_t*           tb_Cof = nullptr; // tdec_set_tb_ragged; consumed by the next tdec_run_groups
+  uint32_t                 tb_width = 0, tb_B = 0, tb_rows0 = 0;
+  std::map<uint32_t, uint32_t*> tbA_tabs;    // K -> device CRC24A share tables of the ragged mode
   std::mutex               mtx;
 };
 
@@ -1739,6 +1792,7 @@ extern "C" void srslte_hip_tdec_destroy(srslte_hip_tdec_t* q)
   (void)hipFree(q->d_xy);
   (void)hipFree(q->d_zeros);
   if (q->d_tb_acc) (void)hipFree(q->d_tb_acc);
+  for (auto& kv : q->tbA_tabs) (void)hipFree(kv.second);
   if (q->d_conv) (void)hipFree(q->d_conv);
   delete q;
 }
@@ -1798,6 +1852,61 @@ int tdec_set_tb_direct(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, 
     HIP_TRY(hipDeviceSynchronize());
   }
   q->tb_out = d_tb; q->tb_out_stride = tb_stride; q->tb_rb = payload_bytes_per_block; q->tb_ok_out = d_tb_ok;
+  return SRSLTE_SUCCESS;
+}
+
+// The same for a RAGGED batch (the next tdec_run_groups, 16-bit LLRs, no block skipped): block slot cb belongs to transport-block slot cb / width,
+// which has d_Cof[cb / width] code blocks; row of d_tb / d_tb_ok: the slot itself below B, rows0 + slot - B from there on.
+int tdec_set_tb_ragged(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, const uint8_t* d_Cof, uint32_t width, uint32_t B,
+                       uint32_t rows0)
+{
+  if (int r = tdec_set_tb_direct(q, d_tb, tb_stride, 0, d_tb_ok)) return r;
+  q->tb_Cof = d_Cof; q->tb_width = width; q->tb_B = B; q->tb_rows0 = rows0;
+  return SRSLTE_SUCCESS;
+}
+
+// CRC24A share tables of block length K for the ragged mode, in the 16-window decoder's array order: [0, K) x^(K-1-n) mod g for every bit n of the
+// block (a transport block of one block); [K, 2K) x^(K-25-n) for the payload bits n < K - 24, 0 on the block's own CRC (one of several blocks);
+// [2K, 2K+16) x^(j (K-24)) mod g: block r of C contributes its payload's remainder times x^((C-1-r)(K-24))
+static int tdec_tbA_table(srslte_hip_tdec_t* q, uint32_t K, const uint32_t** d_tab)
+{
+  auto it = q->tbA_tabs.find(K);
+  if (it == q->tbA_tabs.end()) {
+    std::vector<uint32_t> t(2 * (size_t)K + 16, 0), pw(K);
+    uint32_t              v = 1;
+    for (uint32_t i = 0; i < K; i++) { // pw[i] = x^i mod g
+      pw[i] = v;
+      v <<= 1;
+      if (v & 0x1000000u) v ^= 0x1864CFBu;
+    }
+    const uint32_t Lw = K / 16;
+    for (uint32_t n = 0; n < K; n++) {
+      const uint32_t pos = (n % Lw) * 16 + n / Lw;
+      t[pos] = pw[K - 1 - n];
+      if (n + 24 < K) t[K + pos] = pw[K - 25 - n];
+    }
+    auto mul = [](uint32_t a, uint32_t b) {
+      uint32_t r = 0;
+      for (int i = 23; i >= 0; i--) {
+        r <<= 1;
+        if (r & 0x1000000u) r ^= 0x1864CFBu;
+        if ((b >> i) & 1) r ^= a;
+      }
+      return r;
+    };
+    uint32_t step = 1; // x^(K-24) mod g = x * pw[K-25]
+    step = mul(pw[K - 25], 2u);
+    uint32_t f = 1;
+    for (uint32_t j = 0; j < 16; j++) {
+      t[2 * (size_t)K + j] = f;
+      f = mul(f, step);
+    }
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(uint32_t) * t.size()));
+    HIP_TRY(hipMemcpy(d, t.data(), sizeof(uint32_t) * t.size(), hipMemcpyHostToDevice));
+    it = q->tbA_tabs.emplace(K, d).first;
+  }
+  *d_tab = it->second;
   return SRSLTE_SUCCESS;
 }
 
@@ -1927,7 +2036,13 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
                     uint32_t nof_iterations, uint8_t* d_output, uint32_t out_stride, uint32_t* d_iters, uint8_t* d_crc_ok, hipStream_t st)
 {
   if (!q || !d_input_any || !d_output || !groups || nof_groups > (uint32_t)TDEC_MAX_GROUPS || nof_iterations == 0) return SRSLTE_ERROR_INVALID_INPUTS;
-  if (q->tb_out || q->start_iter || q->tb_rem) return SRSLTE_ERROR_INVALID_INPUTS; // modes of the one-length call
+  // tdec_set_tb_ragged: the decoders assemble the transport blocks (one mixed launch, 16-bit kinds only); consumed by this call whatever its outcome
+  uint8_t* const       rg_tb = q->tb_out;
+  const uint8_t* const rg_Cof = q->tb_Cof;
+  q->tb_out = nullptr;
+  q->tb_Cof = nullptr;
+  const bool ragged = rg_tb != nullptr;
+  if ((ragged && (!rg_Cof || llr8 || q->skip)) || q->start_iter || q->tb_rem) return SRSLTE_ERROR_INVALID_INPUTS; // modes of the one-length call
   enum { T_PAIR, T_WIN8, T_GEN, T_AR32, T_AR16, T_N };
   struct Plan { TdecGroups gs; uint32_t waves, stride, blocks; bool widened; };
   static const TdecGroups none = {};
@@ -1953,6 +2068,10 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     const bool mixable = type == T_PAIR || type == T_WIN8 || type == T_GEN;
     Plan&      p_ = plan[mixable ? T_PAIR : type];
     p_.gs.kind[p_.gs.n] = (uint8_t)(type == T_WIN8 ? TDEC_KIND_WIN8 : (type == T_GEN ? TDEC_KIND_GEN : TDEC_KIND_PAIR));
+    p_.gs.tbA[p_.gs.n]  = nullptr;
+    if (ragged && type == T_PAIR) {
+      if (int r = tdec_tbA_table(q, g.K, &p_.gs.tbA[p_.gs.n])) return r;
+    }
     TdecGroup& d  = p_.gs.g[p_.gs.n++];
     d.K = g.K; d.nof_cb = g.nof_cb; d.first_lcb = total; d.first_wave = p_.waves;
     if (int r = tdec_get_tables(q, g.K, W, g.crc_poly, g.crc_nbits, &d.t)) return r;
@@ -1981,7 +2100,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     if (!p_.gs.n) continue;
     p_.gs.xy_stride = q->max_long_cb;
     // slot T_PAIR: one kind -> that kind's own kernel, several -> the mixed launch (tdec_mix.hip)
-    const int run = type != T_PAIR ? type : (kinds == (1u << T_PAIR) ? T_PAIR : (kinds == (1u << T_WIN8) ? T_WIN8 : (kinds == (1u << T_GEN) ? T_GEN : T_N)));
+    const int run = type != T_PAIR ? type : (ragged ? T_N : (kinds == (1u << T_PAIR) ? T_PAIR : (kinds == (1u << T_WIN8) ? T_WIN8 : (kinds == (1u << T_GEN) ? T_GEN : T_N))));
     TdecArgs a;
     memset(&a, 0, sizeof(a));
     a.in = p_.widened ? q->d_conv : (const int16_t*)d_input_any; a.in_stride = in_stride; a.sb_layout = run != T_GEN; a.nof_iter = nof_iterations;
@@ -1989,6 +2108,10 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
     a.work = q->d_work; a.Kp = q->Kp; a.beta = q->d_beta; a.xy = q->d_xy; a.zeros = q->d_zeros; a.beta_stride = p_.stride;
     a.out = d_output; a.out_stride = out_stride; a.iters = d_iters; a.crc_ok = d_crc_ok; a.tb_C = 1;
     a.skip = q->skip; a.cb_map = q->cb_map;
+    if (ragged && type == T_PAIR) { // consumed below
+      a.tb_out = rg_tb; a.tb_out_stride = q->tb_out_stride; a.tb_ok_out = q->tb_ok_out; a.tb_acc = q->d_tb_acc;
+      a.tb_Cof = rg_Cof; a.tb_C = q->tb_width; a.tb_B = q->tb_B; a.tb_rows0 = q->tb_rows0;
+    }
     switch (run) {
       case T_PAIR: hipLaunchKernelGGL(tdec_pair_kernel, dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
       case T_WIN8: hipLaunchKernelGGL((tdec_win_kernel<8, 0>), dim3(p_.waves), dim3(64), 0, st, a, p_.gs); break;
