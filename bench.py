@@ -407,6 +407,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    issue_s = []
+
     def timed_repeats(src, min_s, with_events, nsteps=None):
         """Repeats of the contract's timed region: K steps between barriers. Returns (per-repeat max-over-ranks seconds, mean tdec ms).
         nsteps: a region of another length (the steady-state figure)."""
@@ -419,6 +421,7 @@ def main():
             t0 = time.perf_counter()
             for k in range(nsteps):
                 step(k0 + k, src, evs[k] if evs else None)
+            issue_s.append((time.perf_counter() - t0) / nsteps)  # host time to submit a step (the region is host-bound when this nears ms_per_step)
             barrier()
             k0 += nsteps
             el = time.perf_counter() - t0
@@ -441,8 +444,10 @@ def main():
     # the contract's W warm-up steps are a few milliseconds; clocks and first-touch effects last longer (round 2: the first repeats of the
     # timed region ran at half speed), so whole untimed repeats follow until 0.15 s have passed
     timed_repeats(d_inputs, 0.15, False)
+    del issue_s[:]
     times, tdec_ms = timed_repeats(d_inputs, args.min_timed_s, pool is None)  # pool mode: one call per batch, no per-stage events
     t_med = float(np.median(times))
+    host_issue_ms = float(np.median(issue_s)) * 1e3
     # What the K-step region costs beyond K steps of a pipeline that never drains: the same loop over 4 K steps per region; the slope between the
     # two region lengths is the steady-state step, the rest of the K-step region is filling and draining the streams around the two barriers.
     long_times, _ = timed_repeats(d_inputs, args.min_timed_s / 2, False, nsteps=4 * args.steps)
@@ -718,6 +723,7 @@ def main():
                    ("srslte_hip_dl_rx_pool_submit (one call per batch, %d objects inside the library)" % nstreams if pool is not None else "srslte_hip_dl_rx_stage x 6 (one fixed grant)"),
                    "input_batches": n_inputs, "input_MB": round(n_inputs * d_iq.numel() * 4 / 1e6, 1),
                    "same_input_value": round(world * B * args.steps / float(np.median(same_times)), 1),
+                   "host_submit_ms_per_step": round(host_issue_ms, 4),
                    "streams": nstreams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")), "pipeline_instances_verified": nstreams if agree_all == world else 0, "results_on_host_verified": gather_ok,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(world * B * args.steps / max(times), 1),
                    "repeat_max_value": round(world * B * args.steps / min(times), 1), "full_iter": full,

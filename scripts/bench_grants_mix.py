@@ -167,6 +167,8 @@ def main(args):
             with torch.cuda.stream(tstreams[s]):
                 h_out[s].copy_(t_res[s], non_blocking=True)
 
+    issue_s = []
+
     def repeats(min_s):
         ts, k0 = [], 0
         while not ts or sum(ts) < min_s:
@@ -174,6 +176,7 @@ def main(args):
             t0 = time.perf_counter()
             for k in range(args.steps):
                 step(k0 + k, d_inputs[(k0 + k) % n_inputs])
+            issue_s.append((time.perf_counter() - t0) / args.steps)  # host time to submit a call (descriptors of 128 grants + the launches)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
             k0 += args.steps
@@ -182,8 +185,10 @@ def main(args):
     for k in range(max(args.warmup, nstreams)):
         step(k, d_inputs[k % n_inputs])
     repeats(0.15)
+    del issue_s[:]
     times = repeats(args.min_timed_s)
     t_med = float(np.median(times))
+    host_issue_ms = float(np.median(issue_s)) * 1e3
 
     # ---- every input batch once more through instance 0: what was delivered, passes per block, the decoder's algorithmic work
     Cmax = pkg.cbsegm(tbs_max)[1].C
@@ -246,7 +251,7 @@ def main(args):
                             "delivered": per_cls[i][0], "of": per_cls[i][1]} for i, m in enumerate(MIX)],
                    "block_lengths": [k for k, _ in ks], "decoder_launches_per_step": len({sg.K1 for sg in segs}),
                    "code_blocks_per_step": blocks // n_inputs, "avg_siso_passes_per_cb": round(passes_sum / max(blocks, 1), 3),
-                   "bler": round(1 - good / (B * n_inputs), 4), "undetected_errors": wrong, "streams": nstreams, "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                   "bler": round(1 - good / (B * n_inputs), 4), "undetected_errors": wrong, "streams": nstreams, "host_submit_ms_per_step": round(host_issue_ms, 4), "hw_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
                    "pipeline_instances_verified": nstreams if agree else 0, "results_on_host_verified": bool(host_ok), "results_to_host": "zero-copy" if zero_copy else "copy", "input_batches": n_inputs,
                    "repeats": len(times), "timed_s": round(sum(times), 3), "repeat_min_value": round(B * args.steps / max(times), 1),
                    "repeat_max_value": round(B * args.steps / min(times), 1)},
