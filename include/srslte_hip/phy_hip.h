@@ -293,7 +293,10 @@ int srslte_hip_dl_rx_grid_batch(srslte_hip_dl_rx_t* q, const void* d_grid, uint3
  * slot s (any subset; the two slots may differ, as with distributed virtual resource blocks), walked as srslte_pdsch_cp does
  * (pdsch.c:81-206). tbs = 0: no transport block in that subframe (tb_ok = 0). rv / new_data as srslte_hip_dl_rx_batch_harq, per subframe.
  * cfg.tbs of the object bounds every grant's tbs; cfg.mod / cfg.rnti / cfg.cfi are not used. Single antenna port or transmit diversity (cfg.nof_ports); cfg.llr_8bit, cfg.csi_enable
- * (csi_correction with every subframe's own allocation and modulation) and cfg.nof_rx_antennas apply. */
+ * (csi_correction with every subframe's own allocation and modulation) and cfg.nof_rx_antennas apply.
+ * With 16-bit LLRs the transport blocks are assembled and judged by the decoder launch itself (no assembly kernel behind it; blocks kept from an
+ * earlier transmission contribute their stored bytes). Environment SRSLTE_HIP_GRANTS_TB_DIRECT=0, read when an object serves its first grants
+ * call, keeps the separate assembly kernel (A/B, tests). Results are the same either way. */
 typedef struct {
   uint32_t prb_mask[2][4];
   int      mod;      /* srslte_mod_t: 1 QPSK, 2 16QAM, 3 64QAM, 4 256QAM */

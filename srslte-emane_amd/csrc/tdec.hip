@@ -294,6 +294,57 @@ __device__ __forceinline__ uint32_t tdec_gf24_mul(uint32_t a, uint32_t b)
   return r;
 }
 
+#ifdef TDEC_MIX_TU
+// Ragged batches (tdec_set_tb_ragged) with HARQ: a block whose CRC passed in an earlier transmission is not decoded again (sch.c:317-318) - its bytes
+// are in its row of a.out since then. It still owes its transport block what a decoded block gives in its last phase: its bytes in the block's
+// place, the CRC24A share of those bytes (table lookups in natural bit order: array position (n % Lw) * 16 + n / Lw) and its arrival. What it
+// does not give is the "a block was decoded in this call" flag (bit 2): a transport block whose blocks had all passed before is not delivered
+// again (the duplicate retransmission of sch.c:404-410 / tb_any_block_decoded in the assembly kernel).
+__device__ __forceinline__ void tdec_tb_stored_block(const TdecArgs& a, int cb, int K, int lane)
+{
+  const int      K8 = K / 8, Lw = K / 16;
+  const int      tbr = (int)(cb % a.tb_C), tbi = (int)(cb / a.tb_C), tbC = (int)a.tb_Cof[tbi];
+  const int      rb = (tbC == 1 ? K : K - 24) / 8, tlim = tbr == tbC - 1 ? K8 : rb;
+  const size_t   row = (uint32_t)tbi < a.tb_B ? (size_t)tbi : (size_t)a.tb_rows0 + tbi - a.tb_B;
+  const uint8_t* o   = a.out + (size_t)cb * a.out_stride;
+  uint8_t*       tbo = a.tb_out + row * a.tb_out_stride + (size_t)tbr * rb;
+  const uint32_t* tab = a.tbA + (tbC == 1 ? 0 : K);
+  const uint32_t magic = (uint32_t)((0x100000000ull + (uint32_t)Lw - 1) / (uint32_t)Lw);
+  uint32_t       tsyn = 0;
+  bool           par_nz = false;
+  for (int bi = lane; bi < K8; bi += 64) {
+    const uint32_t byte = o[bi];
+    if (bi < tlim) tbo[bi] = (uint8_t)byte;
+    par_nz = par_nz || (bi >= rb - 3 && bi < rb && byte != 0);
+    int q = (int)__umulhi((uint32_t)(8 * bi), magic), r = 8 * bi - q * Lw;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (byte & (0x80u >> j)) tsyn ^= tab[r * 16 + q];
+      if (++r == Lw) {
+        r = 0;
+        q++;
+      }
+    }
+  }
+  for (int o2 = 32; o2 > 0; o2 >>= 1) tsyn ^= __shfl_xor(tsyn, o2, 64);
+  par_nz = __ballot(par_nz) != 0;
+  if (lane == 0) {
+    const uint32_t fac = a.tbA[2 * K + (tbC - 1 - tbr)];
+    if (fac != 1) tsyn = tdec_gf24_mul(tsyn, fac);
+    uint32_t*      acc = a.tb_acc + 4 * (size_t)tbi;
+    const uint32_t o1 = atomicXor(acc, tsyn);
+    const uint32_t o2 = atomicOr(acc + 1, (tbr == tbC - 1 && par_nz) ? 2u : 0u);
+    uint32_t       dep = o1 | o2;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(dep)::"memory");
+    if (atomicAdd(acc + 2, 1u) == (uint32_t)tbC - 1) {
+      const uint32_t syn = atomicExch(acc, 0u), fl = atomicExch(acc + 1, 0u);
+      atomicExch(acc + 2, 0u);
+      a.tb_ok_out[row] = (syn == 0 && fl == 6u) ? 1 : 0;
+    }
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------------------------
 // Windowed SISO (W = 16: packed pairs w = 2g+h; W = 8: w = g in the low half, high half idle)
 // ------------------------------------------------------------------------------------------------------------------
@@ -902,6 +953,14 @@ __device__ __forceinline__ void tdec_win_body(const TdecArgs& a0, const TdecGrou
   const int      lcb = (int)bx, cb = a.cb_map ? (int)a.cb_map[lcb] : lcb, K = (int)a.K;
   if (a.skip && a.skip[cb]) { // "Do not process blocks with CRC Ok" (sch.c:317-318): bytes, flag and TB-CRC share stay
     if (threadIdx.x == 0 && a.iters) a.iters[cb] = 0;
+#ifdef TDEC_MIX_TU
+    if (a.tb_out && a.tb_Cof) { // a ragged batch: the block (K <= 800) is a transport block that was delivered before; its row, no second delivery
+      const uint32_t tbi = (uint32_t)cb / a.tb_C;
+      const size_t   row = tbi < a.tb_B ? (size_t)tbi : (size_t)a.tb_rows0 + tbi - a.tb_B;
+      for (int b = (int)threadIdx.x; b < K / 8; b += 64) a.tb_out[row * a.tb_out_stride + b] = a.out[(size_t)cb * a.out_stride + b];
+      if (threadIdx.x == 0) a.tb_ok_out[row] = 0;
+    }
+#endif
     return;
   }
   const LaneGeom L  = lane_geom();
@@ -1643,6 +1702,14 @@ __global__ __launch_bounds__(64) void tdec_gen_kernel(TdecArgs a0, TdecGroups gs
     if (a.crc_ok) a.crc_ok[cb] = ok ? 1 : 0;
   }
   if (L.p == 0 && skipped && a.iters) a.iters[cb] = 0;
+#ifdef TDEC_MIX_TU
+  if (a.tb_out && a.tb_Cof && skipped) { // delivered by an earlier transmission: the stored bytes, no second delivery
+    const uint32_t tbi = cb / a.tb_C;
+    const size_t   row = tbi < a.tb_B ? (size_t)tbi : (size_t)a.tb_rows0 + tbi - a.tb_B;
+    for (uint32_t b = L.p; b < (uint32_t)K / 8; b += 8) a.tb_out[row * a.tb_out_stride + b] = a.out[(size_t)cb * a.out_stride + b];
+    if (L.p == 0) a.tb_ok_out[row] = 0;
+  }
+#endif
 }
 
 #ifdef TDEC_MIX_TU
@@ -1855,7 +1922,7 @@ int tdec_set_tb_direct(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, 
   return SRSLTE_SUCCESS;
 }
 
-// The same for a RAGGED batch (the next tdec_run_groups, 16-bit LLRs, no block skipped): block slot cb belongs to transport-block slot cb / width,
+// The same for a RAGGED batch (the next tdec_run_groups, 16-bit LLRs; a skipped block contributes its stored bytes): block slot cb belongs to transport-block slot cb / width,
 // which has d_Cof[cb / width] code blocks; row of d_tb / d_tb_ok: the slot itself below B, rows0 + slot - B from there on.
 int tdec_set_tb_ragged(srslte_hip_tdec_t* q, uint8_t* d_tb, uint32_t tb_stride, uint8_t* d_tb_ok, const uint8_t* d_Cof, uint32_t width, uint32_t B,
                        uint32_t rows0)
@@ -2042,7 +2109,7 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
   q->tb_out = nullptr;
   q->tb_Cof = nullptr;
   const bool ragged = rg_tb != nullptr;
-  if ((ragged && (!rg_Cof || llr8 || q->skip)) || q->start_iter || q->tb_rem) return SRSLTE_ERROR_INVALID_INPUTS; // modes of the one-length call
+  if ((ragged && (!rg_Cof || llr8)) || q->start_iter || q->tb_rem) return SRSLTE_ERROR_INVALID_INPUTS; // modes of the one-length call
   enum { T_PAIR, T_WIN8, T_GEN, T_AR32, T_AR16, T_N };
   struct Plan { TdecGroups gs; uint32_t waves, stride, blocks; bool widened; };
   static const TdecGroups none = {};

@@ -431,21 +431,26 @@ def test_every_decoder_kind_in_one_call(hp, llr8):
 
 
 def test_transport_blocks_assembled_by_the_decoders_equal_the_assembly_kernel(hp):
-    """A call in which every transport block is new data has its transport blocks assembled and judged by the decoders themselves (tdec_set_tb_ragged:
-    per-slot block counts, CRC24A shares with the factor of the block's position); one retransmission anywhere in the call sends all of it through
-    the assembly kernel (tb_crc_bytes_kernel). Same subframes both ways - blocks of every decoder kind, transport blocks of one, two and three
-    blocks, SNRs around the thresholds so that transport blocks fail as well, a subframe without a transport
-    block - and a dirty result buffer: rows and verdicts must be identical, failed blocks' bytes included, and equal the oracle's."""
+    """A 16-bit grants call has its transport blocks assembled and judged by the decoders themselves (tdec_set_tb_ragged: per-slot block counts, CRC24A
+    shares with the factor of the block's position, the last block to arrive gives the verdict; a block kept from an earlier transmission contributes
+    its stored bytes); with SRSLTE_HIP_GRANTS_TB_DIRECT=0 in the environment an object uses the assembly kernel (tb_crc_bytes_kernel) instead.
+    Same subframes both ways - blocks of every decoder kind, transport blocks of one, two and three blocks, SNRs around the thresholds so that
+    transport blocks fail as well, a subframe without a transport block, a dirty result buffer - then a second call that retransmits every slot
+    (failed blocks combine and pass, delivered transport blocks are refused as duplicates, some slots start a new block): rows and verdicts must be
+    identical call by call, failed blocks' bytes included, and the first call's equal the oracle's."""
+    import os
     P, cell_id, tti0 = 50, 33, 6
     rng = np.random.default_rng(2024)
     plan = [(0, 3, 1, 296, 1.0), (5, 3, 1, 296, -1.5), (0, 5, 1, 616, 2.0), (10, 5, 1, 616, -0.5), (0, 12, 1, 1544, 1.5), (14, 12, 1, 1544, -0.5),
             (0, 25, 2, 4008, 6.5), (0, 50, 2, 12216, 8.5), (0, 50, 2, 15264, 10.5), (0, 50, 2, 15264, 8.3), (0, 50, 2, 12216, 7.0), None, (3, 30, 2, 6200, 9.0)]
-    stream, grants = [], []
+    stream, grants, grants2, iq2 = [], [], [], []
     for b, pl in enumerate(plan):
         if pl is None:  # no transport block in this subframe
             cfg = DlConfig(P, cell_id, 1, 296, cfi=1, rnti=0x300)
             stream.append((None, make_subframe(cfg, tti0 + b, rng, snr_db=3.0)[0], None))
             grants.append(hp.DlGrant.make(P, 1, 0, 0x300))
+            grants2.append(hp.DlGrant.make(P, 1, 0, 0x300))
+            iq2.append(stream[-1][1])
             continue
         first, n, mod, tbs, snr = pl
         mask = np.zeros((2, P), np.uint8)
@@ -454,36 +459,59 @@ def test_transport_blocks_assembled_by_the_decoders_equal_the_assembly_kernel(hp
         iq, data = make_subframe(cfg, tti0 + b, rng, snr_db=snr)
         stream.append((cfg, iq, data))
         grants.append(hp.DlGrant.make(P, mod, tbs, cfg.rnti, cfi=cfg.cfi, prb_mask=mask))
+        # the second call, ten subframes later (same subframe index): rv 2 of the same data in most slots, a new block in slots 2 and 7
+        fresh = b in (2, 7)
+        d2 = rng.integers(0, 256, tbs // 8, dtype=np.uint8) if fresh else data
+        iq2.append(make_subframe(cfg, tti0 + 10 + b, rng, snr_db=snr + 1.0, rv=0 if fresh else 2, data=d2)[0])
+        grants2.append(hp.DlGrant.make(P, mod, tbs, cfg.rnti, cfi=cfg.cfi, rv=0 if fresh else 2, new_data=fresh, prb_mask=mask))
     assert [int(c.seg.C) for c, _, _ in stream if c] == [1, 1, 1, 1, 1, 1, 1, 2, 3, 3, 2, 2]
     hc = hp.ChestDlCfg()
     hc.filter_coef[0], hc.filter_coef[1] = 4.0, 1.0
     tbs_max, nsf = 15264, len(stream)
-    iqs = np.stack([iq for _, iq, _ in stream])
+    iqs, iqs2 = np.stack([iq for _, iq, _ in stream]), np.stack(iq2)
     results = []
-    for extra_retx in (False, True):
-        rx = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, nsf + 1, True, hc)
-        hp.lib().srslte_hip_memset(rx.d_tb.ptr, 0xA5, rx.d_tb.nbytes)
-        hp.lib().srslte_hip_memset(rx.d_ok.ptr, 0xA5, rx.d_ok.nbytes)
-        gr, x = list(grants), iqs
-        if extra_retx:  # a "retransmission" into a never-used HARQ slot: nothing to combine with, but the call is no longer all new data
-            gr = gr + [hp.DlGrant.make(P, 1, 296, 0x3FF, new_data=False)]
-            x = np.concatenate([iqs, iqs[:1]])
-        rc, tb, ok = rx.decode_grants(x, tti0, gr)
-        assert rc == 0
-        results.append((tb[:nsf].copy(), ok[:nsf].copy()))
-        rx.free()
-    (tb_d, ok_d), (tb_k, ok_k) = results
-    assert np.array_equal(ok_d, ok_k), (ok_d, ok_k)
-    n_ok = n_fail = 0
+    for assembly_kernel in (False, True):
+        if assembly_kernel:
+            os.environ["SRSLTE_HIP_GRANTS_TB_DIRECT"] = "0"  # read when the object's grants state is made (first grants call)
+        try:
+            rx = hp.DlRx(cell_id, P, 1, 0, 1, tbs_max, 6, nsf, True, hc)
+            calls = []
+            for x, gr, t0 in ((iqs, grants, tti0), (iqs2, grants2, tti0 + 10)):
+                hp.lib().srslte_hip_memset(rx.d_tb.ptr, 0xA5, rx.d_tb.nbytes)
+                hp.lib().srslte_hip_memset(rx.d_ok.ptr, 0xA5, rx.d_ok.nbytes)
+                rc, tb, ok = rx.decode_grants(x, t0, gr)
+                assert rc == 0
+                calls.append((tb.copy(), ok.copy()))
+            results.append(calls)
+            rx.free()
+        finally:
+            os.environ.pop("SRSLTE_HIP_GRANTS_TB_DIRECT", None)
+    for call in range(2):
+        (tb_d, ok_d), (tb_k, ok_k) = results[0][call], results[1][call]
+        assert np.array_equal(ok_d, ok_k), (call, ok_d, ok_k)
+        for b, (cfg, iq, data) in enumerate(stream):
+            if cfg is None:
+                assert ok_d[b] == 0
+                continue
+            nb = cfg.tbs // 8 + 3
+            assert np.array_equal(tb_d[b, :nb], tb_k[b, :nb]), (call, b, cfg.tbs, np.flatnonzero(tb_d[b, :nb] != tb_k[b, :nb])[:8])
+    (tb_d, ok_d), (tb_2, ok_2) = results[0]
+    n_ok = n_fail = n_retx = n_dup = 0
     for b, (cfg, iq, data) in enumerate(stream):
         if cfg is None:
-            assert ok_d[b] == 0
             continue
         nb = cfg.tbs // 8 + 3
-        assert np.array_equal(tb_d[b, :nb], tb_k[b, :nb]), (b, cfg.tbs, np.flatnonzero(tb_d[b, :nb] != tb_k[b, :nb])[:8])
         r = oracle_rx(cfg, iq, tti0 + b, keep=True)
         assert bool(ok_d[b]) == bool(r["ok"]), (b, cfg.tbs)
         assert np.array_equal(tb_d[b, :nb], r["tb"][:nb]), (b, cfg.tbs, bool(r["ok"]))
         n_ok += bool(r["ok"])
         n_fail += not r["ok"]
-    assert n_ok >= 5 and n_fail >= 3, (n_ok, n_fail)
+        if b in (2, 7):
+            continue
+        if ok_d[b]:  # delivered by the first call: the retransmission is a duplicate, nothing is decoded, no second delivery; the row holds the block
+            assert not ok_2[b] and np.array_equal(tb_2[b, :cfg.tbs // 8], data), b
+            n_dup += 1
+        elif ok_2[b]:
+            assert np.array_equal(tb_2[b, :cfg.tbs // 8], data), b
+            n_retx += 1
+    assert n_ok >= 5 and n_fail >= 3 and n_retx >= 2 and n_dup >= 4, (n_ok, n_fail, n_retx, n_dup)
