@@ -67,7 +67,7 @@ def noisy(sub, rng):
 
 
 # ------------------------------------------------------------------------------------------------ CPU chain (no torch, no GPU)
-def cpu_run(sub, iq, lo, hi, seconds):
+def cpu_run(sub, iq, lo, hi, seconds, llr8=False):
     """Whole passes over subframes [lo, hi) until `seconds` are used: the reference's srslte_chest_dl_estimate_cfg + srslte_pdsch_decode
     (oracle/_ref) with each subframe's own grant behind the oracle's FFT, else the oracle chain. Returns (n, dt, kind, ok flags, tbs)."""
     import refdrv
@@ -80,7 +80,7 @@ def cpu_run(sub, iq, lo, hi, seconds):
         rx = refdrv.RefDl(NOF_PRB, 1, CELL_ID)
         rx.set_rnti(RNTI)
         rx.set_chest_cfg(filter_type=0, coef=(4.0, 1.0))
-        rx.set_pdsch_cfg(max_iterations=MAX_ITER, mmse=True)
+        rx.set_pdsch_cfg(max_iterations=MAX_ITER, mmse=True, llr8=llr8)
         q = OrcOfdm()
         assert O.orc_ofdm_init(C.byref(q), NOF_PRB, True) == 0
         grid = np.zeros(14 * 12 * NOF_PRB, np.complex64)
@@ -99,16 +99,16 @@ def cpu_run(sub, iq, lo, hi, seconds):
                 crc, _ = rx.decode_pdsch()
                 oks[b], tbs_out[b] = bool(crc), rx.payload(tbs // 8)
             else:
-                r = oracle_rx(s["cfg"], iq[b], b)
+                r = oracle_rx(s["cfg"], iq[b], b)  # (16-bit chain; the 8-bit line needs the reference build)
                 oks[b], tbs_out[b] = bool(r["ok"]), r["tb"][:tbs // 8]
             n += 1
     return n, time.perf_counter() - t0, kind, oks, tbs_out
 
 
-def cpu_worker(path, lo, hi, seconds, B, seed):
+def cpu_worker(path, lo, hi, seconds, B, seed, llr8=False):
     sub = build(B, seed)
     iq = np.load(path, mmap_mode="r")
-    n, dt, kind, _, _ = cpu_run(sub, np.ascontiguousarray(iq), lo, hi, seconds)
+    n, dt, kind, _, _ = cpu_run(sub, np.ascontiguousarray(iq), lo, hi, seconds, llr8)
     print(json.dumps({"n": n, "dt": dt, "kind": kind}))
 
 
@@ -125,7 +125,7 @@ def main(args):
             path = os.path.join(tmp, "iq.npy")
             np.save(path, iq_host)
             spans = [sharding.split_contiguous(B, ncores, r) for r in range(ncores)]
-            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(lo), str(hi), str(args.cpu_seconds), str(B), str(seed)],
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, str(lo), str(hi), str(args.cpu_seconds), str(B), str(seed), str(int(args.llr8))],
                                       stdout=subprocess.PIPE) for lo, hi in spans if hi > lo]
             outs = [json.loads(p_.communicate(timeout=300 + 10 * args.cpu_seconds)[0].decode().strip().splitlines()[-1]) for p_ in procs]
             cpu_multi = {"value": round(sum(o["n"] / o["dt"] for o in outs), 1), "cores": len(procs), "kind": outs[0]["kind"]}
@@ -145,7 +145,7 @@ def main(args):
     res_bytes, ok_off = sharding.result_layout(tb_stride, B)
     zero_copy = not getattr(args, "no_zero_copy", False)  # the pipelines store into the pinned host record itself (bench.py --no-zero-copy: a device record + a copy)
     t_res = [(torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() if zero_copy else torch.zeros(res_bytes, dtype=torch.uint8, device=dev)) for _ in range(nstreams)]
-    rxs = [pkg.DlRx(CELL_ID, NOF_PRB, CFI, RNTI, 3, tbs_max, MAX_ITER, B, True, hc, out_ptrs=(t_res[s].data_ptr(), t_res[s].data_ptr() + ok_off)) for s in range(nstreams)]
+    rxs = [pkg.DlRx(CELL_ID, NOF_PRB, CFI, RNTI, 3, tbs_max, MAX_ITER, B, True, hc, llr_8bit=args.llr8, out_ptrs=(t_res[s].data_ptr(), t_res[s].data_ptr() + ok_off)) for s in range(nstreams)]
     tstreams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(nstreams - 1)]
     streams = [t.cuda_stream for t in tstreams]
     h_out = t_res if zero_copy else [torch.zeros(res_bytes, dtype=torch.uint8).pin_memory() for _ in range(nstreams)]
@@ -224,7 +224,7 @@ def main(args):
 
     cpu = None
     if not args.no_cpu:
-        n1, dt1, kind, coks, ctbs = cpu_run(sub, iq_host, 0, B, args.cpu_seconds)
+        n1, dt1, kind, coks, ctbs = cpu_run(sub, iq_host, 0, B, args.cpu_seconds, args.llr8)
         both = [b for b in range(B) if ok0[b] and coks.get(b)]
         mism = int(sum(not np.array_equal(ctbs[b], tb0[b, :sub[b]["cfg"].tbs // 8]) for b in both))
         flags = int(sum(bool(ok0[b]) != bool(coks.get(b, False)) for b in range(B) if b in coks))
@@ -242,7 +242,7 @@ def main(args):
     out = {
         "metric": "DL subframes/s (20 MHz, turbo 6-iter)", "value": round(B * args.steps / t_med, 1), "unit": "subframes/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 (OFDM/chest/eq) + i16 (LLR/turbo)", "data": "synthetic",
+        "dtype": "f32 (OFDM/chest/eq) + %s (LLR/turbo)" % ("i8" if args.llr8 else "i16"), "data": "synthetic",
         "config": {"workload": "20 MHz (100 PRB) DL subframe batch=%d, a different grant per subframe (srslte_hip_dl_rx_batch_grants): 40 %% small (2-25 PRB QPSK/16QAM, "
                                "TBS 296-6456), 30 %% medium (25/50 PRB), 30 %% large (50/75/100 PRB 64QAM, TBS up to 75376); OFDM RX + chest_dl + RE lists and scrambling "
                                "sequences from the grants + MMSE + soft demap + ragged rate dematch + one turbo launch per block length + TB CRC + results to host; "
@@ -268,6 +268,6 @@ def main(args):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-worker":
         w = sys.argv[2:]
-        cpu_worker(w[0], int(w[1]), int(w[2]), float(w[3]), int(w[4]), int(w[5]))
+        cpu_worker(w[0], int(w[1]), int(w[2]), float(w[3]), int(w[4]), int(w[5]), bool(int(w[6])) if len(w) > 6 else False)
     else:
         sys.exit("run through bench.py --grants-mix")

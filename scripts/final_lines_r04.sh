@@ -27,4 +27,5 @@ line final_bench_llr8 bench.py --no-cpu --llr8
 line final_bench_streams1 bench.py --no-cpu --streams 1 --stream-batch 0
 line final_bench_grants_mix bench.py --grants-mix  # with its cpu_baseline (tests/test_profiles_consistency.py)
 line final_bench_grants bench.py --no-cpu --grants
+line final_bench_grants_mix_llr8 bench.py --grants-mix --llr8
 line cfg4_one_device scripts/cfg4_one_device.py
