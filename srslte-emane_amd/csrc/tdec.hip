@@ -1756,6 +1756,20 @@ __global__ void widen_kernel(const int8_t* __restrict__ in, int16_t* __restrict_
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
 
+// The same for a ragged batch: only the launched blocks of the widened groups (K <= 800 under the 8-bit API), each as far as its decoder reads -
+// not every slot of the buffer (the mixed-grant line: 30.8 M elements per call, 55 us, for some 250 short blocks). Workgroup = one launched block.
+__global__ __launch_bounds__(256) void widen_groups_kernel(const int8_t* __restrict__ in, int16_t* __restrict__ out, const uint32_t* __restrict__ cb_map,
+                                                           uint32_t in_stride, TdecGroups gs)
+{
+  uint32_t j = blockIdx.x, gi = 0;
+  while (gi + 1 < gs.n && j >= gs.g[gi].nof_cb) j -= gs.g[gi++].nof_cb;
+  const uint32_t lcb = gs.g[gi].first_lcb + j, cb = cb_map ? cb_map[lcb] : lcb;
+  uint32_t       len = (3 * (gs.g[gi].K + 32) + 12 + 31) & ~31u; // the SB layout's length covers the plain one
+  len                = len < in_stride ? len : in_stride;
+  const size_t o = (size_t)cb * in_stride;
+  for (uint32_t i = threadIdx.x; i < len; i += 256) out[o + i] = in[o + i];
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
@@ -2154,12 +2168,12 @@ int tdec_run_groups(srslte_hip_tdec_t* q, const void* d_input_any, int llr8, uin
   }
   if (total > q->max_nof_cb) return SRSLTE_ERROR_INVALID_INPUTS;
   if (total == 0) return SRSLTE_SUCCESS;
-  if (any_widen) { // the 8-bit API's 16-bit fall-backs (turbodecoder.c:465-469): every slot of the buffer, as tdec_run_batch_w does with a block map
+  if (any_widen) { // the 8-bit API's 16-bit fall-backs (turbodecoder.c:465-469): the blocks of the widened groups, each in its slot of the buffer
     const size_t per_max = ((size_t)3 * (q->max_long_cb + 32) + 12 + 31) & ~(size_t)31;
-    const size_t n = (size_t)q->max_nof_cb * in_stride;
     if (in_stride > per_max) return SRSLTE_ERROR_INVALID_INPUTS;
     if (!q->d_conv) HIP_TRY(hipMalloc((void**)&q->d_conv, (size_t)q->max_nof_cb * per_max * sizeof(int16_t)));
-    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 1023) / 1024 < 4096 ? (n + 1023) / 1024 : 4096)), dim3(256), 0, st, (const int8_t*)d_input_any, q->d_conv, n);
+    const Plan& pw = plan[T_PAIR]; // all widened groups are in the mixable plan
+    hipLaunchKernelGGL(widen_groups_kernel, dim3(pw.blocks), dim3(256), 0, st, (const int8_t*)d_input_any, q->d_conv, q->cb_map, in_stride, pw.gs);
     LAUNCH_CHECK();
   }
   for (int type = 0; type < T_N; type++) {
