@@ -2,7 +2,7 @@
 # HIP API + kernel statistics of the reference's phy_dl_test linked against the library (the drop-in's single-call path)
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r3/trace_dropin
+OUT=$PWD/gpurun_out/r4/trace_dropin
 mkdir -p $OUT
 (cd /tmp && rocprofv3 --hip-trace --kernel-trace --stats -d $OUT -o t --output-format csv -- $OLDPWD/oracle/_ref/hip/phy_dl_test -p 100 -t 1 -m 28 > $OUT/out.txt 2> $OUT/err.txt) || tail -5 $OUT/err.txt
 tail -8 $OUT/out.txt
