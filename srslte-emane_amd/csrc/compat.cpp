@@ -131,6 +131,23 @@ bool d2h_later(void* h, const void* d, size_t n)
   return r;
 }
 bool d2h(void* h, const void* d, size_t n) { return d2h_later(h, d, n) && g_link.flush(); }
+// Small operands (a code block: under 1 KB in, 1.5 KB out): the kernel reads and writes the pinned arena itself - device-visible host memory -
+// instead of two DMA operations queued around it (each costs more than the kernel: rocprofv3 on phy_dl_test, profiles/r04/dropin_phy_dl_test_trace.txt).
+// zc_in: a device-readable copy of h[0, n); zc_out: n device-writable bytes that flush() hands to `h`.
+const uint8_t* zc_in(const void* h, size_t n)
+{
+  uint8_t* p = g_link.take(n);
+  if (!p || !g_link.stream()) return nullptr;
+  memcpy(p, h, n);
+  return p;
+}
+uint8_t* zc_out(void* h, size_t n)
+{
+  uint8_t* p = g_link.take(n);
+  if (!p || !g_link.stream()) return nullptr;
+  g_link.back.push_back({h, p, n});
+  return p;
+}
 
 void* host_alloc(size_t n)
 { // srslte_vec_malloc: posix_memalign to the SIMD width (vector.c:118-125)
@@ -807,10 +824,14 @@ int srslte_tcod_encode_lut(srslte_tcod_t* h, srslte_crc_t* crc_tb, srslte_crc_t*
     if (last_cb) append(crc_tb, n, false);
   }
   const uint32_t npar = long_cb / 4 + 1;
-  uint8_t *      di = (uint8_t*)g_tcod_in.get(nbytes), *dout = (uint8_t*)g_tcod_out.get(npar + 1);
-  if (!di || !dout || !h2d(di, input, nbytes)) return SRSLTE_ERROR;
-  if (srslte_hip_tcod_encode_bytes_batch(di, nbytes, dout, npar, dout + npar, long_cb, 1, tl_stream())) return SRSLTE_ERROR;
-  if (!d2h(parity, dout, npar) || !d2h(&input[nbytes], dout + npar, 1)) return SRSLTE_ERROR;
+  const uint8_t* di   = zc_in(input, nbytes);
+  uint8_t *      dpar = zc_out(parity, npar), *dtail = zc_out(&input[nbytes], 1);
+  if (!di || !dpar || !dtail) return SRSLTE_ERROR;
+  if (srslte_hip_tcod_encode_bytes_batch(di, nbytes, dpar, npar, dtail, long_cb, 1, tl_stream())) {
+    (void)g_link.flush();
+    return SRSLTE_ERROR;
+  }
+  if (!g_link.flush()) return SRSLTE_ERROR;
   return (int)(3 * long_cb + 12);
 }
 
