@@ -31,6 +31,10 @@ void hip_log(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 #define SRSLTE_HIP_GRANTS_TB_DIRECT 1 // 0: the DL grants mode always assembles its transport blocks with tb_crc_bytes_kernel (A/B builds)
 #endif
 
+#ifndef SRSLTE_HIP_GRANTS_DESC_BY_KERNEL
+#define SRSLTE_HIP_GRANTS_DESC_BY_KERNEL 1 // 0: the DL grants mode's descriptors reach the device through hipMemcpyAsync (A/B builds)
+#endif
+
 typedef float2 cf32; // layout-compatible with C99 float _Complex (cf_t, config.h:68)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
